@@ -1,0 +1,231 @@
+/* maelsim.h — C ABI of libmaelsim, the MI355X-native ensemble cluster-simulation engine.
+ *
+ * This is the drop-in boundary for Maelstrom's hot path.  One call replaces, for a
+ * whole ensemble of independent seeded test instances, what the reference does per test with
+ *   - maelstrom.net       /root/reference/src/maelstrom/net.clj:79-247   (queues, latency, loss, partitions)
+ *   - maelstrom.process   /root/reference/src/maelstrom/process.clj:136-215 (node execution: recv! -> node -> send!)
+ *   - maelstrom.nemesis   /root/reference/src/maelstrom/nemesis.clj:10-16 (partition schedule)
+ *   - maelstrom.client    /root/reference/src/maelstrom/client.clj:41-172 (sync RPC, timeouts, op completion)
+ *   - maelstrom.db        /root/reference/src/maelstrom/db.clj:46-69      (init handshake)
+ *   - the demo node programs' state-transition functions (echo, broadcast, g-set)
+ * and returns what `jepsen.core/run!` would have handed to `(checker/check (:checker test) test history opts)`
+ * (core.clj:91-100): the op history, plus the numbers `maelstrom.net.checker` computes from the journal
+ * (net/checker.clj:28-41).
+ *
+ * Plain C, plain pointers and sizes.  No C++ exception crosses this boundary: every entry point returns
+ * an MSIM_E_* code (0 = OK) and msim_last_error() gives the text.  The engine requires a HIP device and
+ * fails loudly (MSIM_E_NO_DEVICE) without one; there is no CPU fallback behind this ABI.
+ */
+#ifndef MAELSIM_H
+#define MAELSIM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSIM_ABI_VERSION 1u
+
+/* ---- error codes -------------------------------------------------------------------------------- */
+enum {
+  MSIM_OK = 0,
+  MSIM_E_INVALID = -1,      /* bad config / argument (text in msim_last_error)                        */
+  MSIM_E_NO_DEVICE = -2,    /* no HIP device visible; the engine has no CPU path                       */
+  MSIM_E_HIP = -3,          /* a HIP runtime call failed                                               */
+  MSIM_E_NOMEM = -4,
+  MSIM_E_RANGE = -5,        /* instance index out of range / nothing run yet                           */
+  MSIM_E_UNSUPPORTED = -6,  /* workload/protocol combination not built into this engine                */
+  MSIM_E_OVERFLOW = -7      /* >=1 instance overflowed a capacity (see msim_inst_meta.flags)           */
+};
+
+/* ---- configuration (mirrors the CLI option map, core.clj:136-229, + ensemble/determinism fields) -- */
+enum { MSIM_WL_ECHO = 0, MSIM_WL_BROADCAST = 1, MSIM_WL_G_SET = 2, MSIM_WL_LIN_KV = 3, MSIM_WL_TXN_LIST_APPEND = 4 };
+
+/* Built-in node programs (the `--bin` of the reference). */
+enum {
+  MSIM_NODE_ECHO = 0,           /* demo/ruby/echo.rb:20-41, demo/python/echo.py:9-10                         */
+  MSIM_NODE_BCAST_FF = 1,       /* doc/03-broadcast/01-broadcast.md:525-547 + 02-performance.md:61-67:
+                                   fire-and-forget gossip, dedup, skip-sender                                 */
+  MSIM_NODE_BCAST_FF_ECHOBACK = 2, /* same without skip-sender (02-performance.md:22-28, KAT-3)               */
+  MSIM_NODE_BCAST_ACK_RETRY = 3,/* doc/03-broadcast/02-performance.md:406-441, demo/js/gossip.js:24-38:
+                                   ack everyone, resend un-acked every 1 s                                    */
+  MSIM_NODE_BCAST_RPC_ALL = 4,  /* demo/ruby/broadcast.rb:29-47: RPC to every other node, no retry           */
+  MSIM_NODE_G_SET = 5,          /* demo/ruby/g_set.rb:8-39: replicate_full to all others every 5 s          */
+  MSIM_NODE_RAFT = 6            /* demo/ruby/raft.rb (not built yet)                                          */
+};
+
+enum { MSIM_LAT_CONSTANT = 0, MSIM_LAT_UNIFORM = 1, MSIM_LAT_EXPONENTIAL = 2 };  /* net.clj:65-77 */
+enum { MSIM_TOPO_GRID = 0, MSIM_TOPO_LINE = 1, MSIM_TOPO_TOTAL = 2,
+       MSIM_TOPO_TREE2 = 3, MSIM_TOPO_TREE3 = 4, MSIM_TOPO_TREE4 = 5 };           /* broadcast.clj:171-179 */
+enum { MSIM_NEMESIS_PARTITION = 1u };                                              /* core.clj:49-51 */
+
+typedef struct msim_config {
+  uint32_t struct_size;          /* = sizeof(msim_config); versioning guard                                */
+  uint32_t abi_version;          /* = MSIM_ABI_VERSION                                                     */
+  uint32_t workload;             /* MSIM_WL_*        (-w, core.clj:141-144)                                */
+  uint32_t node_program;         /* MSIM_NODE_*      (stands in for --bin)                                 */
+  uint32_t n_nodes;              /* --node-count     (core.clj:201-204)                                    */
+  uint32_t concurrency;          /* --concurrency, default 1n = n_nodes [upstream jepsen.cli]              */
+  uint32_t rate_mhz;             /* --rate in milli-ops/s (5/s -> 5000; core.clj:219-222); 0 = no client ops */
+  uint32_t time_limit_ms;        /* --time-limit [upstream], default 60 s                                  */
+  uint32_t latency_mean_ms;      /* --latency        (core.clj:171-174)                                    */
+  uint32_t latency_dist;         /* MSIM_LAT_*       (core.clj:176-180)                                    */
+  uint32_t p_loss_q32;           /* P(loss) * 2^32, clamped to 2^32-1; net.clj:100,122,214. 0 = reference default */
+  uint32_t topology;             /* MSIM_TOPO_*      (core.clj:224-227)                                    */
+  uint32_t nemesis_mask;         /* MSIM_NEMESIS_*   (core.clj:206-212)                                    */
+  uint32_t nemesis_interval_ms;  /* --nemesis-interval, default 10 s (core.clj:214-217)                    */
+  uint32_t client_timeout_ms;    /* client.clj:18-20 default 5000                                          */
+  uint32_t quiesce_ms;           /* final-phase sleep, core.clj:78 (gen/sleep 10) -> 10000                 */
+  uint64_t seed;                 /* base seed; instance i uses the stream keyed (seed, i) — the reference
+                                    has no seed (SURVEY.md §0 finding 1)                                   */
+  /* capacities (0 = let msim_config_defaults derive them from rate/time-limit) */
+  uint32_t max_values;           /* bits per node set (distinct add/broadcast values)                      */
+  uint32_t max_rows;             /* history rows per instance                                              */
+  uint32_t max_payload_words;    /* u32 payload words per instance (read results, grudges)                 */
+  uint32_t inbox_capacity;       /* in-flight messages queued per node endpoint                            */
+  uint32_t reserved[8];
+} msim_config;
+
+/* ---- outputs ------------------------------------------------------------------------------------- */
+
+/* One history row = one Jepsen op map {:index :time :type :process :f :value [:error] [:final?]}
+ * (SURVEY.md §8b "History surface").  16 bytes; :index is the row's position.
+ *   time_len : bits 0..47 = :time in ns since test start; bits 48..63 = payload length in u32 words
+ *              (0 = `value` is an immediate).
+ *   packed   : bits 0-1 type (MSIM_T_*), 2-6 f (MSIM_F_*), 7-10 error (MSIM_ERR_*), 11 final?,
+ *              12-31 process (MSIM_PROCESS_NEMESIS = :nemesis).
+ *   value    : immediate (broadcast/add element, echo payload k of "Please echo k", partition spec) or
+ *              offset in u32 words into the instance's payload area.
+ * A read's :value is a bitmap over elements 0..32*len-1 (bit e set <=> e in the returned collection). */
+typedef struct msim_op {
+  uint64_t time_len;
+  uint32_t packed;
+  uint32_t value;
+} msim_op;
+
+enum { MSIM_T_INVOKE = 0, MSIM_T_OK = 1, MSIM_T_FAIL = 2, MSIM_T_INFO = 3 };
+enum { MSIM_F_ECHO = 0, MSIM_F_BROADCAST = 1, MSIM_F_READ = 2, MSIM_F_ADD = 3,
+       MSIM_F_START_PARTITION = 4, MSIM_F_STOP_PARTITION = 5,
+       MSIM_F_WRITE = 6, MSIM_F_CAS = 7, MSIM_F_TXN = 8 };
+enum { MSIM_ERR_NONE = 0, MSIM_ERR_NET_TIMEOUT = 1 /* client.clj:158-162 */, MSIM_ERR_RPC = 2 };
+enum { MSIM_SPEC_ONE = 0, MSIM_SPEC_MAJORITY = 1, MSIM_SPEC_MAJORITIES_RING = 2, MSIM_SPEC_MINORITY_THIRD = 3 };
+#define MSIM_PROCESS_NEMESIS 0xFFFFFu
+#define MSIM_NO_VALUE 0xFFFFFFFFu   /* :value nil */
+
+#define MSIM_OP_TIME_NS(op)  ((op).time_len & 0xFFFFFFFFFFFFull)
+#define MSIM_OP_LEN(op)      ((uint32_t)((op).time_len >> 48))
+#define MSIM_OP_TYPE(op)     ((op).packed & 3u)
+#define MSIM_OP_F(op)        (((op).packed >> 2) & 31u)
+#define MSIM_OP_ERR(op)      (((op).packed >> 7) & 15u)
+#define MSIM_OP_FINAL(op)    (((op).packed >> 11) & 1u)
+#define MSIM_OP_PROCESS(op)  ((op).packed >> 12)
+
+/* What maelstrom.net.checker reports (net/checker.clj:28-41): journal :send / :recv event counts,
+ * for all messages, messages involving a client (util.clj:12-16), and server<->server messages.
+ * msg-count (distinct message ids, journal.clj:258-268) always equals send-count because every
+ * message is journalled at send (net.clj:208) before the loss decision (net.clj:214). */
+typedef struct msim_net_stats {
+  uint64_t all_send, all_recv;
+  uint64_t clients_send, clients_recv;
+  uint64_t servers_send, servers_recv;
+} msim_net_stats;
+
+/* Per-instance bookkeeping (not part of the algorithmic output bytes). */
+typedef struct msim_inst_meta {
+  uint32_t n_rows;          /* history rows written                                                   */
+  uint32_t n_payload_words; /* payload words written                                                  */
+  uint32_t flags;           /* MSIM_FLAG_*                                                            */
+  uint32_t n_rounds;        /* scheduler rounds executed (diagnostic)                                 */
+} msim_inst_meta;
+enum { MSIM_FLAG_ROWS_OVERFLOW = 1u, MSIM_FLAG_PAYLOAD_OVERFLOW = 2u, MSIM_FLAG_INBOX_OVERFLOW = 4u,
+       MSIM_FLAG_VALUES_OVERFLOW = 8u, MSIM_FLAG_ROUND_LIMIT = 16u };
+
+/* Result of the workload checker for one instance.  For broadcast / g-set this is jepsen's
+ * `checker/set-full` result map (shape: doc/03-broadcast/01-broadcast.md:564-577, KAT-7); for echo the
+ * pair comparison of workload/echo.clj:44-63. */
+typedef struct msim_check_result {
+  uint32_t valid;              /* 1 = :valid? true, 0 = false, 2 = :unknown                          */
+  uint32_t attempt_count;
+  uint32_t stable_count;
+  uint32_t lost_count;
+  uint32_t never_read_count;
+  uint32_t stale_count;
+  uint32_t duplicated_count;
+  uint32_t error_count;        /* echo: mismatching pairs                                            */
+  uint32_t stable_latency_ms[5]; /* quantiles 0, 0.5, 0.95, 0.99, 1 of stable latencies             */
+  uint32_t op_count;           /* non-nemesis :invoke rows (net/checker.clj:55-58)                   */
+  uint32_t ok_count, fail_count, info_count;  /* checker/stats                                        */
+} msim_check_result;
+
+typedef struct msim_ctx msim_ctx;
+
+/* ---- entry points -------------------------------------------------------------------------------- */
+
+/* Version of this ABI (compare with MSIM_ABI_VERSION). */
+uint32_t msim_abi_version(void);
+
+/* Number of HIP devices visible; 0 when none (never an error). */
+int msim_device_count(void);
+
+/* Fill *cfg with the reference's CLI defaults (core.clj:136-229 + [upstream] jepsen.cli: time-limit 60,
+ * concurrency 1n) for the given workload/node count, and derive capacities. */
+int msim_config_defaults(msim_config *cfg, uint32_t workload, uint32_t n_nodes);
+
+/* Derive zero capacities in *cfg from rate/time-limit/topology; validates the rest.
+ * Returns MSIM_E_INVALID (text in err) for configs the reference rejects, e.g. exponential latency
+ * with mean 0 (net.clj:77 divides by zero). */
+int msim_config_finalize(msim_config *cfg, char *err, size_t errlen);
+
+/* Replaces core.clj:53-102 (test-map assembly) + jepsen.core/run! set-up: builds an engine for one
+ * test configuration on HIP device `device`. */
+int msim_create(const msim_config *cfg, int device, msim_ctx **out, char *err, size_t errlen);
+
+/* Replaces N_instances sequential `lein run test ...` executions (core.clj:267-284): simulates global
+ * instances [first_instance, first_instance + n_instances) to completion on the device.  Blocking.
+ * Outputs stay resident in HBM (see msim_device_buffers) until the next run/destroy. */
+int msim_run(msim_ctx *ctx, uint64_t first_instance, uint32_t n_instances);
+
+/* As msim_run, but only enqueues the kernel on `hip_stream` (a hipStream_t; NULL = default stream)
+ * and returns; the caller synchronises the stream. */
+int msim_run_async(msim_ctx *ctx, uint64_t first_instance, uint32_t n_instances, void *hip_stream);
+
+/* Runs the workload checker (set-full / echo) for every instance of the last run, on the device,
+ * reading the HBM-resident histories.  Blocking.  Results via msim_check_results. */
+int msim_check(msim_ctx *ctx);
+
+/* Copies the last run's outputs to host memory (pinned, owned by ctx, valid until next run/destroy). */
+int msim_fetch(msim_ctx *ctx);
+
+/* Per-instance views into the fetched outputs (require msim_fetch). `inst` is 0-based within the run. */
+int msim_history(msim_ctx *ctx, uint32_t inst, const msim_op **ops, uint32_t *n_ops,
+                 const uint32_t **payload, uint32_t *n_words);
+int msim_net_stats_get(msim_ctx *ctx, uint32_t inst, msim_net_stats *out);
+int msim_meta(msim_ctx *ctx, uint32_t inst, msim_inst_meta *out);
+/* Checker results of the last msim_check (copied to host on demand). */
+int msim_check_results(msim_ctx *ctx, const msim_check_result **results, uint32_t *n);
+
+/* Device-resident output buffers of the last run, for zero-copy consumers (RCCL gather, GPU checkers).
+ * rows: n_instances * max_rows msim_op; payload: n_instances * max_payload_words u32;
+ * stats: n_instances msim_net_stats; meta: n_instances msim_inst_meta. */
+typedef struct msim_device_buffers {
+  void *rows; void *payload; void *stats; void *meta;
+  uint64_t rows_bytes, payload_bytes, stats_bytes, meta_bytes;
+  uint32_t n_instances, max_rows, max_payload_words, reserved;
+} msim_device_buffers;
+int msim_device_buffers_get(msim_ctx *ctx, msim_device_buffers *out);
+
+/* Kernel time of the last msim_run in milliseconds, measured with HIP events on the engine's stream. */
+int msim_last_kernel_ms(msim_ctx *ctx, float *sim_ms, float *check_ms);
+
+/* The finalized configuration the ctx runs with. */
+int msim_get_config(const msim_ctx *ctx, msim_config *out);
+
+const char *msim_last_error(const msim_ctx *ctx);
+void msim_destroy(msim_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAELSIM_H */

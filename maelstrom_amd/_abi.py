@@ -1,0 +1,119 @@
+"""ctypes mirror of include/maelsim.h — the C-ABI boundary of libmaelsim.so.
+
+This is the binding a reference maintainer would write on the JVM side as JNI (INTEGRATION.md shows that
+stub); here it is ctypes because the host language available in this image is Python.  Nothing in this
+module touches the oracle: if libmaelsim.so is missing or there is no HIP device the engine raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmaelsim.so")
+
+ABI_VERSION = 1
+
+# enums (include/maelsim.h)
+OK, E_INVALID, E_NO_DEVICE, E_HIP, E_NOMEM, E_RANGE, E_UNSUPPORTED, E_OVERFLOW = 0, -1, -2, -3, -4, -5, -6, -7
+WL_ECHO, WL_BROADCAST, WL_G_SET, WL_LIN_KV, WL_TXN_LIST_APPEND = range(5)
+NODE_ECHO, NODE_BCAST_FF, NODE_BCAST_FF_ECHOBACK, NODE_BCAST_ACK_RETRY, NODE_BCAST_RPC_ALL, NODE_G_SET, NODE_RAFT = range(7)
+LAT_CONSTANT, LAT_UNIFORM, LAT_EXPONENTIAL = range(3)
+TOPO_GRID, TOPO_LINE, TOPO_TOTAL, TOPO_TREE2, TOPO_TREE3, TOPO_TREE4 = range(6)
+NEMESIS_PARTITION = 1
+T_INVOKE, T_OK, T_FAIL, T_INFO = range(4)
+F_ECHO, F_BROADCAST, F_READ, F_ADD, F_START_PARTITION, F_STOP_PARTITION, F_WRITE, F_CAS, F_TXN = range(9)
+ERR_NONE, ERR_NET_TIMEOUT, ERR_RPC = range(3)
+SPEC_ONE, SPEC_MAJORITY, SPEC_MAJORITIES_RING, SPEC_MINORITY_THIRD = range(4)
+PROCESS_NEMESIS = 0xFFFFF
+NO_VALUE = 0xFFFFFFFF
+FLAG_ROWS_OVERFLOW, FLAG_PAYLOAD_OVERFLOW, FLAG_INBOX_OVERFLOW, FLAG_VALUES_OVERFLOW, FLAG_ROUND_LIMIT = 1, 2, 4, 8, 16
+MASK_WORDS = 4
+
+EXPORTS = [
+    "msim_abi_version", "msim_device_count", "msim_config_defaults", "msim_config_finalize", "msim_create",
+    "msim_run", "msim_run_async", "msim_check", "msim_fetch", "msim_history", "msim_net_stats_get", "msim_meta",
+    "msim_check_results", "msim_device_buffers_get", "msim_last_kernel_ms", "msim_get_config",
+    "msim_last_error", "msim_destroy",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("abi_version", C.c_uint32), ("workload", C.c_uint32),
+        ("node_program", C.c_uint32), ("n_nodes", C.c_uint32), ("concurrency", C.c_uint32),
+        ("rate_mhz", C.c_uint32), ("time_limit_ms", C.c_uint32), ("latency_mean_ms", C.c_uint32),
+        ("latency_dist", C.c_uint32), ("p_loss_q32", C.c_uint32), ("topology", C.c_uint32),
+        ("nemesis_mask", C.c_uint32), ("nemesis_interval_ms", C.c_uint32), ("client_timeout_ms", C.c_uint32),
+        ("quiesce_ms", C.c_uint32), ("seed", C.c_uint64), ("max_values", C.c_uint32), ("max_rows", C.c_uint32),
+        ("max_payload_words", C.c_uint32), ("inbox_capacity", C.c_uint32), ("reserved", C.c_uint32 * 8),
+    ]
+
+
+class Op(C.Structure):
+    _fields_ = [("time_len", C.c_uint64), ("packed", C.c_uint32), ("value", C.c_uint32)]
+
+
+class NetStats(C.Structure):
+    _fields_ = [("all_send", C.c_uint64), ("all_recv", C.c_uint64), ("clients_send", C.c_uint64),
+                ("clients_recv", C.c_uint64), ("servers_send", C.c_uint64), ("servers_recv", C.c_uint64)]
+
+
+class InstMeta(C.Structure):
+    _fields_ = [("n_rows", C.c_uint32), ("n_payload_words", C.c_uint32), ("flags", C.c_uint32), ("n_rounds", C.c_uint32)]
+
+
+class CheckResult(C.Structure):
+    _fields_ = [("valid", C.c_uint32), ("attempt_count", C.c_uint32), ("stable_count", C.c_uint32),
+                ("lost_count", C.c_uint32), ("never_read_count", C.c_uint32), ("stale_count", C.c_uint32),
+                ("duplicated_count", C.c_uint32), ("error_count", C.c_uint32), ("stable_latency_ms", C.c_uint32 * 5),
+                ("op_count", C.c_uint32), ("ok_count", C.c_uint32), ("fail_count", C.c_uint32), ("info_count", C.c_uint32)]
+
+
+class DeviceBuffers(C.Structure):
+    _fields_ = [("rows", C.c_void_p), ("payload", C.c_void_p), ("stats", C.c_void_p), ("meta", C.c_void_p),
+                ("rows_bytes", C.c_uint64), ("payload_bytes", C.c_uint64), ("stats_bytes", C.c_uint64),
+                ("meta_bytes", C.c_uint64), ("n_instances", C.c_uint32), ("max_rows", C.c_uint32),
+                ("max_payload_words", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+assert C.sizeof(Config) == 120, C.sizeof(Config)
+assert C.sizeof(Op) == 16 and C.sizeof(NetStats) == 48 and C.sizeof(InstMeta) == 16 and C.sizeof(CheckResult) == 68
+
+_lib = None
+
+
+def load():
+    """Loads libmaelsim.so (built in-tree by maelstrom_amd.build / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -m maelstrom_amd.build` (hipcc, gfx950). "
+                           "There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    P = C.POINTER
+    lib.msim_abi_version.restype = C.c_uint32
+    lib.msim_device_count.restype = C.c_int
+    lib.msim_config_defaults.argtypes = [P(Config), C.c_uint32, C.c_uint32]
+    lib.msim_config_finalize.argtypes = [P(Config), C.c_char_p, C.c_size_t]
+    lib.msim_create.argtypes = [P(Config), C.c_int, P(C.c_void_p), C.c_char_p, C.c_size_t]
+    lib.msim_run.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32]
+    lib.msim_run_async.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
+    lib.msim_check.argtypes = [C.c_void_p]
+    lib.msim_fetch.argtypes = [C.c_void_p]
+    lib.msim_history.argtypes = [C.c_void_p, C.c_uint32, P(P(Op)), P(C.c_uint32), P(P(C.c_uint32)), P(C.c_uint32)]
+    lib.msim_net_stats_get.argtypes = [C.c_void_p, C.c_uint32, P(NetStats)]
+    lib.msim_meta.argtypes = [C.c_void_p, C.c_uint32, P(InstMeta)]
+    lib.msim_check_results.argtypes = [C.c_void_p, P(P(CheckResult)), P(C.c_uint32)]
+    lib.msim_device_buffers_get.argtypes = [C.c_void_p, P(DeviceBuffers)]
+    lib.msim_last_kernel_ms.argtypes = [C.c_void_p, P(C.c_float), P(C.c_float)]
+    lib.msim_get_config.argtypes = [C.c_void_p, P(Config)]
+    lib.msim_last_error.argtypes = [C.c_void_p]
+    lib.msim_last_error.restype = C.c_char_p
+    lib.msim_destroy.argtypes = [C.c_void_p]
+    lib.msim_destroy.restype = None
+    for name in ("msim_config_defaults", "msim_config_finalize", "msim_create", "msim_run", "msim_run_async",
+                 "msim_check", "msim_fetch", "msim_history", "msim_net_stats_get", "msim_meta", "msim_check_results",
+                 "msim_device_buffers_get", "msim_last_kernel_ms", "msim_get_config"):
+        getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib

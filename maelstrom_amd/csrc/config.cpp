@@ -1,0 +1,118 @@
+// config.cpp — host-side option handling of libmaelsim (no device code).
+//
+// Mirrors the reference's CLI option map and its defaults: src/maelstrom/core.clj:136-229 (opt-spec),
+// core.clj:231-265 (parse-node-count / opt-fn), plus [upstream] jepsen.cli defaults (--time-limit 60,
+// --concurrency 1n).  Capacities (history rows, payload words, set width, inbox depth) have no
+// counterpart in the reference (JVM heap); they are derived here from rate x time-limit so that an
+// instance overflows only ~10 sigma away from its expected size, and every overflow is reported
+// (msim_inst_meta.flags), never silently truncated.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/maelsim.h"
+#include "engine_limits.h"
+
+static void set_err(char *err, size_t n, const char *msg) {
+  if (err && n) { std::snprintf(err, n, "%s", msg); }
+}
+
+extern "C" uint32_t msim_abi_version(void) { return MSIM_ABI_VERSION; }
+
+extern "C" int msim_config_defaults(msim_config *cfg, uint32_t workload, uint32_t n_nodes) {
+  if (!cfg) return MSIM_E_INVALID;
+  std::memset(cfg, 0, sizeof *cfg);
+  cfg->struct_size = sizeof *cfg;
+  cfg->abi_version = MSIM_ABI_VERSION;
+  cfg->workload = workload;
+  switch (workload) {
+    case MSIM_WL_ECHO: cfg->node_program = MSIM_NODE_ECHO; break;
+    case MSIM_WL_BROADCAST: cfg->node_program = MSIM_NODE_BCAST_FF; break;
+    case MSIM_WL_G_SET: cfg->node_program = MSIM_NODE_G_SET; break;
+    default: cfg->node_program = MSIM_NODE_RAFT; break;
+  }
+  cfg->n_nodes = n_nodes;
+  cfg->concurrency = n_nodes;           // "1n"
+  cfg->rate_mhz = 5000;                 // core.clj:219-222
+  cfg->time_limit_ms = 60000;           // jepsen.cli
+  cfg->latency_mean_ms = 0;             // core.clj:171-174
+  cfg->latency_dist = MSIM_LAT_CONSTANT;
+  cfg->p_loss_q32 = 0;                  // net.clj:100
+  cfg->topology = MSIM_TOPO_GRID;       // core.clj:224-227
+  cfg->nemesis_mask = 0;
+  cfg->nemesis_interval_ms = 10000;     // core.clj:214-217
+  cfg->client_timeout_ms = 5000;        // client.clj:18-20
+  cfg->quiesce_ms = 10000;              // core.clj:78
+  cfg->seed = 0;
+  return MSIM_OK;
+}
+
+static uint32_t max_degree(const msim_config *c) {
+  uint32_t n = c->n_nodes;
+  if (c->node_program == MSIM_NODE_BCAST_RPC_ALL || c->node_program == MSIM_NODE_G_SET) return n ? n - 1 : 0;
+  switch (c->topology) {
+    case MSIM_TOPO_GRID: return n > 4 ? 4 : (n ? n - 1 : 0);
+    case MSIM_TOPO_LINE: return n > 2 ? 2 : (n ? n - 1 : 0);
+    case MSIM_TOPO_TOTAL: return n ? n - 1 : 0;
+    case MSIM_TOPO_TREE2: return 3;
+    case MSIM_TOPO_TREE3: return 4;
+    default: return 5;
+  }
+}
+
+extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
+  if (!c) return MSIM_E_INVALID;
+  if (c->struct_size != sizeof(msim_config) || c->abi_version != MSIM_ABI_VERSION) {
+    set_err(err, errlen, "msim_config: struct_size/abi_version mismatch"); return MSIM_E_INVALID; }
+  if (c->n_nodes == 0 || c->n_nodes > MSIM_MAX_NODES) { set_err(err, errlen, "n_nodes must be in 1..128"); return MSIM_E_INVALID; }
+  if (c->concurrency == 0) c->concurrency = c->n_nodes;
+  uint32_t slots = c->concurrency > c->n_nodes ? c->concurrency : c->n_nodes;
+  if (c->n_nodes + slots > 255) { set_err(err, errlen, "n_nodes + max(concurrency, n_nodes) must be <= 255"); return MSIM_E_INVALID; }
+  if (c->workload > MSIM_WL_TXN_LIST_APPEND) { set_err(err, errlen, "unknown workload"); return MSIM_E_INVALID; }
+  if (c->latency_dist > MSIM_LAT_EXPONENTIAL) { set_err(err, errlen, "latency_dist must be constant, uniform, or exponential"); return MSIM_E_INVALID; }
+  if (c->latency_dist == MSIM_LAT_EXPONENTIAL && c->latency_mean_ms == 0) {
+    // net.clj:77 (exponential-distribution (/ mean)) throws "Divide by zero" for --latency 0
+    set_err(err, errlen, "exponential latency needs a non-zero mean (net.clj:77 divides by zero)"); return MSIM_E_INVALID; }
+  if (c->topology > MSIM_TOPO_TREE4) { set_err(err, errlen, "unknown topology"); return MSIM_E_INVALID; }
+  if (c->nemesis_mask & ~MSIM_NEMESIS_PARTITION) { set_err(err, errlen, "unknown nemesis fault (only partition, core.clj:49-51)"); return MSIM_E_INVALID; }
+  if (c->nemesis_interval_ms == 0) { set_err(err, errlen, "nemesis interval must be positive"); return MSIM_E_INVALID; }
+  if (c->latency_mean_ms > 60000) { set_err(err, errlen, "latency mean above 60 s is not supported"); return MSIM_E_INVALID; }
+  if ((uint64_t)c->time_limit_ms + c->quiesce_ms + 2ull * c->client_timeout_ms > 3600000ull) {
+    set_err(err, errlen, "time-limit + quiesce must fit in 1 h of virtual time (u32 microseconds)"); return MSIM_E_INVALID; }
+  // workload <-> node program compatibility
+  bool ok = false;
+  switch (c->workload) {
+    case MSIM_WL_ECHO: ok = c->node_program == MSIM_NODE_ECHO; break;
+    case MSIM_WL_BROADCAST: ok = c->node_program >= MSIM_NODE_BCAST_FF && c->node_program <= MSIM_NODE_BCAST_RPC_ALL; break;
+    case MSIM_WL_G_SET: ok = c->node_program == MSIM_NODE_G_SET; break;
+    default: set_err(err, errlen, "workload not built into this engine yet (lin-kv / txn-list-append)"); return MSIM_E_UNSUPPORTED;
+  }
+  if (!ok) { set_err(err, errlen, "node_program does not implement this workload"); return MSIM_E_INVALID; }
+
+  double expected = (double)c->rate_mhz * (double)c->time_limit_ms / 1e6;
+  uint32_t ops_max = (uint32_t)(expected + expected / 8.0) + 64;
+  uint32_t adds = (uint32_t)(ops_max / 2 + 4.0 * std::sqrt((double)ops_max)) + 32;
+  uint32_t nem_ops = 0;
+  if (c->nemesis_mask) nem_ops = 4 * (c->time_limit_ms / c->nemesis_interval_ms + 1) + 16;
+  if (c->max_values == 0) c->max_values = c->workload == MSIM_WL_ECHO ? 32 : ((adds + 31) / 32) * 32;
+  if (c->max_values % 32) c->max_values = ((c->max_values + 31) / 32) * 32;
+  if (c->max_rows == 0) c->max_rows = 2 * (ops_max + c->concurrency) + 2 * nem_ops + 16;
+  if (c->max_payload_words == 0) {
+    uint32_t w = c->max_values / 32;
+    uint64_t words = c->workload == MSIM_WL_ECHO ? 16 : (uint64_t)(adds + c->concurrency) * w;
+    words += (uint64_t)nem_ops * c->n_nodes * MSIM_MASK_WORDS + 16;
+    if (words > 0xFFFFFFu) { set_err(err, errlen, "payload area above 2^24 words per instance"); return MSIM_E_INVALID; }
+    c->max_payload_words = (uint32_t)words;
+  }
+  if (c->max_payload_words > 0xFFFFFFu) { set_err(err, errlen, "max_payload_words must be < 2^24"); return MSIM_E_INVALID; }
+  if (c->max_values > 255u * 32u) { set_err(err, errlen, "max_values above 8160 (read length is 8 bits of words)"); return MSIM_E_INVALID; }
+  if (c->inbox_capacity == 0) {
+    uint32_t deg = max_degree(c);
+    double per_s = (double)c->rate_mhz / 2000.0 * deg;             // server msgs per second into one node
+    if (c->node_program == MSIM_NODE_BCAST_ACK_RETRY || c->node_program == MSIM_NODE_BCAST_RPC_ALL) per_s *= 2;  // + acks
+    double lat_s = c->latency_mean_ms / 1000.0;
+    if (c->latency_dist != MSIM_LAT_CONSTANT) lat_s *= 3.0;
+    c->inbox_capacity = 16 + 2 * deg + (uint32_t)(per_s * lat_s * 1.5);
+  }
+  return MSIM_OK;
+}

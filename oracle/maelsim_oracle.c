@@ -1,0 +1,640 @@
+/* maelsim_oracle.c — CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C, single-threaded, deliberately simple restatement of Maelstrom's hot path for ONE test
+ * instance at a time, in deterministic virtual time.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this; the product (libmaelsim.so, maelstrom_amd/) never does.
+ *
+ * PARITY PINNING: the reference (Clojure/JVM + Ruby/babashka node processes) cannot
+ * run in this environment and is non-deterministic (no seed: net.clj:187,205,214), so there is no
+ * byte-level golden history to pin against.  What this oracle IS pinned against
+ * (tests/test_oracle_kat.py, tests/test_golden_transitions.py):
+ *   - the reference docs' exact message-count known-answers KAT-1..KAT-5,
+ *   - golden node-transition vectors recorded from the reference's own runnable node programs
+ *     (demo/python/echo.py, demo/js/gossip.js, demo/js/crdt_gset.js; tests/golden/make_golden.py),
+ *   - checker verdicts (set-full :valid? true) on every emitted history.
+ * Everything that comes from un-vendored upstream Jepsen (generator interpreter, partition-package)
+ * is restated from its published behaviour and is "parity unpinned" (DESIGN.md §3).
+ *
+ * What is restated, with the reference lines each part follows:
+ *   network   : net.clj:189-221 send!  (id := ++next-message-id; latency 0 if a client is involved,
+ *               util.clj:7-16 / net.clj:178-187; journal :send BEFORE the loss decision :208/:214)
+ *               net.clj:223-247 recv!  (poll the min-deadline envelope even if not yet due :228;
+ *               partition check at poll time :234; sleep (long dt) ms :236-238; journal :recv :244)
+ *               net.clj:39-40 queue order = deadline (ties: this engine defines (deadline, id))
+ *               net.clj:65-77 latency distributions; net.clj:109-113 drop!/heal!
+ *   process   : process.clj:154-166 one message at a time per node (stdin thread loop)
+ *   client    : client.clj:66-117 one outstanding RPC, stale replies skipped, timeout;
+ *               client.clj:153-172 with-errors -> :fail / :info
+ *   db        : db.clj:46-69 init handshake; broadcast.clj:195-197 topology RPC in setup!
+ *   test map  : core.clj:67-80 generator phases (stagger, time-limit, nemesis, sleep 10, final reads)
+ *   workloads : echo.clj:72-75, broadcast.clj:40-185 (topologies) :237-240 (generator),
+ *               g_set.clj:59-61
+ *   nodes     : echo (demo/ruby/echo.rb:20-41), broadcast variants (doc/03-broadcast/01-broadcast.md:
+ *               525-547, 02-performance.md:61-67, :406-441, demo/ruby/broadcast.rb:29-47),
+ *               g-set (demo/ruby/g_set.rb:8-39, node.rb:129-138 periodic task)
+ *   stats     : net/checker.clj:28-41, journal.clj:241-337
+ *
+ * The deterministic schedule ("rounds", canonical id order, counter-based RNG) is specified in
+ * DESIGN.md §2; this file and the HIP engine implement that text independently.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+#include "../include/maelsim.h"
+#include "log2_table.h"
+
+typedef uint8_t u8;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+#define INF 0xFFFFFFFFu
+#define MAXN 128
+#define MW 4 /* mask words: MAXN/32 */
+
+/* message types (doc/protocol.md, doc/workloads.md) */
+enum { M_INIT = 1, M_INIT_OK, M_TOPOLOGY, M_TOPOLOGY_OK, M_ECHO, M_ECHO_OK, M_BROADCAST, M_BROADCAST_OK,
+       M_READ, M_READ_OK, M_ADD, M_ADD_OK, M_REPLICATE };
+
+/* RNG streams */
+enum { S_STAGGER = 1, S_MIX = 2, S_PROC = 3, S_LATENCY = 4, S_LOSS = 5, S_ECHO = 6,
+       S_NEM_STAGGER = 7, S_NEM_SPEC = 8, S_NEM_SHUFFLE = 9, S_NEM_PICK = 10 };
+
+enum { PH_INIT, PH_INIT_WAIT, PH_TOPO, PH_TOPO_WAIT, PH_MAIN_START, PH_MAIN, PH_DRAIN, PH_NEM_FINAL,
+       PH_SLEEP, PH_FINAL, PH_FINAL_WAIT, PH_DONE };
+
+enum { K_NONE = 0, K_INIT, K_TOPO, K_OP };
+
+typedef struct { u32 deadline, id, a, b; u8 src, type; } qent;
+typedef struct { qent *v; u32 n, cap; } inbox_t;
+typedef struct { u32 value, next_retry; u32 unacked[MW]; } task_t;
+typedef struct { task_t *v; u32 n, cap; } tasks_t;
+typedef struct { u8 src_ep, dest_ep, type; u32 a, b; } outmsg;
+
+typedef struct {
+  msim_config cfg;
+  u32 N, C, CS, E, W; /* nodes, workers, client slots, endpoints, words per node set */
+  u64 key;
+  u32 adj[MAXN][MW];
+  /* net (net.clj:79-103) */
+  u32 next_msg_id;
+  msim_net_stats st;
+  u32 part[MAXN][MW]; /* part[dest] = set of src whose packets dest drops (net.clj:109-110) */
+  inbox_t *inbox;
+  qent *committed; u8 *has_committed; u32 *deliver_at;
+  /* nodes */
+  u32 *seen;            /* N * W words */
+  u32 *node_msg_id;     /* per-node RPC msg_id counter (node.rb:91-98) */
+  u32 *nbr_known;       /* node got its topology */
+  tasks_t *tasks;       /* ack/retry tasks per node */
+  u32 *timer_next;      /* g-set replicate timer */
+  u32 **snap; u32 n_snap, cap_snap; /* replicate_full payload snapshots */
+  /* clients */
+  struct cl { u8 busy, kind, mark; u32 want, timeout_at, next_msg_id, f, value, process, m_f, m_value, m_final; } *cl;
+  /* scheduler */
+  u32 phase, T, cutoff, gen_next, gen_k, next_value, nem_next, nem_j, sleep_until, loss_on;
+  u32 rounds;
+  /* outbox for the current round */
+  outmsg *out; u32 n_out, cap_out;
+  /* outputs */
+  msim_op *rows; u32 *payload; msim_inst_meta meta;
+} sim_t;
+
+/* ---- RNG: counter-based, keyed (seed, instance, stream, counter) --------------------------------- */
+static u64 mix64(u64 z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+static u64 inst_key(u64 seed, u64 instance) { return mix64(seed + 0x9E3779B97F4A7C15ull * (instance + 1)); }
+static u32 draw32(const sim_t *s, u32 stream, u64 ctr) {
+  u64 x = ((u64)stream << 48) | ctr;
+  return (u32)(mix64(s->key + x * 0x9E3779B97F4A7C15ull) >> 32);
+}
+static u32 scale32(u32 r, u32 n) { return (u32)(((u64)r * n) >> 32); } /* uniform int in [0, n) */
+
+/* -ln(u) in Q16 for u = (r+1)/2^32, integer-only (table + linear interpolation of log2). */
+static u32 neg_ln_q16(u32 r) {
+  if (r == 0xFFFFFFFFu) return 0; /* u = 1 */
+  u32 v = r + 1;
+  u32 e = 31 - (u32)__builtin_clz(v);
+  u32 m = v << (31 - e);            /* bit 31 set */
+  u32 idx = (m >> 23) & 0xFF;
+  u32 f = (m >> 7) & 0xFFFF;
+  u32 l0 = oracle_log2_q24[idx], l1 = oracle_log2_q24[idx + 1];
+  u32 lg = (e << 24) + l0 + (u32)(((u64)(l1 - l0) * f) >> 16); /* log2(v) in Q24 */
+  u32 d = (32u << 24) - lg;                                   /* -log2(u) in Q24 */
+  return (u32)(((u64)d * 2977044472ull) >> 40);               /* * ln2 (Q32) -> Q16 */
+}
+
+/* net.clj:178-187 latency-for, in ms */
+static u32 latency_ms(const sim_t *s, u32 msg_id, int involves_client) {
+  if (involves_client) return 0;
+  u32 mean = s->cfg.latency_mean_ms;
+  switch (s->cfg.latency_dist) {
+    case MSIM_LAT_CONSTANT: return mean;
+    case MSIM_LAT_UNIFORM: return scale32(draw32(s, S_LATENCY, msg_id), 2 * mean); /* [0, 2*mean) */
+    default: return (u32)(((u64)mean * neg_ln_q16(draw32(s, S_LATENCY, msg_id))) >> 16);
+  }
+}
+
+/* ---- small helpers ------------------------------------------------------------------------------- */
+static int bit(const u32 *m, u32 i) { return (m[i >> 5] >> (i & 31)) & 1; }
+static void setbit(u32 *m, u32 i) { m[i >> 5] |= 1u << (i & 31); }
+static void clrbit(u32 *m, u32 i) { m[i >> 5] &= ~(1u << (i & 31)); }
+static int is_client(const sim_t *s, u32 ep) { return ep >= s->N; }
+
+static void inbox_push(sim_t *s, u32 ep, qent q) {
+  inbox_t *b = &s->inbox[ep];
+  if (b->n == b->cap) { b->cap = b->cap ? b->cap * 2 : 8; b->v = (qent *)realloc(b->v, b->cap * sizeof(qent)); }
+  b->v[b->n++] = q;
+  u32 lim = is_client(s, ep) ? 0xFFFFFFFFu : s->cfg.inbox_capacity;
+  if (b->n > lim) s->meta.flags |= MSIM_FLAG_INBOX_OVERFLOW;
+}
+
+static void out_send(sim_t *s, u32 src, u32 dest, u32 type, u32 a, u32 b) {
+  if (s->n_out == s->cap_out) { s->cap_out = s->cap_out ? s->cap_out * 2 : 64; s->out = (outmsg *)realloc(s->out, s->cap_out * sizeof(outmsg)); }
+  outmsg m = {(u8)src, (u8)dest, (u8)type, a, b};
+  s->out[s->n_out++] = m;
+}
+
+static void add_row(sim_t *s, u32 type, u32 f, u32 err, u32 final, u32 process, u32 value, u32 len) {
+  if (s->meta.n_rows >= s->cfg.max_rows) { s->meta.flags |= MSIM_FLAG_ROWS_OVERFLOW; return; }
+  msim_op *r = &s->rows[s->meta.n_rows++];
+  r->time_len = ((u64)s->T * 1000ull) | ((u64)len << 48);
+  r->packed = type | (f << 2) | (err << 7) | (final << 11) | (process << 12);
+  r->value = value;
+}
+
+/* returns payload offset or INF on overflow */
+static u32 payload_alloc(sim_t *s, u32 words) {
+  if (s->meta.n_payload_words + words > s->cfg.max_payload_words) { s->meta.flags |= MSIM_FLAG_PAYLOAD_OVERFLOW; return INF; }
+  u32 off = s->meta.n_payload_words;
+  s->meta.n_payload_words += words;
+  return off;
+}
+
+/* ---- topologies (broadcast.clj:40-185) ----------------------------------------------------------- */
+static void link2(sim_t *s, u32 a, u32 b) { setbit(s->adj[a], b); setbit(s->adj[b], a); }
+static void build_topology(sim_t *s) {
+  u32 n = s->N;
+  memset(s->adj, 0, sizeof s->adj);
+  switch (s->cfg.topology) {
+    case MSIM_TOPO_GRID: { /* broadcast.clj:40-65: side = ceil(sqrt n), idx = i*side + j */
+      u32 side = 1; while (side * side < n) side++;
+      for (u32 i = 0; i < side; i++) for (u32 j = 0; j < side; j++) {
+        u32 a = i * side + j; if (a >= n) continue;
+        if (j + 1 < side && a + 1 < n) link2(s, a, a + 1);
+        if (a + side < n) link2(s, a, a + side);
+      }
+    } break;
+    case MSIM_TOPO_LINE: for (u32 i = 0; i + 1 < n; i++) link2(s, i, i + 1); break; /* :67-80 */
+    case MSIM_TOPO_TOTAL: for (u32 i = 0; i < n; i++) for (u32 j = i + 1; j < n; j++) link2(s, i, j); break; /* :82-89 */
+    default: { /* trees :91-167: BFS tiers 1,b,b^2.. => parent(i) = (i-1)/b */
+      u32 b = s->cfg.topology == MSIM_TOPO_TREE2 ? 2 : s->cfg.topology == MSIM_TOPO_TREE3 ? 3 : 4;
+      for (u32 i = 1; i < n; i++) link2(s, i, (i - 1) / b);
+    }
+  }
+}
+
+/* ---- nemesis: [upstream] jepsen.nemesis.combined partition-package, restated ------- */
+static void complete_grudge(sim_t *s, const u8 *comp) { /* comp[node] = component id */
+  for (u32 d = 0; d < s->N; d++) for (u32 x = 0; x < s->N; x++) if (comp[d] != comp[x]) setbit(s->part[d], x);
+}
+static void shuffle_nodes(sim_t *s, u32 j, u32 *perm) {
+  for (u32 i = 0; i < s->N; i++) perm[i] = i;
+  for (u32 i = s->N - 1; i >= 1; i--) {
+    u32 k = scale32(draw32(s, S_NEM_SHUFFLE, ((u64)j << 16) | i), i + 1);
+    u32 t = perm[i]; perm[i] = perm[k]; perm[k] = t;
+  }
+}
+static void start_partition(sim_t *s, u32 j, u32 spec) {
+  u32 n = s->N, perm[MAXN]; u8 comp[MAXN];
+  memset(comp, 0, sizeof comp);
+  switch (spec) {
+    case MSIM_SPEC_ONE: comp[scale32(draw32(s, S_NEM_PICK, j), n)] = 1; complete_grudge(s, comp); break;
+    case MSIM_SPEC_MAJORITY: /* bisect (shuffle nodes): split-at floor(n/2) */
+      shuffle_nodes(s, j, perm);
+      for (u32 i = 0; i < n / 2; i++) comp[perm[i]] = 1;
+      complete_grudge(s, comp); break;
+    case MSIM_SPEC_MINORITY_THIRD:
+      shuffle_nodes(s, j, perm);
+      for (u32 i = 0; i < (n - 1) / 3; i++) comp[perm[i]] = 1;
+      complete_grudge(s, comp); break;
+    default: { /* majorities-ring: node perm[(i+m/2)%n] sees only the window perm[i..i+m) */
+      shuffle_nodes(s, j, perm);
+      u32 m = n / 2 + 1;
+      for (u32 i = 0; i < n; i++) {
+        u32 c = perm[(i + m / 2) % n];
+        u32 vis[MW] = {0, 0, 0, 0};
+        for (u32 k = 0; k < m; k++) setbit(vis, perm[(i + k) % n]);
+        for (u32 x = 0; x < n; x++) if (!bit(vis, x)) setbit(s->part[c], x);
+      }
+    }
+  }
+}
+
+/* ---- node programs -------------------------------------------------------------------------------- */
+static u32 *seen_of(sim_t *s, u32 node) { return s->seen + (size_t)node * s->W; }
+
+/* read -> read_ok with the whole set (broadcast.rb:23-27, g_set.rb:13-15): snapshot into the payload */
+static void node_read(sim_t *s, u32 node, const qent *q) {
+  u32 words = (s->next_value + 31) / 32;
+  u32 off = payload_alloc(s, words);
+  if (off != INF) memcpy(s->payload + off, seen_of(s, node), words * 4);
+  out_send(s, node, q->src, M_READ_OK, (off == INF ? 0 : off) | (words << 24), q->b);
+}
+
+static void gossip_targets(sim_t *s, u32 node, u32 src, u32 *tg) {
+  u32 prog = s->cfg.node_program;
+  for (u32 w = 0; w < MW; w++) tg[w] = 0;
+  if (prog == MSIM_NODE_BCAST_RPC_ALL) { for (u32 i = 0; i < s->N; i++) if (i != node) setbit(tg, i); } /* broadcast.rb:37 other_node_ids */
+  else for (u32 w = 0; w < MW; w++) tg[w] = s->adj[node][w];
+  if (prog != MSIM_NODE_BCAST_FF_ECHOBACK && src < s->N) clrbit(tg, src); /* skip-sender, 02-performance.md:61-67 */
+}
+
+static void node_broadcast(sim_t *s, u32 node, const qent *q) {
+  u32 prog = s->cfg.node_program, v = q->a, has_id = q->b != 0;
+  if (prog == MSIM_NODE_BCAST_ACK_RETRY && has_id) out_send(s, node, q->src, M_BROADCAST_OK, v, q->b); /* ack first, 02-performance.md:408-409 */
+  u32 *sn = seen_of(s, node);
+  if (!bit(sn, v)) {
+    setbit(sn, v);
+    u32 tg[MW]; gossip_targets(s, node, q->src, tg);
+    int rpc = prog == MSIM_NODE_BCAST_ACK_RETRY || prog == MSIM_NODE_BCAST_RPC_ALL;
+    int any = 0;
+    for (u32 i = 0; i < s->N; i++) if (bit(tg, i)) { any = 1; out_send(s, node, i, M_BROADCAST, v, rpc ? ++s->node_msg_id[node] : 0); }
+    if (prog == MSIM_NODE_BCAST_ACK_RETRY && any) { /* keep retrying every 1 s until acked, :421-438 */
+      tasks_t *t = &s->tasks[node];
+      if (t->n == t->cap) { t->cap = t->cap ? t->cap * 2 : 8; t->v = (task_t *)realloc(t->v, t->cap * sizeof(task_t)); }
+      task_t k; k.value = v; k.next_retry = s->T + 1000000u; memcpy(k.unacked, tg, sizeof tg);
+      t->v[t->n++] = k;
+    }
+  }
+  if (prog != MSIM_NODE_BCAST_ACK_RETRY && has_id) out_send(s, node, q->src, M_BROADCAST_OK, v, q->b);
+}
+
+static void node_broadcast_ok(sim_t *s, u32 node, const qent *q) { /* callback: unacked.delete dest */
+  if (s->cfg.node_program != MSIM_NODE_BCAST_ACK_RETRY) return;
+  tasks_t *t = &s->tasks[node];
+  for (u32 i = 0; i < t->n; i++) if (t->v[i].value == q->a) {
+    clrbit(t->v[i].unacked, q->src);
+    u32 any = 0; for (u32 w = 0; w < MW; w++) any |= t->v[i].unacked[w];
+    if (!any) t->v[i] = t->v[--t->n];
+    return;
+  }
+}
+
+/* earliest due retry task of a node: min (next_retry, value); returns index or -1 */
+static int due_task(const sim_t *s, u32 node, u32 T) {
+  const tasks_t *t = &s->tasks[node]; int best = -1;
+  for (u32 i = 0; i < t->n; i++) if (t->v[i].next_retry <= T) {
+    if (best < 0 || t->v[i].next_retry < t->v[best].next_retry ||
+        (t->v[i].next_retry == t->v[best].next_retry && t->v[i].value < t->v[best].value)) best = (int)i;
+  }
+  return best;
+}
+static u32 node_timer_time(const sim_t *s, u32 node) {
+  u32 m = s->timer_next[node];
+  const tasks_t *t = &s->tasks[node];
+  for (u32 i = 0; i < t->n; i++) if (t->v[i].next_retry < m) m = t->v[i].next_retry;
+  return m;
+}
+
+static void node_timer(sim_t *s, u32 node) {
+  if (s->timer_next[node] <= s->T) { /* g_set.rb:33-38: every 5 s, replicate_full to all other nodes */
+    s->timer_next[node] = s->T + 5000000u;
+    if (s->n_snap == s->cap_snap) { s->cap_snap = s->cap_snap ? s->cap_snap * 2 : 64; s->snap = (u32 **)realloc(s->snap, s->cap_snap * sizeof(u32 *)); }
+    u32 *cp = (u32 *)malloc(s->W * 4); memcpy(cp, seen_of(s, node), s->W * 4);
+    s->snap[s->n_snap] = cp;
+    for (u32 i = 0; i < s->N; i++) if (i != node) out_send(s, node, i, M_REPLICATE, s->n_snap, 0);
+    s->n_snap++;
+    return;
+  }
+  int k = due_task(s, node, s->T);
+  if (k >= 0) {
+    task_t *t = &s->tasks[node].v[k];
+    for (u32 i = 0; i < s->N; i++) if (bit(t->unacked, i)) out_send(s, node, i, M_BROADCAST, t->value, ++s->node_msg_id[node]);
+    t->next_retry += 1000000u;
+  }
+}
+
+static void node_handle(sim_t *s, u32 node, const qent *q) {
+  switch (q->type) {
+    case M_INIT: /* node.rb init handler -> init_ok; g-set starts its periodic task (node.rb:129-138) */
+      if (s->cfg.node_program == MSIM_NODE_G_SET) s->timer_next[node] = s->T;
+      out_send(s, node, q->src, M_INIT_OK, 0, q->b); break;
+    case M_TOPOLOGY: s->nbr_known[node] = 1; out_send(s, node, q->src, M_TOPOLOGY_OK, 0, q->b); break;
+    case M_ECHO: out_send(s, node, q->src, M_ECHO_OK, q->a, q->b); break; /* echo.rb:32-38 */
+    case M_BROADCAST: node_broadcast(s, node, q); break;
+    case M_BROADCAST_OK: node_broadcast_ok(s, node, q); break;
+    case M_READ: node_read(s, node, q); break;
+    case M_ADD: setbit(seen_of(s, node), q->a); out_send(s, node, q->src, M_ADD_OK, q->a, q->b); break; /* g_set.rb:17-21 */
+    case M_REPLICATE: { u32 *sn = seen_of(s, node), *v = s->snap[q->a]; for (u32 w = 0; w < s->W; w++) sn[w] |= v[w]; } break; /* g_set.rb:29-31 */
+    default: break;
+  }
+}
+
+/* ---- clients (client.clj) ------------------------------------------------------------------------- */
+static int idempotent(const sim_t *s, u32 f) { /* with-errors sets: broadcast.clj:200 #{:read}; echo.clj:33 #{} */
+  return s->cfg.workload == MSIM_WL_BROADCAST && f == MSIM_F_READ;
+}
+
+static void client_complete(sim_t *s, u32 slot, u32 type, u32 err, u32 value, u32 len) {
+  struct cl *c = &s->cl[slot];
+  c->busy = 0;
+  if (c->kind != K_OP) { if (type != MSIM_T_OK) s->meta.flags |= MSIM_FLAG_ROUND_LIMIT; return; }
+  add_row(s, type, c->f, err, c->m_final, c->process, value, len);
+  if (type == MSIM_T_INFO) { /* crashed process: new process id, fresh client [upstream interpreter] */
+    c->process += s->C;
+    c->next_msg_id = 0;
+    s->inbox[s->N + slot].n = 0;
+  }
+}
+
+static void client_deliver(sim_t *s, u32 slot, const qent *q) {
+  struct cl *c = &s->cl[slot];
+  if (!c->busy || q->b != c->want) return; /* stale reply, client.clj:105-107 */
+  switch (q->type) {
+    case M_READ_OK: client_complete(s, slot, MSIM_T_OK, 0, q->a & 0xFFFFFFu, q->a >> 24); break;
+    case M_ECHO_OK: client_complete(s, slot, MSIM_T_OK, 0, q->a, 0); break;
+    default: client_complete(s, slot, MSIM_T_OK, 0, c->value, 0); break;
+  }
+}
+
+static void client_timeout(sim_t *s, u32 slot) { /* client.clj:96-103 + :158-162 */
+  struct cl *c = &s->cl[slot];
+  u32 type = idempotent(s, c->f) ? MSIM_T_FAIL : MSIM_T_INFO;
+  client_complete(s, slot, type, MSIM_ERR_NET_TIMEOUT, c->f == MSIM_F_READ ? MSIM_NO_VALUE : c->value, 0);
+}
+
+static void client_invoke(sim_t *s, u32 slot) {
+  struct cl *c = &s->cl[slot];
+  c->mark = 0; c->busy = 1;
+  u32 ep = s->N + slot, dest, type, a = 0;
+  if (c->kind == K_INIT) { dest = slot; type = M_INIT; c->next_msg_id = 0; }
+  else if (c->kind == K_TOPO) { dest = slot; type = M_TOPOLOGY; c->next_msg_id = 0; }
+  else {
+    c->f = c->m_f; c->value = c->m_value;
+    dest = c->process % s->N; /* worker -> node: nodes[process mod n] [upstream] */
+    add_row(s, MSIM_T_INVOKE, c->f, 0, c->m_final, c->process, c->value, 0);
+    switch (c->f) {
+      case MSIM_F_ECHO: type = M_ECHO; a = c->value; break;
+      case MSIM_F_BROADCAST: type = M_BROADCAST; a = c->value; break;
+      case MSIM_F_ADD: type = M_ADD; a = c->value; break;
+      default: type = M_READ; break;
+    }
+  }
+  c->want = ++c->next_msg_id; /* client.clj:61-64 */
+  c->timeout_at = s->T + (c->kind == K_OP ? s->cfg.client_timeout_ms : 10000u) * 1000u; /* db.clj:54 */
+  out_send(s, ep, dest, type, a, c->want);
+}
+
+/* ---- scheduler: [upstream] generator interpreter for core.clj:67-80 ------------------------------- */
+static u32 stagger_us(const sim_t *s, u32 stream, u32 k, u64 period_us) { /* uniform [0, 2*period) */
+  return (u32)(((u64)draw32(s, stream, k) * (2 * period_us)) >> 32);
+}
+static int any_busy(const sim_t *s, u32 n) { for (u32 i = 0; i < n; i++) if (s->cl[i].busy) return 1; return 0; }
+static int has_final(const sim_t *s) { return s->cfg.workload == MSIM_WL_BROADCAST || s->cfg.workload == MSIM_WL_G_SET; }
+static int nem_on(const sim_t *s) { return (s->cfg.nemesis_mask & MSIM_NEMESIS_PARTITION) != 0; }
+static int gen_live(const sim_t *s) { return s->cfg.rate_mhz > 0 && s->gen_next < s->cutoff; }
+static int nem_live(const sim_t *s) { return nem_on(s) && s->nem_next < s->cutoff; }
+
+/* time-free phase transitions; evaluated at the top of every round */
+static void sched_resolve(sim_t *s) {
+  for (;;) {
+    switch (s->phase) {
+      case PH_INIT_WAIT: if (any_busy(s, s->CS)) return; s->phase = s->cfg.workload == MSIM_WL_BROADCAST ? PH_TOPO : PH_MAIN_START; continue;
+      case PH_TOPO_WAIT: if (any_busy(s, s->CS)) return; s->phase = PH_MAIN_START; continue;
+      case PH_MAIN_START:
+        s->cutoff = s->T + s->cfg.time_limit_ms * 1000u; s->gen_next = s->T; s->nem_next = s->T;
+        for (u32 i = 0; i < s->CS; i++) s->cl[i].next_msg_id = 0; /* workers open fresh clients (client.clj:41-53) */
+        s->loss_on = 1; /* p-loss is a run-time fault (net.clj:121-122), never active during db setup */
+        s->phase = PH_MAIN; continue;
+      case PH_MAIN:
+        if (gen_live(s) || nem_live(s)) return;
+        if (s->cfg.rate_mhz == 0 && s->T < s->cutoff) return; /* (gen/sleep time-limit), core.clj:69 */
+        s->phase = PH_DRAIN; continue;
+      case PH_DRAIN:
+        if (any_busy(s, s->C)) return;
+        s->phase = nem_on(s) && has_final(s) ? PH_NEM_FINAL : has_final(s) ? PH_SLEEP : PH_DONE;
+        if (s->phase == PH_SLEEP) s->sleep_until = s->T + s->cfg.quiesce_ms * 1000u;
+        continue;
+      case PH_FINAL_WAIT: if (any_busy(s, s->C)) return; s->phase = PH_DONE; continue;
+      default: return;
+    }
+  }
+}
+
+/* time at which the scheduler wants to act next (>= T), INF if it only waits for completions */
+static u32 sched_due(const sim_t *s) {
+  u32 T = s->T, d = INF;
+  switch (s->phase) {
+    case PH_INIT: case PH_TOPO: case PH_NEM_FINAL: case PH_FINAL: return T;
+    case PH_SLEEP: return s->sleep_until;
+    case PH_MAIN:
+      if (nem_live(s)) d = s->nem_next > T ? s->nem_next : T;
+      if (gen_live(s)) { int fr = 0; for (u32 i = 0; i < s->C; i++) fr |= !s->cl[i].busy;
+        if (fr) { u32 g = s->gen_next > T ? s->gen_next : T; if (g < d) d = g; } }
+      if (s->cfg.rate_mhz == 0 && !nem_live(s) && s->cutoff < d) d = s->cutoff;
+      return d;
+    default: return INF;
+  }
+}
+
+static void nemesis_rows(sim_t *s, u32 f, u32 v1, u32 v2, u32 len2) {
+  add_row(s, MSIM_T_INFO, f, 0, 0, MSIM_PROCESS_NEMESIS, v1, 0);
+  add_row(s, MSIM_T_INFO, f, 0, 0, MSIM_PROCESS_NEMESIS, v2, len2);
+}
+static void heal(sim_t *s) { memset(s->part, 0, sizeof s->part); } /* net.clj:112-113 */
+
+static void sched_act(sim_t *s) {
+  u32 T = s->T;
+  u64 period = 1000000000ull / (s->cfg.rate_mhz ? s->cfg.rate_mhz : 1);
+  switch (s->phase) {
+    case PH_INIT: for (u32 i = 0; i < s->N; i++) { s->cl[i].mark = 1; s->cl[i].kind = K_INIT; } s->phase = PH_INIT_WAIT; break;
+    case PH_TOPO: for (u32 i = 0; i < s->N; i++) { s->cl[i].mark = 1; s->cl[i].kind = K_TOPO; } s->phase = PH_TOPO_WAIT; break;
+    case PH_MAIN:
+      if (nem_live(s) && s->nem_next <= T) { /* flip-flop start/stop, staggered by the interval */
+        u32 j = s->nem_j++;
+        if ((j & 1) == 0) {
+          u32 spec = scale32(draw32(s, S_NEM_SPEC, j), 4);
+          start_partition(s, j, spec);
+          u32 words = s->N * MW, off = payload_alloc(s, words);
+          if (off != INF) memcpy(s->payload + off, s->part, words * 4);
+          nemesis_rows(s, MSIM_F_START_PARTITION, spec, off == INF ? 0 : off, words);
+        } else { heal(s); nemesis_rows(s, MSIM_F_STOP_PARTITION, MSIM_NO_VALUE, MSIM_NO_VALUE, 0); }
+        s->nem_next = T + stagger_us(s, S_NEM_STAGGER, j, (u64)s->cfg.nemesis_interval_ms * 1000u);
+      }
+      if (gen_live(s) && s->gen_next <= T) {
+        u32 nfree = 0; for (u32 i = 0; i < s->C; i++) nfree += !s->cl[i].busy;
+        if (nfree) {
+          u32 k = s->gen_k++;
+          u32 pick = scale32(draw32(s, S_PROC, k), nfree), slot = 0;
+          for (u32 i = 0; i < s->C; i++) if (!s->cl[i].busy) { if (pick == 0) { slot = i; break; } pick--; }
+          struct cl *c = &s->cl[slot];
+          c->mark = 1; c->kind = K_OP; c->m_final = 0;
+          if (s->cfg.workload == MSIM_WL_ECHO) { c->m_f = MSIM_F_ECHO; c->m_value = scale32(draw32(s, S_ECHO, k), 128); } /* echo.clj:72-75 */
+          else if (draw32(s, S_MIX, k) >> 31) { c->m_f = MSIM_F_READ; c->m_value = MSIM_NO_VALUE; }  /* gen/mix */
+          else {
+            c->m_f = s->cfg.workload == MSIM_WL_BROADCAST ? MSIM_F_BROADCAST : MSIM_F_ADD;
+            if (s->next_value >= s->cfg.max_values) { s->meta.flags |= MSIM_FLAG_VALUES_OVERFLOW; c->mark = 0; s->phase = PH_DONE; return; }
+            c->m_value = s->next_value++;
+          }
+          s->gen_next = T + stagger_us(s, S_STAGGER, k, period); /* gen/stagger (/ rate), core.clj:68 */
+        }
+      }
+      break;
+    case PH_NEM_FINAL: heal(s); nemesis_rows(s, MSIM_F_STOP_PARTITION, MSIM_NO_VALUE, MSIM_NO_VALUE, 0);
+      s->phase = PH_SLEEP; s->sleep_until = T + s->cfg.quiesce_ms * 1000u; break;
+    case PH_SLEEP: if (T >= s->sleep_until) s->phase = PH_FINAL; else break; /* fallthrough */
+    case PH_FINAL: /* (gen/clients (gen/each-thread {:f :read [:final? true]})), broadcast.clj:240, g_set.clj:61 */
+      for (u32 i = 0; i < s->C; i++) { struct cl *c = &s->cl[i]; c->mark = 1; c->kind = K_OP; c->m_f = MSIM_F_READ; c->m_value = MSIM_NO_VALUE;
+        c->m_final = s->cfg.workload == MSIM_WL_BROADCAST; }
+      s->phase = PH_FINAL_WAIT; break;
+    default: break;
+  }
+}
+
+/* ---- one instance --------------------------------------------------------------------------------- */
+static void run_instance(sim_t *s) {
+  u32 N = s->N, E = s->E;
+  for (;;) {
+    sched_resolve(s);
+    if (s->phase == PH_DONE) break;
+    if (++s->rounds > 50000000u) { s->meta.flags |= MSIM_FLAG_ROUND_LIMIT; break; }
+
+    /* R0: next event time.  Deliveries, node timers and the scheduler are "normal" events; client
+     * timeouts only fire in a round where nothing else is due. */
+    u32 tn = sched_due(s), tt = INF;
+    for (u32 e = 0; e < E; e++) if (s->has_committed[e] && s->deliver_at[e] < tn) tn = s->deliver_at[e];
+    for (u32 n = 0; n < N; n++) { u32 t = node_timer_time(s, n); if (t < tn) tn = t; }
+    for (u32 c = 0; c < s->CS; c++) if (s->cl[c].busy && s->cl[c].timeout_at < tt) tt = s->cl[c].timeout_at;
+    if (tn == INF && tt == INF) { s->meta.flags |= MSIM_FLAG_ROUND_LIMIT; break; } /* stuck */
+    int timeout_round = tt < tn;
+    u32 T = timeout_round ? tt : tn;
+    if (T < s->T) T = s->T;
+    s->T = T;
+    s->n_out = 0;
+
+    if (timeout_round) {
+      for (u32 c = 0; c < s->CS; c++) if (s->cl[c].busy && s->cl[c].timeout_at <= T) client_timeout(s, c);
+    } else {
+      /* R1: scheduler */
+      if (sched_due(s) <= T) sched_act(s);
+      if (s->phase == PH_DONE) break;
+      /* R2: one input per endpoint, endpoint-index order */
+      for (u32 n = 0; n < N; n++) {
+        if (node_timer_time(s, n) <= T) node_timer(s, n);
+        else if (s->has_committed[n] && s->deliver_at[n] <= T) {
+          qent q = s->committed[n]; s->has_committed[n] = 0;
+          s->st.all_recv++; if (q.src >= N) s->st.clients_recv++; else s->st.servers_recv++; /* journal :recv */
+          node_handle(s, n, &q);
+        }
+      }
+      for (u32 c = 0; c < s->CS; c++) {
+        u32 e = N + c;
+        if (s->has_committed[e] && s->deliver_at[e] <= T) {
+          qent q = s->committed[e]; s->has_committed[e] = 0;
+          s->st.all_recv++; s->st.clients_recv++;
+          client_deliver(s, c, &q);
+        } else if (s->cl[c].mark) client_invoke(s, c);
+      }
+    }
+
+    /* R3: commit sends in canonical order (net.clj:189-221) */
+    for (u32 i = 0; i < s->n_out; i++) {
+      outmsg *m = &s->out[i];
+      u32 id = s->next_msg_id++;
+      int cl = m->src_ep >= N || m->dest_ep >= N;
+      s->st.all_send++; if (cl) s->st.clients_send++; else s->st.servers_send++; /* journal :send before loss */
+      u32 lat = latency_ms(s, id, cl);
+      if (s->loss_on && s->cfg.p_loss_q32 && draw32(s, S_LOSS, id) < s->cfg.p_loss_q32) continue; /* net.clj:214 */
+      qent q = {T + lat * 1000u, id, m->a, m->b, m->src_ep, m->type};
+      inbox_push(s, m->dest_ep, q);
+    }
+
+    /* R4: idle receivers poll: take the min-(deadline,id) envelope even if not due (net.clj:228-229),
+     * drop it if the partition says so (:234), else sleep floor(dt) ms (:236-238). */
+    for (u32 e = 0; e < E; e++) {
+      if (e >= N && !s->cl[e - N].busy) continue; /* clients only poll inside recv! (client.clj:94-95) */
+      inbox_t *b = &s->inbox[e];
+      while (!s->has_committed[e] && b->n) {
+        u32 k = 0;
+        for (u32 i = 1; i < b->n; i++)
+          if (b->v[i].deadline < b->v[k].deadline || (b->v[i].deadline == b->v[k].deadline && b->v[i].id < b->v[k].id)) k = i;
+        qent q = b->v[k]; b->v[k] = b->v[--b->n];
+        if (e < N && q.src < N && bit(s->part[e], q.src)) continue; /* partitioned: dropped, no :recv */
+        s->committed[e] = q; s->has_committed[e] = 1;
+        s->deliver_at[e] = q.deadline <= T ? T : T + ((q.deadline - T) / 1000u) * 1000u;
+      }
+    }
+  }
+  s->meta.n_rounds = s->rounds;
+}
+
+/* ---- public entry points (loaded by tests via ctypes) --------------------------------------------- */
+
+/* Simulates global instance `instance` of `cfg` (already finalized: capacities non-zero).
+ * rows: max_rows entries; payload: max_payload_words words.  Returns 0, or -1 on a bad config. */
+int oracle_run_instance(const msim_config *cfg, uint64_t instance, msim_op *rows, uint32_t *payload,
+                        msim_net_stats *stats, msim_inst_meta *meta) {
+  if (cfg->n_nodes == 0 || cfg->n_nodes > MAXN || cfg->concurrency == 0) return -1;
+  sim_t *s = (sim_t *)calloc(1, sizeof(sim_t));
+  s->cfg = *cfg;
+  s->N = cfg->n_nodes; s->C = cfg->concurrency; s->CS = s->C > s->N ? s->C : s->N; s->E = s->N + s->CS;
+  if (s->E > 255) { free(s); return -1; }
+  s->W = (cfg->max_values + 31) / 32;
+  s->key = inst_key(cfg->seed, instance);
+  s->next_msg_id = 0; /* net.clj:103,197: counter starts at -1 and is pre-incremented: first id 0 */
+  build_topology(s);
+  s->inbox = (inbox_t *)calloc(s->E, sizeof(inbox_t));
+  s->committed = (qent *)calloc(s->E, sizeof(qent));
+  s->has_committed = (u8 *)calloc(s->E, 1);
+  s->deliver_at = (u32 *)calloc(s->E, 4);
+  s->seen = (u32 *)calloc((size_t)s->N * s->W + 1, 4);
+  s->node_msg_id = (u32 *)calloc(s->N, 4);
+  s->nbr_known = (u32 *)calloc(s->N, 4);
+  s->tasks = (tasks_t *)calloc(s->N, sizeof(tasks_t));
+  s->timer_next = (u32 *)malloc(s->N * 4);
+  for (u32 i = 0; i < s->N; i++) s->timer_next[i] = INF;
+  s->cl = (struct cl *)calloc(s->CS, sizeof(struct cl));
+  for (u32 i = 0; i < s->CS; i++) s->cl[i].process = i;
+  s->rows = rows; s->payload = payload;
+  s->phase = PH_INIT;
+  run_instance(s);
+  *stats = s->st; *meta = s->meta;
+  for (u32 e = 0; e < s->E; e++) free(s->inbox[e].v);
+  for (u32 n = 0; n < s->N; n++) free(s->tasks[n].v);
+  for (u32 i = 0; i < s->n_snap; i++) free(s->snap[i]);
+  free(s->snap); free(s->inbox); free(s->committed); free(s->has_committed); free(s->deliver_at); free(s->seen);
+  free(s->node_msg_id); free(s->nbr_known); free(s->tasks); free(s->timer_next); free(s->cl); free(s->out);
+  free(s);
+  return 0;
+}
+
+/* Runs instances [first, first+n) into instance-major output slabs (same layout as the engine). */
+int oracle_run(const msim_config *cfg, uint64_t first, uint32_t n, msim_op *rows, uint32_t *payload,
+               msim_net_stats *stats, msim_inst_meta *meta) {
+  for (uint32_t i = 0; i < n; i++) {
+    int rc = oracle_run_instance(cfg, first + i, rows + (size_t)i * cfg->max_rows,
+                                 payload + (size_t)i * cfg->max_payload_words, stats + i, meta + i);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+/* Exposed so tests can pin the integer samplers directly. */
+uint32_t oracle_neg_ln_q16(uint32_t r) { return neg_ln_q16(r); }
+uint32_t oracle_draw32(uint64_t seed, uint64_t instance, uint32_t stream, uint64_t ctr) {
+  sim_t s; s.key = inst_key(seed, instance); return draw32(&s, stream, ctr);
+}
+/* adjacency masks (MW words per node) for a topology: pins broadcast.clj:40-185 */
+int oracle_topology(uint32_t topology, uint32_t n, uint32_t *adj_out) {
+  if (n == 0 || n > MAXN) return -1;
+  sim_t *s = (sim_t *)calloc(1, sizeof(sim_t));
+  s->N = n; s->cfg.topology = topology; build_topology(s);
+  memcpy(adj_out, s->adj, (size_t)n * MW * 4);
+  free(s);
+  return 0;
+}
