@@ -113,6 +113,9 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
     double lat_s = c->latency_mean_ms / 1000.0;
     if (c->latency_dist != MSIM_LAT_CONSTANT) lat_s *= 3.0;
     c->inbox_capacity = 16 + 2 * deg + (uint32_t)(per_s * lat_s * 1.5);
+    // g-set traffic does not depend on the op rate: every node gets one replicate_full from each of
+    // the other n-1 nodes per 5 s tick (g_set.rb:33-38)
+    if (c->node_program == MSIM_NODE_G_SET) c->inbox_capacity = 16 + 2 * deg;
   }
   return MSIM_OK;
 }

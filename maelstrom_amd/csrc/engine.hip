@@ -1,0 +1,912 @@
+// engine.hip — the ensemble simulation kernel and the host runtime behind include/maelsim.h.
+//
+// HOT PATH: for every test instance, the message queue with simulated latency / loss /
+// partitions (net.clj:189-247), node execution (process.clj:136-166 collapsed to "a node consumes one
+// message at a time"), the sync RPC clients (client.clj:66-172), the generator/nemesis schedule
+// (core.clj:67-80) and the node programs' state-transition functions (rows a13-a15).
+//
+// MI355X mapping:
+//   * one wavefront (one 64-thread workgroup) simulates one cluster; lane e = endpoint e
+//     (lanes [0,N) = nodes n0..n{N-1}, lanes [N,N+CS) = client worker slots);
+//   * node sets (bitmaps) and the per-endpoint in-flight message queues live in LDS; every endpoint's
+//     queue is written only by its own lane ("receiver-side pull": each round the wave walks the
+//     senders with v_readlane and every addressed lane appends to its own queue) — no LDS atomics;
+//   * the per-round "next event time" is a DPP min-reduction, message ids / history row indices come
+//     from a DPP prefix sum + ballots, so ids and row order are canonical (endpoint order) and the
+//     result is bit-identical to the sequential CPU oracle;
+//   * history rows are staged in LDS and appended to HBM 64 rows (1 KiB) at a time, one 16-B store per
+//     lane; read results (bitmaps) are copied LDS->HBM by the whole wave, 256 B per instruction.
+//   No MFMA: this is integer/indexing work.  No CUDA/hipify/Triton layers.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "engine_internal.h"
+#include "log2_table.h"
+
+#define INF 0xFFFFFFFFu
+#define STAGE_ROWS 128u
+#define CLIENT_INBOX_CAP 4u
+#define ROUND_LIMIT 50000000u
+
+// message types (doc/protocol.md, doc/workloads.md)
+enum { M_INIT = 1, M_INIT_OK, M_TOPOLOGY, M_TOPOLOGY_OK, M_ECHO, M_ECHO_OK, M_BROADCAST, M_BROADCAST_OK,
+       M_READ, M_READ_OK, M_ADD, M_ADD_OK, M_REPLICATE };
+// RNG streams
+enum { S_STAGGER = 1, S_MIX = 2, S_PROC = 3, S_LATENCY = 4, S_LOSS = 5, S_ECHO = 6,
+       S_NEM_STAGGER = 7, S_NEM_SPEC = 8, S_NEM_SHUFFLE = 9, S_NEM_PICK = 10 };
+enum { PH_INIT, PH_INIT_WAIT, PH_TOPO, PH_TOPO_WAIT, PH_MAIN_START, PH_MAIN, PH_DRAIN, PH_NEM_FINAL,
+       PH_SLEEP, PH_FINAL, PH_FINAL_WAIT, PH_DONE };
+enum { K_NONE = 0, K_INIT, K_TOPO, K_OP };
+
+struct KParams {
+  msim_config cfg;
+  u64 first_instance;
+  msim_op *rows;
+  u32 *payload;
+  msim_net_stats *stats;
+  msim_inst_meta *meta;
+  u32 *scratch;
+  u64 scratch_words;  // per instance
+  u32 N, C, CS, W;
+  u32 cap_node;
+  u32 off_inbox, off_seen, off_misc;  // LDS byte offsets
+  u32 gen_period2_us, nem_period2_us;
+};
+
+__constant__ u32 d_log2_q24[257];
+
+// ---- RNG (counter-based) ---------------------------------------------------------
+__device__ __host__ __forceinline__ u64 mix64(u64 z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ u32 draw32(u64 key, u32 stream, u64 ctr) {
+  const u64 x = ((u64)stream << 48) | ctr;
+  return (u32)(mix64(key + x * 0x9E3779B97F4A7C15ull) >> 32);
+}
+__device__ __forceinline__ u32 scale32(u32 r, u32 n) { return __umulhi(r, n); }
+
+// -ln(u), u = (r+1)/2^32, Q16, integer only
+__device__ __forceinline__ u32 neg_ln_q16(u32 r) {
+  if (r == 0xFFFFFFFFu) return 0;
+  const u32 v = r + 1;
+  const u32 e = 31 - __clz(v);
+  const u32 m = v << (31 - e);
+  const u32 idx = (m >> 23) & 0xFF;
+  const u32 f = (m >> 7) & 0xFFFF;
+  const u32 l0 = d_log2_q24[idx], l1 = d_log2_q24[idx + 1];
+  const u32 lg = (e << 24) + l0 + (u32)(((u64)(l1 - l0) * f) >> 16);
+  const u32 d = (32u << 24) - lg;
+  return (u32)(((u64)d * 2977044472ull) >> 40);
+}
+
+// ---- wave primitives (64 lanes; DPP on gfx950) ---------------------------------------------------
+template <int CTRL, int ROW_MASK, int BANK_MASK, bool BOUND>
+__device__ __forceinline__ u32 dpp_mov(u32 old, u32 src) {
+  return (u32)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, ROW_MASK, BANK_MASK, BOUND);
+}
+__device__ __forceinline__ u32 rdlane(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
+
+// min over the 64 lanes, result uniform
+__device__ __forceinline__ u32 wave_min(u32 v) {
+  v = min(v, dpp_mov<0xB1, 0xF, 0xF, false>(v, v));   // quad_perm [1,0,3,2]
+  v = min(v, dpp_mov<0x4E, 0xF, 0xF, false>(v, v));   // quad_perm [2,3,0,1]
+  v = min(v, dpp_mov<0x141, 0xF, 0xF, false>(v, v));  // row_half_mirror
+  v = min(v, dpp_mov<0x140, 0xF, 0xF, false>(v, v));  // row_mirror
+  return min(min(rdlane(v, 0), rdlane(v, 16)), min(rdlane(v, 32), rdlane(v, 48)));
+}
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ u32 wave_incl_scan(u32 v) {
+  v += dpp_mov<0x111, 0xF, 0xF, true>(0, v);   // row_shr:1
+  v += dpp_mov<0x112, 0xF, 0xF, true>(0, v);   // row_shr:2
+  v += dpp_mov<0x114, 0xF, 0xF, true>(0, v);   // row_shr:4
+  v += dpp_mov<0x118, 0xF, 0xF, true>(0, v);   // row_shr:8
+  v += dpp_mov<0x142, 0xA, 0xF, false>(0, v);  // row_bcast:15 -> rows 1,3
+  v += dpp_mov<0x143, 0xC, 0xF, false>(0, v);  // row_bcast:31 -> rows 2,3
+  return v;
+}
+__device__ __forceinline__ u32 wave_sum(u32 v) { return rdlane(wave_incl_scan(v), 63); }
+
+// Reference (shuffle) versions, used only by the self-test to validate the DPP encodings on hardware.
+__device__ u32 wave_min_ref(u32 v) { for (int o = 32; o; o >>= 1) v = min(v, (u32)__shfl_xor((int)v, o)); return v; }
+__device__ u32 wave_incl_scan_ref(u32 v) {
+  const u32 lane = threadIdx.x & 63;
+  for (int o = 1; o < 64; o <<= 1) { u32 t = (u32)__shfl_up((int)v, o); if (lane >= (u32)o) v += t; }
+  return v;
+}
+__global__ void wave_selftest_kernel(const u32 *in, u32 *out) {
+  const u32 lane = threadIdx.x;
+  const u32 v = in[blockIdx.x * 64 + lane];
+  u32 bad = 0;
+  bad |= wave_min(v) != wave_min_ref(v);
+  bad |= wave_incl_scan(v & 0xFFFF) != wave_incl_scan_ref(v & 0xFFFF);
+  bad |= wave_sum(v & 0xFF) != rdlane(wave_incl_scan_ref(v & 0xFF), 63);
+  out[blockIdx.x * 64 + lane] = bad;
+}
+
+// ---- topologies (broadcast.clj:40-185): adjacency mask of node a, N <= 32 -------------------------
+__device__ __forceinline__ u32 topo_adj(u32 topology, u32 n, u32 a) {
+  u32 m = 0;
+  switch (topology) {
+    case MSIM_TOPO_GRID: {
+      u32 side = 1; while (side * side < n) side++;
+      const u32 i = a / side, j = a % side;
+      if (j + 1 < side && a + 1 < n) m |= 1u << (a + 1);
+      if (j > 0) m |= 1u << (a - 1);
+      if (a + side < n) m |= 1u << (a + side);
+      if (i > 0) m |= 1u << (a - side);
+    } break;
+    case MSIM_TOPO_LINE:
+      if (a + 1 < n) m |= 1u << (a + 1);
+      if (a > 0) m |= 1u << (a - 1);
+      break;
+    case MSIM_TOPO_TOTAL: m = ((n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1)) & ~(1u << a)); break;
+    default: {
+      const u32 b = topology == MSIM_TOPO_TREE2 ? 2 : topology == MSIM_TOPO_TREE3 ? 3 : 4;
+      if (a > 0) m |= 1u << ((a - 1) / b);
+      for (u32 c = 1; c <= b; c++) if (b * a + c < n) m |= 1u << (b * a + c);
+    }
+  }
+  return m;
+}
+
+// =====================================================================================================
+// The simulation kernel: one wavefront = one cluster.  PROG = node program (MSIM_NODE_*).
+// Follows DESIGN.md §2 step by step; the CPU oracle implements the same text independently.
+// =====================================================================================================
+template <int PROG>
+__global__ void __launch_bounds__(64) sim_kernel(const KParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint4 *const stage = reinterpret_cast<uint4 *>(smem);
+  uint4 *const inbox = reinterpret_cast<uint4 *>(smem + p.off_inbox);
+  u32 *const seen = reinterpret_cast<u32 *>(smem + p.off_seen);
+  u32 *const misc = reinterpret_cast<u32 *>(smem + p.off_misc);
+
+  constexpr bool IS_BCAST = PROG >= MSIM_NODE_BCAST_FF && PROG <= MSIM_NODE_BCAST_RPC_ALL;
+  constexpr bool IS_RPC = PROG == MSIM_NODE_BCAST_ACK_RETRY || PROG == MSIM_NODE_BCAST_RPC_ALL;
+  constexpr bool IS_ACK = PROG == MSIM_NODE_BCAST_ACK_RETRY;
+  constexpr bool IS_GSET = PROG == MSIM_NODE_G_SET;
+  constexpr bool IS_ECHO = PROG == MSIM_NODE_ECHO;
+  constexpr bool HAS_FINAL = IS_BCAST || IS_GSET;
+  constexpr bool REP_FIRST = IS_ACK;  // ack variant replies before it gossips
+
+  const u32 lane = threadIdx.x;
+  const u32 inst = blockIdx.x;
+  const u32 N = p.N, C = p.C, CS = p.CS, W = p.W;
+  const bool is_node = lane < N;
+  const bool is_client = lane >= N && lane < N + CS;
+  const u32 slot = lane - N;
+  const bool is_worker = is_client && slot < C;
+  const u64 key = mix64(p.cfg.seed + 0x9E3779B97F4A7C15ull * (p.first_instance + inst + 1));
+  const u64 lt_mask = (1ull << lane) - 1;
+  const u64 worker_mask = ((C >= 64 ? ~0ull : ((1ull << C) - 1)) << N);
+  const u32 all_nodes = N >= 32 ? 0xFFFFFFFFu : ((1u << N) - 1);
+  const u32 max_values = p.cfg.max_values, max_rows = p.cfg.max_rows, max_pay = p.cfg.max_payload_words;
+  const u32 p_loss = p.cfg.p_loss_q32, lat_mean = p.cfg.latency_mean_ms, lat_dist = p.cfg.latency_dist;
+  const bool nem_on = (p.cfg.nemesis_mask & MSIM_NEMESIS_PARTITION) != 0;
+  const u32 rate = p.cfg.rate_mhz;
+
+  msim_op *const g_rows = p.rows + (size_t)inst * max_rows;
+  u32 *const g_pay = p.payload + (size_t)inst * max_pay;
+  u32 *const g_scr = p.scratch + (size_t)inst * p.scratch_words;
+  // ack/retry scratch: unacked[N][V], fifo[N][V][2]; g-set scratch: snapshots[tick][N][W]
+  u32 *const g_unacked = g_scr + (size_t)lane * max_values;
+  u32 *const g_fifo = g_scr + (size_t)N * max_values + (size_t)lane * max_values * 2;
+
+  const u32 my_cap = is_node ? p.cap_node : CLIENT_INBOX_CAP;
+  uint4 *const my_inbox = inbox + (is_node ? lane * p.cap_node : (is_client ? N * p.cap_node + slot * CLIENT_INBOX_CAP : 0));
+  u32 *const my_seen = seen + (is_node ? lane : 0) * W;
+
+  for (u32 i = lane; i < N * W; i += 64) seen[i] = 0;
+  if (IS_ACK) { if (is_node) for (u32 v = 0; v < max_values; v++) g_unacked[v] = 0; }
+  __syncthreads();
+
+  const u32 adj = is_node ? topo_adj(p.cfg.topology, N, lane) : 0;
+
+  // ---- per-lane endpoint state ----
+  bool has_c = false; u32 deliver_at = 0; uint4 cm = make_uint4(0, 0, 0, 0);
+  u32 in_n = 0;
+  u32 node_msgid = 0, timer_next = INF, tick = 0, part = 0;
+  u32 fifo_head = 0, fifo_tail = 0, retry_time = INF;
+  bool busy = false, mark = false; u32 kind = K_NONE;
+  u32 want = 0, timeout_at = 0, next_msg_id = 0, c_f = 0, c_value = 0, process = slot, c_final = 0;
+  u32 m_f = 0, m_value = 0, m_final = 0;
+  u32 s_send_cl = 0, s_send_sv = 0, s_recv_cl = 0, s_recv_sv = 0, my_flags = 0;
+  // ---- wave-uniform state ----
+  u32 T = 0, phase = PH_INIT, cutoff = 0, gen_next = 0, gen_k = 0, next_value = 0, nem_next = 0, nem_j = 0;
+  u32 sleep_until = 0, loss_on = 0, next_id = 0, n_rows = 0, n_payload = 0, flags = 0, rounds = 0;
+
+  for (;;) {
+    const u64 busy_mask = __ballot(is_client && busy);
+    const bool gen_live = rate > 0 && gen_next < cutoff;
+    const bool nem_live = nem_on && nem_next < cutoff;
+
+    // ---- time-free phase transitions (oracle: sched_resolve) ----
+    for (bool again = true; again;) {
+      again = false;
+      switch (phase) {
+        case PH_INIT_WAIT: if (!busy_mask) { phase = IS_BCAST ? PH_TOPO : PH_MAIN_START; again = true; } break;
+        case PH_TOPO_WAIT: if (!busy_mask) { phase = PH_MAIN_START; again = true; } break;
+        case PH_MAIN_START:
+          cutoff = T + p.cfg.time_limit_ms * 1000u; gen_next = T; nem_next = T;
+          next_msg_id = 0; loss_on = 1; phase = PH_MAIN; again = true; break;
+        case PH_MAIN: {
+          const bool gl = rate > 0 && gen_next < cutoff, nl = nem_on && nem_next < cutoff;
+          if (gl || nl) break;
+          if (rate == 0 && T < cutoff) break;
+          phase = PH_DRAIN; again = true;
+        } break;
+        case PH_DRAIN:
+          if (busy_mask & worker_mask) break;
+          phase = (nem_on && HAS_FINAL) ? PH_NEM_FINAL : HAS_FINAL ? PH_SLEEP : PH_DONE;
+          if (phase == PH_SLEEP) sleep_until = T + p.cfg.quiesce_ms * 1000u;
+          again = true; break;
+        case PH_FINAL_WAIT: if (!(busy_mask & worker_mask)) { phase = PH_DONE; again = true; } break;
+        default: break;
+      }
+    }
+    if (phase == PH_DONE) break;
+    if (++rounds > ROUND_LIMIT) { flags |= MSIM_FLAG_ROUND_LIMIT; break; }
+
+    // ---- R0: next event time ----
+    const bool gen_live2 = rate > 0 && gen_next < cutoff;
+    const bool nem_live2 = nem_on && nem_next < cutoff;
+    const u64 free_mask = worker_mask & ~busy_mask;
+    u32 due = INF;
+    switch (phase) {
+      case PH_INIT: case PH_TOPO: case PH_NEM_FINAL: case PH_FINAL: due = T; break;
+      case PH_SLEEP: due = sleep_until; break;
+      case PH_MAIN:
+        if (nem_live2) due = max(nem_next, T);
+        if (gen_live2 && free_mask) due = min(due, max(gen_next, T));
+        if (rate == 0 && !nem_live2) due = min(due, cutoff);
+        break;
+      default: break;
+    }
+    u32 k = INF;
+    if (has_c) k = deliver_at * 2;
+    if (is_node) { const u32 t = min(timer_next, retry_time); if (t != INF) k = min(k, t * 2); }
+    if (is_client && busy) k = min(k, timeout_at * 2 + 1);
+    u32 km = wave_min(k);
+    if (due != INF) km = min(km, due * 2);
+    if (km == INF) { flags |= MSIM_FLAG_ROUND_LIMIT; break; }  // stuck
+    const bool timeout_round = (km & 1) != 0;
+    T = max(T, km >> 1);
+    (void)gen_live; (void)nem_live;
+
+    // ---- R1: scheduler (generator interpreter, nemesis) — wave-uniform ----
+    u32 nem_rows = 0, nem_f = 0, nem_v1 = 0, nem_v2 = 0, nem_len2 = 0;
+    if (!timeout_round && due <= T) {
+      switch (phase) {
+        case PH_INIT: if (is_client && slot < N) { mark = true; kind = K_INIT; } phase = PH_INIT_WAIT; break;
+        case PH_TOPO: if (is_client && slot < N) { mark = true; kind = K_TOPO; } phase = PH_TOPO_WAIT; break;
+        case PH_MAIN: {
+          if (nem_live2 && nem_next <= T) {
+            const u32 j = nem_j++;
+            nem_rows = 2;
+            if ((j & 1) == 0) {  // :start-partition (jepsen.nemesis.combined partition-package, restated)
+              const u32 spec = scale32(draw32(key, S_NEM_SPEC, j), 4);
+              // shuffle (Fisher-Yates) in LDS by lane 0; every node lane then derives its own grudge row
+              if (lane < N) misc[lane] = lane;
+              __syncthreads();
+              if (lane == 0 && spec != MSIM_SPEC_ONE) {
+                for (u32 i = N - 1; i >= 1; i--) {
+                  const u32 kk = scale32(draw32(key, S_NEM_SHUFFLE, ((u64)j << 16) | i), i + 1);
+                  const u32 t = misc[i]; misc[i] = misc[kk]; misc[kk] = t;
+                }
+              }
+              __syncthreads();
+              u32 my_part = 0;
+              if (is_node) {
+                if (spec == MSIM_SPEC_ONE) {
+                  const u32 loner = scale32(draw32(key, S_NEM_PICK, j), N);
+                  my_part = lane == loner ? (all_nodes & ~(1u << loner)) : (1u << loner);
+                } else if (spec == MSIM_SPEC_MAJORITY || spec == MSIM_SPEC_MINORITY_THIRD) {
+                  const u32 cnt = spec == MSIM_SPEC_MAJORITY ? N / 2 : (N - 1) / 3;
+                  u32 comp = 0;
+                  for (u32 i = 0; i < cnt; i++) comp |= 1u << misc[i];
+                  my_part = ((comp >> lane) & 1) ? (all_nodes & ~comp) : comp;
+                } else {  // majorities-ring
+                  const u32 m = N / 2 + 1;
+                  u32 pos = 0;
+                  for (u32 i = 0; i < N; i++) if (misc[i] == lane) pos = i;
+                  const u32 i0 = (pos + N - (m / 2) % N) % N;
+                  u32 vis = 0;
+                  for (u32 kk = 0; kk < m; kk++) vis |= 1u << misc[(i0 + kk) % N];
+                  my_part = all_nodes & ~vis;
+                }
+              }
+              part |= my_part;
+              const u32 words = N * MSIM_MASK_WORDS;
+              u32 off = 0;
+              if (n_payload + words > max_pay) flags |= MSIM_FLAG_PAYLOAD_OVERFLOW;
+              else {
+                off = n_payload; n_payload += words;
+                if (is_node) { g_pay[off + lane * 4] = part; g_pay[off + lane * 4 + 1] = 0; g_pay[off + lane * 4 + 2] = 0; g_pay[off + lane * 4 + 3] = 0; }
+              }
+              nem_f = MSIM_F_START_PARTITION; nem_v1 = spec; nem_v2 = off; nem_len2 = words;
+            } else {  // :stop-partition -> heal! (net.clj:112-113)
+              part = 0;
+              nem_f = MSIM_F_STOP_PARTITION; nem_v1 = MSIM_NO_VALUE; nem_v2 = MSIM_NO_VALUE; nem_len2 = 0;
+            }
+            nem_next = T + __umulhi(draw32(key, S_NEM_STAGGER, j), p.nem_period2_us);
+          }
+          if (gen_live2 && gen_next <= T && free_mask) {
+            const u32 nfree = __popcll(free_mask);
+            const u32 kk = gen_k++;
+            const u32 pick = scale32(draw32(key, S_PROC, kk), nfree);
+            const bool sel = is_worker && !busy && (u32)__popcll(free_mask & lt_mask) == pick;
+            u32 f, val = MSIM_NO_VALUE;
+            bool ok = true;
+            if (IS_ECHO) { f = MSIM_F_ECHO; val = scale32(draw32(key, S_ECHO, kk), 128); }
+            else if (draw32(key, S_MIX, kk) >> 31) f = MSIM_F_READ;
+            else {
+              f = IS_BCAST ? MSIM_F_BROADCAST : MSIM_F_ADD;
+              if (next_value >= max_values) { flags |= MSIM_FLAG_VALUES_OVERFLOW; ok = false; }
+              else val = next_value++;
+            }
+            if (!ok) { phase = PH_DONE; break; }
+            if (sel) { mark = true; kind = K_OP; m_f = f; m_value = val; m_final = 0; }
+            gen_next = T + __umulhi(draw32(key, S_STAGGER, kk), p.gen_period2_us);
+          }
+        } break;
+        case PH_NEM_FINAL:
+          part = 0; nem_rows = 2; nem_f = MSIM_F_STOP_PARTITION; nem_v1 = MSIM_NO_VALUE; nem_v2 = MSIM_NO_VALUE;
+          phase = PH_SLEEP; sleep_until = T + p.cfg.quiesce_ms * 1000u; break;
+        case PH_SLEEP:
+          if (T < sleep_until) break;
+          phase = PH_FINAL;
+          [[fallthrough]];
+        case PH_FINAL:
+          if (is_worker) { mark = true; kind = K_OP; m_f = MSIM_F_READ; m_value = MSIM_NO_VALUE; m_final = IS_BCAST ? 1 : 0; }
+          phase = PH_FINAL_WAIT; break;
+        default: break;
+      }
+      if (phase == PH_DONE) break;
+    }
+
+    // ---- R2: one input per endpoint ----
+    u32 fan_mask = 0, fan_type = 0, fan_a = 0, fan_b0 = 0;
+    bool rep = false; u32 rep_dest = 0, rep_type = 0, rep_a = 0, rep_b = 0;
+    bool row = false; u32 row_packed = 0, row_value = 0, row_len = 0;
+    bool rd = false;
+
+    // completion of a client op (oracle: client_complete)
+    auto complete = [&](u32 type, u32 err, u32 value, u32 len) {
+      busy = false;
+      if (kind != K_OP) { if (type != MSIM_T_OK) my_flags |= MSIM_FLAG_ROUND_LIMIT; return; }
+      row = true; row_packed = type | (c_f << 2) | (err << 7) | (c_final << 11) | (process << 12);
+      row_value = value; row_len = len;
+      if (type == MSIM_T_INFO) { process += C; next_msg_id = 0; in_n = 0; }
+    };
+
+    if (timeout_round) {
+      if (is_client && busy && timeout_at <= T) {  // client.clj:96-103 + :158-162
+        const bool idem = IS_BCAST && c_f == MSIM_F_READ;
+        complete(idem ? MSIM_T_FAIL : MSIM_T_INFO, MSIM_ERR_NET_TIMEOUT, c_f == MSIM_F_READ ? MSIM_NO_VALUE : c_value, 0);
+      }
+    } else if (is_node) {
+      if (IS_GSET && timer_next <= T) {  // g_set.rb:33-38
+        timer_next = T + 5000000u;
+        u32 *snap = g_scr + ((size_t)tick * N + lane) * W;
+        for (u32 w = 0; w < W; w++) snap[w] = my_seen[w];
+        fan_mask = all_nodes & ~(1u << lane); fan_type = M_REPLICATE; fan_a = tick; tick++;
+      } else if (IS_ACK && retry_time <= T) {  // gossip thread wakes (02-performance.md:421-438)
+        const u32 slot_i = (fifo_head % max_values) * 2;
+        const u32 v = g_fifo[slot_i];
+        fifo_head++;
+        const u32 un = g_unacked[v];
+        if (un) {
+          fan_mask = un; fan_type = M_BROADCAST; fan_a = v; fan_b0 = node_msgid + 1; node_msgid += __popc(un);
+          const u32 ts = (fifo_tail % max_values) * 2;
+          g_fifo[ts] = v; g_fifo[ts + 1] = T + 1000000u; fifo_tail++;
+        }
+        retry_time = fifo_head < fifo_tail ? g_fifo[(fifo_head % max_values) * 2 + 1] : INF;
+      } else if (has_c && deliver_at <= T) {
+        const uint4 q = cm; has_c = false;
+        const u32 qsrc = q.w >> 24, qb = q.w & 0xFFFFFFu, qtype = q.y & 0xFFu, qa = q.z;
+        if (qsrc >= N) s_recv_cl++; else s_recv_sv++;  // journal :recv (net.clj:244)
+        switch (qtype) {
+          case M_INIT:
+            if (IS_GSET) timer_next = T;
+            rep = true; rep_dest = qsrc; rep_type = M_INIT_OK; rep_b = qb; break;
+          case M_TOPOLOGY: rep = true; rep_dest = qsrc; rep_type = M_TOPOLOGY_OK; rep_b = qb; break;
+          case M_ECHO: rep = true; rep_dest = qsrc; rep_type = M_ECHO_OK; rep_a = qa; rep_b = qb; break;
+          case M_READ: rd = true; rep = true; rep_dest = qsrc; rep_type = M_READ_OK; rep_b = qb; break;
+          case M_ADD: my_seen[qa >> 5] |= 1u << (qa & 31); rep = true; rep_dest = qsrc; rep_type = M_ADD_OK; rep_a = qa; rep_b = qb; break;
+          case M_REPLICATE: {
+            const u32 *snap = g_scr + ((size_t)qa * N + qsrc) * W;
+            for (u32 w = 0; w < W; w++) my_seen[w] |= snap[w];
+          } break;
+          case M_BROADCAST: {
+            const u32 v = qa, bitm = 1u << (v & 31);
+            const u32 wv = my_seen[v >> 5];
+            if (!(wv & bitm)) {
+              my_seen[v >> 5] = wv | bitm;
+              u32 tg = PROG == MSIM_NODE_BCAST_RPC_ALL ? (all_nodes & ~(1u << lane)) : adj;
+              if (PROG != MSIM_NODE_BCAST_FF_ECHOBACK && qsrc < N) tg &= ~(1u << qsrc);
+              fan_mask = tg; fan_type = M_BROADCAST; fan_a = v;
+              if (IS_RPC) { fan_b0 = node_msgid + 1; node_msgid += __popc(tg); }
+              if (IS_ACK && tg) {
+                g_unacked[v] = tg;
+                const u32 ts = (fifo_tail % max_values) * 2;
+                g_fifo[ts] = v; g_fifo[ts + 1] = T + 1000000u;
+                if (fifo_head == fifo_tail) retry_time = T + 1000000u;
+                fifo_tail++;
+              }
+            }
+            if (qb != 0) { rep = true; rep_dest = qsrc; rep_type = M_BROADCAST_OK; rep_a = v; rep_b = qb; }
+          } break;
+          case M_BROADCAST_OK: if (IS_ACK) g_unacked[qa] &= ~(1u << qsrc); break;
+          default: break;
+        }
+      }
+    } else if (is_client) {
+      if (has_c && deliver_at <= T) {
+        const uint4 q = cm; has_c = false;
+        s_recv_cl++;
+        const u32 qb = q.w & 0xFFFFFFu, qtype = q.y & 0xFFu, qa = q.z;
+        if (busy && qb == want) {  // else: stale reply (client.clj:105-107)
+          if (qtype == M_READ_OK) complete(MSIM_T_OK, 0, qa & 0xFFFFFFu, qa >> 24);
+          else if (qtype == M_ECHO_OK) complete(MSIM_T_OK, 0, qa, 0);
+          else complete(MSIM_T_OK, 0, c_value, 0);
+        }
+      } else if (mark) {  // oracle: client_invoke
+        mark = false; busy = true;
+        u32 dest, type, a = 0;
+        if (kind == K_INIT) { dest = slot; type = M_INIT; next_msg_id = 0; }
+        else if (kind == K_TOPO) { dest = slot; type = M_TOPOLOGY; next_msg_id = 0; }
+        else {
+          c_f = m_f; c_value = m_value; c_final = m_final;
+          dest = process % N;
+          row = true; row_packed = MSIM_T_INVOKE | (c_f << 2) | (c_final << 11) | (process << 12); row_value = c_value; row_len = 0;
+          switch (c_f) {
+            case MSIM_F_ECHO: type = M_ECHO; a = c_value; break;
+            case MSIM_F_BROADCAST: type = M_BROADCAST; a = c_value; break;
+            case MSIM_F_ADD: type = M_ADD; a = c_value; break;
+            default: type = M_READ; break;
+          }
+        }
+        want = ++next_msg_id;
+        timeout_at = T + (kind == K_OP ? p.cfg.client_timeout_ms : 10000u) * 1000u;
+        rep = true; rep_dest = dest; rep_type = type; rep_a = a; rep_b = want;
+      }
+    }
+
+    // ---- history rows: canonical order = nemesis rows, then client slots ascending ----
+    {
+      const u64 rmask = __ballot(row);
+      const u32 nr = nem_rows + (u32)__popcll(rmask);
+      if (nr) {
+        if (n_rows + nr > max_rows) { flags |= MSIM_FLAG_ROWS_OVERFLOW; break; }
+        const u32 tlo = (u32)((u64)T * 1000ull), thi = (u32)(((u64)T * 1000ull) >> 32);
+        if (nem_rows && lane == 0) {
+          const u32 pk = MSIM_T_INFO | (nem_f << 2) | (MSIM_PROCESS_NEMESIS << 12);
+          stage[n_rows % STAGE_ROWS] = make_uint4(tlo, thi, pk, nem_v1);
+          stage[(n_rows + 1) % STAGE_ROWS] = make_uint4(tlo, thi | (nem_len2 << 16), pk, nem_v2);
+        }
+        if (row) {
+          const u32 idx = n_rows + nem_rows + (u32)__popcll(rmask & lt_mask);
+          stage[idx % STAGE_ROWS] = make_uint4(tlo, thi | (row_len << 16), row_packed, row_value);
+        }
+        const u32 new_n = n_rows + nr;
+        if ((new_n >> 6) != (n_rows >> 6)) {  // a 64-row block completed: coalesced 1 KiB append to HBM
+          __syncthreads();
+          for (u32 blk = n_rows >> 6; blk < (new_n >> 6); blk++) {
+            const u32 gi = blk * 64 + lane;
+            if (gi < max_rows) reinterpret_cast<uint4 *>(g_rows)[gi] = stage[gi % STAGE_ROWS];
+          }
+          __syncthreads();
+        }
+        n_rows = new_n;
+      }
+    }
+
+    // ---- read results: the whole wave copies the node's set LDS -> HBM payload ----
+    {
+      u64 rdmask = __ballot(rd);
+      if (rdmask) {
+        __syncthreads();
+        const u32 words = (next_value + 31) >> 5;
+        while (rdmask) {
+          const u32 r = (u32)__builtin_ctzll(rdmask); rdmask &= rdmask - 1;
+          u32 off = 0;
+          if (n_payload + words > max_pay) flags |= MSIM_FLAG_PAYLOAD_OVERFLOW;
+          else {
+            off = n_payload; n_payload += words;
+            for (u32 w = lane; w < words; w += 64) g_pay[off + w] = seen[r * W + w];
+          }
+          if (lane == r) rep_a = off | (words << 24);
+        }
+      }
+    }
+
+    // ---- R3: commit sends (net.clj:189-221).  ids: endpoint order, then emission order ----
+    {
+      const u32 fan_cnt = __popc(fan_mask);
+      const u32 cnt = fan_cnt + (rep ? 1u : 0u);
+      u64 senders = __ballot(cnt > 0);
+      if (senders) {
+        const u32 incl = wave_incl_scan(cnt);
+        const u32 excl = incl - cnt;
+        const u32 total = rdlane(incl, 63);
+        if (is_node) { s_send_sv += fan_cnt; if (rep) { if (rep_dest >= N) s_send_cl++; else s_send_sv++; } }
+        else if (rep) s_send_cl++;
+        const u32 rep_pack = rep ? (1u | (rep_dest << 8) | (rep_type << 16)) : 0u;
+
+        auto push = [&](u32 id, u32 type, u32 a, u32 b, u32 src) {
+          u32 lat = 0;
+          if (src < N && is_node) {  // latency only between servers (net.clj:178-187)
+            if (lat_dist == MSIM_LAT_CONSTANT) lat = lat_mean;
+            else if (lat_dist == MSIM_LAT_UNIFORM) lat = scale32(draw32(key, S_LATENCY, id), 2 * lat_mean);
+            else lat = (u32)(((u64)lat_mean * neg_ln_q16(draw32(key, S_LATENCY, id))) >> 16);
+          }
+          if (loss_on && p_loss && draw32(key, S_LOSS, id) < p_loss) return;  // net.clj:214
+          if (in_n >= my_cap) { my_flags |= MSIM_FLAG_INBOX_OVERFLOW; return; }
+          my_inbox[in_n++] = make_uint4(T + lat * 1000u, (id << 8) | type, a, b | (src << 24));
+        };
+
+        while (senders) {
+          const u32 s = (u32)__builtin_ctzll(senders); senders &= senders - 1;
+          const u32 f_mask = rdlane(fan_mask, s);
+          const u32 base = next_id + rdlane(excl, s);
+          const u32 r_pack = rdlane(rep_pack, s);
+          const u32 f_cnt = __popc(f_mask);
+          if (f_mask) {
+            const u32 f_type = rdlane(fan_type, s), f_a = rdlane(fan_a, s), f_b0 = rdlane(fan_b0, s);
+            if (lane < 32 && ((f_mask >> lane) & 1)) {
+              const u32 rank = __popc(f_mask & ((1u << lane) - 1));
+              const u32 kk = rank + ((REP_FIRST && (r_pack & 1)) ? 1u : 0u);
+              push(base + kk, f_type, f_a, f_b0 ? f_b0 + rank : 0u, s);
+            }
+          }
+          if (r_pack & 1) {
+            const u32 r_a = rdlane(rep_a, s), r_b = rdlane(rep_b, s);
+            if (lane == ((r_pack >> 8) & 0xFF)) push(base + (REP_FIRST ? 0u : f_cnt), (r_pack >> 16) & 0xFF, r_a, r_b, s);
+          }
+        }
+        next_id += total;
+      }
+    }
+
+    // ---- R4: idle receivers poll (net.clj:223-247) ----
+    {
+      const bool elig = is_node || (is_client && busy);
+      while (elig && !has_c && in_n > 0) {
+        u32 best = 0;
+        uint2 bk = *reinterpret_cast<const uint2 *>(&my_inbox[0]);
+        for (u32 i = 1; i < in_n; i++) {
+          const uint2 kk = *reinterpret_cast<const uint2 *>(&my_inbox[i]);
+          if (kk.x < bk.x || (kk.x == bk.x && kk.y < bk.y)) { bk = kk; best = i; }
+        }
+        const uint4 e = my_inbox[best];
+        in_n--;
+        if (best != in_n) my_inbox[best] = my_inbox[in_n];
+        const u32 src = e.w >> 24;
+        if (is_node && src < N && ((part >> src) & 1)) continue;  // partitioned: dropped, no :recv (:234)
+        cm = e; has_c = true;
+        deliver_at = e.x <= T ? T : T + ((e.x - T) / 1000u) * 1000u;  // (Thread/sleep (long dt)) :236-238
+      }
+    }
+  }
+
+  // ---- epilogue: flush the partial row block, reduce counters, write stats + meta ----
+  __syncthreads();
+  {
+    const u32 blk = n_rows >> 6;
+    const u32 gi = blk * 64 + lane;
+    if (gi < n_rows) reinterpret_cast<uint4 *>(g_rows)[gi] = stage[gi % STAGE_ROWS];
+  }
+  const u32 t_send_cl = wave_sum(s_send_cl), t_send_sv = wave_sum(s_send_sv);
+  const u32 t_recv_cl = wave_sum(s_recv_cl), t_recv_sv = wave_sum(s_recv_sv);
+  for (u32 b = 1; b <= MSIM_FLAG_ROUND_LIMIT; b <<= 1) if (__ballot((my_flags & b) != 0)) flags |= b;
+  if (lane == 0) {
+    msim_net_stats st;
+    st.all_send = (u64)t_send_cl + t_send_sv; st.all_recv = (u64)t_recv_cl + t_recv_sv;
+    st.clients_send = t_send_cl; st.clients_recv = t_recv_cl;
+    st.servers_send = t_send_sv; st.servers_recv = t_recv_sv;
+    p.stats[inst] = st;
+    msim_inst_meta m; m.n_rows = n_rows; m.n_payload_words = n_payload; m.flags = flags; m.n_rounds = rounds;
+    p.meta[inst] = m;
+  }
+}
+
+// =====================================================================================================
+// Host runtime
+// =====================================================================================================
+static void set_err(char *err, size_t n, const char *msg) { if (err && n) std::snprintf(err, n, "%s", msg); }
+
+extern "C" int msim_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+static void free_buffers(msim_ctx *c) {
+  if (c->d_rows) (void)hipFree(c->d_rows);
+  if (c->d_payload) (void)hipFree(c->d_payload);
+  if (c->d_stats) (void)hipFree(c->d_stats);
+  if (c->d_meta) (void)hipFree(c->d_meta);
+  if (c->d_scratch) (void)hipFree(c->d_scratch);
+  if (c->d_check) (void)hipFree(c->d_check);
+  if (c->h_rows) (void)hipHostFree(c->h_rows);
+  if (c->h_payload) (void)hipHostFree(c->h_payload);
+  if (c->h_stats) (void)hipHostFree(c->h_stats);
+  if (c->h_meta) (void)hipHostFree(c->h_meta);
+  if (c->h_check) (void)hipHostFree(c->h_check);
+  delete[] c->h_row_off; delete[] c->h_pay_off;
+  c->d_rows = nullptr; c->d_payload = nullptr; c->d_stats = nullptr; c->d_meta = nullptr; c->d_scratch = nullptr; c->d_check = nullptr;
+  c->h_rows = nullptr; c->h_payload = nullptr; c->h_stats = nullptr; c->h_meta = nullptr; c->h_check = nullptr;
+  c->h_row_off = nullptr; c->h_pay_off = nullptr;
+  c->cap_inst = 0;
+}
+
+extern "C" int msim_create(const msim_config *cfg, int device, msim_ctx **out, char *err, size_t errlen) {
+  if (!cfg || !out) { set_err(err, errlen, "null argument"); return MSIM_E_INVALID; }
+  *out = nullptr;
+  msim_config c = *cfg;
+  int rc = msim_config_finalize(&c, err, errlen);
+  if (rc != MSIM_OK) return rc;
+  const uint32_t slots = c.concurrency > c.n_nodes ? c.concurrency : c.n_nodes;
+  if (c.n_nodes > 32 || c.n_nodes + slots > 64) {
+    set_err(err, errlen, "this build maps one cluster to one wavefront: n_nodes <= 32 and n_nodes + max(concurrency, n_nodes) <= 64");
+    return MSIM_E_UNSUPPORTED;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_err(err, errlen, "no HIP device visible: libmaelsim has no CPU path"); return MSIM_E_NO_DEVICE; }
+  if (device < 0 || device >= ndev) { set_err(err, errlen, "device index out of range"); return MSIM_E_INVALID; }
+  msim_ctx *ctx = new (std::nothrow) msim_ctx();
+  if (!ctx) return MSIM_E_NOMEM;
+  ctx->cfg = c; ctx->device = device;
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+  if (e == hipSuccess) e = hipEventCreate(&ctx->ev2);
+  if (e == hipSuccess) e = hipEventCreate(&ctx->ev3);
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(d_log2_q24), msim_log2_q24, sizeof(msim_log2_q24));
+  if (e != hipSuccess) { set_err(err, errlen, hipGetErrorString(e)); delete ctx; return MSIM_E_HIP; }
+  *out = ctx;
+  return MSIM_OK;
+}
+
+static uint64_t scratch_words(const msim_config &c) {
+  if (c.node_program == MSIM_NODE_BCAST_ACK_RETRY) return (uint64_t)c.n_nodes * c.max_values * 3;
+  if (c.node_program == MSIM_NODE_G_SET) {
+    const uint64_t total_ms = (uint64_t)c.time_limit_ms + c.quiesce_ms + 2ull * c.client_timeout_ms;
+    const uint64_t ticks = total_ms / 5000 + 3;
+    return ticks * c.n_nodes * (c.max_values / 32);
+  }
+  return 4;
+}
+
+static int ensure_buffers(msim_ctx *ctx, uint32_t n) {
+  if (n <= ctx->cap_inst) return MSIM_OK;
+  free_buffers(ctx);
+  const msim_config &c = ctx->cfg;
+  ctx->scratch_words_per_inst = scratch_words(c);
+  MSIM_HIP_TRY(ctx, hipMalloc(&ctx->d_rows, (size_t)n * c.max_rows * sizeof(msim_op)));
+  MSIM_HIP_TRY(ctx, hipMalloc(&ctx->d_payload, (size_t)n * c.max_payload_words * 4));
+  MSIM_HIP_TRY(ctx, hipMalloc(&ctx->d_stats, (size_t)n * sizeof(msim_net_stats)));
+  MSIM_HIP_TRY(ctx, hipMalloc(&ctx->d_meta, (size_t)n * sizeof(msim_inst_meta)));
+  MSIM_HIP_TRY(ctx, hipMalloc(&ctx->d_scratch, (size_t)n * ctx->scratch_words_per_inst * 4));
+  MSIM_HIP_TRY(ctx, hipMalloc(&ctx->d_check, (size_t)n * sizeof(msim_check_result)));
+  ctx->cap_inst = n;
+  return MSIM_OK;
+}
+
+template <int PROG>
+static hipError_t launch(const KParams &kp, uint32_t n, size_t lds, hipStream_t st) {
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sim_kernel<PROG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(sim_kernel<PROG>, dim3(n), dim3(64), lds, st, kp);
+  return hipGetLastError();
+}
+
+static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, bool blocking) {
+  if (!ctx) return MSIM_E_INVALID;
+  if (n == 0) { ctx->err = "n_instances must be > 0"; return MSIM_E_INVALID; }
+  MSIM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_buffers(ctx, n);
+  if (rc != MSIM_OK) return rc;
+  const msim_config &c = ctx->cfg;
+  KParams kp;
+  std::memset(&kp, 0, sizeof kp);
+  kp.cfg = c; kp.first_instance = first;
+  kp.rows = ctx->d_rows; kp.payload = ctx->d_payload; kp.stats = ctx->d_stats; kp.meta = ctx->d_meta;
+  kp.scratch = ctx->d_scratch; kp.scratch_words = ctx->scratch_words_per_inst;
+  kp.N = c.n_nodes; kp.C = c.concurrency; kp.CS = c.concurrency > c.n_nodes ? c.concurrency : c.n_nodes;
+  kp.W = c.max_values / 32;
+  kp.cap_node = c.inbox_capacity;
+  const uint64_t period_us = 1000000000ull / (c.rate_mhz ? c.rate_mhz : 1);
+  if (2 * period_us > 0xFFFFFFFFull || 2000ull * c.nemesis_interval_ms > 0xFFFFFFFFull) { ctx->err = "rate too low / nemesis interval too long for u32 microseconds"; return MSIM_E_INVALID; }
+  kp.gen_period2_us = (u32)(2 * period_us);
+  kp.nem_period2_us = (u32)(2000ull * c.nemesis_interval_ms);
+  size_t off = STAGE_ROWS * 16;
+  kp.off_inbox = (u32)off; off += ((size_t)kp.N * kp.cap_node + (size_t)kp.CS * CLIENT_INBOX_CAP) * 16;
+  kp.off_seen = (u32)off; off += (size_t)kp.N * kp.W * 4; off = (off + 15) & ~(size_t)15;
+  kp.off_misc = (u32)off; off += 64 * 4;
+  const size_t lds = off;
+  if (lds > 160 * 1024) { ctx->err = "cluster state exceeds the 160 KiB LDS of a CU (lower inbox_capacity / max_values)"; return MSIM_E_INVALID; }
+
+  if (blocking) MSIM_HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
+  hipError_t e;
+  switch (c.node_program) {
+    case MSIM_NODE_ECHO: e = launch<MSIM_NODE_ECHO>(kp, n, lds, st); break;
+    case MSIM_NODE_BCAST_FF: e = launch<MSIM_NODE_BCAST_FF>(kp, n, lds, st); break;
+    case MSIM_NODE_BCAST_FF_ECHOBACK: e = launch<MSIM_NODE_BCAST_FF_ECHOBACK>(kp, n, lds, st); break;
+    case MSIM_NODE_BCAST_ACK_RETRY: e = launch<MSIM_NODE_BCAST_ACK_RETRY>(kp, n, lds, st); break;
+    case MSIM_NODE_BCAST_RPC_ALL: e = launch<MSIM_NODE_BCAST_RPC_ALL>(kp, n, lds, st); break;
+    case MSIM_NODE_G_SET: e = launch<MSIM_NODE_G_SET>(kp, n, lds, st); break;
+    default: ctx->err = "node program not built into this engine"; return MSIM_E_UNSUPPORTED;
+  }
+  if (e != hipSuccess) { ctx->err = std::string("kernel launch: ") + hipGetErrorString(e); return MSIM_E_HIP; }
+  ctx->n_inst = n; ctx->first_instance = first;
+  ctx->fetched = false; ctx->checked = false; ctx->check_fetched = false; ctx->ran = true;
+  if (blocking) {
+    MSIM_HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
+    MSIM_HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+    MSIM_HIP_TRY(ctx, hipEventElapsedTime(&ctx->sim_ms, ctx->ev0, ctx->ev1));
+  }
+  return MSIM_OK;
+}
+
+extern "C" int msim_run(msim_ctx *ctx, uint64_t first_instance, uint32_t n_instances) {
+  if (!ctx) return MSIM_E_INVALID;
+  return run_impl(ctx, first_instance, n_instances, ctx->stream, true);
+}
+
+extern "C" int msim_run_async(msim_ctx *ctx, uint64_t first_instance, uint32_t n_instances, void *hip_stream) {
+  if (!ctx) return MSIM_E_INVALID;
+  return run_impl(ctx, first_instance, n_instances, hip_stream ? (hipStream_t)hip_stream : ctx->stream, false);
+}
+
+extern "C" int msim_check(msim_ctx *ctx) {
+  if (!ctx) return MSIM_E_INVALID;
+  if (!ctx->ran) { ctx->err = "msim_check before msim_run"; return MSIM_E_RANGE; }
+  return msim_check_launch(ctx);
+}
+
+extern "C" int msim_fetch(msim_ctx *ctx) {
+  if (!ctx) return MSIM_E_INVALID;
+  if (!ctx->ran) { ctx->err = "msim_fetch before msim_run"; return MSIM_E_RANGE; }
+  if (ctx->fetched) return MSIM_OK;
+  MSIM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const msim_config &c = ctx->cfg;
+  const uint32_t n = ctx->n_inst;
+  if (ctx->h_meta) { (void)hipHostFree(ctx->h_meta); ctx->h_meta = nullptr; }
+  if (ctx->h_stats) { (void)hipHostFree(ctx->h_stats); ctx->h_stats = nullptr; }
+  if (ctx->h_rows) { (void)hipHostFree(ctx->h_rows); ctx->h_rows = nullptr; }
+  if (ctx->h_payload) { (void)hipHostFree(ctx->h_payload); ctx->h_payload = nullptr; }
+  delete[] ctx->h_row_off; delete[] ctx->h_pay_off;
+  ctx->h_row_off = new uint64_t[n + 1]; ctx->h_pay_off = new uint64_t[n + 1];
+  MSIM_HIP_TRY(ctx, hipHostMalloc(&ctx->h_meta, (size_t)n * sizeof(msim_inst_meta)));
+  MSIM_HIP_TRY(ctx, hipHostMalloc(&ctx->h_stats, (size_t)n * sizeof(msim_net_stats)));
+  MSIM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  MSIM_HIP_TRY(ctx, hipMemcpy(ctx->h_meta, ctx->d_meta, (size_t)n * sizeof(msim_inst_meta), hipMemcpyDeviceToHost));
+  MSIM_HIP_TRY(ctx, hipMemcpy(ctx->h_stats, ctx->d_stats, (size_t)n * sizeof(msim_net_stats), hipMemcpyDeviceToHost));
+  uint64_t ro = 0, po = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    ctx->h_row_off[i] = ro; ctx->h_pay_off[i] = po;
+    ro += ctx->h_meta[i].n_rows; po += ctx->h_meta[i].n_payload_words;
+  }
+  ctx->h_row_off[n] = ro; ctx->h_pay_off[n] = po;
+  MSIM_HIP_TRY(ctx, hipHostMalloc(&ctx->h_rows, (size_t)(ro + 1) * sizeof(msim_op)));
+  MSIM_HIP_TRY(ctx, hipHostMalloc(&ctx->h_payload, (size_t)(po + 1) * 4));
+  // only the used prefix of every instance's slab crosses PCIe
+  for (uint32_t i = 0; i < n; i++) {
+    const msim_inst_meta &m = ctx->h_meta[i];
+    if (m.n_rows) MSIM_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_rows + ctx->h_row_off[i], ctx->d_rows + (size_t)i * c.max_rows,
+                                                 (size_t)m.n_rows * sizeof(msim_op), hipMemcpyDeviceToHost, ctx->stream));
+    if (m.n_payload_words) MSIM_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_payload + ctx->h_pay_off[i], ctx->d_payload + (size_t)i * c.max_payload_words,
+                                                          (size_t)m.n_payload_words * 4, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  MSIM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->fetched = true;
+  return MSIM_OK;
+}
+
+extern "C" int msim_history(msim_ctx *ctx, uint32_t inst, const msim_op **ops, uint32_t *n_ops, const uint32_t **payload, uint32_t *n_words) {
+  if (!ctx) return MSIM_E_INVALID;
+  if (!ctx->fetched || inst >= ctx->n_inst) { ctx->err = "msim_history: not fetched or instance out of range"; return MSIM_E_RANGE; }
+  if (ops) *ops = ctx->h_rows + ctx->h_row_off[inst];
+  if (n_ops) *n_ops = ctx->h_meta[inst].n_rows;
+  if (payload) *payload = ctx->h_payload + ctx->h_pay_off[inst];
+  if (n_words) *n_words = ctx->h_meta[inst].n_payload_words;
+  return MSIM_OK;
+}
+
+extern "C" int msim_net_stats_get(msim_ctx *ctx, uint32_t inst, msim_net_stats *out) {
+  if (!ctx || !out) return MSIM_E_INVALID;
+  if (!ctx->fetched || inst >= ctx->n_inst) { ctx->err = "msim_net_stats_get: not fetched or instance out of range"; return MSIM_E_RANGE; }
+  *out = ctx->h_stats[inst];
+  return MSIM_OK;
+}
+
+extern "C" int msim_meta(msim_ctx *ctx, uint32_t inst, msim_inst_meta *out) {
+  if (!ctx || !out) return MSIM_E_INVALID;
+  if (!ctx->fetched || inst >= ctx->n_inst) { ctx->err = "msim_meta: not fetched or instance out of range"; return MSIM_E_RANGE; }
+  *out = ctx->h_meta[inst];
+  return MSIM_OK;
+}
+
+extern "C" int msim_check_results(msim_ctx *ctx, const msim_check_result **results, uint32_t *n) {
+  if (!ctx) return MSIM_E_INVALID;
+  if (!ctx->checked) { ctx->err = "msim_check_results before msim_check"; return MSIM_E_RANGE; }
+  if (!ctx->check_fetched) {
+    MSIM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->h_check) { (void)hipHostFree(ctx->h_check); ctx->h_check = nullptr; }
+    MSIM_HIP_TRY(ctx, hipHostMalloc(&ctx->h_check, (size_t)ctx->n_inst * sizeof(msim_check_result)));
+    MSIM_HIP_TRY(ctx, hipMemcpy(ctx->h_check, ctx->d_check, (size_t)ctx->n_inst * sizeof(msim_check_result), hipMemcpyDeviceToHost));
+    ctx->check_fetched = true;
+  }
+  if (results) *results = ctx->h_check;
+  if (n) *n = ctx->n_inst;
+  return MSIM_OK;
+}
+
+extern "C" int msim_device_buffers_get(msim_ctx *ctx, msim_device_buffers *out) {
+  if (!ctx || !out) return MSIM_E_INVALID;
+  if (!ctx->ran) { ctx->err = "no run yet"; return MSIM_E_RANGE; }
+  const msim_config &c = ctx->cfg;
+  out->rows = ctx->d_rows; out->payload = ctx->d_payload; out->stats = ctx->d_stats; out->meta = ctx->d_meta;
+  out->rows_bytes = (uint64_t)ctx->n_inst * c.max_rows * sizeof(msim_op);
+  out->payload_bytes = (uint64_t)ctx->n_inst * c.max_payload_words * 4;
+  out->stats_bytes = (uint64_t)ctx->n_inst * sizeof(msim_net_stats);
+  out->meta_bytes = (uint64_t)ctx->n_inst * sizeof(msim_inst_meta);
+  out->n_instances = ctx->n_inst; out->max_rows = c.max_rows; out->max_payload_words = c.max_payload_words; out->reserved = 0;
+  return MSIM_OK;
+}
+
+extern "C" int msim_last_kernel_ms(msim_ctx *ctx, float *sim_ms, float *check_ms) {
+  if (!ctx) return MSIM_E_INVALID;
+  if (sim_ms) *sim_ms = ctx->sim_ms;
+  if (check_ms) *check_ms = ctx->check_ms;
+  return MSIM_OK;
+}
+
+extern "C" int msim_get_config(const msim_ctx *ctx, msim_config *out) {
+  if (!ctx || !out) return MSIM_E_INVALID;
+  *out = ctx->cfg;
+  return MSIM_OK;
+}
+
+extern "C" const char *msim_last_error(const msim_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+extern "C" void msim_destroy(msim_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  free_buffers(ctx);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
+  if (ctx->ev3) (void)hipEventDestroy(ctx->ev3);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+// Validates the DPP encodings of wave_min / wave_incl_scan against shuffle-based references on the
+// device.  Returns 0 when they agree, >0 = number of mismatching lanes, <0 = MSIM_E_*.
+extern "C" int msim_selftest_wave(int device) {
+  if (hipSetDevice(device) != hipSuccess) return MSIM_E_NO_DEVICE;
+  const int blocks = 64, n = blocks * 64;
+  u32 *h = new u32[n], *d_in = nullptr, *d_out = nullptr;
+  u64 x = 12345;
+  for (int i = 0; i < n; i++) { x = mix64(x + i); h[i] = (u32)x; if (i % 7 == 0) h[i] = 0xFFFFFFFFu; }
+  int bad = 0;
+  if (hipMalloc(&d_in, n * 4) != hipSuccess || hipMalloc(&d_out, n * 4) != hipSuccess) { delete[] h; return MSIM_E_HIP; }
+  (void)hipMemcpy(d_in, h, n * 4, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(wave_selftest_kernel, dim3(blocks), dim3(64), 0, 0, d_in, d_out);
+  if (hipMemcpy(h, d_out, n * 4, hipMemcpyDeviceToHost) != hipSuccess) bad = MSIM_E_HIP;
+  else for (int i = 0; i < n; i++) bad += h[i] != 0;
+  (void)hipFree(d_in); (void)hipFree(d_out);
+  delete[] h;
+  return bad;
+}

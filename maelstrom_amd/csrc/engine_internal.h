@@ -1,0 +1,53 @@
+// engine_internal.h — private to libmaelsim (engine.hip, checker.hip).
+#ifndef MSIM_ENGINE_INTERNAL_H
+#define MSIM_ENGINE_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <string>
+
+#include "../../include/maelsim.h"
+#include "engine_limits.h"
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+struct msim_ctx {
+  msim_config cfg{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+  // device buffers of the last run
+  uint32_t n_inst = 0, cap_inst = 0;
+  uint64_t first_instance = 0;
+  msim_op *d_rows = nullptr;
+  uint32_t *d_payload = nullptr;
+  msim_net_stats *d_stats = nullptr;
+  msim_inst_meta *d_meta = nullptr;
+  uint32_t *d_scratch = nullptr;
+  uint64_t scratch_words_per_inst = 0;
+  msim_check_result *d_check = nullptr;
+  // host (pinned) mirrors
+  msim_op *h_rows = nullptr;
+  uint32_t *h_payload = nullptr;
+  msim_net_stats *h_stats = nullptr;
+  msim_inst_meta *h_meta = nullptr;
+  msim_check_result *h_check = nullptr;
+  uint64_t *h_row_off = nullptr, *h_pay_off = nullptr;  // compacted offsets per instance
+  bool fetched = false, checked = false, check_fetched = false, ran = false;
+  float sim_ms = 0.f, check_ms = 0.f;
+  std::string err;
+};
+
+// checker.hip
+int msim_check_launch(msim_ctx *ctx);
+
+#define MSIM_HIP_TRY(ctx, call)                                                        \
+  do {                                                                                 \
+    hipError_t e_ = (call);                                                            \
+    if (e_ != hipSuccess) {                                                            \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                 \
+      return MSIM_E_HIP;                                                               \
+    }                                                                                  \
+  } while (0)
+
+#endif

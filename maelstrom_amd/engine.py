@@ -1,0 +1,247 @@
+"""Host-side mirror of the reference's test-map -> history surface, above the C-ABI (include/maelsim.h).
+
+`test_config(...)` plays the role of `maelstrom.core/maelstrom-test` (core.clj:53-102): it takes the CLI
+option names of core.clj:136-229 and returns the finalized engine config.  `Engine.run` replaces
+`jepsen.core/run!` for an ensemble of instances; `Engine.history(i)` yields the op maps that
+`(checker/check (:checker test) test history opts)` consumes (core.clj:91-100), `Engine.net_stats(i)`
+the map of net/checker.clj:28-41.  Everything here calls libmaelsim.so; there is no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi as A
+
+OP_DT = np.dtype([("time_len", "<u8"), ("packed", "<u4"), ("value", "<u4")])
+STATS_DT = np.dtype([(n, "<u8") for n in ("all_send", "all_recv", "clients_send", "clients_recv", "servers_send", "servers_recv")])
+META_DT = np.dtype([(n, "<u4") for n in ("n_rows", "n_payload_words", "flags", "n_rounds")])
+CHECK_DT = np.dtype([("valid", "<u4"), ("attempt_count", "<u4"), ("stable_count", "<u4"), ("lost_count", "<u4"),
+                     ("never_read_count", "<u4"), ("stale_count", "<u4"), ("duplicated_count", "<u4"),
+                     ("error_count", "<u4"), ("stable_latency_ms", "<u4", (5,)), ("op_count", "<u4"),
+                     ("ok_count", "<u4"), ("fail_count", "<u4"), ("info_count", "<u4")])
+
+WORKLOADS = {"echo": A.WL_ECHO, "broadcast": A.WL_BROADCAST, "g-set": A.WL_G_SET, "lin-kv": A.WL_LIN_KV,
+             "txn-list-append": A.WL_TXN_LIST_APPEND}
+NODE_PROGRAMS = {"echo": A.NODE_ECHO, "broadcast-ff": A.NODE_BCAST_FF, "broadcast-ff-echoback": A.NODE_BCAST_FF_ECHOBACK,
+                 "broadcast-ack-retry": A.NODE_BCAST_ACK_RETRY, "broadcast-rpc-all": A.NODE_BCAST_RPC_ALL,
+                 "g-set": A.NODE_G_SET}
+TOPOLOGIES = {"grid": A.TOPO_GRID, "line": A.TOPO_LINE, "total": A.TOPO_TOTAL, "tree": A.TOPO_TREE2,
+              "tree2": A.TOPO_TREE2, "tree3": A.TOPO_TREE3, "tree4": A.TOPO_TREE4}
+LATENCY_DISTS = {"constant": A.LAT_CONSTANT, "uniform": A.LAT_UNIFORM, "exponential": A.LAT_EXPONENTIAL}
+TYPE_KW = {A.T_INVOKE: ":invoke", A.T_OK: ":ok", A.T_FAIL: ":fail", A.T_INFO: ":info"}
+F_KW = {A.F_ECHO: ":echo", A.F_BROADCAST: ":broadcast", A.F_READ: ":read", A.F_ADD: ":add",
+        A.F_START_PARTITION: ":start-partition", A.F_STOP_PARTITION: ":stop-partition"}
+SPEC_KW = {A.SPEC_ONE: ":one", A.SPEC_MAJORITY: ":majority", A.SPEC_MAJORITIES_RING: ":majorities-ring",
+           A.SPEC_MINORITY_THIRD: ":minority-third"}
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def test_config(workload="broadcast", bin=None, node_count=5, concurrency=None, rate=5.0, time_limit=60.0,
+                latency=0, latency_dist="constant", topology="grid", nemesis=(), nemesis_interval=10.0,
+                p_loss=0.0, seed=0, **capacities):
+    """Option map -> finalized msim_config.  Names follow core.clj:136-229; `bin` names a built-in node
+    program (NODE_PROGRAMS) instead of an executable; `p_loss` is the net's :p-loss (net.clj:100,122)."""
+    lib = A.load()
+    cfg = A.Config()
+    rc = lib.msim_config_defaults(C.byref(cfg), WORKLOADS[workload], int(node_count))
+    if rc:
+        raise EngineError(f"msim_config_defaults: {rc}")
+    if bin is not None:
+        cfg.node_program = NODE_PROGRAMS[bin]
+    if concurrency is not None:
+        cfg.concurrency = int(concurrency)
+    cfg.rate_mhz = int(round(rate * 1000))
+    cfg.time_limit_ms = int(round(time_limit * 1000))
+    cfg.latency_mean_ms = int(latency)
+    cfg.latency_dist = LATENCY_DISTS[latency_dist]
+    cfg.topology = TOPOLOGIES[topology]
+    cfg.nemesis_mask = A.NEMESIS_PARTITION if "partition" in set(nemesis) else 0
+    cfg.nemesis_interval_ms = int(round(nemesis_interval * 1000))
+    cfg.p_loss_q32 = min(int(p_loss * 2**32), 2**32 - 1)
+    cfg.seed = int(seed)
+    for k, v in capacities.items():
+        if not hasattr(cfg, k):
+            raise EngineError(f"unknown option {k}")
+        setattr(cfg, k, int(v))
+    err = C.create_string_buffer(256)
+    rc = lib.msim_config_finalize(C.byref(cfg), err, 256)
+    if rc:
+        raise EngineError(f"invalid test options ({rc}): {err.value.decode()}")
+    return cfg
+
+
+class Engine:
+    """One engine context on one HIP device (msim_create ... msim_destroy)."""
+
+    def __init__(self, cfg, device=0):
+        self.lib = A.load()
+        self._ctx = C.c_void_p()
+        err = C.create_string_buffer(256)
+        rc = self.lib.msim_create(C.byref(cfg), device, C.byref(self._ctx), err, 256)
+        if rc:
+            raise EngineError(f"msim_create failed ({rc}): {err.value.decode()}")
+        self.cfg = A.Config()
+        self.lib.msim_get_config(self._ctx, C.byref(self.cfg))
+        self.n = 0
+
+    def _chk(self, rc, what):
+        if rc:
+            raise EngineError(f"{what} failed ({rc}): {self.lib.msim_last_error(self._ctx).decode()}")
+
+    def close(self):
+        if self._ctx:
+            self.lib.msim_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, first_instance, n_instances):
+        self._chk(self.lib.msim_run(self._ctx, first_instance, n_instances), "msim_run")
+        self.n = n_instances
+
+    def run_async(self, first_instance, n_instances, stream=None):
+        self._chk(self.lib.msim_run_async(self._ctx, first_instance, n_instances, stream), "msim_run_async")
+        self.n = n_instances
+
+    def check(self):
+        self._chk(self.lib.msim_check(self._ctx), "msim_check")
+
+    def fetch(self):
+        self._chk(self.lib.msim_fetch(self._ctx), "msim_fetch")
+
+    def kernel_ms(self):
+        a, b = C.c_float(), C.c_float()
+        self._chk(self.lib.msim_last_kernel_ms(self._ctx, C.byref(a), C.byref(b)), "msim_last_kernel_ms")
+        return a.value, b.value
+
+    def device_buffers(self):
+        db = A.DeviceBuffers()
+        self._chk(self.lib.msim_device_buffers_get(self._ctx, C.byref(db)), "msim_device_buffers_get")
+        return db
+
+    def raw_history(self, i):
+        """(rows, payload) numpy views of instance i (after fetch)."""
+        ops, n_ops = C.POINTER(A.Op)(), C.c_uint32()
+        pay, n_words = C.POINTER(C.c_uint32)(), C.c_uint32()
+        self._chk(self.lib.msim_history(self._ctx, i, C.byref(ops), C.byref(n_ops), C.byref(pay), C.byref(n_words)), "msim_history")
+        rows = np.ctypeslib.as_array(C.cast(ops, C.POINTER(C.c_uint8)), shape=(max(n_ops.value, 1) * 16,))[: n_ops.value * 16].view(OP_DT)
+        payload = np.ctypeslib.as_array(pay, shape=(max(n_words.value, 1),))[: n_words.value]
+        return rows, payload
+
+    def net_stats_raw(self, i):
+        st = A.NetStats()
+        self._chk(self.lib.msim_net_stats_get(self._ctx, i, C.byref(st)), "msim_net_stats_get")
+        return st
+
+    def meta(self, i):
+        m = A.InstMeta()
+        self._chk(self.lib.msim_meta(self._ctx, i, C.byref(m)), "msim_meta")
+        return m
+
+    def check_results(self):
+        res, n = C.POINTER(A.CheckResult)(), C.c_uint32()
+        self._chk(self.lib.msim_check_results(self._ctx, C.byref(res), C.byref(n)), "msim_check_results")
+        arr = np.ctypeslib.as_array(C.cast(res, C.POINTER(C.c_uint8)), shape=(n.value * C.sizeof(A.CheckResult),))
+        return arr.view(CHECK_DT)
+
+    # ---- Jepsen-shaped views ---------------------------------------------------------------------
+    def history(self, i):
+        rows, payload = self.raw_history(i)
+        return decode_history(rows, payload, self.cfg.n_nodes)
+
+    def net_stats(self, i):
+        """The :net :stats map of net/checker.clj:28-41,55-67."""
+        st = self.net_stats_raw(i)
+        rows, _ = self.raw_history(i)
+        return net_stats_map(st, rows)
+
+
+def net_stats_map(st, rows):
+    typ = rows["packed"] & 3
+    proc = rows["packed"] >> 12
+    op_count = int(((typ == A.T_INVOKE) & (proc != A.PROCESS_NEMESIS)).sum())
+    get = (lambda k: int(st[k])) if isinstance(st, (np.void, dict)) else (lambda k: int(getattr(st, k)))
+    m = {k: {"send-count": get(f"{k}_send"), "recv-count": get(f"{k}_recv"), "msg-count": get(f"{k}_send")}
+         for k in ("all", "clients", "servers")}
+    if op_count:
+        m["all"]["msgs-per-op"] = m["all"]["msg-count"] / op_count
+        m["servers"]["msgs-per-op"] = m["servers"]["msg-count"] / op_count
+    m["valid?"] = True
+    return m
+
+
+def bitmap_to_list(words):
+    out = []
+    for wi, w in enumerate(np.asarray(words, dtype=np.uint32)):
+        w = int(w)
+        while w:
+            b = w & -w
+            out.append(wi * 32 + b.bit_length() - 1)
+            w ^= b
+    return out
+
+
+def decode_history(rows, payload, n_nodes):
+    """Binary rows -> list of Jepsen op maps (SURVEY.md §8b 'History surface')."""
+    ops = []
+    for idx in range(len(rows)):
+        tl, packed, value = int(rows["time_len"][idx]), int(rows["packed"][idx]), int(rows["value"][idx])
+        typ, f, err = packed & 3, (packed >> 2) & 31, (packed >> 7) & 15
+        final, process, ln = (packed >> 11) & 1, packed >> 12, tl >> 48
+        op = {"index": idx, "time": tl & 0xFFFFFFFFFFFF, "type": TYPE_KW[typ], "f": F_KW.get(f, f),
+              "process": ":nemesis" if process == A.PROCESS_NEMESIS else process}
+        if f == A.F_READ:
+            op["value"] = bitmap_to_list(payload[value:value + ln]) if typ == A.T_OK else None
+        elif f == A.F_ECHO:
+            v = f"Please echo {value}"
+            op["value"] = {"type": "echo_ok", "echo": v} if typ == A.T_OK else v
+        elif f == A.F_START_PARTITION:
+            if ln:
+                g = payload[value:value + ln].reshape(n_nodes, A.MASK_WORDS)
+                op["value"] = [":isolated", {f"n{d}": [f"n{s}" for s in bitmap_to_list(g[d])] for d in range(n_nodes) if g[d].any()}]
+            else:
+                op["value"] = SPEC_KW[value]
+        elif f == A.F_STOP_PARTITION:
+            op["value"] = None if idx == 0 or int(rows["packed"][idx - 1]) != packed or False else ":network-healed"
+        else:
+            op["value"] = None if value == A.NO_VALUE else value
+        if err == A.ERR_NET_TIMEOUT:
+            op["error"] = ":net-timeout"
+        if final:
+            op["final?"] = True
+        ops.append(op)
+    return ops
+
+
+def history_edn(ops):
+    """Jepsen history.edn text (one op map per line)."""
+    def edn(v):
+        if v is None:
+            return "nil"
+        if v is True:
+            return "true"
+        if isinstance(v, str):
+            return v if v.startswith(":") else '"' + v + '"'
+        if isinstance(v, dict):
+            return "{" + ", ".join(f"{edn(k if str(k).startswith(':') else ':' + str(k)) if not str(k).startswith('n') else edn(str(k))} {edn(x)}" for k, x in v.items()) + "}"
+        if isinstance(v, (list, tuple)):
+            return "[" + " ".join(edn(x) for x in v) + "]"
+        return str(v)
+    lines = []
+    for op in ops:
+        keys = ["type", "f", "value", "time", "process", "index"] + [k for k in ("error", "final?") if k in op]
+        lines.append("{" + ", ".join(f":{k} {edn(op[k])}" for k in keys) + "}")
+    return "\n".join(lines) + "\n"

@@ -68,8 +68,8 @@ enum { K_NONE = 0, K_INIT, K_TOPO, K_OP };
 
 typedef struct { u32 deadline, id, a, b; u8 src, type; } qent;
 typedef struct { qent *v; u32 n, cap; } inbox_t;
-typedef struct { u32 value, next_retry; u32 unacked[MW]; } task_t;
-typedef struct { task_t *v; u32 n, cap; } tasks_t;
+typedef struct { u32 value, next_retry; } task_t;
+typedef struct { task_t *v; u32 n, cap, head; } tasks_t;
 typedef struct { u8 src_ep, dest_ep, type; u32 a, b; } outmsg;
 
 typedef struct {
@@ -87,7 +87,8 @@ typedef struct {
   u32 *seen;            /* N * W words */
   u32 *node_msg_id;     /* per-node RPC msg_id counter (node.rb:91-98) */
   u32 *nbr_known;       /* node got its topology */
-  tasks_t *tasks;       /* ack/retry tasks per node */
+  tasks_t *tasks;       /* ack/retry: FIFO of gossip threads per node */
+  u32 *unacked;         /* ack/retry: [node][value][MW] un-acked neighbour sets */
   u32 *timer_next;      /* g-set replicate timer */
   u32 **snap; u32 n_snap, cap_snap; /* replicate_full payload snapshots */
   /* clients */
@@ -149,7 +150,7 @@ static void inbox_push(sim_t *s, u32 ep, qent q) {
   inbox_t *b = &s->inbox[ep];
   if (b->n == b->cap) { b->cap = b->cap ? b->cap * 2 : 8; b->v = (qent *)realloc(b->v, b->cap * sizeof(qent)); }
   b->v[b->n++] = q;
-  u32 lim = is_client(s, ep) ? 0xFFFFFFFFu : s->cfg.inbox_capacity;
+  u32 lim = is_client(s, ep) ? 4u : s->cfg.inbox_capacity; /* engine capacities: overflow is flagged, never silent */
   if (b->n > lim) s->meta.flags |= MSIM_FLAG_INBOX_OVERFLOW;
 }
 
@@ -254,6 +255,15 @@ static void gossip_targets(sim_t *s, u32 node, u32 src, u32 *tg) {
   if (prog != MSIM_NODE_BCAST_FF_ECHOBACK && src < s->N) clrbit(tg, src); /* skip-sender, 02-performance.md:61-67 */
 }
 
+static u32 *unacked_of(sim_t *s, u32 node, u32 v) { return s->unacked + ((size_t)node * s->cfg.max_values + v) * MW; }
+
+/* ack/retry tasks: one FIFO of (value, wake time) per node; unacked sets indexed by (node, value) */
+static void task_push(sim_t *s, u32 node, u32 value, u32 wake) {
+  tasks_t *t = &s->tasks[node];
+  if (t->n == t->cap) { t->cap = t->cap ? t->cap * 2 : 16; t->v = (task_t *)realloc(t->v, t->cap * sizeof(task_t)); }
+  t->v[t->n].value = value; t->v[t->n].next_retry = wake; t->n++;
+}
+
 static void node_broadcast(sim_t *s, u32 node, const qent *q) {
   u32 prog = s->cfg.node_program, v = q->a, has_id = q->b != 0;
   if (prog == MSIM_NODE_BCAST_ACK_RETRY && has_id) out_send(s, node, q->src, M_BROADCAST_OK, v, q->b); /* ack first, 02-performance.md:408-409 */
@@ -264,40 +274,24 @@ static void node_broadcast(sim_t *s, u32 node, const qent *q) {
     int rpc = prog == MSIM_NODE_BCAST_ACK_RETRY || prog == MSIM_NODE_BCAST_RPC_ALL;
     int any = 0;
     for (u32 i = 0; i < s->N; i++) if (bit(tg, i)) { any = 1; out_send(s, node, i, M_BROADCAST, v, rpc ? ++s->node_msg_id[node] : 0); }
-    if (prog == MSIM_NODE_BCAST_ACK_RETRY && any) { /* keep retrying every 1 s until acked, :421-438 */
-      tasks_t *t = &s->tasks[node];
-      if (t->n == t->cap) { t->cap = t->cap ? t->cap * 2 : 8; t->v = (task_t *)realloc(t->v, t->cap * sizeof(task_t)); }
-      task_t k; k.value = v; k.next_retry = s->T + 1000000u; memcpy(k.unacked, tg, sizeof tg);
-      t->v[t->n++] = k;
+    if (prog == MSIM_NODE_BCAST_ACK_RETRY && any) { /* `until unacked.empty? ... sleep 1`, :421-438 */
+      memcpy(unacked_of(s, node, v), tg, sizeof tg);
+      task_push(s, node, v, s->T + 1000000u);
     }
   }
   if (prog != MSIM_NODE_BCAST_ACK_RETRY && has_id) out_send(s, node, q->src, M_BROADCAST_OK, v, q->b);
 }
 
-static void node_broadcast_ok(sim_t *s, u32 node, const qent *q) { /* callback: unacked.delete dest */
+static void node_broadcast_ok(sim_t *s, u32 node, const qent *q) { /* callback: unacked.delete dest, :428-432 */
   if (s->cfg.node_program != MSIM_NODE_BCAST_ACK_RETRY) return;
-  tasks_t *t = &s->tasks[node];
-  for (u32 i = 0; i < t->n; i++) if (t->v[i].value == q->a) {
-    clrbit(t->v[i].unacked, q->src);
-    u32 any = 0; for (u32 w = 0; w < MW; w++) any |= t->v[i].unacked[w];
-    if (!any) t->v[i] = t->v[--t->n];
-    return;
-  }
+  clrbit(unacked_of(s, node, q->a), q->src);
 }
 
-/* earliest due retry task of a node: min (next_retry, value); returns index or -1 */
-static int due_task(const sim_t *s, u32 node, u32 T) {
-  const tasks_t *t = &s->tasks[node]; int best = -1;
-  for (u32 i = 0; i < t->n; i++) if (t->v[i].next_retry <= T) {
-    if (best < 0 || t->v[i].next_retry < t->v[best].next_retry ||
-        (t->v[i].next_retry == t->v[best].next_retry && t->v[i].value < t->v[best].value)) best = (int)i;
-  }
-  return best;
-}
+/* next timer of a node: g-set replicate tick, or the wake time of the oldest gossip task */
 static u32 node_timer_time(const sim_t *s, u32 node) {
   u32 m = s->timer_next[node];
   const tasks_t *t = &s->tasks[node];
-  for (u32 i = 0; i < t->n; i++) if (t->v[i].next_retry < m) m = t->v[i].next_retry;
+  if (t->head < t->n && t->v[t->head].next_retry < m) m = t->v[t->head].next_retry;
   return m;
 }
 
@@ -311,12 +305,13 @@ static void node_timer(sim_t *s, u32 node) {
     s->n_snap++;
     return;
   }
-  int k = due_task(s, node, s->T);
-  if (k >= 0) {
-    task_t *t = &s->tasks[node].v[k];
-    for (u32 i = 0; i < s->N; i++) if (bit(t->unacked, i)) out_send(s, node, i, M_BROADCAST, t->value, ++s->node_msg_id[node]);
-    t->next_retry += 1000000u;
-  }
+  /* the gossip thread of the oldest task wakes: resend to whoever has not acked, sleep 1 s again;
+   * if everyone acked the thread exits (02-performance.md:421-438) */
+  tasks_t *t = &s->tasks[node];
+  task_t k = t->v[t->head++];
+  u32 *un = unacked_of(s, node, k.value), any = 0;
+  for (u32 i = 0; i < s->N; i++) if (bit(un, i)) { any = 1; out_send(s, node, i, M_BROADCAST, k.value, ++s->node_msg_id[node]); }
+  if (any) task_push(s, node, k.value, s->T + 1000000u);
 }
 
 static void node_handle(sim_t *s, u32 node, const qent *q) {
@@ -596,6 +591,7 @@ int oracle_run_instance(const msim_config *cfg, uint64_t instance, msim_op *rows
   s->node_msg_id = (u32 *)calloc(s->N, 4);
   s->nbr_known = (u32 *)calloc(s->N, 4);
   s->tasks = (tasks_t *)calloc(s->N, sizeof(tasks_t));
+  if (cfg->node_program == MSIM_NODE_BCAST_ACK_RETRY) s->unacked = (u32 *)calloc((size_t)s->N * cfg->max_values * MW, 4);
   s->timer_next = (u32 *)malloc(s->N * 4);
   for (u32 i = 0; i < s->N; i++) s->timer_next[i] = INF;
   s->cl = (struct cl *)calloc(s->CS, sizeof(struct cl));
@@ -608,7 +604,7 @@ int oracle_run_instance(const msim_config *cfg, uint64_t instance, msim_op *rows
   for (u32 n = 0; n < s->N; n++) free(s->tasks[n].v);
   for (u32 i = 0; i < s->n_snap; i++) free(s->snap[i]);
   free(s->snap); free(s->inbox); free(s->committed); free(s->has_committed); free(s->deliver_at); free(s->seen);
-  free(s->node_msg_id); free(s->nbr_known); free(s->tasks); free(s->timer_next); free(s->cl); free(s->out);
+  free(s->unacked); free(s->node_msg_id); free(s->nbr_known); free(s->tasks); free(s->timer_next); free(s->cl); free(s->out);
   free(s);
   return 0;
 }

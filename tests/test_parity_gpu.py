@@ -1,0 +1,84 @@
+"""GPU parity tests proper: the HIP engine (through the C-ABI) against the CPU oracle, bit-exact.
+
+T0 parity: history rows, payload words, net stats and meta of every instance must be
+byte-identical between libmaelsim.so (MI355X) and oracle/libmaelsim_oracle.so on the same (seed, instance)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from maelstrom_amd import _abi as A
+from maelstrom_amd import engine as E
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(cfg, first, n):
+    ora = O.run(cfg, first, n)
+    with E.Engine(cfg) as eng:
+        eng.run(first, n)
+        eng.fetch()
+        for i in range(n):
+            m = eng.meta(i)
+            om = ora.meta[i]
+            assert (m.n_rows, m.n_payload_words, m.flags, m.n_rounds) == (om["n_rows"], om["n_payload_words"], om["flags"], om["n_rounds"]), \
+                f"meta differs for instance {first + i}: gpu {(m.n_rows, m.n_payload_words, m.flags, m.n_rounds)} oracle {tuple(om)}"
+            assert m.flags == 0
+            rows, pay = eng.raw_history(i)
+            orows, opay = ora.history(i)
+            assert rows.tobytes() == orows.tobytes(), f"history rows differ for instance {first + i}"
+            assert pay.tobytes() == opay.tobytes(), f"payload differs for instance {first + i}"
+            st = eng.net_stats_raw(i)
+            assert tuple(getattr(st, f) for f, _ in A.NetStats._fields_) == tuple(int(x) for x in ora.stats[i]), \
+                f"net stats differ for instance {first + i}"
+    return ora
+
+
+def test_wave_primitives_selftest(lib):
+    """DPP min / prefix-sum encodings agree with shuffle-based references on the device."""
+    lib.msim_selftest_wave.argtypes = [C.c_int]
+    lib.msim_selftest_wave.restype = C.c_int
+    assert lib.msim_selftest_wave(0) == 0
+
+
+def test_echo_parity(lib):
+    cfg = E.test_config("echo", node_count=3, rate=5, time_limit=10, seed=1)
+    _compare(cfg, 0, 8)
+
+
+@pytest.mark.parametrize("topology", ["grid", "line", "total", "tree4"])
+def test_broadcast_ff_parity_small(lib, topology):
+    cfg = E.test_config("broadcast", node_count=5, rate=10, time_limit=5, topology=topology, seed=7)
+    _compare(cfg, 0, 16)
+
+
+@pytest.mark.parametrize("latency,dist", [(0, "constant"), (10, "constant"), (100, "constant"), (100, "exponential"), (50, "uniform")])
+def test_broadcast_n25_parity(lib, latency, dist):
+    cfg = E.test_config("broadcast", node_count=25, rate=100, time_limit=20, latency=latency, latency_dist=dist, seed=42)
+    _compare(cfg, 100, 4)
+
+
+@pytest.mark.parametrize("prog", ["broadcast-ff-echoback", "broadcast-rpc-all", "broadcast-ack-retry"])
+def test_broadcast_variants_parity(lib, prog):
+    cfg = E.test_config("broadcast", bin=prog, node_count=5, rate=20, time_limit=5, latency=10, seed=3)
+    _compare(cfg, 0, 8)
+
+
+def test_broadcast_partition_parity(lib):
+    cfg = E.test_config("broadcast", bin="broadcast-ack-retry", node_count=5, rate=10, time_limit=20, topology="tree4",
+                        nemesis=["partition"], nemesis_interval=5, latency=5, seed=11)
+    _compare(cfg, 0, 16)
+
+
+def test_broadcast_loss_parity(lib):
+    cfg = E.test_config("broadcast", bin="broadcast-ack-retry", node_count=9, rate=20, time_limit=10, latency=20,
+                        latency_dist="exponential", p_loss=0.05, seed=5)
+    _compare(cfg, 0, 8)
+
+
+def test_g_set_parity(lib):
+    cfg = E.test_config("g-set", node_count=5, rate=10, time_limit=10, seed=9)
+    _compare(cfg, 0, 8)
+    cfg = E.test_config("g-set", node_count=25, rate=100, time_limit=10, latency=100, latency_dist="exponential", seed=9)
+    _compare(cfg, 0, 4)
