@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: simulated msgs/sec (+ histories/sec passing the checker), broadcast n=25.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one pass of the hot path over one batch: every rank simulates `--instances` (default 4096,
+BASELINE.json configs[1]) independent broadcast test instances (25 nodes, grid topology, --rate 100,
+--time-limit 20 + 10 s quiesce + 25 final reads — the invocation of doc/03-broadcast/02-performance.md:87)
+to completion and runs the set-full checker over all emitted histories, everything resident in HBM.
+Scaling is weak (fixed instances per GPU, distinct seeds per rank): the data path has no
+collective; per step only the per-rank verdict/message totals (16 B) are all-reduced over RCCL.  After the
+timed region the variable-length history gather to rank 0 (RCCL all_gather over xGMI) is measured once
+and reported as `history_gather` (north_star asks for it; it is not part of `value`).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def headline_config(E, seed):
+    return E.test_config("broadcast", bin="broadcast-ff", node_count=25, rate=100, time_limit=20, latency=0,
+                         latency_dist="constant", topology="grid", seed=seed, inbox_capacity=6)
+
+
+def cpu_baseline(cfg, n_sample):
+    """The CPU oracle (a port with identical semantics) on the host cores: all cores, and one core."""
+    import concurrent.futures as cf
+    import oracle_lib as O
+    O.load()
+    cores = os.cpu_count() or 1
+    per = max(1, n_sample // cores)
+    t0 = time.perf_counter()
+    one = O.run(cfg, 10_000_000, min(32, n_sample))
+    t1 = time.perf_counter()
+    msgs_1 = int(one.stats["all_send"].sum())
+    single = msgs_1 / (t1 - t0)
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(cores) as ex:  # ctypes releases the GIL: real parallelism
+        outs = list(ex.map(lambda k: O.run(cfg, 20_000_000 + k * per, per), range(cores)))
+    dt = time.perf_counter() - t0
+    msgs = sum(int(o.stats["all_send"].sum()) for o in outs)
+    return {"value": msgs / dt, "unit": "msgs/s", "cores": cores, "kind": "port",
+            "sample": f"{per * cores} instances of the same workload on {cores} threads ({dt:.1f} s); single core: {single:.3g} msgs/s",
+            "single_core_value": single}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--instances", type=int, default=4096, help="test instances per GPU per step")
+    ap.add_argument("--cpu-sample", type=int, default=1024, help="instances for the CPU baseline (0 = skip)")
+    ap.add_argument("--seed", type=int, default=2026)
+    ap.add_argument("--no-gather", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from maelstrom_amd import build, engine as E
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if rank == 0:
+        build.build(verbose=False)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.barrier()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    cfg = headline_config(E, args.seed)
+    eng = E.Engine(cfg, device=local_rank)
+    n = args.instances
+
+    def step(k):
+        first = (k * world + rank) * n  # distinct instances for every (step, rank)
+        eng.run(first, n)
+        eng.check()
+
+    def totals():
+        res = eng.check_results()
+        db = eng.device_buffers()
+        stats = torch_view(db.stats, db.stats_bytes, torch.int64, dev).view(-1, 6)
+        meta = torch_view(db.meta, db.meta_bytes, torch.int32, dev).view(-1, 4)
+        msgs = int(stats[:, 0].sum().item())
+        rows = int(meta[:, 0].sum().item())
+        words = int(meta[:, 1].sum().item())
+        flags = int((meta[:, 2] != 0).sum().item())
+        valid = int((res["valid"] == 1).sum())
+        return msgs, rows, words, flags, valid
+
+    def torch_view(ptr, nbytes, dtype, device):
+        class _W:  # zero-copy view of engine-owned HBM through __cuda_array_interface__
+            pass
+        w = _W()
+        w.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+        return torch.as_tensor(w, device=device).view(dtype)
+
+    for k in range(args.warmup):
+        step(k)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    sim_ms, chk_ms, msgs_tot, rows_tot, words_tot, valid_tot, flagged = [], [], 0, 0, 0, 0, 0
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+        a, b = eng.kernel_ms()
+        sim_ms.append(a)
+        chk_ms.append(b)
+        m, r, w, fl, v = totals()
+        msgs_tot += m; rows_tot += r; words_tot += w; flagged += fl; valid_tot += v
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    agg = torch.tensor([msgs_tot, valid_tot, flagged, rows_tot, words_tot], dtype=torch.int64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist:
+        dist.all_reduce(agg)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    msgs_all, valid_all, flagged_all = int(agg[0]), int(agg[1]), int(agg[2])
+
+    gather = None
+    if not args.no_gather:
+        gather = history_gather(eng, torch, dist, dev, world, rank, torch_view)
+
+    if rank == 0:
+        k = args.steps
+        sim_avg = sum(sim_ms) / k
+        chk_avg = sum(chk_ms) / k
+        # algorithmic bytes of one sim launch on this rank: 16 B/row + 4 B/payload word + 48 B stats
+        b_alg = (16.0 * rows_tot + 4.0 * words_tot) / k + 48.0 * n
+        achieved = b_alg / (sim_avg * 1e-3) / 1e9
+        out = {
+            "metric": "simulated_msgs_per_sec (histories/sec passing checker in histories_per_sec)",
+            "value": msgs_all / elapsed,
+            "unit": "msgs/s",
+            "n_gpus": world, "steps": k, "warmup": args.warmup,
+            "ms_per_step": elapsed / k * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "broadcast n=25 x %d instances/GPU (grid, rate 100/s, time-limit 20 s + 10 s quiesce + final reads, latency 0, fire-and-forget gossip)" % n,
+                       "instances_per_gpu": n, "parallelism": "ensemble-dp%d" % world},
+            "histories_per_sec": valid_all / elapsed,
+            "histories_checked": n * k * world, "histories_valid": valid_all, "instances_flagged": flagged_all,
+            "msgs_per_instance": msgs_all / (n * k * world),
+            "kernel_ms": {"sim": sim_avg, "check": chk_avg},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "sim_kernel<BCAST_FF>", "algorithmic_bytes_per_launch": b_alg},
+        }
+        if gather:
+            out["history_gather"] = gather
+        if args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample)
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+def history_gather(eng, torch, dist, dev, world, rank, torch_view):
+    """Variable-length history gather to every rank over RCCL (all_gather of sizes, then of padded
+    compacted buffers); at world=1 this is the on-device compaction only."""
+    db = eng.device_buffers()
+    meta = torch_view(db.meta, db.meta_bytes, torch.int32, dev).view(-1, 4)
+    rows = torch_view(db.rows, db.rows_bytes, torch.int32, dev).view(db.n_instances, db.max_rows, 4)
+    pay = torch_view(db.payload, db.payload_bytes, torch.int32, dev).view(db.n_instances, db.max_payload_words)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nr = meta[:, 0].long()
+    nw = meta[:, 1].long()
+    rmask = torch.arange(db.max_rows, device=dev)[None, :] < nr[:, None]
+    wmask = torch.arange(db.max_payload_words, device=dev)[None, :] < nw[:, None]
+    crow = rows[rmask]          # compacted rows  [sum n_rows, 4] i32
+    cpay = pay[wmask]           # compacted words [sum n_words]
+    sizes = torch.tensor([crow.shape[0], cpay.shape[0]], dtype=torch.int64, device=dev)
+    nbytes = int(crow.numel() * 4 + cpay.numel() * 4)
+    if dist:
+        all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+        dist.all_gather(all_sizes, sizes)
+        mr = max(int(s[0]) for s in all_sizes)
+        mw = max(int(s[1]) for s in all_sizes)
+        prow = torch.zeros((mr, 4), dtype=torch.int32, device=dev); prow[: crow.shape[0]] = crow
+        ppay = torch.zeros((mw,), dtype=torch.int32, device=dev); ppay[: cpay.shape[0]] = cpay
+        out_r = torch.empty((world, mr, 4), dtype=torch.int32, device=dev)
+        out_p = torch.empty((world, mw), dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(out_r, prow)
+        dist.all_gather_into_tensor(out_p, ppay)
+        nbytes = sum(int(s[0]) * 16 + int(s[1]) * 4 for s in all_sizes)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"bytes": nbytes, "ms": dt * 1e3, "GB_per_s": nbytes / dt / 1e9, "ranks": world}
+
+
+if __name__ == "__main__":
+    main()

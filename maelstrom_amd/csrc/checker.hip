@@ -1,3 +1,162 @@
-// checker.hip — placeholder until the device checkers land.
+// checker.hip — workload checkers at ensemble scale, on the device.
+//
+// The reference hands each history to `(checker/check (:checker test) test history opts)` (core.clj:91-100).
+// For broadcast / g-set that is jepsen's `checker/set-full` (workload/broadcast.clj:216-228 maps
+// :broadcast -> :add; workload/g_set.clj:62); for echo the pair comparison of workload/echo.clj:44-63;
+// checker/stats counts ok/fail/info.  [upstream] jepsen.checker/set-full is restated here from its
+// published algorithm (result-map shape: doc/03-broadcast/01-broadcast.md:564-577):
+//   per element: known        = first :ok add completion or first :ok read containing it
+//                last-present = latest-invoked :ok read containing it (by invoke :index)
+//                last-absent  = latest-invoked :ok read (completed after the add's invoke) lacking it
+//   stable  <=> last-present and index(last-absent, -1) < index(last-present)
+//   lost    <=> known and last-absent and index(last-present, -1) < index(last-absent) and index(known) < index(last-absent)
+//   stable-latency = long(nanos->ms(max(0, (time(last-absent)+1 | 0) - time(known))));  stale <=> stable-latency > 0
+//   :valid? = false if any lost, :unknown if nothing stable, else true
+//   :stable-latencies = points {0 .5 .95 .99 1} -> sorted[min(n-1, floor(n*q))]
+//
+// One wavefront checks one history: rows are read back from HBM 64 at a time (1 KiB, coalesced) and
+// walked with v_readlane; lanes = elements (strided), per-element state in LDS owned by lane e%64.
+#include <hip/hip_runtime.h>
+
 #include "engine_internal.h"
-int msim_check_launch(msim_ctx *ctx) { ctx->err = "checker not built yet"; return MSIM_E_UNSUPPORTED; }
+
+#define NONE 0xFFFFFFFFu
+
+struct CParams {
+  const msim_op *rows;
+  const u32 *payload;
+  const msim_inst_meta *meta;
+  msim_check_result *out;
+  u32 max_rows, max_pay, max_values, C, workload;
+};
+
+__device__ __forceinline__ u32 c_rdlane(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ __forceinline__ u32 c_wave_sum(u32 v) {
+  for (int o = 32; o; o >>= 1) v += (u32)__shfl_xor((int)v, o);
+  return v;
+}
+
+__global__ void __launch_bounds__(64) check_kernel(const CParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char csmem[];
+  u32 *const known = reinterpret_cast<u32 *>(csmem);
+  u32 *const lp_idx = known + p.max_values;
+  u32 *const la_idx = lp_idx + p.max_values;
+
+  const u32 lane = threadIdx.x, inst = blockIdx.x;
+  const msim_inst_meta meta = p.meta[inst];
+  const uint4 *const rows = reinterpret_cast<const uint4 *>(p.rows + (size_t)inst * p.max_rows);
+  const u32 *const pay = p.payload + (size_t)inst * p.max_pay;
+  const u32 n_rows = meta.n_rows, C = p.C;
+  const bool setfull = p.workload != MSIM_WL_ECHO;
+
+  for (u32 i = lane; i < p.max_values; i += 64) { known[i] = NONE; lp_idx[i] = NONE; la_idx[i] = NONE; }
+
+  u32 my_inv = NONE, my_val = 0;  // lane t = worker thread t: its pending invoke (reads / echo)
+  u32 v_cur = 0, op_count = 0, n_ok = 0, n_fail = 0, n_info = 0, errors = 0;
+
+  for (u32 base = 0; base < n_rows; base += 64) {
+    const u32 cnt = min(64u, n_rows - base);
+    uint4 r = make_uint4(0, 0, 0, 0);
+    if (lane < cnt) r = rows[base + lane];
+    for (u32 j = 0; j < cnt; j++) {
+      const u32 packed = c_rdlane(r.z, j), value = c_rdlane(r.w, j), hi = c_rdlane(r.y, j);
+      const u32 type = packed & 3, f = (packed >> 2) & 31, process = packed >> 12;
+      if (process == MSIM_PROCESS_NEMESIS) continue;  // (r/filter (comp number? :process))
+      const u32 idx = base + j, t = process % C;
+      if (type == MSIM_T_INVOKE) op_count++; else if (type == MSIM_T_OK) n_ok++; else if (type == MSIM_T_FAIL) n_fail++; else n_info++;
+      if (f == MSIM_F_ADD || f == MSIM_F_BROADCAST) {
+        if (type == MSIM_T_INVOKE) v_cur = max(v_cur, value + 1);
+        else if (type == MSIM_T_OK && value < p.max_values && lane == (value & 63) && known[value] == NONE) known[value] = idx;
+      } else if (f == MSIM_F_READ) {
+        if (type == MSIM_T_INVOKE) { if (lane == t) my_inv = idx; }
+        else if (type == MSIM_T_FAIL) { if (lane == t) my_inv = NONE; }
+        else if (type == MSIM_T_OK) {
+          const u32 inv = c_rdlane(my_inv, t), len = hi >> 16, off = value;
+          for (u32 e = lane; e < v_cur; e += 64) {
+            const u32 w = (e >> 5) < len ? pay[off + (e >> 5)] : 0u;
+            if ((w >> (e & 31)) & 1) {
+              if (known[e] == NONE) known[e] = idx;
+              const u32 lp = lp_idx[e];
+              if (lp == NONE || lp < inv) lp_idx[e] = inv;
+            } else {
+              const u32 la = la_idx[e];
+              if (la == NONE || la < inv) la_idx[e] = inv;
+            }
+          }
+        }
+      } else if (f == MSIM_F_ECHO) {
+        if (type == MSIM_T_INVOKE) { if (lane == t) my_val = value; }
+        else if (type == MSIM_T_OK) { if (c_rdlane(my_val, t) != value) errors++; }  // echo.clj:52-60
+      }
+    }
+  }
+
+  // ---- per-element outcomes ----
+  u32 c_stable = 0, c_lost = 0, c_never = 0, c_stale = 0;
+  for (u32 e = lane; e < v_cur; e += 64) {
+    const u32 k = known[e], lp = lp_idx[e], la = la_idx[e];
+    const bool stable = lp != NONE && (la == NONE || la < lp);
+    const bool lost = k != NONE && la != NONE && (lp == NONE || lp < la) && k < la;
+    u32 lat = NONE;
+    if (stable) {
+      lat = 0;
+      if (la != NONE) {
+        const uint4 ra = rows[la], rk = rows[k];
+        const u64 ta = (((u64)(ra.y & 0xFFFF) << 32) | ra.x) + 1, tk = ((u64)(rk.y & 0xFFFF) << 32) | rk.x;
+        if (ta > tk) lat = (u32)((ta - tk) / 1000000ull);
+      }
+      c_stable++; if (lat > 0) c_stale++;
+    } else if (lost) c_lost++; else c_never++;
+    known[e] = lat;  // reuse: stable latency in ms, NONE if not stable
+  }
+  const u32 n_stable = c_wave_sum(c_stable), n_lost = c_wave_sum(c_lost), n_never = c_wave_sum(c_never), n_stale = c_wave_sum(c_stale);
+
+  // ---- quantiles of the stable latencies: idx-th smallest by bisection on the value ----
+  u32 q[5] = {0, 0, 0, 0, 0};
+  if (n_stable) {
+    const double pts[5] = {0.0, 0.5, 0.95, 0.99, 1.0};
+    for (int qi = 0; qi < 5; qi++) {
+      const u32 want = min(n_stable - 1, (u32)floor((double)n_stable * pts[qi]));
+      u32 lo = 0, hi = 0x7FFFFFFFu;  // smallest v with count(lat <= v) > want
+      while (lo < hi) {
+        const u32 mid = lo + (hi - lo) / 2;
+        u32 c = 0;
+        for (u32 e = lane; e < v_cur; e += 64) { const u32 l = known[e]; c += (l != NONE && l <= mid) ? 1u : 0u; }
+        if (c_wave_sum(c) > want) hi = mid; else lo = mid + 1;
+      }
+      q[qi] = lo;
+    }
+  }
+
+  if (lane == 0) {
+    msim_check_result o;
+    o.attempt_count = v_cur; o.stable_count = n_stable; o.lost_count = n_lost; o.never_read_count = n_never;
+    o.stale_count = n_stale; o.duplicated_count = 0; o.error_count = errors;
+    for (int i = 0; i < 5; i++) o.stable_latency_ms[i] = q[i];
+    o.op_count = op_count; o.ok_count = n_ok; o.fail_count = n_fail; o.info_count = n_info;
+    if (meta.flags) o.valid = 0;
+    else if (!setfull) o.valid = errors == 0 ? 1 : 0;
+    else o.valid = n_lost ? 0u : (n_stable == 0 ? 2u : 1u);
+    p.out[inst] = o;
+  }
+}
+
+int msim_check_launch(msim_ctx *ctx) {
+  MSIM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const msim_config &c = ctx->cfg;
+  CParams cp;
+  cp.rows = ctx->d_rows; cp.payload = ctx->d_payload; cp.meta = ctx->d_meta; cp.out = ctx->d_check;
+  cp.max_rows = c.max_rows; cp.max_pay = c.max_payload_words; cp.max_values = c.max_values; cp.C = c.concurrency; cp.workload = c.workload;
+  const size_t lds = (size_t)c.max_values * 3 * 4;
+  if (lds > 64 * 1024) {
+    MSIM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&check_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  MSIM_HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
+  hipLaunchKernelGGL(check_kernel, dim3(ctx->n_inst), dim3(64), lds, ctx->stream, cp);
+  MSIM_HIP_TRY(ctx, hipGetLastError());
+  MSIM_HIP_TRY(ctx, hipEventRecord(ctx->ev3, ctx->stream));
+  MSIM_HIP_TRY(ctx, hipEventSynchronize(ctx->ev3));
+  MSIM_HIP_TRY(ctx, hipEventElapsedTime(&ctx->check_ms, ctx->ev2, ctx->ev3));
+  ctx->checked = true; ctx->check_fetched = false;
+  return MSIM_OK;
+}

@@ -28,7 +28,7 @@
 
 #define INF 0xFFFFFFFFu
 #define STAGE_ROWS 128u
-#define CLIENT_INBOX_CAP 4u
+#define CLIENT_INBOX_CAP 2u
 #define ROUND_LIMIT 50000000u
 
 // message types (doc/protocol.md, doc/workloads.md)
@@ -732,7 +732,7 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   size_t off = STAGE_ROWS * 16;
   kp.off_inbox = (u32)off; off += ((size_t)kp.N * kp.cap_node + (size_t)kp.CS * CLIENT_INBOX_CAP) * 16;
   kp.off_seen = (u32)off; off += (size_t)kp.N * kp.W * 4; off = (off + 15) & ~(size_t)15;
-  kp.off_misc = (u32)off; off += 64 * 4;
+  kp.off_misc = (u32)off; if (c.nemesis_mask) off += 64 * 4;  // shuffle scratch, only the partition nemesis needs it
   const size_t lds = off;
   if (lds > 160 * 1024) { ctx->err = "cluster state exceeds the 160 KiB LDS of a CU (lower inbox_capacity / max_values)"; return MSIM_E_INVALID; }
 

@@ -155,7 +155,7 @@ class Engine:
         res, n = C.POINTER(A.CheckResult)(), C.c_uint32()
         self._chk(self.lib.msim_check_results(self._ctx, C.byref(res), C.byref(n)), "msim_check_results")
         arr = np.ctypeslib.as_array(C.cast(res, C.POINTER(C.c_uint8)), shape=(n.value * C.sizeof(A.CheckResult),))
-        return arr.view(CHECK_DT)
+        return arr.view(CHECK_DT).copy()  # small; a copy outlives the ctx
 
     # ---- Jepsen-shaped views ---------------------------------------------------------------------
     def history(self, i):

@@ -1,0 +1,69 @@
+"""Device checker (set-full / echo) against the pure-Python restatement of jepsen's algorithm."""
+import numpy as np
+import pytest
+
+from maelstrom_amd import engine as E
+import setfull_ref as R
+
+pytestmark = pytest.mark.gpu
+
+VALID = {1: True, 0: False, 2: "unknown"}
+
+
+def _check(cfg, n):
+    with E.Engine(cfg) as eng:
+        eng.run(0, n)
+        eng.check()
+        eng.fetch()
+        res = eng.check_results()
+        for i in range(n):
+            h = eng.history(i)
+            ref = R.set_full(h)
+            g = res[i]
+            assert VALID[int(g["valid"])] == ref["valid?"], (i, g, ref)
+            for k, rk in (("attempt_count", "attempt-count"), ("stable_count", "stable-count"), ("lost_count", "lost-count"),
+                          ("never_read_count", "never-read-count"), ("stale_count", "stale-count"), ("duplicated_count", "duplicated-count")):
+                assert int(g[k]) == ref[rk], (i, k, int(g[k]), ref[rk])
+            if ref["stable-latencies"]:
+                assert [int(x) for x in g["stable_latency_ms"]] == [ref["stable-latencies"][q] for q in (0, 0.5, 0.95, 0.99, 1)], (i, g, ref)
+            inv = sum(1 for op in h if op["type"] == ":invoke" and op["process"] != ":nemesis")
+            assert int(g["op_count"]) == inv
+        return res
+
+
+def test_set_full_healthy_broadcast(lib):
+    res = _check(E.test_config("broadcast", node_count=5, rate=20, time_limit=5, latency=50, seed=4), 8)
+    assert (res["valid"] == 1).all() and (res["lost_count"] == 0).all()
+
+
+def test_set_full_stale_latencies_n25(lib):
+    res = _check(E.test_config("broadcast", node_count=25, rate=50, time_limit=5, latency=100, latency_dist="exponential", seed=8), 4)
+    assert (res["stale_count"] > 0).all()  # 100 ms hops are visible as stale reads (02-performance.md:205-211)
+
+
+def test_set_full_partitioned_fire_and_forget_loses_or_stales(lib):
+    # fire-and-forget gossip under partitions: messages dropped for good => elements missing on some nodes
+    res = _check(E.test_config("broadcast", bin="broadcast-ff", node_count=5, rate=20, time_limit=20, nemesis=["partition"],
+                               nemesis_interval=3, latency=10, seed=6), 16)
+    assert ((res["lost_count"] > 0) | (res["stale_count"] > 0)).any()
+
+
+def test_set_full_partitioned_retry_is_valid(lib):
+    res = _check(E.test_config("broadcast", bin="broadcast-ack-retry", node_count=5, rate=10, time_limit=20, topology="tree4",
+                               nemesis=["partition"], nemesis_interval=5, latency=10, seed=6), 16)
+    assert (res["valid"] == 1).all() and (res["lost_count"] == 0).all()  # 02-performance.md:519-541
+
+
+def test_g_set_checker(lib):
+    _check(E.test_config("g-set", node_count=5, rate=10, time_limit=10, seed=2), 4)
+
+
+def test_echo_checker(lib):
+    cfg = E.test_config("echo", node_count=3, rate=10, time_limit=5, seed=2)
+    with E.Engine(cfg) as eng:
+        eng.run(0, 8)
+        eng.check()
+        eng.fetch()
+        res = eng.check_results()
+        for i in range(8):
+            assert R.echo_check(eng.history(i))["valid?"] and int(res[i]["valid"]) == 1 and int(res[i]["error_count"]) == 0
