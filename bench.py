@@ -91,23 +91,6 @@ def main():
     eng = E.Engine(cfg, device=local_rank)
     n = args.instances
 
-    def step(k):
-        first = (k * world + rank) * n  # distinct instances for every (step, rank)
-        eng.run(first, n)
-        eng.check()
-
-    def totals():
-        res = eng.check_results()
-        db = eng.device_buffers()
-        stats = torch_view(db.stats, db.stats_bytes, torch.int64, dev).view(-1, 6)
-        meta = torch_view(db.meta, db.meta_bytes, torch.int32, dev).view(-1, 4)
-        msgs = int(stats[:, 0].sum().item())
-        rows = int(meta[:, 0].sum().item())
-        words = int(meta[:, 1].sum().item())
-        flags = int((meta[:, 2] != 0).sum().item())
-        valid = int((res["valid"] == 1).sum())
-        return msgs, rows, words, flags, valid
-
     def torch_view(ptr, nbytes, dtype, device):
         class _W:  # zero-copy view of engine-owned HBM through __cuda_array_interface__
             pass
@@ -115,25 +98,38 @@ def main():
         w.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
         return torch.as_tensor(w, device=device).view(dtype)
 
+    acc = torch.zeros(5, dtype=torch.int64, device=dev)  # msgs, valid histories, flagged, rows, payload words
+
+    def step(k):
+        first = (k * world + rank) * n  # distinct instances for every (step, rank)
+        eng.run(first, n)     # simulate (blocking; kernel time from HIP events inside the library)
+        eng.check()           # set-full over the HBM-resident histories
+        db = eng.device_buffers()
+        stats = torch_view(db.stats, db.stats_bytes, torch.int64, dev).view(-1, 6)
+        meta = torch_view(db.meta, db.meta_bytes, torch.int32, dev).view(-1, 4)
+        chk = torch_view(db.check, db.check_bytes, torch.int32, dev).view(-1, 17)
+        acc.add_(torch.stack([stats[:, 0].sum(), (chk[:, 0] == 1).sum(), (meta[:, 2] != 0).sum(),
+                              meta[:, 0].sum(dtype=torch.int64), meta[:, 1].sum(dtype=torch.int64)]))
+        return eng.kernel_ms()
+
     for k in range(args.warmup):
         step(k)
+    acc.zero_()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
-    sim_ms, chk_ms, msgs_tot, rows_tot, words_tot, valid_tot, flagged = [], [], 0, 0, 0, 0, 0
+    sim_ms, chk_ms = [], []
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(args.warmup + k)
-        a, b = eng.kernel_ms()
+        a, b = step(args.warmup + k)
         sim_ms.append(a)
         chk_ms.append(b)
-        m, r, w, fl, v = totals()
-        msgs_tot += m; rows_tot += r; words_tot += w; flagged += fl; valid_tot += v
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    agg = torch.tensor([msgs_tot, valid_tot, flagged, rows_tot, words_tot], dtype=torch.int64, device=dev)
+    rows_tot, words_tot = int(acc[3]), int(acc[4])
+    agg = acc[:3].clone()
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist:
         dist.all_reduce(agg)

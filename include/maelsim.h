@@ -208,10 +208,11 @@ int msim_check_results(msim_ctx *ctx, const msim_check_result **results, uint32_
 
 /* Device-resident output buffers of the last run, for zero-copy consumers (RCCL gather, GPU checkers).
  * rows: n_instances * max_rows msim_op; payload: n_instances * max_payload_words u32;
- * stats: n_instances msim_net_stats; meta: n_instances msim_inst_meta. */
+ * stats: n_instances msim_net_stats; meta: n_instances msim_inst_meta; check: n_instances msim_check_result. */
 typedef struct msim_device_buffers {
   void *rows; void *payload; void *stats; void *meta;
-  uint64_t rows_bytes, payload_bytes, stats_bytes, meta_bytes;
+  void *check;                 /* n_instances msim_check_result (valid after msim_check) */
+  uint64_t rows_bytes, payload_bytes, stats_bytes, meta_bytes, check_bytes;
   uint32_t n_instances, max_rows, max_payload_words, reserved;
 } msim_device_buffers;
 int msim_device_buffers_get(msim_ctx *ctx, msim_device_buffers *out);

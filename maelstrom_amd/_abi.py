@@ -70,8 +70,9 @@ class CheckResult(C.Structure):
 
 class DeviceBuffers(C.Structure):
     _fields_ = [("rows", C.c_void_p), ("payload", C.c_void_p), ("stats", C.c_void_p), ("meta", C.c_void_p),
+                ("check", C.c_void_p),
                 ("rows_bytes", C.c_uint64), ("payload_bytes", C.c_uint64), ("stats_bytes", C.c_uint64),
-                ("meta_bytes", C.c_uint64), ("n_instances", C.c_uint32), ("max_rows", C.c_uint32),
+                ("meta_bytes", C.c_uint64), ("check_bytes", C.c_uint64), ("n_instances", C.c_uint32), ("max_rows", C.c_uint32),
                 ("max_payload_words", C.c_uint32), ("reserved", C.c_uint32)]
 
 

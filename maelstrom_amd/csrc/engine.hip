@@ -35,7 +35,7 @@
 enum { M_INIT = 1, M_INIT_OK, M_TOPOLOGY, M_TOPOLOGY_OK, M_ECHO, M_ECHO_OK, M_BROADCAST, M_BROADCAST_OK,
        M_READ, M_READ_OK, M_ADD, M_ADD_OK, M_REPLICATE };
 // RNG streams
-enum { S_STAGGER = 1, S_MIX = 2, S_PROC = 3, S_LATENCY = 4, S_LOSS = 5, S_ECHO = 6,
+enum { S_GEN = 1, S_LATENCY = 4, S_LOSS = 5,
        S_NEM_STAGGER = 7, S_NEM_SPEC = 8, S_NEM_SHUFFLE = 9, S_NEM_PICK = 10 };
 enum { PH_INIT, PH_INIT_WAIT, PH_TOPO, PH_TOPO_WAIT, PH_MAIN_START, PH_MAIN, PH_DRAIN, PH_NEM_FINAL,
        PH_SLEEP, PH_FINAL, PH_FINAL_WAIT, PH_DONE };
@@ -64,10 +64,11 @@ __device__ __host__ __forceinline__ u64 mix64(u64 z) {
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
-__device__ __forceinline__ u32 draw32(u64 key, u32 stream, u64 ctr) {
+__device__ __forceinline__ u64 draw64(u64 key, u32 stream, u64 ctr) {
   const u64 x = ((u64)stream << 48) | ctr;
-  return (u32)(mix64(key + x * 0x9E3779B97F4A7C15ull) >> 32);
+  return mix64(key + x * 0x9E3779B97F4A7C15ull);
 }
+__device__ __forceinline__ u32 draw32(u64 key, u32 stream, u64 ctr) { return (u32)(draw64(key, stream, ctr) >> 32); }
 __device__ __forceinline__ u32 scale32(u32 r, u32 n) { return __umulhi(r, n); }
 
 // -ln(u), u = (r+1)/2^32, Q16, integer only
@@ -110,6 +111,17 @@ __device__ __forceinline__ u32 wave_incl_scan(u32 v) {
   return v;
 }
 __device__ __forceinline__ u32 wave_sum(u32 v) { return rdlane(wave_incl_scan(v), 63); }
+// inclusive prefix sum over lanes 0..31 (node lanes); lanes >= 32 hold garbage
+__device__ __forceinline__ u32 scan32(u32 v) {
+  v += dpp_mov<0x111, 0xF, 0xF, true>(0, v);
+  v += dpp_mov<0x112, 0xF, 0xF, true>(0, v);
+  v += dpp_mov<0x114, 0xF, 0xF, true>(0, v);
+  v += dpp_mov<0x118, 0xF, 0xF, true>(0, v);
+  v += dpp_mov<0x142, 0xA, 0xF, false>(0, v);  // row_bcast:15 -> row 1 (and 3)
+  return v;
+}
+// value of `v` in lane `l` (per-lane l; every lane must execute this: ds_bpermute_b32)
+__device__ __forceinline__ u32 lane_get(u32 v, u32 l) { return (u32)__builtin_amdgcn_ds_bpermute((int)(l << 2), (int)v); }
 
 // Reference (shuffle) versions, used only by the self-test to validate the DPP encodings on hardware.
 __device__ u32 wave_min_ref(u32 v) { for (int o = 32; o; o >>= 1) v = min(v, (u32)__shfl_xor((int)v, o)); return v; }
@@ -125,6 +137,8 @@ __global__ void wave_selftest_kernel(const u32 *in, u32 *out) {
   bad |= wave_min(v) != wave_min_ref(v);
   bad |= wave_incl_scan(v & 0xFFFF) != wave_incl_scan_ref(v & 0xFFFF);
   bad |= wave_sum(v & 0xFF) != rdlane(wave_incl_scan_ref(v & 0xFF), 63);
+  bad |= (lane < 32) && scan32(v & 0xFFFF) != wave_incl_scan_ref(v & 0xFFFF);
+  bad |= lane_get(v, (lane * 7 + 3) & 63) != (u32)__shfl((int)v, (int)((lane * 7 + 3) & 63));
   out[blockIdx.x * 64 + lane] = bad;
 }
 
@@ -155,10 +169,20 @@ __device__ __forceinline__ u32 topo_adj(u32 topology, u32 n, u32 a) {
 }
 
 // =====================================================================================================
-// The simulation kernel: one wavefront = one cluster.  PROG = node program (MSIM_NODE_*).
-// Follows DESIGN.md §2 step by step; the CPU oracle implements the same text independently.
+// The simulation kernel: one wavefront = one cluster.  PROG = node program (MSIM_NODE_*), NEM = the
+// partition nemesis is compiled in, NET_RANDOM = latency is drawn per message and/or messages can be lost
+// (false: constant latency, no loss — no per-message RNG in the hot path).  Follows DESIGN.md §2 step by step; the CPU oracle implements the
+// same text independently.
+//
+// One round:
+//   R0 pick the time: stay at T while anything is due, else jump to the next event (DPP min)
+//   R1 scheduler (generator interpreter, nemesis) — wave-uniform, scalar
+//   R2 marked clients invoke -> COMMIT -> idle receivers poll
+//   R3 one input per node (timer or due message) -> COMMIT -> idle receivers poll
+//   R4 clients run their recv! loop -> completion rows
+// so an RPC to an idle node completes inside one round, and a gossip hop costs one round.
 // =====================================================================================================
-template <int PROG>
+template <int PROG, bool NEM, bool NET_RANDOM>
 __global__ void __launch_bounds__(64) sim_kernel(const KParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint4 *const stage = reinterpret_cast<uint4 *>(smem);
@@ -172,7 +196,13 @@ __global__ void __launch_bounds__(64) sim_kernel(const KParams p) {
   constexpr bool IS_GSET = PROG == MSIM_NODE_G_SET;
   constexpr bool IS_ECHO = PROG == MSIM_NODE_ECHO;
   constexpr bool HAS_FINAL = IS_BCAST || IS_GSET;
-  constexpr bool REP_FIRST = IS_ACK;  // ack variant replies before it gossips
+  constexpr bool HAS_TIMERS = IS_ACK || IS_GSET;
+  constexpr bool REP_FIRST = IS_ACK;  // the ack variant replies before it gossips
+  constexpr u32 FAN_TYPE = IS_GSET ? M_REPLICATE : M_BROADCAST;
+  // fan-outs of these programs only ever go to topology neighbours
+  constexpr bool TOPO_BOUND = PROG == MSIM_NODE_BCAST_FF || PROG == MSIM_NODE_BCAST_FF_ECHOBACK || IS_ACK;
+  // programs whose server<->server traffic is plain gossip (no msg_id, no reply): eligible for the cascade loop
+  constexpr bool FAST_OK = PROG == MSIM_NODE_BCAST_FF || PROG == MSIM_NODE_BCAST_FF_ECHOBACK;
 
   const u32 lane = threadIdx.x;
   const u32 inst = blockIdx.x;
@@ -183,11 +213,11 @@ __global__ void __launch_bounds__(64) sim_kernel(const KParams p) {
   const bool is_worker = is_client && slot < C;
   const u64 key = mix64(p.cfg.seed + 0x9E3779B97F4A7C15ull * (p.first_instance + inst + 1));
   const u64 lt_mask = (1ull << lane) - 1;
+  const u32 lt32 = lane < 32 ? ((1u << lane) - 1) : 0xFFFFFFFFu;
   const u64 worker_mask = ((C >= 64 ? ~0ull : ((1ull << C) - 1)) << N);
   const u32 all_nodes = N >= 32 ? 0xFFFFFFFFu : ((1u << N) - 1);
   const u32 max_values = p.cfg.max_values, max_rows = p.cfg.max_rows, max_pay = p.cfg.max_payload_words;
   const u32 p_loss = p.cfg.p_loss_q32, lat_mean = p.cfg.latency_mean_ms, lat_dist = p.cfg.latency_dist;
-  const bool nem_on = (p.cfg.nemesis_mask & MSIM_NEMESIS_PARTITION) != 0;
   const u32 rate = p.cfg.rate_mhz;
 
   msim_op *const g_rows = p.rows + (size_t)inst * max_rows;
@@ -206,293 +236,434 @@ __global__ void __launch_bounds__(64) sim_kernel(const KParams p) {
   __syncthreads();
 
   const u32 adj = is_node ? topo_adj(p.cfg.topology, N, lane) : 0;
+  // which lanes can ever address a fan-out to this node
+  const u32 cand_all = is_node ? (TOPO_BOUND ? adj : (all_nodes & ~(1u << lane))) : 0u;
+  const u32 c_mod_n = C % N;
 
   // ---- per-lane endpoint state ----
-  bool has_c = false; u32 deliver_at = 0; uint4 cm = make_uint4(0, 0, 0, 0);
-  u32 in_n = 0;
+  bool has_c = false; u32 deliver_at = 0; uint4 cm = make_uint4(0, 0, 0, 0);  // the envelope recv! is sleeping on
+  bool have_pm = false; uint4 pm = make_uint4(0, 0, 0, 0);                    // smallest arrival of this commit
+  u32 in_n = 0;                                                               // queued envelopes in LDS
   u32 node_msgid = 0, timer_next = INF, tick = 0, part = 0;
   u32 fifo_head = 0, fifo_tail = 0, retry_time = INF;
   bool busy = false, mark = false; u32 kind = K_NONE;
   u32 want = 0, timeout_at = 0, next_msg_id = 0, c_f = 0, c_value = 0, process = slot, c_final = 0;
+  u32 dest_node = is_client ? slot % N : 0;  // nodes[process mod n] [upstream], kept incrementally
   u32 m_f = 0, m_value = 0, m_final = 0;
   u32 s_send_cl = 0, s_send_sv = 0, s_recv_cl = 0, s_recv_sv = 0, my_flags = 0;
   // ---- wave-uniform state ----
   u32 T = 0, phase = PH_INIT, cutoff = 0, gen_next = 0, gen_k = 0, next_value = 0, nem_next = 0, nem_j = 0;
   u32 sleep_until = 0, loss_on = 0, next_id = 0, n_rows = 0, n_payload = 0, flags = 0, rounds = 0;
 
-  for (;;) {
-    const u64 busy_mask = __ballot(is_client && busy);
-    const bool gen_live = rate > 0 && gen_next < cutoff;
-    const bool nem_live = nem_on && nem_next < cutoff;
-
-    // ---- time-free phase transitions (oracle: sched_resolve) ----
-    for (bool again = true; again;) {
-      again = false;
-      switch (phase) {
-        case PH_INIT_WAIT: if (!busy_mask) { phase = IS_BCAST ? PH_TOPO : PH_MAIN_START; again = true; } break;
-        case PH_TOPO_WAIT: if (!busy_mask) { phase = PH_MAIN_START; again = true; } break;
-        case PH_MAIN_START:
-          cutoff = T + p.cfg.time_limit_ms * 1000u; gen_next = T; nem_next = T;
-          next_msg_id = 0; loss_on = 1; phase = PH_MAIN; again = true; break;
-        case PH_MAIN: {
-          const bool gl = rate > 0 && gen_next < cutoff, nl = nem_on && nem_next < cutoff;
-          if (gl || nl) break;
-          if (rate == 0 && T < cutoff) break;
-          phase = PH_DRAIN; again = true;
-        } break;
-        case PH_DRAIN:
-          if (busy_mask & worker_mask) break;
-          phase = (nem_on && HAS_FINAL) ? PH_NEM_FINAL : HAS_FINAL ? PH_SLEEP : PH_DONE;
-          if (phase == PH_SLEEP) sleep_until = T + p.cfg.quiesce_ms * 1000u;
-          again = true; break;
-        case PH_FINAL_WAIT: if (!(busy_mask & worker_mask)) { phase = PH_DONE; again = true; } break;
-        default: break;
+  // queue an envelope in this lane's LDS inbox
+  auto lds_push = [&](const uint4 m) {
+    if (in_n >= my_cap) { my_flags |= MSIM_FLAG_INBOX_OVERFLOW; return; }
+    my_inbox[in_n++] = m;
+  };
+  // a message addressed to this lane arrives (net.clj:189-221: latency, loss, enqueue)
+  auto arrive = [&](u32 id, u32 type, u32 a, u32 b, u32 src) {
+    u32 lat = 0;
+    if (src < N && is_node) {  // latency only between servers (net.clj:178-187)
+      if (!NET_RANDOM || lat_dist == MSIM_LAT_CONSTANT) lat = lat_mean;
+      else if (lat_dist == MSIM_LAT_UNIFORM) lat = scale32(draw32(key, S_LATENCY, id), 2 * lat_mean);
+      else lat = (u32)(((u64)lat_mean * neg_ln_q16(draw32(key, S_LATENCY, id))) >> 16);
+    }
+    if (NET_RANDOM && loss_on && p_loss && draw32(key, S_LOSS, id) < p_loss) return;  // net.clj:214
+    uint4 m = make_uint4(T + lat * 1000u, (id << 8) | type, a, b | (src << 24));
+    if (!have_pm) { pm = m; have_pm = true; return; }
+    if (m.x < pm.x || (m.x == pm.x && m.y < pm.y)) { const uint4 t = m; m = pm; pm = t; }
+    lds_push(m);
+  };
+  // commit an envelope to this receiver: partition check at poll time (net.clj:234), sleep floor(dt) ms (:236-238)
+  auto try_commit = [&](const uint4 e) {
+    const u32 src = e.w >> 24;
+    if (NEM && is_node && src < N && ((part >> src) & 1)) return;  // dropped, no :recv
+    cm = e; has_c = true;
+    deliver_at = e.x <= T ? T : T + ((e.x - T) / 1000u) * 1000u;
+  };
+  // idle receivers poll (net.clj:223-247): min (deadline, id) over queued + just-arrived envelopes
+  auto poll = [&]() {
+    const bool elig = is_node || busy;  // clients only poll inside recv! (client.clj:94-95)
+    if (have_pm) {
+      have_pm = false;
+      if (elig && !has_c && in_n == 0) try_commit(pm);  // common case: nothing queued, no LDS traffic
+      else lds_push(pm);
+    }
+    while (elig && !has_c && in_n > 0) {
+      u32 best = 0;
+      uint2 bk = *reinterpret_cast<const uint2 *>(&my_inbox[0]);
+      for (u32 i = 1; i < in_n; i++) {
+        const uint2 kk = *reinterpret_cast<const uint2 *>(&my_inbox[i]);
+        if (kk.x < bk.x || (kk.x == bk.x && kk.y < bk.y)) { bk = kk; best = i; }
+      }
+      const uint4 e = my_inbox[best];
+      in_n--;
+      if (best != in_n) my_inbox[best] = my_inbox[in_n];
+      try_commit(e);
+    }
+  };
+  // COMMIT of the nodes' fan-outs, receiver side: every node pulls from the lanes that may address it.
+  // ids = next_id + id_off(sender) + rank of the receiver inside the sender's fan mask (net.clj:197).
+  auto commit_fan = [&](u32 fan_mask, u32 fan_a, u32 fan_b0, u32 id_off) {
+    const u32 send = (u32)__ballot(fan_mask != 0);
+    u32 cand = cand_all & send;
+    while (__ballot(cand != 0)) {
+      const bool has = cand != 0;
+      const u32 s = has ? (u32)__builtin_ctz(cand) : 0u;
+      cand &= cand - 1;
+      const u32 fs = lane_get(fan_mask, s);
+      const u32 as = lane_get(fan_a, s);
+      const u32 os = lane_get(id_off, s);
+      u32 bs = 0;
+      if (IS_RPC) bs = lane_get(fan_b0, s);
+      if (has && ((fs >> lane) & 1)) {
+        const u32 rank = __popc(fs & lt32);
+        arrive(next_id + os + rank, FAN_TYPE, as, IS_RPC ? bs + rank : 0u, s);
       }
     }
-    if (phase == PH_DONE) break;
+  };
+
+  for (;;) {
+    const u64 busy_mask = __ballot(busy);  // only client lanes are ever busy
+
+    // ---- time-free phase transitions (oracle: sched_resolve) ----
+    if (!(phase == PH_MAIN && ((rate > 0 && gen_next < cutoff) || (NEM && nem_next < cutoff)))) {
+      for (bool again = true; again;) {
+        again = false;
+        switch (phase) {
+          case PH_INIT_WAIT: if (!busy_mask) { phase = IS_BCAST ? PH_TOPO : PH_MAIN_START; again = true; } break;
+          case PH_TOPO_WAIT: if (!busy_mask) { phase = PH_MAIN_START; again = true; } break;
+          case PH_MAIN_START:
+            cutoff = T + p.cfg.time_limit_ms * 1000u; gen_next = T; nem_next = T;
+            next_msg_id = 0; loss_on = 1; phase = PH_MAIN; again = true; break;
+          case PH_MAIN: {
+            const bool gl = rate > 0 && gen_next < cutoff, nl = NEM && nem_next < cutoff;
+            if (gl || nl) break;
+            if (rate == 0 && T < cutoff) break;
+            phase = PH_DRAIN; again = true;
+          } break;
+          case PH_DRAIN:
+            if (busy_mask & worker_mask) break;
+            phase = (NEM && HAS_FINAL) ? PH_NEM_FINAL : HAS_FINAL ? PH_SLEEP : PH_DONE;
+            if (phase == PH_SLEEP) sleep_until = T + p.cfg.quiesce_ms * 1000u;
+            again = true; break;
+          case PH_FINAL_WAIT: if (!(busy_mask & worker_mask)) { phase = PH_DONE; again = true; } break;
+          default: break;
+        }
+      }
+      if (phase == PH_DONE) break;
+    }
     if (++rounds > ROUND_LIMIT) { flags |= MSIM_FLAG_ROUND_LIMIT; break; }
 
-    // ---- R0: next event time ----
-    const bool gen_live2 = rate > 0 && gen_next < cutoff;
-    const bool nem_live2 = nem_on && nem_next < cutoff;
+    // ---- R0: time ----
+    const bool gen_live = rate > 0 && gen_next < cutoff;
+    const bool nem_live = NEM && nem_next < cutoff;
     const u64 free_mask = worker_mask & ~busy_mask;
     u32 due = INF;
     switch (phase) {
       case PH_INIT: case PH_TOPO: case PH_NEM_FINAL: case PH_FINAL: due = T; break;
       case PH_SLEEP: due = sleep_until; break;
       case PH_MAIN:
-        if (nem_live2) due = max(nem_next, T);
-        if (gen_live2 && free_mask) due = min(due, max(gen_next, T));
-        if (rate == 0 && !nem_live2) due = min(due, cutoff);
+        if (nem_live) due = max(nem_next, T);
+        if (gen_live && free_mask) due = min(due, max(gen_next, T));
+        if (rate == 0 && !nem_live) due = min(due, cutoff);
         break;
       default: break;
     }
-    u32 k = INF;
-    if (has_c) k = deliver_at * 2;
-    if (is_node) { const u32 t = min(timer_next, retry_time); if (t != INF) k = min(k, t * 2); }
-    if (is_client && busy) k = min(k, timeout_at * 2 + 1);
-    u32 km = wave_min(k);
-    if (due != INF) km = min(km, due * 2);
-    if (km == INF) { flags |= MSIM_FLAG_ROUND_LIMIT; break; }  // stuck
-    const bool timeout_round = (km & 1) != 0;
-    T = max(T, km >> 1);
-    (void)gen_live; (void)nem_live;
-
-    // ---- R1: scheduler (generator interpreter, nemesis) — wave-uniform ----
-    u32 nem_rows = 0, nem_f = 0, nem_v1 = 0, nem_v2 = 0, nem_len2 = 0;
-    if (!timeout_round && due <= T) {
-      switch (phase) {
-        case PH_INIT: if (is_client && slot < N) { mark = true; kind = K_INIT; } phase = PH_INIT_WAIT; break;
-        case PH_TOPO: if (is_client && slot < N) { mark = true; kind = K_TOPO; } phase = PH_TOPO_WAIT; break;
-        case PH_MAIN: {
-          if (nem_live2 && nem_next <= T) {
-            const u32 j = nem_j++;
-            nem_rows = 2;
-            if ((j & 1) == 0) {  // :start-partition (jepsen.nemesis.combined partition-package, restated)
-              const u32 spec = scale32(draw32(key, S_NEM_SPEC, j), 4);
-              // shuffle (Fisher-Yates) in LDS by lane 0; every node lane then derives its own grudge row
-              if (lane < N) misc[lane] = lane;
-              __syncthreads();
-              if (lane == 0 && spec != MSIM_SPEC_ONE) {
-                for (u32 i = N - 1; i >= 1; i--) {
-                  const u32 kk = scale32(draw32(key, S_NEM_SHUFFLE, ((u64)j << 16) | i), i + 1);
-                  const u32 t = misc[i]; misc[i] = misc[kk]; misc[kk] = t;
-                }
-              }
-              __syncthreads();
-              u32 my_part = 0;
-              if (is_node) {
-                if (spec == MSIM_SPEC_ONE) {
-                  const u32 loner = scale32(draw32(key, S_NEM_PICK, j), N);
-                  my_part = lane == loner ? (all_nodes & ~(1u << loner)) : (1u << loner);
-                } else if (spec == MSIM_SPEC_MAJORITY || spec == MSIM_SPEC_MINORITY_THIRD) {
-                  const u32 cnt = spec == MSIM_SPEC_MAJORITY ? N / 2 : (N - 1) / 3;
-                  u32 comp = 0;
-                  for (u32 i = 0; i < cnt; i++) comp |= 1u << misc[i];
-                  my_part = ((comp >> lane) & 1) ? (all_nodes & ~comp) : comp;
-                } else {  // majorities-ring
-                  const u32 m = N / 2 + 1;
-                  u32 pos = 0;
-                  for (u32 i = 0; i < N; i++) if (misc[i] == lane) pos = i;
-                  const u32 i0 = (pos + N - (m / 2) % N) % N;
-                  u32 vis = 0;
-                  for (u32 kk = 0; kk < m; kk++) vis |= 1u << misc[(i0 + kk) % N];
-                  my_part = all_nodes & ~vis;
-                }
-              }
-              part |= my_part;
-              const u32 words = N * MSIM_MASK_WORDS;
-              u32 off = 0;
-              if (n_payload + words > max_pay) flags |= MSIM_FLAG_PAYLOAD_OVERFLOW;
-              else {
-                off = n_payload; n_payload += words;
-                if (is_node) { g_pay[off + lane * 4] = part; g_pay[off + lane * 4 + 1] = 0; g_pay[off + lane * 4 + 2] = 0; g_pay[off + lane * 4 + 3] = 0; }
-              }
-              nem_f = MSIM_F_START_PARTITION; nem_v1 = spec; nem_v2 = off; nem_len2 = words;
-            } else {  // :stop-partition -> heal! (net.clj:112-113)
-              part = 0;
-              nem_f = MSIM_F_STOP_PARTITION; nem_v1 = MSIM_NO_VALUE; nem_v2 = MSIM_NO_VALUE; nem_len2 = 0;
-            }
-            nem_next = T + __umulhi(draw32(key, S_NEM_STAGGER, j), p.nem_period2_us);
-          }
-          if (gen_live2 && gen_next <= T && free_mask) {
-            const u32 nfree = __popcll(free_mask);
-            const u32 kk = gen_k++;
-            const u32 pick = scale32(draw32(key, S_PROC, kk), nfree);
-            const bool sel = is_worker && !busy && (u32)__popcll(free_mask & lt_mask) == pick;
-            u32 f, val = MSIM_NO_VALUE;
-            bool ok = true;
-            if (IS_ECHO) { f = MSIM_F_ECHO; val = scale32(draw32(key, S_ECHO, kk), 128); }
-            else if (draw32(key, S_MIX, kk) >> 31) f = MSIM_F_READ;
-            else {
-              f = IS_BCAST ? MSIM_F_BROADCAST : MSIM_F_ADD;
-              if (next_value >= max_values) { flags |= MSIM_FLAG_VALUES_OVERFLOW; ok = false; }
-              else val = next_value++;
-            }
-            if (!ok) { phase = PH_DONE; break; }
-            if (sel) { mark = true; kind = K_OP; m_f = f; m_value = val; m_final = 0; }
-            gen_next = T + __umulhi(draw32(key, S_STAGGER, kk), p.gen_period2_us);
-          }
-        } break;
-        case PH_NEM_FINAL:
-          part = 0; nem_rows = 2; nem_f = MSIM_F_STOP_PARTITION; nem_v1 = MSIM_NO_VALUE; nem_v2 = MSIM_NO_VALUE;
-          phase = PH_SLEEP; sleep_until = T + p.cfg.quiesce_ms * 1000u; break;
-        case PH_SLEEP:
-          if (T < sleep_until) break;
-          phase = PH_FINAL;
-          [[fallthrough]];
-        case PH_FINAL:
-          if (is_worker) { mark = true; kind = K_OP; m_f = MSIM_F_READ; m_value = MSIM_NO_VALUE; m_final = IS_BCAST ? 1 : 0; }
-          phase = PH_FINAL_WAIT; break;
-        default: break;
-      }
-      if (phase == PH_DONE) break;
+    u32 my_t = has_c ? deliver_at : INF;  // this lane's next "normal" event
+    if (HAS_TIMERS && is_node) my_t = min(my_t, min(timer_next, retry_time));
+    bool timeout_round = false;
+    if (due > T && !__ballot(my_t <= T)) {  // nothing due now: jump to the next event
+      u32 k = my_t == INF ? INF : my_t * 2;
+      if (busy) k = min(k, timeout_at * 2 + 1);
+      u32 km = wave_min(k);
+      if (due != INF) km = min(km, due * 2);
+      if (km == INF) { flags |= MSIM_FLAG_ROUND_LIMIT; break; }  // stuck
+      timeout_round = (km & 1) != 0;
+      T = max(T, km >> 1);
     }
 
-    // ---- R2: one input per endpoint ----
-    u32 fan_mask = 0, fan_type = 0, fan_a = 0, fan_b0 = 0;
-    bool rep = false; u32 rep_dest = 0, rep_type = 0, rep_a = 0, rep_b = 0;
-    bool row = false; u32 row_packed = 0, row_value = 0, row_len = 0;
-    bool rd = false;
+    bool inv_row = false; u32 inv_packed = 0, inv_value = 0;               // invoke row of this round
+    bool cmp_row = false; u32 cmp_packed = 0, cmp_value = 0, cmp_len = 0;  // completion row of this round
+    u32 nem_rows = 0, nem_f = 0, nem_v1 = 0, nem_v2 = 0, nem_len2 = 0;
 
     // completion of a client op (oracle: client_complete)
     auto complete = [&](u32 type, u32 err, u32 value, u32 len) {
       busy = false;
       if (kind != K_OP) { if (type != MSIM_T_OK) my_flags |= MSIM_FLAG_ROUND_LIMIT; return; }
-      row = true; row_packed = type | (c_f << 2) | (err << 7) | (c_final << 11) | (process << 12);
-      row_value = value; row_len = len;
-      if (type == MSIM_T_INFO) { process += C; next_msg_id = 0; in_n = 0; }
+      cmp_row = true; cmp_packed = type | (c_f << 2) | (err << 7) | (c_final << 11) | (process << 12);
+      cmp_value = value; cmp_len = len;
+      if (type == MSIM_T_INFO) {  // crashed process: new process id, fresh client [upstream interpreter]
+        process += C; dest_node += c_mod_n; if (dest_node >= N) dest_node -= N;
+        next_msg_id = 0; in_n = 0;
+      }
     };
 
     if (timeout_round) {
-      if (is_client && busy && timeout_at <= T) {  // client.clj:96-103 + :158-162
+      if (busy && timeout_at <= T) {  // client.clj:96-103 + :158-162
         const bool idem = IS_BCAST && c_f == MSIM_F_READ;
         complete(idem ? MSIM_T_FAIL : MSIM_T_INFO, MSIM_ERR_NET_TIMEOUT, c_f == MSIM_F_READ ? MSIM_NO_VALUE : c_value, 0);
       }
-    } else if (is_node) {
-      if (IS_GSET && timer_next <= T) {  // g_set.rb:33-38
-        timer_next = T + 5000000u;
-        u32 *snap = g_scr + ((size_t)tick * N + lane) * W;
-        for (u32 w = 0; w < W; w++) snap[w] = my_seen[w];
-        fan_mask = all_nodes & ~(1u << lane); fan_type = M_REPLICATE; fan_a = tick; tick++;
-      } else if (IS_ACK && retry_time <= T) {  // gossip thread wakes (02-performance.md:421-438)
-        const u32 slot_i = (fifo_head % max_values) * 2;
-        const u32 v = g_fifo[slot_i];
-        fifo_head++;
-        const u32 un = g_unacked[v];
-        if (un) {
-          fan_mask = un; fan_type = M_BROADCAST; fan_a = v; fan_b0 = node_msgid + 1; node_msgid += __popc(un);
-          const u32 ts = (fifo_tail % max_values) * 2;
-          g_fifo[ts] = v; g_fifo[ts + 1] = T + 1000000u; fifo_tail++;
-        }
-        retry_time = fifo_head < fifo_tail ? g_fifo[(fifo_head % max_values) * 2 + 1] : INF;
-      } else if (has_c && deliver_at <= T) {
-        const uint4 q = cm; has_c = false;
-        const u32 qsrc = q.w >> 24, qb = q.w & 0xFFFFFFu, qtype = q.y & 0xFFu, qa = q.z;
-        if (qsrc >= N) s_recv_cl++; else s_recv_sv++;  // journal :recv (net.clj:244)
-        switch (qtype) {
-          case M_INIT:
-            if (IS_GSET) timer_next = T;
-            rep = true; rep_dest = qsrc; rep_type = M_INIT_OK; rep_b = qb; break;
-          case M_TOPOLOGY: rep = true; rep_dest = qsrc; rep_type = M_TOPOLOGY_OK; rep_b = qb; break;
-          case M_ECHO: rep = true; rep_dest = qsrc; rep_type = M_ECHO_OK; rep_a = qa; rep_b = qb; break;
-          case M_READ: rd = true; rep = true; rep_dest = qsrc; rep_type = M_READ_OK; rep_b = qb; break;
-          case M_ADD: my_seen[qa >> 5] |= 1u << (qa & 31); rep = true; rep_dest = qsrc; rep_type = M_ADD_OK; rep_a = qa; rep_b = qb; break;
-          case M_REPLICATE: {
-            const u32 *snap = g_scr + ((size_t)qa * N + qsrc) * W;
-            for (u32 w = 0; w < W; w++) my_seen[w] |= snap[w];
-          } break;
-          case M_BROADCAST: {
-            const u32 v = qa, bitm = 1u << (v & 31);
-            const u32 wv = my_seen[v >> 5];
-            if (!(wv & bitm)) {
-              my_seen[v >> 5] = wv | bitm;
-              u32 tg = PROG == MSIM_NODE_BCAST_RPC_ALL ? (all_nodes & ~(1u << lane)) : adj;
-              if (PROG != MSIM_NODE_BCAST_FF_ECHOBACK && qsrc < N) tg &= ~(1u << qsrc);
-              fan_mask = tg; fan_type = M_BROADCAST; fan_a = v;
-              if (IS_RPC) { fan_b0 = node_msgid + 1; node_msgid += __popc(tg); }
-              if (IS_ACK && tg) {
-                g_unacked[v] = tg;
-                const u32 ts = (fifo_tail % max_values) * 2;
-                g_fifo[ts] = v; g_fifo[ts + 1] = T + 1000000u;
-                if (fifo_head == fifo_tail) retry_time = T + 1000000u;
-                fifo_tail++;
+    } else {
+      // ---- R1: scheduler (generator interpreter, nemesis) — wave-uniform ----
+      if (due <= T) {
+        switch (phase) {
+          case PH_INIT: if (is_client && slot < N) { mark = true; kind = K_INIT; } phase = PH_INIT_WAIT; break;
+          case PH_TOPO: if (is_client && slot < N) { mark = true; kind = K_TOPO; } phase = PH_TOPO_WAIT; break;
+          case PH_MAIN: {
+            if (NEM && nem_live && nem_next <= T) {
+              const u32 j = nem_j++;
+              nem_rows = 2;
+              if ((j & 1) == 0) {  // :start-partition (jepsen.nemesis.combined partition-package, restated)
+                const u32 spec = scale32(draw32(key, S_NEM_SPEC, j), 4);
+                // shuffle (Fisher-Yates) in LDS by lane 0; every node lane then derives its own grudge row
+                if (lane < N) misc[lane] = lane;
+                __syncthreads();
+                if (lane == 0 && spec != MSIM_SPEC_ONE) {
+                  for (u32 i = N - 1; i >= 1; i--) {
+                    const u32 kk = scale32(draw32(key, S_NEM_SHUFFLE, ((u64)j << 16) | i), i + 1);
+                    const u32 t = misc[i]; misc[i] = misc[kk]; misc[kk] = t;
+                  }
+                }
+                __syncthreads();
+                u32 my_part = 0;
+                if (is_node) {
+                  if (spec == MSIM_SPEC_ONE) {
+                    const u32 loner = scale32(draw32(key, S_NEM_PICK, j), N);
+                    my_part = lane == loner ? (all_nodes & ~(1u << loner)) : (1u << loner);
+                  } else if (spec == MSIM_SPEC_MAJORITY || spec == MSIM_SPEC_MINORITY_THIRD) {
+                    const u32 cnt = spec == MSIM_SPEC_MAJORITY ? N / 2 : (N - 1) / 3;
+                    u32 comp = 0;
+                    for (u32 i = 0; i < cnt; i++) comp |= 1u << misc[i];
+                    my_part = ((comp >> lane) & 1) ? (all_nodes & ~comp) : comp;
+                  } else {  // majorities-ring
+                    const u32 m = N / 2 + 1;
+                    u32 pos = 0;
+                    for (u32 i = 0; i < N; i++) if (misc[i] == lane) pos = i;
+                    const u32 i0 = (pos + N - (m / 2) % N) % N;
+                    u32 vis = 0;
+                    for (u32 kk = 0; kk < m; kk++) vis |= 1u << misc[(i0 + kk) % N];
+                    my_part = all_nodes & ~vis;
+                  }
+                }
+                part |= my_part;
+                const u32 words = N * MSIM_MASK_WORDS;
+                u32 off = 0;
+                if (n_payload + words > max_pay) flags |= MSIM_FLAG_PAYLOAD_OVERFLOW;
+                else {
+                  off = n_payload; n_payload += words;
+                  if (is_node) { g_pay[off + lane * 4] = part; g_pay[off + lane * 4 + 1] = 0; g_pay[off + lane * 4 + 2] = 0; g_pay[off + lane * 4 + 3] = 0; }
+                }
+                nem_f = MSIM_F_START_PARTITION; nem_v1 = spec; nem_v2 = off; nem_len2 = words;
+              } else {  // :stop-partition -> heal! (net.clj:112-113)
+                part = 0;
+                nem_f = MSIM_F_STOP_PARTITION; nem_v1 = MSIM_NO_VALUE; nem_v2 = MSIM_NO_VALUE; nem_len2 = 0;
               }
+              nem_next = T + __umulhi(draw32(key, S_NEM_STAGGER, j), p.nem_period2_us);
             }
-            if (qb != 0) { rep = true; rep_dest = qsrc; rep_type = M_BROADCAST_OK; rep_a = v; rep_b = qb; }
+            if (gen_live && gen_next <= T && free_mask) {
+              // one 64-bit draw per generated op: high word -> stagger, low word -> pick / mix / echo payload
+              const u32 nfree = __popcll(free_mask);
+              const u32 kk = gen_k++;
+              const u64 h = draw64(key, S_GEN, kk);
+              const u32 r_hi = (u32)(h >> 32), r_lo = (u32)h;
+              const u32 pick = scale32(r_lo, nfree);
+              const bool sel = is_worker && !busy && (u32)__popcll(free_mask & lt_mask) == pick;
+              u32 f, val = MSIM_NO_VALUE;
+              bool ok = true;
+              if (IS_ECHO) { f = MSIM_F_ECHO; val = (r_lo >> 4) & 127; }
+              else if (r_lo & 1) f = MSIM_F_READ;
+              else {
+                f = IS_BCAST ? MSIM_F_BROADCAST : MSIM_F_ADD;
+                if (next_value >= max_values) { flags |= MSIM_FLAG_VALUES_OVERFLOW; ok = false; }
+                else val = next_value++;
+              }
+              if (!ok) { phase = PH_DONE; break; }
+              if (sel) { mark = true; kind = K_OP; m_f = f; m_value = val; m_final = 0; }
+              gen_next = T + __umulhi(r_hi, p.gen_period2_us);
+            }
           } break;
-          case M_BROADCAST_OK: if (IS_ACK) g_unacked[qa] &= ~(1u << qsrc); break;
+          case PH_NEM_FINAL:
+            part = 0; nem_rows = 2; nem_f = MSIM_F_STOP_PARTITION; nem_v1 = MSIM_NO_VALUE; nem_v2 = MSIM_NO_VALUE;
+            phase = PH_SLEEP; sleep_until = T + p.cfg.quiesce_ms * 1000u; break;
+          case PH_SLEEP:
+            if (T < sleep_until) break;
+            phase = PH_FINAL;
+            [[fallthrough]];
+          case PH_FINAL:
+            if (is_worker) { mark = true; kind = K_OP; m_f = MSIM_F_READ; m_value = MSIM_NO_VALUE; m_final = IS_BCAST ? 1 : 0; }
+            phase = PH_FINAL_WAIT; break;
           default: break;
         }
+        if (phase == PH_DONE) break;
       }
-    } else if (is_client) {
-      if (has_c && deliver_at <= T) {
-        const uint4 q = cm; has_c = false;
-        s_recv_cl++;
-        const u32 qb = q.w & 0xFFFFFFu, qtype = q.y & 0xFFu, qa = q.z;
-        if (busy && qb == want) {  // else: stale reply (client.clj:105-107)
-          if (qtype == M_READ_OK) complete(MSIM_T_OK, 0, qa & 0xFFFFFFu, qa >> 24);
-          else if (qtype == M_ECHO_OK) complete(MSIM_T_OK, 0, qa, 0);
-          else complete(MSIM_T_OK, 0, c_value, 0);
+
+      // ---- R2: marked clients invoke; COMMIT (ids in slot order); idle receivers poll ----
+      u64 inv_mask = __ballot(mark);
+      if (inv_mask) {
+        u32 rq_dest = 0, rq_type = 0, rq_a = 0;
+        if (mark) {  // oracle: client_invoke
+          mark = false; busy = true;
+          if (kind == K_INIT) { rq_dest = slot; rq_type = M_INIT; next_msg_id = 0; }
+          else if (kind == K_TOPO) { rq_dest = slot; rq_type = M_TOPOLOGY; next_msg_id = 0; }
+          else {
+            c_f = m_f; c_value = m_value; c_final = m_final;
+            rq_dest = dest_node;
+            inv_row = true; inv_packed = MSIM_T_INVOKE | (c_f << 2) | (c_final << 11) | (process << 12); inv_value = c_value;
+            rq_type = c_f == MSIM_F_ECHO ? M_ECHO : c_f == MSIM_F_BROADCAST ? M_BROADCAST : c_f == MSIM_F_ADD ? M_ADD : M_READ;
+            rq_a = c_f == MSIM_F_READ ? 0u : c_value;
+          }
+          want = ++next_msg_id;
+          timeout_at = T + (kind == K_OP ? p.cfg.client_timeout_ms : 10000u) * 1000u;
+          s_send_cl++;
         }
-      } else if (mark) {  // oracle: client_invoke
-        mark = false; busy = true;
-        u32 dest, type, a = 0;
-        if (kind == K_INIT) { dest = slot; type = M_INIT; next_msg_id = 0; }
-        else if (kind == K_TOPO) { dest = slot; type = M_TOPOLOGY; next_msg_id = 0; }
-        else {
-          c_f = m_f; c_value = m_value; c_final = m_final;
-          dest = process % N;
-          row = true; row_packed = MSIM_T_INVOKE | (c_f << 2) | (c_final << 11) | (process << 12); row_value = c_value; row_len = 0;
-          switch (c_f) {
-            case MSIM_F_ECHO: type = M_ECHO; a = c_value; break;
-            case MSIM_F_BROADCAST: type = M_BROADCAST; a = c_value; break;
-            case MSIM_F_ADD: type = M_ADD; a = c_value; break;
-            default: type = M_READ; break;
+        const u32 rq_pack = rq_dest | (rq_type << 8);
+        while (inv_mask) {
+          const u32 s = (u32)__builtin_ctzll(inv_mask); inv_mask &= inv_mask - 1;
+          const u32 pk = rdlane(rq_pack, s);
+          const u32 a = rdlane(rq_a, s), b = rdlane(want, s);
+          if (lane == (pk & 0xFF)) arrive(next_id, pk >> 8, a, b, s);
+          next_id++;
+        }
+        poll();
+      }
+
+      // ---- R3: one input per node: a due timer, else the due committed envelope ----
+      u32 fan_mask = 0, fan_a = 0, fan_b0 = 0;
+      bool rep = false; u32 rep_dest = 0, rep_type = 0, rep_a = 0, rep_b = 0;
+      bool rd = false;
+      if (is_node) {
+        if (IS_GSET && timer_next <= T) {  // g_set.rb:33-38
+          timer_next = T + 5000000u;
+          u32 *snap = g_scr + ((size_t)tick * N + lane) * W;
+          for (u32 w = 0; w < W; w++) snap[w] = my_seen[w];
+          fan_mask = all_nodes & ~(1u << lane); fan_a = tick; tick++;
+        } else if (IS_ACK && retry_time <= T) {  // gossip thread wakes (02-performance.md:421-438)
+          const u32 slot_i = (fifo_head % max_values) * 2;
+          const u32 v = g_fifo[slot_i];
+          fifo_head++;
+          const u32 un = g_unacked[v];
+          if (un) {
+            fan_mask = un; fan_a = v; fan_b0 = node_msgid + 1; node_msgid += __popc(un);
+            const u32 ts = (fifo_tail % max_values) * 2;
+            g_fifo[ts] = v; g_fifo[ts + 1] = T + 1000000u; fifo_tail++;
+          }
+          retry_time = fifo_head < fifo_tail ? g_fifo[(fifo_head % max_values) * 2 + 1] : INF;
+        } else if (has_c && deliver_at <= T) {
+          const uint4 q = cm; has_c = false;
+          const u32 qsrc = q.w >> 24, qb = q.w & 0xFFFFFFu, qtype = q.y & 0xFFu, qa = q.z;
+          if (qsrc >= N) s_recv_cl++; else s_recv_sv++;  // journal :recv (net.clj:244)
+          switch (qtype) {
+            case M_INIT:
+              if (IS_GSET) timer_next = T;
+              rep = true; rep_dest = qsrc; rep_type = M_INIT_OK; rep_b = qb; break;
+            case M_TOPOLOGY: rep = true; rep_dest = qsrc; rep_type = M_TOPOLOGY_OK; rep_b = qb; break;
+            case M_ECHO: rep = true; rep_dest = qsrc; rep_type = M_ECHO_OK; rep_a = qa; rep_b = qb; break;
+            case M_READ: rd = true; rep = true; rep_dest = qsrc; rep_type = M_READ_OK; rep_b = qb; break;
+            case M_ADD: my_seen[qa >> 5] |= 1u << (qa & 31); rep = true; rep_dest = qsrc; rep_type = M_ADD_OK; rep_a = qa; rep_b = qb; break;
+            case M_REPLICATE: {
+              const u32 *snap = g_scr + ((size_t)qa * N + qsrc) * W;
+              for (u32 w = 0; w < W; w++) my_seen[w] |= snap[w];
+            } break;
+            case M_BROADCAST: {
+              const u32 v = qa, bitm = 1u << (v & 31);
+              const u32 wv = my_seen[v >> 5];
+              if (!(wv & bitm)) {
+                my_seen[v >> 5] = wv | bitm;
+                u32 tg = PROG == MSIM_NODE_BCAST_RPC_ALL ? (all_nodes & ~(1u << lane)) : adj;
+                if (PROG != MSIM_NODE_BCAST_FF_ECHOBACK && qsrc < N) tg &= ~(1u << qsrc);
+                fan_mask = tg; fan_a = v;
+                if (IS_RPC) { fan_b0 = node_msgid + 1; node_msgid += __popc(tg); }
+                if (IS_ACK && tg) {
+                  g_unacked[v] = tg;
+                  const u32 ts = (fifo_tail % max_values) * 2;
+                  g_fifo[ts] = v; g_fifo[ts + 1] = T + 1000000u;
+                  if (fifo_head == fifo_tail) retry_time = T + 1000000u;
+                  fifo_tail++;
+                }
+              }
+              if (qb != 0) { rep = true; rep_dest = qsrc; rep_type = M_BROADCAST_OK; rep_a = v; rep_b = qb; }
+            } break;
+            case M_BROADCAST_OK: if (IS_ACK) g_unacked[qa] &= ~(1u << qsrc); break;
+            default: break;
           }
         }
-        want = ++next_msg_id;
-        timeout_at = T + (kind == K_OP ? p.cfg.client_timeout_ms : 10000u) * 1000u;
-        rep = true; rep_dest = dest; rep_type = type; rep_a = a; rep_b = want;
+      }
+
+      // read results: the whole wave copies the node's set LDS -> HBM payload (256 B per instruction)
+      {
+        u64 rdmask = __ballot(rd);
+        if (rdmask) {
+          __syncthreads();
+          const u32 words = (next_value + 31) >> 5;
+          while (rdmask) {
+            const u32 r = (u32)__builtin_ctzll(rdmask); rdmask &= rdmask - 1;
+            u32 off = 0;
+            if (n_payload + words > max_pay) flags |= MSIM_FLAG_PAYLOAD_OVERFLOW;
+            else {
+              off = n_payload; n_payload += words;
+              for (u32 w = lane; w < words; w += 64) g_pay[off + w] = seen[r * W + w];
+            }
+            if (lane == r) rep_a = off | (words << 24);
+          }
+        }
+      }
+
+      // COMMIT node sends (net.clj:189-221): ids in node order, then emission order
+      {
+        const u32 fan_cnt = __popc(fan_mask);
+        const u32 cnt = fan_cnt + (rep ? 1u : 0u);
+        if (__ballot(cnt != 0)) {
+          const u32 incl = scan32(cnt);  // senders are node lanes (< 32)
+          if (is_node) { s_send_sv += fan_cnt; if (rep) { if (rep_dest >= N) s_send_cl++; else s_send_sv++; } }
+          if (__ballot(fan_mask != 0)) commit_fan(fan_mask, fan_a, fan_b0, incl - cnt + ((REP_FIRST && rep) ? 1u : 0u));
+          u64 reps = __ballot(rep);
+          if (reps) {
+            const u32 rep_pack = rep_dest | (rep_type << 8);
+            const u32 rep_off = incl - cnt + (REP_FIRST ? 0u : fan_cnt);
+            while (reps) {
+              const u32 s = (u32)__builtin_ctzll(reps); reps &= reps - 1;
+              const u32 pk = rdlane(rep_pack, s), o = rdlane(rep_off, s);
+              const u32 r_a = rdlane(rep_a, s), r_b = rdlane(rep_b, s);
+              if (lane == (pk & 0xFF)) arrive(next_id + o, pk >> 8, r_a, r_b, s);
+            }
+          }
+          next_id += rdlane(incl, 31);
+        }
+        poll();  // every round: a node that just went idle may still have queued envelopes
+      }
+
+      // ---- R4: clients run their recv! loop (client.clj:94-107) ----
+      if (__ballot(is_client && has_c)) {
+        while (is_client && has_c && deliver_at <= T) {
+          const uint4 q = cm; has_c = false;
+          s_recv_cl++;
+          const u32 qb = q.w & 0xFFFFFFu, qtype = q.y & 0xFFu, qa = q.z;
+          if (busy && qb == want) {  // else: stale reply, keep polling (client.clj:105-107)
+            if (qtype == M_READ_OK) complete(MSIM_T_OK, 0, qa & 0xFFFFFFu, qa >> 24);
+            else if (qtype == M_ECHO_OK) complete(MSIM_T_OK, 0, qa, 0);
+            else complete(MSIM_T_OK, 0, c_value, 0);
+          }
+          poll();
+        }
       }
     }
 
-    // ---- history rows: canonical order = nemesis rows, then client slots ascending ----
+    // ---- history rows: canonical order = nemesis rows, invokes (slot order), completions (slot order) ----
     {
-      const u64 rmask = __ballot(row);
-      const u32 nr = nem_rows + (u32)__popcll(rmask);
+      const u64 imask = __ballot(inv_row), cmask = __ballot(cmp_row);
+      const u32 ni = (u32)__popcll(imask);
+      const u32 nr = nem_rows + ni + (u32)__popcll(cmask);
       if (nr) {
         if (n_rows + nr > max_rows) { flags |= MSIM_FLAG_ROWS_OVERFLOW; break; }
         const u32 tlo = (u32)((u64)T * 1000ull), thi = (u32)(((u64)T * 1000ull) >> 32);
-        if (nem_rows && lane == 0) {
+        if (NEM && nem_rows && lane == 0) {
           const u32 pk = MSIM_T_INFO | (nem_f << 2) | (MSIM_PROCESS_NEMESIS << 12);
           stage[n_rows % STAGE_ROWS] = make_uint4(tlo, thi, pk, nem_v1);
           stage[(n_rows + 1) % STAGE_ROWS] = make_uint4(tlo, thi | (nem_len2 << 16), pk, nem_v2);
         }
-        if (row) {
-          const u32 idx = n_rows + nem_rows + (u32)__popcll(rmask & lt_mask);
-          stage[idx % STAGE_ROWS] = make_uint4(tlo, thi | (row_len << 16), row_packed, row_value);
-        }
+        if (inv_row) stage[(n_rows + nem_rows + (u32)__popcll(imask & lt_mask)) % STAGE_ROWS] = make_uint4(tlo, thi, inv_packed, inv_value);
+        if (cmp_row) stage[(n_rows + nem_rows + ni + (u32)__popcll(cmask & lt_mask)) % STAGE_ROWS] = make_uint4(tlo, thi | (cmp_len << 16), cmp_packed, cmp_value);
         const u32 new_n = n_rows + nr;
         if ((new_n >> 6) != (n_rows >> 6)) {  // a 64-row block completed: coalesced 1 KiB append to HBM
           __syncthreads();
@@ -506,91 +677,46 @@ __global__ void __launch_bounds__(64) sim_kernel(const KParams p) {
       }
     }
 
-    // ---- read results: the whole wave copies the node's set LDS -> HBM payload ----
-    {
-      u64 rdmask = __ballot(rd);
-      if (rdmask) {
-        __syncthreads();
-        const u32 words = (next_value + 31) >> 5;
-        while (rdmask) {
-          const u32 r = (u32)__builtin_ctzll(rdmask); rdmask &= rdmask - 1;
-          u32 off = 0;
-          if (n_payload + words > max_pay) flags |= MSIM_FLAG_PAYLOAD_OVERFLOW;
-          else {
-            off = n_payload; n_payload += words;
-            for (u32 w = lane; w < words; w += 64) g_pay[off + w] = seen[r * W + w];
-          }
-          if (lane == r) rep_a = off | (words << 24);
+    // ---- cascade loop: while the scheduler is quiet at T and only plain gossip is due, every round is
+    //      R3 + COMMIT + poll (no scheduler, no clients, no rows).  Same rounds the loop above would run. ----
+    if (FAST_OK && !timeout_round) {
+      const u64 bm = __ballot(busy);
+      bool quiet = false;
+      if (phase == PH_MAIN) {
+        const bool gl = rate > 0 && gen_next < cutoff, nl = NEM && nem_next < cutoff;
+        if (gl || nl) {
+          u32 d2 = INF;
+          if (nl) d2 = max(nem_next, T);
+          if (gl && (worker_mask & ~bm)) d2 = min(d2, max(gen_next, T));
+          quiet = d2 > T;
         }
-      }
-    }
-
-    // ---- R3: commit sends (net.clj:189-221).  ids: endpoint order, then emission order ----
-    {
-      const u32 fan_cnt = __popc(fan_mask);
-      const u32 cnt = fan_cnt + (rep ? 1u : 0u);
-      u64 senders = __ballot(cnt > 0);
-      if (senders) {
-        const u32 incl = wave_incl_scan(cnt);
-        const u32 excl = incl - cnt;
-        const u32 total = rdlane(incl, 63);
-        if (is_node) { s_send_sv += fan_cnt; if (rep) { if (rep_dest >= N) s_send_cl++; else s_send_sv++; } }
-        else if (rep) s_send_cl++;
-        const u32 rep_pack = rep ? (1u | (rep_dest << 8) | (rep_type << 16)) : 0u;
-
-        auto push = [&](u32 id, u32 type, u32 a, u32 b, u32 src) {
-          u32 lat = 0;
-          if (src < N && is_node) {  // latency only between servers (net.clj:178-187)
-            if (lat_dist == MSIM_LAT_CONSTANT) lat = lat_mean;
-            else if (lat_dist == MSIM_LAT_UNIFORM) lat = scale32(draw32(key, S_LATENCY, id), 2 * lat_mean);
-            else lat = (u32)(((u64)lat_mean * neg_ln_q16(draw32(key, S_LATENCY, id))) >> 16);
-          }
-          if (loss_on && p_loss && draw32(key, S_LOSS, id) < p_loss) return;  // net.clj:214
-          if (in_n >= my_cap) { my_flags |= MSIM_FLAG_INBOX_OVERFLOW; return; }
-          my_inbox[in_n++] = make_uint4(T + lat * 1000u, (id << 8) | type, a, b | (src << 24));
-        };
-
-        while (senders) {
-          const u32 s = (u32)__builtin_ctzll(senders); senders &= senders - 1;
-          const u32 f_mask = rdlane(fan_mask, s);
-          const u32 base = next_id + rdlane(excl, s);
-          const u32 r_pack = rdlane(rep_pack, s);
-          const u32 f_cnt = __popc(f_mask);
-          if (f_mask) {
-            const u32 f_type = rdlane(fan_type, s), f_a = rdlane(fan_a, s), f_b0 = rdlane(fan_b0, s);
-            if (lane < 32 && ((f_mask >> lane) & 1)) {
-              const u32 rank = __popc(f_mask & ((1u << lane) - 1));
-              const u32 kk = rank + ((REP_FIRST && (r_pack & 1)) ? 1u : 0u);
-              push(base + kk, f_type, f_a, f_b0 ? f_b0 + rank : 0u, s);
-            }
-          }
-          if (r_pack & 1) {
-            const u32 r_a = rdlane(rep_a, s), r_b = rdlane(rep_b, s);
-            if (lane == ((r_pack >> 8) & 0xFF)) push(base + (REP_FIRST ? 0u : f_cnt), (r_pack >> 16) & 0xFF, r_a, r_b, s);
+      } else if (phase == PH_SLEEP) quiet = sleep_until > T;
+      while (quiet) {
+        const bool due_now = has_c && deliver_at <= T;  // only node lanes hold an envelope across rounds
+        if (!__ballot(due_now)) break;
+        const bool plain = (cm.y & 0xFFu) == M_BROADCAST && (cm.w & 0xFFFFFFu) == 0;
+        if (__ballot(due_now && !plain)) break;
+        if (++rounds > ROUND_LIMIT) { flags |= MSIM_FLAG_ROUND_LIMIT; phase = PH_DONE; break; }
+        const u32 v = cm.z;
+        u32 fan = 0;
+        if (due_now) {
+          has_c = false; s_recv_sv++;
+          const u32 wv = my_seen[v >> 5], bitm = 1u << (v & 31);
+          if (!(wv & bitm)) {
+            my_seen[v >> 5] = wv | bitm;
+            fan = PROG == MSIM_NODE_BCAST_FF_ECHOBACK ? adj : (adj & ~(1u << (cm.w >> 24)));
           }
         }
-        next_id += total;
-      }
-    }
-
-    // ---- R4: idle receivers poll (net.clj:223-247) ----
-    {
-      const bool elig = is_node || (is_client && busy);
-      while (elig && !has_c && in_n > 0) {
-        u32 best = 0;
-        uint2 bk = *reinterpret_cast<const uint2 *>(&my_inbox[0]);
-        for (u32 i = 1; i < in_n; i++) {
-          const uint2 kk = *reinterpret_cast<const uint2 *>(&my_inbox[i]);
-          if (kk.x < bk.x || (kk.x == bk.x && kk.y < bk.y)) { bk = kk; best = i; }
+        if (__ballot(fan != 0)) {
+          const u32 cnt = __popc(fan);
+          const u32 incl = scan32(cnt);
+          s_send_sv += cnt;
+          commit_fan(fan, v, 0, incl - cnt);
+          next_id += rdlane(incl, 31);
         }
-        const uint4 e = my_inbox[best];
-        in_n--;
-        if (best != in_n) my_inbox[best] = my_inbox[in_n];
-        const u32 src = e.w >> 24;
-        if (is_node && src < N && ((part >> src) & 1)) continue;  // partitioned: dropped, no :recv (:234)
-        cm = e; has_c = true;
-        deliver_at = e.x <= T ? T : T + ((e.x - T) / 1000u) * 1000u;  // (Thread/sleep (long dt)) :236-238
+        poll();
       }
+      if (phase == PH_DONE) break;
     }
   }
 
@@ -700,14 +826,20 @@ static int ensure_buffers(msim_ctx *ctx, uint32_t n) {
   return MSIM_OK;
 }
 
-template <int PROG>
-static hipError_t launch(const KParams &kp, uint32_t n, size_t lds, hipStream_t st) {
+template <int PROG, bool NEM, bool NET_RANDOM>
+static hipError_t launch3(const KParams &kp, uint32_t n, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sim_kernel<PROG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sim_kernel<PROG, NEM, NET_RANDOM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(sim_kernel<PROG>, dim3(n), dim3(64), lds, st, kp);
+  hipLaunchKernelGGL((sim_kernel<PROG, NEM, NET_RANDOM>), dim3(n), dim3(64), lds, st, kp);
   return hipGetLastError();
+}
+template <int PROG>
+static hipError_t launch(const KParams &kp, uint32_t n, size_t lds, hipStream_t st) {
+  const bool rnd = kp.cfg.latency_dist != MSIM_LAT_CONSTANT || kp.cfg.p_loss_q32 != 0;
+  if (kp.cfg.nemesis_mask) return rnd ? launch3<PROG, true, true>(kp, n, lds, st) : launch3<PROG, true, false>(kp, n, lds, st);
+  return rnd ? launch3<PROG, false, true>(kp, n, lds, st) : launch3<PROG, false, false>(kp, n, lds, st);
 }
 
 static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, bool blocking) {
@@ -857,6 +989,7 @@ extern "C" int msim_device_buffers_get(msim_ctx *ctx, msim_device_buffers *out) 
   if (!ctx->ran) { ctx->err = "no run yet"; return MSIM_E_RANGE; }
   const msim_config &c = ctx->cfg;
   out->rows = ctx->d_rows; out->payload = ctx->d_payload; out->stats = ctx->d_stats; out->meta = ctx->d_meta;
+  out->check = ctx->d_check; out->check_bytes = (uint64_t)ctx->n_inst * sizeof(msim_check_result);
   out->rows_bytes = (uint64_t)ctx->n_inst * c.max_rows * sizeof(msim_op);
   out->payload_bytes = (uint64_t)ctx->n_inst * c.max_payload_words * 4;
   out->stats_bytes = (uint64_t)ctx->n_inst * sizeof(msim_net_stats);

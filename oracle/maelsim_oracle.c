@@ -58,7 +58,7 @@ enum { M_INIT = 1, M_INIT_OK, M_TOPOLOGY, M_TOPOLOGY_OK, M_ECHO, M_ECHO_OK, M_BR
        M_READ, M_READ_OK, M_ADD, M_ADD_OK, M_REPLICATE };
 
 /* RNG streams */
-enum { S_STAGGER = 1, S_MIX = 2, S_PROC = 3, S_LATENCY = 4, S_LOSS = 5, S_ECHO = 6,
+enum { S_GEN = 1, S_LATENCY = 4, S_LOSS = 5,
        S_NEM_STAGGER = 7, S_NEM_SPEC = 8, S_NEM_SHUFFLE = 9, S_NEM_PICK = 10 };
 
 enum { PH_INIT, PH_INIT_WAIT, PH_TOPO, PH_TOPO_WAIT, PH_MAIN_START, PH_MAIN, PH_DRAIN, PH_NEM_FINAL,
@@ -109,10 +109,11 @@ static u64 mix64(u64 z) {
   return z ^ (z >> 31);
 }
 static u64 inst_key(u64 seed, u64 instance) { return mix64(seed + 0x9E3779B97F4A7C15ull * (instance + 1)); }
-static u32 draw32(const sim_t *s, u32 stream, u64 ctr) {
+static u64 draw64(const sim_t *s, u32 stream, u64 ctr) {
   u64 x = ((u64)stream << 48) | ctr;
-  return (u32)(mix64(s->key + x * 0x9E3779B97F4A7C15ull) >> 32);
+  return mix64(s->key + x * 0x9E3779B97F4A7C15ull);
 }
+static u32 draw32(const sim_t *s, u32 stream, u64 ctr) { return (u32)(draw64(s, stream, ctr) >> 32); }
 static u32 scale32(u32 r, u32 n) { return (u32)(((u64)r * n) >> 32); } /* uniform int in [0, n) */
 
 /* -ln(u) in Q16 for u = (r+1)/2^32, integer-only (table + linear interpolation of log2). */
@@ -464,19 +465,23 @@ static void sched_act(sim_t *s) {
       if (gen_live(s) && s->gen_next <= T) {
         u32 nfree = 0; for (u32 i = 0; i < s->C; i++) nfree += !s->cl[i].busy;
         if (nfree) {
+          /* one 64-bit draw per generated op k: high word -> stagger delay, low word -> process pick
+           * (top bits), gen/mix choice (bit 0), echo payload (bits 4..10) */
           u32 k = s->gen_k++;
-          u32 pick = scale32(draw32(s, S_PROC, k), nfree), slot = 0;
+          u64 h = draw64(s, S_GEN, k);
+          u32 r_hi = (u32)(h >> 32), r_lo = (u32)h;
+          u32 pick = scale32(r_lo, nfree), slot = 0;
           for (u32 i = 0; i < s->C; i++) if (!s->cl[i].busy) { if (pick == 0) { slot = i; break; } pick--; }
           struct cl *c = &s->cl[slot];
           c->mark = 1; c->kind = K_OP; c->m_final = 0;
-          if (s->cfg.workload == MSIM_WL_ECHO) { c->m_f = MSIM_F_ECHO; c->m_value = scale32(draw32(s, S_ECHO, k), 128); } /* echo.clj:72-75 */
-          else if (draw32(s, S_MIX, k) >> 31) { c->m_f = MSIM_F_READ; c->m_value = MSIM_NO_VALUE; }  /* gen/mix */
+          if (s->cfg.workload == MSIM_WL_ECHO) { c->m_f = MSIM_F_ECHO; c->m_value = (r_lo >> 4) & 127; } /* echo.clj:72-75 */
+          else if (r_lo & 1) { c->m_f = MSIM_F_READ; c->m_value = MSIM_NO_VALUE; }  /* gen/mix */
           else {
             c->m_f = s->cfg.workload == MSIM_WL_BROADCAST ? MSIM_F_BROADCAST : MSIM_F_ADD;
             if (s->next_value >= s->cfg.max_values) { s->meta.flags |= MSIM_FLAG_VALUES_OVERFLOW; c->mark = 0; s->phase = PH_DONE; return; }
             c->m_value = s->next_value++;
           }
-          s->gen_next = T + stagger_us(s, S_STAGGER, k, period); /* gen/stagger (/ rate), core.clj:68 */
+          s->gen_next = T + (u32)(((u64)r_hi * (2 * period)) >> 32); /* gen/stagger (/ rate), core.clj:68 */
         }
       }
       break;
@@ -492,6 +497,40 @@ static void sched_act(sim_t *s) {
 }
 
 /* ---- one instance --------------------------------------------------------------------------------- */
+
+/* commit the round's staged sends in canonical order (net.clj:189-221) */
+static void commit_sends(sim_t *s) {
+  u32 N = s->N, T = s->T;
+  for (u32 i = 0; i < s->n_out; i++) {
+    outmsg *m = &s->out[i];
+    u32 id = s->next_msg_id++;
+    int cl = m->src_ep >= N || m->dest_ep >= N;
+    s->st.all_send++; if (cl) s->st.clients_send++; else s->st.servers_send++; /* journal :send before loss */
+    u32 lat = latency_ms(s, id, cl);
+    if (s->loss_on && s->cfg.p_loss_q32 && draw32(s, S_LOSS, id) < s->cfg.p_loss_q32) continue; /* net.clj:214 */
+    qent q = {T + lat * 1000u, id, m->a, m->b, m->src_ep, m->type};
+    inbox_push(s, m->dest_ep, q);
+  }
+  s->n_out = 0;
+}
+
+/* an idle receiver polls: take the min-(deadline,id) envelope even if not due (net.clj:228-229), drop it
+ * if the partition says so (:234), else sleep floor(dt) ms (:236-238). */
+static void poll_endpoint(sim_t *s, u32 e) {
+  u32 N = s->N, T = s->T;
+  if (e >= N && !s->cl[e - N].busy) return; /* clients only poll inside recv! (client.clj:94-95) */
+  inbox_t *b = &s->inbox[e];
+  while (!s->has_committed[e] && b->n) {
+    u32 k = 0;
+    for (u32 i = 1; i < b->n; i++)
+      if (b->v[i].deadline < b->v[k].deadline || (b->v[i].deadline == b->v[k].deadline && b->v[i].id < b->v[k].id)) k = i;
+    qent q = b->v[k]; b->v[k] = b->v[--b->n];
+    if (e < N && q.src < N && bit(s->part[e], q.src)) continue; /* partitioned: dropped, no :recv */
+    s->committed[e] = q; s->has_committed[e] = 1;
+    s->deliver_at[e] = q.deadline <= T ? T : T + ((q.deadline - T) / 1000u) * 1000u;
+  }
+}
+
 static void run_instance(sim_t *s) {
   u32 N = s->N, E = s->E;
   for (;;) {
@@ -514,54 +553,35 @@ static void run_instance(sim_t *s) {
 
     if (timeout_round) {
       for (u32 c = 0; c < s->CS; c++) if (s->cl[c].busy && s->cl[c].timeout_at <= T) client_timeout(s, c);
-    } else {
-      /* R1: scheduler */
-      if (sched_due(s) <= T) sched_act(s);
-      if (s->phase == PH_DONE) break;
-      /* R2: one input per endpoint, endpoint-index order */
-      for (u32 n = 0; n < N; n++) {
-        if (node_timer_time(s, n) <= T) node_timer(s, n);
-        else if (s->has_committed[n] && s->deliver_at[n] <= T) {
-          qent q = s->committed[n]; s->has_committed[n] = 0;
-          s->st.all_recv++; if (q.src >= N) s->st.clients_recv++; else s->st.servers_recv++; /* journal :recv */
-          node_handle(s, n, &q);
-        }
-      }
-      for (u32 c = 0; c < s->CS; c++) {
-        u32 e = N + c;
-        if (s->has_committed[e] && s->deliver_at[e] <= T) {
-          qent q = s->committed[e]; s->has_committed[e] = 0;
-          s->st.all_recv++; s->st.clients_recv++;
-          client_deliver(s, c, &q);
-        } else if (s->cl[c].mark) client_invoke(s, c);
+      continue;
+    }
+    /* R1: scheduler (generator interpreter + nemesis) */
+    if (sched_due(s) <= T) sched_act(s);
+    if (s->phase == PH_DONE) break;
+    /* R2: marked clients invoke (slot order); their requests are committed and idle receivers poll */
+    for (u32 c = 0; c < s->CS; c++) if (s->cl[c].mark) client_invoke(s, c);
+    commit_sends(s);
+    for (u32 e = 0; e < E; e++) poll_endpoint(s, e);
+    /* R3: one input per node (node order): a due timer, else the due committed message */
+    for (u32 n = 0; n < N; n++) {
+      if (node_timer_time(s, n) <= T) node_timer(s, n);
+      else if (s->has_committed[n] && s->deliver_at[n] <= T) {
+        qent q = s->committed[n]; s->has_committed[n] = 0;
+        s->st.all_recv++; if (q.src >= N) s->st.clients_recv++; else s->st.servers_recv++; /* journal :recv */
+        node_handle(s, n, &q);
       }
     }
-
-    /* R3: commit sends in canonical order (net.clj:189-221) */
-    for (u32 i = 0; i < s->n_out; i++) {
-      outmsg *m = &s->out[i];
-      u32 id = s->next_msg_id++;
-      int cl = m->src_ep >= N || m->dest_ep >= N;
-      s->st.all_send++; if (cl) s->st.clients_send++; else s->st.servers_send++; /* journal :send before loss */
-      u32 lat = latency_ms(s, id, cl);
-      if (s->loss_on && s->cfg.p_loss_q32 && draw32(s, S_LOSS, id) < s->cfg.p_loss_q32) continue; /* net.clj:214 */
-      qent q = {T + lat * 1000u, id, m->a, m->b, m->src_ep, m->type};
-      inbox_push(s, m->dest_ep, q);
-    }
-
-    /* R4: idle receivers poll: take the min-(deadline,id) envelope even if not due (net.clj:228-229),
-     * drop it if the partition says so (:234), else sleep floor(dt) ms (:236-238). */
-    for (u32 e = 0; e < E; e++) {
-      if (e >= N && !s->cl[e - N].busy) continue; /* clients only poll inside recv! (client.clj:94-95) */
-      inbox_t *b = &s->inbox[e];
-      while (!s->has_committed[e] && b->n) {
-        u32 k = 0;
-        for (u32 i = 1; i < b->n; i++)
-          if (b->v[i].deadline < b->v[k].deadline || (b->v[i].deadline == b->v[k].deadline && b->v[i].id < b->v[k].id)) k = i;
-        qent q = b->v[k]; b->v[k] = b->v[--b->n];
-        if (e < N && q.src < N && bit(s->part[e], q.src)) continue; /* partitioned: dropped, no :recv */
-        s->committed[e] = q; s->has_committed[e] = 1;
-        s->deliver_at[e] = q.deadline <= T ? T : T + ((q.deadline - T) / 1000u) * 1000u;
+    commit_sends(s);
+    for (u32 e = 0; e < E; e++) poll_endpoint(s, e);
+    /* R4: clients (slot order) run their recv! loop: consume due envelopes until the awaited reply
+     * arrives; stale replies are skipped (client.clj:94-107) */
+    for (u32 c = 0; c < s->CS; c++) {
+      u32 e = N + c;
+      while (s->has_committed[e] && s->deliver_at[e] <= T) {
+        qent q = s->committed[e]; s->has_committed[e] = 0;
+        s->st.all_recv++; s->st.clients_recv++;
+        client_deliver(s, c, &q);
+        poll_endpoint(s, e);
       }
     }
   }

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Summarises a rocprofv3 rocpd (sqlite) result: per-kernel dispatch statistics (what `--stats` prints)
+and per-kernel PMC counter sums.  Usage: tools/rocpd_summary.py <results.db> [more.db ...]"""
+import sqlite3
+import sys
+
+
+def table(con, prefix):
+    return [r[0] for r in con.execute("select name from sqlite_master where type='table'") if r[0].startswith(prefix)][0]
+
+
+def summarise(path):
+    con = sqlite3.connect(path)
+    kd, ks = table(con, "rocpd_kernel_dispatch"), table(con, "rocpd_info_kernel_symbol")
+    print(f"== {path}")
+    print(f"{'kernel':60s} {'calls':>6s} {'total_ms':>10s} {'avg_ms':>10s} {'min_ms':>10s} {'max_ms':>10s} {'lds':>6s} {'vgpr':>5s} {'sgpr':>5s}")
+    q = (f"select s.display_name, count(*), sum(d.end-d.start), avg(d.end-d.start), min(d.end-d.start), max(d.end-d.start), "
+         f"max(d.group_segment_size), max(s.arch_vgpr_count), max(s.sgpr_count) from '{kd}' d join '{ks}' s on d.kernel_id = s.id "
+         f"group by s.display_name order by 3 desc")
+    for name, n, tot, avg, mn, mx, lds, vg, sg in con.execute(q):
+        print(f"{name[:60]:60s} {n:6d} {tot/1e6:10.3f} {avg/1e6:10.4f} {mn/1e6:10.4f} {mx/1e6:10.4f} {lds:6d} {vg:5d} {sg:5d}")
+    try:
+        pe, pi = table(con, "rocpd_pmc_event"), table(con, "rocpd_info_pmc")
+        q = (f"select s.display_name, i.name, count(*), sum(e.value), avg(e.value) from '{pe}' e join '{pi}' i on e.pmc_id = i.id "
+             f"join '{kd}' d on e.event_id = d.event_id join '{ks}' s on d.kernel_id = s.id group by 1, 2 order by 1, 2")
+        rows = list(con.execute(q))
+        if rows:
+            print("-- PMC counters (sum over dispatches / per-dispatch average)")
+            for name, ctr, n, tot, avg in rows:
+                print(f"{name[:60]:60s} {ctr:24s} n={n:4d} sum={tot:.6g} avg={avg:.6g}")
+    except Exception as e:  # no counters collected in this pass
+        print(f"-- no PMC data ({e.__class__.__name__}: {e})")
+
+
+if __name__ == "__main__":
+    for p in sys.argv[1:]:
+        summarise(p)
