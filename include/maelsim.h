@@ -223,6 +223,10 @@ int msim_last_kernel_ms(msim_ctx *ctx, float *sim_ms, float *check_ms);
 /* The finalized configuration the ctx runs with. */
 int msim_get_config(const msim_ctx *ctx, msim_config *out);
 
+/* Diagnostic: validates the engine's DPP wave primitives against shuffle-based references on `device`.
+ * 0 = ok, >0 = mismatching lanes, <0 = MSIM_E_*. */
+int msim_selftest_wave(int device);
+
 const char *msim_last_error(const msim_ctx *ctx);
 void msim_destroy(msim_ctx *ctx);
 

@@ -32,7 +32,7 @@ EXPORTS = [
     "msim_abi_version", "msim_device_count", "msim_config_defaults", "msim_config_finalize", "msim_create",
     "msim_run", "msim_run_async", "msim_check", "msim_fetch", "msim_history", "msim_net_stats_get", "msim_meta",
     "msim_check_results", "msim_device_buffers_get", "msim_last_kernel_ms", "msim_get_config",
-    "msim_last_error", "msim_destroy",
+    "msim_selftest_wave", "msim_last_error", "msim_destroy",
 ]
 
 
@@ -110,6 +110,8 @@ def load():
     lib.msim_get_config.argtypes = [C.c_void_p, P(Config)]
     lib.msim_last_error.argtypes = [C.c_void_p]
     lib.msim_last_error.restype = C.c_char_p
+    lib.msim_selftest_wave.argtypes = [C.c_int]
+    lib.msim_selftest_wave.restype = C.c_int
     lib.msim_destroy.argtypes = [C.c_void_p]
     lib.msim_destroy.restype = None
     for name in ("msim_config_defaults", "msim_config_finalize", "msim_create", "msim_run", "msim_run_async",

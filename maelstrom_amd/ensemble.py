@@ -1,0 +1,56 @@
+"""Multi-GPU ensemble plumbing: instances are independent, so the hot path shards with no
+data-path collective — rank r simulates a contiguous block of global instance ids.  The only exchange is
+the end-of-batch, variable-length gather of the emitted histories (RCCL over xGMI on GPUs; the same code
+runs over gloo on CPU tensors in tests/test_ensemble_gloo.py).
+"""
+import torch
+
+
+def shard(n_total, rank, world):
+    """Contiguous block of global instance ids for `rank`: (first, count).  Blocks differ by at most one."""
+    base, rem = divmod(n_total, world)
+    count = base + (1 if rank < rem else 0)
+    first = rank * base + min(rank, rem)
+    return first, count
+
+
+def compact(rows, payload, meta):
+    """Drops the unused tail of every instance's slab.
+    rows [n, max_rows, 4] i32, payload [n, max_words] i32, meta [n, 4] i32 (n_rows, n_words, flags, rounds)
+    -> (rows [sum n_rows, 4], payload [sum n_words], n_rows [n] i64, n_words [n] i64)."""
+    nr = meta[:, 0].long()
+    nw = meta[:, 1].long()
+    rmask = torch.arange(rows.shape[1], device=rows.device)[None, :] < nr[:, None]
+    wmask = torch.arange(payload.shape[1], device=payload.device)[None, :] < nw[:, None]
+    return rows[rmask], payload[wmask], nr, nw
+
+
+def gather_histories(crow, cpay, nr, nw, dist=None, world=1):
+    """All-gathers compacted histories of every rank.  Returns per-rank lists
+    (rows_r [R_r, 4], payload_r [W_r], n_rows_r [n_r], n_words_r [n_r]) in rank order, and the byte count moved."""
+    if dist is None or world == 1:
+        return [(crow, cpay, nr, nw)], int(crow.numel() * 4 + cpay.numel() * 4)
+    dev = crow.device
+    sizes = torch.tensor([crow.shape[0], cpay.shape[0], nr.shape[0]], dtype=torch.int64, device=dev)
+    all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes)
+    mr = max(int(s[0]) for s in all_sizes)
+    mw = max(int(s[1]) for s in all_sizes)
+    mi = max(int(s[2]) for s in all_sizes)
+
+    def padded(t, n, shape_tail=()):
+        out = torch.zeros((n,) + shape_tail, dtype=t.dtype, device=dev)
+        out[: t.shape[0]] = t
+        return out
+    bufs = []
+    for t, n, tail in ((crow, mr, (4,)), (cpay, mw, ()), (nr, mi, ()), (nw, mi, ())):
+        mine = padded(t, n, tail)
+        out = torch.empty((world * mine.numel(),), dtype=t.dtype, device=dev)
+        dist.all_gather_into_tensor(out, mine.reshape(-1))  # one flat collective per buffer
+        bufs.append(out.view((world,) + tuple(mine.shape)))
+    res = []
+    for r in range(world):
+        a, b, c = (int(x) for x in all_sizes[r])
+        res.append((bufs[0][r, :a], bufs[1][r, :b], bufs[2][r, :c], bufs[3][r, :c]))
+    nbytes = sum(int(s[0]) * 16 + int(s[1]) * 4 for s in all_sizes)
+    return res, nbytes

@@ -590,15 +590,12 @@ static void run_instance(sim_t *s) {
 
 /* ---- public entry points (loaded by tests via ctypes) --------------------------------------------- */
 
-/* Simulates global instance `instance` of `cfg` (already finalized: capacities non-zero).
- * rows: max_rows entries; payload: max_payload_words words.  Returns 0, or -1 on a bad config. */
-int oracle_run_instance(const msim_config *cfg, uint64_t instance, msim_op *rows, uint32_t *payload,
-                        msim_net_stats *stats, msim_inst_meta *meta) {
-  if (cfg->n_nodes == 0 || cfg->n_nodes > MAXN || cfg->concurrency == 0) return -1;
+static sim_t *sim_new(const msim_config *cfg, uint64_t instance, msim_op *rows, uint32_t *payload) {
+  if (cfg->n_nodes == 0 || cfg->n_nodes > MAXN || cfg->concurrency == 0) return NULL;
   sim_t *s = (sim_t *)calloc(1, sizeof(sim_t));
   s->cfg = *cfg;
   s->N = cfg->n_nodes; s->C = cfg->concurrency; s->CS = s->C > s->N ? s->C : s->N; s->E = s->N + s->CS;
-  if (s->E > 255) { free(s); return -1; }
+  if (s->E > 255) { free(s); return NULL; }
   s->W = (cfg->max_values + 31) / 32;
   s->key = inst_key(cfg->seed, instance);
   s->next_msg_id = 0; /* net.clj:103,197: counter starts at -1 and is pre-incremented: first id 0 */
@@ -618,14 +615,68 @@ int oracle_run_instance(const msim_config *cfg, uint64_t instance, msim_op *rows
   for (u32 i = 0; i < s->CS; i++) s->cl[i].process = i;
   s->rows = rows; s->payload = payload;
   s->phase = PH_INIT;
-  run_instance(s);
-  *stats = s->st; *meta = s->meta;
+  return s;
+}
+
+static void sim_free(sim_t *s) {
   for (u32 e = 0; e < s->E; e++) free(s->inbox[e].v);
   for (u32 n = 0; n < s->N; n++) free(s->tasks[n].v);
   for (u32 i = 0; i < s->n_snap; i++) free(s->snap[i]);
   free(s->snap); free(s->inbox); free(s->committed); free(s->has_committed); free(s->deliver_at); free(s->seen);
   free(s->unacked); free(s->node_msg_id); free(s->nbr_known); free(s->tasks); free(s->timer_next); free(s->cl); free(s->out);
   free(s);
+}
+
+/* Simulates global instance `instance` of `cfg` (already finalized: capacities non-zero).
+ * rows: max_rows entries; payload: max_payload_words words.  Returns 0, or -1 on a bad config. */
+int oracle_run_instance(const msim_config *cfg, uint64_t instance, msim_op *rows, uint32_t *payload,
+                        msim_net_stats *stats, msim_inst_meta *meta) {
+  sim_t *s = sim_new(cfg, instance, rows, payload);
+  if (!s) return -1;
+  run_instance(s);
+  *stats = s->st; *meta = s->meta;
+  sim_free(s);
+  return 0;
+}
+
+/* Test hook: the state-transition function of ONE node, outside the network.  Feeds `n_in` inputs
+ * {src endpoint, message type (oracle_msg_type), a, b} to node `node` in order and records every message
+ * the node emits as {input index, dest endpoint, type, a, b}.  An input of type 0 means "let `a`
+ * microseconds pass and run every timer that becomes due" (g-set replicate tick, gossip retries).
+ * Used to replay golden vectors recorded from the reference's own node programs
+ * (tests/golden/make_golden.py).  Returns the number of emitted messages, or -1. */
+int oracle_node_trace(const msim_config *cfg, uint32_t node, const uint32_t *in, uint32_t n_in,
+                      uint32_t *out, uint32_t out_cap, uint32_t *payload, uint32_t *final_set) {
+  msim_op *rows = (msim_op *)calloc(cfg->max_rows, sizeof(msim_op));
+  sim_t *s = sim_new(cfg, 0, rows, payload);
+  if (!s || node >= s->N) { free(rows); return -1; }
+  u32 n = 0;
+  for (u32 i = 0; i < n_in; i++) {
+    const u32 *m = in + 4 * i;
+    s->n_out = 0;
+    if (m[1] == 0) {
+      s->T += m[2];
+      while (node_timer_time(s, node) <= s->T) node_timer(s, node);
+    } else {
+      qent q = {s->T, i, m[2], m[3], (u8)m[0], (u8)m[1]};
+      if (q.type == M_BROADCAST || q.type == M_ADD) { if (q.a + 1 > s->next_value) s->next_value = q.a + 1; }
+      node_handle(s, node, &q);
+    }
+    for (u32 k = 0; k < s->n_out && n < out_cap; k++, n++) {
+      u32 *o = out + 5 * n;
+      o[0] = i; o[1] = s->out[k].dest_ep; o[2] = s->out[k].type; o[3] = s->out[k].a; o[4] = s->out[k].b;
+      if (s->out[k].type == M_REPLICATE && final_set) memcpy(final_set, s->snap[s->out[k].a], s->W * 4); /* last replicated value */
+    }
+  }
+  if (final_set && cfg->node_program != MSIM_NODE_G_SET) memcpy(final_set, seen_of(s, node), s->W * 4);
+  sim_free(s); free(rows);
+  return (int)n;
+}
+
+uint32_t oracle_msg_type(const char *name) {
+  static const char *names[] = {"", "init", "init_ok", "topology", "topology_ok", "echo", "echo_ok", "broadcast", "broadcast_ok",
+                                "read", "read_ok", "add", "add_ok", "replicate"};
+  for (u32 i = 1; i < sizeof(names) / sizeof(names[0]); i++) if (!strcmp(names[i], name)) return i;
   return 0;
 }
 
