@@ -1,0 +1,61 @@
+/* maelsim_jni.c — thin JNI shim over include/maelsim.h for the reference's host language (Clojure/JVM).
+ * NOT compiled in this image (no jni.h / JDK); build on a box with a JDK:
+ *   cc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -Iinclude integration/jni/maelsim_jni.c \
+ *      -Lmaelstrom_amd -lmaelsim -o libmaelsim_jni.so
+ * Java side: class maelstrom.gpu.Native { static native long create(int[] cfg, long seed, int device); ... }
+ * Buffers cross as direct ByteBuffers over the engine-owned pinned host memory (valid until the next run). */
+#include <jni.h>
+#include <string.h>
+#include "maelsim.h"
+
+static void throw_msim(JNIEnv *env, const char *msg) {
+  (*env)->ThrowNew(env, (*env)->FindClass(env, "java/lang/RuntimeException"), msg);
+}
+
+/* cfg = the msim_config u32 fields in declaration order up to quiesce_ms (16 ints) */
+JNIEXPORT jlong JNICALL Java_maelstrom_gpu_Native_create(JNIEnv *env, jclass cls, jintArray cfg_fields, jlong seed, jint device) {
+  msim_config c;
+  jint f[16];
+  char err[256];
+  msim_ctx *ctx = NULL;
+  (void)cls;
+  (*env)->GetIntArrayRegion(env, cfg_fields, 0, 16, f);
+  msim_config_defaults(&c, (uint32_t)f[2], (uint32_t)f[4]);
+  memcpy(&c.workload, &f[2], 14 * sizeof(uint32_t)); /* workload .. quiesce_ms */
+  c.seed = (uint64_t)seed;
+  if (msim_create(&c, device, &ctx, err, sizeof err) != MSIM_OK) { throw_msim(env, err); return 0; }
+  return (jlong)(intptr_t)ctx;
+}
+
+JNIEXPORT void JNICALL Java_maelstrom_gpu_Native_run(JNIEnv *env, jclass cls, jlong h, jlong first, jint n) {
+  msim_ctx *ctx = (msim_ctx *)(intptr_t)h;
+  (void)cls;
+  if (msim_run(ctx, (uint64_t)first, (uint32_t)n) || msim_check(ctx) || msim_fetch(ctx)) throw_msim(env, msim_last_error(ctx));
+}
+
+/* returns {rows ByteBuffer (16 B each), payload ByteBuffer (u32)} of instance i */
+JNIEXPORT jobjectArray JNICALL Java_maelstrom_gpu_Native_history(JNIEnv *env, jclass cls, jlong h, jint i) {
+  msim_ctx *ctx = (msim_ctx *)(intptr_t)h;
+  const msim_op *ops; const uint32_t *pay; uint32_t n_ops, n_words;
+  jobjectArray out;
+  (void)cls;
+  if (msim_history(ctx, (uint32_t)i, &ops, &n_ops, &pay, &n_words)) { throw_msim(env, msim_last_error(ctx)); return NULL; }
+  out = (*env)->NewObjectArray(env, 2, (*env)->FindClass(env, "java/nio/ByteBuffer"), NULL);
+  (*env)->SetObjectArrayElement(env, out, 0, (*env)->NewDirectByteBuffer(env, (void *)ops, (jlong)n_ops * 16));
+  (*env)->SetObjectArrayElement(env, out, 1, (*env)->NewDirectByteBuffer(env, (void *)pay, (jlong)n_words * 4));
+  return out;
+}
+
+/* 6 longs: all/clients/servers x send/recv (net/checker.clj:28-41) */
+JNIEXPORT jlongArray JNICALL Java_maelstrom_gpu_Native_netStats(JNIEnv *env, jclass cls, jlong h, jint i) {
+  msim_net_stats st; jlongArray out = (*env)->NewLongArray(env, 6);
+  (void)cls;
+  if (msim_net_stats_get((msim_ctx *)(intptr_t)h, (uint32_t)i, &st)) { throw_msim(env, "net stats"); return NULL; }
+  (*env)->SetLongArrayRegion(env, out, 0, 6, (const jlong *)&st);
+  return out;
+}
+
+JNIEXPORT void JNICALL Java_maelstrom_gpu_Native_destroy(JNIEnv *env, jclass cls, jlong h) {
+  (void)env; (void)cls;
+  msim_destroy((msim_ctx *)(intptr_t)h);
+}
