@@ -34,25 +34,35 @@ def headline_config(E, seed):
                          latency_dist="constant", topology="grid", seed=seed, inbox_capacity=6)
 
 
-def cpu_baseline(cfg, n_sample):
-    """The CPU oracle (a port with identical semantics) on the host cores: all cores, and one core."""
+def cpu_baseline(cfg, seconds):
+    """The CPU oracle (a port with identical semantics) on the host cores, for ~`seconds` of wall time on all
+    cores (each thread loops over chunks of 8 instances; ctypes releases the GIL) and on one core."""
     import concurrent.futures as cf
     import oracle_lib as O
     O.load()
     cores = os.cpu_count() or 1
-    per = max(1, n_sample // cores)
+    chunk = 8
+
+    def worker(tid, budget):
+        msgs = inst = 0
+        t_end = time.perf_counter() + budget
+        while time.perf_counter() < t_end:
+            o = O.run(cfg, 20_000_000 + (tid * 1_000_000 + inst), chunk)
+            msgs += int(o.stats["all_send"].sum())
+            inst += chunk
+        return msgs, inst
+
     t0 = time.perf_counter()
-    one = O.run(cfg, 10_000_000, min(32, n_sample))
-    t1 = time.perf_counter()
-    msgs_1 = int(one.stats["all_send"].sum())
-    single = msgs_1 / (t1 - t0)
+    m1, i1 = worker(0, min(3.0, seconds))
+    single = m1 / (time.perf_counter() - t0)
     t0 = time.perf_counter()
-    with cf.ThreadPoolExecutor(cores) as ex:  # ctypes releases the GIL: real parallelism
-        outs = list(ex.map(lambda k: O.run(cfg, 20_000_000 + k * per, per), range(cores)))
+    with cf.ThreadPoolExecutor(cores) as ex:
+        outs = list(ex.map(lambda k: worker(k + 1, seconds), range(cores)))
     dt = time.perf_counter() - t0
-    msgs = sum(int(o.stats["all_send"].sum()) for o in outs)
+    msgs = sum(o[0] for o in outs)
+    insts = sum(o[1] for o in outs)
     return {"value": msgs / dt, "unit": "msgs/s", "cores": cores, "kind": "port",
-            "sample": f"{per * cores} instances of the same workload on {cores} threads ({dt:.1f} s); single core: {single:.3g} msgs/s",
+            "sample": f"{insts} instances of the same workload on {cores} threads for {dt:.1f} s; single core: {single:.3g} msgs/s over {i1} instances",
             "single_core_value": single}
 
 
@@ -62,7 +72,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--instances", type=int, default=4096, help="test instances per GPU per step")
-    ap.add_argument("--cpu-sample", type=int, default=1024, help="instances for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=float, default=10.0, help="seconds of CPU-oracle work for cpu_baseline (0 = skip)")
     ap.add_argument("--seed", type=int, default=2026)
     ap.add_argument("--no-gather", action="store_true")
     args = ap.parse_args()
