@@ -741,6 +741,8 @@ __global__ void __launch_bounds__(64) sim_kernel(const KParams p) {
   }
 }
 
+#include "sim_kernel_colo.inc"
+
 // =====================================================================================================
 // Host runtime
 // =====================================================================================================
@@ -828,11 +830,16 @@ static int ensure_buffers(msim_ctx *ctx, uint32_t n) {
 
 template <int PROG, bool NEM, bool NET_RANDOM>
 static hipError_t launch3(const KParams &kp, uint32_t n, size_t lds, hipStream_t st) {
+  // colocated layout when every worker is pinned to "its" node (concurrency == n_nodes, the default 1n)
+  const bool colo = kp.C == kp.N;
+  const void *fn = colo ? reinterpret_cast<const void *>(&sim_kernel_colo<PROG, NEM, NET_RANDOM>)
+                        : reinterpret_cast<const void *>(&sim_kernel<PROG, NEM, NET_RANDOM>);
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sim_kernel<PROG, NEM, NET_RANDOM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((sim_kernel<PROG, NEM, NET_RANDOM>), dim3(n), dim3(64), lds, st, kp);
+  if (colo) hipLaunchKernelGGL((sim_kernel_colo<PROG, NEM, NET_RANDOM>), dim3(n), dim3(64), lds, st, kp);
+  else hipLaunchKernelGGL((sim_kernel<PROG, NEM, NET_RANDOM>), dim3(n), dim3(64), lds, st, kp);
   return hipGetLastError();
 }
 template <int PROG>

@@ -82,3 +82,13 @@ def test_g_set_parity(lib):
     _compare(cfg, 0, 8)
     cfg = E.test_config("g-set", node_count=25, rate=100, time_limit=10, latency=100, latency_dist="exponential", seed=9)
     _compare(cfg, 0, 4)
+
+
+@pytest.mark.parametrize("conc", [3, 10, 7])
+def test_general_layout_parity_when_concurrency_differs_from_nodes(lib, conc):
+    """concurrency != n_nodes uses the general (endpoint-per-lane) kernel instead of the colocated one."""
+    cfg = E.test_config("broadcast", node_count=5, concurrency=conc, rate=20, time_limit=5, latency=10, seed=21)
+    _compare(cfg, 0, 8)
+    cfg = E.test_config("broadcast", bin="broadcast-ack-retry", node_count=5, concurrency=conc, rate=20, time_limit=8,
+                        nemesis=["partition"], nemesis_interval=3, latency=5, latency_dist="uniform", seed=22)
+    _compare(cfg, 0, 8)
