@@ -84,8 +84,9 @@ typedef struct msim_config {
   uint32_t max_values;           /* bits per node set (distinct add/broadcast values)                      */
   uint32_t max_rows;             /* history rows per instance                                              */
   uint32_t max_payload_words;    /* u32 payload words per instance (read results, grudges)                 */
-  uint32_t inbox_capacity;       /* in-flight messages queued per node endpoint                            */
-  uint32_t reserved[8];
+  uint32_t inbox_capacity;       /* envelopes queued per node endpoint in LDS                              */
+  uint32_t spill_capacity;       /* further envelopes per node endpoint in an HBM spill area behind the LDS queue */
+  uint32_t reserved[7];
 } msim_config;
 
 /* ---- outputs ------------------------------------------------------------------------------------- */

@@ -44,7 +44,8 @@ class Config(C.Structure):
         ("latency_dist", C.c_uint32), ("p_loss_q32", C.c_uint32), ("topology", C.c_uint32),
         ("nemesis_mask", C.c_uint32), ("nemesis_interval_ms", C.c_uint32), ("client_timeout_ms", C.c_uint32),
         ("quiesce_ms", C.c_uint32), ("seed", C.c_uint64), ("max_values", C.c_uint32), ("max_rows", C.c_uint32),
-        ("max_payload_words", C.c_uint32), ("inbox_capacity", C.c_uint32), ("reserved", C.c_uint32 * 8),
+        ("max_payload_words", C.c_uint32), ("inbox_capacity", C.c_uint32), ("spill_capacity", C.c_uint32),
+        ("reserved", C.c_uint32 * 7),
     ]
 
 

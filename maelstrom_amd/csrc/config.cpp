@@ -106,16 +106,20 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
   }
   if (c->max_payload_words > 0xFFFFFFu) { set_err(err, errlen, "max_payload_words must be < 2^24"); return MSIM_E_INVALID; }
   if (c->max_values > 255u * 32u) { set_err(err, errlen, "max_values above 8160 (read length is 8 bits of words)"); return MSIM_E_INVALID; }
-  if (c->inbox_capacity == 0) {
+  {
+    // Queue depth per node = inflow x how long recv! can sleep on one envelope (head-of-line blocking,
+    // net.clj:236-238).  The LDS part stays small; the rest lives in an HBM spill area.
     uint32_t deg = max_degree(c);
     double per_s = (double)c->rate_mhz / 2000.0 * deg;             // server msgs per second into one node
     if (c->node_program == MSIM_NODE_BCAST_ACK_RETRY || c->node_program == MSIM_NODE_BCAST_RPC_ALL) per_s *= 2;  // + acks
     double lat_s = c->latency_mean_ms / 1000.0;
-    if (c->latency_dist != MSIM_LAT_CONSTANT) lat_s *= 3.0;
-    c->inbox_capacity = 16 + 2 * deg + (uint32_t)(per_s * lat_s * 1.5);
-    // g-set traffic does not depend on the op rate: every node gets one replicate_full from each of
-    // the other n-1 nodes per 5 s tick (g_set.rb:33-38)
-    if (c->node_program == MSIM_NODE_G_SET) c->inbox_capacity = 16 + 2 * deg;
+    if (c->latency_dist == MSIM_LAT_UNIFORM) lat_s *= 2.0;         // max of uniform [0, 2 mean)
+    if (c->latency_dist == MSIM_LAT_EXPONENTIAL) lat_s *= 16.0;    // P(latency > 16 mean) ~ 1e-7 per message
+    uint32_t depth = 16 + 2 * deg + (uint32_t)(per_s * lat_s * 3.0);  // x3: bursts
+    if (c->node_program == MSIM_NODE_G_SET) depth = 16 + 2 * deg;  // one replicate_full per peer per 5 s tick (g_set.rb:33-38)
+    if (c->inbox_capacity == 0) c->inbox_capacity = depth < 24 ? depth : 24;
+    if (c->spill_capacity == 0) c->spill_capacity = depth > c->inbox_capacity ? depth - c->inbox_capacity : 0;
+    if (c->spill_capacity > 65536) { set_err(err, errlen, "spill_capacity above 65536 envelopes per node"); return MSIM_E_INVALID; }
   }
   return MSIM_OK;
 }

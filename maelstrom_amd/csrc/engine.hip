@@ -51,7 +51,8 @@ struct KParams {
   u32 *scratch;
   u64 scratch_words;  // per instance
   u32 N, C, CS, W;
-  u32 cap_node;
+  u32 cap_node, spill_cap;
+  u64 spill_off;  // word offset of the spill area inside the per-instance scratch
   u32 off_inbox, off_seen, off_misc;  // LDS byte offsets
   u32 gen_period2_us, nem_period2_us;
 };
@@ -183,7 +184,7 @@ __device__ __forceinline__ u32 topo_adj(u32 topology, u32 n, u32 a) {
 // so an RPC to an idle node completes inside one round, and a gossip hop costs one round.
 // =====================================================================================================
 template <int PROG, bool NEM, bool NET_RANDOM>
-__global__ void __launch_bounds__(64) sim_kernel(const KParams p) {
+__global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint4 *const stage = reinterpret_cast<uint4 *>(smem);
   uint4 *const inbox = reinterpret_cast<uint4 *>(smem + p.off_inbox);
@@ -228,7 +229,9 @@ __global__ void __launch_bounds__(64) sim_kernel(const KParams p) {
   u32 *const g_fifo = g_scr + (size_t)N * max_values + (size_t)lane * max_values * 2;
 
   const u32 my_cap = is_node ? p.cap_node : CLIENT_INBOX_CAP;
+  const u32 my_spill_cap = is_node ? p.spill_cap : 0u;
   uint4 *const my_inbox = inbox + (is_node ? lane * p.cap_node : (is_client ? N * p.cap_node + slot * CLIENT_INBOX_CAP : 0));
+  uint4 *const my_spill = reinterpret_cast<uint4 *>(g_scr + p.spill_off) + (size_t)(is_node ? lane : 0) * p.spill_cap;  // HBM spill behind the LDS queue
   u32 *const my_seen = seen + (is_node ? lane : 0) * W;
 
   for (u32 i = lane; i < N * W; i += 64) seen[i] = 0;
@@ -243,7 +246,7 @@ __global__ void __launch_bounds__(64) sim_kernel(const KParams p) {
   // ---- per-lane endpoint state ----
   bool has_c = false; u32 deliver_at = 0; uint4 cm = make_uint4(0, 0, 0, 0);  // the envelope recv! is sleeping on
   bool have_pm = false; uint4 pm = make_uint4(0, 0, 0, 0);                    // smallest arrival of this commit
-  u32 in_n = 0;                                                               // queued envelopes in LDS
+  u32 in_n = 0, sp_n = 0;                                                     // queued envelopes in LDS / in the HBM spill
   u32 node_msgid = 0, timer_next = INF, tick = 0, part = 0;
   u32 fifo_head = 0, fifo_tail = 0, retry_time = INF;
   bool busy = false, mark = false; u32 kind = K_NONE;
@@ -257,8 +260,9 @@ __global__ void __launch_bounds__(64) sim_kernel(const KParams p) {
 
   // queue an envelope in this lane's LDS inbox
   auto lds_push = [&](const uint4 m) {
-    if (in_n >= my_cap) { my_flags |= MSIM_FLAG_INBOX_OVERFLOW; return; }
-    my_inbox[in_n++] = m;
+    if (in_n < my_cap) { my_inbox[in_n++] = m; return; }
+    if (sp_n < my_spill_cap) { my_spill[sp_n++] = m; return; }
+    my_flags |= MSIM_FLAG_INBOX_OVERFLOW;
   };
   // a message addressed to this lane arrives (net.clj:189-221: latency, loss, enqueue)
   auto arrive = [&](u32 id, u32 type, u32 a, u32 b, u32 src) {
@@ -286,19 +290,23 @@ __global__ void __launch_bounds__(64) sim_kernel(const KParams p) {
     const bool elig = is_node || busy;  // clients only poll inside recv! (client.clj:94-95)
     if (have_pm) {
       have_pm = false;
-      if (elig && !has_c && in_n == 0) try_commit(pm);  // common case: nothing queued, no LDS traffic
+      if (elig && !has_c && (in_n | sp_n) == 0) try_commit(pm);  // common case: nothing queued, no LDS traffic
       else lds_push(pm);
     }
-    while (elig && !has_c && in_n > 0) {
-      u32 best = 0;
-      uint2 bk = *reinterpret_cast<const uint2 *>(&my_inbox[0]);
-      for (u32 i = 1; i < in_n; i++) {
+    while (elig && !has_c && (in_n | sp_n) != 0) {
+      u32 best = 0; bool in_spill = false;
+      uint2 bk = make_uint2(INF, INF);
+      for (u32 i = 0; i < in_n; i++) {
         const uint2 kk = *reinterpret_cast<const uint2 *>(&my_inbox[i]);
         if (kk.x < bk.x || (kk.x == bk.x && kk.y < bk.y)) { bk = kk; best = i; }
       }
-      const uint4 e = my_inbox[best];
-      in_n--;
-      if (best != in_n) my_inbox[best] = my_inbox[in_n];
+      for (u32 i = 0; i < sp_n; i++) {  // deep queues only (long head-of-line sleeps)
+        const uint2 kk = *reinterpret_cast<const uint2 *>(&my_spill[i]);
+        if (kk.x < bk.x || (kk.x == bk.x && kk.y < bk.y)) { bk = kk; best = i; in_spill = true; }
+      }
+      uint4 e;
+      if (in_spill) { e = my_spill[best]; sp_n--; if (best != sp_n) my_spill[best] = my_spill[sp_n]; }
+      else { e = my_inbox[best]; in_n--; if (best != in_n) my_inbox[best] = my_inbox[in_n]; }
       try_commit(e);
     }
   };
@@ -803,14 +811,19 @@ extern "C" int msim_create(const msim_config *cfg, int device, msim_ctx **out, c
   return MSIM_OK;
 }
 
-static uint64_t scratch_words(const msim_config &c) {
-  if (c.node_program == MSIM_NODE_BCAST_ACK_RETRY) return (uint64_t)c.n_nodes * c.max_values * 3;
+// per-instance scratch = [protocol scratch][spill area: n_nodes x spill_capacity envelopes]
+static uint64_t proto_scratch_words(const msim_config &c) {
+  uint64_t w = 4;
+  if (c.node_program == MSIM_NODE_BCAST_ACK_RETRY) w = (uint64_t)c.n_nodes * c.max_values * 3;
   if (c.node_program == MSIM_NODE_G_SET) {
     const uint64_t total_ms = (uint64_t)c.time_limit_ms + c.quiesce_ms + 2ull * c.client_timeout_ms;
     const uint64_t ticks = total_ms / 5000 + 3;
-    return ticks * c.n_nodes * (c.max_values / 32);
+    w = ticks * c.n_nodes * (c.max_values / 32);
   }
-  return 4;
+  return (w + 3) & ~3ull;  // keep the spill area 16-byte aligned
+}
+static uint64_t scratch_words(const msim_config &c) {
+  return proto_scratch_words(c) + (uint64_t)c.n_nodes * c.spill_capacity * 4;
 }
 
 static int ensure_buffers(msim_ctx *ctx, uint32_t n) {
@@ -863,7 +876,7 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   kp.scratch = ctx->d_scratch; kp.scratch_words = ctx->scratch_words_per_inst;
   kp.N = c.n_nodes; kp.C = c.concurrency; kp.CS = c.concurrency > c.n_nodes ? c.concurrency : c.n_nodes;
   kp.W = c.max_values / 32;
-  kp.cap_node = c.inbox_capacity;
+  kp.cap_node = c.inbox_capacity; kp.spill_cap = c.spill_capacity; kp.spill_off = proto_scratch_words(c);
   const uint64_t period_us = 1000000000ull / (c.rate_mhz ? c.rate_mhz : 1);
   if (2 * period_us > 0xFFFFFFFFull || 2000ull * c.nemesis_interval_ms > 0xFFFFFFFFull) { ctx->err = "rate too low / nemesis interval too long for u32 microseconds"; return MSIM_E_INVALID; }
   kp.gen_period2_us = (u32)(2 * period_us);

@@ -37,7 +37,7 @@ def test_set_full_healthy_broadcast(lib):
 
 
 def test_set_full_stale_latencies_n25(lib):
-    res = _check(E.test_config("broadcast", node_count=25, rate=50, time_limit=5, latency=100, latency_dist="exponential", seed=8, inbox_capacity=256), 4)
+    res = _check(E.test_config("broadcast", node_count=25, rate=50, time_limit=5, latency=100, latency_dist="exponential", seed=8), 4)
     assert (res["stale_count"] > 0).all()  # 100 ms hops are visible as stale reads (02-performance.md:205-211)
 
 

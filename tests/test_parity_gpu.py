@@ -92,3 +92,13 @@ def test_general_layout_parity_when_concurrency_differs_from_nodes(lib, conc):
     cfg = E.test_config("broadcast", bin="broadcast-ack-retry", node_count=5, concurrency=conc, rate=20, time_limit=8,
                         nemesis=["partition"], nemesis_interval=3, latency=5, latency_dist="uniform", seed=22)
     _compare(cfg, 0, 8)
+
+
+def test_deep_queues_spill_to_hbm(lib):
+    """Exponential latency => long head-of-line sleeps => queues far deeper than the LDS part: the HBM spill area
+    behind each node's queue keeps the result bit-identical (and unflagged)."""
+    cfg = E.test_config("broadcast", node_count=25, rate=100, time_limit=20, latency=100, latency_dist="exponential", seed=8)
+    assert cfg.spill_capacity > 100
+    _compare(cfg, 0, 4)
+    cfg = E.test_config("broadcast", node_count=5, rate=50, time_limit=5, latency=200, latency_dist="exponential", seed=9, inbox_capacity=2)
+    _compare(cfg, 0, 8)
