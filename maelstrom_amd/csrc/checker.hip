@@ -58,24 +58,35 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
     const u32 cnt = min(64u, n_rows - base);
     uint4 r = make_uint4(0, 0, 0, 0);
     if (lane < cnt) r = rows[base + lane];
-    for (u32 j = 0; j < cnt; j++) {
+    // every lane classifies its own row; only rows that need ordered handling are walked serially
+    const u32 my_type = r.z & 3, my_f = (r.z >> 2) & 31, my_proc = r.z >> 12;
+    const bool live = lane < cnt && my_proc != MSIM_PROCESS_NEMESIS;  // (r/filter (comp number? :process))
+    const bool add_like = my_f == MSIM_F_ADD || my_f == MSIM_F_BROADCAST;
+    op_count += (u32)__popcll(__ballot(live && my_type == MSIM_T_INVOKE));
+    n_ok += (u32)__popcll(__ballot(live && my_type == MSIM_T_OK));
+    n_fail += (u32)__popcll(__ballot(live && my_type == MSIM_T_FAIL));
+    n_info += (u32)__popcll(__ballot(live && my_type == MSIM_T_INFO));
+    // add :ok -> known (first of add-ok / first containing read, by :index): order-free as a minimum
+    if (live && add_like && my_type == MSIM_T_OK && r.w < p.max_values) atomicMin(&known[r.w], base + lane);
+    const u64 add_inv = __ballot(live && add_like && my_type == MSIM_T_INVOKE);  // elements come into existence
+    u64 walk = __ballot(live && (my_f == MSIM_F_READ || my_f == MSIM_F_ECHO));
+    const u32 v_base = v_cur;
+    v_cur += (u32)__popcll(add_inv);  // values are handed out 0,1,2,... in invoke order
+    while (walk) {
+      const u32 j = (u32)__builtin_ctzll(walk); walk &= walk - 1;
       const u32 packed = c_rdlane(r.z, j), value = c_rdlane(r.w, j), hi = c_rdlane(r.y, j);
-      const u32 type = packed & 3, f = (packed >> 2) & 31, process = packed >> 12;
-      if (process == MSIM_PROCESS_NEMESIS) continue;  // (r/filter (comp number? :process))
-      const u32 idx = base + j, t = process % C;
-      if (type == MSIM_T_INVOKE) op_count++; else if (type == MSIM_T_OK) n_ok++; else if (type == MSIM_T_FAIL) n_fail++; else n_info++;
-      if (f == MSIM_F_ADD || f == MSIM_F_BROADCAST) {
-        if (type == MSIM_T_INVOKE) v_cur = max(v_cur, value + 1);
-        else if (type == MSIM_T_OK && value < p.max_values && lane == (value & 63) && known[value] == NONE) known[value] = idx;
-      } else if (f == MSIM_F_READ) {
+      const u32 type = packed & 3, f = (packed >> 2) & 31, t = (packed >> 12) % C;
+      const u32 idx = base + j;
+      if (f == MSIM_F_READ) {
         if (type == MSIM_T_INVOKE) { if (lane == t) my_inv = idx; }
         else if (type == MSIM_T_FAIL) { if (lane == t) my_inv = NONE; }
         else if (type == MSIM_T_OK) {
           const u32 inv = c_rdlane(my_inv, t), len = hi >> 16, off = value;
-          for (u32 e = lane; e < v_cur; e += 64) {
+          const u32 v_here = v_base + (u32)__popcll(add_inv & ((1ull << j) - 1));  // elements existing at this row
+          for (u32 e = lane; e < v_here; e += 64) {
             const u32 w = (e >> 5) < len ? pay[off + (e >> 5)] : 0u;
             if ((w >> (e & 31)) & 1) {
-              if (known[e] == NONE) known[e] = idx;
+              if (known[e] > idx) known[e] = idx;
               const u32 lp = lp_idx[e];
               if (lp == NONE || lp < inv) lp_idx[e] = inv;
             } else {
@@ -84,12 +95,13 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
             }
           }
         }
-      } else if (f == MSIM_F_ECHO) {
+      } else {  // echo
         if (type == MSIM_T_INVOKE) { if (lane == t) my_val = value; }
         else if (type == MSIM_T_OK) { if (c_rdlane(my_val, t) != value) errors++; }  // echo.clj:52-60
       }
     }
   }
+  __syncthreads();
 
   // ---- per-element outcomes ----
   u32 c_stable = 0, c_lost = 0, c_never = 0, c_stale = 0;
@@ -114,10 +126,13 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
   // ---- quantiles of the stable latencies: idx-th smallest by bisection on the value ----
   u32 q[5] = {0, 0, 0, 0, 0};
   if (n_stable) {
+    u32 lmax = 0;  // the search range is [0, largest stable latency]
+    for (u32 e = lane; e < v_cur; e += 64) { const u32 l = known[e]; if (l != NONE) lmax = max(lmax, l); }
+    for (int o = 32; o; o >>= 1) lmax = max(lmax, (u32)__shfl_xor((int)lmax, o));
     const double pts[5] = {0.0, 0.5, 0.95, 0.99, 1.0};
     for (int qi = 0; qi < 5; qi++) {
       const u32 want = min(n_stable - 1, (u32)floor((double)n_stable * pts[qi]));
-      u32 lo = 0, hi = 0x7FFFFFFFu;  // smallest v with count(lat <= v) > want
+      u32 lo = 0, hi = lmax;  // smallest v with count(lat <= v) > want
       while (lo < hi) {
         const u32 mid = lo + (hi - lo) / 2;
         u32 c = 0;
