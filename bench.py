@@ -118,7 +118,7 @@ def main():
         eng.check()           # set-full over the HBM-resident histories
         db = eng.device_buffers()
         stats = torch_view(db.stats, db.stats_bytes, torch.int64, dev).view(-1, 6)
-        meta = torch_view(db.meta, db.meta_bytes, torch.int32, dev).view(-1, 4)
+        meta = torch_view(db.meta, db.meta_bytes, torch.int32, dev).view(-1, 8)
         chk = torch_view(db.check, db.check_bytes, torch.int32, dev).view(-1, 17)
         acc.add_(torch.stack([stats[:, 0].sum(), (chk[:, 0] == 1).sum(), (meta[:, 2] != 0).sum(),
                               meta[:, 0].sum(dtype=torch.int64), meta[:, 1].sum(dtype=torch.int64)]))
@@ -194,7 +194,7 @@ def history_gather(eng, torch, dist, dev, world, rank, torch_view):
     is the on-device compaction only."""
     from maelstrom_amd import ensemble as EN
     db = eng.device_buffers()
-    meta = torch_view(db.meta, db.meta_bytes, torch.int32, dev).view(-1, 4)
+    meta = torch_view(db.meta, db.meta_bytes, torch.int32, dev).view(-1, 8)
     rows = torch_view(db.rows, db.rows_bytes, torch.int32, dev).view(db.n_instances, db.max_rows, 4)
     pay = torch_view(db.payload, db.payload_bytes, torch.int32, dev).view(db.n_instances, db.max_payload_words)
     best = None

@@ -86,7 +86,8 @@ typedef struct msim_config {
   uint32_t max_payload_words;    /* u32 payload words per instance (read results, grudges)                 */
   uint32_t inbox_capacity;       /* envelopes queued per node endpoint in LDS                              */
   uint32_t spill_capacity;       /* further envelopes per node endpoint in an HBM spill area behind the LDS queue */
-  uint32_t reserved[7];
+  uint32_t journal_capacity;     /* net-journal events per instance (journal.clj:53); 0 = journal off (default)   */
+  uint32_t reserved[6];
 } msim_config;
 
 /* ---- outputs ------------------------------------------------------------------------------------- */
@@ -133,15 +134,34 @@ typedef struct msim_net_stats {
   uint64_t servers_send, servers_recv;
 } msim_net_stats;
 
+/* One net-journal event = `(Event. id time type message)` of net/journal.clj:53,220-239: a :send is logged
+ * for every `send!` (before the loss decision, net.clj:208), a :recv for every delivery (net.clj:244).
+ * 16 bytes; the event's :id is its position.  Feeds maelstrom.net.checker / net.viz.
+ *   time_us : :time in microseconds since test start
+ *   msg     : bits 8-31 message :id (net.clj:197), bit 7 = 1 for :recv / 0 for :send, bits 0-6 body :type (MSIM_M_*)
+ *   a       : body payload (element / echo k / read payload ref (offset | words<<24) / replicate tick)
+ *   route   : bits 0-7 src endpoint, 8-15 dest endpoint (nodes 0..n-1, then client slots), 16-31 low 16 bits of
+ *             the body's msg_id (requests) or in_reply_to (replies); 0 = none */
+typedef struct msim_event {
+  uint32_t time_us;
+  uint32_t msg;
+  uint32_t a;
+  uint32_t route;
+} msim_event;
+enum { MSIM_M_INIT = 1, MSIM_M_INIT_OK, MSIM_M_TOPOLOGY, MSIM_M_TOPOLOGY_OK, MSIM_M_ECHO, MSIM_M_ECHO_OK, MSIM_M_BROADCAST,
+       MSIM_M_BROADCAST_OK, MSIM_M_READ, MSIM_M_READ_OK, MSIM_M_ADD, MSIM_M_ADD_OK, MSIM_M_REPLICATE };
+
 /* Per-instance bookkeeping (not part of the algorithmic output bytes). */
 typedef struct msim_inst_meta {
   uint32_t n_rows;          /* history rows written                                                   */
   uint32_t n_payload_words; /* payload words written                                                  */
   uint32_t flags;           /* MSIM_FLAG_*                                                            */
   uint32_t n_rounds;        /* scheduler rounds executed (diagnostic)                                 */
+  uint32_t n_events;        /* journal events produced (may exceed journal_capacity: then flagged)    */
+  uint32_t reserved[3];
 } msim_inst_meta;
 enum { MSIM_FLAG_ROWS_OVERFLOW = 1u, MSIM_FLAG_PAYLOAD_OVERFLOW = 2u, MSIM_FLAG_INBOX_OVERFLOW = 4u,
-       MSIM_FLAG_VALUES_OVERFLOW = 8u, MSIM_FLAG_ROUND_LIMIT = 16u };
+       MSIM_FLAG_VALUES_OVERFLOW = 8u, MSIM_FLAG_ROUND_LIMIT = 16u, MSIM_FLAG_JOURNAL_OVERFLOW = 32u };
 
 /* Result of the workload checker for one instance.  For broadcast / g-set this is jepsen's
  * `checker/set-full` result map (shape: doc/03-broadcast/01-broadcast.md:564-577, KAT-7); for echo the
@@ -203,18 +223,22 @@ int msim_fetch(msim_ctx *ctx);
 int msim_history(msim_ctx *ctx, uint32_t inst, const msim_op **ops, uint32_t *n_ops,
                  const uint32_t **payload, uint32_t *n_words);
 int msim_net_stats_get(msim_ctx *ctx, uint32_t inst, msim_net_stats *out);
+/* The instance's net journal (requires journal_capacity > 0 and msim_fetch). */
+int msim_journal(msim_ctx *ctx, uint32_t inst, const msim_event **events, uint32_t *n_events);
 int msim_meta(msim_ctx *ctx, uint32_t inst, msim_inst_meta *out);
 /* Checker results of the last msim_check (copied to host on demand). */
 int msim_check_results(msim_ctx *ctx, const msim_check_result **results, uint32_t *n);
 
 /* Device-resident output buffers of the last run, for zero-copy consumers (RCCL gather, GPU checkers).
  * rows: n_instances * max_rows msim_op; payload: n_instances * max_payload_words u32;
- * stats: n_instances msim_net_stats; meta: n_instances msim_inst_meta; check: n_instances msim_check_result. */
+ * stats: n_instances msim_net_stats; meta: n_instances msim_inst_meta; check: n_instances msim_check_result;
+ * journal: n_instances * journal_capacity msim_event. */
 typedef struct msim_device_buffers {
   void *rows; void *payload; void *stats; void *meta;
   void *check;                 /* n_instances msim_check_result (valid after msim_check) */
-  uint64_t rows_bytes, payload_bytes, stats_bytes, meta_bytes, check_bytes;
-  uint32_t n_instances, max_rows, max_payload_words, reserved;
+  void *journal;               /* n_instances * journal_capacity msim_event (NULL when the journal is off) */
+  uint64_t rows_bytes, payload_bytes, stats_bytes, meta_bytes, check_bytes, journal_bytes;
+  uint32_t n_instances, max_rows, max_payload_words, journal_capacity;
 } msim_device_buffers;
 int msim_device_buffers_get(msim_ctx *ctx, msim_device_buffers *out);
 

@@ -25,12 +25,14 @@ ERR_NONE, ERR_NET_TIMEOUT, ERR_RPC = range(3)
 SPEC_ONE, SPEC_MAJORITY, SPEC_MAJORITIES_RING, SPEC_MINORITY_THIRD = range(4)
 PROCESS_NEMESIS = 0xFFFFF
 NO_VALUE = 0xFFFFFFFF
-FLAG_ROWS_OVERFLOW, FLAG_PAYLOAD_OVERFLOW, FLAG_INBOX_OVERFLOW, FLAG_VALUES_OVERFLOW, FLAG_ROUND_LIMIT = 1, 2, 4, 8, 16
+FLAG_ROWS_OVERFLOW, FLAG_PAYLOAD_OVERFLOW, FLAG_INBOX_OVERFLOW, FLAG_VALUES_OVERFLOW, FLAG_ROUND_LIMIT, FLAG_JOURNAL_OVERFLOW = 1, 2, 4, 8, 16, 32
+MSG_TYPES = ["", "init", "init_ok", "topology", "topology_ok", "echo", "echo_ok", "broadcast", "broadcast_ok", "read", "read_ok",
+             "add", "add_ok", "replicate"]
 MASK_WORDS = 4
 
 EXPORTS = [
     "msim_abi_version", "msim_device_count", "msim_config_defaults", "msim_config_finalize", "msim_create",
-    "msim_run", "msim_run_async", "msim_check", "msim_fetch", "msim_history", "msim_net_stats_get", "msim_meta",
+    "msim_run", "msim_run_async", "msim_check", "msim_fetch", "msim_history", "msim_net_stats_get", "msim_journal", "msim_meta",
     "msim_check_results", "msim_device_buffers_get", "msim_last_kernel_ms", "msim_get_config",
     "msim_selftest_wave", "msim_last_error", "msim_destroy",
 ]
@@ -45,7 +47,7 @@ class Config(C.Structure):
         ("nemesis_mask", C.c_uint32), ("nemesis_interval_ms", C.c_uint32), ("client_timeout_ms", C.c_uint32),
         ("quiesce_ms", C.c_uint32), ("seed", C.c_uint64), ("max_values", C.c_uint32), ("max_rows", C.c_uint32),
         ("max_payload_words", C.c_uint32), ("inbox_capacity", C.c_uint32), ("spill_capacity", C.c_uint32),
-        ("reserved", C.c_uint32 * 7),
+        ("journal_capacity", C.c_uint32), ("reserved", C.c_uint32 * 6),
     ]
 
 
@@ -59,7 +61,12 @@ class NetStats(C.Structure):
 
 
 class InstMeta(C.Structure):
-    _fields_ = [("n_rows", C.c_uint32), ("n_payload_words", C.c_uint32), ("flags", C.c_uint32), ("n_rounds", C.c_uint32)]
+    _fields_ = [("n_rows", C.c_uint32), ("n_payload_words", C.c_uint32), ("flags", C.c_uint32), ("n_rounds", C.c_uint32),
+                ("n_events", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+
+
+class Event(C.Structure):
+    _fields_ = [("time_us", C.c_uint32), ("msg", C.c_uint32), ("a", C.c_uint32), ("route", C.c_uint32)]
 
 
 class CheckResult(C.Structure):
@@ -71,14 +78,15 @@ class CheckResult(C.Structure):
 
 class DeviceBuffers(C.Structure):
     _fields_ = [("rows", C.c_void_p), ("payload", C.c_void_p), ("stats", C.c_void_p), ("meta", C.c_void_p),
-                ("check", C.c_void_p),
+                ("check", C.c_void_p), ("journal", C.c_void_p),
                 ("rows_bytes", C.c_uint64), ("payload_bytes", C.c_uint64), ("stats_bytes", C.c_uint64),
-                ("meta_bytes", C.c_uint64), ("check_bytes", C.c_uint64), ("n_instances", C.c_uint32), ("max_rows", C.c_uint32),
-                ("max_payload_words", C.c_uint32), ("reserved", C.c_uint32)]
+                ("meta_bytes", C.c_uint64), ("check_bytes", C.c_uint64), ("journal_bytes", C.c_uint64),
+                ("n_instances", C.c_uint32), ("max_rows", C.c_uint32),
+                ("max_payload_words", C.c_uint32), ("journal_capacity", C.c_uint32)]
 
 
 assert C.sizeof(Config) == 120, C.sizeof(Config)
-assert C.sizeof(Op) == 16 and C.sizeof(NetStats) == 48 and C.sizeof(InstMeta) == 16 and C.sizeof(CheckResult) == 68
+assert C.sizeof(Op) == 16 and C.sizeof(NetStats) == 48 and C.sizeof(InstMeta) == 32 and C.sizeof(CheckResult) == 68 and C.sizeof(Event) == 16
 
 _lib = None
 
@@ -105,6 +113,7 @@ def load():
     lib.msim_history.argtypes = [C.c_void_p, C.c_uint32, P(P(Op)), P(C.c_uint32), P(P(C.c_uint32)), P(C.c_uint32)]
     lib.msim_net_stats_get.argtypes = [C.c_void_p, C.c_uint32, P(NetStats)]
     lib.msim_meta.argtypes = [C.c_void_p, C.c_uint32, P(InstMeta)]
+    lib.msim_journal.argtypes = [C.c_void_p, C.c_uint32, P(P(Event)), P(C.c_uint32)]
     lib.msim_check_results.argtypes = [C.c_void_p, P(P(CheckResult)), P(C.c_uint32)]
     lib.msim_device_buffers_get.argtypes = [C.c_void_p, P(DeviceBuffers)]
     lib.msim_last_kernel_ms.argtypes = [C.c_void_p, P(C.c_float), P(C.c_float)]
@@ -116,7 +125,7 @@ def load():
     lib.msim_destroy.argtypes = [C.c_void_p]
     lib.msim_destroy.restype = None
     for name in ("msim_config_defaults", "msim_config_finalize", "msim_create", "msim_run", "msim_run_async",
-                 "msim_check", "msim_fetch", "msim_history", "msim_net_stats_get", "msim_meta", "msim_check_results",
+                 "msim_check", "msim_fetch", "msim_history", "msim_net_stats_get", "msim_journal", "msim_meta", "msim_check_results",
                  "msim_device_buffers_get", "msim_last_kernel_ms", "msim_get_config"):
         getattr(lib, name).restype = C.c_int
     _lib = lib

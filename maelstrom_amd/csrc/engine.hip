@@ -50,6 +50,7 @@ struct KParams {
   msim_inst_meta *meta;
   u32 *scratch;
   u64 scratch_words;  // per instance
+  uint4 *journal;     // n * journal_capacity events, or null
   u32 N, C, CS, W;
   u32 cap_node, spill_cap;
   u64 spill_off;  // word offset of the spill area inside the per-instance scratch
@@ -228,6 +229,8 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
   u32 *const g_unacked = g_scr + (size_t)lane * max_values;
   u32 *const g_fifo = g_scr + (size_t)N * max_values + (size_t)lane * max_values * 2;
 
+  const u32 jcap = p.cfg.journal_capacity;  // net journal (journal.clj:53,220-239); 0 = off
+  uint4 *const g_ev = p.journal + (size_t)inst * jcap;
   const u32 my_cap = is_node ? p.cap_node : CLIENT_INBOX_CAP;
   const u32 my_spill_cap = is_node ? p.spill_cap : 0u;
   uint4 *const my_inbox = inbox + (is_node ? lane * p.cap_node : (is_client ? N * p.cap_node + slot * CLIENT_INBOX_CAP : 0));
@@ -257,7 +260,13 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
   // ---- wave-uniform state ----
   u32 T = 0, phase = PH_INIT, cutoff = 0, gen_next = 0, gen_k = 0, next_value = 0, nem_next = 0, nem_j = 0;
   u32 sleep_until = 0, loss_on = 0, next_id = 0, n_rows = 0, n_payload = 0, flags = 0, rounds = 0;
+  u32 n_ev = 0, ev_base = 0, id_base = 0;  // journal cursor; :send events of a COMMIT sit at ev_base + (id - id_base)
 
+  // one journal event (event :id = idx); y = (message id << 8) | body type
+  auto jwrite = [&](u32 idx, u32 recv, u32 y, u32 a, u32 b, u32 src, u32 dest) {
+    if (idx < jcap) g_ev[idx] = make_uint4(T, (y & ~0x80u) | (recv << 7), a, src | (dest << 8) | ((b & 0xFFFFu) << 16));
+    else my_flags |= MSIM_FLAG_JOURNAL_OVERFLOW;
+  };
   // queue an envelope in this lane's LDS inbox
   auto lds_push = [&](const uint4 m) {
     if (in_n < my_cap) { my_inbox[in_n++] = m; return; }
@@ -272,6 +281,7 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
       else if (lat_dist == MSIM_LAT_UNIFORM) lat = scale32(draw32(key, S_LATENCY, id), 2 * lat_mean);
       else lat = (u32)(((u64)lat_mean * neg_ln_q16(draw32(key, S_LATENCY, id))) >> 16);
     }
+    if (jcap) jwrite(ev_base + (id - id_base), 0, (id << 8) | type, a, b, src, lane);  // journal :send precedes the loss decision (net.clj:208)
     if (NET_RANDOM && loss_on && p_loss && draw32(key, S_LOSS, id) < p_loss) return;  // net.clj:214
     uint4 m = make_uint4(T + lat * 1000u, (id << 8) | type, a, b | (src << 24));
     if (!have_pm) { pm = m; have_pm = true; return; }
@@ -526,6 +536,7 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
           s_send_cl++;
         }
         const u32 rq_pack = rq_dest | (rq_type << 8);
+        ev_base = n_ev; id_base = next_id; n_ev += (u32)__popcll(inv_mask);
         while (inv_mask) {
           const u32 s = (u32)__builtin_ctzll(inv_mask); inv_mask &= inv_mask - 1;
           const u32 pk = rdlane(rq_pack, s);
@@ -540,6 +551,8 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
       u32 fan_mask = 0, fan_a = 0, fan_b0 = 0;
       bool rep = false; u32 rep_dest = 0, rep_type = 0, rep_a = 0, rep_b = 0;
       bool rd = false;
+      u64 jd_mask = 0;  // nodes delivering an envelope this round (their :recv events come first, node order)
+      if (jcap) jd_mask = __ballot(is_node && !(IS_GSET && timer_next <= T) && !(IS_ACK && retry_time <= T) && has_c && deliver_at <= T);
       if (is_node) {
         if (IS_GSET && timer_next <= T) {  // g_set.rb:33-38
           timer_next = T + 5000000u;
@@ -561,6 +574,7 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
           const uint4 q = cm; has_c = false;
           const u32 qsrc = q.w >> 24, qb = q.w & 0xFFFFFFu, qtype = q.y & 0xFFu, qa = q.z;
           if (qsrc >= N) s_recv_cl++; else s_recv_sv++;  // journal :recv (net.clj:244)
+          if (jcap) jwrite(n_ev + (u32)__popcll(jd_mask & lt_mask), 1, q.y, qa, qb, qsrc, lane);
           switch (qtype) {
             case M_INIT:
               if (IS_GSET) timer_next = T;
@@ -598,6 +612,7 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
         }
       }
 
+      n_ev += (u32)__popcll(jd_mask);
       // read results: the whole wave copies the node's set LDS -> HBM payload (256 B per instruction)
       {
         u64 rdmask = __ballot(rd);
@@ -623,6 +638,7 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
         const u32 cnt = fan_cnt + (rep ? 1u : 0u);
         if (__ballot(cnt != 0)) {
           const u32 incl = scan32(cnt);  // senders are node lanes (< 32)
+          ev_base = n_ev; id_base = next_id; n_ev += rdlane(incl, 31);
           if (is_node) { s_send_sv += fan_cnt; if (rep) { if (rep_dest >= N) s_send_cl++; else s_send_sv++; } }
           if (__ballot(fan_mask != 0)) commit_fan(fan_mask, fan_a, fan_b0, incl - cnt + ((REP_FIRST && rep) ? 1u : 0u));
           u64 reps = __ballot(rep);
@@ -641,12 +657,16 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
         poll();  // every round: a node that just went idle may still have queued envelopes
       }
 
-      // ---- R4: clients run their recv! loop (client.clj:94-107) ----
-      if (__ballot(is_client && has_c)) {
-        while (is_client && has_c && deliver_at <= T) {
+      // ---- R4: clients run their recv! loops (client.clj:94-107); envelope k of every client before envelope k+1 ----
+      for (;;) {
+        const bool dl = is_client && has_c && deliver_at <= T;
+        const u64 dm = __ballot(dl);
+        if (!dm) break;
+        if (dl) {
           const uint4 q = cm; has_c = false;
           s_recv_cl++;
           const u32 qb = q.w & 0xFFFFFFu, qtype = q.y & 0xFFu, qa = q.z;
+          if (jcap) jwrite(n_ev + (u32)__popcll(dm & lt_mask), 1, q.y, qa, qb, q.w >> 24, lane);
           if (busy && qb == want) {  // else: stale reply, keep polling (client.clj:105-107)
             if (qtype == M_READ_OK) complete(MSIM_T_OK, 0, qa & 0xFFFFFFu, qa >> 24);
             else if (qtype == M_ECHO_OK) complete(MSIM_T_OK, 0, qa, 0);
@@ -654,6 +674,7 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
           }
           poll();
         }
+        n_ev += (u32)__popcll(dm);
       }
     }
 
@@ -707,6 +728,11 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
         if (++rounds > ROUND_LIMIT) { flags |= MSIM_FLAG_ROUND_LIMIT; phase = PH_DONE; break; }
         const u32 v = cm.z;
         u32 fan = 0;
+        if (jcap) {
+          const u64 dmj = __ballot(due_now);
+          if (due_now) jwrite(n_ev + (u32)__popcll(dmj & lt_mask), 1, cm.y, v, 0, cm.w >> 24, lane);
+          n_ev += (u32)__popcll(dmj);
+        }
         if (due_now) {
           has_c = false; s_recv_sv++;
           const u32 wv = my_seen[v >> 5], bitm = 1u << (v & 31);
@@ -719,6 +745,7 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
           const u32 cnt = __popc(fan);
           const u32 incl = scan32(cnt);
           s_send_sv += cnt;
+          ev_base = n_ev; id_base = next_id; n_ev += rdlane(incl, 31);
           commit_fan(fan, v, 0, incl - cnt);
           next_id += rdlane(incl, 31);
         }
@@ -737,7 +764,7 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
   }
   const u32 t_send_cl = wave_sum(s_send_cl), t_send_sv = wave_sum(s_send_sv);
   const u32 t_recv_cl = wave_sum(s_recv_cl), t_recv_sv = wave_sum(s_recv_sv);
-  for (u32 b = 1; b <= MSIM_FLAG_ROUND_LIMIT; b <<= 1) if (__ballot((my_flags & b) != 0)) flags |= b;
+  for (u32 b = 1; b <= MSIM_FLAG_JOURNAL_OVERFLOW; b <<= 1) if (__ballot((my_flags & b) != 0)) flags |= b;
   if (lane == 0) {
     msim_net_stats st;
     st.all_send = (u64)t_send_cl + t_send_sv; st.all_recv = (u64)t_recv_cl + t_recv_sv;
@@ -745,6 +772,7 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
     st.servers_send = t_send_sv; st.servers_recv = t_recv_sv;
     p.stats[inst] = st;
     msim_inst_meta m; m.n_rows = n_rows; m.n_payload_words = n_payload; m.flags = flags; m.n_rounds = rounds;
+    m.n_events = jcap ? n_ev : 0; m.reserved[0] = 0; m.reserved[1] = 0; m.reserved[2] = 0;
     p.meta[inst] = m;
   }
 }
@@ -769,12 +797,15 @@ static void free_buffers(msim_ctx *c) {
   if (c->d_meta) (void)hipFree(c->d_meta);
   if (c->d_scratch) (void)hipFree(c->d_scratch);
   if (c->d_check) (void)hipFree(c->d_check);
+  if (c->d_journal) (void)hipFree(c->d_journal);
   if (c->h_rows) (void)hipHostFree(c->h_rows);
   if (c->h_payload) (void)hipHostFree(c->h_payload);
   if (c->h_stats) (void)hipHostFree(c->h_stats);
   if (c->h_meta) (void)hipHostFree(c->h_meta);
   if (c->h_check) (void)hipHostFree(c->h_check);
-  delete[] c->h_row_off; delete[] c->h_pay_off;
+  if (c->h_journal) (void)hipHostFree(c->h_journal);
+  delete[] c->h_row_off; delete[] c->h_pay_off; delete[] c->h_ev_off;
+  c->d_journal = nullptr; c->h_journal = nullptr; c->h_ev_off = nullptr;
   c->d_rows = nullptr; c->d_payload = nullptr; c->d_stats = nullptr; c->d_meta = nullptr; c->d_scratch = nullptr; c->d_check = nullptr;
   c->h_rows = nullptr; c->h_payload = nullptr; c->h_stats = nullptr; c->h_meta = nullptr; c->h_check = nullptr;
   c->h_row_off = nullptr; c->h_pay_off = nullptr;
@@ -837,6 +868,7 @@ static int ensure_buffers(msim_ctx *ctx, uint32_t n) {
   MSIM_HIP_TRY(ctx, hipMalloc(&ctx->d_meta, (size_t)n * sizeof(msim_inst_meta)));
   MSIM_HIP_TRY(ctx, hipMalloc(&ctx->d_scratch, (size_t)n * ctx->scratch_words_per_inst * 4));
   MSIM_HIP_TRY(ctx, hipMalloc(&ctx->d_check, (size_t)n * sizeof(msim_check_result)));
+  if (c.journal_capacity) MSIM_HIP_TRY(ctx, hipMalloc(&ctx->d_journal, (size_t)n * c.journal_capacity * sizeof(msim_event)));
   ctx->cap_inst = n;
   return MSIM_OK;
 }
@@ -874,6 +906,7 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   kp.cfg = c; kp.first_instance = first;
   kp.rows = ctx->d_rows; kp.payload = ctx->d_payload; kp.stats = ctx->d_stats; kp.meta = ctx->d_meta;
   kp.scratch = ctx->d_scratch; kp.scratch_words = ctx->scratch_words_per_inst;
+  kp.journal = reinterpret_cast<uint4 *>(ctx->d_journal);
   kp.N = c.n_nodes; kp.C = c.concurrency; kp.CS = c.concurrency > c.n_nodes ? c.concurrency : c.n_nodes;
   kp.W = c.max_values / 32;
   kp.cap_node = c.inbox_capacity; kp.spill_cap = c.spill_capacity; kp.spill_off = proto_scratch_words(c);
@@ -937,19 +970,22 @@ extern "C" int msim_fetch(msim_ctx *ctx) {
   if (ctx->h_stats) { (void)hipHostFree(ctx->h_stats); ctx->h_stats = nullptr; }
   if (ctx->h_rows) { (void)hipHostFree(ctx->h_rows); ctx->h_rows = nullptr; }
   if (ctx->h_payload) { (void)hipHostFree(ctx->h_payload); ctx->h_payload = nullptr; }
-  delete[] ctx->h_row_off; delete[] ctx->h_pay_off;
-  ctx->h_row_off = new uint64_t[n + 1]; ctx->h_pay_off = new uint64_t[n + 1];
+  if (ctx->h_journal) { (void)hipHostFree(ctx->h_journal); ctx->h_journal = nullptr; }
+  delete[] ctx->h_row_off; delete[] ctx->h_pay_off; delete[] ctx->h_ev_off;
+  ctx->h_row_off = new uint64_t[n + 1]; ctx->h_pay_off = new uint64_t[n + 1]; ctx->h_ev_off = new uint64_t[n + 1];
   MSIM_HIP_TRY(ctx, hipHostMalloc(&ctx->h_meta, (size_t)n * sizeof(msim_inst_meta)));
   MSIM_HIP_TRY(ctx, hipHostMalloc(&ctx->h_stats, (size_t)n * sizeof(msim_net_stats)));
   MSIM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   MSIM_HIP_TRY(ctx, hipMemcpy(ctx->h_meta, ctx->d_meta, (size_t)n * sizeof(msim_inst_meta), hipMemcpyDeviceToHost));
   MSIM_HIP_TRY(ctx, hipMemcpy(ctx->h_stats, ctx->d_stats, (size_t)n * sizeof(msim_net_stats), hipMemcpyDeviceToHost));
-  uint64_t ro = 0, po = 0;
+  uint64_t ro = 0, po = 0, eo = 0;
   for (uint32_t i = 0; i < n; i++) {
-    ctx->h_row_off[i] = ro; ctx->h_pay_off[i] = po;
+    ctx->h_row_off[i] = ro; ctx->h_pay_off[i] = po; ctx->h_ev_off[i] = eo;
     ro += ctx->h_meta[i].n_rows; po += ctx->h_meta[i].n_payload_words;
+    eo += ctx->h_meta[i].n_events < c.journal_capacity ? ctx->h_meta[i].n_events : c.journal_capacity;
   }
-  ctx->h_row_off[n] = ro; ctx->h_pay_off[n] = po;
+  ctx->h_row_off[n] = ro; ctx->h_pay_off[n] = po; ctx->h_ev_off[n] = eo;
+  if (c.journal_capacity) MSIM_HIP_TRY(ctx, hipHostMalloc(&ctx->h_journal, (size_t)(eo + 1) * sizeof(msim_event)));
   MSIM_HIP_TRY(ctx, hipHostMalloc(&ctx->h_rows, (size_t)(ro + 1) * sizeof(msim_op)));
   MSIM_HIP_TRY(ctx, hipHostMalloc(&ctx->h_payload, (size_t)(po + 1) * 4));
   // only the used prefix of every instance's slab crosses PCIe
@@ -959,6 +995,9 @@ extern "C" int msim_fetch(msim_ctx *ctx) {
                                                  (size_t)m.n_rows * sizeof(msim_op), hipMemcpyDeviceToHost, ctx->stream));
     if (m.n_payload_words) MSIM_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_payload + ctx->h_pay_off[i], ctx->d_payload + (size_t)i * c.max_payload_words,
                                                           (size_t)m.n_payload_words * 4, hipMemcpyDeviceToHost, ctx->stream));
+    const uint64_t ne = ctx->h_ev_off[i + 1] - ctx->h_ev_off[i];
+    if (ne) MSIM_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_journal + ctx->h_ev_off[i], ctx->d_journal + (size_t)i * c.journal_capacity,
+                                           (size_t)ne * sizeof(msim_event), hipMemcpyDeviceToHost, ctx->stream));
   }
   MSIM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ctx->fetched = true;
@@ -979,6 +1018,15 @@ extern "C" int msim_net_stats_get(msim_ctx *ctx, uint32_t inst, msim_net_stats *
   if (!ctx || !out) return MSIM_E_INVALID;
   if (!ctx->fetched || inst >= ctx->n_inst) { ctx->err = "msim_net_stats_get: not fetched or instance out of range"; return MSIM_E_RANGE; }
   *out = ctx->h_stats[inst];
+  return MSIM_OK;
+}
+
+extern "C" int msim_journal(msim_ctx *ctx, uint32_t inst, const msim_event **events, uint32_t *n_events) {
+  if (!ctx) return MSIM_E_INVALID;
+  if (!ctx->fetched || inst >= ctx->n_inst) { ctx->err = "msim_journal: not fetched or instance out of range"; return MSIM_E_RANGE; }
+  if (!ctx->cfg.journal_capacity) { ctx->err = "msim_journal: journal_capacity is 0 (journal off)"; return MSIM_E_INVALID; }
+  if (events) *events = ctx->h_journal + ctx->h_ev_off[inst];
+  if (n_events) *n_events = (uint32_t)(ctx->h_ev_off[inst + 1] - ctx->h_ev_off[inst]);
   return MSIM_OK;
 }
 
@@ -1010,11 +1058,12 @@ extern "C" int msim_device_buffers_get(msim_ctx *ctx, msim_device_buffers *out) 
   const msim_config &c = ctx->cfg;
   out->rows = ctx->d_rows; out->payload = ctx->d_payload; out->stats = ctx->d_stats; out->meta = ctx->d_meta;
   out->check = ctx->d_check; out->check_bytes = (uint64_t)ctx->n_inst * sizeof(msim_check_result);
+  out->journal = ctx->d_journal; out->journal_bytes = (uint64_t)ctx->n_inst * c.journal_capacity * sizeof(msim_event);
   out->rows_bytes = (uint64_t)ctx->n_inst * c.max_rows * sizeof(msim_op);
   out->payload_bytes = (uint64_t)ctx->n_inst * c.max_payload_words * 4;
   out->stats_bytes = (uint64_t)ctx->n_inst * sizeof(msim_net_stats);
   out->meta_bytes = (uint64_t)ctx->n_inst * sizeof(msim_inst_meta);
-  out->n_instances = ctx->n_inst; out->max_rows = c.max_rows; out->max_payload_words = c.max_payload_words; out->reserved = 0;
+  out->n_instances = ctx->n_inst; out->max_rows = c.max_rows; out->max_payload_words = c.max_payload_words; out->journal_capacity = c.journal_capacity;
   return MSIM_OK;
 }
 

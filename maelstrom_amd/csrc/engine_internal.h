@@ -26,13 +26,15 @@ struct msim_ctx {
   uint32_t *d_scratch = nullptr;
   uint64_t scratch_words_per_inst = 0;
   msim_check_result *d_check = nullptr;
+  msim_event *d_journal = nullptr;
   // host (pinned) mirrors
   msim_op *h_rows = nullptr;
   uint32_t *h_payload = nullptr;
   msim_net_stats *h_stats = nullptr;
   msim_inst_meta *h_meta = nullptr;
   msim_check_result *h_check = nullptr;
-  uint64_t *h_row_off = nullptr, *h_pay_off = nullptr;  // compacted offsets per instance
+  msim_event *h_journal = nullptr;
+  uint64_t *h_row_off = nullptr, *h_pay_off = nullptr, *h_ev_off = nullptr;  // compacted offsets per instance
   bool fetched = false, checked = false, check_fetched = false, ran = false;
   float sim_ms = 0.f, check_ms = 0.f;
   std::string err;

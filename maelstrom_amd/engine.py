@@ -14,7 +14,8 @@ from . import _abi as A
 
 OP_DT = np.dtype([("time_len", "<u8"), ("packed", "<u4"), ("value", "<u4")])
 STATS_DT = np.dtype([(n, "<u8") for n in ("all_send", "all_recv", "clients_send", "clients_recv", "servers_send", "servers_recv")])
-META_DT = np.dtype([(n, "<u4") for n in ("n_rows", "n_payload_words", "flags", "n_rounds")])
+META_DT = np.dtype([(n, "<u4") for n in ("n_rows", "n_payload_words", "flags", "n_rounds", "n_events", "r0", "r1", "r2")])
+EVENT_DT = np.dtype([(n, "<u4") for n in ("time_us", "msg", "a", "route")])
 CHECK_DT = np.dtype([("valid", "<u4"), ("attempt_count", "<u4"), ("stable_count", "<u4"), ("lost_count", "<u4"),
                      ("never_read_count", "<u4"), ("stale_count", "<u4"), ("duplicated_count", "<u4"),
                      ("error_count", "<u4"), ("stable_latency_ms", "<u4", (5,)), ("op_count", "<u4"),
@@ -141,6 +142,15 @@ class Engine:
         payload = np.ctypeslib.as_array(pay, shape=(max(n_words.value, 1),))[: n_words.value]
         return rows, payload
 
+    def raw_journal(self, i):
+        """numpy view of instance i's net journal (journal_capacity > 0, after fetch)."""
+        ev, n = C.POINTER(A.Event)(), C.c_uint32()
+        self._chk(self.lib.msim_journal(self._ctx, i, C.byref(ev), C.byref(n)), "msim_journal")
+        return np.ctypeslib.as_array(C.cast(ev, C.POINTER(C.c_uint8)), shape=(max(n.value, 1) * 16,))[: n.value * 16].view(EVENT_DT)
+
+    def journal(self, i):
+        return decode_journal(self.raw_journal(i), self.cfg.n_nodes)
+
     def net_stats_raw(self, i):
         st = A.NetStats()
         self._chk(self.lib.msim_net_stats_get(self._ctx, i, C.byref(st)), "msim_net_stats_get")
@@ -181,6 +191,38 @@ def net_stats_map(st, rows):
         m["servers"]["msgs-per-op"] = m["servers"]["msg-count"] / op_count
     m["valid?"] = True
     return m
+
+
+def endpoint_name(ep, n_nodes):
+    return f"n{ep}" if ep < n_nodes else f"c{ep - n_nodes}"
+
+
+def decode_journal(events, n_nodes):
+    """Binary events -> the Event maps of net/journal.clj:53 ({:id :time :type :message {:id :src :dest :body}})."""
+    out = []
+    for i in range(len(events)):
+        msg, route = int(events["msg"][i]), int(events["route"][i])
+        body = {"type": A.MSG_TYPES[msg & 0x7F], "a": int(events["a"][i])}
+        if route >> 16:
+            body["msg_id/in_reply_to"] = route >> 16
+        out.append({"id": i, "time": int(events["time_us"][i]) * 1000, "type": ":recv" if msg & 0x80 else ":send",
+                    "message": {"id": msg >> 8, "src": endpoint_name(route & 0xFF, n_nodes),
+                                "dest": endpoint_name((route >> 8) & 0xFF, n_nodes), "body": body}})
+    return out
+
+
+def journal_stats(events, n_nodes):
+    """maelstrom.net.checker's fold over the journal (net/checker.clj:28-41): send/recv/msg counts for all,
+    clients (a client endpoint involved, util.clj:12-16) and servers."""
+    msg, route = events["msg"], events["route"]
+    recv = (msg & 0x80) != 0
+    cl = ((route & 0xFF) >= n_nodes) | (((route >> 8) & 0xFF) >= n_nodes)
+    ids = msg >> 8
+    res = {}
+    for name, sel in (("all", np.ones(len(events), bool)), ("clients", cl), ("servers", ~cl)):
+        res[name] = {"send-count": int((sel & ~recv).sum()), "recv-count": int((sel & recv).sum()),
+                     "msg-count": int(len(np.unique(ids[sel])))}
+    return res
 
 
 def bitmap_to_list(words):

@@ -16,7 +16,7 @@ def shard(n_total, rank, world):
 
 def compact(rows, payload, meta):
     """Drops the unused tail of every instance's slab.
-    rows [n, max_rows, 4] i32, payload [n, max_words] i32, meta [n, 4] i32 (n_rows, n_words, flags, rounds)
+    rows [n, max_rows, 4] i32, payload [n, max_words] i32, meta [n, 8] i32 (n_rows, n_words, flags, rounds, n_events, ...)
     -> (rows [sum n_rows, 4], payload [sum n_words], n_rows [n] i64, n_words [n] i64)."""
     nr = meta[:, 0].long()
     nw = meta[:, 1].long()

@@ -90,6 +90,7 @@ typedef struct {
   tasks_t *tasks;       /* ack/retry: FIFO of gossip threads per node */
   u32 *unacked;         /* ack/retry: [node][value][MW] un-acked neighbour sets */
   u32 *timer_next;      /* g-set replicate timer */
+  u32 *tick;            /* g-set: replicate ticks so far, per node */
   u32 **snap; u32 n_snap, cap_snap; /* replicate_full payload snapshots */
   /* clients */
   struct cl { u8 busy, kind, mark; u32 want, timeout_at, next_msg_id, f, value, process, m_f, m_value, m_final; } *cl;
@@ -100,6 +101,9 @@ typedef struct {
   outmsg *out; u32 n_out, cap_out;
   /* outputs */
   msim_op *rows; u32 *payload; msim_inst_meta meta;
+  msim_event *journal;  /* net journal (journal.clj:53,220-239), optional */
+  struct { u8 on; u32 type, f, err, final, process, value, len; } *pend; /* completion rows of the current round, by slot */
+  int defer_rows;
 } sim_t;
 
 /* ---- RNG: counter-based, keyed (seed, instance, stream, counter) --------------------------------- */
@@ -167,6 +171,16 @@ static void add_row(sim_t *s, u32 type, u32 f, u32 err, u32 final, u32 process, 
   r->time_len = ((u64)s->T * 1000ull) | ((u64)len << 48);
   r->packed = type | (f << 2) | (err << 7) | (final << 11) | (process << 12);
   r->value = value;
+}
+
+/* journal/log-send! / log-recv! (journal.clj:225-239): event id = position */
+static void jlog(sim_t *s, u32 recv, u32 id, u32 type, u32 a, u32 b, u32 src, u32 dest) {
+  if (!s->cfg.journal_capacity) return;
+  if (s->meta.n_events < s->cfg.journal_capacity) {
+    msim_event *e = &s->journal[s->meta.n_events];
+    e->time_us = s->T; e->msg = (id << 8) | (recv << 7) | type; e->a = a; e->route = src | (dest << 8) | ((b & 0xFFFFu) << 16);
+  } else s->meta.flags |= MSIM_FLAG_JOURNAL_OVERFLOW;
+  s->meta.n_events++;
 }
 
 /* returns payload offset or INF on overflow */
@@ -299,11 +313,18 @@ static u32 node_timer_time(const sim_t *s, u32 node) {
 static void node_timer(sim_t *s, u32 node) {
   if (s->timer_next[node] <= s->T) { /* g_set.rb:33-38: every 5 s, replicate_full to all other nodes */
     s->timer_next[node] = s->T + 5000000u;
-    if (s->n_snap == s->cap_snap) { s->cap_snap = s->cap_snap ? s->cap_snap * 2 : 64; s->snap = (u32 **)realloc(s->snap, s->cap_snap * sizeof(u32 *)); }
+    u32 tick = s->tick[node]++;           /* the message carries (sender, tick): a reference to the sender's set then */
+    u32 idx = tick * s->N + node;
+    while (idx >= s->cap_snap) {
+      u32 nc = s->cap_snap ? s->cap_snap * 2 : 64;
+      s->snap = (u32 **)realloc(s->snap, nc * sizeof(u32 *));
+      for (u32 i = s->cap_snap; i < nc; i++) s->snap[i] = NULL;
+      s->cap_snap = nc;
+    }
     u32 *cp = (u32 *)malloc(s->W * 4); memcpy(cp, seen_of(s, node), s->W * 4);
-    s->snap[s->n_snap] = cp;
-    for (u32 i = 0; i < s->N; i++) if (i != node) out_send(s, node, i, M_REPLICATE, s->n_snap, 0);
-    s->n_snap++;
+    s->snap[idx] = cp;
+    if (idx + 1 > s->n_snap) s->n_snap = idx + 1;
+    for (u32 i = 0; i < s->N; i++) if (i != node) out_send(s, node, i, M_REPLICATE, tick, 0);
     return;
   }
   /* the gossip thread of the oldest task wakes: resend to whoever has not acked, sleep 1 s again;
@@ -326,7 +347,7 @@ static void node_handle(sim_t *s, u32 node, const qent *q) {
     case M_BROADCAST_OK: node_broadcast_ok(s, node, q); break;
     case M_READ: node_read(s, node, q); break;
     case M_ADD: setbit(seen_of(s, node), q->a); out_send(s, node, q->src, M_ADD_OK, q->a, q->b); break; /* g_set.rb:17-21 */
-    case M_REPLICATE: { u32 *sn = seen_of(s, node), *v = s->snap[q->a]; for (u32 w = 0; w < s->W; w++) sn[w] |= v[w]; } break; /* g_set.rb:29-31 */
+    case M_REPLICATE: { u32 *sn = seen_of(s, node), *v = s->snap[q->a * s->N + q->src]; for (u32 w = 0; w < s->W; w++) sn[w] |= v[w]; } break; /* g_set.rb:29-31 */
     default: break;
   }
 }
@@ -340,7 +361,10 @@ static void client_complete(sim_t *s, u32 slot, u32 type, u32 err, u32 value, u3
   struct cl *c = &s->cl[slot];
   c->busy = 0;
   if (c->kind != K_OP) { if (type != MSIM_T_OK) s->meta.flags |= MSIM_FLAG_ROUND_LIMIT; return; }
-  add_row(s, type, c->f, err, c->m_final, c->process, value, len);
+  if (s->defer_rows) { /* R4: completion rows of a round are written in slot order after the recv! loops */
+    s->pend[slot].on = 1; s->pend[slot].type = type; s->pend[slot].f = c->f; s->pend[slot].err = err; s->pend[slot].final = c->m_final;
+    s->pend[slot].process = c->process; s->pend[slot].value = value; s->pend[slot].len = len;
+  } else add_row(s, type, c->f, err, c->m_final, c->process, value, len);
   if (type == MSIM_T_INFO) { /* crashed process: new process id, fresh client [upstream interpreter] */
     c->process += s->C;
     c->next_msg_id = 0;
@@ -506,6 +530,7 @@ static void commit_sends(sim_t *s) {
     u32 id = s->next_msg_id++;
     int cl = m->src_ep >= N || m->dest_ep >= N;
     s->st.all_send++; if (cl) s->st.clients_send++; else s->st.servers_send++; /* journal :send before loss */
+    jlog(s, 0, id, m->type, m->a, m->b, m->src_ep, m->dest_ep);
     u32 lat = latency_ms(s, id, cl);
     if (s->loss_on && s->cfg.p_loss_q32 && draw32(s, S_LOSS, id) < s->cfg.p_loss_q32) continue; /* net.clj:214 */
     qent q = {T + lat * 1000u, id, m->a, m->b, m->src_ep, m->type};
@@ -568,21 +593,34 @@ static void run_instance(sim_t *s) {
       else if (s->has_committed[n] && s->deliver_at[n] <= T) {
         qent q = s->committed[n]; s->has_committed[n] = 0;
         s->st.all_recv++; if (q.src >= N) s->st.clients_recv++; else s->st.servers_recv++; /* journal :recv */
+        jlog(s, 1, q.id, q.type, q.a, q.b, q.src, n);
         node_handle(s, n, &q);
       }
     }
     commit_sends(s);
     for (u32 e = 0; e < E; e++) poll_endpoint(s, e);
-    /* R4: clients (slot order) run their recv! loop: consume due envelopes until the awaited reply
-     * arrives; stale replies are skipped (client.clj:94-107) */
-    for (u32 c = 0; c < s->CS; c++) {
-      u32 e = N + c;
-      while (s->has_committed[e] && s->deliver_at[e] <= T) {
-        qent q = s->committed[e]; s->has_committed[e] = 0;
-        s->st.all_recv++; s->st.clients_recv++;
-        client_deliver(s, c, &q);
-        poll_endpoint(s, e);
+    /* R4: clients run their recv! loops: consume due envelopes until the awaited reply arrives; stale replies
+     * are skipped (client.clj:94-107).  Envelope k of every client is handled before envelope k+1 of any
+     * (journal order); the completion rows of the round are then written in slot order. */
+    s->defer_rows = 1;
+    for (int any = 1; any;) {
+      any = 0;
+      for (u32 c = 0; c < s->CS; c++) {
+        u32 e = N + c;
+        if (s->has_committed[e] && s->deliver_at[e] <= T) {
+          qent q = s->committed[e]; s->has_committed[e] = 0;
+          s->st.all_recv++; s->st.clients_recv++;
+          jlog(s, 1, q.id, q.type, q.a, q.b, q.src, e);
+          client_deliver(s, c, &q);
+          poll_endpoint(s, e);
+          any = 1;
+        }
       }
+    }
+    s->defer_rows = 0;
+    for (u32 c = 0; c < s->CS; c++) if (s->pend[c].on) {
+      s->pend[c].on = 0;
+      add_row(s, s->pend[c].type, s->pend[c].f, s->pend[c].err, s->pend[c].final, s->pend[c].process, s->pend[c].value, s->pend[c].len);
     }
   }
   s->meta.n_rounds = s->rounds;
@@ -610,8 +648,10 @@ static sim_t *sim_new(const msim_config *cfg, uint64_t instance, msim_op *rows, 
   s->tasks = (tasks_t *)calloc(s->N, sizeof(tasks_t));
   if (cfg->node_program == MSIM_NODE_BCAST_ACK_RETRY) s->unacked = (u32 *)calloc((size_t)s->N * cfg->max_values * MW, 4);
   s->timer_next = (u32 *)malloc(s->N * 4);
+  s->tick = (u32 *)calloc(s->N, 4);
   for (u32 i = 0; i < s->N; i++) s->timer_next[i] = INF;
   s->cl = (struct cl *)calloc(s->CS, sizeof(struct cl));
+  s->pend = calloc(s->CS, sizeof(*s->pend));
   for (u32 i = 0; i < s->CS; i++) s->cl[i].process = i;
   s->rows = rows; s->payload = payload;
   s->phase = PH_INIT;
@@ -623,16 +663,18 @@ static void sim_free(sim_t *s) {
   for (u32 n = 0; n < s->N; n++) free(s->tasks[n].v);
   for (u32 i = 0; i < s->n_snap; i++) free(s->snap[i]);
   free(s->snap); free(s->inbox); free(s->committed); free(s->has_committed); free(s->deliver_at); free(s->seen);
-  free(s->unacked); free(s->node_msg_id); free(s->nbr_known); free(s->tasks); free(s->timer_next); free(s->cl); free(s->out);
+  free(s->unacked); free(s->node_msg_id); free(s->nbr_known); free(s->tasks); free(s->timer_next); free(s->tick); free(s->cl); free(s->pend); free(s->out);
   free(s);
 }
 
 /* Simulates global instance `instance` of `cfg` (already finalized: capacities non-zero).
  * rows: max_rows entries; payload: max_payload_words words.  Returns 0, or -1 on a bad config. */
 int oracle_run_instance(const msim_config *cfg, uint64_t instance, msim_op *rows, uint32_t *payload,
-                        msim_net_stats *stats, msim_inst_meta *meta) {
+                        msim_net_stats *stats, msim_inst_meta *meta, msim_event *journal) {
   sim_t *s = sim_new(cfg, instance, rows, payload);
   if (!s) return -1;
+  if (cfg->journal_capacity && !journal) { sim_free(s); return -1; }
+  s->journal = journal;
   run_instance(s);
   *stats = s->st; *meta = s->meta;
   sim_free(s);
@@ -665,7 +707,7 @@ int oracle_node_trace(const msim_config *cfg, uint32_t node, const uint32_t *in,
     for (u32 k = 0; k < s->n_out && n < out_cap; k++, n++) {
       u32 *o = out + 5 * n;
       o[0] = i; o[1] = s->out[k].dest_ep; o[2] = s->out[k].type; o[3] = s->out[k].a; o[4] = s->out[k].b;
-      if (s->out[k].type == M_REPLICATE && final_set) memcpy(final_set, s->snap[s->out[k].a], s->W * 4); /* last replicated value */
+      if (s->out[k].type == M_REPLICATE && final_set) memcpy(final_set, s->snap[s->out[k].a * s->N + node], s->W * 4); /* last replicated value */
     }
   }
   if (final_set && cfg->node_program != MSIM_NODE_G_SET) memcpy(final_set, seen_of(s, node), s->W * 4);
@@ -682,10 +724,11 @@ uint32_t oracle_msg_type(const char *name) {
 
 /* Runs instances [first, first+n) into instance-major output slabs (same layout as the engine). */
 int oracle_run(const msim_config *cfg, uint64_t first, uint32_t n, msim_op *rows, uint32_t *payload,
-               msim_net_stats *stats, msim_inst_meta *meta) {
+               msim_net_stats *stats, msim_inst_meta *meta, msim_event *journal) {
   for (uint32_t i = 0; i < n; i++) {
     int rc = oracle_run_instance(cfg, first + i, rows + (size_t)i * cfg->max_rows,
-                                 payload + (size_t)i * cfg->max_payload_words, stats + i, meta + i);
+                                 payload + (size_t)i * cfg->max_payload_words, stats + i, meta + i,
+                                 journal ? journal + (size_t)i * cfg->journal_capacity : NULL);
     if (rc) return rc;
   }
   return 0;

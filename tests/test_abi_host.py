@@ -23,8 +23,8 @@ def test_header_symbols_are_exported(lib):
 
 def test_struct_layouts_match_header():
     assert C.sizeof(A.Config) == 120 and A.Config.seed.offset == 64 and A.Config.max_values.offset == 72
-    assert C.sizeof(A.Op) == 16 and C.sizeof(A.NetStats) == 48 and C.sizeof(A.InstMeta) == 16
-    assert C.sizeof(A.CheckResult) == 68 and C.sizeof(A.DeviceBuffers) == 96
+    assert C.sizeof(A.Op) == 16 and C.sizeof(A.NetStats) == 48 and C.sizeof(A.InstMeta) == 32 and C.sizeof(A.Event) == 16
+    assert C.sizeof(A.CheckResult) == 68 and C.sizeof(A.DeviceBuffers) == 112 and A.Config.journal_capacity.offset == 92
 
 
 def test_defaults_mirror_reference_cli(lib):

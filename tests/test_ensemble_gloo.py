@@ -35,7 +35,7 @@ def _worker(rank, world, port, n_total, q):
     o = O.run(cfg, first, count)
     rows = torch.from_numpy(o.rows.view(np.int32).reshape(count, cfg.max_rows, 4).copy())
     pay = torch.from_numpy(o.payload.view(np.int32).copy())
-    meta = torch.from_numpy(o.meta.view(np.int32).reshape(count, 4).copy())
+    meta = torch.from_numpy(o.meta.view(np.int32).reshape(count, 8).copy())
     crow, cpay, nr, nw = EN.compact(rows, pay, meta)
     parts, nbytes = EN.gather_histories(crow, cpay, nr, nw, dist, world)
     msgs = torch.tensor([int(o.stats["all_send"].sum())], dtype=torch.int64)

@@ -185,3 +185,31 @@ def test_topologies_match_reference_builders(lib):
     assert sum(len(E.bitmap_to_list(adj[i])) for i in range(5)) == 2 * 5
     lib_o.oracle_topology(A.TOPO_TREE4, 25, (adj25 := np.zeros((25, 4), dtype=np.uint32)).ctypes.data)
     assert E.bitmap_to_list(adj25[0]) == [1, 2, 3, 4] and E.bitmap_to_list(adj25[1]) == [0, 5, 6, 7, 8]
+
+
+def test_journal_reproduces_net_checker_stats(lib):
+    """maelstrom.net.checker folds the journal into {:all :clients :servers} x {send,recv,msg}-count
+    (net/checker.clj:28-41): the journal the oracle emits must fold to exactly the engine's counters, every
+    :recv must follow its :send, and a lost or partition-dropped message has a :send but no :recv
+    (02-performance.md:519-529: 1277 sent / 734 received)."""
+    cfg = E.test_config("broadcast", bin="broadcast-ack-retry", node_count=5, rate=10, time_limit=20, topology="tree4",
+                        nemesis=["partition"], nemesis_interval=5, latency=10, seed=13, journal_capacity=100000)
+    r = O.run(cfg, 0, 4)
+    for i in range(4):
+        ev = r.events(i)
+        assert r.meta[i]["flags"] == 0 and len(ev) == r.meta[i]["n_events"]
+        st = E.journal_stats(ev, 5)
+        for k in ("all", "clients", "servers"):
+            assert st[k]["send-count"] == int(r.stats[i][f"{k}_send"]) and st[k]["recv-count"] == int(r.stats[i][f"{k}_recv"])
+            assert st[k]["msg-count"] == st[k]["send-count"]          # every id is journalled at send (net.clj:208)
+        assert st["servers"]["send-count"] > st["servers"]["recv-count"]  # partitions drop at recv time (net.clj:234)
+        seen_send = set()
+        last_t = 0
+        for e in E.decode_journal(ev, 5):
+            assert e["time"] >= last_t; last_t = e["time"]
+            mid = e["message"]["id"]
+            if e["type"] == ":send":
+                assert mid == len(seen_send)                          # ids count every send!, from 0 (net.clj:103,197)
+                seen_send.add(mid)
+            else:
+                assert mid in seen_send

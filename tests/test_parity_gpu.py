@@ -29,6 +29,9 @@ def _compare(cfg, first, n):
             orows, opay = ora.history(i)
             assert rows.tobytes() == orows.tobytes(), f"history rows differ for instance {first + i}"
             assert pay.tobytes() == opay.tobytes(), f"payload differs for instance {first + i}"
+            assert m.n_events == om["n_events"]
+            if cfg.journal_capacity:
+                assert eng.raw_journal(i).tobytes() == ora.events(i).tobytes(), f"net journal differs for instance {first + i}"
             st = eng.net_stats_raw(i)
             assert tuple(getattr(st, f) for f, _ in A.NetStats._fields_) == tuple(int(x) for x in ora.stats[i]), \
                 f"net stats differ for instance {first + i}"
@@ -102,3 +105,21 @@ def test_deep_queues_spill_to_hbm(lib):
     _compare(cfg, 0, 4)
     cfg = E.test_config("broadcast", node_count=5, rate=50, time_limit=5, latency=200, latency_dist="exponential", seed=9, inbox_capacity=2)
     _compare(cfg, 0, 8)
+
+
+@pytest.mark.parametrize("bin,conc,kw", [
+    ("broadcast-ff", 5, dict(latency=0)),
+    ("broadcast-ff", 5, dict(latency=20, latency_dist="exponential", p_loss=0.05)),
+    ("broadcast-ack-retry", 5, dict(latency=10, nemesis=["partition"], nemesis_interval=3)),
+    ("broadcast-rpc-all", 7, dict(latency=5)),
+    ("broadcast-ff", 3, dict(latency=30, latency_dist="uniform")),
+])
+def test_net_journal_parity(lib, bin, conc, kw):
+    """journal.clj:53,220-239: every send!/recv! as an event, bit-identical (ids, order, times) to the oracle,
+    in both kernel layouts (concurrency == / != node count)."""
+    cfg = E.test_config("broadcast", bin=bin, node_count=5, concurrency=conc, rate=20, time_limit=6, seed=31,
+                        journal_capacity=60000, **kw)
+    ora = _compare(cfg, 0, 8)
+    assert (ora.meta["n_events"] > 100).all()
+    cfg = E.test_config("g-set", node_count=5, rate=10, time_limit=10, seed=32, journal_capacity=20000)
+    _compare(cfg, 0, 4)
