@@ -100,7 +100,9 @@ typedef struct msim_config {
  *              12-31 process (MSIM_PROCESS_NEMESIS = :nemesis).
  *   value    : immediate (broadcast/add element, echo payload k of "Please echo k", partition spec) or
  *              offset in u32 words into the instance's payload area.
- * A read's :value is a bitmap over elements 0..32*len-1 (bit e set <=> e in the returned collection). */
+ * A read's :value is a bitmap over elements 0..32*len-1 (bit e set <=> e in the returned collection).
+ * lin-kv ops (lin_kv.clj:53-67) pack their independent tuple into `value`: bits 0-7 key k, 8-15 v, 16-23 v'
+ * (0xFF = nil): read [k v], write [k v], cas [k [v v']]. */
 typedef struct msim_op {
   uint64_t time_len;
   uint32_t packed;
@@ -111,7 +113,10 @@ enum { MSIM_T_INVOKE = 0, MSIM_T_OK = 1, MSIM_T_FAIL = 2, MSIM_T_INFO = 3 };
 enum { MSIM_F_ECHO = 0, MSIM_F_BROADCAST = 1, MSIM_F_READ = 2, MSIM_F_ADD = 3,
        MSIM_F_START_PARTITION = 4, MSIM_F_STOP_PARTITION = 5,
        MSIM_F_WRITE = 6, MSIM_F_CAS = 7, MSIM_F_TXN = 8 };
-enum { MSIM_ERR_NONE = 0, MSIM_ERR_NET_TIMEOUT = 1 /* client.clj:158-162 */, MSIM_ERR_RPC = 2 };
+enum { MSIM_ERR_NONE = 0, MSIM_ERR_NET_TIMEOUT = 1 /* client.clj:158-162 */, MSIM_ERR_RPC = 2,
+       /* RPC errors of resources/errors.edn, as :error [name text] (client.clj:163-172) */
+       MSIM_ERR_TEMPORARILY_UNAVAILABLE = 3 /* code 11 */, MSIM_ERR_KEY_DOES_NOT_EXIST = 4 /* code 20 */,
+       MSIM_ERR_PRECONDITION_FAILED = 5 /* code 22 */ };
 enum { MSIM_SPEC_ONE = 0, MSIM_SPEC_MAJORITY = 1, MSIM_SPEC_MAJORITIES_RING = 2, MSIM_SPEC_MINORITY_THIRD = 3 };
 #define MSIM_PROCESS_NEMESIS 0xFFFFFu
 #define MSIM_NO_VALUE 0xFFFFFFFFu   /* :value nil */
@@ -149,7 +154,9 @@ typedef struct msim_event {
   uint32_t route;
 } msim_event;
 enum { MSIM_M_INIT = 1, MSIM_M_INIT_OK, MSIM_M_TOPOLOGY, MSIM_M_TOPOLOGY_OK, MSIM_M_ECHO, MSIM_M_ECHO_OK, MSIM_M_BROADCAST,
-       MSIM_M_BROADCAST_OK, MSIM_M_READ, MSIM_M_READ_OK, MSIM_M_ADD, MSIM_M_ADD_OK, MSIM_M_REPLICATE };
+       MSIM_M_BROADCAST_OK, MSIM_M_READ, MSIM_M_READ_OK, MSIM_M_ADD, MSIM_M_ADD_OK, MSIM_M_REPLICATE,
+       MSIM_M_WRITE, MSIM_M_WRITE_OK, MSIM_M_CAS, MSIM_M_CAS_OK, MSIM_M_ERROR,
+       MSIM_M_REQUEST_VOTE, MSIM_M_REQUEST_VOTE_RES, MSIM_M_APPEND_ENTRIES, MSIM_M_APPEND_ENTRIES_RES };
 
 /* Per-instance bookkeeping (not part of the algorithmic output bytes). */
 typedef struct msim_inst_meta {

@@ -21,13 +21,14 @@ TOPO_GRID, TOPO_LINE, TOPO_TOTAL, TOPO_TREE2, TOPO_TREE3, TOPO_TREE4 = range(6)
 NEMESIS_PARTITION = 1
 T_INVOKE, T_OK, T_FAIL, T_INFO = range(4)
 F_ECHO, F_BROADCAST, F_READ, F_ADD, F_START_PARTITION, F_STOP_PARTITION, F_WRITE, F_CAS, F_TXN = range(9)
-ERR_NONE, ERR_NET_TIMEOUT, ERR_RPC = range(3)
+ERR_NONE, ERR_NET_TIMEOUT, ERR_RPC, ERR_TEMPORARILY_UNAVAILABLE, ERR_KEY_DOES_NOT_EXIST, ERR_PRECONDITION_FAILED = range(6)
 SPEC_ONE, SPEC_MAJORITY, SPEC_MAJORITIES_RING, SPEC_MINORITY_THIRD = range(4)
 PROCESS_NEMESIS = 0xFFFFF
 NO_VALUE = 0xFFFFFFFF
 FLAG_ROWS_OVERFLOW, FLAG_PAYLOAD_OVERFLOW, FLAG_INBOX_OVERFLOW, FLAG_VALUES_OVERFLOW, FLAG_ROUND_LIMIT, FLAG_JOURNAL_OVERFLOW = 1, 2, 4, 8, 16, 32
 MSG_TYPES = ["", "init", "init_ok", "topology", "topology_ok", "echo", "echo_ok", "broadcast", "broadcast_ok", "read", "read_ok",
-             "add", "add_ok", "replicate"]
+             "add", "add_ok", "replicate", "write", "write_ok", "cas", "cas_ok", "error", "request_vote", "request_vote_res",
+             "append_entries", "append_entries_res"]
 MASK_WORDS = 4
 
 EXPORTS = [

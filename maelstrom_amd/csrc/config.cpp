@@ -33,6 +33,7 @@ extern "C" int msim_config_defaults(msim_config *cfg, uint32_t workload, uint32_
   }
   cfg->n_nodes = n_nodes;
   cfg->concurrency = n_nodes;           // "1n"
+  if (workload == MSIM_WL_LIN_KV) cfg->concurrency = 2 * n_nodes;  // linearizable-register needs 2n threads per key (core.clj:111)
   cfg->rate_mhz = 5000;                 // core.clj:219-222
   cfg->time_limit_ms = 60000;           // jepsen.cli
   cfg->latency_mean_ms = 0;             // core.clj:171-174
@@ -85,7 +86,8 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
     case MSIM_WL_ECHO: ok = c->node_program == MSIM_NODE_ECHO; break;
     case MSIM_WL_BROADCAST: ok = c->node_program >= MSIM_NODE_BCAST_FF && c->node_program <= MSIM_NODE_BCAST_RPC_ALL; break;
     case MSIM_WL_G_SET: ok = c->node_program == MSIM_NODE_G_SET; break;
-    default: set_err(err, errlen, "workload not built into this engine yet (lin-kv / txn-list-append)"); return MSIM_E_UNSUPPORTED;
+    case MSIM_WL_LIN_KV: ok = c->node_program == MSIM_NODE_RAFT; break;
+    default: set_err(err, errlen, "workload not built into this engine yet (txn-list-append)"); return MSIM_E_UNSUPPORTED;
   }
   if (!ok) { set_err(err, errlen, "node_program does not implement this workload"); return MSIM_E_INVALID; }
 
@@ -94,12 +96,15 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
   uint32_t adds = (uint32_t)(ops_max / 2 + 4.0 * std::sqrt((double)ops_max)) + 32;
   uint32_t nem_ops = 0;
   if (c->nemesis_mask) nem_ops = 4 * (c->time_limit_ms / c->nemesis_interval_ms + 1) + 16;
-  if (c->max_values == 0) c->max_values = c->workload == MSIM_WL_ECHO ? 32 : ((adds + 31) / 32) * 32;
+  if (c->workload == MSIM_WL_LIN_KV && c->concurrency % (2 * c->n_nodes)) {
+    set_err(err, errlen, "lin-kv: concurrency must be a multiple of 2 x node-count ([upstream] independent/concurrent-generator)"); return MSIM_E_INVALID; }
+  const bool no_sets = c->workload == MSIM_WL_ECHO || c->workload == MSIM_WL_LIN_KV;
+  if (c->max_values == 0) c->max_values = no_sets ? 32 : ((adds + 31) / 32) * 32;
   if (c->max_values % 32) c->max_values = ((c->max_values + 31) / 32) * 32;
   if (c->max_rows == 0) c->max_rows = 2 * (ops_max + c->concurrency) + 2 * nem_ops + 16;
   if (c->max_payload_words == 0) {
     uint32_t w = c->max_values / 32;
-    uint64_t words = c->workload == MSIM_WL_ECHO ? 16 : (uint64_t)(adds + c->concurrency) * w;
+    uint64_t words = no_sets ? 16 : (uint64_t)(adds + c->concurrency) * w;
     words += (uint64_t)nem_ops * c->n_nodes * MSIM_MASK_WORDS + 16;
     if (words > 0xFFFFFFu) { set_err(err, errlen, "payload area above 2^24 words per instance"); return MSIM_E_INVALID; }
     c->max_payload_words = (uint32_t)words;

@@ -819,6 +819,10 @@ extern "C" int msim_create(const msim_config *cfg, int device, msim_ctx **out, c
   int rc = msim_config_finalize(&c, err, errlen);
   if (rc != MSIM_OK) return rc;
   const uint32_t slots = c.concurrency > c.n_nodes ? c.concurrency : c.n_nodes;
+  if (c.node_program == MSIM_NODE_RAFT) {
+    set_err(err, errlen, "raft / lin-kv: restated and pinned in the CPU oracle only so far; the HIP node program is not built yet");
+    return MSIM_E_UNSUPPORTED;
+  }
   if (c.n_nodes > 32 || c.n_nodes + slots > 64) {
     set_err(err, errlen, "this build maps one cluster to one wavefront: n_nodes <= 32 and n_nodes + max(concurrency, n_nodes) <= 64");
     return MSIM_E_UNSUPPORTED;

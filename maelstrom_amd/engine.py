@@ -25,13 +25,15 @@ WORKLOADS = {"echo": A.WL_ECHO, "broadcast": A.WL_BROADCAST, "g-set": A.WL_G_SET
              "txn-list-append": A.WL_TXN_LIST_APPEND}
 NODE_PROGRAMS = {"echo": A.NODE_ECHO, "broadcast-ff": A.NODE_BCAST_FF, "broadcast-ff-echoback": A.NODE_BCAST_FF_ECHOBACK,
                  "broadcast-ack-retry": A.NODE_BCAST_ACK_RETRY, "broadcast-rpc-all": A.NODE_BCAST_RPC_ALL,
-                 "g-set": A.NODE_G_SET}
+                 "g-set": A.NODE_G_SET, "raft": A.NODE_RAFT}
 TOPOLOGIES = {"grid": A.TOPO_GRID, "line": A.TOPO_LINE, "total": A.TOPO_TOTAL, "tree": A.TOPO_TREE2,
               "tree2": A.TOPO_TREE2, "tree3": A.TOPO_TREE3, "tree4": A.TOPO_TREE4}
 LATENCY_DISTS = {"constant": A.LAT_CONSTANT, "uniform": A.LAT_UNIFORM, "exponential": A.LAT_EXPONENTIAL}
 TYPE_KW = {A.T_INVOKE: ":invoke", A.T_OK: ":ok", A.T_FAIL: ":fail", A.T_INFO: ":info"}
 F_KW = {A.F_ECHO: ":echo", A.F_BROADCAST: ":broadcast", A.F_READ: ":read", A.F_ADD: ":add",
-        A.F_START_PARTITION: ":start-partition", A.F_STOP_PARTITION: ":stop-partition"}
+        A.F_START_PARTITION: ":start-partition", A.F_STOP_PARTITION: ":stop-partition", A.F_WRITE: ":write", A.F_CAS: ":cas"}
+ERR_KW = {A.ERR_NET_TIMEOUT: ":net-timeout", A.ERR_TEMPORARILY_UNAVAILABLE: [":temporarily-unavailable", "not a leader"],
+          A.ERR_KEY_DOES_NOT_EXIST: [":key-does-not-exist", "not found"], A.ERR_PRECONDITION_FAILED: [":precondition-failed", "cas mismatch"]}
 SPEC_KW = {A.SPEC_ONE: ":one", A.SPEC_MAJORITY: ":majority", A.SPEC_MAJORITIES_RING: ":majorities-ring",
            A.SPEC_MINORITY_THIRD: ":minority-third"}
 
@@ -170,7 +172,7 @@ class Engine:
     # ---- Jepsen-shaped views ---------------------------------------------------------------------
     def history(self, i):
         rows, payload = self.raw_history(i)
-        return decode_history(rows, payload, self.cfg.n_nodes)
+        return decode_history(rows, payload, self.cfg.n_nodes, self.cfg.workload)
 
     def net_stats(self, i):
         """The :net :stats map of net/checker.clj:28-41,55-67."""
@@ -236,7 +238,11 @@ def bitmap_to_list(words):
     return out
 
 
-def decode_history(rows, payload, n_nodes):
+def _nil(x):
+    return None if x == 0xFF else x
+
+
+def decode_history(rows, payload, n_nodes, workload=A.WL_BROADCAST):
     """Binary rows -> list of Jepsen op maps (SURVEY.md §8b 'History surface')."""
     ops = []
     for idx in range(len(rows)):
@@ -245,7 +251,10 @@ def decode_history(rows, payload, n_nodes):
         final, process, ln = (packed >> 11) & 1, packed >> 12, tl >> 48
         op = {"index": idx, "time": tl & 0xFFFFFFFFFFFF, "type": TYPE_KW[typ], "f": F_KW.get(f, f),
               "process": ":nemesis" if process == A.PROCESS_NEMESIS else process}
-        if f == A.F_READ:
+        if workload == A.WL_LIN_KV and f in (A.F_READ, A.F_WRITE, A.F_CAS):  # independent tuples, lin_kv.clj:53-67
+            k, v1, v2 = value & 0xFF, _nil((value >> 8) & 0xFF), _nil((value >> 16) & 0xFF)
+            op["value"] = [k, [v1, v2]] if f == A.F_CAS else [k, v1]
+        elif f == A.F_READ:
             op["value"] = bitmap_to_list(payload[value:value + ln]) if typ == A.T_OK else None
         elif f == A.F_ECHO:
             v = f"Please echo {value}"
@@ -260,8 +269,8 @@ def decode_history(rows, payload, n_nodes):
             op["value"] = None if idx == 0 or int(rows["packed"][idx - 1]) != packed or False else ":network-healed"
         else:
             op["value"] = None if value == A.NO_VALUE else value
-        if err == A.ERR_NET_TIMEOUT:
-            op["error"] = ":net-timeout"
+        if err in ERR_KW:
+            op["error"] = ERR_KW[err]
         if final:
             op["final?"] = True
         ops.append(op)

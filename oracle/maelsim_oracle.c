@@ -55,10 +55,12 @@ typedef uint64_t u64;
 
 /* message types (doc/protocol.md, doc/workloads.md) */
 enum { M_INIT = 1, M_INIT_OK, M_TOPOLOGY, M_TOPOLOGY_OK, M_ECHO, M_ECHO_OK, M_BROADCAST, M_BROADCAST_OK,
-       M_READ, M_READ_OK, M_ADD, M_ADD_OK, M_REPLICATE };
+       M_READ, M_READ_OK, M_ADD, M_ADD_OK, M_REPLICATE,
+       M_WRITE, M_WRITE_OK, M_CAS, M_CAS_OK, M_ERROR,                                   /* lin-kv RPCs, doc/workloads.md */
+       M_REQUEST_VOTE, M_REQUEST_VOTE_RES, M_APPEND_ENTRIES, M_APPEND_ENTRIES_RES };    /* raft.py:290-297,412-420 */
 
 /* RNG streams */
-enum { S_GEN = 1, S_LATENCY = 4, S_LOSS = 5,
+enum { S_GEN = 1, S_GEN2 = 2, S_LATENCY = 4, S_LOSS = 5, S_NODE = 11,
        S_NEM_STAGGER = 7, S_NEM_SPEC = 8, S_NEM_SHUFFLE = 9, S_NEM_PICK = 10 };
 
 enum { PH_INIT, PH_INIT_WAIT, PH_TOPO, PH_TOPO_WAIT, PH_MAIN_START, PH_MAIN, PH_DRAIN, PH_NEM_FINAL,
@@ -66,11 +68,12 @@ enum { PH_INIT, PH_INIT_WAIT, PH_TOPO, PH_TOPO_WAIT, PH_MAIN_START, PH_MAIN, PH_
 
 enum { K_NONE = 0, K_INIT, K_TOPO, K_OP };
 
-typedef struct { u32 deadline, id, a, b; u8 src, type; } qent;
+struct rext;
+typedef struct { u32 deadline, id, a, b; u8 src, type; struct rext *r; } qent;
 typedef struct { qent *v; u32 n, cap; } inbox_t;
 typedef struct { u32 value, next_retry; } task_t;
 typedef struct { task_t *v; u32 n, cap, head; } tasks_t;
-typedef struct { u8 src_ep, dest_ep, type; u32 a, b; } outmsg;
+typedef struct { u8 src_ep, dest_ep, type; u32 a, b; struct rext *r; } outmsg;
 
 typedef struct {
   msim_config cfg;
@@ -91,6 +94,8 @@ typedef struct {
   u32 *unacked;         /* ack/retry: [node][value][MW] un-acked neighbour sets */
   u32 *timer_next;      /* g-set replicate timer */
   u32 *tick;            /* g-set: replicate ticks so far, per node */
+  struct rnode_s *raft; /* raft: per-node state (raft_nodes.inc) */
+  u32 cur_key, key_procs; u8 *key_reg; /* lin-kv generator: current key, distinct processes seen on it */
   u32 **snap; u32 n_snap, cap_snap; /* replicate_full payload snapshots */
   /* clients */
   struct cl { u8 busy, kind, mark; u32 want, timeout_at, next_msg_id, f, value, process, m_f, m_value, m_final; } *cl;
@@ -155,15 +160,19 @@ static void inbox_push(sim_t *s, u32 ep, qent q) {
   inbox_t *b = &s->inbox[ep];
   if (b->n == b->cap) { b->cap = b->cap ? b->cap * 2 : 8; b->v = (qent *)realloc(b->v, b->cap * sizeof(qent)); }
   b->v[b->n++] = q;
-  u32 lim = is_client(s, ep) ? 2u : s->cfg.inbox_capacity + s->cfg.spill_capacity; /* engine capacities: overflow is flagged, never silent */
+  u32 lim = is_client(s, ep) ? (s->cfg.workload == MSIM_WL_LIN_KV ? 16u : 2u) /* Reusable lin-kv clients collect late replies */
+                             : s->cfg.inbox_capacity + s->cfg.spill_capacity; /* engine capacities: overflow is flagged, never silent */
   if (b->n > lim) s->meta.flags |= MSIM_FLAG_INBOX_OVERFLOW;
 }
 
-static void out_send(sim_t *s, u32 src, u32 dest, u32 type, u32 a, u32 b) {
+/* `sender` emits a message whose :src is `src` (a node may forward a client's message unchanged, raft.py:543-546) */
+static void out_send_x(sim_t *s, u32 sender, u32 src, u32 dest, u32 type, u32 a, u32 b, struct rext *r) {
+  (void)sender;
   if (s->n_out == s->cap_out) { s->cap_out = s->cap_out ? s->cap_out * 2 : 64; s->out = (outmsg *)realloc(s->out, s->cap_out * sizeof(outmsg)); }
-  outmsg m = {(u8)src, (u8)dest, (u8)type, a, b};
+  outmsg m = {(u8)src, (u8)dest, (u8)type, a, b, r};
   s->out[s->n_out++] = m;
 }
+static void out_send(sim_t *s, u32 src, u32 dest, u32 type, u32 a, u32 b) { out_send_x(s, src, src, dest, type, a, b, NULL); }
 
 static void add_row(sim_t *s, u32 type, u32 f, u32 err, u32 final, u32 process, u32 value, u32 len) {
   if (s->meta.n_rows >= s->cfg.max_rows) { s->meta.flags |= MSIM_FLAG_ROWS_OVERFLOW; return; }
@@ -336,7 +345,10 @@ static void node_timer(sim_t *s, u32 node) {
   if (any) task_push(s, node, k.value, s->T + 1000000u);
 }
 
+#include "raft_nodes.inc"
+
 static void node_handle(sim_t *s, u32 node, const qent *q) {
+  if (s->cfg.node_program == MSIM_NODE_RAFT) { raft_handle(s, node, q); return; }
   switch (q->type) {
     case M_INIT: /* node.rb init handler -> init_ok; g-set starts its periodic task (node.rb:129-138) */
       if (s->cfg.node_program == MSIM_NODE_G_SET) s->timer_next[node] = s->T;
@@ -354,7 +366,7 @@ static void node_handle(sim_t *s, u32 node, const qent *q) {
 
 /* ---- clients (client.clj) ------------------------------------------------------------------------- */
 static int idempotent(const sim_t *s, u32 f) { /* with-errors sets: broadcast.clj:200 #{:read}; echo.clj:33 #{} */
-  return s->cfg.workload == MSIM_WL_BROADCAST && f == MSIM_F_READ;
+  return (s->cfg.workload == MSIM_WL_BROADCAST || s->cfg.workload == MSIM_WL_LIN_KV) && f == MSIM_F_READ; /* lin_kv.clj:52 */
 }
 
 static void client_complete(sim_t *s, u32 slot, u32 type, u32 err, u32 value, u32 len) {
@@ -367,8 +379,10 @@ static void client_complete(sim_t *s, u32 slot, u32 type, u32 err, u32 value, u3
   } else add_row(s, type, c->f, err, c->m_final, c->process, value, len);
   if (type == MSIM_T_INFO) { /* crashed process: new process id, fresh client [upstream interpreter] */
     c->process += s->C;
-    c->next_msg_id = 0;
-    s->inbox[s->N + slot].n = 0;
+    if (s->cfg.workload != MSIM_WL_LIN_KV) { /* lin-kv clients are Reusable (lin_kv.clj:74-76): not re-opened */
+      c->next_msg_id = 0;
+      s->inbox[s->N + slot].n = 0;
+    }
   }
 }
 
@@ -376,8 +390,14 @@ static void client_deliver(sim_t *s, u32 slot, const qent *q) {
   struct cl *c = &s->cl[slot];
   if (!c->busy || q->b != c->want) return; /* stale reply, client.clj:105-107 */
   switch (q->type) {
-    case M_READ_OK: client_complete(s, slot, MSIM_T_OK, 0, q->a & 0xFFFFFFu, q->a >> 24); break;
+    case M_READ_OK:
+      if (s->cfg.workload == MSIM_WL_LIN_KV) client_complete(s, slot, MSIM_T_OK, 0, (c->value & 0xFFu) | ((q->a & 0xFFu) << 8) | 0xFF0000u, 0); /* [k v], lin_kv.clj:56-61 */
+      else client_complete(s, slot, MSIM_T_OK, 0, q->a & 0xFFFFFFu, q->a >> 24);
+      break;
     case M_ECHO_OK: client_complete(s, slot, MSIM_T_OK, 0, q->a, 0); break;
+    case M_ERROR: { /* client.clj:125-138 throw-errors!; every code the raft node emits is :definite? => :fail (errors.edn) */
+      u32 err = q->a == 11 ? MSIM_ERR_TEMPORARILY_UNAVAILABLE : q->a == 20 ? MSIM_ERR_KEY_DOES_NOT_EXIST : MSIM_ERR_PRECONDITION_FAILED;
+      client_complete(s, slot, MSIM_T_FAIL, err, c->value, 0); } break;
     default: client_complete(s, slot, MSIM_T_OK, 0, c->value, 0); break;
   }
 }
@@ -385,7 +405,8 @@ static void client_deliver(sim_t *s, u32 slot, const qent *q) {
 static void client_timeout(sim_t *s, u32 slot) { /* client.clj:96-103 + :158-162 */
   struct cl *c = &s->cl[slot];
   u32 type = idempotent(s, c->f) ? MSIM_T_FAIL : MSIM_T_INFO;
-  client_complete(s, slot, type, MSIM_ERR_NET_TIMEOUT, c->f == MSIM_F_READ ? MSIM_NO_VALUE : c->value, 0);
+  u32 v = c->f == MSIM_F_READ && s->cfg.workload != MSIM_WL_LIN_KV ? MSIM_NO_VALUE : c->value;
+  client_complete(s, slot, type, MSIM_ERR_NET_TIMEOUT, v, 0);
 }
 
 static void client_invoke(sim_t *s, u32 slot) {
@@ -402,11 +423,15 @@ static void client_invoke(sim_t *s, u32 slot) {
       case MSIM_F_ECHO: type = M_ECHO; a = c->value; break;
       case MSIM_F_BROADCAST: type = M_BROADCAST; a = c->value; break;
       case MSIM_F_ADD: type = M_ADD; a = c->value; break;
-      default: type = M_READ; break;
+      case MSIM_F_WRITE: type = M_WRITE; a = c->value; break;
+      case MSIM_F_CAS: type = M_CAS; a = c->value; break;
+      default: type = M_READ; a = s->cfg.workload == MSIM_WL_LIN_KV ? c->value : 0; break;
     }
   }
   c->want = ++c->next_msg_id; /* client.clj:61-64 */
-  c->timeout_at = s->T + (c->kind == K_OP ? s->cfg.client_timeout_ms : 10000u) * 1000u; /* db.clj:54 */
+  u32 to_ms = s->cfg.client_timeout_ms;
+  if (s->cfg.workload == MSIM_WL_LIN_KV) { to_ms = 10 * s->cfg.latency_mean_ms; if (to_ms < 1000) to_ms = 1000; } /* lin_kv.clj:54 */
+  c->timeout_at = s->T + (c->kind == K_OP ? to_ms : 10000u) * 1000u; /* db.clj:54 */
   out_send(s, ep, dest, type, a, c->want);
 }
 
@@ -498,7 +523,21 @@ static void sched_act(sim_t *s) {
           for (u32 i = 0; i < s->C; i++) if (!s->cl[i].busy) { if (pick == 0) { slot = i; break; } pick--; }
           struct cl *c = &s->cl[slot];
           c->mark = 1; c->kind = K_OP; c->m_final = 0;
-          if (s->cfg.workload == MSIM_WL_ECHO) { c->m_f = MSIM_F_ECHO; c->m_value = (r_lo >> 4) & 127; } /* echo.clj:72-75 */
+          if (s->cfg.workload == MSIM_WL_LIN_KV) {
+            /* [upstream] jepsen.tests.linearizable-register: one key at a time per group of 2n threads; the
+             * first n threads read, the others mix [w cas cas]; values 0..4; (gen/process-limit 20) retires a key
+             * once 20 distinct processes have used it */
+            if (!s->key_reg[slot] || s->key_reg[slot] != 1 + (c->process & 0x7F)) {
+              if (s->key_procs == 20) { s->cur_key++; s->key_procs = 0; memset(s->key_reg, 0, s->CS); }
+              s->key_reg[slot] = (u8)(1 + (c->process & 0x7F)); s->key_procs++;
+            }
+            u64 h2 = draw64(s, S_GEN2, k);
+            u32 v1 = scale32((u32)(h2 >> 32), 5), v2 = (((u32)(h2 >> 20) & 0xFFFu) * 5u) >> 12, key = s->cur_key & 0xFF;
+            if (slot < s->N) { c->m_f = MSIM_F_READ; c->m_value = key | 0xFFFF00u; }
+            else if (scale32((u32)h2, 3) == 0) { c->m_f = MSIM_F_WRITE; c->m_value = key | (v1 << 8) | 0xFF0000u; }
+            else { c->m_f = MSIM_F_CAS; c->m_value = key | (v1 << 8) | (v2 << 16); }
+          }
+          else if (s->cfg.workload == MSIM_WL_ECHO) { c->m_f = MSIM_F_ECHO; c->m_value = (r_lo >> 4) & 127; } /* echo.clj:72-75 */
           else if (r_lo & 1) { c->m_f = MSIM_F_READ; c->m_value = MSIM_NO_VALUE; }  /* gen/mix */
           else {
             c->m_f = s->cfg.workload == MSIM_WL_BROADCAST ? MSIM_F_BROADCAST : MSIM_F_ADD;
@@ -522,6 +561,8 @@ static void sched_act(sim_t *s) {
 
 /* ---- one instance --------------------------------------------------------------------------------- */
 
+static void rext_free(struct rext *r) { if (r) { free(r->ents); free(r); } }
+
 /* commit the round's staged sends in canonical order (net.clj:189-221) */
 static void commit_sends(sim_t *s) {
   u32 N = s->N, T = s->T;
@@ -532,8 +573,8 @@ static void commit_sends(sim_t *s) {
     s->st.all_send++; if (cl) s->st.clients_send++; else s->st.servers_send++; /* journal :send before loss */
     jlog(s, 0, id, m->type, m->a, m->b, m->src_ep, m->dest_ep);
     u32 lat = latency_ms(s, id, cl);
-    if (s->loss_on && s->cfg.p_loss_q32 && draw32(s, S_LOSS, id) < s->cfg.p_loss_q32) continue; /* net.clj:214 */
-    qent q = {T + lat * 1000u, id, m->a, m->b, m->src_ep, m->type};
+    if (s->loss_on && s->cfg.p_loss_q32 && draw32(s, S_LOSS, id) < s->cfg.p_loss_q32) { rext_free(m->r); continue; } /* net.clj:214 */
+    qent q = {T + lat * 1000u, id, m->a, m->b, m->src_ep, m->type, m->r};
     inbox_push(s, m->dest_ep, q);
   }
   s->n_out = 0;
@@ -550,7 +591,7 @@ static void poll_endpoint(sim_t *s, u32 e) {
     for (u32 i = 1; i < b->n; i++)
       if (b->v[i].deadline < b->v[k].deadline || (b->v[i].deadline == b->v[k].deadline && b->v[i].id < b->v[k].id)) k = i;
     qent q = b->v[k]; b->v[k] = b->v[--b->n];
-    if (e < N && q.src < N && bit(s->part[e], q.src)) continue; /* partitioned: dropped, no :recv */
+    if (e < N && q.src < N && bit(s->part[e], q.src)) { rext_free(q.r); continue; } /* partitioned: dropped, no :recv */
     s->committed[e] = q; s->has_committed[e] = 1;
     s->deliver_at[e] = q.deadline <= T ? T : T + ((q.deadline - T) / 1000u) * 1000u;
   }
@@ -567,7 +608,7 @@ static void run_instance(sim_t *s) {
      * timeouts only fire in a round where nothing else is due. */
     u32 tn = sched_due(s), tt = INF;
     for (u32 e = 0; e < E; e++) if (s->has_committed[e] && s->deliver_at[e] < tn) tn = s->deliver_at[e];
-    for (u32 n = 0; n < N; n++) { u32 t = node_timer_time(s, n); if (t < tn) tn = t; }
+    for (u32 n = 0; n < N; n++) { u32 t = s->raft ? raft_next_time(s, n) : node_timer_time(s, n); if (t < tn) tn = t; }
     for (u32 c = 0; c < s->CS; c++) if (s->cl[c].busy && s->cl[c].timeout_at < tt) tt = s->cl[c].timeout_at;
     if (tn == INF && tt == INF) { s->meta.flags |= MSIM_FLAG_ROUND_LIMIT; break; } /* stuck */
     int timeout_round = tt < tn;
@@ -589,12 +630,16 @@ static void run_instance(sim_t *s) {
     for (u32 e = 0; e < E; e++) poll_endpoint(s, e);
     /* R3: one input per node (node order): a due timer, else the due committed message */
     for (u32 n = 0; n < N; n++) {
-      if (node_timer_time(s, n) <= T) node_timer(s, n);
-      else if (s->has_committed[n] && s->deliver_at[n] <= T) {
+      int msg_due = s->has_committed[n] && s->deliver_at[n] <= T;
+      if (s->raft ? !msg_due : node_timer_time(s, n) <= T) {  /* raft.py's loop takes a message first (raft.py:577-585) */
+        if (!s->raft) node_timer(s, n);
+        else if (raft_next_time(s, n) <= T) raft_act(s, n);
+      } else if (msg_due) {
         qent q = s->committed[n]; s->has_committed[n] = 0;
         s->st.all_recv++; if (q.src >= N) s->st.clients_recv++; else s->st.servers_recv++; /* journal :recv */
         jlog(s, 1, q.id, q.type, q.a, q.b, q.src, n);
         node_handle(s, n, &q);
+        rext_free(q.r);
       }
     }
     commit_sends(s);
@@ -652,6 +697,12 @@ static sim_t *sim_new(const msim_config *cfg, uint64_t instance, msim_op *rows, 
   for (u32 i = 0; i < s->N; i++) s->timer_next[i] = INF;
   s->cl = (struct cl *)calloc(s->CS, sizeof(struct cl));
   s->pend = calloc(s->CS, sizeof(*s->pend));
+  s->key_reg = (u8 *)calloc(s->CS, 1);
+  if (cfg->node_program == MSIM_NODE_RAFT) {
+    s->raft = (rnode *)calloc(s->N, sizeof(rnode));
+    for (u32 i = 0; i < s->N; i++) { rnode *r = &s->raft[i]; r->voted_for = -1; r->leader = -1; r->last_applied = 1; memset(r->kv, 0xFF, sizeof r->kv);
+      rentry e0; memset(&e0, 0, sizeof e0); r_append(r, &e0, 1); }
+  }
   for (u32 i = 0; i < s->CS; i++) s->cl[i].process = i;
   s->rows = rows; s->payload = payload;
   s->phase = PH_INIT;
@@ -659,11 +710,18 @@ static sim_t *sim_new(const msim_config *cfg, uint64_t instance, msim_op *rows, 
 }
 
 static void sim_free(sim_t *s) {
-  for (u32 e = 0; e < s->E; e++) free(s->inbox[e].v);
+  for (u32 e = 0; e < s->E; e++) {
+    for (u32 i = 0; i < s->inbox[e].n; i++) rext_free(s->inbox[e].v[i].r);
+    if (s->has_committed[e]) rext_free(s->committed[e].r);
+    free(s->inbox[e].v);
+  }
+  for (u32 i = 0; i < s->n_out; i++) rext_free(s->out[i].r);
   for (u32 n = 0; n < s->N; n++) free(s->tasks[n].v);
   for (u32 i = 0; i < s->n_snap; i++) free(s->snap[i]);
+  if (s->raft) { for (u32 i = 0; i < s->N; i++) free(s->raft[i].log); free(s->raft); }
   free(s->snap); free(s->inbox); free(s->committed); free(s->has_committed); free(s->deliver_at); free(s->seen);
-  free(s->unacked); free(s->node_msg_id); free(s->nbr_known); free(s->tasks); free(s->timer_next); free(s->tick); free(s->cl); free(s->pend); free(s->out);
+  free(s->unacked); free(s->node_msg_id); free(s->nbr_known); free(s->tasks); free(s->key_reg); free(s->timer_next); free(s->tick);
+  free(s->cl); free(s->pend); free(s->out);
   free(s);
 }
 
@@ -717,9 +775,57 @@ int oracle_node_trace(const msim_config *cfg, uint32_t node, const uint32_t *in,
 
 uint32_t oracle_msg_type(const char *name) {
   static const char *names[] = {"", "init", "init_ok", "topology", "topology_ok", "echo", "echo_ok", "broadcast", "broadcast_ok",
-                                "read", "read_ok", "add", "add_ok", "replicate"};
+                                "read", "read_ok", "add", "add_ok", "replicate", "write", "write_ok", "cas", "cas_ok", "error",
+                                "request_vote", "request_vote_res", "append_entries", "append_entries_res"};
   for (u32 i = 1; i < sizeof(names) / sizeof(names[0]); i++) if (!strcmp(names[i], name)) return i;
   return 0;
+}
+
+/* Test hook for the Raft node program: like oracle_node_trace, with the extra message payload.
+ * in : n_in x 12 words {src, type, a, b, x0..x4, n_ents, first_ent, 0}; type 0 = let `a` microseconds pass and
+ *      run the main loop until it idles.  ents_in: entries {term, msg_id, type, key, v1, v2, client} (7 words each).
+ * out: records of 12 words {input index, src, dest, type, a, b, x0..x4, n_ents}; entries of emitted
+ *      append_entries are appended to ents_out (7 words each, in order).  Returns #records or -1. */
+int oracle_raft_trace(const msim_config *cfg, uint32_t node, const uint32_t *in, uint32_t n_in, const uint32_t *ents_in,
+                      uint32_t *out, uint32_t out_cap, uint32_t *ents_out, uint32_t ents_cap, uint32_t *state_out) {
+  msim_op *rows = (msim_op *)calloc(cfg->max_rows, sizeof(msim_op));
+  u32 *payload = (u32 *)calloc(cfg->max_payload_words + 1, 4);
+  sim_t *s = sim_new(cfg, 0, rows, payload);
+  if (!s || !s->raft || node >= s->N) { free(rows); free(payload); return -1; }
+  u32 n = 0, ne = 0;
+  for (u32 i = 0; i < n_in; i++) {
+    const u32 *m = in + 12 * i;
+    s->n_out = 0;
+    u32 steps = 1;
+    if (m[1] == 0) { s->T += m[2]; steps = 64; }
+    else {
+      qent q = {s->T, i, m[2], m[3], (u8)m[0], (u8)m[1], NULL};
+      rext *x = rext_new(m[4], m[5], m[6], m[7], m[8]);
+      if (m[9]) { x->n_ents = m[9]; x->ents = (rentry *)calloc(m[9], sizeof(rentry));
+        for (u32 k = 0; k < m[9]; k++) { const u32 *e = ents_in + 7 * (m[10] + k); rentry *t = &x->ents[k];
+          t->term = e[0]; t->msg_id = e[1]; t->type = (u8)e[2]; t->key = (u8)e[3]; t->v1 = (u8)e[4]; t->v2 = (u8)e[5]; t->client = (u8)e[6]; } }
+      q.r = x;
+      raft_handle(s, node, &q);
+      rext_free(x);
+      steps = 64;  /* then let the main loop run (commit / apply) */
+    }
+    while (steps-- && raft_next_time(s, node) <= s->T) raft_act(s, node);
+    for (u32 k = 0; k < s->n_out && n < out_cap; k++, n++) {
+      u32 *o = out + 12 * n; outmsg *om = &s->out[k];
+      o[0] = i; o[1] = om->src_ep; o[2] = om->dest_ep; o[3] = om->type; o[4] = om->a; o[5] = om->b;
+      for (u32 j = 0; j < 5; j++) o[6 + j] = om->r ? om->r->x[j] : 0;
+      o[11] = om->r ? om->r->n_ents : 0;
+      for (u32 j = 0; om->r && j < om->r->n_ents && ne < ents_cap; j++, ne++) { u32 *e = ents_out + 7 * ne; rentry *t = &om->r->ents[j];
+        e[0] = t->term; e[1] = t->msg_id; e[2] = t->type; e[3] = t->key; e[4] = t->v1; e[5] = t->v2; e[6] = t->client; }
+      rext_free(om->r); om->r = NULL;
+    }
+    s->n_out = 0;
+  }
+  rnode *r = &s->raft[node];
+  state_out[0] = r->role; state_out[1] = r->term; state_out[2] = r->commit_index; state_out[3] = r->last_applied; state_out[4] = r->log_n;
+  state_out[5] = (u32)r->voted_for; state_out[6] = (u32)r->leader;
+  sim_free(s); free(rows); free(payload);
+  return (int)n;
 }
 
 /* Runs instances [first, first+n) into instance-major output slabs (same layout as the engine). */

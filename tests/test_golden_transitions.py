@@ -23,14 +23,14 @@ GOLD = json.load(open(os.path.join(HERE, "golden", "node_transitions.json")))["c
 _SLOTS = {}
 
 
-def _ep(name, n_nodes):
+def _ep(name, n_nodes, max_slots=None):
     """endpoint name -> oracle endpoint index (nodes first, then one client slot per distinct client name)."""
     if name[0] == "n":
         return int(name[1:])
     slots = _SLOTS.setdefault(n_nodes, {})
     if name not in slots:
         slots[name] = len(slots)
-        assert slots[name] < n_nodes, "more client names than client slots in this fixture"
+        assert slots[name] < (max_slots or n_nodes), "more client names than client slots in this fixture"
     return n_nodes + slots[name]
 
 
@@ -168,3 +168,124 @@ def test_crdt_gset_js(lib):
         # (node.rb's `every` also fires once at start-up, node.rb:129-138, where crdt_gset.js's setInterval
         #  does not; the trace hook only runs timers inside the wait step, so the 5 s tick is what is compared)
         assert sorted(got, key=repr) == ref, (si, got, st["out"])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Raft: golden vectors recorded from the reference's runnable demo/python/raft.py
+# ------------------------------------------------------------------------------------------------------------------
+RAFT = json.load(open(os.path.join(HERE, "golden", "raft_transitions.json")))
+
+
+def _raft_trace(cfg, node, inputs, ents):
+    lib = O.load()
+    lib.oracle_raft_trace.argtypes = [C.POINTER(A.Config), C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
+                                      C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.oracle_raft_trace.restype = C.c_int
+    inp = np.array(inputs, dtype=np.uint32).reshape(-1, 12)
+    ein = np.array(ents if ents else [[0] * 7], dtype=np.uint32).reshape(-1, 7)
+    out = np.zeros((4096, 12), dtype=np.uint32)
+    eout = np.zeros((8192, 7), dtype=np.uint32)
+    st = np.zeros(8, dtype=np.uint32)
+    n = lib.oracle_raft_trace(C.byref(cfg), node, inp.ctypes.data, len(inp), ein.ctypes.data, out.ctypes.data, 4096,
+                              eout.ctypes.data, 8192, st.ctypes.data)
+    assert n >= 0
+    return out[:n], eout, st
+
+
+def test_raft_py_handlers_and_leader_path(lib):
+    """init, error 11 without a leader, vote rules, append_entries (append / commit / gap / stale term), proxying with
+    the client's src, candidacy after the election timeout, leadership on a majority, replication of new entries,
+    commit on a majority ack, apply -> write_ok / cas_ok / error 22 / error 20 — against real raft.py output."""
+    ids = RAFT["node_ids"]
+    n = len(ids)
+    cfg = E.test_config("lin-kv", bin="raft", node_count=n, rate=5, time_limit=5, seed=3)
+    _SLOTS.pop(n, None)
+
+    def ep(name):
+        return _ep(name, n, 2 * n)
+
+    def enc_entry(e):
+        op = e["op"]
+        v1 = op.get("value", op.get("from", 0xFF))
+        return [e["term"], op["msg_id"], _t(op["type"]), op["key"], v1, op.get("to", 0xFF), ep(op["client"])]
+
+    inputs, ents, step_of_input, sent_ae = [], [], [], {}
+    for st in RAFT["steps"]:  # remember what raft.py sent, to decode the acks' closures
+        for o in st["out"]:
+            if o["body"]["type"] == "append_entries":
+                sent_ae[o["body"]["msg_id"]] = o["body"]
+    for si, st in enumerate(RAFT["steps"]):
+        if "in" not in st:
+            inputs.append([0, 0, 4050000, 0] + [0] * 8); step_of_input.append(si); continue
+        m = st["in"]; b = m["body"]; t = b["type"]
+        row = [ep(m["src"]), _t(t), 0, b.get("msg_id", b.get("in_reply_to", 0))] + [0] * 8
+        if t in ("read", "write", "cas"):
+            row[2] = b["key"] | (b.get("value", b.get("from", 0xFF)) << 8) | (b.get("to", 0xFF) << 16)
+        elif t == "request_vote":
+            row[4:7] = [b["term"], b["last_log_index"], b["last_log_term"]]
+        elif t == "request_vote_res":
+            row[4:7] = [b["term"], int(b["vote_granted"]), b["term"]]
+        elif t == "append_entries":
+            row[4:8] = [b["term"], b["prev_log_index"], b["prev_log_term"], b["leader_commit"]]
+            row[9], row[10] = len(b["entries"]), len(ents)
+            ents += [enc_entry(e) for e in b["entries"]]
+        elif t == "append_entries_res":
+            rq = sent_ae[b["in_reply_to"]]
+            row[4:9] = [b["term"], int(b["success"]), rq["prev_log_index"] + 1, len(rq["entries"]), rq["term"]]
+        inputs.append(row); step_of_input.append(si)
+        inputs.append([0, 0, 200000, 0] + [0] * 8); step_of_input.append(si)  # the recording's drain window: timers run
+
+    out, eout, state = _raft_trace(cfg, 1, inputs, ents)
+    names = {v: k for k, v in _SLOTS[n].items()}
+    tn = {_t(k): k for k in ("init_ok", "error", "request_vote_res", "append_entries_res", "read", "request_vote", "append_entries",
+                             "write_ok", "cas_ok", "read_ok")}
+
+    def ename(x):
+        return f"n{x}" if x < n else names[x - n]
+
+    got_steps = [[] for _ in RAFT["steps"]]
+    got_ae, eo = set(), 0
+    for o in out:
+        si = step_of_input[int(o[0])]
+        typ = tn[int(o[3])]
+        src, dest = ename(int(o[1])), ename(int(o[2]))
+        if typ == "append_entries":
+            k = int(o[11]); es = tuple(tuple(int(x) for x in eout[eo + j]) for j in range(k)); eo += k
+            got_ae.add((dest, int(o[6]), int(o[7]), int(o[8]), es))
+        elif typ == "request_vote":
+            got_steps[si].append((src, dest, typ, int(o[6]), int(o[7]), int(o[8])))
+        elif typ == "request_vote_res":
+            got_steps[si].append((src, dest, typ, int(o[6]), bool(o[7])))
+        elif typ == "append_entries_res":
+            got_steps[si].append((src, dest, typ, int(o[6]), bool(o[7])))
+        elif typ == "error":
+            got_steps[si].append((src, dest, typ, int(o[4]), int(o[5])))
+        elif typ == "read":
+            got_steps[si].append((src, dest, typ, int(o[4]) & 0xFF, int(o[5])))
+        else:
+            got_steps[si].append((src, dest, typ, int(o[5])))
+
+    want_ae = set()
+    for si, st in enumerate(RAFT["steps"]):
+        want = []
+        for o in st["out"]:
+            b, src, dest = o["body"], o["src"], o["dest"]
+            t = b["type"]
+            if t == "append_entries":
+                want_ae.add((dest, b["term"], b["prev_log_index"], b["prev_log_term"], tuple(tuple(enc_entry(e)) for e in b["entries"])))
+            elif t == "request_vote":
+                want.append((src, dest, t, b["term"], b["last_log_index"], b["last_log_term"]))
+            elif t == "request_vote_res":
+                want.append((src, dest, t, b["term"], b["vote_granted"]))
+            elif t == "append_entries_res":
+                want.append((src, dest, t, b["term"], b["success"]))
+            elif t == "error":
+                want.append((src, dest, t, b["code"], b["in_reply_to"]))
+            elif t == "read":
+                want.append((src, dest, t, b["key"], b["msg_id"]))   # proxied: the client's src and msg_id survive (raft.py:543-546)
+            else:
+                want.append((src, dest, t, b["in_reply_to"]))
+        assert sorted(set(got_steps[si]), key=repr) == sorted(set(want), key=repr), (si, st.get("in"), got_steps[si], want)
+    # every distinct append_entries raft.py sent (dest, term, prev index/term, entries) and nothing else
+    assert got_ae == want_ae, (sorted(got_ae - want_ae, key=repr), sorted(want_ae - got_ae, key=repr))
+    assert int(state[0]) == 3 and int(state[1]) == 4  # leader of term 4, like the recorded node
