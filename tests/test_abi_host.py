@@ -46,7 +46,13 @@ def test_finalize_derives_capacities_and_rejects_bad_options(lib):
     with pytest.raises(E.EngineError, match="n_nodes"):
         E.test_config("broadcast", node_count=0)
     with pytest.raises(E.EngineError, match="not built"):
-        E.test_config("lin-kv", node_count=5)
+        E.test_config("txn-list-append", node_count=5)
+    with pytest.raises(E.EngineError, match="multiple of 2 x node-count"):
+        E.test_config("lin-kv", bin="raft", node_count=5, concurrency=5)
+    cfg = E.test_config("lin-kv", bin="raft", node_count=5)  # options are valid (the oracle runs them) ...
+    assert cfg.concurrency == 10
+    with pytest.raises(E.EngineError, match="HIP node program is not built yet"):  # ... but the engine says so loudly
+        E.Engine(cfg)
     with pytest.raises(KeyError):
         E.test_config("broadcast", topology="hypercube")
 
