@@ -53,7 +53,7 @@ enum {
                                    ack everyone, resend un-acked every 1 s                                    */
   MSIM_NODE_BCAST_RPC_ALL = 4,  /* demo/ruby/broadcast.rb:29-47: RPC to every other node, no retry           */
   MSIM_NODE_G_SET = 5,          /* demo/ruby/g_set.rb:8-39: replicate_full to all others every 5 s          */
-  MSIM_NODE_RAFT = 6            /* demo/ruby/raft.rb (not built yet)                                          */
+  MSIM_NODE_RAFT = 6            /* demo/ruby/raft.rb:1-497 == demo/python/raft.py:1-593 (lin-kv)             */
 };
 
 enum { MSIM_LAT_CONSTANT = 0, MSIM_LAT_UNIFORM = 1, MSIM_LAT_EXPONENTIAL = 2 };  /* net.clj:65-77 */
@@ -168,7 +168,8 @@ typedef struct msim_inst_meta {
   uint32_t reserved[3];
 } msim_inst_meta;
 enum { MSIM_FLAG_ROWS_OVERFLOW = 1u, MSIM_FLAG_PAYLOAD_OVERFLOW = 2u, MSIM_FLAG_INBOX_OVERFLOW = 4u,
-       MSIM_FLAG_VALUES_OVERFLOW = 8u, MSIM_FLAG_ROUND_LIMIT = 16u, MSIM_FLAG_JOURNAL_OVERFLOW = 32u };
+       MSIM_FLAG_VALUES_OVERFLOW = 8u, MSIM_FLAG_ROUND_LIMIT = 16u, MSIM_FLAG_JOURNAL_OVERFLOW = 32u,
+       MSIM_FLAG_ARENA_OVERRUN = 64u /* raft: a message descriptor was recycled while still in flight */ };
 
 /* Result of the workload checker for one instance.  For broadcast / g-set this is jepsen's
  * `checker/set-full` result map (shape: doc/03-broadcast/01-broadcast.md:564-577, KAT-7); for echo the

@@ -25,7 +25,7 @@ ERR_NONE, ERR_NET_TIMEOUT, ERR_RPC, ERR_TEMPORARILY_UNAVAILABLE, ERR_KEY_DOES_NO
 SPEC_ONE, SPEC_MAJORITY, SPEC_MAJORITIES_RING, SPEC_MINORITY_THIRD = range(4)
 PROCESS_NEMESIS = 0xFFFFF
 NO_VALUE = 0xFFFFFFFF
-FLAG_ROWS_OVERFLOW, FLAG_PAYLOAD_OVERFLOW, FLAG_INBOX_OVERFLOW, FLAG_VALUES_OVERFLOW, FLAG_ROUND_LIMIT, FLAG_JOURNAL_OVERFLOW = 1, 2, 4, 8, 16, 32
+FLAG_ROWS_OVERFLOW, FLAG_PAYLOAD_OVERFLOW, FLAG_INBOX_OVERFLOW, FLAG_VALUES_OVERFLOW, FLAG_ROUND_LIMIT, FLAG_JOURNAL_OVERFLOW, FLAG_ARENA_OVERRUN = 1, 2, 4, 8, 16, 32, 64
 MSG_TYPES = ["", "init", "init_ok", "topology", "topology_ok", "echo", "echo_ok", "broadcast", "broadcast_ok", "read", "read_ok",
              "add", "add_ok", "replicate", "write", "write_ok", "cas", "cas_ok", "error", "request_vote", "request_vote_res",
              "append_entries", "append_entries_res"]

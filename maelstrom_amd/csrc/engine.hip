@@ -56,6 +56,7 @@ struct KParams {
   u64 spill_off;  // word offset of the spill area inside the per-instance scratch
   u32 off_inbox, off_seen, off_misc;  // LDS byte offsets
   u32 gen_period2_us, nem_period2_us;
+  u32 raft_log_cap;   // raft: entries per node log
 };
 
 __constant__ u32 d_log2_q24[257];
@@ -778,6 +779,7 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
 }
 
 #include "sim_kernel_colo.inc"
+#include "sim_kernel_raft.inc"
 
 // =====================================================================================================
 // Host runtime
@@ -819,10 +821,6 @@ extern "C" int msim_create(const msim_config *cfg, int device, msim_ctx **out, c
   int rc = msim_config_finalize(&c, err, errlen);
   if (rc != MSIM_OK) return rc;
   const uint32_t slots = c.concurrency > c.n_nodes ? c.concurrency : c.n_nodes;
-  if (c.node_program == MSIM_NODE_RAFT) {
-    set_err(err, errlen, "raft / lin-kv: restated and pinned in the CPU oracle only so far; the HIP node program is not built yet");
-    return MSIM_E_UNSUPPORTED;
-  }
   if (c.n_nodes > 32 || c.n_nodes + slots > 64) {
     set_err(err, errlen, "this build maps one cluster to one wavefront: n_nodes <= 32 and n_nodes + max(concurrency, n_nodes) <= 64");
     return MSIM_E_UNSUPPORTED;
@@ -847,8 +845,13 @@ extern "C" int msim_create(const msim_config *cfg, int device, msim_ctx **out, c
 }
 
 // per-instance scratch = [protocol scratch][spill area: n_nodes x spill_capacity envelopes]
+static uint32_t raft_log_cap(const msim_config &c) {  // every client op is appended at most once, by the leader that takes it
+  const double expected = (double)c.rate_mhz * (double)c.time_limit_ms / 1e6;
+  return (uint32_t)(expected + expected / 8.0) + 64 + 8;
+}
 static uint64_t proto_scratch_words(const msim_config &c) {
   uint64_t w = 4;
+  if (c.node_program == MSIM_NODE_RAFT) w = (uint64_t)c.n_nodes * raft_log_cap(c) * 2 + (uint64_t)c.n_nodes * R_ARENA_WORDS;
   if (c.node_program == MSIM_NODE_BCAST_ACK_RETRY) w = (uint64_t)c.n_nodes * c.max_values * 3;
   if (c.node_program == MSIM_NODE_G_SET) {
     const uint64_t total_ms = (uint64_t)c.time_limit_ms + c.quiesce_ms + 2ull * c.client_timeout_ms;
@@ -918,9 +921,14 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   if (2 * period_us > 0xFFFFFFFFull || 2000ull * c.nemesis_interval_ms > 0xFFFFFFFFull) { ctx->err = "rate too low / nemesis interval too long for u32 microseconds"; return MSIM_E_INVALID; }
   kp.gen_period2_us = (u32)(2 * period_us);
   kp.nem_period2_us = (u32)(2000ull * c.nemesis_interval_ms);
+  const bool is_raft = c.node_program == MSIM_NODE_RAFT;
+  kp.raft_log_cap = is_raft ? raft_log_cap(c) : 0;
   size_t off = STAGE_ROWS * 16;
-  kp.off_inbox = (u32)off; off += ((size_t)kp.N * kp.cap_node + (size_t)kp.CS * CLIENT_INBOX_CAP) * 16;
-  kp.off_seen = (u32)off; off += (size_t)kp.N * kp.W * 4; off = (off + 15) & ~(size_t)15;
+  kp.off_inbox = (u32)off; off += ((size_t)kp.N * kp.cap_node + (size_t)kp.CS * (is_raft ? R_CLIENT_CAP : CLIENT_INBOX_CAP)) * 16;
+  kp.off_seen = (u32)off;
+  off += is_raft ? (size_t)kp.N * 256 + (size_t)kp.N * kp.N * 3 * 4   // KV state + next/match index + append_entries refs
+                 : (size_t)kp.N * kp.W * 4;
+  off = (off + 15) & ~(size_t)15;
   kp.off_misc = (u32)off; if (c.nemesis_mask) off += 64 * 4;  // shuffle scratch, only the partition nemesis needs it
   const size_t lds = off;
   if (lds > 160 * 1024) { ctx->err = "cluster state exceeds the 160 KiB LDS of a CU (lower inbox_capacity / max_values)"; return MSIM_E_INVALID; }
@@ -934,6 +942,12 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
     case MSIM_NODE_BCAST_ACK_RETRY: e = launch<MSIM_NODE_BCAST_ACK_RETRY>(kp, n, lds, st); break;
     case MSIM_NODE_BCAST_RPC_ALL: e = launch<MSIM_NODE_BCAST_RPC_ALL>(kp, n, lds, st); break;
     case MSIM_NODE_G_SET: e = launch<MSIM_NODE_G_SET>(kp, n, lds, st); break;
+    case MSIM_NODE_RAFT: {
+      const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
+      if (c.nemesis_mask) { if (rnd) hipLaunchKernelGGL((raft_kernel<true, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((raft_kernel<true, false>), dim3(n), dim3(64), lds, st, kp); }
+      else { if (rnd) hipLaunchKernelGGL((raft_kernel<false, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((raft_kernel<false, false>), dim3(n), dim3(64), lds, st, kp); }
+      e = hipGetLastError();
+    } break;
     default: ctx->err = "node program not built into this engine"; return MSIM_E_UNSUPPORTED;
   }
   if (e != hipSuccess) { ctx->err = std::string("kernel launch: ") + hipGetErrorString(e); return MSIM_E_HIP; }

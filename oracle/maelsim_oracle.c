@@ -95,7 +95,7 @@ typedef struct {
   u32 *timer_next;      /* g-set replicate timer */
   u32 *tick;            /* g-set: replicate ticks so far, per node */
   struct rnode_s *raft; /* raft: per-node state (raft_nodes.inc) */
-  u32 cur_key, key_procs; u8 *key_reg; /* lin-kv generator: current key, distinct processes seen on it */
+  u32 cur_key, key_procs; u32 *key_reg; /* lin-kv generator: current key; per thread the process id it registered on that key (+1) */
   u32 **snap; u32 n_snap, cap_snap; /* replicate_full payload snapshots */
   /* clients */
   struct cl { u8 busy, kind, mark; u32 want, timeout_at, next_msg_id, f, value, process, m_f, m_value, m_final; } *cl;
@@ -527,9 +527,9 @@ static void sched_act(sim_t *s) {
             /* [upstream] jepsen.tests.linearizable-register: one key at a time per group of 2n threads; the
              * first n threads read, the others mix [w cas cas]; values 0..4; (gen/process-limit 20) retires a key
              * once 20 distinct processes have used it */
-            if (!s->key_reg[slot] || s->key_reg[slot] != 1 + (c->process & 0x7F)) {
-              if (s->key_procs == 20) { s->cur_key++; s->key_procs = 0; memset(s->key_reg, 0, s->CS); }
-              s->key_reg[slot] = (u8)(1 + (c->process & 0x7F)); s->key_procs++;
+            if (s->key_reg[slot] != 1 + c->process) {
+              if (s->key_procs == 20) { s->cur_key++; s->key_procs = 0; memset(s->key_reg, 0, s->CS * 4); }
+              s->key_reg[slot] = 1 + c->process; s->key_procs++;
             }
             u64 h2 = draw64(s, S_GEN2, k);
             u32 v1 = scale32((u32)(h2 >> 32), 5), v2 = (((u32)(h2 >> 20) & 0xFFFu) * 5u) >> 12, key = s->cur_key & 0xFF;
@@ -697,7 +697,7 @@ static sim_t *sim_new(const msim_config *cfg, uint64_t instance, msim_op *rows, 
   for (u32 i = 0; i < s->N; i++) s->timer_next[i] = INF;
   s->cl = (struct cl *)calloc(s->CS, sizeof(struct cl));
   s->pend = calloc(s->CS, sizeof(*s->pend));
-  s->key_reg = (u8 *)calloc(s->CS, 1);
+  s->key_reg = (u32 *)calloc(s->CS, 4);
   if (cfg->node_program == MSIM_NODE_RAFT) {
     s->raft = (rnode *)calloc(s->N, sizeof(rnode));
     for (u32 i = 0; i < s->N; i++) { rnode *r = &s->raft[i]; r->voted_for = -1; r->leader = -1; r->last_applied = 1; memset(r->kv, 0xFF, sizeof r->kv);

@@ -49,10 +49,9 @@ def test_finalize_derives_capacities_and_rejects_bad_options(lib):
         E.test_config("txn-list-append", node_count=5)
     with pytest.raises(E.EngineError, match="multiple of 2 x node-count"):
         E.test_config("lin-kv", bin="raft", node_count=5, concurrency=5)
-    cfg = E.test_config("lin-kv", bin="raft", node_count=5)  # options are valid (the oracle runs them) ...
+    cfg = E.test_config("lin-kv", bin="raft", node_count=5)
     assert cfg.concurrency == 10
-    with pytest.raises(E.EngineError, match="HIP node program is not built yet"):  # ... but the engine says so loudly
-        E.Engine(cfg)
+    assert cfg.spill_capacity >= 256
     with pytest.raises(KeyError):
         E.test_config("broadcast", topology="hypercube")
 

@@ -123,3 +123,19 @@ def test_net_journal_parity(lib, bin, conc, kw):
     assert (ora.meta["n_events"] > 100).all()
     cfg = E.test_config("g-set", node_count=5, rate=10, time_limit=10, seed=32, journal_capacity=20000)
     _compare(cfg, 0, 4)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(),
+    dict(latency=10),
+    dict(latency=20, latency_dist="exponential", p_loss=0.02),
+    dict(nemesis=["partition"], nemesis_interval=5, latency=5),
+    dict(node_count=3, concurrency=6, nemesis=["partition"], nemesis_interval=4, time_limit=30, latency=10, latency_dist="uniform"),
+    dict(journal_capacity=200000, latency=5),
+])
+def test_raft_lin_kv_parity(lib, kw):
+    """Raft lin-kv (raft.rb / raft.py restated): elections, replication, commit/apply, proxying, timeouts, key rotation —
+    history, stats, round count (and journal) bit-identical to the oracle."""
+    kw = dict(dict(node_count=5, rate=30, time_limit=20, seed=17), **kw)
+    cfg = E.test_config("lin-kv", bin="raft", **kw)
+    _compare(cfg, 0, 6)
