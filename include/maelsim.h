@@ -224,6 +224,11 @@ int msim_run_async(msim_ctx *ctx, uint64_t first_instance, uint32_t n_instances,
  * reading the HBM-resident histories.  Blocking.  Results via msim_check_results. */
 int msim_check(msim_ctx *ctx);
 
+/* Host-only utility behind msim_check for lin-kv: per-key linearizability (CAS-register model) of ONE history given
+ * as rows — what `independent/checker` + Knossos do for workload/lin_kv.clj:84.  out->valid: 1 linearizable, 0 not,
+ * 2 unknown; attempt_count = keys, error_count = non-linearizable keys.  Needs no device. */
+int msim_check_lin_kv_rows(const msim_op *rows, uint32_t n_rows, msim_check_result *out);
+
 /* Copies the last run's outputs to host memory (pinned, owned by ctx, valid until next run/destroy). */
 int msim_fetch(msim_ctx *ctx);
 

@@ -120,9 +120,11 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
     double lat_s = c->latency_mean_ms / 1000.0;
     if (c->latency_dist == MSIM_LAT_UNIFORM) lat_s *= 2.0;         // max of uniform [0, 2 mean)
     if (c->latency_dist == MSIM_LAT_EXPONENTIAL) lat_s *= 16.0;    // P(latency > 16 mean) ~ 1e-7 per message
-    uint32_t depth = 16 + 2 * deg + (uint32_t)(per_s * lat_s * 3.0);  // x3: bursts
+    uint32_t depth = 32 + 2 * deg + (uint32_t)(per_s * lat_s * 6.0);  // x6: fan-in bursts (every neighbour forwards at once)
+    // retrying gossip under partitions: at heal time every neighbour re-sends everything it could not deliver
+    if (c->node_program == MSIM_NODE_BCAST_ACK_RETRY && c->nemesis_mask) depth += (deg < 4 ? deg : 4) * adds;
     if (c->node_program == MSIM_NODE_G_SET) depth = 16 + 2 * deg;  // one replicate_full per peer per 5 s tick (g_set.rb:33-38)
-    if (c->node_program == MSIM_NODE_RAFT) depth = 24 + 256;        // heartbeats / re-sent append_entries pile up behind a sleeping recv!
+    if (c->node_program == MSIM_NODE_RAFT) depth = 24 + 1024;       // heartbeats / re-sent append_entries pile up behind a sleeping recv!
     if (c->inbox_capacity == 0) c->inbox_capacity = depth < 24 ? depth : 24;
     if (c->spill_capacity == 0) c->spill_capacity = depth > c->inbox_capacity ? depth - c->inbox_capacity : 0;
     if (c->spill_capacity > 65536) { set_err(err, errlen, "spill_capacity above 65536 envelopes per node"); return MSIM_E_INVALID; }

@@ -974,6 +974,7 @@ extern "C" int msim_run_async(msim_ctx *ctx, uint64_t first_instance, uint32_t n
 extern "C" int msim_check(msim_ctx *ctx) {
   if (!ctx) return MSIM_E_INVALID;
   if (!ctx->ran) { ctx->err = "msim_check before msim_run"; return MSIM_E_RANGE; }
+  if (ctx->cfg.workload == MSIM_WL_LIN_KV) return msim_check_lin_kv_host(ctx);
   return msim_check_launch(ctx);
 }
 

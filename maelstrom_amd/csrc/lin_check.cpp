@@ -1,0 +1,177 @@
+// lin_check.cpp — per-key linearizability of lin-kv histories (host side of msim_check for MSIM_WL_LIN_KV).
+//
+// In the reference the lin-kv workload's checker is [upstream] jepsen.tests.linearizable-register:
+// `independent/checker` over Knossos' `checker/linearizable` with a CAS-register model
+// (workload/lin_kv.clj:84).  Restated here as just-in-time linearization (Lowe; Knossos' "linear" analysis):
+// walk one key's history; keep the set of configurations (register value, set of pending ops already
+// linearized); when an op returns, every surviving configuration must have linearized it.  :fail ops never
+// happened; :info ops stay pending forever (they may take effect at any later time, or never).
+// Histories are small per key (process-limit 20 retires a key), so this runs on the host cores, one
+// thread per slice of instances.  A device version is future work.
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <thread>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "engine_internal.h"
+
+namespace {
+
+struct Op { uint32_t f, v1, v2; bool ok; bool skip; };  // effective op of a call
+
+struct Cfg { uint64_t lin; uint32_t val; };
+struct CfgHash { size_t operator()(const Cfg &c) const { return std::hash<uint64_t>()(c.lin * 0x9E3779B97F4A7C15ull ^ c.val); } };
+struct CfgEq { bool operator()(const Cfg &a, const Cfg &b) const { return a.lin == b.lin && a.val == b.val; } };
+
+// apply op to register value `val` (0..4, 0xFF = nil); returns legal?
+inline bool step(uint32_t val, const Op &op, uint32_t *out) {
+  *out = val;
+  if (op.f == MSIM_F_READ) return val == op.v1;             // only :ok reads are stepped; they must see the current value
+  if (op.f == MSIM_F_WRITE) { *out = op.v1; return true; }
+  if (val != op.v1) return false;                           // cas [v v']
+  *out = op.v2; return true;
+}
+
+// one key: rows (indices into the instance history) in order.  Returns 1 linearizable, 0 not, 2 unknown (too wide).
+int check_key(const msim_op *rows, const std::vector<uint32_t> &idx) {
+  // pair invocations with completions by process
+  std::unordered_map<uint32_t, uint32_t> open;         // process -> position in idx of its invoke
+  std::vector<int> comp(idx.size(), -1);               // invoke position -> completion position
+  for (uint32_t k = 0; k < idx.size(); k++) {
+    const msim_op &r = rows[idx[k]];
+    const uint32_t proc = MSIM_OP_PROCESS(r);
+    if (MSIM_OP_TYPE(r) == MSIM_T_INVOKE) open[proc] = k;
+    else { auto it = open.find(proc); if (it != open.end()) { comp[it->second] = (int)k; open.erase(it); } }
+  }
+  struct Ev { bool call; uint32_t id; };
+  std::vector<Ev> events;
+  std::vector<Op> eff(idx.size());
+  std::vector<int> inv_of(idx.size(), -1);
+  for (uint32_t k = 0; k < idx.size(); k++) {
+    const msim_op &r = rows[idx[k]];
+    if (MSIM_OP_TYPE(r) == MSIM_T_INVOKE) {
+      const int c = comp[k];
+      if (c >= 0 && MSIM_OP_TYPE(rows[idx[c]]) == MSIM_T_FAIL) continue;      // never happened
+      const bool ok = c >= 0 && MSIM_OP_TYPE(rows[idx[c]]) == MSIM_T_OK;
+      const msim_op &src = ok ? rows[idx[c]] : r;                              // an :ok read carries the value it saw
+      Op o; o.f = MSIM_OP_F(r); o.v1 = (src.value >> 8) & 0xFF; o.v2 = (src.value >> 16) & 0xFF; o.ok = ok;
+      o.skip = !ok && o.f == MSIM_F_READ;                                      // an unfinished read constrains nothing
+      eff[k] = o;
+      events.push_back({true, k});
+      if (c >= 0) inv_of[c] = (int)k;
+    } else if (MSIM_OP_TYPE(r) == MSIM_T_OK && inv_of[k] >= 0) events.push_back({false, (uint32_t)inv_of[k]});
+  }
+  // pending ops get slots 0..63 in a bitmask
+  std::unordered_map<uint32_t, uint32_t> slot_of;
+  std::vector<uint32_t> op_in_slot(64, 0);
+  uint64_t pending = 0, info_bits = 0;   // info_bits: pending ops that will never return (:info, or no completion)
+  // Dominance: for equal (register value, linearized returning ops), a configuration that has linearized FEWER
+  // never-returning ops can still do everything the other can (it may apply them later, or never).  Only the
+  // minimal ones are kept — without this, k indeterminate writes cost 2^k configurations.
+  struct Group { std::vector<uint64_t> mins; };
+  auto gkey = [&](const Cfg &c) { return Cfg{c.lin & ~info_bits, c.val}; };
+  std::unordered_map<Cfg, Group, CfgHash, CfgEq> seen;
+  auto admit = [&](const Cfg &c) -> bool {   // true if c is not dominated; removes what c dominates
+    Group &g = seen[gkey(c)];
+    const uint64_t ib = c.lin & info_bits;
+    for (uint64_t m : g.mins) if ((m & ib) == m) return false;           // an existing subset dominates c
+    g.mins.erase(std::remove_if(g.mins.begin(), g.mins.end(), [&](uint64_t m) { return (m & ib) == ib; }), g.mins.end());
+    g.mins.push_back(ib);
+    return true;
+  };
+  std::vector<Cfg> configs{{0, 0xFF}}, stack, out;
+  for (const Ev &ev : events) {
+    if (ev.call) {
+      if (pending == ~0ull) return 2;
+      const uint32_t s = (uint32_t)__builtin_ctzll(~pending);
+      pending |= 1ull << s; slot_of[ev.id] = s; op_in_slot[s] = ev.id;
+      if (!eff[ev.id].ok) info_bits |= 1ull << s;
+      continue;
+    }
+    const uint32_t s = slot_of[ev.id];
+    const uint64_t bit = 1ull << s;
+    seen.clear(); out.clear(); stack.clear();
+    for (const Cfg &c : configs) if (admit(c)) stack.push_back(c);
+    size_t explored = 0;
+    while (!stack.empty()) {
+      const Cfg c = stack.back(); stack.pop_back();
+      { // c may have been superseded by a smaller configuration found later
+        const Group &g = seen[gkey(c)]; const uint64_t ib = c.lin & info_bits;
+        if (std::find(g.mins.begin(), g.mins.end(), ib) == g.mins.end()) continue;
+      }
+      if (++explored > 2000000) return 2;
+      if (c.lin & bit) { out.push_back({c.lin & ~bit, c.val}); continue; }
+      uint64_t cand = pending & ~c.lin;
+      while (cand) {
+        const uint32_t j = (uint32_t)__builtin_ctzll(cand); cand &= cand - 1;
+        const Op &o = eff[op_in_slot[j]];
+        if (o.skip) continue;
+        uint32_t nv;
+        if (!step(c.val, o, &nv)) continue;
+        const Cfg c2{c.lin | (1ull << j), nv};
+        if (admit(c2)) stack.push_back(c2);
+      }
+    }
+    pending &= ~bit; slot_of.erase(ev.id);
+    // re-minimise the survivors (bit s is gone from their keys)
+    seen.clear(); configs.clear();
+    for (const Cfg &c : out) (void)admit(c);
+    for (auto &kv : seen) for (uint64_t m : kv.second.mins) configs.push_back({kv.first.lin | m, kv.first.val});
+    if (configs.empty()) return 0;
+  }
+  return 1;
+}
+
+void check_instance(const msim_op *rows, uint32_t n_rows, uint32_t flags, msim_check_result *res) {
+  std::memset(res, 0, sizeof *res);
+  std::unordered_map<uint32_t, std::vector<uint32_t>> by_key;
+  for (uint32_t i = 0; i < n_rows; i++) {
+    const msim_op &r = rows[i];
+    if (MSIM_OP_PROCESS(r) == MSIM_PROCESS_NEMESIS) continue;
+    const uint32_t t = MSIM_OP_TYPE(r);
+    if (t == MSIM_T_INVOKE) res->op_count++; else if (t == MSIM_T_OK) res->ok_count++; else if (t == MSIM_T_FAIL) res->fail_count++; else res->info_count++;
+    const uint32_t f = MSIM_OP_F(r);
+    if (f == MSIM_F_READ || f == MSIM_F_WRITE || f == MSIM_F_CAS) by_key[r.value & 0xFF].push_back(i);
+  }
+  uint32_t bad = 0, unknown = 0;
+  for (auto &kv : by_key) { const int v = check_key(rows, kv.second); bad += v == 0; unknown += v == 2; }
+  res->attempt_count = (uint32_t)by_key.size();    // keys checked (independent/checker)
+  res->error_count = bad;                          // keys whose history is not linearizable
+  res->valid = flags ? 0u : bad ? 0u : unknown ? 2u : 1u;
+}
+
+}  // namespace
+
+// Host-only entry point: checks one lin-kv history given as rows (no device involved).
+extern "C" int msim_check_lin_kv_rows(const msim_op *rows, uint32_t n_rows, msim_check_result *out) {
+  if (!rows || !out) return MSIM_E_INVALID;
+  check_instance(rows, n_rows, 0, out);
+  return MSIM_OK;
+}
+
+// Runs the lin-kv checker over the fetched histories of the last run; results to ctx->h_check and ctx->d_check.
+int msim_check_lin_kv_host(msim_ctx *ctx) {
+  const auto t0 = std::chrono::steady_clock::now();
+  int rc = msim_fetch(ctx);
+  if (rc != MSIM_OK) return rc;
+  const uint32_t n = ctx->n_inst;
+  if (ctx->h_check) { (void)hipHostFree(ctx->h_check); ctx->h_check = nullptr; }
+  MSIM_HIP_TRY(ctx, hipHostMalloc(&ctx->h_check, (size_t)n * sizeof(msim_check_result)));
+  unsigned nt = std::thread::hardware_concurrency();
+  if (nt == 0) nt = 1;
+  if (nt > n) nt = n;
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; t++)
+    th.emplace_back([ctx, n, nt, t]() {
+      for (uint32_t i = t; i < n; i += nt)
+        check_instance(ctx->h_rows + ctx->h_row_off[i], ctx->h_meta[i].n_rows, ctx->h_meta[i].flags, &ctx->h_check[i]);
+    });
+  for (auto &x : th) x.join();
+  MSIM_HIP_TRY(ctx, hipMemcpy(ctx->d_check, ctx->h_check, (size_t)n * sizeof(msim_check_result), hipMemcpyHostToDevice));
+  ctx->checked = true; ctx->check_fetched = true;
+  ctx->check_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return MSIM_OK;
+}

@@ -160,7 +160,7 @@ static void inbox_push(sim_t *s, u32 ep, qent q) {
   inbox_t *b = &s->inbox[ep];
   if (b->n == b->cap) { b->cap = b->cap ? b->cap * 2 : 8; b->v = (qent *)realloc(b->v, b->cap * sizeof(qent)); }
   b->v[b->n++] = q;
-  u32 lim = is_client(s, ep) ? (s->cfg.workload == MSIM_WL_LIN_KV ? 16u : 2u) /* Reusable lin-kv clients collect late replies */
+  u32 lim = is_client(s, ep) ? (s->cfg.workload == MSIM_WL_LIN_KV ? 32u : 2u) /* Reusable lin-kv clients collect late replies */
                              : s->cfg.inbox_capacity + s->cfg.spill_capacity; /* engine capacities: overflow is flagged, never silent */
   if (b->n > lim) s->meta.flags |= MSIM_FLAG_INBOX_OVERFLOW;
 }

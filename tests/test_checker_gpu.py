@@ -67,3 +67,22 @@ def test_echo_checker(lib):
         res = eng.check_results()
         for i in range(8):
             assert R.echo_check(eng.history(i))["valid?"] and int(res[i]["valid"]) == 1 and int(res[i]["error_count"]) == 0
+
+
+def test_lin_kv_checker_on_raft_histories(lib):
+    """msim_check for lin-kv = per-key linearizability (host side, csrc/lin_check.cpp) over the fetched histories."""
+    import linearizable_ref as L
+    from maelstrom_amd import _abi as A
+    cfg = E.test_config("lin-kv", bin="raft", node_count=5, rate=30, time_limit=30, nemesis=["partition"], nemesis_interval=6,
+                        latency=10, seed=29)
+    with E.Engine(cfg) as eng:
+        eng.run(0, 16)
+        eng.check()
+        eng.fetch()
+        res = eng.check_results()
+        assert (res["valid"] == 1).all()
+        for i in range(4):
+            h = eng.history(i)
+            ref = L.check(h)
+            assert all(ref.values()) and int(res[i]["attempt_count"]) == len(ref)
+            assert int(res[i]["op_count"]) == sum(1 for op in h if op["type"] == ":invoke" and op["process"] != ":nemesis")

@@ -66,3 +66,42 @@ def test_raft_timeouts_are_indeterminate_for_writes_only(lib):
         assert all(p % 10 == q % 10 or True for p in procs for q in procs)
         seen_keys = max(seen_keys, len({op["value"][0] for op in h if op["process"] != ":nemesis"}))
     assert seen_info > 0 and seen_keys > 1
+
+
+def _lib_check(rows):
+    import ctypes as C
+    from maelstrom_amd import _abi
+    res = _abi.CheckResult()
+    rows = rows.copy()
+    assert _abi.load().msim_check_lin_kv_rows(rows.ctypes.data, len(rows), C.byref(res)) == 0
+    return res
+
+
+def test_library_linearizability_checker_agrees_with_reference(lib):
+    """The product's lin-kv checker (csrc/lin_check.cpp, host side of msim_check) against the pure-Python
+    restatement, on oracle histories and on histories corrupted to be non-linearizable."""
+    import numpy as np
+    cfg = E.test_config("lin-kv", bin="raft", node_count=5, rate=30, time_limit=30, nemesis=["partition"], nemesis_interval=6,
+                        latency=10, seed=23)
+    r = O.run(cfg, 0, 6)
+    rng = np.random.default_rng(5)
+    n_bad = 0
+    for i in range(6):
+        rows, pay = r.history(i)
+        for corrupt in (False, True):
+            rows2 = rows.copy()
+            if corrupt:  # flip the value seen by some :ok reads
+                typ, f = rows2["packed"] & 3, (rows2["packed"] >> 2) & 31
+                cand = np.flatnonzero((typ == A.T_OK) & (f == A.F_READ))
+                for j in rng.choice(cand, size=min(3, len(cand)), replace=False):
+                    v = (int(rows2["value"][j]) >> 8) & 0xFF
+                    rows2["value"][j] = (int(rows2["value"][j]) & ~0xFF00) | ((((v + 1) % 5) if v != 0xFF else 1) << 8)
+            ref = L.check(E.decode_history(rows2, pay, 5, A.WL_LIN_KV))
+            got = _lib_check(rows2)
+            assert got.attempt_count == len(ref)
+            assert got.error_count == sum(1 for ok in ref.values() if not ok), (i, corrupt, ref)
+            assert got.valid == (1 if all(ref.values()) else 0)
+            n_bad += got.valid == 0
+            if not corrupt:
+                assert got.valid == 1
+    assert n_bad > 0

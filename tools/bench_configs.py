@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Runs the non-headline BASELINE.json configs that the engine supports and prints one line each
+(msgs/s, checked histories/s, kernel ms).  Parity for these is covered by tests/; this is measurement only."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from maelstrom_amd import engine as E  # noqa: E402
+
+CONFIGS = {
+    "cfg1 echo n=3": (dict(workload="echo", node_count=3, rate=5, time_limit=10), 4096),
+    "cfg2 broadcast n=25 grid lat0": (dict(workload="broadcast", node_count=25, rate=100, time_limit=20, inbox_capacity=6), 4096),
+    "cfg2 broadcast n=25 grid lat10": (dict(workload="broadcast", node_count=25, rate=100, time_limit=20, latency=10), 4096),
+    "cfg2 broadcast n=25 grid lat100": (dict(workload="broadcast", node_count=25, rate=100, time_limit=20, latency=100), 4096),
+    "cfg2 broadcast n=25 grid lat100 exponential": (dict(workload="broadcast", node_count=25, rate=100, time_limit=20, latency=100, latency_dist="exponential"), 4096),
+    "cfg2 broadcast n=25 total lat100": (dict(workload="broadcast", node_count=25, rate=100, time_limit=20, latency=100, topology="total"), 1024),
+    "broadcast n=25 ack-retry + partitions": (dict(workload="broadcast", bin="broadcast-ack-retry", node_count=25, rate=100, time_limit=20, latency=10,
+                                                   nemesis=["partition"], nemesis_interval=10), 2048),
+    "g-set n=25 lat100 exponential p_loss 0.05": (dict(workload="g-set", node_count=25, rate=100, time_limit=20, latency=100, latency_dist="exponential", p_loss=0.05), 4096),
+    "cfg4 lin-kv raft n=5 c=10 rate30 60s": (dict(workload="lin-kv", bin="raft", node_count=5, rate=30, time_limit=60), 8192),
+    "cfg4 lin-kv raft + partitions lat10": (dict(workload="lin-kv", bin="raft", node_count=5, rate=30, time_limit=60, latency=10, nemesis=["partition"], nemesis_interval=10), 8192),
+}
+
+
+def main():
+    only = sys.argv[1:] or list(CONFIGS)
+    for name in only:
+        kw, n = CONFIGS[name]
+        cfg = E.test_config(seed=99, **kw)
+        with E.Engine(cfg) as eng:
+            eng.run(0, n)                      # warm-up (allocation, code load)
+            t0 = time.perf_counter()
+            eng.run(n, n)
+            eng.check()
+            dt = time.perf_counter() - t0
+            sim_ms, chk_ms = eng.kernel_ms()
+            eng.fetch()
+            msgs = sum(int(eng.net_stats_raw(i).all_send) for i in range(n))
+            flagged = sum(1 for i in range(n) if eng.meta(i).flags)
+            flag_or = 0
+            for i in range(n):
+                flag_or |= eng.meta(i).flags
+            res = eng.check_results()
+            valid = int((res["valid"] == 1).sum())
+        print(json.dumps({"config": name, "instances": n, "msgs_per_s": msgs / dt, "histories_per_s": valid / dt, "valid": valid, "flagged": flagged, "flags_seen": flag_or,
+                          "msgs_per_instance": msgs / n, "sim_ms": sim_ms, "check_ms": chk_ms}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
