@@ -712,18 +712,26 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
     if (FAST_OK && !timeout_round) {
       const u64 bm = __ballot(busy);
       bool quiet = false;
+      u32 d2 = INF;  // when the scheduler next wants to act (the clients' busy set cannot change inside this loop)
       if (phase == PH_MAIN) {
         const bool gl = rate > 0 && gen_next < cutoff, nl = NEM && nem_next < cutoff;
         if (gl || nl) {
-          u32 d2 = INF;
           if (nl) d2 = max(nem_next, T);
           if (gl && (worker_mask & ~bm)) d2 = min(d2, max(gen_next, T));
           quiet = d2 > T;
         }
-      } else if (phase == PH_SLEEP) quiet = sleep_until > T;
+      } else if (phase == PH_SLEEP) { d2 = sleep_until; quiet = d2 > T; }
       while (quiet) {
-        const bool due_now = has_c && deliver_at <= T;  // only node lanes hold an envelope across rounds
-        if (!__ballot(due_now)) break;
+        bool due_now = has_c && deliver_at <= T;  // only node lanes hold an envelope across rounds
+        if (!__ballot(due_now)) {
+          // R0 inside the loop: jump to the next delivery if it precedes the scheduler and every client timeout
+          u32 k = has_c ? deliver_at * 2 : INF;
+          if (busy) k = min(k, timeout_at * 2 + 1);
+          const u32 km = wave_min(k);
+          if (km == INF || (km & 1) || (km >> 1) >= d2) break;
+          T = km >> 1;
+          due_now = has_c && deliver_at <= T;
+        }
         const bool plain = (cm.y & 0xFFu) == M_BROADCAST && (cm.w & 0xFFFFFFu) == 0;
         if (__ballot(due_now && !plain)) break;
         if (++rounds > ROUND_LIMIT) { flags |= MSIM_FLAG_ROUND_LIMIT; phase = PH_DONE; break; }
@@ -884,14 +892,19 @@ template <int PROG, bool NEM, bool NET_RANDOM>
 static hipError_t launch3(const KParams &kp, uint32_t n, size_t lds, hipStream_t st) {
   // colocated layout when every worker is pinned to "its" node (concurrency == n_nodes, the default 1n)
   const bool colo = kp.C == kp.N;
-  const void *fn = colo ? reinterpret_cast<const void *>(&sim_kernel_colo<PROG, NEM, NET_RANDOM>)
-                        : reinterpret_cast<const void *>(&sim_kernel<PROG, NEM, NET_RANDOM>);
+  // FIFO queues (constant latency only) when deep queues are expected: the scan-based poll is cheaper for shallow ones
+  constexpr bool CAN_FIFO = !NET_RANDOM && PROG != MSIM_NODE_BCAST_ACK_RETRY && PROG != MSIM_NODE_BCAST_RPC_ALL;
+  const bool fifo = CAN_FIFO && colo && kp.spill_cap >= 64;
+  const void *fn = !colo ? reinterpret_cast<const void *>(&sim_kernel<PROG, NEM, NET_RANDOM>)
+                 : fifo ? reinterpret_cast<const void *>(&sim_kernel_colo<PROG, NEM, NET_RANDOM, CAN_FIFO>)
+                        : reinterpret_cast<const void *>(&sim_kernel_colo<PROG, NEM, NET_RANDOM, false>);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  if (colo) hipLaunchKernelGGL((sim_kernel_colo<PROG, NEM, NET_RANDOM>), dim3(n), dim3(64), lds, st, kp);
-  else hipLaunchKernelGGL((sim_kernel<PROG, NEM, NET_RANDOM>), dim3(n), dim3(64), lds, st, kp);
+  if (!colo) hipLaunchKernelGGL((sim_kernel<PROG, NEM, NET_RANDOM>), dim3(n), dim3(64), lds, st, kp);
+  else if (fifo) hipLaunchKernelGGL((sim_kernel_colo<PROG, NEM, NET_RANDOM, CAN_FIFO>), dim3(n), dim3(64), lds, st, kp);
+  else hipLaunchKernelGGL((sim_kernel_colo<PROG, NEM, NET_RANDOM, false>), dim3(n), dim3(64), lds, st, kp);
   return hipGetLastError();
 }
 template <int PROG>
