@@ -20,7 +20,8 @@
 
 #include "engine_internal.h"
 
-#define NONE 0xFFFFFFFFu
+#define NONE 0xFFFFu      /* per-element row index: none */
+#define NOLAT 0xFFFFFFFFu  /* per-element latency: not stable */
 
 struct CParams {
   const msim_op *rows;
@@ -38,9 +39,12 @@ __device__ __forceinline__ u32 c_wave_sum(u32 v) {
 
 __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char csmem[];
-  u32 *const known = reinterpret_cast<u32 *>(csmem);
-  u32 *const lp_idx = known + p.max_values;
-  u32 *const la_idx = lp_idx + p.max_values;
+  // per-element row indices as u16 (max_rows < 65535): 6 B per element keeps every history of a 4096-batch resident
+  typedef unsigned short u16;
+  u16 *const known = reinterpret_cast<u16 *>(csmem);
+  u16 *const lp_idx = known + p.max_values;
+  u16 *const la_idx = lp_idx + p.max_values;
+  u32 *const lat = reinterpret_cast<u32 *>(csmem);  // reused after the walk: stable latency per element (needs 4 B each)
 
   const u32 lane = threadIdx.x, inst = blockIdx.x;
   const msim_inst_meta meta = p.meta[inst];
@@ -51,7 +55,8 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
 
   for (u32 i = lane; i < p.max_values; i += 64) { known[i] = NONE; lp_idx[i] = NONE; la_idx[i] = NONE; }
 
-  u32 my_inv = NONE, my_val = 0;  // lane t = worker thread t: its pending invoke (reads / echo)
+  // worker thread t lives in lane t % 64, slot t / 64 (up to 128 workers): its pending invoke (reads / echo)
+  u32 my_inv = NONE, my_inv1 = NONE, my_val = 0, my_val1 = 0;
   u32 v_cur = 0, op_count = 0, n_ok = 0, n_fail = 0, n_info = 0, errors = 0;
 
   for (u32 base = 0; base < n_rows; base += 64) {
@@ -67,7 +72,7 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
     n_fail += (u32)__popcll(__ballot(live && my_type == MSIM_T_FAIL));
     n_info += (u32)__popcll(__ballot(live && my_type == MSIM_T_INFO));
     // add :ok -> known (first of add-ok / first containing read, by :index): order-free as a minimum
-    if (live && add_like && my_type == MSIM_T_OK && r.w < p.max_values) atomicMin(&known[r.w], base + lane);
+    if (live && add_like && my_type == MSIM_T_OK && r.w < p.max_values && known[r.w] > base + lane) known[r.w] = (u16)(base + lane);  // one add per element: no race
     const u64 add_inv = __ballot(live && add_like && my_type == MSIM_T_INVOKE);  // elements come into existence
     u64 walk = __ballot(live && (my_f == MSIM_F_READ || my_f == MSIM_F_ECHO));
     const u32 v_base = v_cur;
@@ -75,59 +80,69 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
     while (walk) {
       const u32 j = (u32)__builtin_ctzll(walk); walk &= walk - 1;
       const u32 packed = c_rdlane(r.z, j), value = c_rdlane(r.w, j), hi = c_rdlane(r.y, j);
-      const u32 type = packed & 3, f = (packed >> 2) & 31, t = (packed >> 12) % C;
+      const u32 type = packed & 3, f = (packed >> 2) & 31, tt = (packed >> 12) % C, t = tt & 63;
+      const bool hi_slot = tt >= 64;
       const u32 idx = base + j;
       if (f == MSIM_F_READ) {
-        if (type == MSIM_T_INVOKE) { if (lane == t) my_inv = idx; }
-        else if (type == MSIM_T_FAIL) { if (lane == t) my_inv = NONE; }
+        if (type == MSIM_T_INVOKE) { if (lane == t) { if (hi_slot) my_inv1 = idx; else my_inv = idx; } }
+        else if (type == MSIM_T_FAIL) { if (lane == t) { if (hi_slot) my_inv1 = NONE; else my_inv = NONE; } }
         else if (type == MSIM_T_OK) {
-          const u32 inv = c_rdlane(my_inv, t), len = hi >> 16, off = value;
+          const u32 inv = hi_slot ? c_rdlane(my_inv1, t) : c_rdlane(my_inv, t), len = hi >> 16, off = value;
           const u32 v_here = v_base + (u32)__popcll(add_inv & ((1ull << j) - 1));  // elements existing at this row
           for (u32 e = lane; e < v_here; e += 64) {
             const u32 w = (e >> 5) < len ? pay[off + (e >> 5)] : 0u;
             if ((w >> (e & 31)) & 1) {
-              if (known[e] > idx) known[e] = idx;
+              if (known[e] > idx) known[e] = (u16)idx;
               const u32 lp = lp_idx[e];
-              if (lp == NONE || lp < inv) lp_idx[e] = inv;
+              if (lp == NONE || lp < inv) lp_idx[e] = (u16)inv;
             } else {
               const u32 la = la_idx[e];
-              if (la == NONE || la < inv) la_idx[e] = inv;
+              if (la == NONE || la < inv) la_idx[e] = (u16)inv;
             }
           }
         }
       } else {  // echo
-        if (type == MSIM_T_INVOKE) { if (lane == t) my_val = value; }
-        else if (type == MSIM_T_OK) { if (c_rdlane(my_val, t) != value) errors++; }  // echo.clj:52-60
+        if (type == MSIM_T_INVOKE) { if (lane == t) { if (hi_slot) my_val1 = value; else my_val = value; } }
+        else if (type == MSIM_T_OK) { if ((hi_slot ? c_rdlane(my_val1, t) : c_rdlane(my_val, t)) != value) errors++; }  // echo.clj:52-60
       }
     }
   }
   __syncthreads();
 
-  // ---- per-element outcomes ----
+  // ---- per-element outcomes (each lane owns elements e = lane, lane+64, ...; at most 32 per lane) ----
   u32 c_stable = 0, c_lost = 0, c_never = 0, c_stale = 0;
-  for (u32 e = lane; e < v_cur; e += 64) {
-    const u32 k = known[e], lp = lp_idx[e], la = la_idx[e];
-    const bool stable = lp != NONE && (la == NONE || la < lp);
-    const bool lost = k != NONE && la != NONE && (lp == NONE || lp < la) && k < la;
-    u32 lat = NONE;
-    if (stable) {
-      lat = 0;
-      if (la != NONE) {
-        const uint4 ra = rows[la], rk = rows[k];
-        const u64 ta = (((u64)(ra.y & 0xFFFF) << 32) | ra.x) + 1, tk = ((u64)(rk.y & 0xFFFF) << 32) | rk.x;
-        if (ta > tk) lat = (u32)((ta - tk) / 1000000ull);
-      }
-      c_stable++; if (lat > 0) c_stale++;
-    } else if (lost) c_lost++; else c_never++;
-    known[e] = lat;  // reuse: stable latency in ms, NONE if not stable
+  u32 my_lat[32];  // statically indexed (unrolled): stays in VGPRs
+#pragma unroll
+  for (u32 k = 0; k < 32; k++) {
+    const u32 e = lane + 64 * k;
+    u32 l = NOLAT;
+    if (e < v_cur) {
+      const u32 kn = known[e], lp = lp_idx[e], la = la_idx[e];
+      const bool stable = lp != NONE && (la == NONE || la < lp);
+      const bool lost = kn != NONE && la != NONE && (lp == NONE || lp < la) && kn < la;
+      if (stable) {
+        l = 0;
+        if (la != NONE) {
+          const uint4 ra = rows[la], rk = rows[kn];
+          const u64 ta = (((u64)(ra.y & 0xFFFF) << 32) | ra.x) + 1, tk = ((u64)(rk.y & 0xFFFF) << 32) | rk.x;
+          if (ta > tk) l = (u32)((ta - tk) / 1000000ull);
+        }
+        c_stable++; if (l > 0) c_stale++;
+      } else if (lost) c_lost++; else c_never++;
+    }
+    my_lat[k] = l;
   }
+  __syncthreads();  // everyone has read the u16 arrays: the same LDS now holds the latencies
+#pragma unroll
+  for (u32 k = 0; k < 32; k++) { const u32 e = lane + 64 * k; if (e < v_cur) lat[e] = my_lat[k]; }
+  __syncthreads();
   const u32 n_stable = c_wave_sum(c_stable), n_lost = c_wave_sum(c_lost), n_never = c_wave_sum(c_never), n_stale = c_wave_sum(c_stale);
 
   // ---- quantiles of the stable latencies: idx-th smallest by bisection on the value ----
   u32 q[5] = {0, 0, 0, 0, 0};
   if (n_stable) {
     u32 lmax = 0;  // the search range is [0, largest stable latency]
-    for (u32 e = lane; e < v_cur; e += 64) { const u32 l = known[e]; if (l != NONE) lmax = max(lmax, l); }
+    for (u32 e = lane; e < v_cur; e += 64) { const u32 l = lat[e]; if (l != NOLAT) lmax = max(lmax, l); }
     for (int o = 32; o; o >>= 1) lmax = max(lmax, (u32)__shfl_xor((int)lmax, o));
     const double pts[5] = {0.0, 0.5, 0.95, 0.99, 1.0};
     for (int qi = 0; qi < 5; qi++) {
@@ -136,7 +151,7 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
       while (lo < hi) {
         const u32 mid = lo + (hi - lo) / 2;
         u32 c = 0;
-        for (u32 e = lane; e < v_cur; e += 64) { const u32 l = known[e]; c += (l != NONE && l <= mid) ? 1u : 0u; }
+        for (u32 e = lane; e < v_cur; e += 64) { const u32 l = lat[e]; c += (l != NOLAT && l <= mid) ? 1u : 0u; }
         if (c_wave_sum(c) > want) hi = mid; else lo = mid + 1;
       }
       q[qi] = lo;
@@ -162,7 +177,8 @@ int msim_check_launch(msim_ctx *ctx) {
   CParams cp;
   cp.rows = ctx->d_rows; cp.payload = ctx->d_payload; cp.meta = ctx->d_meta; cp.out = ctx->d_check;
   cp.max_rows = c.max_rows; cp.max_pay = c.max_payload_words; cp.max_values = c.max_values; cp.C = c.concurrency; cp.workload = c.workload;
-  const size_t lds = (size_t)c.max_values * 3 * 4;
+  if (c.max_rows >= 0xFFFF || c.max_values > 2048 || c.concurrency > 128) { ctx->err = "device checker: max_rows must be < 65535, max_values <= 2048, concurrency <= 128"; return MSIM_E_UNSUPPORTED; }
+  const size_t lds = (size_t)c.max_values * 3 * 2 < (size_t)c.max_values * 4 ? (size_t)c.max_values * 4 : (size_t)c.max_values * 3 * 2;
   if (lds > 64 * 1024) {
     MSIM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&check_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }

@@ -788,6 +788,7 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
 
 #include "sim_kernel_colo.inc"
 #include "sim_kernel_raft.inc"
+#include "sim_kernel_wide.inc"
 
 // =====================================================================================================
 // Host runtime
@@ -829,8 +830,11 @@ extern "C" int msim_create(const msim_config *cfg, int device, msim_ctx **out, c
   int rc = msim_config_finalize(&c, err, errlen);
   if (rc != MSIM_OK) return rc;
   const uint32_t slots = c.concurrency > c.n_nodes ? c.concurrency : c.n_nodes;
-  if (c.n_nodes > 32 || c.n_nodes + slots > 64) {
-    set_err(err, errlen, "this build maps one cluster to one wavefront: n_nodes <= 32 and n_nodes + max(concurrency, n_nodes) <= 64");
+  // wide clusters (33..127 nodes): two node/client pairs per lane, built for the g-set CRDT with one worker per node
+  const bool wide = c.n_nodes > 32 && c.node_program == MSIM_NODE_G_SET && c.concurrency == c.n_nodes && c.nemesis_mask == 0;
+  if (!wide && (c.n_nodes > 32 || c.n_nodes + slots > 64)) {
+    set_err(err, errlen, "this build maps one cluster to one wavefront: n_nodes <= 32 and n_nodes + max(concurrency, n_nodes) <= 64 "
+                         "(g-set with concurrency == n_nodes and no nemesis: up to 127 nodes)");
     return MSIM_E_UNSUPPORTED;
   }
   int ndev = 0;
@@ -936,7 +940,8 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   kp.nem_period2_us = (u32)(2000ull * c.nemesis_interval_ms);
   const bool is_raft = c.node_program == MSIM_NODE_RAFT;
   kp.raft_log_cap = is_raft ? raft_log_cap(c) : 0;
-  size_t off = STAGE_ROWS * 16;
+  const bool wide = c.n_nodes > 32;
+  size_t off = (wide ? WIDE_STAGE_ROWS : STAGE_ROWS) * 16;
   kp.off_inbox = (u32)off; off += ((size_t)kp.N * kp.cap_node + (size_t)kp.CS * (is_raft ? R_CLIENT_CAP : CLIENT_INBOX_CAP)) * 16;
   kp.off_seen = (u32)off;
   off += is_raft ? (size_t)kp.N * 256 + (size_t)kp.N * kp.N * 3 * 4   // KV state + next/match index + append_entries refs
@@ -954,7 +959,16 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
     case MSIM_NODE_BCAST_FF_ECHOBACK: e = launch<MSIM_NODE_BCAST_FF_ECHOBACK>(kp, n, lds, st); break;
     case MSIM_NODE_BCAST_ACK_RETRY: e = launch<MSIM_NODE_BCAST_ACK_RETRY>(kp, n, lds, st); break;
     case MSIM_NODE_BCAST_RPC_ALL: e = launch<MSIM_NODE_BCAST_RPC_ALL>(kp, n, lds, st); break;
-    case MSIM_NODE_G_SET: e = launch<MSIM_NODE_G_SET>(kp, n, lds, st); break;
+    case MSIM_NODE_G_SET:
+      if (wide) {
+        const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
+        const void *fn = rnd ? reinterpret_cast<const void *>(&sim_kernel_wide<true>) : reinterpret_cast<const void *>(&sim_kernel_wide<false>);
+        if (lds > 64 * 1024) MSIM_HIP_TRY(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (rnd) hipLaunchKernelGGL((sim_kernel_wide<true>), dim3(n), dim3(64), lds, st, kp);
+        else hipLaunchKernelGGL((sim_kernel_wide<false>), dim3(n), dim3(64), lds, st, kp);
+        e = hipGetLastError();
+      } else e = launch<MSIM_NODE_G_SET>(kp, n, lds, st);
+      break;
     case MSIM_NODE_RAFT: {
       const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
       if (c.nemesis_mask) { if (rnd) hipLaunchKernelGGL((raft_kernel<true, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((raft_kernel<true, false>), dim3(n), dim3(64), lds, st, kp); }

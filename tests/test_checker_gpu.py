@@ -58,6 +58,11 @@ def test_g_set_checker(lib):
     _check(E.test_config("g-set", node_count=5, rate=10, time_limit=10, seed=2), 4)
 
 
+def test_wide_g_set_checker(lib):
+    """100 worker threads: the checker keeps two pending invocations per lane."""
+    _check(E.test_config("g-set", node_count=100, rate=100, time_limit=10, latency=100, latency_dist="exponential", p_loss=0.05, seed=4), 3)
+
+
 def test_echo_checker(lib):
     cfg = E.test_config("echo", node_count=3, rate=10, time_limit=5, seed=2)
     with E.Engine(cfg) as eng:

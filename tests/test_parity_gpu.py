@@ -87,6 +87,28 @@ def test_g_set_parity(lib):
     _compare(cfg, 0, 4)
 
 
+@pytest.mark.parametrize("n,kw", [
+    (40, dict(latency=0)),
+    (64, dict(latency=20, latency_dist="uniform")),
+    (65, dict(latency=50, latency_dist="exponential", p_loss=0.05)),
+    (100, dict(latency=100, latency_dist="exponential")),
+    (100, dict(latency=100, latency_dist="exponential", p_loss=0.5)),
+    (127, dict(latency=10)),
+])
+def test_wide_g_set_parity(lib, n, kw):
+    """BASELINE cfg3: clusters wider than 32 nodes (two node/client pairs per lane, sim_kernel_wide<>), with
+    randomized latency and message loss; same oracle code path as narrow clusters."""
+    cfg = E.test_config("g-set", node_count=n, rate=100, time_limit=12, seed=77, **kw)
+    _compare(cfg, 0, 3)
+
+
+def test_wide_g_set_journal_parity(lib):
+    cfg = E.test_config("g-set", node_count=70, rate=50, time_limit=6, latency=30, latency_dist="exponential", p_loss=0.05,
+                        seed=78, journal_capacity=200000)
+    ora = _compare(cfg, 0, 2)
+    assert (ora.meta["n_events"] > 10000).all()
+
+
 @pytest.mark.parametrize("conc", [3, 10, 7])
 def test_general_layout_parity_when_concurrency_differs_from_nodes(lib, conc):
     """concurrency != n_nodes uses the general (endpoint-per-lane) kernel instead of the colocated one."""

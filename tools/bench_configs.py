@@ -19,6 +19,9 @@ CONFIGS = {
     "broadcast n=25 ack-retry + partitions": (dict(workload="broadcast", bin="broadcast-ack-retry", node_count=25, rate=100, time_limit=20, latency=10,
                                                    nemesis=["partition"], nemesis_interval=10), 2048),
     "g-set n=25 lat100 exponential p_loss 0.05": (dict(workload="g-set", node_count=25, rate=100, time_limit=20, latency=100, latency_dist="exponential", p_loss=0.05), 4096),
+    "cfg3 g-set n=100 lat100 exponential": (dict(workload="g-set", node_count=100, rate=100, time_limit=20, latency=100, latency_dist="exponential"), 16384),
+    "cfg3 g-set n=100 lat100 exponential p_loss 0.05": (dict(workload="g-set", node_count=100, rate=100, time_limit=20, latency=100, latency_dist="exponential", p_loss=0.05), 16384),
+    "cfg3 g-set n=100 lat100 exponential p_loss 0.5": (dict(workload="g-set", node_count=100, rate=100, time_limit=20, latency=100, latency_dist="exponential", p_loss=0.5), 16384),
     "cfg4 lin-kv raft n=5 c=10 rate30 60s": (dict(workload="lin-kv", bin="raft", node_count=5, rate=30, time_limit=60), 8192),
     "cfg4 lin-kv raft + partitions lat10": (dict(workload="lin-kv", bin="raft", node_count=5, rate=30, time_limit=60, latency=10, nemesis=["partition"], nemesis_interval=10), 8192),
 }
