@@ -53,7 +53,10 @@ enum {
                                    ack everyone, resend un-acked every 1 s                                    */
   MSIM_NODE_BCAST_RPC_ALL = 4,  /* demo/ruby/broadcast.rb:29-47: RPC to every other node, no retry           */
   MSIM_NODE_G_SET = 5,          /* demo/ruby/g_set.rb:8-39: replicate_full to all others every 5 s          */
-  MSIM_NODE_RAFT = 6            /* demo/ruby/raft.rb:1-497 == demo/python/raft.py:1-593 (lin-kv)             */
+  MSIM_NODE_RAFT = 6,           /* demo/ruby/raft.rb:1-497 == demo/python/raft.py:1-593 (lin-kv)             */
+  MSIM_NODE_TXN_SINGLE_KEY = 7  /* demo/clojure/single_key_txn.clj:116-180: whole database under one lin-kv key:
+                                   read root -> apply txn -> cas root (create_if_not_exists), conflict => error 30.
+                                   Brings the `lin-kv` service endpoint with it (service.clj:31-61,141-155,290-296) */
 };
 
 enum { MSIM_LAT_CONSTANT = 0, MSIM_LAT_UNIFORM = 1, MSIM_LAT_EXPONENTIAL = 2 };  /* net.clj:65-77 */
@@ -87,7 +90,11 @@ typedef struct msim_config {
   uint32_t inbox_capacity;       /* envelopes queued per node endpoint in LDS                              */
   uint32_t spill_capacity;       /* further envelopes per node endpoint in an HBM spill area behind the LDS queue */
   uint32_t journal_capacity;     /* net-journal events per instance (journal.clj:53); 0 = journal off (default)   */
-  uint32_t reserved[6];
+  /* txn-list-append generator ([upstream] jepsen.tests.cycle.append / elle.list-append gen; core.clj:167-199) */
+  uint32_t key_count;            /* --key-count: keys worked on at once; 0 = 10 [upstream default, exponential key choice] */
+  uint32_t max_txn_length;       /* --max-txn-length, default 4 (core.clj:191-194); min length is 1 [upstream]    */
+  uint32_t max_writes_per_key;   /* --max-writes-per-key, default 16 (core.clj:196-199)                           */
+  uint32_t reserved[3];
 } msim_config;
 
 /* ---- outputs ------------------------------------------------------------------------------------- */
@@ -102,7 +109,11 @@ typedef struct msim_config {
  *              offset in u32 words into the instance's payload area.
  * A read's :value is a bitmap over elements 0..32*len-1 (bit e set <=> e in the returned collection).
  * lin-kv ops (lin_kv.clj:53-67) pack their independent tuple into `value`: bits 0-7 key k, 8-15 v, 16-23 v'
- * (0xFF = nil): read [k v], write [k v], cas [k [v v']]. */
+ * (0xFF = nil): read [k v], write [k v], cas [k [v v']].
+ * txn ops (txn_list_append.clj:27-39,54-60): `value` = payload offset, len = words of the transaction
+ * [[f k v] ...].  One header word per micro-op: bit 0 f (0 = :r, 1 = :append), bits 1-15 key, bits 16-23 the appended
+ * element (:append) or the length n of the list read (:r; 0xFF = nil, i.e. an :invoke or a key that does not exist);
+ * a read of n elements is followed by ceil(n/4) words holding them one per byte, first element in the low byte. */
 typedef struct msim_op {
   uint64_t time_len;
   uint32_t packed;
@@ -116,7 +127,7 @@ enum { MSIM_F_ECHO = 0, MSIM_F_BROADCAST = 1, MSIM_F_READ = 2, MSIM_F_ADD = 3,
 enum { MSIM_ERR_NONE = 0, MSIM_ERR_NET_TIMEOUT = 1 /* client.clj:158-162 */, MSIM_ERR_RPC = 2,
        /* RPC errors of resources/errors.edn, as :error [name text] (client.clj:163-172) */
        MSIM_ERR_TEMPORARILY_UNAVAILABLE = 3 /* code 11 */, MSIM_ERR_KEY_DOES_NOT_EXIST = 4 /* code 20 */,
-       MSIM_ERR_PRECONDITION_FAILED = 5 /* code 22 */ };
+       MSIM_ERR_PRECONDITION_FAILED = 5 /* code 22 */, MSIM_ERR_TXN_CONFLICT = 6 /* code 30 */ };
 enum { MSIM_SPEC_ONE = 0, MSIM_SPEC_MAJORITY = 1, MSIM_SPEC_MAJORITIES_RING = 2, MSIM_SPEC_MINORITY_THIRD = 3 };
 #define MSIM_PROCESS_NEMESIS 0xFFFFFu
 #define MSIM_NO_VALUE 0xFFFFFFFFu   /* :value nil */
@@ -156,7 +167,8 @@ typedef struct msim_event {
 enum { MSIM_M_INIT = 1, MSIM_M_INIT_OK, MSIM_M_TOPOLOGY, MSIM_M_TOPOLOGY_OK, MSIM_M_ECHO, MSIM_M_ECHO_OK, MSIM_M_BROADCAST,
        MSIM_M_BROADCAST_OK, MSIM_M_READ, MSIM_M_READ_OK, MSIM_M_ADD, MSIM_M_ADD_OK, MSIM_M_REPLICATE,
        MSIM_M_WRITE, MSIM_M_WRITE_OK, MSIM_M_CAS, MSIM_M_CAS_OK, MSIM_M_ERROR,
-       MSIM_M_REQUEST_VOTE, MSIM_M_REQUEST_VOTE_RES, MSIM_M_APPEND_ENTRIES, MSIM_M_APPEND_ENTRIES_RES };
+       MSIM_M_REQUEST_VOTE, MSIM_M_REQUEST_VOTE_RES, MSIM_M_APPEND_ENTRIES, MSIM_M_APPEND_ENTRIES_RES,
+       MSIM_M_TXN, MSIM_M_TXN_OK };
 
 /* Per-instance bookkeeping (not part of the algorithmic output bytes). */
 typedef struct msim_inst_meta {
@@ -228,6 +240,18 @@ int msim_check(msim_ctx *ctx);
  * as rows — what `independent/checker` + Knossos do for workload/lin_kv.clj:84.  out->valid: 1 linearizable, 0 not,
  * 2 unknown; attempt_count = keys, error_count = non-linearizable keys.  Needs no device. */
 int msim_check_lin_kv_rows(const msim_op *rows, uint32_t n_rows, msim_check_result *out);
+
+/* Host-only utility behind msim_check for txn-list-append: the list-append analysis of [upstream] elle
+ * (jepsen.tests.cycle.append, txn_list_append.clj:142) for the default --consistency-models strict-serializable
+ * (core.clj:160-165): per-key version orders from the longest reads, ww/wr/rw + realtime dependency graph, cycle search,
+ * plus the non-cycle anomalies.  out->error_count = bitmask of MSIM_ANOMALY_* found; valid = 1 iff none, 2 (unknown) if
+ * no transaction completed :ok; attempt_count = transactions, stable_count = :ok transactions, lost_count = edges of
+ * the dependency graph, stale_count = transactions inside some cycle.  Needs no device. */
+enum { MSIM_ANOMALY_G0 = 1u, MSIM_ANOMALY_G1A = 2u, MSIM_ANOMALY_G1B = 4u, MSIM_ANOMALY_G1C = 8u, MSIM_ANOMALY_G_SINGLE = 16u,
+       MSIM_ANOMALY_G2 = 32u, MSIM_ANOMALY_INTERNAL = 64u, MSIM_ANOMALY_DUPLICATE_ELEMENTS = 128u,
+       MSIM_ANOMALY_INCOMPATIBLE_ORDER = 256u, MSIM_ANOMALY_REALTIME = 512u /* cycle needs a realtime edge (G*-realtime) */,
+       MSIM_ANOMALY_DIRTY_UPDATE = 1024u };
+int msim_check_txn_rows(const msim_op *rows, uint32_t n_rows, const uint32_t *payload, uint32_t n_words, msim_check_result *out);
 
 /* Copies the last run's outputs to host memory (pinned, owned by ctx, valid until next run/destroy). */
 int msim_fetch(msim_ctx *ctx);

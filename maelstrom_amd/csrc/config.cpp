@@ -29,6 +29,7 @@ extern "C" int msim_config_defaults(msim_config *cfg, uint32_t workload, uint32_
     case MSIM_WL_ECHO: cfg->node_program = MSIM_NODE_ECHO; break;
     case MSIM_WL_BROADCAST: cfg->node_program = MSIM_NODE_BCAST_FF; break;
     case MSIM_WL_G_SET: cfg->node_program = MSIM_NODE_G_SET; break;
+    case MSIM_WL_TXN_LIST_APPEND: cfg->node_program = MSIM_NODE_TXN_SINGLE_KEY; break;
     default: cfg->node_program = MSIM_NODE_RAFT; break;
   }
   cfg->n_nodes = n_nodes;
@@ -45,6 +46,9 @@ extern "C" int msim_config_defaults(msim_config *cfg, uint32_t workload, uint32_
   cfg->client_timeout_ms = 5000;        // client.clj:18-20
   cfg->quiesce_ms = 10000;              // core.clj:78
   cfg->seed = 0;
+  cfg->key_count = 0;                   // core.clj:167-169: no default here; [upstream] elle picks 10 for the exponential key choice
+  cfg->max_txn_length = 4;              // core.clj:191-194
+  cfg->max_writes_per_key = 16;         // core.clj:196-199
   return MSIM_OK;
 }
 
@@ -87,10 +91,21 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
     case MSIM_WL_BROADCAST: ok = c->node_program >= MSIM_NODE_BCAST_FF && c->node_program <= MSIM_NODE_BCAST_RPC_ALL; break;
     case MSIM_WL_G_SET: ok = c->node_program == MSIM_NODE_G_SET; break;
     case MSIM_WL_LIN_KV: ok = c->node_program == MSIM_NODE_RAFT; break;
-    default: set_err(err, errlen, "workload not built into this engine yet (txn-list-append)"); return MSIM_E_UNSUPPORTED;
+    case MSIM_WL_TXN_LIST_APPEND: ok = c->node_program == MSIM_NODE_TXN_SINGLE_KEY; break;
+    default: break;
   }
   if (!ok) { set_err(err, errlen, "node_program does not implement this workload"); return MSIM_E_INVALID; }
 
+  const bool txn = c->workload == MSIM_WL_TXN_LIST_APPEND;
+  if (txn) {
+    if (c->key_count == 0) c->key_count = 10;
+    if (c->max_txn_length == 0) c->max_txn_length = 4;
+    if (c->max_writes_per_key == 0) c->max_writes_per_key = 16;
+    if (c->key_count > 16 || c->max_txn_length > 8 || c->max_writes_per_key > 63) {
+      set_err(err, errlen, "txn-list-append: key-count <= 16, max-txn-length <= 8, max-writes-per-key <= 63"); return MSIM_E_INVALID; }
+    if (c->concurrency != c->n_nodes || c->n_nodes > 31) {
+      set_err(err, errlen, "txn-list-append: one worker per node (concurrency == node-count <= 31) in this build"); return MSIM_E_UNSUPPORTED; }
+  }
   double expected = (double)c->rate_mhz * (double)c->time_limit_ms / 1e6;
   uint32_t ops_max = (uint32_t)(expected + expected / 8.0) + 64;
   uint32_t adds = (uint32_t)(ops_max / 2 + 4.0 * std::sqrt((double)ops_max)) + 32;
@@ -98,13 +113,18 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
   if (c->nemesis_mask) nem_ops = 4 * (c->time_limit_ms / c->nemesis_interval_ms + 1) + 16;
   if (c->workload == MSIM_WL_LIN_KV && c->concurrency % (2 * c->n_nodes)) {
     set_err(err, errlen, "lin-kv: concurrency must be a multiple of 2 x node-count ([upstream] independent/concurrent-generator)"); return MSIM_E_INVALID; }
-  const bool no_sets = c->workload == MSIM_WL_ECHO || c->workload == MSIM_WL_LIN_KV;
+  const bool no_sets = c->workload == MSIM_WL_ECHO || c->workload == MSIM_WL_LIN_KV || txn;
+  // txn-list-append: max_values = distinct keys ever used (a key is retired after max_writes_per_key appends)
+  if (txn && c->max_values == 0) c->max_values = c->key_count + (ops_max * c->max_txn_length) / c->max_writes_per_key + 32;
+  if (txn && c->max_values > 32767) { set_err(err, errlen, "txn-list-append: more than 32767 keys"); return MSIM_E_INVALID; }
   if (c->max_values == 0) c->max_values = no_sets ? 32 : ((adds + 31) / 32) * 32;
   if (c->max_values % 32) c->max_values = ((c->max_values + 31) / 32) * 32;
   if (c->max_rows == 0) c->max_rows = 2 * (ops_max + c->concurrency) + 2 * nem_ops + 16;
   if (c->max_payload_words == 0) {
     uint32_t w = c->max_values / 32;
     uint64_t words = no_sets ? 16 : (uint64_t)(adds + c->concurrency) * w;
+    // a transaction: <= L header words at :invoke, <= L x (1 + ceil((writes-per-key + L) / 4)) at completion
+    if (txn) words = (uint64_t)(ops_max + c->concurrency) * c->max_txn_length * (2 + (c->max_writes_per_key + c->max_txn_length + 3) / 4) / 2 + 64;
     words += (uint64_t)nem_ops * c->n_nodes * MSIM_MASK_WORDS + 16;
     if (words > 0xFFFFFFu) { set_err(err, errlen, "payload area above 2^24 words per instance"); return MSIM_E_INVALID; }
     c->max_payload_words = (uint32_t)words;
@@ -124,7 +144,8 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
     // retrying gossip under partitions: at heal time every neighbour re-sends everything it could not deliver
     if (c->node_program == MSIM_NODE_BCAST_ACK_RETRY && c->nemesis_mask) depth += (deg < 4 ? deg : 4) * adds;
     if (c->node_program == MSIM_NODE_G_SET) depth = 16 + 2 * deg;  // one replicate_full per peer per 5 s tick (g_set.rb:33-38)
-    if (c->node_program == MSIM_NODE_RAFT) depth = 24 + 1024;       // heartbeats / re-sent append_entries pile up behind a sleeping recv!
+    if (c->node_program == MSIM_NODE_RAFT) depth = 24 + 1024;
+    if (txn) depth = 16 + 4 * c->n_nodes;                           // the service sees <= 2 requests per transaction in flight       // heartbeats / re-sent append_entries pile up behind a sleeping recv!
     const uint32_t lds_part = c->n_nodes > 32 ? 8 : 24;  // wide clusters keep 100+ queues in one CU's LDS
     if (c->inbox_capacity == 0) c->inbox_capacity = depth < lds_part ? depth : lds_part;
     if (c->spill_capacity == 0) c->spill_capacity = depth > c->inbox_capacity ? depth - c->inbox_capacity : 0;

@@ -789,6 +789,7 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
 #include "sim_kernel_colo.inc"
 #include "sim_kernel_raft.inc"
 #include "sim_kernel_wide.inc"
+#include "sim_kernel_txn.inc"
 
 // =====================================================================================================
 // Host runtime
@@ -865,6 +866,7 @@ static uint64_t proto_scratch_words(const msim_config &c) {
   uint64_t w = 4;
   if (c.node_program == MSIM_NODE_RAFT) w = (uint64_t)c.n_nodes * raft_log_cap(c) * 2 + (uint64_t)c.n_nodes * R_ARENA_WORDS;
   if (c.node_program == MSIM_NODE_BCAST_ACK_RETRY) w = (uint64_t)c.n_nodes * c.max_values * 3;
+  if (c.node_program == MSIM_NODE_TXN_SINGLE_KEY) w = (uint64_t)c.max_values * (c.max_writes_per_key + 1);  // elements + counts per key
   if (c.node_program == MSIM_NODE_G_SET) {
     const uint64_t total_ms = (uint64_t)c.time_limit_ms + c.quiesce_ms + 2ull * c.client_timeout_ms;
     const uint64_t ticks = total_ms / 5000 + 3;
@@ -873,7 +875,8 @@ static uint64_t proto_scratch_words(const msim_config &c) {
   return (w + 3) & ~3ull;  // keep the spill area 16-byte aligned
 }
 static uint64_t scratch_words(const msim_config &c) {
-  return proto_scratch_words(c) + (uint64_t)c.n_nodes * c.spill_capacity * 4;
+  const uint64_t queues = c.n_nodes + (c.node_program == MSIM_NODE_TXN_SINGLE_KEY ? 1 : 0);  // + the lin-kv service
+  return proto_scratch_words(c) + queues * c.spill_capacity * 4;
 }
 
 static int ensure_buffers(msim_ctx *ctx, uint32_t n) {
@@ -942,9 +945,13 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   kp.raft_log_cap = is_raft ? raft_log_cap(c) : 0;
   const bool wide = c.n_nodes > 32;
   size_t off = (wide ? WIDE_STAGE_ROWS : STAGE_ROWS) * 16;
-  kp.off_inbox = (u32)off; off += ((size_t)kp.N * kp.cap_node + (size_t)kp.CS * (is_raft ? R_CLIENT_CAP : CLIENT_INBOX_CAP)) * 16;
+  const bool is_txn = c.node_program == MSIM_NODE_TXN_SINGLE_KEY;
+  kp.off_inbox = (u32)off;
+  off += is_txn ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16
+                : ((size_t)kp.N * kp.cap_node + (size_t)kp.CS * (is_raft ? R_CLIENT_CAP : CLIENT_INBOX_CAP)) * 16;
   kp.off_seen = (u32)off;
-  off += is_raft ? (size_t)kp.N * 256 + (size_t)kp.N * kp.N * 3 * 4   // KV state + next/match index + append_entries refs
+  off += is_txn ? (size_t)kp.N * TXN_SLOTS * 16 + 36 * 4   // transactions in flight per node + the generator's key pool
+       : is_raft ? (size_t)kp.N * 256 + (size_t)kp.N * kp.N * 3 * 4   // KV state + next/match index + append_entries refs
                  : (size_t)kp.N * kp.W * 4;
   off = (off + 15) & ~(size_t)15;
   kp.off_misc = (u32)off; if (c.nemesis_mask) off += 64 * 4;  // shuffle scratch, only the partition nemesis needs it
@@ -975,6 +982,12 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
       else { if (rnd) hipLaunchKernelGGL((raft_kernel<false, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((raft_kernel<false, false>), dim3(n), dim3(64), lds, st, kp); }
       e = hipGetLastError();
     } break;
+    case MSIM_NODE_TXN_SINGLE_KEY: {
+      const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
+      if (c.nemesis_mask) { if (rnd) hipLaunchKernelGGL((txn_kernel<true, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((txn_kernel<true, false>), dim3(n), dim3(64), lds, st, kp); }
+      else { if (rnd) hipLaunchKernelGGL((txn_kernel<false, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((txn_kernel<false, false>), dim3(n), dim3(64), lds, st, kp); }
+      e = hipGetLastError();
+    } break;
     default: ctx->err = "node program not built into this engine"; return MSIM_E_UNSUPPORTED;
   }
   if (e != hipSuccess) { ctx->err = std::string("kernel launch: ") + hipGetErrorString(e); return MSIM_E_HIP; }
@@ -1002,6 +1015,7 @@ extern "C" int msim_check(msim_ctx *ctx) {
   if (!ctx) return MSIM_E_INVALID;
   if (!ctx->ran) { ctx->err = "msim_check before msim_run"; return MSIM_E_RANGE; }
   if (ctx->cfg.workload == MSIM_WL_LIN_KV) return msim_check_lin_kv_host(ctx);
+  if (ctx->cfg.workload == MSIM_WL_TXN_LIST_APPEND) return msim_check_txn_host(ctx);
   return msim_check_launch(ctx);
 }
 

@@ -44,6 +44,8 @@ struct msim_ctx {
 int msim_check_launch(msim_ctx *ctx);
 // lin_check.cpp
 int msim_check_lin_kv_host(msim_ctx *ctx);
+// txn_check.cpp
+int msim_check_txn_host(msim_ctx *ctx);
 
 #define MSIM_HIP_TRY(ctx, call)                                                        \
   do {                                                                                 \

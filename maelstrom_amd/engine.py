@@ -25,15 +25,17 @@ WORKLOADS = {"echo": A.WL_ECHO, "broadcast": A.WL_BROADCAST, "g-set": A.WL_G_SET
              "txn-list-append": A.WL_TXN_LIST_APPEND}
 NODE_PROGRAMS = {"echo": A.NODE_ECHO, "broadcast-ff": A.NODE_BCAST_FF, "broadcast-ff-echoback": A.NODE_BCAST_FF_ECHOBACK,
                  "broadcast-ack-retry": A.NODE_BCAST_ACK_RETRY, "broadcast-rpc-all": A.NODE_BCAST_RPC_ALL,
-                 "g-set": A.NODE_G_SET, "raft": A.NODE_RAFT}
+                 "g-set": A.NODE_G_SET, "raft": A.NODE_RAFT, "single-key-txn": A.NODE_TXN_SINGLE_KEY}
 TOPOLOGIES = {"grid": A.TOPO_GRID, "line": A.TOPO_LINE, "total": A.TOPO_TOTAL, "tree": A.TOPO_TREE2,
               "tree2": A.TOPO_TREE2, "tree3": A.TOPO_TREE3, "tree4": A.TOPO_TREE4}
 LATENCY_DISTS = {"constant": A.LAT_CONSTANT, "uniform": A.LAT_UNIFORM, "exponential": A.LAT_EXPONENTIAL}
 TYPE_KW = {A.T_INVOKE: ":invoke", A.T_OK: ":ok", A.T_FAIL: ":fail", A.T_INFO: ":info"}
 F_KW = {A.F_ECHO: ":echo", A.F_BROADCAST: ":broadcast", A.F_READ: ":read", A.F_ADD: ":add",
-        A.F_START_PARTITION: ":start-partition", A.F_STOP_PARTITION: ":stop-partition", A.F_WRITE: ":write", A.F_CAS: ":cas"}
+        A.F_START_PARTITION: ":start-partition", A.F_STOP_PARTITION: ":stop-partition", A.F_WRITE: ":write", A.F_CAS: ":cas",
+        A.F_TXN: ":txn"}
 ERR_KW = {A.ERR_NET_TIMEOUT: ":net-timeout", A.ERR_TEMPORARILY_UNAVAILABLE: [":temporarily-unavailable", "not a leader"],
-          A.ERR_KEY_DOES_NOT_EXIST: [":key-does-not-exist", "not found"], A.ERR_PRECONDITION_FAILED: [":precondition-failed", "cas mismatch"]}
+          A.ERR_KEY_DOES_NOT_EXIST: [":key-does-not-exist", "not found"], A.ERR_PRECONDITION_FAILED: [":precondition-failed", "cas mismatch"],
+          A.ERR_TXN_CONFLICT: [":txn-conflict", "root altered"]}
 SPEC_KW = {A.SPEC_ONE: ":one", A.SPEC_MAJORITY: ":majority", A.SPEC_MAJORITIES_RING: ":majorities-ring",
            A.SPEC_MINORITY_THIRD: ":minority-third"}
 
@@ -242,6 +244,66 @@ def _nil(x):
     return None if x == 0xFF else x
 
 
+def decode_txn(words):
+    """Payload words of one transaction -> [[f k v] ...] (txn_list_append.clj:27-39; encoding: include/maelsim.h msim_op)."""
+    out, i, words = [], 0, [int(w) for w in words]
+    while i < len(words):
+        w = words[i]; i += 1
+        key, x = (w >> 1) & 0x7FFF, (w >> 16) & 0xFF
+        if w & 1:
+            out.append([":append", key, x])
+        elif x == 0xFF:
+            out.append([":r", key, None])
+        else:
+            nw = (x + 3) // 4
+            out.append([":r", key, [(words[i + e // 4] >> (8 * (e % 4))) & 0xFF for e in range(x)]])
+            i += nw
+    return out
+
+
+def encode_txn(txn):
+    """[[f k v] ...] -> payload words (inverse of decode_txn)."""
+    words = []
+    for f, k, v in txn:
+        if f == ":append":
+            words.append(1 | (k << 1) | (v << 16))
+        elif v is None:
+            words.append((k << 1) | (0xFF << 16))
+        else:
+            words.append((k << 1) | (len(v) << 16))
+            for i in range(0, len(v), 4):
+                words.append(sum(x << (8 * j) for j, x in enumerate(v[i:i + 4])))
+    return words
+
+
+def encode_txn_history(ops):
+    """Jepsen-shaped txn ops ({type, process, value[, time]}) -> (rows, payload) in the engine's binary layout, so that
+    externally produced list-append histories can be fed to msim_check_txn_rows."""
+    tkw = {v: k for k, v in TYPE_KW.items()}
+    rows = np.zeros(len(ops), dtype=OP_DT)
+    payload = []
+    for i, op in enumerate(ops):
+        w = encode_txn(op["value"])
+        rows["time_len"][i] = int(op.get("time", i * 1000)) | (len(w) << 48)
+        rows["packed"][i] = tkw[op["type"]] | (A.F_TXN << 2) | (int(op["process"]) << 12)
+        rows["value"][i] = len(payload)
+        payload.extend(w)
+    return rows, np.asarray(payload, dtype=np.uint32)
+
+
+def check_txn_history(rows, payload):
+    """The host list-append checker (msim_check_txn_rows) on one history -> dict with :valid? and the anomaly names."""
+    lib = A.load()
+    res = A.CheckResult()
+    rows = np.ascontiguousarray(rows); payload = np.ascontiguousarray(payload, dtype=np.uint32)
+    rc = lib.msim_check_txn_rows(rows.ctypes.data_as(C.c_void_p), len(rows), payload.ctypes.data_as(C.c_void_p), len(payload), C.byref(res))
+    if rc:
+        raise EngineError(f"msim_check_txn_rows: {rc}")
+    return {"valid?": {1: True, 0: False, 2: "unknown"}[res.valid], "anomalies": sorted(n for b, n in A.ANOMALIES.items() if res.error_count & b),
+            "txn-count": res.attempt_count, "ok-count": res.ok_count, "fail-count": res.fail_count, "info-count": res.info_count,
+            "edge-count": res.lost_count, "cycle-txns": res.stale_count}
+
+
 def decode_history(rows, payload, n_nodes, workload=A.WL_BROADCAST):
     """Binary rows -> list of Jepsen op maps (SURVEY.md §8b 'History surface')."""
     ops = []
@@ -254,6 +316,8 @@ def decode_history(rows, payload, n_nodes, workload=A.WL_BROADCAST):
         if workload == A.WL_LIN_KV and f in (A.F_READ, A.F_WRITE, A.F_CAS):  # independent tuples, lin_kv.clj:53-67
             k, v1, v2 = value & 0xFF, _nil((value >> 8) & 0xFF), _nil((value >> 16) & 0xFF)
             op["value"] = [k, [v1, v2]] if f == A.F_CAS else [k, v1]
+        elif f == A.F_TXN:
+            op["value"] = decode_txn(payload[value:value + ln])
         elif f == A.F_READ:
             op["value"] = bitmap_to_list(payload[value:value + ln]) if typ == A.T_OK else None
         elif f == A.F_ECHO:

@@ -57,10 +57,11 @@ typedef uint64_t u64;
 enum { M_INIT = 1, M_INIT_OK, M_TOPOLOGY, M_TOPOLOGY_OK, M_ECHO, M_ECHO_OK, M_BROADCAST, M_BROADCAST_OK,
        M_READ, M_READ_OK, M_ADD, M_ADD_OK, M_REPLICATE,
        M_WRITE, M_WRITE_OK, M_CAS, M_CAS_OK, M_ERROR,                                   /* lin-kv RPCs, doc/workloads.md */
-       M_REQUEST_VOTE, M_REQUEST_VOTE_RES, M_APPEND_ENTRIES, M_APPEND_ENTRIES_RES };    /* raft.py:290-297,412-420 */
+       M_REQUEST_VOTE, M_REQUEST_VOTE_RES, M_APPEND_ENTRIES, M_APPEND_ENTRIES_RES,      /* raft.py:290-297,412-420 */
+       M_TXN, M_TXN_OK };                                                                /* txn_list_append.clj:73-80 */
 
 /* RNG streams */
-enum { S_GEN = 1, S_GEN2 = 2, S_LATENCY = 4, S_LOSS = 5, S_NODE = 11,
+enum { S_GEN = 1, S_GEN2 = 2, S_GEN3 = 3, S_LATENCY = 4, S_LOSS = 5, S_NODE = 11,
        S_NEM_STAGGER = 7, S_NEM_SPEC = 8, S_NEM_SHUFFLE = 9, S_NEM_PICK = 10 };
 
 enum { PH_INIT, PH_INIT_WAIT, PH_TOPO, PH_TOPO_WAIT, PH_MAIN_START, PH_MAIN, PH_DRAIN, PH_NEM_FINAL,
@@ -78,6 +79,8 @@ typedef struct { u8 src_ep, dest_ep, type; u32 a, b; struct rext *r; } outmsg;
 typedef struct {
   msim_config cfg;
   u32 N, C, CS, E, W; /* nodes, workers, client slots, endpoints, words per node set */
+  u32 S;              /* services (endpoints after the client slots): 1 = lin-kv for the txn workload */
+  struct txn_s *txn;  /* txn-list-append state (txn_nodes.inc) */
   u64 key;
   u32 adj[MAXN][MW];
   /* net (net.clj:79-103) */
@@ -154,13 +157,16 @@ static u32 latency_ms(const sim_t *s, u32 msg_id, int involves_client) {
 static int bit(const u32 *m, u32 i) { return (m[i >> 5] >> (i & 31)) & 1; }
 static void setbit(u32 *m, u32 i) { m[i >> 5] |= 1u << (i & 31); }
 static void clrbit(u32 *m, u32 i) { m[i >> 5] &= ~(1u << (i & 31)); }
-static int is_client(const sim_t *s, u32 ep) { return ep >= s->N; }
+static int is_client(const sim_t *s, u32 ep) { return ep >= s->N && ep < s->N + s->CS; }
+
+/* lin_kv.clj:74-76, txn_list_append.clj:124-126: Reusable clients are not re-opened after a crash */
+static int reusable_clients(const sim_t *s) { return s->cfg.workload == MSIM_WL_LIN_KV || s->cfg.workload == MSIM_WL_TXN_LIST_APPEND; }
 
 static void inbox_push(sim_t *s, u32 ep, qent q) {
   inbox_t *b = &s->inbox[ep];
   if (b->n == b->cap) { b->cap = b->cap ? b->cap * 2 : 8; b->v = (qent *)realloc(b->v, b->cap * sizeof(qent)); }
   b->v[b->n++] = q;
-  u32 lim = is_client(s, ep) ? (s->cfg.workload == MSIM_WL_LIN_KV ? 32u : 2u) /* Reusable lin-kv clients collect late replies */
+  u32 lim = is_client(s, ep) ? (reusable_clients(s) ? 32u : 2u) /* Reusable clients collect late replies */
                              : s->cfg.inbox_capacity + s->cfg.spill_capacity; /* engine capacities: overflow is flagged, never silent */
   if (b->n > lim) s->meta.flags |= MSIM_FLAG_INBOX_OVERFLOW;
 }
@@ -346,9 +352,11 @@ static void node_timer(sim_t *s, u32 node) {
 }
 
 #include "raft_nodes.inc"
+#include "txn_nodes.inc"
 
 static void node_handle(sim_t *s, u32 node, const qent *q) {
   if (s->cfg.node_program == MSIM_NODE_RAFT) { raft_handle(s, node, q); return; }
+  if (s->cfg.node_program == MSIM_NODE_TXN_SINGLE_KEY) { txn_node_handle(s, node, q); return; }
   switch (q->type) {
     case M_INIT: /* node.rb init handler -> init_ok; g-set starts its periodic task (node.rb:129-138) */
       if (s->cfg.node_program == MSIM_NODE_G_SET) s->timer_next[node] = s->T;
@@ -379,7 +387,7 @@ static void client_complete(sim_t *s, u32 slot, u32 type, u32 err, u32 value, u3
   } else add_row(s, type, c->f, err, c->m_final, c->process, value, len);
   if (type == MSIM_T_INFO) { /* crashed process: new process id, fresh client [upstream interpreter] */
     c->process += s->C;
-    if (s->cfg.workload != MSIM_WL_LIN_KV) { /* lin-kv clients are Reusable (lin_kv.clj:74-76): not re-opened */
+    if (!reusable_clients(s)) { /* Reusable clients (lin_kv.clj:74-76) are not re-opened */
       c->next_msg_id = 0;
       s->inbox[s->N + slot].n = 0;
     }
@@ -395,9 +403,11 @@ static void client_deliver(sim_t *s, u32 slot, const qent *q) {
       else client_complete(s, slot, MSIM_T_OK, 0, q->a & 0xFFFFFFu, q->a >> 24);
       break;
     case M_ECHO_OK: client_complete(s, slot, MSIM_T_OK, 0, q->a, 0); break;
+    case M_TXN_OK: client_complete(s, slot, MSIM_T_OK, 0, q->a & 0xFFFFFFu, q->a >> 24); break; /* txn_list_append.clj:109-117 */
     case M_ERROR: { /* client.clj:125-138 throw-errors!; every code the raft node emits is :definite? => :fail (errors.edn) */
-      u32 err = q->a == 11 ? MSIM_ERR_TEMPORARILY_UNAVAILABLE : q->a == 20 ? MSIM_ERR_KEY_DOES_NOT_EXIST : MSIM_ERR_PRECONDITION_FAILED;
-      client_complete(s, slot, MSIM_T_FAIL, err, c->value, 0); } break;
+      u32 err = q->a == 11 ? MSIM_ERR_TEMPORARILY_UNAVAILABLE : q->a == 20 ? MSIM_ERR_KEY_DOES_NOT_EXIST : q->a == 30 ? MSIM_ERR_TXN_CONFLICT : MSIM_ERR_PRECONDITION_FAILED;
+      if (s->cfg.workload == MSIM_WL_TXN_LIST_APPEND) client_complete(s, slot, MSIM_T_FAIL, err, c->value & 0xFFFFFFu, c->value >> 24); /* :value stays the requested txn */
+      else client_complete(s, slot, MSIM_T_FAIL, err, c->value, 0); } break;
     default: client_complete(s, slot, MSIM_T_OK, 0, c->value, 0); break;
   }
 }
@@ -406,7 +416,8 @@ static void client_timeout(sim_t *s, u32 slot) { /* client.clj:96-103 + :158-162
   struct cl *c = &s->cl[slot];
   u32 type = idempotent(s, c->f) ? MSIM_T_FAIL : MSIM_T_INFO;
   u32 v = c->f == MSIM_F_READ && s->cfg.workload != MSIM_WL_LIN_KV ? MSIM_NO_VALUE : c->value;
-  client_complete(s, slot, type, MSIM_ERR_NET_TIMEOUT, v, 0);
+  if (c->f == MSIM_F_TXN) client_complete(s, slot, type, MSIM_ERR_NET_TIMEOUT, v & 0xFFFFFFu, v >> 24);
+  else client_complete(s, slot, type, MSIM_ERR_NET_TIMEOUT, v, 0);
 }
 
 static void client_invoke(sim_t *s, u32 slot) {
@@ -418,13 +429,15 @@ static void client_invoke(sim_t *s, u32 slot) {
   else {
     c->f = c->m_f; c->value = c->m_value;
     dest = c->process % s->N; /* worker -> node: nodes[process mod n] [upstream] */
-    add_row(s, MSIM_T_INVOKE, c->f, 0, c->m_final, c->process, c->value, 0);
+    if (c->f == MSIM_F_TXN) add_row(s, MSIM_T_INVOKE, c->f, 0, 0, c->process, c->value & 0xFFFFFFu, c->value >> 24);
+    else add_row(s, MSIM_T_INVOKE, c->f, 0, c->m_final, c->process, c->value, 0);
     switch (c->f) {
       case MSIM_F_ECHO: type = M_ECHO; a = c->value; break;
       case MSIM_F_BROADCAST: type = M_BROADCAST; a = c->value; break;
       case MSIM_F_ADD: type = M_ADD; a = c->value; break;
       case MSIM_F_WRITE: type = M_WRITE; a = c->value; break;
       case MSIM_F_CAS: type = M_CAS; a = c->value; break;
+      case MSIM_F_TXN: type = M_TXN; a = c->value; break;
       default: type = M_READ; a = s->cfg.workload == MSIM_WL_LIN_KV ? c->value : 0; break;
     }
   }
@@ -537,6 +550,11 @@ static void sched_act(sim_t *s) {
             else if (scale32((u32)h2, 3) == 0) { c->m_f = MSIM_F_WRITE; c->m_value = key | (v1 << 8) | 0xFF0000u; }
             else { c->m_f = MSIM_F_CAS; c->m_value = key | (v1 << 8) | (v2 << 16); }
           }
+          else if (s->cfg.workload == MSIM_WL_TXN_LIST_APPEND) {
+            u32 ref = txn_generate(s, k);
+            if (ref == INF) { c->mark = 0; s->phase = PH_DONE; return; }
+            c->m_f = MSIM_F_TXN; c->m_value = ref;
+          }
           else if (s->cfg.workload == MSIM_WL_ECHO) { c->m_f = MSIM_F_ECHO; c->m_value = (r_lo >> 4) & 127; } /* echo.clj:72-75 */
           else if (r_lo & 1) { c->m_f = MSIM_F_READ; c->m_value = MSIM_NO_VALUE; }  /* gen/mix */
           else {
@@ -565,11 +583,11 @@ static void rext_free(struct rext *r) { if (r) { free(r->ents); free(r); } }
 
 /* commit the round's staged sends in canonical order (net.clj:189-221) */
 static void commit_sends(sim_t *s) {
-  u32 N = s->N, T = s->T;
+  u32 T = s->T;
   for (u32 i = 0; i < s->n_out; i++) {
     outmsg *m = &s->out[i];
     u32 id = s->next_msg_id++;
-    int cl = m->src_ep >= N || m->dest_ep >= N;
+    int cl = is_client(s, m->src_ep) || is_client(s, m->dest_ep);
     s->st.all_send++; if (cl) s->st.clients_send++; else s->st.servers_send++; /* journal :send before loss */
     jlog(s, 0, id, m->type, m->a, m->b, m->src_ep, m->dest_ep);
     u32 lat = latency_ms(s, id, cl);
@@ -584,7 +602,7 @@ static void commit_sends(sim_t *s) {
  * if the partition says so (:234), else sleep floor(dt) ms (:236-238). */
 static void poll_endpoint(sim_t *s, u32 e) {
   u32 N = s->N, T = s->T;
-  if (e >= N && !s->cl[e - N].busy) return; /* clients only poll inside recv! (client.clj:94-95) */
+  if (is_client(s, e) && !s->cl[e - N].busy) return; /* clients only poll inside recv! (client.clj:94-95) */
   inbox_t *b = &s->inbox[e];
   while (!s->has_committed[e] && b->n) {
     u32 k = 0;
@@ -636,12 +654,19 @@ static void run_instance(sim_t *s) {
         else if (raft_next_time(s, n) <= T) raft_act(s, n);
       } else if (msg_due) {
         qent q = s->committed[n]; s->has_committed[n] = 0;
-        s->st.all_recv++; if (q.src >= N) s->st.clients_recv++; else s->st.servers_recv++; /* journal :recv */
+        s->st.all_recv++; if (is_client(s, q.src)) s->st.clients_recv++; else s->st.servers_recv++; /* journal :recv */
         jlog(s, 1, q.id, q.type, q.a, q.b, q.src, n);
         node_handle(s, n, &q);
         rext_free(q.r);
       }
     }
+    for (u32 e = N + s->CS; e < E; e++) /* services run after the nodes (endpoint order): one request per round (service.clj:252-258) */
+      if (s->has_committed[e] && s->deliver_at[e] <= T) {
+        qent q = s->committed[e]; s->has_committed[e] = 0;
+        s->st.all_recv++; s->st.servers_recv++;
+        jlog(s, 1, q.id, q.type, q.a, q.b, q.src, e);
+        svc_handle(s, &q);
+      }
     commit_sends(s);
     for (u32 e = 0; e < E; e++) poll_endpoint(s, e);
     /* R4: clients run their recv! loops: consume due envelopes until the awaited reply arrives; stale replies
@@ -677,7 +702,9 @@ static sim_t *sim_new(const msim_config *cfg, uint64_t instance, msim_op *rows, 
   if (cfg->n_nodes == 0 || cfg->n_nodes > MAXN || cfg->concurrency == 0) return NULL;
   sim_t *s = (sim_t *)calloc(1, sizeof(sim_t));
   s->cfg = *cfg;
-  s->N = cfg->n_nodes; s->C = cfg->concurrency; s->CS = s->C > s->N ? s->C : s->N; s->E = s->N + s->CS;
+  s->N = cfg->n_nodes; s->C = cfg->concurrency; s->CS = s->C > s->N ? s->C : s->N;
+  s->S = cfg->node_program == MSIM_NODE_TXN_SINGLE_KEY ? 1 : 0;
+  s->E = s->N + s->CS + s->S;
   if (s->E > 255) { free(s); return NULL; }
   s->W = (cfg->max_values + 31) / 32;
   s->key = inst_key(cfg->seed, instance);
@@ -703,6 +730,16 @@ static sim_t *sim_new(const msim_config *cfg, uint64_t instance, msim_op *rows, 
     for (u32 i = 0; i < s->N; i++) { rnode *r = &s->raft[i]; r->voted_for = -1; r->leader = -1; r->last_applied = 1; memset(r->kv, 0xFF, sizeof r->kv);
       rentry e0; memset(&e0, 0, sizeof e0); r_append(r, &e0, 1); }
   }
+  if (s->S) {
+    txn_t *t = (txn_t *)calloc(1, sizeof(txn_t));
+    t->slots = (tslot *)calloc((size_t)s->N * TXN_SLOTS, sizeof(tslot));
+    t->root = V_NIL;
+    t->kv = (u32 *)calloc((size_t)cfg->max_values * cfg->max_writes_per_key, 4);
+    t->kv_n = (u8 *)calloc(cfg->max_values, 1);
+    for (u32 i = 0; i < cfg->key_count && i < 16; i++) { t->active[i] = i; t->next_val[i] = 1; }
+    t->next_key = cfg->key_count;
+    s->txn = t;
+  }
   for (u32 i = 0; i < s->CS; i++) s->cl[i].process = i;
   s->rows = rows; s->payload = payload;
   s->phase = PH_INIT;
@@ -719,6 +756,7 @@ static void sim_free(sim_t *s) {
   for (u32 n = 0; n < s->N; n++) free(s->tasks[n].v);
   for (u32 i = 0; i < s->n_snap; i++) free(s->snap[i]);
   if (s->raft) { for (u32 i = 0; i < s->N; i++) free(s->raft[i].log); free(s->raft); }
+  if (s->txn) { free(s->txn->slots); free(s->txn->kv); free(s->txn->kv_n); free(s->txn); }
   free(s->snap); free(s->inbox); free(s->committed); free(s->has_committed); free(s->deliver_at); free(s->seen);
   free(s->unacked); free(s->node_msg_id); free(s->nbr_known); free(s->tasks); free(s->key_reg); free(s->timer_next); free(s->tick);
   free(s->cl); free(s->pend); free(s->out);

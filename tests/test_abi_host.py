@@ -24,7 +24,7 @@ def test_header_symbols_are_exported(lib):
 def test_struct_layouts_match_header():
     assert C.sizeof(A.Config) == 120 and A.Config.seed.offset == 64 and A.Config.max_values.offset == 72
     assert C.sizeof(A.Op) == 16 and C.sizeof(A.NetStats) == 48 and C.sizeof(A.InstMeta) == 32 and C.sizeof(A.Event) == 16
-    assert C.sizeof(A.CheckResult) == 68 and C.sizeof(A.DeviceBuffers) == 112 and A.Config.journal_capacity.offset == 92
+    assert C.sizeof(A.CheckResult) == 68 and C.sizeof(A.DeviceBuffers) == 112 and A.Config.journal_capacity.offset == 92 and A.Config.key_count.offset == 96
 
 
 def test_defaults_mirror_reference_cli(lib):
@@ -45,8 +45,12 @@ def test_finalize_derives_capacities_and_rejects_bad_options(lib):
         E.test_config("echo", bin="g-set", node_count=3)
     with pytest.raises(E.EngineError, match="n_nodes"):
         E.test_config("broadcast", node_count=0)
-    with pytest.raises(E.EngineError, match="not built"):
-        E.test_config("txn-list-append", node_count=5)
+    cfg = E.test_config("txn-list-append", node_count=5)
+    assert (cfg.node_program, cfg.key_count, cfg.max_txn_length, cfg.max_writes_per_key) == (A.NODE_TXN_SINGLE_KEY, 10, 4, 16)  # core.clj:191-199
+    with pytest.raises(E.EngineError, match="one worker per node"):
+        E.test_config("txn-list-append", node_count=5, concurrency=10)
+    with pytest.raises(E.EngineError, match="max-txn-length"):
+        E.test_config("txn-list-append", node_count=5, max_txn_length=9)
     with pytest.raises(E.EngineError, match="multiple of 2 x node-count"):
         E.test_config("lin-kv", bin="raft", node_count=5, concurrency=5)
     cfg = E.test_config("lin-kv", bin="raft", node_count=5)

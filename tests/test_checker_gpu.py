@@ -91,3 +91,19 @@ def test_lin_kv_checker_on_raft_histories(lib):
             ref = L.check(h)
             assert all(ref.values()) and int(res[i]["attempt_count"]) == len(ref)
             assert int(res[i]["op_count"]) == sum(1 for op in h if op["type"] == ":invoke" and op["process"] != ":nemesis")
+
+
+def test_txn_list_append_checker_on_engine_histories(lib):
+    """msim_check for txn-list-append = the host list-append checker over the fetched histories: every history the
+    single-root node produces is strict-serializable; conflicts show up as :fail, never as anomalies."""
+    cfg = E.test_config("txn-list-append", node_count=5, rate=100, time_limit=15, latency=5, nemesis=["partition"], nemesis_interval=5, seed=9)
+    with E.Engine(cfg) as eng:
+        eng.run(0, 16)
+        eng.check()
+        eng.fetch()
+        res = eng.check_results()
+        assert (res["valid"] == 1).all() and (res["error_count"] == 0).all()
+        assert (res["fail_count"] > 0).all() and (res["ok_count"] > res["fail_count"]).all()
+        rows, pay = eng.raw_history(3)
+        one = E.check_txn_history(rows, pay)
+        assert one["valid?"] is True and one["txn-count"] == int(res["attempt_count"][3])

@@ -161,3 +161,27 @@ def test_raft_lin_kv_parity(lib, kw):
     kw = dict(dict(node_count=5, rate=30, time_limit=20, seed=17), **kw)
     cfg = E.test_config("lin-kv", bin="raft", **kw)
     _compare(cfg, 0, 6)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(),
+    dict(latency=5),
+    dict(latency=20, latency_dist="exponential"),
+    dict(latency=5, nemesis=["partition"], nemesis_interval=3),
+    dict(latency=10, latency_dist="uniform", p_loss=0.02),
+    dict(node_count=3, rate=200, latency=2),
+    dict(node_count=9, rate=100, latency=50),
+])
+def test_txn_list_append_parity(lib, kw):
+    """BASELINE configs[4]: single-root transactional nodes over the lin-kv service (txn_kernel<>)."""
+    base = dict(node_count=5, rate=50, time_limit=10, seed=61)
+    base.update(kw)
+    cfg = E.test_config("txn-list-append", **base)
+    _compare(cfg, 0, 6)
+
+
+def test_txn_list_append_journal_parity(lib):
+    cfg = E.test_config("txn-list-append", node_count=5, rate=50, time_limit=6, latency=5, nemesis=["partition"], nemesis_interval=2,
+                        seed=62, journal_capacity=40000)
+    ora = _compare(cfg, 0, 4)
+    assert (ora.meta["n_events"] > 2000).all()

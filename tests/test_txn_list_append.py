@@ -1,0 +1,176 @@
+"""txn-list-append (BASELINE configs[4]) on the CPU side: the oracle's single-root
+transactional node + lin-kv service against the reference's known answers, and the host list-append checker
+(restating [upstream] elle, txn_list_append.clj:142) against hand-made anomalous histories.
+
+No golden transitions exist for this node program: demo/clojure/single_key_txn.clj needs babashka, which is not in
+this image — parity with the JVM path is unpinned here; what IS pinned: message counts per transaction
+(read + cas per txn, service.clj / single_key_txn.clj:171-180) and strict serializability of every history."""
+import numpy as np
+import pytest
+
+from maelstrom_amd import _abi as A
+from maelstrom_amd import engine as E
+import oracle_lib as O
+
+
+def _cfg(**kw):
+    base = dict(node_count=5, rate=50, time_limit=10, seed=5)
+    base.update(kw)
+    return E.test_config("txn-list-append", **base)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(latency=5), dict(latency=20, latency_dist="exponential"),
+                                dict(latency=5, nemesis=["partition"], nemesis_interval=3), dict(node_count=3, rate=200)])
+def test_messages_per_transaction_and_verdict(kw):
+    cfg = _cfg(**kw)
+    r = O.run(cfg, 0, 4)
+    for i in range(4):
+        assert r.meta["flags"][i] == 0
+        rows, pay = r.history(i)
+        ops = [o for o in E.decode_history(rows, pay, cfg.n_nodes, A.WL_TXN_LIST_APPEND) if o["process"] != ":nemesis"]
+        inv = [o for o in ops if o["type"] == ":invoke"]
+        done = [o for o in ops if o["type"] != ":invoke"]
+        assert len(inv) == len(done) > 50 and not any(o["type"] == ":info" for o in done)
+        st = r.stats[i]
+        # every txn: client -> node, node -> client; node -> lin-kv read, reply, cas, reply (single_key_txn.clj:171-180)
+        assert int(st["clients_send"]) == 2 * (len(inv) + cfg.n_nodes)
+        assert int(st["servers_send"]) == 4 * len(inv)
+        assert int(st["all_recv"]) == int(st["all_send"])
+        # completed transactions echo the requested micro-ops, reads filled in (txn_list_append.clj:40-52)
+        by_proc = {}
+        for o in ops:
+            if o["type"] == ":invoke":
+                by_proc[o["process"]] = o
+            else:
+                req = by_proc.pop(o["process"])["value"]
+                assert [(f, k) for f, k, _ in req] == [(f, k) for f, k, _ in o["value"]]
+                if o["type"] == ":fail":
+                    assert o["value"] == req and o["error"][0] == ":txn-conflict"
+                else:
+                    assert all(v is not None or f == ":r" for f, _, v in o["value"])
+        res = E.check_txn_history(rows, pay)
+        assert res["valid?"] is True and res["anomalies"] == [], res
+        assert res["txn-count"] == len(inv)
+
+
+def test_conflicts_need_concurrency():
+    """With one node there is one worker: no cas can lose the race."""
+    cfg = _cfg(node_count=1, rate=50, latency=5)
+    r = O.run(cfg, 0, 2)
+    for i in range(2):
+        rows, pay = r.history(i)
+        assert not (((rows["packed"] & 3) == A.T_FAIL).any())
+
+
+def test_appends_are_unique_per_key_and_keys_rotate():
+    cfg = _cfg(rate=200, time_limit=10)
+    r = O.run(cfg, 0, 1)
+    rows, pay = r.history(0)
+    seen, keys = set(), set()
+    for o in E.decode_history(rows, pay, 5, A.WL_TXN_LIST_APPEND):
+        if o["type"] == ":invoke":
+            assert 1 <= len(o["value"]) <= cfg.max_txn_length
+            for f, k, v in o["value"]:
+                keys.add(k)
+                if f == ":append":
+                    assert (k, v) not in seen and 1 <= v <= cfg.max_writes_per_key
+                    seen.add((k, v))
+    assert len(keys) > cfg.key_count  # keys were retired and replaced
+
+
+def test_txn_payload_roundtrip():
+    txn = [[":append", 7, 3], [":r", 7, [1, 2, 3]], [":r", 9, None], [":r", 300, [5, 6, 7, 8, 9]], [":append", 32000, 63]]
+    assert E.decode_txn(E.encode_txn(txn)) == txn
+
+
+def _h(*ops):
+    """ops: (type, process, txn) in history order."""
+    return E.encode_txn_history([{"type": t, "process": p, "value": v} for t, p, v in ops])
+
+
+def _check(*ops):
+    return E.check_txn_history(*_h(*ops))
+
+
+A_, R_ = ":append", ":r"
+
+
+def test_checker_accepts_a_serial_history():
+    res = _check((":invoke", 0, [[A_, 1, 1], [R_, 1, None]]), (":ok", 0, [[A_, 1, 1], [R_, 1, [1]]]),
+                 (":invoke", 1, [[R_, 1, None], [A_, 1, 2]]), (":ok", 1, [[R_, 1, [1]], [A_, 1, 2]]),
+                 (":invoke", 0, [[R_, 1, None]]), (":ok", 0, [[R_, 1, [1, 2]]]))
+    assert res["valid?"] is True and res["anomalies"] == []
+
+
+def test_checker_g0_write_cycle():
+    res = _check((":invoke", 0, [[A_, 1, 1], [A_, 2, 1]]), (":invoke", 1, [[A_, 1, 2], [A_, 2, 2]]),
+                 (":ok", 0, [[A_, 1, 1], [A_, 2, 1]]), (":ok", 1, [[A_, 1, 2], [A_, 2, 2]]),
+                 (":invoke", 2, [[R_, 1, None], [R_, 2, None]]), (":ok", 2, [[R_, 1, [1, 2]], [R_, 2, [2, 1]]]))
+    assert res["valid?"] is False and "G0" in res["anomalies"]
+
+
+def test_checker_g1a_aborted_read():
+    res = _check((":invoke", 0, [[A_, 1, 1]]), (":fail", 0, [[A_, 1, 1]]),
+                 (":invoke", 1, [[R_, 1, None]]), (":ok", 1, [[R_, 1, [1]]]))
+    assert res["valid?"] is False and "G1a" in res["anomalies"]
+
+
+def test_checker_g1b_intermediate_read():
+    res = _check((":invoke", 0, [[A_, 1, 1], [A_, 1, 2]]), (":invoke", 1, [[R_, 1, None]]),
+                 (":ok", 1, [[R_, 1, [1]]]), (":ok", 0, [[A_, 1, 1], [A_, 1, 2]]))
+    assert res["valid?"] is False and "G1b" in res["anomalies"]
+
+
+def test_checker_g1c_circular_information_flow():
+    res = _check((":invoke", 0, [[A_, 1, 1], [R_, 2, None]]), (":invoke", 1, [[A_, 2, 1], [R_, 1, None]]),
+                 (":ok", 0, [[A_, 1, 1], [R_, 2, [1]]]), (":ok", 1, [[A_, 2, 1], [R_, 1, [1]]]))
+    assert res["valid?"] is False and "G1c" in res["anomalies"]
+
+
+def test_checker_g_single_read_skew():
+    res = _check((":invoke", 0, [[A_, 1, 1], [A_, 2, 1]]), (":invoke", 1, [[R_, 1, None], [R_, 2, None]]),
+                 (":ok", 0, [[A_, 1, 1], [A_, 2, 1]]), (":ok", 1, [[R_, 1, [1]], [R_, 2, None]]),
+                 (":invoke", 2, [[R_, 2, None]]), (":ok", 2, [[R_, 2, [1]]]))
+    assert res["valid?"] is False and res["anomalies"] == ["G-single"]
+
+
+def test_checker_g2_write_skew():
+    res = _check((":invoke", 0, [[R_, 1, None], [A_, 2, 1]]), (":invoke", 1, [[R_, 2, None], [A_, 1, 1]]),
+                 (":ok", 0, [[R_, 1, None], [A_, 2, 1]]), (":ok", 1, [[R_, 2, None], [A_, 1, 1]]),
+                 (":invoke", 2, [[R_, 1, None], [R_, 2, None]]), (":ok", 2, [[R_, 1, [1]], [R_, 2, [1]]]))
+    assert res["valid?"] is False and res["anomalies"] == ["G2"]
+
+
+def test_checker_internal_inconsistency():
+    res = _check((":invoke", 0, [[A_, 1, 1], [R_, 1, None]]), (":ok", 0, [[A_, 1, 1], [R_, 1, None]]))
+    assert res["valid?"] is False and "internal" in res["anomalies"]
+    res = _check((":invoke", 0, [[R_, 1, None], [A_, 1, 1], [R_, 1, None]]), (":ok", 0, [[R_, 1, None], [A_, 1, 1], [R_, 1, [1]]]))
+    assert res["valid?"] is True
+
+
+def test_checker_incompatible_orders_and_duplicates():
+    res = _check((":invoke", 0, [[A_, 1, 1]]), (":ok", 0, [[A_, 1, 1]]), (":invoke", 1, [[A_, 1, 2]]), (":ok", 1, [[A_, 1, 2]]),
+                 (":invoke", 2, [[R_, 1, None]]), (":ok", 2, [[R_, 1, [1, 2]]]),
+                 (":invoke", 3, [[R_, 1, None]]), (":ok", 3, [[R_, 1, [2, 1]]]))
+    assert res["valid?"] is False and "incompatible-order" in res["anomalies"]
+    res = _check((":invoke", 0, [[A_, 1, 1]]), (":ok", 0, [[A_, 1, 1]]),
+                 (":invoke", 1, [[R_, 1, None]]), (":ok", 1, [[R_, 1, [1, 1]]]))
+    assert res["valid?"] is False and "duplicate-elements" in res["anomalies"]
+
+
+def test_checker_stale_read_is_a_realtime_anomaly_only():
+    """Serializable but not strict: T2 starts after T1 completed and does not see its append."""
+    ops = ((":invoke", 0, [[A_, 1, 1]]), (":ok", 0, [[A_, 1, 1]]),
+           (":invoke", 1, [[R_, 1, None]]), (":ok", 1, [[R_, 1, None]]),
+           (":invoke", 2, [[R_, 1, None]]), (":ok", 2, [[R_, 1, [1]]]))
+    res = _check(*ops)
+    assert res["valid?"] is False and "realtime" in res["anomalies"] and "G-single" in res["anomalies"]
+    # the same reads issued concurrently with the append are fine
+    res = _check(ops[0], ops[2], ops[1], ops[3], ops[4], ops[5])
+    assert res["valid?"] is True
+
+
+def test_checker_indeterminate_appends_may_be_observed():
+    res = _check((":invoke", 0, [[A_, 1, 1]]), (":info", 0, [[A_, 1, 1]]),
+                 (":invoke", 1, [[R_, 1, None]]), (":ok", 1, [[R_, 1, [1]]]))
+    assert res["valid?"] is True and res["info-count"] == 1
