@@ -816,6 +816,10 @@ static void free_buffers(msim_ctx *c) {
   if (c->h_meta) (void)hipHostFree(c->h_meta);
   if (c->h_check) (void)hipHostFree(c->h_check);
   if (c->h_journal) (void)hipHostFree(c->h_journal);
+  if (c->d_compact) (void)hipFree(c->d_compact);
+  if (c->d_off) (void)hipFree(c->d_off);
+  c->d_compact = nullptr; c->d_off = nullptr;
+  c->cap_compact = c->cap_off = c->cap_h_rows = c->cap_h_payload = c->cap_h_journal = c->cap_h_meta = 0;
   delete[] c->h_row_off; delete[] c->h_pay_off; delete[] c->h_ev_off;
   c->d_journal = nullptr; c->h_journal = nullptr; c->h_ev_off = nullptr;
   c->d_rows = nullptr; c->d_payload = nullptr; c->d_stats = nullptr; c->d_meta = nullptr; c->d_scratch = nullptr; c->d_check = nullptr;
@@ -1019,6 +1023,63 @@ extern "C" int msim_check(msim_ctx *ctx) {
   return msim_check_launch(ctx);
 }
 
+// Gathers the used prefix of every instance's slab into one contiguous device buffer (16-byte units):
+// block (i, j) copies units [j*256*UNROLL ...) of instance i.  off[i] = first unit of instance i in dst.
+__global__ void __launch_bounds__(256) compact_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, const uint64_t *__restrict__ off,
+                                                      uint64_t stride_units) {
+  const u32 i = blockIdx.x;
+  const uint64_t o = off[i], cnt = off[i + 1] - o;
+  const uint4 *s = src + (size_t)i * stride_units;
+  for (uint64_t k = (uint64_t)blockIdx.y * 256 + threadIdx.x; k < cnt; k += (uint64_t)gridDim.y * 256) dst[o + k] = s[k];
+}
+// same for 4-byte units whose per-instance slabs are not 16-byte aligned relative to their compacted position
+__global__ void __launch_bounds__(256) compact_words_kernel(const u32 *__restrict__ src, u32 *__restrict__ dst, const uint64_t *__restrict__ off,
+                                                            uint64_t stride_words) {
+  const u32 i = blockIdx.x;
+  const uint64_t o = off[i], cnt = off[i + 1] - o;
+  const u32 *s = src + (size_t)i * stride_words;
+  for (uint64_t k = (uint64_t)blockIdx.y * 256 + threadIdx.x; k < cnt; k += (uint64_t)gridDim.y * 256) dst[o + k] = s[k];
+}
+
+template <typename T>
+static int grow_pinned(msim_ctx *ctx, T **buf, size_t *cap, size_t bytes) {
+  if (*buf && *cap >= bytes) return MSIM_OK;
+  if (*buf) { (void)hipHostFree(*buf); *buf = nullptr; *cap = 0; }
+  const size_t want = bytes + bytes / 8 + 4096;  // pinning is slow (pages are faulted in and locked): grow with slack, reuse
+  MSIM_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(buf), want));
+  *cap = want;
+  return MSIM_OK;
+}
+
+// one slab kind: compact on the device, then ONE device-to-host copy
+static int fetch_compacted(msim_ctx *ctx, const void *d_src, uint64_t stride_units, bool units16, const uint64_t *h_off, void *h_dst) {
+  const uint32_t n = ctx->n_inst;
+  const uint64_t total = h_off[n];
+  if (!total) return MSIM_OK;
+  const size_t unit = units16 ? 16 : 4, bytes = (size_t)total * unit;
+  if (ctx->cap_compact < bytes) {
+    if (ctx->d_compact) (void)hipFree(ctx->d_compact);
+    ctx->d_compact = nullptr; ctx->cap_compact = 0;
+    MSIM_HIP_TRY(ctx, hipMalloc(&ctx->d_compact, bytes + bytes / 8));
+    ctx->cap_compact = bytes + bytes / 8;
+  }
+  if (ctx->cap_off < (size_t)(n + 1) * 8) {
+    if (ctx->d_off) (void)hipFree(ctx->d_off);
+    ctx->d_off = nullptr; ctx->cap_off = 0;
+    MSIM_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_off), (size_t)(n + 1) * 8));
+    ctx->cap_off = (size_t)(n + 1) * 8;
+  }
+  MSIM_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_off, h_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  const uint64_t avg = total / n + 1;
+  const unsigned gy = (unsigned)((avg + 1023) / 1024 < 1 ? 1 : ((avg + 1023) / 1024 > 64 ? 64 : (avg + 1023) / 1024));
+  if (units16) hipLaunchKernelGGL(compact_kernel, dim3(n, gy), dim3(256), 0, ctx->stream, static_cast<const uint4 *>(d_src), static_cast<uint4 *>(ctx->d_compact), ctx->d_off, stride_units);
+  else hipLaunchKernelGGL(compact_words_kernel, dim3(n, gy), dim3(256), 0, ctx->stream, static_cast<const u32 *>(d_src), static_cast<u32 *>(ctx->d_compact), ctx->d_off, stride_units);
+  MSIM_HIP_TRY(ctx, hipGetLastError());
+  MSIM_HIP_TRY(ctx, hipMemcpyAsync(h_dst, ctx->d_compact, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  MSIM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // d_compact / h_off are reused by the next slab kind
+  return MSIM_OK;
+}
+
 extern "C" int msim_fetch(msim_ctx *ctx) {
   if (!ctx) return MSIM_E_INVALID;
   if (!ctx->ran) { ctx->err = "msim_fetch before msim_run"; return MSIM_E_RANGE; }
@@ -1026,15 +1087,17 @@ extern "C" int msim_fetch(msim_ctx *ctx) {
   MSIM_HIP_TRY(ctx, hipSetDevice(ctx->device));
   const msim_config &c = ctx->cfg;
   const uint32_t n = ctx->n_inst;
-  if (ctx->h_meta) { (void)hipHostFree(ctx->h_meta); ctx->h_meta = nullptr; }
-  if (ctx->h_stats) { (void)hipHostFree(ctx->h_stats); ctx->h_stats = nullptr; }
-  if (ctx->h_rows) { (void)hipHostFree(ctx->h_rows); ctx->h_rows = nullptr; }
-  if (ctx->h_payload) { (void)hipHostFree(ctx->h_payload); ctx->h_payload = nullptr; }
-  if (ctx->h_journal) { (void)hipHostFree(ctx->h_journal); ctx->h_journal = nullptr; }
+  int rc;
+  if (ctx->cap_h_meta < n) {  // meta + stats mirrors are sized by instance count
+    if (ctx->h_meta) { (void)hipHostFree(ctx->h_meta); ctx->h_meta = nullptr; }
+    if (ctx->h_stats) { (void)hipHostFree(ctx->h_stats); ctx->h_stats = nullptr; }
+    ctx->cap_h_meta = 0;
+    MSIM_HIP_TRY(ctx, hipHostMalloc(&ctx->h_meta, (size_t)n * sizeof(msim_inst_meta)));
+    MSIM_HIP_TRY(ctx, hipHostMalloc(&ctx->h_stats, (size_t)n * sizeof(msim_net_stats)));
+    ctx->cap_h_meta = n;
+  }
   delete[] ctx->h_row_off; delete[] ctx->h_pay_off; delete[] ctx->h_ev_off;
   ctx->h_row_off = new uint64_t[n + 1]; ctx->h_pay_off = new uint64_t[n + 1]; ctx->h_ev_off = new uint64_t[n + 1];
-  MSIM_HIP_TRY(ctx, hipHostMalloc(&ctx->h_meta, (size_t)n * sizeof(msim_inst_meta)));
-  MSIM_HIP_TRY(ctx, hipHostMalloc(&ctx->h_stats, (size_t)n * sizeof(msim_net_stats)));
   MSIM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   MSIM_HIP_TRY(ctx, hipMemcpy(ctx->h_meta, ctx->d_meta, (size_t)n * sizeof(msim_inst_meta), hipMemcpyDeviceToHost));
   MSIM_HIP_TRY(ctx, hipMemcpy(ctx->h_stats, ctx->d_stats, (size_t)n * sizeof(msim_net_stats), hipMemcpyDeviceToHost));
@@ -1045,21 +1108,13 @@ extern "C" int msim_fetch(msim_ctx *ctx) {
     eo += ctx->h_meta[i].n_events < c.journal_capacity ? ctx->h_meta[i].n_events : c.journal_capacity;
   }
   ctx->h_row_off[n] = ro; ctx->h_pay_off[n] = po; ctx->h_ev_off[n] = eo;
-  if (c.journal_capacity) MSIM_HIP_TRY(ctx, hipHostMalloc(&ctx->h_journal, (size_t)(eo + 1) * sizeof(msim_event)));
-  MSIM_HIP_TRY(ctx, hipHostMalloc(&ctx->h_rows, (size_t)(ro + 1) * sizeof(msim_op)));
-  MSIM_HIP_TRY(ctx, hipHostMalloc(&ctx->h_payload, (size_t)(po + 1) * 4));
-  // only the used prefix of every instance's slab crosses PCIe
-  for (uint32_t i = 0; i < n; i++) {
-    const msim_inst_meta &m = ctx->h_meta[i];
-    if (m.n_rows) MSIM_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_rows + ctx->h_row_off[i], ctx->d_rows + (size_t)i * c.max_rows,
-                                                 (size_t)m.n_rows * sizeof(msim_op), hipMemcpyDeviceToHost, ctx->stream));
-    if (m.n_payload_words) MSIM_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_payload + ctx->h_pay_off[i], ctx->d_payload + (size_t)i * c.max_payload_words,
-                                                          (size_t)m.n_payload_words * 4, hipMemcpyDeviceToHost, ctx->stream));
-    const uint64_t ne = ctx->h_ev_off[i + 1] - ctx->h_ev_off[i];
-    if (ne) MSIM_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_journal + ctx->h_ev_off[i], ctx->d_journal + (size_t)i * c.journal_capacity,
-                                           (size_t)ne * sizeof(msim_event), hipMemcpyDeviceToHost, ctx->stream));
-  }
-  MSIM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if ((rc = grow_pinned(ctx, &ctx->h_rows, &ctx->cap_h_rows, (size_t)(ro + 1) * sizeof(msim_op))) != MSIM_OK) return rc;
+  if ((rc = grow_pinned(ctx, &ctx->h_payload, &ctx->cap_h_payload, (size_t)(po + 1) * 4)) != MSIM_OK) return rc;
+  if (c.journal_capacity && (rc = grow_pinned(ctx, &ctx->h_journal, &ctx->cap_h_journal, (size_t)(eo + 1) * sizeof(msim_event))) != MSIM_OK) return rc;
+  // only the used prefix of every instance's slab crosses PCIe, as one copy per slab kind
+  if ((rc = fetch_compacted(ctx, ctx->d_rows, c.max_rows, true, ctx->h_row_off, ctx->h_rows)) != MSIM_OK) return rc;
+  if ((rc = fetch_compacted(ctx, ctx->d_payload, c.max_payload_words, false, ctx->h_pay_off, ctx->h_payload)) != MSIM_OK) return rc;
+  if (c.journal_capacity && (rc = fetch_compacted(ctx, ctx->d_journal, c.journal_capacity, true, ctx->h_ev_off, ctx->h_journal)) != MSIM_OK) return rc;
   ctx->fetched = true;
   return MSIM_OK;
 }

@@ -22,110 +22,115 @@
 #include <chrono>
 #include <cstring>
 #include <thread>
-#include <unordered_map>
 #include <vector>
 
 #include "engine_internal.h"
 
 namespace {
 
-struct Mop { uint8_t f; uint16_t key; uint8_t val; bool nil; std::vector<uint8_t> list; };
-struct Txn {
-  uint32_t process; int inv, cmp; uint8_t type;  // MSIM_T_OK / FAIL / INFO
-  std::vector<Mop> mops;
-};
+// All working storage of one checker thread: flat arenas that are cleared, not freed, between histories (256 threads
+// allocating and unmapping per-history vectors serialise on the kernel's address-space lock).
+struct Mop { uint8_t f; uint8_t val; uint8_t nil; uint8_t len; uint16_t key; uint32_t off; };  // list = bytes[off, off+len)
+struct Txn { uint32_t process; int inv, cmp; uint8_t type; uint32_t mop0, n_mops, rt0, n_rt; };
 enum { E_WW = 1, E_WR = 2, E_RW = 4, E_RT = 8 };
-struct Edge { uint32_t to; uint8_t kind; };
+struct Edge { uint32_t from, to; uint8_t kind; };
 
-void parse_txn(const uint32_t *w, uint32_t n, std::vector<Mop> &out) {
+struct Scratch {
+  std::vector<Txn> txns; std::vector<Mop> mops; std::vector<uint8_t> bytes; std::vector<uint32_t> rt, frontier, nf;
+  std::vector<int> open;        // process -> txn
+  std::vector<int> writer;      // (key << 8 | element) -> txn
+  std::vector<int> longest;     // key -> mop index of the longest read
+  std::vector<Edge> edges; std::vector<uint32_t> adj_off; std::vector<Edge> adj;
+  std::vector<int> idx, low, comp; std::vector<char> on, seen; std::vector<uint32_t> st, work, pos, q;
+};
+
+void parse_txn(Scratch &S, const uint32_t *w, uint32_t n) {
   for (uint32_t i = 0; i < n;) {
     const uint32_t h = w[i++];
-    Mop m; m.f = h & 1; m.key = (h >> 1) & 0x7FFF; m.val = 0; m.nil = false;
+    Mop m; m.f = h & 1; m.key = (h >> 1) & 0x7FFF; m.val = 0; m.nil = 0; m.len = 0; m.off = (uint32_t)S.bytes.size();
     const uint32_t x = (h >> 16) & 0xFF;
     if (m.f) m.val = (uint8_t)x;
-    else if (x == 0xFF) m.nil = true;
-    else { for (uint32_t e = 0; e < x && i + e / 4 < n; e++) m.list.push_back((uint8_t)(w[i + e / 4] >> (8 * (e % 4)))); i += (x + 3) / 4; }
-    out.push_back(std::move(m));
+    else if (x == 0xFF) m.nil = 1;
+    else {
+      for (uint32_t e = 0; e < x && i + e / 4 < n; e++) S.bytes.push_back((uint8_t)(w[i + e / 4] >> (8 * (e % 4))));
+      m.len = (uint8_t)(S.bytes.size() - m.off);
+      i += (x + 3) / 4;
+    }
+    S.mops.push_back(m);
   }
 }
 
-// strongly connected components (iterative Tarjan) over the edges whose kind is in `mask`; comp[v] = component id,
+// strongly connected components (iterative Tarjan) over the CSR edges whose kind is in `mask`; comp[v] = component id,
 // returns the number of vertices that sit in a component of size > 1
-uint32_t scc(const std::vector<std::vector<Edge>> &g, uint8_t mask, std::vector<int> &comp) {
-  const uint32_t n = (uint32_t)g.size();
-  std::vector<int> idx(n, -1), low(n, 0); std::vector<char> on(n, 0);
-  std::vector<uint32_t> st, work, pos;
-  comp.assign(n, -1);
+uint32_t scc(Scratch &S, uint32_t n, uint8_t mask) {
+  S.idx.assign(n, -1); S.low.assign(n, 0); S.on.assign(n, 0); S.comp.assign(n, -1);
+  S.st.clear(); S.work.clear(); S.pos.clear();
   int counter = 0, ncomp = 0; uint32_t in_cycles = 0;
   for (uint32_t r = 0; r < n; r++) {
-    if (idx[r] != -1) continue;
-    work.push_back(r); pos.push_back(0);
-    while (!work.empty()) {
-      const uint32_t v = work.back();
-      if (pos.back() == 0) { idx[v] = low[v] = counter++; st.push_back(v); on[v] = 1; }
+    if (S.idx[r] != -1) continue;
+    S.work.push_back(r); S.pos.push_back(S.adj_off[r]);
+    while (!S.work.empty()) {
+      const uint32_t v = S.work.back();
+      if (S.pos.back() == S.adj_off[v] && S.idx[v] == -1) { S.idx[v] = S.low[v] = counter++; S.st.push_back(v); S.on[v] = 1; }
       bool descended = false;
-      while (pos.back() < g[v].size()) {
-        const Edge e = g[v][pos.back()++];
+      while (S.pos.back() < S.adj_off[v + 1]) {
+        const Edge e = S.adj[S.pos.back()++];
         if (!(e.kind & mask)) continue;
-        if (idx[e.to] == -1) { work.push_back(e.to); pos.push_back(0); descended = true; break; }
-        if (on[e.to]) low[v] = std::min(low[v], idx[e.to]);
+        if (S.idx[e.to] == -1) { S.work.push_back(e.to); S.pos.push_back(S.adj_off[e.to]); descended = true; break; }
+        if (S.on[e.to]) S.low[v] = std::min(S.low[v], S.idx[e.to]);
       }
       if (descended) continue;
-      if (low[v] == idx[v]) {
+      if (S.low[v] == S.idx[v]) {
         uint32_t size = 0, w;
-        do { w = st.back(); st.pop_back(); on[w] = 0; comp[w] = ncomp; size++; } while (w != v);
+        do { w = S.st.back(); S.st.pop_back(); S.on[w] = 0; S.comp[w] = ncomp; size++; } while (w != v);
         if (size > 1) in_cycles += size;
         ncomp++;
       }
-      work.pop_back(); pos.pop_back();
-      if (!work.empty()) low[work.back()] = std::min(low[work.back()], low[v]);
+      S.work.pop_back(); S.pos.pop_back();
+      if (!S.work.empty()) S.low[S.work.back()] = std::min(S.low[S.work.back()], S.low[v]);
     }
   }
   return in_cycles;
 }
 
-// is `dst` reachable from `src` over edges of `mask`, staying inside component `c` of `comp`?
-bool reach(const std::vector<std::vector<Edge>> &g, uint8_t mask, const std::vector<int> &comp, uint32_t src, uint32_t dst) {
+// is `dst` reachable from `src` over edges of `mask`, staying inside the component of `src`?
+bool reach(Scratch &S, uint32_t n, uint8_t mask, uint32_t src, uint32_t dst) {
   if (src == dst) return true;
-  std::vector<char> seen(g.size(), 0); std::vector<uint32_t> q{src}; seen[src] = 1;
-  while (!q.empty()) {
-    const uint32_t v = q.back(); q.pop_back();
-    for (const Edge &e : g[v]) {
-      if (!(e.kind & mask) || comp[e.to] != comp[src] || seen[e.to]) continue;
+  S.seen.assign(n, 0); S.q.clear(); S.q.push_back(src); S.seen[src] = 1;
+  while (!S.q.empty()) {
+    const uint32_t v = S.q.back(); S.q.pop_back();
+    for (uint32_t k = S.adj_off[v]; k < S.adj_off[v + 1]; k++) {
+      const Edge &e = S.adj[k];
+      if (!(e.kind & mask) || S.comp[e.to] != S.comp[src] || S.seen[e.to]) continue;
       if (e.to == dst) return true;
-      seen[e.to] = 1; q.push_back(e.to);
+      S.seen[e.to] = 1; S.q.push_back(e.to);
     }
   }
   return false;
 }
 
-// classify the cycles of the graph restricted to `dep_mask` (+ E_RT when rt): returns anomaly bits
-uint32_t classify(const std::vector<std::vector<Edge>> &g, bool rt, uint32_t *in_cycles) {
+// classify the cycles of the dependency graph (+ realtime edges when rt): returns anomaly bits
+uint32_t classify(Scratch &S, uint32_t n, bool rt, uint32_t *in_cycles) {
   const uint8_t x = rt ? E_RT : 0;
-  std::vector<int> comp;
   uint32_t bits = 0;
-  if (scc(g, E_WW | x, comp)) bits |= MSIM_ANOMALY_G0;
-  if (scc(g, E_WW | E_WR | x, comp) && !bits) bits |= MSIM_ANOMALY_G1C;
-  const uint32_t cyc = scc(g, E_WW | E_WR | E_RW | x, comp);
+  if (scc(S, n, E_WW | x)) bits |= MSIM_ANOMALY_G0;
+  if (scc(S, n, E_WW | E_WR | x) && !bits) bits |= MSIM_ANOMALY_G1C;
+  const uint32_t cyc = scc(S, n, E_WW | E_WR | E_RW | x);
   if (in_cycles) *in_cycles = cyc;
   if (cyc && !bits) {
     // a cycle with exactly one anti-dependency: some rw edge u->v inside a component with v ~> u over ww/wr(/rt)
     bool single = false;
-    for (uint32_t u = 0; u < g.size() && !single; u++)
-      for (const Edge &e : g[u])
-        if ((e.kind & E_RW) && comp[u] == comp[e.to] && u != e.to && reach(g, E_WW | E_WR | x, comp, e.to, u)) { single = true; break; }
+    for (const Edge &e : S.adj)
+      if ((e.kind & E_RW) && S.comp[e.from] == S.comp[e.to] && e.from != e.to && reach(S, n, E_WW | E_WR | x, e.to, e.from)) { single = true; break; }
     bits |= single ? MSIM_ANOMALY_G_SINGLE : MSIM_ANOMALY_G2;
   }
   return bits;
 }
 
-void check_history(const msim_op *rows, uint32_t n_rows, const uint32_t *payload, uint32_t n_words, uint32_t flags, msim_check_result *out) {
+void check_history(Scratch &S, const msim_op *rows, uint32_t n_rows, const uint32_t *payload, uint32_t n_words, uint32_t flags, msim_check_result *out) {
   std::memset(out, 0, sizeof *out);
-  std::vector<Txn> txns;
-  std::unordered_map<uint32_t, uint32_t> open;  // process -> txn index
-  std::vector<std::vector<uint32_t>> rt_in;     // realtime predecessors (the frontier at invocation)
-  std::vector<uint32_t> frontier;
-  uint32_t anomalies = 0;
+  S.txns.clear(); S.mops.clear(); S.bytes.clear(); S.rt.clear(); S.frontier.clear(); S.open.clear(); S.edges.clear();
+  uint32_t anomalies = 0, max_key = 0;
 
   for (uint32_t i = 0; i < n_rows; i++) {
     const msim_op &r = rows[i];
@@ -133,125 +138,149 @@ void check_history(const msim_op *rows, uint32_t n_rows, const uint32_t *payload
     if (proc == MSIM_PROCESS_NEMESIS || MSIM_OP_F(r) != MSIM_F_TXN) continue;
     const uint32_t off = r.value, len = MSIM_OP_LEN(r);
     if ((uint64_t)off + len > n_words) { anomalies |= MSIM_ANOMALY_INTERNAL; continue; }
+    if (proc >= S.open.size()) S.open.resize(proc + 64, -1);
     if (type == MSIM_T_INVOKE) {
       out->op_count++;
       Txn t; t.process = proc; t.inv = (int)i; t.cmp = -1; t.type = MSIM_T_INFO;  // never completed = indeterminate
-      parse_txn(payload + off, len, t.mops);
-      open[proc] = (uint32_t)txns.size();
-      txns.push_back(std::move(t));
-      rt_in.push_back(frontier);
+      t.mop0 = (uint32_t)S.mops.size();
+      parse_txn(S, payload + off, len);
+      t.n_mops = (uint32_t)S.mops.size() - t.mop0;
+      t.rt0 = (uint32_t)S.rt.size(); t.n_rt = (uint32_t)S.frontier.size();   // realtime predecessors = the frontier now
+      S.rt.insert(S.rt.end(), S.frontier.begin(), S.frontier.end());
+      S.open[proc] = (int)S.txns.size();
+      S.txns.push_back(t);
     } else {
-      auto it = open.find(proc);
-      if (it == open.end()) continue;
-      const uint32_t id = it->second; open.erase(it);
-      Txn &t = txns[id];
+      const int id = S.open[proc];
+      if (id < 0) continue;
+      S.open[proc] = -1;
+      Txn &t = S.txns[(size_t)id];
       t.cmp = (int)i; t.type = (uint8_t)type;
       if (type == MSIM_T_OK) {
         out->ok_count++;
-        t.mops.clear(); parse_txn(payload + off, len, t.mops);
+        t.mop0 = (uint32_t)S.mops.size();
+        parse_txn(S, payload + off, len);   // the completed form replaces the requested one (the old mops stay unused)
+        t.n_mops = (uint32_t)S.mops.size() - t.mop0;
         // frontier := (frontier - predecessors of t) + t  (transitive reduction of the realtime order)
-        std::vector<uint32_t> nf;
-        for (uint32_t f : frontier) if (std::find(rt_in[id].begin(), rt_in[id].end(), f) == rt_in[id].end()) nf.push_back(f);
-        nf.push_back(id);
-        frontier.swap(nf);
+        S.nf.clear();
+        const uint32_t *pb = S.rt.data() + t.rt0, *pe = pb + t.n_rt;
+        for (uint32_t f : S.frontier) if (std::find(pb, pe, f) == pe) S.nf.push_back(f);
+        S.nf.push_back((uint32_t)id);
+        S.frontier.swap(S.nf);
       } else if (type == MSIM_T_FAIL) out->fail_count++;
       else out->info_count++;
     }
   }
-  const uint32_t n = (uint32_t)txns.size();
+  const uint32_t n = (uint32_t)S.txns.size();
   out->attempt_count = n; out->stable_count = out->ok_count;
+  for (const Txn &t : S.txns) for (uint32_t k = 0; k < t.n_mops; k++) max_key = std::max<uint32_t>(max_key, S.mops[t.mop0 + k].key);
 
-  // writers: (key, element) -> transaction; last append of each transaction per key (for G1b)
+  // writers: (key, element) -> transaction
   auto kv = [](uint32_t k, uint32_t v) { return (k << 8) | v; };
-  std::unordered_map<uint32_t, uint32_t> writer, final_of;  // final_of[(txn<<15 | key)] = last element that txn appended to key
+  S.writer.assign((size_t)(max_key + 1) << 8, -1);
   for (uint32_t t = 0; t < n; t++)
-    for (const Mop &m : txns[t].mops) if (m.f) {
-      if (writer.count(kv(m.key, m.val))) anomalies |= MSIM_ANOMALY_DUPLICATE_ELEMENTS;  // the generator never repeats (k, v)
-      writer[kv(m.key, m.val)] = t;
-      final_of[(t << 15) | m.key] = m.val;
+    for (uint32_t k = 0; k < S.txns[t].n_mops; k++) {
+      const Mop &m = S.mops[S.txns[t].mop0 + k];
+      if (!m.f) continue;
+      if (S.writer[kv(m.key, m.val)] >= 0) anomalies |= MSIM_ANOMALY_DUPLICATE_ELEMENTS;  // the generator never repeats (k, v)
+      S.writer[kv(m.key, m.val)] = (int)t;
     }
+  // last element transaction t appended to key (for G1b)
+  auto final_of = [&](uint32_t t, uint32_t key) -> int {
+    const Txn &x = S.txns[t]; int v = -1;
+    for (uint32_t k = 0; k < x.n_mops; k++) { const Mop &m = S.mops[x.mop0 + k]; if (m.f && m.key == key) v = m.val; }
+    return v;
+  };
+  auto is_own = [&](uint32_t t, uint32_t key, uint8_t el) { const int w = S.writer[kv(key, el)]; return w >= 0 && (uint32_t)w == t; };
 
   // per-transaction checks + longest read per key
-  std::unordered_map<uint32_t, const std::vector<uint8_t> *> longest;
+  S.longest.assign(max_key + 1, -1);
   for (uint32_t t = 0; t < n; t++) {
-    const Txn &x = txns[t];
+    const Txn &x = S.txns[t];
     if (x.type != MSIM_T_OK) continue;
-    std::unordered_map<uint32_t, std::vector<uint8_t>> known;   // what this txn must see for a key from its own earlier mops
-    std::unordered_map<uint32_t, std::vector<uint8_t>> own;     // own appends so far (key never read yet)
-    for (const Mop &m : x.mops) {
-      if (m.f) {
-        auto k = known.find(m.key);
-        if (k != known.end()) k->second.push_back(m.val); else own[m.key].push_back(m.val);
-        continue;
+    for (uint32_t k = 0; k < x.n_mops; k++) {
+      const Mop &m = S.mops[x.mop0 + k];
+      if (m.f) continue;
+      const uint8_t *l = S.bytes.data() + m.off; const uint32_t len = m.len;
+      // duplicates (lists are <= 63 long)
+      for (uint32_t a = 0; a < len; a++) for (uint32_t b2 = a + 1; b2 < len; b2++) if (l[a] == l[b2]) anomalies |= MSIM_ANOMALY_DUPLICATE_ELEMENTS;
+      // internal consistency: what the transaction's own earlier micro-ops imply for this read
+      {
+        int prev = -1;  // the latest earlier read of this key
+        for (uint32_t e = 0; e < k; e++) { const Mop &p = S.mops[x.mop0 + e]; if (!p.f && p.key == m.key) prev = (int)e; }
+        uint32_t n_app = 0; uint8_t apps[8];
+        for (uint32_t e = prev < 0 ? 0 : (uint32_t)prev + 1; e < k; e++) { const Mop &p = S.mops[x.mop0 + e]; if (p.f && p.key == m.key && n_app < 8) apps[n_app++] = p.val; }
+        bool ok = true;
+        if (prev >= 0) {  // must equal the earlier read followed by the appends since
+          const Mop &p = S.mops[x.mop0 + (uint32_t)prev];
+          ok = len == (uint32_t)p.len + n_app && std::equal(l, l + p.len, S.bytes.data() + p.off) && std::equal(apps, apps + n_app, l + p.len);
+        } else ok = len >= n_app && std::equal(apps, apps + n_app, l + (len - n_app));  // must end with the own appends
+        if (!ok) anomalies |= MSIM_ANOMALY_INTERNAL;
       }
-      const std::vector<uint8_t> &l = m.list;
-      // duplicates
-      { std::vector<uint8_t> s = l; std::sort(s.begin(), s.end()); if (std::adjacent_find(s.begin(), s.end()) != s.end()) anomalies |= MSIM_ANOMALY_DUPLICATE_ELEMENTS; }
-      // internal consistency
-      auto k = known.find(m.key);
-      if (k != known.end()) { if (k->second != l) anomalies |= MSIM_ANOMALY_INTERNAL; }
-      else {
-        const std::vector<uint8_t> &o = own[m.key];
-        if (o.size() > l.size() || !std::equal(o.begin(), o.end(), l.end() - (long)o.size())) anomalies |= MSIM_ANOMALY_INTERNAL;
-      }
-      known[m.key] = l;
       // the externally visible part of the read: without the transaction's own appends at the tail
-      size_t ext = l.size();
-      while (ext > 0) { auto w = writer.find(kv(m.key, l[ext - 1])); if (w != writer.end() && w->second == t) ext--; else break; }
-      for (size_t e = 0; e < ext; e++) {
-        auto w = writer.find(kv(m.key, l[e]));
-        if (w == writer.end()) { anomalies |= MSIM_ANOMALY_G1A; continue; }         // an element nobody appended (garbage read)
-        if (txns[w->second].type == MSIM_T_FAIL) anomalies |= MSIM_ANOMALY_G1A;     // aborted read
+      uint32_t ext = len;
+      while (ext > 0 && is_own(t, m.key, l[ext - 1])) ext--;
+      for (uint32_t e = 0; e < ext; e++) {
+        const int w = S.writer[kv(m.key, l[e])];
+        if (w < 0) { anomalies |= MSIM_ANOMALY_G1A; continue; }                         // an element nobody appended (garbage read)
+        if (S.txns[(size_t)w].type == MSIM_T_FAIL) anomalies |= MSIM_ANOMALY_G1A;       // aborted read
       }
       if (ext > 0) {
-        auto w = writer.find(kv(m.key, l[ext - 1]));
-        if (w != writer.end() && w->second != t && final_of[(w->second << 15) | m.key] != l[ext - 1]) anomalies |= MSIM_ANOMALY_G1B;
+        const int w = S.writer[kv(m.key, l[ext - 1])];
+        if (w >= 0 && (uint32_t)w != t && final_of((uint32_t)w, m.key) != (int)l[ext - 1]) anomalies |= MSIM_ANOMALY_G1B;
       }
-      auto lg = longest.find(m.key);
-      if (lg == longest.end() || lg->second->size() < l.size()) longest[m.key] = &l;
+      const int lg = S.longest[m.key];
+      if (lg < 0 || S.mops[(size_t)lg].len < len) S.longest[m.key] = (int)(x.mop0 + k);
     }
   }
 
   // version orders, prefix property, dependency edges
-  std::vector<std::vector<Edge>> g(n);
-  uint32_t n_edges = 0;
-  auto add = [&](uint32_t a, uint32_t b, uint8_t kind) { if (a != b) { g[a].push_back(Edge{b, kind}); n_edges++; } };
-  std::unordered_map<uint32_t, uint32_t> pos;  // (key, element) -> index in the key's version order
-  for (auto &kvp : longest) {
-    const uint32_t key = kvp.first; const std::vector<uint8_t> &ord = *kvp.second;
-    for (size_t i = 0; i < ord.size(); i++) pos[kv(key, ord[i])] = (uint32_t)i;
-    for (size_t i = 0; i + 1 < ord.size(); i++) {
-      auto a = writer.find(kv(key, ord[i])), b = writer.find(kv(key, ord[i + 1]));
-      if (a == writer.end() || b == writer.end()) continue;
-      if (txns[a->second].type == MSIM_T_FAIL && txns[b->second].type != MSIM_T_FAIL) anomalies |= MSIM_ANOMALY_DIRTY_UPDATE;
-      if (txns[a->second].type != MSIM_T_FAIL && txns[b->second].type != MSIM_T_FAIL) add(a->second, b->second, E_WW);
+  auto add = [&](uint32_t a, uint32_t b2, uint8_t kind) { if (a != b2) S.edges.push_back(Edge{a, b2, kind}); };
+  for (uint32_t key = 0; key <= max_key; key++) {
+    if (S.longest[key] < 0) continue;
+    const Mop &lm = S.mops[(size_t)S.longest[key]];
+    const uint8_t *ord = S.bytes.data() + lm.off;
+    for (uint32_t i = 0; i + 1 < lm.len; i++) {
+      const int a = S.writer[kv(key, ord[i])], b2 = S.writer[kv(key, ord[i + 1])];
+      if (a < 0 || b2 < 0) continue;
+      const bool fa = S.txns[(size_t)a].type == MSIM_T_FAIL, fb = S.txns[(size_t)b2].type == MSIM_T_FAIL;
+      if (fa && !fb) anomalies |= MSIM_ANOMALY_DIRTY_UPDATE;
+      if (!fa && !fb) add((uint32_t)a, (uint32_t)b2, E_WW);
     }
   }
   for (uint32_t t = 0; t < n; t++) {
-    const Txn &x = txns[t];
+    const Txn &x = S.txns[t];
     if (x.type != MSIM_T_OK) continue;
-    for (const Mop &m : x.mops) {
-      if (m.f) continue;
-      auto lg = longest.find(m.key);
-      if (lg == longest.end()) continue;
-      const std::vector<uint8_t> &ord = *lg->second, &l = m.list;
-      if (l.size() > ord.size() || !std::equal(l.begin(), l.end(), ord.begin())) { anomalies |= MSIM_ANOMALY_INCOMPATIBLE_ORDER; continue; }
-      size_t ext = l.size();
-      while (ext > 0) { auto w = writer.find(kv(m.key, l[ext - 1])); if (w != writer.end() && w->second == t) ext--; else break; }
-      if (ext > 0) { auto w = writer.find(kv(m.key, l[ext - 1])); if (w != writer.end() && txns[w->second].type != MSIM_T_FAIL) add(w->second, t, E_WR); }
-      // anti-dependency: the next version after the one read (skipping this transaction's own appends)
-      size_t nx = l.size();
-      if (nx < ord.size()) { auto w = writer.find(kv(m.key, ord[nx])); if (w != writer.end() && txns[w->second].type != MSIM_T_FAIL) add(t, w->second, E_RW); }
+    for (uint32_t k = 0; k < x.n_mops; k++) {
+      const Mop &m = S.mops[x.mop0 + k];
+      if (m.f || S.longest[m.key] < 0) continue;
+      const Mop &lm = S.mops[(size_t)S.longest[m.key]];
+      const uint8_t *ord = S.bytes.data() + lm.off, *l = S.bytes.data() + m.off;
+      if (m.len > lm.len || !std::equal(l, l + m.len, ord)) { anomalies |= MSIM_ANOMALY_INCOMPATIBLE_ORDER; continue; }
+      uint32_t ext = m.len;
+      while (ext > 0 && is_own(t, m.key, l[ext - 1])) ext--;
+      if (ext > 0) { const int w = S.writer[kv(m.key, l[ext - 1])]; if (w >= 0 && S.txns[(size_t)w].type != MSIM_T_FAIL) add((uint32_t)w, t, E_WR); }
+      // anti-dependency: the next version after the one read
+      if (m.len < lm.len) { const int w = S.writer[kv(m.key, ord[m.len])]; if (w >= 0 && S.txns[(size_t)w].type != MSIM_T_FAIL) add(t, (uint32_t)w, E_RW); }
     }
   }
-  for (uint32_t t = 0; t < n; t++) if (txns[t].type != MSIM_T_FAIL) for (uint32_t f : rt_in[t]) add(f, t, E_RT);
+  for (uint32_t t = 0; t < n; t++) if (S.txns[t].type != MSIM_T_FAIL) for (uint32_t k = 0; k < S.txns[t].n_rt; k++) add(S.rt[S.txns[t].rt0 + k], t, E_RT);
 
-  uint32_t cyc = 0;
-  uint32_t dep = classify(g, false, &cyc);
-  if (!dep) { const uint32_t with_rt = classify(g, true, &cyc); if (with_rt) dep = with_rt | MSIM_ANOMALY_REALTIME; }
-  anomalies |= dep;
+  // CSR adjacency
+  S.adj_off.assign(n + 1, 0);
+  for (const Edge &e : S.edges) S.adj_off[e.from + 1]++;
+  for (uint32_t v = 0; v < n; v++) S.adj_off[v + 1] += S.adj_off[v];
+  S.adj.resize(S.edges.size());
+  S.pos.assign(S.adj_off.begin(), S.adj_off.end() - 1);
+  for (const Edge &e : S.edges) S.adj[S.pos[e.from]++] = e;
 
-  out->lost_count = n_edges; out->stale_count = cyc; out->error_count = anomalies;
+  uint32_t cyc = scc(S, n, E_WW | E_WR | E_RW | E_RT);  // acyclic over every edge kind (the common case): nothing to classify
+  if (cyc) {
+    uint32_t dep = classify(S, n, false, &cyc);
+    if (!dep) { const uint32_t with_rt = classify(S, n, true, &cyc); if (with_rt) dep = with_rt | MSIM_ANOMALY_REALTIME; }
+    anomalies |= dep;
+  }
+
+  out->lost_count = (uint32_t)S.edges.size(); out->stale_count = cyc; out->error_count = anomalies;
   out->valid = flags ? 0u : anomalies ? 0u : (out->ok_count == 0 ? 2u : 1u);
 }
 
@@ -259,7 +288,8 @@ void check_history(const msim_op *rows, uint32_t n_rows, const uint32_t *payload
 
 extern "C" int msim_check_txn_rows(const msim_op *rows, uint32_t n_rows, const uint32_t *payload, uint32_t n_words, msim_check_result *out) {
   if (!rows || !out || (!payload && n_words)) return MSIM_E_INVALID;
-  check_history(rows, n_rows, payload, n_words, 0, out);
+  Scratch S;
+  check_history(S, rows, n_rows, payload, n_words, 0, out);
   return MSIM_OK;
 }
 
@@ -276,8 +306,9 @@ int msim_check_txn_host(msim_ctx *ctx) {
   std::vector<std::thread> th;
   for (unsigned t = 0; t < nt; t++)
     th.emplace_back([ctx, n, nt, t]() {
+      Scratch S;
       for (uint32_t i = t; i < n; i += nt)
-        check_history(ctx->h_rows + ctx->h_row_off[i], ctx->h_meta[i].n_rows, ctx->h_payload + ctx->h_pay_off[i],
+        check_history(S, ctx->h_rows + ctx->h_row_off[i], ctx->h_meta[i].n_rows, ctx->h_payload + ctx->h_pay_off[i],
                       ctx->h_meta[i].n_payload_words, ctx->h_meta[i].flags, &ctx->h_check[i]);
     });
   for (auto &x : th) x.join();
