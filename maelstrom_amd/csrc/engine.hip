@@ -124,6 +124,10 @@ __device__ __forceinline__ u32 scan32(u32 v) {
   return v;
 }
 // value of `v` in lane `l` (per-lane l; every lane must execute this: ds_bpermute_b32)
+// tells the compiler a value is dead here (freeze of undef): a register that is only meaningful inside a round must not
+// be carried around the round loops as a PHI
+__device__ __forceinline__ void forget(u32 &v) { v = __builtin_nondeterministic_value(v); }
+__device__ __forceinline__ void forget(uint4 &v) { forget(v.x); forget(v.y); forget(v.z); forget(v.w); }
 __device__ __forceinline__ u32 lane_get(u32 v, u32 l) { return (u32)__builtin_amdgcn_ds_bpermute((int)(l << 2), (int)v); }
 
 // Reference (shuffle) versions, used only by the self-test to validate the DPP encodings on hardware.
@@ -964,6 +968,10 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
 
   if (blocking) MSIM_HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
   hipError_t e;
+#ifdef MSIM_ISA_PROBE  // developer hook (tools/isa_probe.sh): instantiate only the headline kernel so its ISA compiles in seconds
+  hipLaunchKernelGGL((sim_kernel_colo<MSIM_NODE_BCAST_FF, false, false, false>), dim3(n), dim3(64), lds, st, kp);
+  e = hipGetLastError();
+#else
   switch (c.node_program) {
     case MSIM_NODE_ECHO: e = launch<MSIM_NODE_ECHO>(kp, n, lds, st); break;
     case MSIM_NODE_BCAST_FF: e = launch<MSIM_NODE_BCAST_FF>(kp, n, lds, st); break;
@@ -994,6 +1002,7 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
     } break;
     default: ctx->err = "node program not built into this engine"; return MSIM_E_UNSUPPORTED;
   }
+#endif
   if (e != hipSuccess) { ctx->err = std::string("kernel launch: ") + hipGetErrorString(e); return MSIM_E_HIP; }
   ctx->n_inst = n; ctx->first_instance = first;
   ctx->fetched = false; ctx->checked = false; ctx->check_fetched = false; ctx->ran = true;

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun): rocprofv3 kernel trace + separate PMC passes for the headline bench, summarised by
+# tools/rocpd_summary.py.  Usage: tools/profile_headline.sh <tag>   -> gpurun_out/<tag>/{trace,pmc_*} + summary.txt
+set -u
+TAG=${1:-prof}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+CMD="python $ROOT/bench.py --steps 3 --warmup 3 --cpu-sample 0 --no-gather"
+rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o t -- $CMD > "$OUT/trace.log" 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_WAVES -d "$OUT/pmc_sq" -o s -- $CMD > "$OUT/pmc_sq.log" 2>&1
+if [ "${2:-}" = "full" ]; then
+  rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o f -- $CMD > "$OUT/pmc_fetch.log" 2>&1
+  rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_write" -o w -- $CMD > "$OUT/pmc_write.log" 2>&1
+  rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU -d "$OUT/pmc_cyc" -o c -- $CMD > "$OUT/pmc_cyc.log" 2>&1
+fi
+python $ROOT/tools/rocpd_summary.py $(find "$OUT" -name "*_results.db" | sort) > "$OUT/summary.txt" 2>&1
+tail -40 "$OUT/summary.txt"
