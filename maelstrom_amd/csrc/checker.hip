@@ -14,8 +14,19 @@
 //   :valid? = false if any lost, :unknown if nothing stable, else true
 //   :stable-latencies = points {0 .5 .95 .99 1} -> sorted[min(n-1, floor(n*q))]
 //
-// One wavefront checks one history: rows are read back from HBM 64 at a time (1 KiB, coalesced) and
-// walked with v_readlane; lanes = elements (strided), per-element state in LDS owned by lane e%64.
+// One wavefront checks one history, bit-parallel over the read bitmaps:
+//   pass 1  rows are read back from HBM 64 at a time (1 KiB, coalesced); every lane classifies its own row; only read /
+//           echo rows are walked serially (v_readlane), and a read :ok only RECORDS itself: once in completion order
+//           {payload ref, :ok index} and once at the rank of its invocation {payload ref, invoke index, elements
+//           existing at completion} (8 B each, HBM scratch).
+//   pass 2a completion order, lane w = word w of the bitmap: elements whose first containing read this is
+//           (word & not-yet-seen) get known = min(known, :ok index).  One AND per lane and read; a bit loop runs once
+//           per element in total.
+//   pass 2b invocation order, latest first: the first read that contains an element is its last-present, the first one
+//           that lacks it (while it exists) its last-absent — again one AND per lane and read plus one bit loop per
+//           element.  Reads are prefetched 64 records at a time, the bitmap word of the next read while the current one
+//           is folded in.
+// Per-element state: three u16 row indices in LDS (8.4 KB for 1408 elements keeps 4096 histories resident).
 #include <hip/hip_runtime.h>
 
 #include "engine_internal.h"
@@ -28,7 +39,8 @@ struct CParams {
   const u32 *payload;
   const msim_inst_meta *meta;
   msim_check_result *out;
-  u32 max_rows, max_pay, max_values, C, workload;
+  uint2 *recs;  // per instance: rec_c[max_reads] then rec_i[max_reads]
+  u32 max_rows, max_pay, max_values, C, workload, max_reads;
 };
 
 __device__ __forceinline__ u32 c_rdlane(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
@@ -39,31 +51,34 @@ __device__ __forceinline__ u32 c_wave_sum(u32 v) {
 
 __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char csmem[];
-  // per-element row indices as u16 (max_rows < 65535): 6 B per element keeps every history of a 4096-batch resident
   typedef unsigned short u16;
   u16 *const known = reinterpret_cast<u16 *>(csmem);
   u16 *const lp_idx = known + p.max_values;
   u16 *const la_idx = lp_idx + p.max_values;
   u32 *const lat = reinterpret_cast<u32 *>(csmem);  // reused after the walk: stable latency per element (needs 4 B each)
+  u32 *const valid = reinterpret_cast<u32 *>(csmem + (size_t)p.max_values * 6);  // bitmap over invocation ranks: read completed :ok
 
   const u32 lane = threadIdx.x, inst = blockIdx.x;
   const msim_inst_meta meta = p.meta[inst];
   const uint4 *const rows = reinterpret_cast<const uint4 *>(p.rows + (size_t)inst * p.max_rows);
   const u32 *const pay = p.payload + (size_t)inst * p.max_pay;
+  uint2 *const rec_c = p.recs + (size_t)inst * p.max_reads * 2, *const rec_i = rec_c + p.max_reads;
   const u32 n_rows = meta.n_rows, C = p.C;
   const bool setfull = p.workload != MSIM_WL_ECHO;
 
   for (u32 i = lane; i < p.max_values; i += 64) { known[i] = NONE; lp_idx[i] = NONE; la_idx[i] = NONE; }
+  for (u32 i = lane; i < (p.max_reads + 31) / 32; i += 64) valid[i] = 0;
+  __syncthreads();
 
   // worker thread t lives in lane t % 64, slot t / 64 (up to 128 workers): its pending invoke (reads / echo)
-  u32 my_inv = NONE, my_inv1 = NONE, my_val = 0, my_val1 = 0;
-  u32 v_cur = 0, op_count = 0, n_ok = 0, n_fail = 0, n_info = 0, errors = 0;
+  u32 my_inv = NONE, my_inv1 = NONE, my_val = 0, my_val1 = 0, my_rank = 0, my_rank1 = 0;
+  u32 v_cur = 0, op_count = 0, n_ok = 0, n_fail = 0, n_info = 0, errors = 0, n_ri = 0, n_rc = 0;
 
+  // ---- pass 1 ----
   for (u32 base = 0; base < n_rows; base += 64) {
     const u32 cnt = min(64u, n_rows - base);
     uint4 r = make_uint4(0, 0, 0, 0);
     if (lane < cnt) r = rows[base + lane];
-    // every lane classifies its own row; only rows that need ordered handling are walked serially
     const u32 my_type = r.z & 3, my_f = (r.z >> 2) & 31, my_proc = r.z >> 12;
     const bool live = lane < cnt && my_proc != MSIM_PROCESS_NEMESIS;  // (r/filter (comp number? :process))
     const bool add_like = my_f == MSIM_F_ADD || my_f == MSIM_F_BROADCAST;
@@ -71,8 +86,8 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
     n_ok += (u32)__popcll(__ballot(live && my_type == MSIM_T_OK));
     n_fail += (u32)__popcll(__ballot(live && my_type == MSIM_T_FAIL));
     n_info += (u32)__popcll(__ballot(live && my_type == MSIM_T_INFO));
-    // add :ok -> known (first of add-ok / first containing read, by :index): order-free as a minimum
-    if (live && add_like && my_type == MSIM_T_OK && r.w < p.max_values && known[r.w] > base + lane) known[r.w] = (u16)(base + lane);  // one add per element: no race
+    // add :ok -> known (first of add-ok / first containing read, by :index): order-free as a minimum; one add per element
+    if (live && add_like && my_type == MSIM_T_OK && r.w < p.max_values && known[r.w] > base + lane) known[r.w] = (u16)(base + lane);
     const u64 add_inv = __ballot(live && add_like && my_type == MSIM_T_INVOKE);  // elements come into existence
     u64 walk = __ballot(live && (my_f == MSIM_F_READ || my_f == MSIM_F_ECHO));
     const u32 v_base = v_cur;
@@ -84,26 +99,77 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
       const bool hi_slot = tt >= 64;
       const u32 idx = base + j;
       if (f == MSIM_F_READ) {
-        if (type == MSIM_T_INVOKE) { if (lane == t) { if (hi_slot) my_inv1 = idx; else my_inv = idx; } }
+        if (type == MSIM_T_INVOKE) { if (lane == t) { if (hi_slot) { my_inv1 = idx; my_rank1 = n_ri; } else { my_inv = idx; my_rank = n_ri; } } n_ri++; }
         else if (type == MSIM_T_FAIL) { if (lane == t) { if (hi_slot) my_inv1 = NONE; else my_inv = NONE; } }
         else if (type == MSIM_T_OK) {
-          const u32 inv = hi_slot ? c_rdlane(my_inv1, t) : c_rdlane(my_inv, t), len = hi >> 16, off = value;
+          const u32 inv = hi_slot ? c_rdlane(my_inv1, t) : c_rdlane(my_inv, t), rank = hi_slot ? c_rdlane(my_rank1, t) : c_rdlane(my_rank, t);
+          const u32 len = hi >> 16, off = value;
           const u32 v_here = v_base + (u32)__popcll(add_inv & ((1ull << j) - 1));  // elements existing at this row
-          for (u32 e = lane; e < v_here; e += 64) {
-            const u32 w = (e >> 5) < len ? pay[off + (e >> 5)] : 0u;
-            if ((w >> (e & 31)) & 1) {
-              if (known[e] > idx) known[e] = (u16)idx;
-              const u32 lp = lp_idx[e];
-              if (lp == NONE || lp < inv) lp_idx[e] = (u16)inv;
-            } else {
-              const u32 la = la_idx[e];
-              if (la == NONE || la < inv) la_idx[e] = (u16)inv;
-            }
+          if (inv != NONE && rank < p.max_reads && n_rc < p.max_reads && lane == 0) {
+            rec_c[n_rc] = make_uint2(off | (len << 24), idx);
+            rec_i[rank] = make_uint2(off | (len << 24), inv | (v_here << 16));
+            valid[rank >> 5] |= 1u << (rank & 31);
           }
+          n_rc++;
         }
       } else {  // echo
         if (type == MSIM_T_INVOKE) { if (lane == t) { if (hi_slot) my_val1 = value; else my_val = value; } }
         else if (type == MSIM_T_OK) { if ((hi_slot ? c_rdlane(my_val1, t) : c_rdlane(my_val, t)) != value) errors++; }  // echo.clj:52-60
+      }
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (n_rc > p.max_reads) n_rc = p.max_reads;
+  if (n_ri > p.max_reads) n_ri = p.max_reads;
+
+  // lane w owns word w of the read bitmaps, i.e. elements 32w .. 32w+31
+  // ---- pass 2a: known by reads (completion order) ----
+  {
+    u32 unk = 0xFFFFFFFFu;
+    for (u32 cb = 0; cb < n_rc; cb += 64) {
+      const u32 cn = min(64u, n_rc - cb);
+      uint2 my_rec = make_uint2(0, 0);
+      if (lane < cn) my_rec = rec_c[cb + lane];
+      u32 ref = c_rdlane(my_rec.x, 0);
+      u32 word = lane < (ref >> 24) ? pay[(ref & 0xFFFFFFu) + lane] : 0u;
+      for (u32 j = 0; j < cn; j++) {
+        const u32 idx = c_rdlane(my_rec.y, j);
+        const u32 w = word;
+        if (j + 1 < cn) { ref = c_rdlane(my_rec.x, j + 1); word = lane < (ref >> 24) ? pay[(ref & 0xFFFFFFu) + lane] : 0u; }  // prefetch
+        u32 hits = w & unk;
+        unk &= ~w;
+        while (hits) {
+          const u32 e = lane * 32 + (u32)__builtin_ctz(hits); hits &= hits - 1;
+          if (e < p.max_values && known[e] > idx) known[e] = (u16)idx;
+        }
+      }
+    }
+  }
+  // ---- pass 2b: last-present / last-absent (invocation order, latest first) ----
+  {
+    u32 pend_p = 0xFFFFFFFFu, pend_a = 0xFFFFFFFFu;
+    for (u32 cbp = (n_ri + 63) / 64; cbp > 0; cbp--) {
+      const u32 cb = (cbp - 1) * 64, cn = min(64u, n_ri - cb);
+      const u64 vmask = ((u64)valid[cb / 32 + 1] << 32 | valid[cb / 32]) & (cn >= 64 ? ~0ull : ((1ull << cn) - 1));
+      if (!vmask) continue;
+      uint2 my_rec = make_uint2(0, 0);
+      if ((vmask >> lane) & 1) my_rec = rec_i[cb + lane];
+      u64 todo = vmask;
+      u32 j = 63 - (u32)__builtin_clzll(todo);
+      u32 ref = c_rdlane(my_rec.x, j);
+      u32 word = lane < (ref >> 24) ? pay[(ref & 0xFFFFFFu) + lane] : 0u;
+      while (todo) {
+        todo &= ~(1ull << j);
+        const u32 iv = c_rdlane(my_rec.y, j), inv = iv & 0xFFFFu, v_here = iv >> 16;
+        const u32 w = word;
+        if (todo) { j = 63 - (u32)__builtin_clzll(todo); ref = c_rdlane(my_rec.x, j); word = lane < (ref >> 24) ? pay[(ref & 0xFFFFFFu) + lane] : 0u; }  // prefetch
+        const u32 lo = lane * 32;
+        const u32 ex = v_here >= lo + 32 ? 0xFFFFFFFFu : (v_here <= lo ? 0u : ((1u << (v_here - lo)) - 1));  // elements that exist at this read
+        u32 hp = w & pend_p; pend_p &= ~w;
+        u32 ha = ~w & ex & pend_a; pend_a &= ~(~w & ex);
+        while (hp) { const u32 e = lo + (u32)__builtin_ctz(hp); hp &= hp - 1; if (e < p.max_values) lp_idx[e] = (u16)inv; }
+        while (ha) { const u32 e = lo + (u32)__builtin_ctz(ha); ha &= ha - 1; if (e < p.max_values) la_idx[e] = (u16)inv; }
       }
     }
   }
@@ -178,7 +244,17 @@ int msim_check_launch(msim_ctx *ctx) {
   cp.rows = ctx->d_rows; cp.payload = ctx->d_payload; cp.meta = ctx->d_meta; cp.out = ctx->d_check;
   cp.max_rows = c.max_rows; cp.max_pay = c.max_payload_words; cp.max_values = c.max_values; cp.C = c.concurrency; cp.workload = c.workload;
   if (c.max_rows >= 0xFFFF || c.max_values > 2048 || c.concurrency > 128) { ctx->err = "device checker: max_rows must be < 65535, max_values <= 2048, concurrency <= 128"; return MSIM_E_UNSUPPORTED; }
-  const size_t lds = (size_t)c.max_values * 3 * 2 < (size_t)c.max_values * 4 ? (size_t)c.max_values * 4 : (size_t)c.max_values * 3 * 2;
+  cp.max_reads = c.max_rows / 2 + 1;  // every :ok read has its own :invoke row
+  const size_t rec_bytes = (size_t)ctx->n_inst * cp.max_reads * 2 * sizeof(uint2);
+  if (ctx->cap_check_scratch < rec_bytes) {
+    if (ctx->d_check_scratch) (void)hipFree(ctx->d_check_scratch);
+    ctx->d_check_scratch = nullptr; ctx->cap_check_scratch = 0;
+    MSIM_HIP_TRY(ctx, hipMalloc(&ctx->d_check_scratch, rec_bytes));
+    ctx->cap_check_scratch = rec_bytes;
+  }
+  cp.recs = static_cast<uint2 *>(ctx->d_check_scratch);
+  size_t lds = (size_t)c.max_values * 3 * 2 < (size_t)c.max_values * 4 ? (size_t)c.max_values * 4 : (size_t)c.max_values * 3 * 2;
+  lds += ((size_t)(cp.max_reads + 31) / 32 + 2) * 4;  // + the valid bitmap (read one word past the last chunk)
   if (lds > 64 * 1024) {
     MSIM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&check_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }

@@ -820,6 +820,8 @@ static void free_buffers(msim_ctx *c) {
   if (c->h_meta) (void)hipHostFree(c->h_meta);
   if (c->h_check) (void)hipHostFree(c->h_check);
   if (c->h_journal) (void)hipHostFree(c->h_journal);
+  if (c->d_check_scratch) (void)hipFree(c->d_check_scratch);
+  c->d_check_scratch = nullptr; c->cap_check_scratch = 0;
   if (c->d_compact) (void)hipFree(c->d_compact);
   if (c->d_off) (void)hipFree(c->d_off);
   c->d_compact = nullptr; c->d_off = nullptr;

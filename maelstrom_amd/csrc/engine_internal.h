@@ -36,6 +36,7 @@ struct msim_ctx {
   msim_event *h_journal = nullptr;
   uint64_t *h_row_off = nullptr, *h_pay_off = nullptr, *h_ev_off = nullptr;  // compacted offsets per instance
   // fetch path: device-side compaction buffers + grow-only capacities (bytes) of the pinned mirrors
+  void *d_check_scratch = nullptr; size_t cap_check_scratch = 0;  // checker.hip: read records per instance
   void *d_compact = nullptr; uint64_t *d_off = nullptr;
   size_t cap_compact = 0, cap_off = 0, cap_h_rows = 0, cap_h_payload = 0, cap_h_journal = 0, cap_h_meta = 0;
   bool fetched = false, checked = false, check_fetched = false, ran = false;
