@@ -184,8 +184,21 @@ def main():
             "kernel_ms": {"sim": sim_avg, "check": chk_avg},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "sim_kernel<BCAST_FF>", "algorithmic_bytes_per_launch": b_alg},
+                         "kernel": "sim_kernel_colo<BCAST_FF>", "algorithmic_bytes_per_launch": b_alg},
         }
+        # HBM bytes per launch from the PMC passes of the committed profile (counters cannot be read inside this process):
+        # FETCH_SIZE x 2 + WRITE_SIZE, KiB -> bytes (tools/rocpd_summary.py --traffic); null if the profile is absent or was
+        # taken with a different batch size
+        tj = os.path.join(ROOT, "profiles", "r01_headline_traffic.json")
+        if os.path.exists(tj) and n == 4096:
+            try:
+                kern = json.load(open(tj))["kernels"]
+                b = [v["hbm_bytes_per_dispatch"] for kname, v in kern.items() if "sim_kernel_colo" in kname and "hbm_bytes_per_dispatch" in v]
+                if b:
+                    out["roofline"]["traffic"] = b[0]
+                    out["roofline"]["traffic_source"] = "profiles/r01_headline_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+            except Exception:
+                pass
         if gather:
             out["history_gather"] = gather
         if args.cpu_sample > 0:

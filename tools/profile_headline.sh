@@ -16,4 +16,5 @@ if [ "${2:-}" = "full" ]; then
   rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU -d "$OUT/pmc_cyc" -o c -- $CMD > "$OUT/pmc_cyc.log" 2>&1
 fi
 python $ROOT/tools/rocpd_summary.py $(find "$OUT" -name "*_results.db" | sort) > "$OUT/summary.txt" 2>&1
+if [ "${2:-}" = "full" ]; then python $ROOT/tools/rocpd_summary.py --traffic "$OUT/traffic.json" $(find "$OUT" -name "*_results.db" | sort); fi
 tail -40 "$OUT/summary.txt"

@@ -32,6 +32,37 @@ def summarise(path):
         print(f"-- no PMC data ({e.__class__.__name__}: {e})")
 
 
+def traffic_json(paths, out):
+    """--traffic OUT.json: per-kernel HBM traffic per dispatch from the FETCH_SIZE / WRITE_SIZE passes, corrected as
+    /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes for gfx950: both counters are in KiB; FETCH_SIZE counts
+    128-B read requests as 64 B, so it is doubled; WRITE_SIZE is taken as is (calibrated here against the kernel's known
+    write volume: WRITE_SIZE x 1024 = 1.01 x the algorithmic bytes)."""
+    import json
+    acc = {}
+    for path in paths:
+        con = sqlite3.connect(path)
+        try:
+            kd, ks = table(con, "rocpd_kernel_dispatch"), table(con, "rocpd_info_kernel_symbol")
+            pe, pi = table(con, "rocpd_pmc_event"), table(con, "rocpd_info_pmc")
+        except IndexError:
+            continue
+        q = (f"select s.display_name, i.name, sum(e.value), count(distinct d.id) from '{pe}' e join '{pi}' i on e.pmc_id = i.id "
+             f"join '{kd}' d on e.event_id = d.event_id join '{ks}' s on d.kernel_id = s.id where i.name in ('FETCH_SIZE', 'WRITE_SIZE') group by 1, 2")
+        for name, ctr, tot, nd in con.execute(q):
+            if not any(k in name for k in ("sim_kernel", "check_kernel", "raft_kernel", "txn_kernel", "compact_")):
+                continue  # the engine's own kernels only (torch's reductions in bench.py are not the path)
+            acc.setdefault(name, {})[ctr + "_KiB_per_dispatch"] = tot / max(nd, 1)
+    for name, d in acc.items():
+        f, w = d.get("FETCH_SIZE_KiB_per_dispatch"), d.get("WRITE_SIZE_KiB_per_dispatch")
+        if f is not None and w is not None:
+            d["hbm_bytes_per_dispatch"] = (2.0 * f + w) * 1024.0
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), tools/profile_headline.sh", "kernels": acc}, open(out, "w"), indent=1)
+
+
 if __name__ == "__main__":
-    for p in sys.argv[1:]:
-        summarise(p)
+    args = sys.argv[1:]
+    if args and args[0] == "--traffic":
+        traffic_json(args[2:], args[1])
+    else:
+        for p in args:
+            summarise(p)
