@@ -814,7 +814,7 @@ int oracle_node_trace(const msim_config *cfg, uint32_t node, const uint32_t *in,
 uint32_t oracle_msg_type(const char *name) {
   static const char *names[] = {"", "init", "init_ok", "topology", "topology_ok", "echo", "echo_ok", "broadcast", "broadcast_ok",
                                 "read", "read_ok", "add", "add_ok", "replicate", "write", "write_ok", "cas", "cas_ok", "error",
-                                "request_vote", "request_vote_res", "append_entries", "append_entries_res"};
+                                "request_vote", "request_vote_res", "append_entries", "append_entries_res", "txn", "txn_ok"};
   for (u32 i = 1; i < sizeof(names) / sizeof(names[0]); i++) if (!strcmp(names[i], name)) return i;
   return 0;
 }
@@ -863,6 +863,35 @@ int oracle_raft_trace(const msim_config *cfg, uint32_t node, const uint32_t *in,
   state_out[0] = r->role; state_out[1] = r->term; state_out[2] = r->commit_index; state_out[3] = r->last_applied; state_out[4] = r->log_n;
   state_out[5] = (u32)r->voted_for; state_out[6] = (u32)r->leader;
   sim_free(s); free(rows); free(payload);
+  return (int)n;
+}
+
+/* Test hook for the txn-list-append programs: replays a conversation between the transactional nodes and the lin-kv
+ * service outside the network.  Each input is {target endpoint, src endpoint, message type, a, b}: the target (a node, or
+ * the service at endpoint N + CS) handles it at once; every message it emits is recorded as
+ * {input index, src endpoint, dest endpoint, type, a, b}.  `payload` must already hold the micro-ops that txn requests
+ * refer to (a = offset | n << 24) and have room behind `payload_used` words for the completed transactions.  Used to
+ * replay golden vectors recorded from the reference's own demo/js/single_key_txn.js (tests/golden/make_golden_txn.py). */
+int oracle_txn_trace(const msim_config *cfg, const uint32_t *in, uint32_t n_in, uint32_t *out, uint32_t out_cap,
+                     uint32_t *payload, uint32_t payload_used) {
+  msim_op *rows = (msim_op *)calloc(cfg->max_rows, sizeof(msim_op));
+  sim_t *s = sim_new(cfg, 0, rows, payload);
+  if (!s || !s->txn) { free(rows); return -1; }
+  s->meta.n_payload_words = payload_used;
+  u32 n = 0;
+  for (u32 i = 0; i < n_in; i++) {
+    const u32 *m = in + 5 * i;
+    s->n_out = 0;
+    qent q = {s->T, i, m[3], m[4], (u8)m[1], (u8)m[2], NULL};
+    if (m[0] < s->N) node_handle(s, m[0], &q);
+    else if (m[0] == svc_ep(s)) svc_handle(s, &q);
+    else { sim_free(s); free(rows); return -1; }
+    for (u32 k = 0; k < s->n_out && n < out_cap; k++, n++) {
+      u32 *o = out + 6 * n;
+      o[0] = i; o[1] = s->out[k].src_ep; o[2] = s->out[k].dest_ep; o[3] = s->out[k].type; o[4] = s->out[k].a; o[5] = s->out[k].b;
+    }
+  }
+  sim_free(s); free(rows);
   return (int)n;
 }
 

@@ -289,3 +289,114 @@ def test_raft_py_handlers_and_leader_path(lib):
     # every distinct append_entries raft.py sent (dest, term, prev index/term, entries) and nothing else
     assert got_ae == want_ae, (sorted(got_ae - want_ae, key=repr), sorted(want_ae - got_ae, key=repr))
     assert int(state[0]) == 3 and int(state[1]) == 4  # leader of term 4, like the recorded node
+
+
+# ---- txn-list-append: demo/js/single_key_txn.js + the lin-kv service (a17/a18) ---------------------------------------
+
+def _txn_trace(cfg, inputs, payload, used):
+    lib = O.load()
+    lib.oracle_txn_trace.argtypes = [C.POINTER(A.Config), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+    lib.oracle_txn_trace.restype = C.c_int
+    inp = np.array(inputs, dtype=np.uint32).reshape(-1, 5)
+    out = np.zeros((512, 6), dtype=np.uint32)
+    pay = payload.copy()
+    n = lib.oracle_txn_trace(C.byref(cfg), inp.ctypes.data, len(inp), out.ctypes.data, 512, pay.ctypes.data, used)
+    assert n >= 0
+    return out[:n], pay
+
+
+def test_txn_node_and_service_follow_the_reference_js_node():
+    """Replays the conversations recorded from two real demo/js/single_key_txn.js processes (tests/golden/make_golden_txn.py)
+    against the oracle's transactional node AND its lin-kv service: every message either side emits must match, including
+    the completed transactions (reads filled in from the state read + the transaction's own appends), the conflict (code 22
+    -> error 30) and the write-back of read-only transactions.
+
+    Translation between the wire format and the engine's encoding: a database state (flat [k [v..] k [v..]] list) <-> its
+    version = number of elements in it (states form one append chain).  Documented differences between the
+    reference's own demos: the JS runtime numbers RPCs from 0, the Clojure one (which the engine follows) from 1; for a
+    missing key the JS node cas-es from [] where the Clojure node cas-es from nil — with create_if_not_exists both create."""
+    gold = json.load(open(os.path.join(HERE, "golden", "txn_transitions.json")))
+    ids = gold["node_ids"]
+    N = len(ids)
+    cfg = E.test_config("txn-list-append", node_count=N, rate=10, time_limit=5, seed=1)
+    SVC = 2 * N
+    V_NIL = 0xFFFF
+    clients = {}
+
+    def ep(name):
+        if name == "lin-kv":
+            return SVC
+        if name[0] == "n":
+            return ids.index(name)
+        return N + clients.setdefault(name, len(clients) % N)
+
+    def version(state):
+        return sum(len(state[i + 1]) for i in range(0, len(state), 2))
+
+    payload = np.zeros(cfg.max_payload_words, dtype=np.uint32)
+    used = 0
+    inputs = []                       # oracle inputs so far
+    golden_by_ep, oracle_by_ep = {}, {}
+    pending = {}                      # (src, dest) -> oracle messages emitted and not yet delivered, FIFO
+    store_exists = False
+    for k in range(0, len(gold["log"]), 2):
+        m, emitted = gold["log"][k]["deliver"], gold["log"][k + 1]
+        b = m["body"]
+        src, dest = ep(m["src"]), ep(m["dest"])
+        if m["src"][0] == "c":        # from a client: built from the golden message
+            if b["type"] == "init":
+                rec = [dest, src, _t("init"), 0, b["msg_id"]]
+            else:
+                words = E.encode_txn([[":append" if f == "append" else ":r", kk, v] for f, kk, v in b["txn"]])
+                payload[used:used + len(words)] = words
+                rec = [dest, src, _t("txn"), used | (len(words) << 24), b["msg_id"]]
+                used += len(words)
+        else:                         # node <-> service: what the ORACLE emitted earlier on this link, in order
+            o = pending[(src, dest)].pop(0)
+            rec = [dest, src, int(o[3]), int(o[4]), int(o[5])]
+            # and it must say what the golden message says
+            assert int(o[3]) == _t(b["type"])
+            if b["type"] == "read_ok":
+                assert int(o[4]) == version(b["value"])
+            elif b["type"] == "error":
+                assert int(o[4]) == b["code"]
+            elif b["type"] == "cas":
+                frm = int(o[4]) & 0xFFFF
+                assert frm == (version(b["from"]) if store_exists else V_NIL), (frm, b["from"])   # [] (JS) / nil (Clojure) for a missing root
+                # the new state is the state read + this transaction's appends: what the engine leaves implicit
+                assert version(b["to"]) >= version(b["from"]) and b["create_if_not_exists"] is True
+            if "in_reply_to" in b:
+                assert int(o[5]) == b["in_reply_to"] + 1   # JS numbers its RPCs from 0
+            elif "msg_id" in b:
+                assert int(o[5]) == b["msg_id"] + 1
+        inputs.append(rec)
+        out, pay = _txn_trace(cfg, inputs, payload, used)
+        new = [o for o in out if int(o[0]) == len(inputs) - 1]
+        for o in new:
+            pending.setdefault((int(o[1]), int(o[2])), []).append(o)
+            oracle_by_ep.setdefault(int(o[1]), []).append((int(o[2]), int(o[3]), o, pay))
+        for g in emitted["out"]:
+            golden_by_ep.setdefault(ep(g["src"]), []).append(g)
+        if b["type"] == "cas" and dest == SVC and any(int(o[3]) == _t("cas_ok") for o in new):
+            store_exists = True
+
+    # every endpoint emitted the same messages in the same order
+    assert set(golden_by_ep) == set(oracle_by_ep)
+    n_txn_ok = 0
+    for e, gl in golden_by_ep.items():
+        ol = oracle_by_ep[e]
+        assert len(gl) == len(ol), (e, len(gl), len(ol))
+        for g, (odest, otype, o, pay) in zip(gl, ol):
+            gb = g["body"]
+            assert ep(g["dest"]) == odest and _t(gb["type"]) == otype, (g, o)
+            if gb["type"] == "txn_ok":
+                a = int(o[4])
+                got = E.decode_txn(pay[a & 0xFFFFFF:(a & 0xFFFFFF) + (a >> 24)])
+                want = [[":append" if f == "append" else ":r", kk, v] for f, kk, v in gb["txn"]]
+                assert got == want, (got, want)
+                assert int(o[5]) == gb["in_reply_to"]
+                n_txn_ok += 1
+            elif gb["type"] == "error":
+                assert int(o[4]) == gb["code"]
+    assert n_txn_ok >= 4
+    assert gold["final_store"]["state"] == [1, [1, 2, 4], 2, [5], 3, [1, 2]]

@@ -2,9 +2,9 @@
 transactional node + lin-kv service against the reference's known answers, and the host list-append checker
 (restating [upstream] elle, txn_list_append.clj:142) against hand-made anomalous histories.
 
-No golden transitions exist for this node program: demo/clojure/single_key_txn.clj needs babashka, which is not in
-this image — parity with the JVM path is unpinned here; what IS pinned: message counts per transaction
-(read + cas per txn, service.clj / single_key_txn.clj:171-180) and strict serializability of every history."""
+The node + service transition functions are pinned separately by golden vectors recorded from the reference's own
+demo/js/single_key_txn.js (tests/test_golden_transitions.py); pinned here: message counts per transaction (read + cas per
+txn, service.clj / single_key_txn.clj:171-180) and strict serializability of every history."""
 import numpy as np
 import pytest
 
