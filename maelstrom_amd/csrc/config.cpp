@@ -146,7 +146,7 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
     if (c->node_program == MSIM_NODE_G_SET) depth = 16 + 2 * deg;  // one replicate_full per peer per 5 s tick (g_set.rb:33-38)
     if (c->node_program == MSIM_NODE_RAFT) depth = 24 + 1024;
     if (txn) depth = 16 + 4 * c->n_nodes;                           // the service sees <= 2 requests per transaction in flight       // heartbeats / re-sent append_entries pile up behind a sleeping recv!
-    const uint32_t lds_part = c->n_nodes > 32 ? 8 : 24;  // wide clusters keep 100+ queues in one CU's LDS
+    const uint32_t lds_part = c->n_nodes > 32 ? 4 : 24;  // wide clusters keep 100+ queues in one CU's LDS
     if (c->inbox_capacity == 0) c->inbox_capacity = depth < lds_part ? depth : lds_part;
     if (c->spill_capacity == 0) c->spill_capacity = depth > c->inbox_capacity ? depth - c->inbox_capacity : 0;
     if (c->spill_capacity > 65536) { set_err(err, errlen, "spill_capacity above 65536 envelopes per node"); return MSIM_E_INVALID; }
