@@ -15,12 +15,26 @@ SOURCES = ["config.cpp", "engine.hip", "checker.hip", "lin_check.cpp", "txn_chec
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 
 
+STAMP = OUT + ".stamp"
+
+
+def _digest():
+    """Content hash of everything the library is built from (mtimes do not survive every copy of the tree)."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(HERE, "..", "include", "maelsim.h")]
+    for d in deps:
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def _stale():
-    if not os.path.exists(OUT):
+    if not os.path.exists(OUT) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "maelsim.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(STAMP) as f:
+        return f.read().strip() != _digest()
 
 
 def build(force=False, verbose=True):
@@ -31,6 +45,8 @@ def build(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    with open(STAMP, "w") as f:
+        f.write(_digest())
     return OUT
 
 

@@ -18,6 +18,7 @@
 //     lane; read results (bitmaps) are copied LDS->HBM by the whole wave, 256 B per instruction.
 //   No MFMA: this is integer/indexing work.  No CUDA/hipify/Triton layers.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <cstdio>
 #include <cstring>
@@ -911,7 +912,8 @@ static hipError_t launch3(const KParams &kp, uint32_t n, size_t lds, hipStream_t
   const bool colo = kp.C == kp.N;
   // FIFO queues (constant latency only) when deep queues are expected: the scan-based poll is cheaper for shallow ones
   constexpr bool CAN_FIFO = !NET_RANDOM && PROG != MSIM_NODE_BCAST_ACK_RETRY && PROG != MSIM_NODE_BCAST_RPC_ALL;
-  const bool fifo = CAN_FIFO && colo && kp.spill_cap >= 64;
+  static const char *force = std::getenv("MSIM_QUEUE");  // developer knob: "fifo" / "scan" override the choice below
+  const bool fifo = CAN_FIFO && colo && (force && force[0] == 'f' ? true : force && force[0] == 's' ? false : kp.spill_cap >= 64);
   const void *fn = !colo ? reinterpret_cast<const void *>(&sim_kernel<PROG, NEM, NET_RANDOM>)
                  : fifo ? reinterpret_cast<const void *>(&sim_kernel_colo<PROG, NEM, NET_RANDOM, CAN_FIFO>)
                         : reinterpret_cast<const void *>(&sim_kernel_colo<PROG, NEM, NET_RANDOM, false>);
