@@ -41,7 +41,8 @@ enum {
 };
 
 /* ---- configuration (mirrors the CLI option map, core.clj:136-229, + ensemble/determinism fields) -- */
-enum { MSIM_WL_ECHO = 0, MSIM_WL_BROADCAST = 1, MSIM_WL_G_SET = 2, MSIM_WL_LIN_KV = 3, MSIM_WL_TXN_LIST_APPEND = 4 };
+enum { MSIM_WL_ECHO = 0, MSIM_WL_BROADCAST = 1, MSIM_WL_G_SET = 2, MSIM_WL_LIN_KV = 3, MSIM_WL_TXN_LIST_APPEND = 4,
+       MSIM_WL_PN_COUNTER = 5 /* workload/pn_counter.clj */ };
 
 /* Built-in node programs (the `--bin` of the reference). */
 enum {
@@ -54,9 +55,11 @@ enum {
   MSIM_NODE_BCAST_RPC_ALL = 4,  /* demo/ruby/broadcast.rb:29-47: RPC to every other node, no retry           */
   MSIM_NODE_G_SET = 5,          /* demo/ruby/g_set.rb:8-39: replicate_full to all others every 5 s          */
   MSIM_NODE_RAFT = 6,           /* demo/ruby/raft.rb:1-497 == demo/python/raft.py:1-593 (lin-kv)             */
-  MSIM_NODE_TXN_SINGLE_KEY = 7  /* demo/clojure/single_key_txn.clj:116-180: whole database under one lin-kv key:
+  MSIM_NODE_TXN_SINGLE_KEY = 7, /* demo/clojure/single_key_txn.clj:116-180: whole database under one lin-kv key:
                                    read root -> apply txn -> cas root (create_if_not_exists), conflict => error 30.
                                    Brings the `lin-kv` service endpoint with it (service.clj:31-61,141-155,290-296) */
+  MSIM_NODE_PN_COUNTER = 8      /* demo/ruby/pn_counter.rb:8-121 == demo/js/crdt_pn_counter.js: increments and decrements in two
+                                   per-node G-counters, merged by element-wise max, replicated to all others every 5 s      */
 };
 
 enum { MSIM_LAT_CONSTANT = 0, MSIM_LAT_UNIFORM = 1, MSIM_LAT_EXPONENTIAL = 2 };  /* net.clj:65-77 */
@@ -110,6 +113,8 @@ typedef struct msim_config {
  * A read's :value is a bitmap over elements 0..32*len-1 (bit e set <=> e in the returned collection).
  * lin-kv ops (lin_kv.clj:53-67) pack their independent tuple into `value`: bits 0-7 key k, 8-15 v, 16-23 v'
  * (0xFF = nil): read [k v], write [k v], cas [k [v v']].
+ * pn-counter ops (pn_counter.clj:22-58,134-137): `value` of an :add is the delta, of an :ok :read the counter, both as
+ * two's-complement int32; a read's :invoke (and :fail / :info) has value nil.
  * txn ops (txn_list_append.clj:27-39,54-60): `value` = payload offset, len = words of the transaction
  * [[f k v] ...].  One header word per micro-op: bit 0 f (0 = :r, 1 = :append), bits 1-15 key, bits 16-23 the appended
  * element (:append) or the length n of the list read (:r; 0xFF = nil, i.e. an :invoke or a key that does not exist);
@@ -252,6 +257,13 @@ enum { MSIM_ANOMALY_G0 = 1u, MSIM_ANOMALY_G1A = 2u, MSIM_ANOMALY_G1B = 4u, MSIM_
        MSIM_ANOMALY_INCOMPATIBLE_ORDER = 256u, MSIM_ANOMALY_REALTIME = 512u /* cycle needs a realtime edge (G*-realtime) */,
        MSIM_ANOMALY_DIRTY_UPDATE = 1024u };
 int msim_check_txn_rows(const msim_op *rows, uint32_t n_rows, const uint32_t *payload, uint32_t n_words, msim_check_result *out);
+
+/* Host-only utility behind msim_check for pn-counter: the checker of workload/pn_counter.clj:84-123 — every :ok read
+ * marked :final? must lie in the acceptable set = sum of the :ok adds plus any subset of the :info adds, kept as merged
+ * closed integer ranges.  out->valid 1/0; attempt_count = final reads, error_count = final reads outside the set,
+ * stable_count = ranges in the set.  `ranges` (may be NULL) receives up to `cap` [lower, upper] pairs in ascending order,
+ * *n_ranges the number of ranges (the reference's :acceptable).  Needs no device. */
+int msim_check_pn_rows(const msim_op *rows, uint32_t n_rows, msim_check_result *out, int64_t *ranges, uint32_t cap, uint32_t *n_ranges);
 
 /* Copies the last run's outputs to host memory (pinned, owned by ctx, valid until next run/destroy). */
 int msim_fetch(msim_ctx *ctx);

@@ -14,8 +14,8 @@ ABI_VERSION = 1
 
 # enums (include/maelsim.h)
 OK, E_INVALID, E_NO_DEVICE, E_HIP, E_NOMEM, E_RANGE, E_UNSUPPORTED, E_OVERFLOW = 0, -1, -2, -3, -4, -5, -6, -7
-WL_ECHO, WL_BROADCAST, WL_G_SET, WL_LIN_KV, WL_TXN_LIST_APPEND = range(5)
-NODE_ECHO, NODE_BCAST_FF, NODE_BCAST_FF_ECHOBACK, NODE_BCAST_ACK_RETRY, NODE_BCAST_RPC_ALL, NODE_G_SET, NODE_RAFT, NODE_TXN_SINGLE_KEY = range(8)
+WL_ECHO, WL_BROADCAST, WL_G_SET, WL_LIN_KV, WL_TXN_LIST_APPEND, WL_PN_COUNTER = range(6)
+NODE_ECHO, NODE_BCAST_FF, NODE_BCAST_FF_ECHOBACK, NODE_BCAST_ACK_RETRY, NODE_BCAST_RPC_ALL, NODE_G_SET, NODE_RAFT, NODE_TXN_SINGLE_KEY, NODE_PN_COUNTER = range(9)
 LAT_CONSTANT, LAT_UNIFORM, LAT_EXPONENTIAL = range(3)
 TOPO_GRID, TOPO_LINE, TOPO_TOTAL, TOPO_TREE2, TOPO_TREE3, TOPO_TREE4 = range(6)
 NEMESIS_PARTITION = 1
@@ -35,7 +35,7 @@ MASK_WORDS = 4
 
 EXPORTS = [
     "msim_abi_version", "msim_device_count", "msim_config_defaults", "msim_config_finalize", "msim_create",
-    "msim_run", "msim_run_async", "msim_check", "msim_check_lin_kv_rows", "msim_check_txn_rows", "msim_fetch", "msim_history", "msim_net_stats_get", "msim_journal", "msim_meta",
+    "msim_run", "msim_run_async", "msim_check", "msim_check_lin_kv_rows", "msim_check_txn_rows", "msim_check_pn_rows", "msim_fetch", "msim_history", "msim_net_stats_get", "msim_journal", "msim_meta",
     "msim_check_results", "msim_device_buffers_get", "msim_last_kernel_ms", "msim_get_config",
     "msim_selftest_wave", "msim_last_error", "msim_destroy",
 ]

@@ -30,6 +30,7 @@ extern "C" int msim_config_defaults(msim_config *cfg, uint32_t workload, uint32_
     case MSIM_WL_BROADCAST: cfg->node_program = MSIM_NODE_BCAST_FF; break;
     case MSIM_WL_G_SET: cfg->node_program = MSIM_NODE_G_SET; break;
     case MSIM_WL_TXN_LIST_APPEND: cfg->node_program = MSIM_NODE_TXN_SINGLE_KEY; break;
+    case MSIM_WL_PN_COUNTER: cfg->node_program = MSIM_NODE_PN_COUNTER; break;
     default: cfg->node_program = MSIM_NODE_RAFT; break;
   }
   cfg->n_nodes = n_nodes;
@@ -54,7 +55,7 @@ extern "C" int msim_config_defaults(msim_config *cfg, uint32_t workload, uint32_
 
 static uint32_t max_degree(const msim_config *c) {
   uint32_t n = c->n_nodes;
-  if (c->node_program == MSIM_NODE_BCAST_RPC_ALL || c->node_program == MSIM_NODE_G_SET) return n ? n - 1 : 0;
+  if (c->node_program == MSIM_NODE_BCAST_RPC_ALL || c->node_program == MSIM_NODE_G_SET || c->node_program == MSIM_NODE_PN_COUNTER) return n ? n - 1 : 0;
   switch (c->topology) {
     case MSIM_TOPO_GRID: return n > 4 ? 4 : (n ? n - 1 : 0);
     case MSIM_TOPO_LINE: return n > 2 ? 2 : (n ? n - 1 : 0);
@@ -73,7 +74,7 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
   if (c->concurrency == 0) c->concurrency = c->n_nodes;
   uint32_t slots = c->concurrency > c->n_nodes ? c->concurrency : c->n_nodes;
   if (c->n_nodes + slots > 255) { set_err(err, errlen, "n_nodes + max(concurrency, n_nodes) must be <= 255"); return MSIM_E_INVALID; }
-  if (c->workload > MSIM_WL_TXN_LIST_APPEND) { set_err(err, errlen, "unknown workload"); return MSIM_E_INVALID; }
+  if (c->workload > MSIM_WL_PN_COUNTER) { set_err(err, errlen, "unknown workload"); return MSIM_E_INVALID; }
   if (c->latency_dist > MSIM_LAT_EXPONENTIAL) { set_err(err, errlen, "latency_dist must be constant, uniform, or exponential"); return MSIM_E_INVALID; }
   if (c->latency_dist == MSIM_LAT_EXPONENTIAL && c->latency_mean_ms == 0) {
     // net.clj:77 (exponential-distribution (/ mean)) throws "Divide by zero" for --latency 0
@@ -92,6 +93,7 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
     case MSIM_WL_G_SET: ok = c->node_program == MSIM_NODE_G_SET; break;
     case MSIM_WL_LIN_KV: ok = c->node_program == MSIM_NODE_RAFT; break;
     case MSIM_WL_TXN_LIST_APPEND: ok = c->node_program == MSIM_NODE_TXN_SINGLE_KEY; break;
+    case MSIM_WL_PN_COUNTER: ok = c->node_program == MSIM_NODE_PN_COUNTER; break;
     default: break;
   }
   if (!ok) { set_err(err, errlen, "node_program does not implement this workload"); return MSIM_E_INVALID; }
@@ -113,7 +115,11 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
   if (c->nemesis_mask) nem_ops = 4 * (c->time_limit_ms / c->nemesis_interval_ms + 1) + 16;
   if (c->workload == MSIM_WL_LIN_KV && c->concurrency % (2 * c->n_nodes)) {
     set_err(err, errlen, "lin-kv: concurrency must be a multiple of 2 x node-count ([upstream] independent/concurrent-generator)"); return MSIM_E_INVALID; }
-  const bool no_sets = c->workload == MSIM_WL_ECHO || c->workload == MSIM_WL_LIN_KV || txn;
+  const bool pn = c->workload == MSIM_WL_PN_COUNTER;
+  if (pn && c->n_nodes > 32) { set_err(err, errlen, "pn-counter: at most 32 nodes in this build"); return MSIM_E_UNSUPPORTED; }
+  // pn-counter: a node's state is 2 x n_nodes counters (one G-counter for increments, one for decrements): max_values / 32 words
+  if (pn) c->max_values = 64 * c->n_nodes;
+  const bool no_sets = c->workload == MSIM_WL_ECHO || c->workload == MSIM_WL_LIN_KV || txn || pn;
   // txn-list-append: max_values = distinct keys ever used (a key is retired after max_writes_per_key appends)
   if (txn && c->max_values == 0) c->max_values = c->key_count + (ops_max * c->max_txn_length) / c->max_writes_per_key + 32;
   if (txn && c->max_values > 32767) { set_err(err, errlen, "txn-list-append: more than 32767 keys"); return MSIM_E_INVALID; }
@@ -143,7 +149,7 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
     uint32_t depth = 32 + 2 * deg + (uint32_t)(per_s * lat_s * 6.0);  // x6: fan-in bursts (every neighbour forwards at once)
     // retrying gossip under partitions: at heal time every neighbour re-sends everything it could not deliver
     if (c->node_program == MSIM_NODE_BCAST_ACK_RETRY && c->nemesis_mask) depth += (deg < 4 ? deg : 4) * adds;
-    if (c->node_program == MSIM_NODE_G_SET) depth = 16 + 2 * deg;  // one replicate_full per peer per 5 s tick (g_set.rb:33-38)
+    if (c->node_program == MSIM_NODE_G_SET || c->node_program == MSIM_NODE_PN_COUNTER) depth = 16 + 2 * deg;  // one replicate_full per peer per 5 s tick (g_set.rb:33-38)
     if (c->node_program == MSIM_NODE_RAFT) depth = 24 + 1024;
     if (txn) depth = 16 + 4 * c->n_nodes;                           // the service sees <= 2 requests per transaction in flight       // heartbeats / re-sent append_entries pile up behind a sleeping recv!
     const uint32_t lds_part = c->n_nodes > 32 ? 4 : 24;  // wide clusters keep 100+ queues in one CU's LDS

@@ -201,9 +201,11 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
   constexpr bool IS_BCAST = PROG >= MSIM_NODE_BCAST_FF && PROG <= MSIM_NODE_BCAST_RPC_ALL;
   constexpr bool IS_RPC = PROG == MSIM_NODE_BCAST_ACK_RETRY || PROG == MSIM_NODE_BCAST_RPC_ALL;
   constexpr bool IS_ACK = PROG == MSIM_NODE_BCAST_ACK_RETRY;
-  constexpr bool IS_GSET = PROG == MSIM_NODE_G_SET;
+  constexpr bool IS_PN = PROG == MSIM_NODE_PN_COUNTER;    // pn_counter.rb: same replication skeleton as g-set, counters instead of a set
+  constexpr bool IS_GSET = PROG == MSIM_NODE_G_SET || IS_PN;  // "CRDT with a 5 s replicate timer"
   constexpr bool IS_ECHO = PROG == MSIM_NODE_ECHO;
   constexpr bool HAS_FINAL = IS_BCAST || IS_GSET;
+  constexpr bool FINAL_FLAG = IS_BCAST || IS_PN;  // :final? true on the last reads (broadcast.clj:240, pn_counter.clj:137)
   constexpr bool HAS_TIMERS = IS_ACK || IS_GSET;
   constexpr bool REP_FIRST = IS_ACK;  // the ack variant replies before it gossips
   constexpr u32 FAN_TYPE = IS_GSET ? M_REPLICATE : M_BROADCAST;
@@ -499,7 +501,8 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
               else if (r_lo & 1) f = MSIM_F_READ;
               else {
                 f = IS_BCAST ? MSIM_F_BROADCAST : MSIM_F_ADD;
-                if (next_value >= max_values) { flags |= MSIM_FLAG_VALUES_OVERFLOW; ok = false; }
+                if (IS_PN) val = (u32)((int)((((r_lo >> 4) & 0xFFFFu) * 10u) >> 16) - 5);  // (- (rand-int 10) 5), pn_counter.clj:134-135
+                else if (next_value >= max_values) { flags |= MSIM_FLAG_VALUES_OVERFLOW; ok = false; }
                 else val = next_value++;
               }
               if (!ok) { phase = PH_DONE; break; }
@@ -515,7 +518,7 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
             phase = PH_FINAL;
             [[fallthrough]];
           case PH_FINAL:
-            if (is_worker) { mark = true; kind = K_OP; m_f = MSIM_F_READ; m_value = MSIM_NO_VALUE; m_final = IS_BCAST ? 1 : 0; }
+            if (is_worker) { mark = true; kind = K_OP; m_f = MSIM_F_READ; m_value = MSIM_NO_VALUE; m_final = FINAL_FLAG ? 1 : 0; }
             phase = PH_FINAL_WAIT; break;
           default: break;
         }
@@ -587,11 +590,19 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
               rep = true; rep_dest = qsrc; rep_type = M_INIT_OK; rep_b = qb; break;
             case M_TOPOLOGY: rep = true; rep_dest = qsrc; rep_type = M_TOPOLOGY_OK; rep_b = qb; break;
             case M_ECHO: rep = true; rep_dest = qsrc; rep_type = M_ECHO_OK; rep_a = qa; rep_b = qb; break;
-            case M_READ: rd = true; rep = true; rep_dest = qsrc; rep_type = M_READ_OK; rep_b = qb; break;
-            case M_ADD: my_seen[qa >> 5] |= 1u << (qa & 31); rep = true; rep_dest = qsrc; rep_type = M_ADD_OK; rep_a = qa; rep_b = qb; break;
+            case M_READ:
+              rep = true; rep_dest = qsrc; rep_type = M_READ_OK; rep_b = qb;
+              if (IS_PN) { u32 v = 0; for (u32 i = 0; i < N; i++) v += my_seen[i] - my_seen[N + i]; rep_a = v; }  // increments - decrements
+              else rd = true;
+              break;
+            case M_ADD:
+              if (IS_PN) { const int d = (int)qa; if (d >= 0) my_seen[lane] += (u32)d; else my_seen[N + lane] += (u32)(-d); }  // own slot of inc / dec
+              else my_seen[qa >> 5] |= 1u << (qa & 31);
+              rep = true; rep_dest = qsrc; rep_type = M_ADD_OK; rep_a = qa; rep_b = qb; break;
             case M_REPLICATE: {
               const u32 *snap = g_scr + ((size_t)qa * N + qsrc) * W;
-              for (u32 w = 0; w < W; w++) my_seen[w] |= snap[w];
+              if (IS_PN) { for (u32 w = 0; w < W; w++) my_seen[w] = max(my_seen[w], snap[w]); }  // element-wise max
+              else for (u32 w = 0; w < W; w++) my_seen[w] |= snap[w];
             } break;
             case M_BROADCAST: {
               const u32 v = qa, bitm = 1u << (v & 31);
@@ -674,7 +685,7 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
           const u32 qb = q.w & 0xFFFFFFu, qtype = q.y & 0xFFu, qa = q.z;
           if (jcap) jwrite(n_ev + (u32)__popcll(dm & lt_mask), 1, q.y, qa, qb, q.w >> 24, lane);
           if (busy && qb == want) {  // else: stale reply, keep polling (client.clj:105-107)
-            if (qtype == M_READ_OK) complete(MSIM_T_OK, 0, qa & 0xFFFFFFu, qa >> 24);
+            if (qtype == M_READ_OK) { if (IS_PN) complete(MSIM_T_OK, 0, qa, 0); else complete(MSIM_T_OK, 0, qa & 0xFFFFFFu, qa >> 24); }
             else if (qtype == M_ECHO_OK) complete(MSIM_T_OK, 0, qa, 0);
             else complete(MSIM_T_OK, 0, c_value, 0);
           }
@@ -878,7 +889,7 @@ static uint64_t proto_scratch_words(const msim_config &c) {
   if (c.node_program == MSIM_NODE_RAFT) w = (uint64_t)c.n_nodes * raft_log_cap(c) * 2 + (uint64_t)c.n_nodes * R_ARENA_WORDS;
   if (c.node_program == MSIM_NODE_BCAST_ACK_RETRY) w = (uint64_t)c.n_nodes * c.max_values * 3;
   if (c.node_program == MSIM_NODE_TXN_SINGLE_KEY) w = (uint64_t)c.max_values * (c.max_writes_per_key + 1);  // elements + counts per key
-  if (c.node_program == MSIM_NODE_G_SET) {
+  if (c.node_program == MSIM_NODE_G_SET || c.node_program == MSIM_NODE_PN_COUNTER) {
     const uint64_t total_ms = (uint64_t)c.time_limit_ms + c.quiesce_ms + 2ull * c.client_timeout_ms;
     const uint64_t ticks = total_ms / 5000 + 3;
     w = ticks * c.n_nodes * (c.max_values / 32);
@@ -992,6 +1003,7 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
         e = hipGetLastError();
       } else e = launch<MSIM_NODE_G_SET>(kp, n, lds, st);
       break;
+    case MSIM_NODE_PN_COUNTER: e = launch<MSIM_NODE_PN_COUNTER>(kp, n, lds, st); break;
     case MSIM_NODE_RAFT: {
       const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
       if (c.nemesis_mask) { if (rnd) hipLaunchKernelGGL((raft_kernel<true, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((raft_kernel<true, false>), dim3(n), dim3(64), lds, st, kp); }
@@ -1033,6 +1045,7 @@ extern "C" int msim_check(msim_ctx *ctx) {
   if (!ctx->ran) { ctx->err = "msim_check before msim_run"; return MSIM_E_RANGE; }
   if (ctx->cfg.workload == MSIM_WL_LIN_KV) return msim_check_lin_kv_host(ctx);
   if (ctx->cfg.workload == MSIM_WL_TXN_LIST_APPEND) return msim_check_txn_host(ctx);
+  if (ctx->cfg.workload == MSIM_WL_PN_COUNTER) return msim_check_pn_host(ctx);
   return msim_check_launch(ctx);
 }
 

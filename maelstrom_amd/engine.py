@@ -22,10 +22,11 @@ CHECK_DT = np.dtype([("valid", "<u4"), ("attempt_count", "<u4"), ("stable_count"
                      ("ok_count", "<u4"), ("fail_count", "<u4"), ("info_count", "<u4")])
 
 WORKLOADS = {"echo": A.WL_ECHO, "broadcast": A.WL_BROADCAST, "g-set": A.WL_G_SET, "lin-kv": A.WL_LIN_KV,
-             "txn-list-append": A.WL_TXN_LIST_APPEND}
+             "txn-list-append": A.WL_TXN_LIST_APPEND, "pn-counter": A.WL_PN_COUNTER}
 NODE_PROGRAMS = {"echo": A.NODE_ECHO, "broadcast-ff": A.NODE_BCAST_FF, "broadcast-ff-echoback": A.NODE_BCAST_FF_ECHOBACK,
                  "broadcast-ack-retry": A.NODE_BCAST_ACK_RETRY, "broadcast-rpc-all": A.NODE_BCAST_RPC_ALL,
-                 "g-set": A.NODE_G_SET, "raft": A.NODE_RAFT, "single-key-txn": A.NODE_TXN_SINGLE_KEY}
+                 "g-set": A.NODE_G_SET, "raft": A.NODE_RAFT, "single-key-txn": A.NODE_TXN_SINGLE_KEY,
+                 "pn-counter": A.NODE_PN_COUNTER}
 TOPOLOGIES = {"grid": A.TOPO_GRID, "line": A.TOPO_LINE, "total": A.TOPO_TOTAL, "tree": A.TOPO_TREE2,
               "tree2": A.TOPO_TREE2, "tree3": A.TOPO_TREE3, "tree4": A.TOPO_TREE4}
 LATENCY_DISTS = {"constant": A.LAT_CONSTANT, "uniform": A.LAT_UNIFORM, "exponential": A.LAT_EXPONENTIAL}
@@ -304,6 +305,35 @@ def check_txn_history(rows, payload):
             "edge-count": res.lost_count, "cycle-txns": res.stale_count}
 
 
+def check_pn_history(rows):
+    """The host pn-counter checker (msim_check_pn_rows) on one history -> the reference's result map (pn_counter.clj:120-123
+    minus the op maps of :errors)."""
+    lib = A.load()
+    res = A.CheckResult()
+    rows = np.ascontiguousarray(rows)
+    ranges = (C.c_int64 * 512)()
+    n = C.c_uint32()
+    rc = lib.msim_check_pn_rows(rows.ctypes.data_as(C.c_void_p), len(rows), C.byref(res), ranges, 256, C.byref(n))
+    if rc:
+        raise EngineError(f"msim_check_pn_rows: {rc}")
+    finals = [int(np.int32(np.uint32(v))) for v, p in zip(rows["value"], rows["packed"]) if (p >> 11) & 1 and (p & 3) == A.T_OK and (p >> 12) != A.PROCESS_NEMESIS]
+    return {"valid?": bool(res.valid), "error-count": res.error_count, "final-reads": finals,
+            "acceptable": [[ranges[2 * i], ranges[2 * i + 1]] for i in range(min(n.value, 256))]}
+
+
+def encode_pn_history(ops):
+    """Jepsen-shaped pn-counter ops ({type, f, value[, final?, process]}) -> rows, for msim_check_pn_rows."""
+    tkw = {v: k for k, v in TYPE_KW.items()}
+    rows = np.zeros(len(ops), dtype=OP_DT)
+    for i, op in enumerate(ops):
+        rows["time_len"][i] = i * 1000
+        v = op.get("value")
+        rows["value"][i] = 0xFFFFFFFF if v is None else (int(v) & 0xFFFFFFFF)
+        f = A.F_ADD if op["f"] == ":add" else A.F_READ
+        rows["packed"][i] = tkw[op["type"]] | (f << 2) | ((1 if op.get("final?") else 0) << 11) | (int(op.get("process", 0)) << 12)
+    return rows
+
+
 def decode_history(rows, payload, n_nodes, workload=A.WL_BROADCAST):
     """Binary rows -> list of Jepsen op maps (SURVEY.md §8b 'History surface')."""
     ops = []
@@ -318,6 +348,9 @@ def decode_history(rows, payload, n_nodes, workload=A.WL_BROADCAST):
             op["value"] = [k, [v1, v2]] if f == A.F_CAS else [k, v1]
         elif f == A.F_TXN:
             op["value"] = decode_txn(payload[value:value + ln])
+        elif workload == A.WL_PN_COUNTER and f in (A.F_ADD, A.F_READ):  # pn_counter.clj:22-58: signed delta / counter value
+            signed = value - (1 << 32) if value & 0x80000000 else value
+            op["value"] = signed if (f == A.F_ADD or typ == A.T_OK) else None
         elif f == A.F_READ:
             op["value"] = bitmap_to_list(payload[value:value + ln]) if typ == A.T_OK else None
         elif f == A.F_ECHO:

@@ -325,20 +325,26 @@ static u32 node_timer_time(const sim_t *s, u32 node) {
   return m;
 }
 
+/* stores a copy of W state words as snapshot (tick, node): what a replicate message refers to */
+static void snap_put(sim_t *s, u32 tick, u32 node, const u32 *words) {
+  u32 idx = tick * s->N + node;
+  while (idx >= s->cap_snap) {
+    u32 nc = s->cap_snap ? s->cap_snap * 2 : 64;
+    s->snap = (u32 **)realloc(s->snap, nc * sizeof(u32 *));
+    for (u32 i = s->cap_snap; i < nc; i++) s->snap[i] = NULL;
+    s->cap_snap = nc;
+  }
+  u32 *cp = (u32 *)malloc(s->W * 4); memcpy(cp, words, s->W * 4);
+  free(s->snap[idx]);
+  s->snap[idx] = cp;
+  if (idx + 1 > s->n_snap) s->n_snap = idx + 1;
+}
+
 static void node_timer(sim_t *s, u32 node) {
   if (s->timer_next[node] <= s->T) { /* g_set.rb:33-38: every 5 s, replicate_full to all other nodes */
     s->timer_next[node] = s->T + 5000000u;
     u32 tick = s->tick[node]++;           /* the message carries (sender, tick): a reference to the sender's set then */
-    u32 idx = tick * s->N + node;
-    while (idx >= s->cap_snap) {
-      u32 nc = s->cap_snap ? s->cap_snap * 2 : 64;
-      s->snap = (u32 **)realloc(s->snap, nc * sizeof(u32 *));
-      for (u32 i = s->cap_snap; i < nc; i++) s->snap[i] = NULL;
-      s->cap_snap = nc;
-    }
-    u32 *cp = (u32 *)malloc(s->W * 4); memcpy(cp, seen_of(s, node), s->W * 4);
-    s->snap[idx] = cp;
-    if (idx + 1 > s->n_snap) s->n_snap = idx + 1;
+    snap_put(s, tick, node, seen_of(s, node));
     for (u32 i = 0; i < s->N; i++) if (i != node) out_send(s, node, i, M_REPLICATE, tick, 0);
     return;
   }
@@ -359,15 +365,28 @@ static void node_handle(sim_t *s, u32 node, const qent *q) {
   if (s->cfg.node_program == MSIM_NODE_TXN_SINGLE_KEY) { txn_node_handle(s, node, q); return; }
   switch (q->type) {
     case M_INIT: /* node.rb init handler -> init_ok; g-set starts its periodic task (node.rb:129-138) */
-      if (s->cfg.node_program == MSIM_NODE_G_SET) s->timer_next[node] = s->T;
+      if (s->cfg.node_program == MSIM_NODE_G_SET || s->cfg.node_program == MSIM_NODE_PN_COUNTER) s->timer_next[node] = s->T;
       out_send(s, node, q->src, M_INIT_OK, 0, q->b); break;
     case M_TOPOLOGY: s->nbr_known[node] = 1; out_send(s, node, q->src, M_TOPOLOGY_OK, 0, q->b); break;
     case M_ECHO: out_send(s, node, q->src, M_ECHO_OK, q->a, q->b); break; /* echo.rb:32-38 */
     case M_BROADCAST: node_broadcast(s, node, q); break;
     case M_BROADCAST_OK: node_broadcast_ok(s, node, q); break;
-    case M_READ: node_read(s, node, q); break;
-    case M_ADD: setbit(seen_of(s, node), q->a); out_send(s, node, q->src, M_ADD_OK, q->a, q->b); break; /* g_set.rb:17-21 */
-    case M_REPLICATE: { u32 *sn = seen_of(s, node), *v = s->snap[q->a * s->N + q->src]; for (u32 w = 0; w < s->W; w++) sn[w] |= v[w]; } break; /* g_set.rb:29-31 */
+    case M_READ:
+      if (s->cfg.node_program == MSIM_NODE_PN_COUNTER) { /* pn_counter.rb:69-71: increments minus decrements */
+        u32 *st = seen_of(s, node), v = 0;
+        for (u32 i = 0; i < s->N; i++) v += st[i] - st[s->N + i];
+        out_send(s, node, q->src, M_READ_OK, v, q->b);
+      } else node_read(s, node, q);
+      break;
+    case M_ADD:
+      if (s->cfg.node_program == MSIM_NODE_PN_COUNTER) { /* pn_counter.rb:75-81: the node's own slot of the inc / dec G-counter */
+        int d = (int)q->a;
+        if (d >= 0) seen_of(s, node)[node] += (u32)d; else seen_of(s, node)[s->N + node] += (u32)(-d);
+      } else setbit(seen_of(s, node), q->a); /* g_set.rb:17-21 */
+      out_send(s, node, q->src, M_ADD_OK, q->a, q->b); break;
+    case M_REPLICATE: { u32 *sn = seen_of(s, node), *v = s->snap[q->a * s->N + q->src];
+      if (s->cfg.node_program == MSIM_NODE_PN_COUNTER) { for (u32 w = 0; w < s->W; w++) if (v[w] > sn[w]) sn[w] = v[w]; } /* pn_counter.rb:41-45 element-wise max */
+      else for (u32 w = 0; w < s->W; w++) sn[w] |= v[w]; } break; /* g_set.rb:29-31 */
     default: break;
   }
 }
@@ -400,6 +419,7 @@ static void client_deliver(sim_t *s, u32 slot, const qent *q) {
   switch (q->type) {
     case M_READ_OK:
       if (s->cfg.workload == MSIM_WL_LIN_KV) client_complete(s, slot, MSIM_T_OK, 0, (c->value & 0xFFu) | ((q->a & 0xFFu) << 8) | 0xFF0000u, 0); /* [k v], lin_kv.clj:56-61 */
+      else if (s->cfg.workload == MSIM_WL_PN_COUNTER) client_complete(s, slot, MSIM_T_OK, 0, q->a, 0); /* (long (:value ..)), pn_counter.clj:52-55 */
       else client_complete(s, slot, MSIM_T_OK, 0, q->a & 0xFFFFFFu, q->a >> 24);
       break;
     case M_ECHO_OK: client_complete(s, slot, MSIM_T_OK, 0, q->a, 0); break;
@@ -453,7 +473,7 @@ static u32 stagger_us(const sim_t *s, u32 stream, u32 k, u64 period_us) { /* uni
   return (u32)(((u64)draw32(s, stream, k) * (2 * period_us)) >> 32);
 }
 static int any_busy(const sim_t *s, u32 n) { for (u32 i = 0; i < n; i++) if (s->cl[i].busy) return 1; return 0; }
-static int has_final(const sim_t *s) { return s->cfg.workload == MSIM_WL_BROADCAST || s->cfg.workload == MSIM_WL_G_SET; }
+static int has_final(const sim_t *s) { return s->cfg.workload == MSIM_WL_BROADCAST || s->cfg.workload == MSIM_WL_G_SET || s->cfg.workload == MSIM_WL_PN_COUNTER; }
 static int nem_on(const sim_t *s) { return (s->cfg.nemesis_mask & MSIM_NEMESIS_PARTITION) != 0; }
 static int gen_live(const sim_t *s) { return s->cfg.rate_mhz > 0 && s->gen_next < s->cutoff; }
 static int nem_live(const sim_t *s) { return nem_on(s) && s->nem_next < s->cutoff; }
@@ -557,6 +577,9 @@ static void sched_act(sim_t *s) {
           }
           else if (s->cfg.workload == MSIM_WL_ECHO) { c->m_f = MSIM_F_ECHO; c->m_value = (r_lo >> 4) & 127; } /* echo.clj:72-75 */
           else if (r_lo & 1) { c->m_f = MSIM_F_READ; c->m_value = MSIM_NO_VALUE; }  /* gen/mix */
+          else if (s->cfg.workload == MSIM_WL_PN_COUNTER) { /* {:f :add, :value (- (rand-int 10) 5)}, pn_counter.clj:134-135 */
+            c->m_f = MSIM_F_ADD; c->m_value = (u32)((int)((((r_lo >> 4) & 0xFFFFu) * 10u) >> 16) - 5);
+          }
           else {
             c->m_f = s->cfg.workload == MSIM_WL_BROADCAST ? MSIM_F_BROADCAST : MSIM_F_ADD;
             if (s->next_value >= s->cfg.max_values) { s->meta.flags |= MSIM_FLAG_VALUES_OVERFLOW; c->mark = 0; s->phase = PH_DONE; return; }
@@ -571,7 +594,7 @@ static void sched_act(sim_t *s) {
     case PH_SLEEP: if (T >= s->sleep_until) s->phase = PH_FINAL; else break; /* fallthrough */
     case PH_FINAL: /* (gen/clients (gen/each-thread {:f :read [:final? true]})), broadcast.clj:240, g_set.clj:61 */
       for (u32 i = 0; i < s->C; i++) { struct cl *c = &s->cl[i]; c->mark = 1; c->kind = K_OP; c->m_f = MSIM_F_READ; c->m_value = MSIM_NO_VALUE;
-        c->m_final = s->cfg.workload == MSIM_WL_BROADCAST; }
+        c->m_final = s->cfg.workload == MSIM_WL_BROADCAST || s->cfg.workload == MSIM_WL_PN_COUNTER; } /* pn_counter.clj:137 */
       s->phase = PH_FINAL_WAIT; break;
     default: break;
   }
@@ -789,12 +812,21 @@ int oracle_node_trace(const msim_config *cfg, uint32_t node, const uint32_t *in,
   sim_t *s = sim_new(cfg, 0, rows, payload);
   if (!s || node >= s->N) { free(rows); return -1; }
   u32 n = 0;
+  u32 *stg = (u32 *)calloc(s->W + 1, 4); /* staging for a peer's replicate payload: inputs of type 0xFE set word a := b */
   for (u32 i = 0; i < n_in; i++) {
     const u32 *m = in + 4 * i;
     s->n_out = 0;
     if (m[1] == 0) {
       s->T += m[2];
       while (node_timer_time(s, node) <= s->T) node_timer(s, node);
+    } else if (m[1] == 0xFE) {
+      if (m[2] < s->W) stg[m[2]] = m[3];
+    } else if (m[1] == M_REPLICATE && m[0] < s->N && m[0] != node) { /* a peer's replicate: its payload is the staged words */
+      u32 tick = s->tick[m[0]]++;
+      snap_put(s, tick, m[0], stg);
+      memset(stg, 0, s->W * 4);
+      qent q = {s->T, i, tick, 0, (u8)m[0], (u8)M_REPLICATE, NULL};
+      node_handle(s, node, &q);
     } else {
       qent q = {s->T, i, m[2], m[3], (u8)m[0], (u8)m[1]};
       if (q.type == M_BROADCAST || q.type == M_ADD) { if (q.a + 1 > s->next_value) s->next_value = q.a + 1; }
@@ -806,7 +838,8 @@ int oracle_node_trace(const msim_config *cfg, uint32_t node, const uint32_t *in,
       if (s->out[k].type == M_REPLICATE && final_set) memcpy(final_set, s->snap[s->out[k].a * s->N + node], s->W * 4); /* last replicated value */
     }
   }
-  if (final_set && cfg->node_program != MSIM_NODE_G_SET) memcpy(final_set, seen_of(s, node), s->W * 4);
+  if (final_set && cfg->node_program != MSIM_NODE_G_SET && cfg->node_program != MSIM_NODE_PN_COUNTER) memcpy(final_set, seen_of(s, node), s->W * 4);
+  free(stg);
   sim_free(s); free(rows);
   return (int)n;
 }

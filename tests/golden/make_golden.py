@@ -112,6 +112,21 @@ def main():
             msg("c10", "n1", type="read", msg_id=4),
             {"wait": 5.3},                                                     # setInterval(5000): replicate to all peers
         ])}
+    # ---- PN-counter CRDT: demo/js/crdt_pn_counter.js (workload/pn_counter.clj) ----
+    cases["crdt_pn_counter.js"] = {
+        "source": "demo/js/crdt_pn_counter.js", "node": "n1", "node_ids": nodes5,
+        "steps": run_script(["node", "crdt_pn_counter.js"], os.path.join(REF, "demo/js"), [
+            msg("c0", "n1", type="init", msg_id=1, node_id="n1", node_ids=nodes5),
+            msg("c10", "n1", type="add", msg_id=1, delta=3),
+            msg("c10", "n1", type="add", msg_id=2, delta=-2),
+            msg("c10", "n1", type="add", msg_id=3, delta=0),
+            msg("c10", "n1", type="read", msg_id=4),
+            msg("n2", "n1", type="replicate", value={"plus": {"n2": 4, "n1": 1, "n0": 7}, "minus": {"n0": 2, "n1": 5}}),
+            msg("c10", "n1", type="read", msg_id=5),
+            msg("n3", "n1", type="replicate", value={"plus": {"n2": 1}, "minus": {"n3": 9}}),
+            msg("c10", "n1", type="read", msg_id=6),
+            {"wait": 5.3},                                                     # setInterval(5000): replicate to all peers
+        ])}
     with open(OUT, "w") as f:
         json.dump({"generated_by": "tests/golden/make_golden.py", "reference": "jepsen-io/maelstrom demo node programs",
                    "cases": cases}, f, indent=1, sort_keys=True)

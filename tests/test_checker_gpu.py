@@ -107,3 +107,16 @@ def test_txn_list_append_checker_on_engine_histories(lib):
         rows, pay = eng.raw_history(3)
         one = E.check_txn_history(rows, pay)
         assert one["valid?"] is True and one["txn-count"] == int(res["attempt_count"][3])
+
+
+def test_pn_counter_checker_on_engine_histories(lib):
+    cfg = E.test_config("pn-counter", node_count=5, rate=50, time_limit=10, latency=20, latency_dist="exponential", p_loss=0.05, seed=12)
+    with E.Engine(cfg) as eng:
+        eng.run(0, 16)
+        eng.check()
+        eng.fetch()
+        res = eng.check_results()
+        assert (res["valid"] == 1).all() and (res["error_count"] == 0).all() and (res["attempt_count"] >= 1).all()
+        rows, _ = eng.raw_history(5)
+        one = E.check_pn_history(rows)
+        assert one["valid?"] is True and len(one["final-reads"]) == int(res["attempt_count"][5])

@@ -170,6 +170,53 @@ def test_crdt_gset_js(lib):
         assert sorted(got, key=repr) == ref, (si, got, st["out"])
 
 
+def test_crdt_pn_counter_js(lib):
+    """demo/js/crdt_pn_counter.js (== demo/ruby/pn_counter.rb): adds into the node's own slot of the inc / dec G-counter,
+    read = increments - decrements, merge = element-wise max of a peer's replicate payload, replicate to every other
+    node on the 5 s tick with the merged state."""
+    case = GOLD["crdt_pn_counter.js"]
+    ids = case["node_ids"]
+    n = len(ids)
+    cfg = E.test_config("pn-counter", node_count=n, rate=5, time_limit=5)
+    inputs, names, step_of = [], {}, []
+    for si, st in enumerate(case["steps"]):
+        if "in" not in st:
+            inputs.append([0, 0, st["wait_ms"] * 1000, 0]); step_of.append(si); continue
+        m = st["in"]; b = m["body"]
+        if b["type"] == "replicate":   # stage the payload (word i = plus[n_i], word n+i = minus[n_i]), then deliver it
+            for k, v in b["value"]["plus"].items():
+                inputs.append([0, 0xFE, ids.index(k), v]); step_of.append(-1)
+            for k, v in b["value"]["minus"].items():
+                inputs.append([0, 0xFE, n + ids.index(k), v]); step_of.append(-1)
+            inputs.append([_ep(m["src"], n), _t("replicate"), 0, 0]); step_of.append(si)
+            continue
+        a = b.get("delta", 0) & 0xFFFFFFFF
+        inputs.append([_ep(m["src"], n), _t(b["type"]), a, b["msg_id"]]); step_of.append(si)
+        names[_ep(m["src"], n)] = m["src"]
+    out, pay, fin = _trace(cfg, 1, inputs)
+    tn = {_t(k): k for k in ("init_ok", "add_ok", "read_ok", "replicate")}
+    for si, st in enumerate(case["steps"]):
+        got = []
+        for o in out:
+            if step_of[int(o[0])] != si:
+                continue
+            typ, dest = tn[int(o[2])], int(o[1])
+            if typ == "replicate":
+                state = {"plus": {ids[i]: int(fin[i]) for i in range(n) if fin[i]}, "minus": {ids[i]: int(fin[n + i]) for i in range(n) if fin[n + i]}}
+                got.append((f"n{dest}", typ, json.dumps(state, sort_keys=True), None, False))
+            elif typ == "read_ok":
+                got.append((names[dest], typ, int(np.int32(np.uint32(o[3]))), int(o[4]), False))
+            else:
+                got.append((names[dest], typ, None, int(o[4]), False))
+        ref = []
+        for o in st["out"]:
+            b = o["body"]
+            pl = json.dumps(b["value"], sort_keys=True) if b["type"] == "replicate" else b.get("value")
+            ref.append((o["dest"], b["type"], pl, b.get("in_reply_to"), "msg_id" in b))
+        assert sorted(got, key=repr) == sorted(ref, key=repr), (si, got, st["out"])
+    assert len([o for o in out if tn[int(o[2])] == "replicate"]) == n - 1
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # Raft (SURVEY.md §8a row a16): golden vectors recorded from the reference's runnable demo/python/raft.py
 # ------------------------------------------------------------------------------------------------------------------

@@ -185,3 +185,20 @@ def test_txn_list_append_journal_parity(lib):
                         seed=62, journal_capacity=40000)
     ora = _compare(cfg, 0, 4)
     assert (ora.meta["n_events"] > 2000).all()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(),
+    dict(latency=20),
+    dict(latency=50, latency_dist="exponential", p_loss=0.1),
+    dict(latency=10, nemesis=["partition"], nemesis_interval=4, time_limit=20),
+    dict(node_count=25, rate=100, latency=100, latency_dist="uniform"),
+    dict(concurrency=10, latency=5),
+    dict(journal_capacity=60000, latency=5),
+])
+def test_pn_counter_parity(lib, kw):
+    """workload/pn_counter.clj over the CRDT node of demo/ruby/pn_counter.rb, both kernel layouts."""
+    base = dict(node_count=5, rate=20, time_limit=12, seed=71)
+    base.update(kw)
+    cfg = E.test_config("pn-counter", **base)
+    _compare(cfg, 0, 6)

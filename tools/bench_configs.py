@@ -24,6 +24,7 @@ CONFIGS = {
     "cfg3 g-set n=100 lat100 exponential p_loss 0.5": (dict(workload="g-set", node_count=100, rate=100, time_limit=20, latency=100, latency_dist="exponential", p_loss=0.5), 16384),
     "cfg4 lin-kv raft n=5 c=10 rate30 60s": (dict(workload="lin-kv", bin="raft", node_count=5, rate=30, time_limit=60), 8192),
     "cfg4 lin-kv raft + partitions lat10": (dict(workload="lin-kv", bin="raft", node_count=5, rate=30, time_limit=60, latency=10, nemesis=["partition"], nemesis_interval=10), 8192),
+    "pn-counter n=5 rate100 20s lat100 exponential": (dict(workload="pn-counter", node_count=5, rate=100, time_limit=20, latency=100, latency_dist="exponential"), 16384),
     "cfg5 txn-list-append n=5 rate100 30s lat5 + partitions": (dict(workload="txn-list-append", node_count=5, rate=100, time_limit=30, latency=5,
                                                                      nemesis=["partition"], nemesis_interval=10), 32768),
 }
