@@ -42,7 +42,7 @@ enum {
 
 /* ---- configuration (mirrors the CLI option map, core.clj:136-229, + ensemble/determinism fields) -- */
 enum { MSIM_WL_ECHO = 0, MSIM_WL_BROADCAST = 1, MSIM_WL_G_SET = 2, MSIM_WL_LIN_KV = 3, MSIM_WL_TXN_LIST_APPEND = 4,
-       MSIM_WL_PN_COUNTER = 5 /* workload/pn_counter.clj */ };
+       MSIM_WL_PN_COUNTER = 5 /* workload/pn_counter.clj */, MSIM_WL_G_COUNTER = 6 /* workload/g_counter.clj: pn-counter without negative adds */ };
 
 /* Built-in node programs (the `--bin` of the reference). */
 enum {

@@ -14,7 +14,7 @@ ABI_VERSION = 1
 
 # enums (include/maelsim.h)
 OK, E_INVALID, E_NO_DEVICE, E_HIP, E_NOMEM, E_RANGE, E_UNSUPPORTED, E_OVERFLOW = 0, -1, -2, -3, -4, -5, -6, -7
-WL_ECHO, WL_BROADCAST, WL_G_SET, WL_LIN_KV, WL_TXN_LIST_APPEND, WL_PN_COUNTER = range(6)
+WL_ECHO, WL_BROADCAST, WL_G_SET, WL_LIN_KV, WL_TXN_LIST_APPEND, WL_PN_COUNTER, WL_G_COUNTER = range(7)
 NODE_ECHO, NODE_BCAST_FF, NODE_BCAST_FF_ECHOBACK, NODE_BCAST_ACK_RETRY, NODE_BCAST_RPC_ALL, NODE_G_SET, NODE_RAFT, NODE_TXN_SINGLE_KEY, NODE_PN_COUNTER = range(9)
 LAT_CONSTANT, LAT_UNIFORM, LAT_EXPONENTIAL = range(3)
 TOPO_GRID, TOPO_LINE, TOPO_TOTAL, TOPO_TREE2, TOPO_TREE3, TOPO_TREE4 = range(6)

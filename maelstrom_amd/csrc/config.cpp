@@ -30,7 +30,7 @@ extern "C" int msim_config_defaults(msim_config *cfg, uint32_t workload, uint32_
     case MSIM_WL_BROADCAST: cfg->node_program = MSIM_NODE_BCAST_FF; break;
     case MSIM_WL_G_SET: cfg->node_program = MSIM_NODE_G_SET; break;
     case MSIM_WL_TXN_LIST_APPEND: cfg->node_program = MSIM_NODE_TXN_SINGLE_KEY; break;
-    case MSIM_WL_PN_COUNTER: cfg->node_program = MSIM_NODE_PN_COUNTER; break;
+    case MSIM_WL_PN_COUNTER: case MSIM_WL_G_COUNTER: cfg->node_program = MSIM_NODE_PN_COUNTER; break;
     default: cfg->node_program = MSIM_NODE_RAFT; break;
   }
   cfg->n_nodes = n_nodes;
@@ -74,7 +74,7 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
   if (c->concurrency == 0) c->concurrency = c->n_nodes;
   uint32_t slots = c->concurrency > c->n_nodes ? c->concurrency : c->n_nodes;
   if (c->n_nodes + slots > 255) { set_err(err, errlen, "n_nodes + max(concurrency, n_nodes) must be <= 255"); return MSIM_E_INVALID; }
-  if (c->workload > MSIM_WL_PN_COUNTER) { set_err(err, errlen, "unknown workload"); return MSIM_E_INVALID; }
+  if (c->workload > MSIM_WL_G_COUNTER) { set_err(err, errlen, "unknown workload"); return MSIM_E_INVALID; }
   if (c->latency_dist > MSIM_LAT_EXPONENTIAL) { set_err(err, errlen, "latency_dist must be constant, uniform, or exponential"); return MSIM_E_INVALID; }
   if (c->latency_dist == MSIM_LAT_EXPONENTIAL && c->latency_mean_ms == 0) {
     // net.clj:77 (exponential-distribution (/ mean)) throws "Divide by zero" for --latency 0
@@ -93,7 +93,7 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
     case MSIM_WL_G_SET: ok = c->node_program == MSIM_NODE_G_SET; break;
     case MSIM_WL_LIN_KV: ok = c->node_program == MSIM_NODE_RAFT; break;
     case MSIM_WL_TXN_LIST_APPEND: ok = c->node_program == MSIM_NODE_TXN_SINGLE_KEY; break;
-    case MSIM_WL_PN_COUNTER: ok = c->node_program == MSIM_NODE_PN_COUNTER; break;
+    case MSIM_WL_PN_COUNTER: case MSIM_WL_G_COUNTER: ok = c->node_program == MSIM_NODE_PN_COUNTER; break;
     default: break;
   }
   if (!ok) { set_err(err, errlen, "node_program does not implement this workload"); return MSIM_E_INVALID; }
@@ -115,7 +115,7 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
   if (c->nemesis_mask) nem_ops = 4 * (c->time_limit_ms / c->nemesis_interval_ms + 1) + 16;
   if (c->workload == MSIM_WL_LIN_KV && c->concurrency % (2 * c->n_nodes)) {
     set_err(err, errlen, "lin-kv: concurrency must be a multiple of 2 x node-count ([upstream] independent/concurrent-generator)"); return MSIM_E_INVALID; }
-  const bool pn = c->workload == MSIM_WL_PN_COUNTER;
+  const bool pn = c->workload == MSIM_WL_PN_COUNTER || c->workload == MSIM_WL_G_COUNTER;
   if (pn && c->n_nodes > 32) { set_err(err, errlen, "pn-counter: at most 32 nodes in this build"); return MSIM_E_UNSUPPORTED; }
   // pn-counter: a node's state is 2 x n_nodes counters (one G-counter for increments, one for decrements): max_values / 32 words
   if (pn) c->max_values = 64 * c->n_nodes;

@@ -36,7 +36,7 @@
 enum { M_INIT = 1, M_INIT_OK, M_TOPOLOGY, M_TOPOLOGY_OK, M_ECHO, M_ECHO_OK, M_BROADCAST, M_BROADCAST_OK,
        M_READ, M_READ_OK, M_ADD, M_ADD_OK, M_REPLICATE };
 // RNG streams
-enum { S_GEN = 1, S_LATENCY = 4, S_LOSS = 5,
+enum { S_GEN = 1, S_GEN2 = 2, S_LATENCY = 4, S_LOSS = 5,
        S_NEM_STAGGER = 7, S_NEM_SPEC = 8, S_NEM_SHUFFLE = 9, S_NEM_PICK = 10 };
 enum { PH_INIT, PH_INIT_WAIT, PH_TOPO, PH_TOPO_WAIT, PH_MAIN_START, PH_MAIN, PH_DRAIN, PH_NEM_FINAL,
        PH_SLEEP, PH_FINAL, PH_FINAL_WAIT, PH_DONE };
@@ -498,6 +498,13 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
               u32 f, val = MSIM_NO_VALUE;
               bool ok = true;
               if (IS_ECHO) { f = MSIM_F_ECHO; val = (r_lo >> 4) & 127; }
+              else if (IS_PN && p.cfg.workload == MSIM_WL_G_COUNTER) {
+                // g_counter.clj:37-41: (gen/filter ...) skips negative adds and takes the mix's next op at once
+                u32 rr = r_lo, a = 0;
+                int d = (int)((((rr >> 4) & 0xFFFFu) * 10u) >> 16) - 5;
+                while (!(rr & 1) && d < 0 && a < 15) { a++; rr = (u32)draw64(key, S_GEN2, (u64)kk * 16 + a); d = (int)((((rr >> 4) & 0xFFFFu) * 10u) >> 16) - 5; }
+                if ((rr & 1) || d < 0) f = MSIM_F_READ; else { f = MSIM_F_ADD; val = (u32)d; }
+              }
               else if (r_lo & 1) f = MSIM_F_READ;
               else {
                 f = IS_BCAST ? MSIM_F_BROADCAST : MSIM_F_ADD;
@@ -1045,7 +1052,7 @@ extern "C" int msim_check(msim_ctx *ctx) {
   if (!ctx->ran) { ctx->err = "msim_check before msim_run"; return MSIM_E_RANGE; }
   if (ctx->cfg.workload == MSIM_WL_LIN_KV) return msim_check_lin_kv_host(ctx);
   if (ctx->cfg.workload == MSIM_WL_TXN_LIST_APPEND) return msim_check_txn_host(ctx);
-  if (ctx->cfg.workload == MSIM_WL_PN_COUNTER) return msim_check_pn_host(ctx);
+  if (ctx->cfg.workload == MSIM_WL_PN_COUNTER || ctx->cfg.workload == MSIM_WL_G_COUNTER) return msim_check_pn_host(ctx);
   return msim_check_launch(ctx);
 }
 

@@ -22,7 +22,7 @@ CHECK_DT = np.dtype([("valid", "<u4"), ("attempt_count", "<u4"), ("stable_count"
                      ("ok_count", "<u4"), ("fail_count", "<u4"), ("info_count", "<u4")])
 
 WORKLOADS = {"echo": A.WL_ECHO, "broadcast": A.WL_BROADCAST, "g-set": A.WL_G_SET, "lin-kv": A.WL_LIN_KV,
-             "txn-list-append": A.WL_TXN_LIST_APPEND, "pn-counter": A.WL_PN_COUNTER}
+             "txn-list-append": A.WL_TXN_LIST_APPEND, "pn-counter": A.WL_PN_COUNTER, "g-counter": A.WL_G_COUNTER}
 NODE_PROGRAMS = {"echo": A.NODE_ECHO, "broadcast-ff": A.NODE_BCAST_FF, "broadcast-ff-echoback": A.NODE_BCAST_FF_ECHOBACK,
                  "broadcast-ack-retry": A.NODE_BCAST_ACK_RETRY, "broadcast-rpc-all": A.NODE_BCAST_RPC_ALL,
                  "g-set": A.NODE_G_SET, "raft": A.NODE_RAFT, "single-key-txn": A.NODE_TXN_SINGLE_KEY,
@@ -348,7 +348,7 @@ def decode_history(rows, payload, n_nodes, workload=A.WL_BROADCAST):
             op["value"] = [k, [v1, v2]] if f == A.F_CAS else [k, v1]
         elif f == A.F_TXN:
             op["value"] = decode_txn(payload[value:value + ln])
-        elif workload == A.WL_PN_COUNTER and f in (A.F_ADD, A.F_READ):  # pn_counter.clj:22-58: signed delta / counter value
+        elif workload in (A.WL_PN_COUNTER, A.WL_G_COUNTER) and f in (A.F_ADD, A.F_READ):  # pn_counter.clj:22-58: signed delta / counter value
             signed = value - (1 << 32) if value & 0x80000000 else value
             op["value"] = signed if (f == A.F_ADD or typ == A.T_OK) else None
         elif f == A.F_READ:

@@ -419,7 +419,7 @@ static void client_deliver(sim_t *s, u32 slot, const qent *q) {
   switch (q->type) {
     case M_READ_OK:
       if (s->cfg.workload == MSIM_WL_LIN_KV) client_complete(s, slot, MSIM_T_OK, 0, (c->value & 0xFFu) | ((q->a & 0xFFu) << 8) | 0xFF0000u, 0); /* [k v], lin_kv.clj:56-61 */
-      else if (s->cfg.workload == MSIM_WL_PN_COUNTER) client_complete(s, slot, MSIM_T_OK, 0, q->a, 0); /* (long (:value ..)), pn_counter.clj:52-55 */
+      else if (s->cfg.workload == MSIM_WL_PN_COUNTER || s->cfg.workload == MSIM_WL_G_COUNTER) client_complete(s, slot, MSIM_T_OK, 0, q->a, 0); /* (long (:value ..)), pn_counter.clj:52-55 */
       else client_complete(s, slot, MSIM_T_OK, 0, q->a & 0xFFFFFFu, q->a >> 24);
       break;
     case M_ECHO_OK: client_complete(s, slot, MSIM_T_OK, 0, q->a, 0); break;
@@ -473,7 +473,8 @@ static u32 stagger_us(const sim_t *s, u32 stream, u32 k, u64 period_us) { /* uni
   return (u32)(((u64)draw32(s, stream, k) * (2 * period_us)) >> 32);
 }
 static int any_busy(const sim_t *s, u32 n) { for (u32 i = 0; i < n; i++) if (s->cl[i].busy) return 1; return 0; }
-static int has_final(const sim_t *s) { return s->cfg.workload == MSIM_WL_BROADCAST || s->cfg.workload == MSIM_WL_G_SET || s->cfg.workload == MSIM_WL_PN_COUNTER; }
+static int counter_workload(const sim_t *s) { return s->cfg.workload == MSIM_WL_PN_COUNTER || s->cfg.workload == MSIM_WL_G_COUNTER; }
+static int has_final(const sim_t *s) { return s->cfg.workload == MSIM_WL_BROADCAST || s->cfg.workload == MSIM_WL_G_SET || counter_workload(s); }
 static int nem_on(const sim_t *s) { return (s->cfg.nemesis_mask & MSIM_NEMESIS_PARTITION) != 0; }
 static int gen_live(const sim_t *s) { return s->cfg.rate_mhz > 0 && s->gen_next < s->cutoff; }
 static int nem_live(const sim_t *s) { return nem_on(s) && s->nem_next < s->cutoff; }
@@ -576,6 +577,12 @@ static void sched_act(sim_t *s) {
             c->m_f = MSIM_F_TXN; c->m_value = ref;
           }
           else if (s->cfg.workload == MSIM_WL_ECHO) { c->m_f = MSIM_F_ECHO; c->m_value = (r_lo >> 4) & 127; } /* echo.clj:72-75 */
+          else if (s->cfg.workload == MSIM_WL_G_COUNTER) { /* g_counter.clj:37-41: (gen/filter ...) skips negative adds, takes the next op of the mix at once */
+            u32 rr = r_lo, a = 0;
+            int d = (int)((((rr >> 4) & 0xFFFFu) * 10u) >> 16) - 5;
+            while (!(rr & 1) && d < 0 && a < 15) { a++; rr = (u32)draw64(s, S_GEN2, (u64)k * 16 + a); d = (int)((((rr >> 4) & 0xFFFFu) * 10u) >> 16) - 5; }
+            if ((rr & 1) || d < 0) { c->m_f = MSIM_F_READ; c->m_value = MSIM_NO_VALUE; } else { c->m_f = MSIM_F_ADD; c->m_value = (u32)d; }
+          }
           else if (r_lo & 1) { c->m_f = MSIM_F_READ; c->m_value = MSIM_NO_VALUE; }  /* gen/mix */
           else if (s->cfg.workload == MSIM_WL_PN_COUNTER) { /* {:f :add, :value (- (rand-int 10) 5)}, pn_counter.clj:134-135 */
             c->m_f = MSIM_F_ADD; c->m_value = (u32)((int)((((r_lo >> 4) & 0xFFFFu) * 10u) >> 16) - 5);
@@ -594,7 +601,7 @@ static void sched_act(sim_t *s) {
     case PH_SLEEP: if (T >= s->sleep_until) s->phase = PH_FINAL; else break; /* fallthrough */
     case PH_FINAL: /* (gen/clients (gen/each-thread {:f :read [:final? true]})), broadcast.clj:240, g_set.clj:61 */
       for (u32 i = 0; i < s->C; i++) { struct cl *c = &s->cl[i]; c->mark = 1; c->kind = K_OP; c->m_f = MSIM_F_READ; c->m_value = MSIM_NO_VALUE;
-        c->m_final = s->cfg.workload == MSIM_WL_BROADCAST || s->cfg.workload == MSIM_WL_PN_COUNTER; } /* pn_counter.clj:137 */
+        c->m_final = s->cfg.workload == MSIM_WL_BROADCAST || s->cfg.workload == MSIM_WL_PN_COUNTER || s->cfg.workload == MSIM_WL_G_COUNTER; } /* pn_counter.clj:137 */
       s->phase = PH_FINAL_WAIT; break;
     default: break;
   }

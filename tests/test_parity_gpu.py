@@ -202,3 +202,10 @@ def test_pn_counter_parity(lib, kw):
     base.update(kw)
     cfg = E.test_config("pn-counter", **base)
     _compare(cfg, 0, 6)
+
+
+def test_g_counter_parity(lib):
+    cfg = E.test_config("g-counter", node_count=5, rate=50, time_limit=10, latency=10, seed=72)
+    _compare(cfg, 0, 6)
+    cfg = E.test_config("g-counter", node_count=7, concurrency=14, rate=50, time_limit=8, latency=30, latency_dist="exponential", p_loss=0.05, seed=73)
+    _compare(cfg, 0, 4)

@@ -70,3 +70,20 @@ def test_oracle_histories_converge_and_pass_the_checker(kw):
             assert len(finals) == 5 and {o["value"] for o in finals} == {total}
         # g-counter style message accounting (KAT-4 shape): every tick N*(N-1) replicate messages
         assert int(r.stats["servers_send"][i]) % (5 * 4) == 0
+
+
+def test_g_counter_never_adds_a_negative_delta():
+    """workload/g_counter.clj:37-41: the pn-counter workload with negative adds filtered out of the generator."""
+    cfg = E.test_config("g-counter", node_count=5, rate=50, time_limit=10, latency=10, seed=3)
+    assert cfg.node_program == A.NODE_PN_COUNTER
+    r = O.run(cfg, 0, 3)
+    for i in range(3):
+        rows, pay = r.history(i)
+        ops = [o for o in E.decode_history(rows, pay, 5, A.WL_G_COUNTER) if o["process"] != ":nemesis"]
+        adds = [o["value"] for o in ops if o["f"] == ":add" and o["type"] == ":invoke"]
+        reads = [o for o in ops if o["f"] == ":read" and o["type"] == ":invoke" and not o.get("final?")]
+        assert adds and min(adds) >= 0 and max(adds) <= 4
+        assert 1.3 < len(reads) / len(adds) < 3.2      # 1/2 : 1/4 after the filter
+        assert E.check_pn_history(rows)["valid?"] is True
+        finals = [o["value"] for o in ops if o.get("final?") and o["type"] == ":ok"]
+        assert finals == [sum(o["value"] for o in ops if o["f"] == ":add" and o["type"] == ":ok")] * 5
