@@ -199,6 +199,9 @@ def main():
                     out["roofline"]["traffic_source"] = "profiles/r01_headline_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
             except Exception:
                 pass
+        # the reference's only published figure for this path (README.md:39-42; other hardware, not reproduced here: no JVM)
+        out["reference_published"] = {"value": 6.0e4, "unit": "msgs/s", "hardware": "48-way Xeon", "source": "jepsen-io/maelstrom README.md:39-42",
+                                      "note": "quoted for scale only; vs_baseline stays null because BASELINE.json publishes no number for this metric"}
         if gather:
             out["history_gather"] = gather
         if args.cpu_sample > 0:

@@ -42,7 +42,8 @@ enum {
 
 /* ---- configuration (mirrors the CLI option map, core.clj:136-229, + ensemble/determinism fields) -- */
 enum { MSIM_WL_ECHO = 0, MSIM_WL_BROADCAST = 1, MSIM_WL_G_SET = 2, MSIM_WL_LIN_KV = 3, MSIM_WL_TXN_LIST_APPEND = 4,
-       MSIM_WL_PN_COUNTER = 5 /* workload/pn_counter.clj */, MSIM_WL_G_COUNTER = 6 /* workload/g_counter.clj: pn-counter without negative adds */ };
+       MSIM_WL_PN_COUNTER = 5 /* workload/pn_counter.clj */, MSIM_WL_G_COUNTER = 6 /* workload/g_counter.clj: pn-counter without negative adds */,
+       MSIM_WL_UNIQUE_IDS = 7 /* workload/unique_ids.clj */ };
 
 /* Built-in node programs (the `--bin` of the reference). */
 enum {
@@ -58,6 +59,7 @@ enum {
   MSIM_NODE_TXN_SINGLE_KEY = 7, /* demo/clojure/single_key_txn.clj:116-180: whole database under one lin-kv key:
                                    read root -> apply txn -> cas root (create_if_not_exists), conflict => error 30.
                                    Brings the `lin-kv` service endpoint with it (service.clj:31-61,141-155,290-296) */
+  MSIM_NODE_FLAKE_IDS = 9,      /* demo/clojure/flake_ids.clj:10-33: id = [seconds, counter within that second, node id] */
   MSIM_NODE_PN_COUNTER = 8      /* demo/ruby/pn_counter.rb:8-121 == demo/js/crdt_pn_counter.js: increments and decrements in two
                                    per-node G-counters, merged by element-wise max, replicated to all others every 5 s      */
 };
@@ -115,6 +117,8 @@ typedef struct msim_config {
  * (0xFF = nil): read [k v], write [k v], cas [k [v v']].
  * pn-counter ops (pn_counter.clj:22-58,134-137): `value` of an :add is the delta, of an :ok :read the counter, both as
  * two's-complement int32; a read's :invoke (and :fail / :info) has value nil.
+ * unique-ids ops (unique_ids.clj:38-55): `value` of an :ok :generate is the flake id [time count node] packed as
+ * time << 20 | count << 5 | node index (time in s, flake_ids.clj:19).
  * txn ops (txn_list_append.clj:27-39,54-60): `value` = payload offset, len = words of the transaction
  * [[f k v] ...].  One header word per micro-op: bit 0 f (0 = :r, 1 = :append), bits 1-15 key, bits 16-23 the appended
  * element (:append) or the length n of the list read (:r; 0xFF = nil, i.e. an :invoke or a key that does not exist);
@@ -128,7 +132,7 @@ typedef struct msim_op {
 enum { MSIM_T_INVOKE = 0, MSIM_T_OK = 1, MSIM_T_FAIL = 2, MSIM_T_INFO = 3 };
 enum { MSIM_F_ECHO = 0, MSIM_F_BROADCAST = 1, MSIM_F_READ = 2, MSIM_F_ADD = 3,
        MSIM_F_START_PARTITION = 4, MSIM_F_STOP_PARTITION = 5,
-       MSIM_F_WRITE = 6, MSIM_F_CAS = 7, MSIM_F_TXN = 8 };
+       MSIM_F_WRITE = 6, MSIM_F_CAS = 7, MSIM_F_TXN = 8, MSIM_F_GENERATE = 9 };
 enum { MSIM_ERR_NONE = 0, MSIM_ERR_NET_TIMEOUT = 1 /* client.clj:158-162 */, MSIM_ERR_RPC = 2,
        /* RPC errors of resources/errors.edn, as :error [name text] (client.clj:163-172) */
        MSIM_ERR_TEMPORARILY_UNAVAILABLE = 3 /* code 11 */, MSIM_ERR_KEY_DOES_NOT_EXIST = 4 /* code 20 */,
@@ -173,7 +177,7 @@ enum { MSIM_M_INIT = 1, MSIM_M_INIT_OK, MSIM_M_TOPOLOGY, MSIM_M_TOPOLOGY_OK, MSI
        MSIM_M_BROADCAST_OK, MSIM_M_READ, MSIM_M_READ_OK, MSIM_M_ADD, MSIM_M_ADD_OK, MSIM_M_REPLICATE,
        MSIM_M_WRITE, MSIM_M_WRITE_OK, MSIM_M_CAS, MSIM_M_CAS_OK, MSIM_M_ERROR,
        MSIM_M_REQUEST_VOTE, MSIM_M_REQUEST_VOTE_RES, MSIM_M_APPEND_ENTRIES, MSIM_M_APPEND_ENTRIES_RES,
-       MSIM_M_TXN, MSIM_M_TXN_OK };
+       MSIM_M_TXN, MSIM_M_TXN_OK, MSIM_M_GENERATE, MSIM_M_GENERATE_OK };
 
 /* Per-instance bookkeeping (not part of the algorithmic output bytes). */
 typedef struct msim_inst_meta {
@@ -263,6 +267,12 @@ int msim_check_txn_rows(const msim_op *rows, uint32_t n_rows, const uint32_t *pa
  * closed integer ranges.  out->valid 1/0; attempt_count = final reads, error_count = final reads outside the set,
  * stable_count = ranges in the set.  `ranges` (may be NULL) receives up to `cap` [lower, upper] pairs in ascending order,
  * *n_ranges the number of ranges (the reference's :acceptable).  Needs no device. */
+/* Host-only utility behind msim_check for unique-ids: [upstream] jepsen.checker/unique-ids (unique_ids.clj:67) — every
+ * :ok :generate value must be distinct.  out->attempt_count = :attempted-count (invocations), ok_count = :acknowledged-count,
+ * duplicated_count = number of distinct values acknowledged more than once, stable_latency_ms[0..1] = :range [min max] of the
+ * packed ids; valid = 1 iff duplicated_count == 0.  Needs no device. */
+int msim_check_unique_rows(const msim_op *rows, uint32_t n_rows, msim_check_result *out);
+
 int msim_check_pn_rows(const msim_op *rows, uint32_t n_rows, msim_check_result *out, int64_t *ranges, uint32_t cap, uint32_t *n_ranges);
 
 /* Copies the last run's outputs to host memory (pinned, owned by ctx, valid until next run/destroy). */

@@ -14,13 +14,13 @@ ABI_VERSION = 1
 
 # enums (include/maelsim.h)
 OK, E_INVALID, E_NO_DEVICE, E_HIP, E_NOMEM, E_RANGE, E_UNSUPPORTED, E_OVERFLOW = 0, -1, -2, -3, -4, -5, -6, -7
-WL_ECHO, WL_BROADCAST, WL_G_SET, WL_LIN_KV, WL_TXN_LIST_APPEND, WL_PN_COUNTER, WL_G_COUNTER = range(7)
-NODE_ECHO, NODE_BCAST_FF, NODE_BCAST_FF_ECHOBACK, NODE_BCAST_ACK_RETRY, NODE_BCAST_RPC_ALL, NODE_G_SET, NODE_RAFT, NODE_TXN_SINGLE_KEY, NODE_PN_COUNTER = range(9)
+WL_ECHO, WL_BROADCAST, WL_G_SET, WL_LIN_KV, WL_TXN_LIST_APPEND, WL_PN_COUNTER, WL_G_COUNTER, WL_UNIQUE_IDS = range(8)
+NODE_ECHO, NODE_BCAST_FF, NODE_BCAST_FF_ECHOBACK, NODE_BCAST_ACK_RETRY, NODE_BCAST_RPC_ALL, NODE_G_SET, NODE_RAFT, NODE_TXN_SINGLE_KEY, NODE_PN_COUNTER, NODE_FLAKE_IDS = range(10)
 LAT_CONSTANT, LAT_UNIFORM, LAT_EXPONENTIAL = range(3)
 TOPO_GRID, TOPO_LINE, TOPO_TOTAL, TOPO_TREE2, TOPO_TREE3, TOPO_TREE4 = range(6)
 NEMESIS_PARTITION = 1
 T_INVOKE, T_OK, T_FAIL, T_INFO = range(4)
-F_ECHO, F_BROADCAST, F_READ, F_ADD, F_START_PARTITION, F_STOP_PARTITION, F_WRITE, F_CAS, F_TXN = range(9)
+F_ECHO, F_BROADCAST, F_READ, F_ADD, F_START_PARTITION, F_STOP_PARTITION, F_WRITE, F_CAS, F_TXN, F_GENERATE = range(10)
 ERR_NONE, ERR_NET_TIMEOUT, ERR_RPC, ERR_TEMPORARILY_UNAVAILABLE, ERR_KEY_DOES_NOT_EXIST, ERR_PRECONDITION_FAILED, ERR_TXN_CONFLICT = range(7)
 SPEC_ONE, SPEC_MAJORITY, SPEC_MAJORITIES_RING, SPEC_MINORITY_THIRD = range(4)
 PROCESS_NEMESIS = 0xFFFFF
@@ -28,14 +28,14 @@ NO_VALUE = 0xFFFFFFFF
 FLAG_ROWS_OVERFLOW, FLAG_PAYLOAD_OVERFLOW, FLAG_INBOX_OVERFLOW, FLAG_VALUES_OVERFLOW, FLAG_ROUND_LIMIT, FLAG_JOURNAL_OVERFLOW, FLAG_ARENA_OVERRUN = 1, 2, 4, 8, 16, 32, 64
 MSG_TYPES = ["", "init", "init_ok", "topology", "topology_ok", "echo", "echo_ok", "broadcast", "broadcast_ok", "read", "read_ok",
              "add", "add_ok", "replicate", "write", "write_ok", "cas", "cas_ok", "error", "request_vote", "request_vote_res",
-             "append_entries", "append_entries_res", "txn", "txn_ok"]
+             "append_entries", "append_entries_res", "txn", "txn_ok", "generate", "generate_ok"]
 ANOMALIES = {1: "G0", 2: "G1a", 4: "G1b", 8: "G1c", 16: "G-single", 32: "G2", 64: "internal", 128: "duplicate-elements",
              256: "incompatible-order", 512: "realtime", 1024: "dirty-update"}
 MASK_WORDS = 4
 
 EXPORTS = [
     "msim_abi_version", "msim_device_count", "msim_config_defaults", "msim_config_finalize", "msim_create",
-    "msim_run", "msim_run_async", "msim_check", "msim_check_lin_kv_rows", "msim_check_txn_rows", "msim_check_pn_rows", "msim_fetch", "msim_history", "msim_net_stats_get", "msim_journal", "msim_meta",
+    "msim_run", "msim_run_async", "msim_check", "msim_check_lin_kv_rows", "msim_check_txn_rows", "msim_check_pn_rows", "msim_check_unique_rows", "msim_fetch", "msim_history", "msim_net_stats_get", "msim_journal", "msim_meta",
     "msim_check_results", "msim_device_buffers_get", "msim_last_kernel_ms", "msim_get_config",
     "msim_selftest_wave", "msim_last_error", "msim_destroy",
 ]

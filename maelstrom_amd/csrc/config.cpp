@@ -31,6 +31,7 @@ extern "C" int msim_config_defaults(msim_config *cfg, uint32_t workload, uint32_
     case MSIM_WL_G_SET: cfg->node_program = MSIM_NODE_G_SET; break;
     case MSIM_WL_TXN_LIST_APPEND: cfg->node_program = MSIM_NODE_TXN_SINGLE_KEY; break;
     case MSIM_WL_PN_COUNTER: case MSIM_WL_G_COUNTER: cfg->node_program = MSIM_NODE_PN_COUNTER; break;
+    case MSIM_WL_UNIQUE_IDS: cfg->node_program = MSIM_NODE_FLAKE_IDS; break;
     default: cfg->node_program = MSIM_NODE_RAFT; break;
   }
   cfg->n_nodes = n_nodes;
@@ -74,7 +75,7 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
   if (c->concurrency == 0) c->concurrency = c->n_nodes;
   uint32_t slots = c->concurrency > c->n_nodes ? c->concurrency : c->n_nodes;
   if (c->n_nodes + slots > 255) { set_err(err, errlen, "n_nodes + max(concurrency, n_nodes) must be <= 255"); return MSIM_E_INVALID; }
-  if (c->workload > MSIM_WL_G_COUNTER) { set_err(err, errlen, "unknown workload"); return MSIM_E_INVALID; }
+  if (c->workload > MSIM_WL_UNIQUE_IDS) { set_err(err, errlen, "unknown workload"); return MSIM_E_INVALID; }
   if (c->latency_dist > MSIM_LAT_EXPONENTIAL) { set_err(err, errlen, "latency_dist must be constant, uniform, or exponential"); return MSIM_E_INVALID; }
   if (c->latency_dist == MSIM_LAT_EXPONENTIAL && c->latency_mean_ms == 0) {
     // net.clj:77 (exponential-distribution (/ mean)) throws "Divide by zero" for --latency 0
@@ -94,6 +95,7 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
     case MSIM_WL_LIN_KV: ok = c->node_program == MSIM_NODE_RAFT; break;
     case MSIM_WL_TXN_LIST_APPEND: ok = c->node_program == MSIM_NODE_TXN_SINGLE_KEY; break;
     case MSIM_WL_PN_COUNTER: case MSIM_WL_G_COUNTER: ok = c->node_program == MSIM_NODE_PN_COUNTER; break;
+    case MSIM_WL_UNIQUE_IDS: ok = c->node_program == MSIM_NODE_FLAKE_IDS; break;
     default: break;
   }
   if (!ok) { set_err(err, errlen, "node_program does not implement this workload"); return MSIM_E_INVALID; }
@@ -119,7 +121,7 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
   if (pn && c->n_nodes > 32) { set_err(err, errlen, "pn-counter: at most 32 nodes in this build"); return MSIM_E_UNSUPPORTED; }
   // pn-counter: a node's state is 2 x n_nodes counters (one G-counter for increments, one for decrements): max_values / 32 words
   if (pn) c->max_values = 64 * c->n_nodes;
-  const bool no_sets = c->workload == MSIM_WL_ECHO || c->workload == MSIM_WL_LIN_KV || txn || pn;
+  const bool no_sets = c->workload == MSIM_WL_UNIQUE_IDS || c->workload == MSIM_WL_ECHO || c->workload == MSIM_WL_LIN_KV || txn || pn;
   // txn-list-append: max_values = distinct keys ever used (a key is retired after max_writes_per_key appends)
   if (txn && c->max_values == 0) c->max_values = c->key_count + (ops_max * c->max_txn_length) / c->max_writes_per_key + 32;
   if (txn && c->max_values > 32767) { set_err(err, errlen, "txn-list-append: more than 32767 keys"); return MSIM_E_INVALID; }

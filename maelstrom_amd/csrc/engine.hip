@@ -35,6 +35,7 @@
 // message types (doc/protocol.md, doc/workloads.md)
 enum { M_INIT = 1, M_INIT_OK, M_TOPOLOGY, M_TOPOLOGY_OK, M_ECHO, M_ECHO_OK, M_BROADCAST, M_BROADCAST_OK,
        M_READ, M_READ_OK, M_ADD, M_ADD_OK, M_REPLICATE };
+enum { M_GENERATE = 25, M_GENERATE_OK = 26 };  // unique-ids (after the raft and txn types, include/maelsim.h MSIM_M_*)
 // RNG streams
 enum { S_GEN = 1, S_GEN2 = 2, S_LATENCY = 4, S_LOSS = 5,
        S_NEM_STAGGER = 7, S_NEM_SPEC = 8, S_NEM_SHUFFLE = 9, S_NEM_PICK = 10 };
@@ -204,6 +205,7 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
   constexpr bool IS_PN = PROG == MSIM_NODE_PN_COUNTER;    // pn_counter.rb: same replication skeleton as g-set, counters instead of a set
   constexpr bool IS_GSET = PROG == MSIM_NODE_G_SET || IS_PN;  // "CRDT with a 5 s replicate timer"
   constexpr bool IS_ECHO = PROG == MSIM_NODE_ECHO;
+  constexpr bool IS_FLAKE = PROG == MSIM_NODE_FLAKE_IDS;  // flake_ids.clj: unique-ids workload, Reusable clients (unique_ids.clj:59-61)
   constexpr bool HAS_FINAL = IS_BCAST || IS_GSET;
   constexpr bool FINAL_FLAG = IS_BCAST || IS_PN;  // :final? true on the last reads (broadcast.clj:240, pn_counter.clj:137)
   constexpr bool HAS_TIMERS = IS_ACK || IS_GSET;
@@ -259,6 +261,7 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
   bool have_pm = false; uint4 pm = make_uint4(0, 0, 0, 0);                    // smallest arrival of this commit
   u32 in_n = 0, sp_n = 0;                                                     // queued envelopes in LDS / in the HBM spill
   u32 node_msgid = 0, timer_next = INF, tick = 0, part = 0;
+  u32 flake_time = 0, flake_count = 0;  // flake_ids.clj:10-14
   u32 fifo_head = 0, fifo_tail = 0, retry_time = INF;
   bool busy = false, mark = false; u32 kind = K_NONE;
   u32 want = 0, timeout_at = 0, next_msg_id = 0, c_f = 0, c_value = 0, process = slot, c_final = 0;
@@ -421,7 +424,7 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
       cmp_value = value; cmp_len = len;
       if (type == MSIM_T_INFO) {  // crashed process: new process id, fresh client [upstream interpreter]
         process += C; dest_node += c_mod_n; if (dest_node >= N) dest_node -= N;
-        next_msg_id = 0; in_n = 0;
+        if (!IS_FLAKE) { next_msg_id = 0; in_n = 0; }  // Reusable clients (unique_ids.clj:59-61) are not re-opened
       }
     };
 
@@ -498,6 +501,7 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
               u32 f, val = MSIM_NO_VALUE;
               bool ok = true;
               if (IS_ECHO) { f = MSIM_F_ECHO; val = (r_lo >> 4) & 127; }
+              else if (IS_FLAKE) f = MSIM_F_GENERATE;  // (gen/repeat {:f :generate}), unique_ids.clj:72
               else if (IS_PN && p.cfg.workload == MSIM_WL_G_COUNTER) {
                 // g_counter.clj:37-41: (gen/filter ...) skips negative adds and takes the mix's next op at once
                 u32 rr = r_lo, a = 0;
@@ -544,7 +548,7 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
             c_f = m_f; c_value = m_value; c_final = m_final;
             rq_dest = dest_node;
             inv_row = true; inv_packed = MSIM_T_INVOKE | (c_f << 2) | (c_final << 11) | (process << 12); inv_value = c_value;
-            rq_type = c_f == MSIM_F_ECHO ? M_ECHO : c_f == MSIM_F_BROADCAST ? M_BROADCAST : c_f == MSIM_F_ADD ? M_ADD : M_READ;
+            rq_type = c_f == MSIM_F_ECHO ? M_ECHO : c_f == MSIM_F_BROADCAST ? M_BROADCAST : c_f == MSIM_F_ADD ? M_ADD : c_f == MSIM_F_GENERATE ? M_GENERATE : M_READ;
             rq_a = c_f == MSIM_F_READ ? 0u : c_value;
           }
           want = ++next_msg_id;
@@ -597,6 +601,12 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
               rep = true; rep_dest = qsrc; rep_type = M_INIT_OK; rep_b = qb; break;
             case M_TOPOLOGY: rep = true; rep_dest = qsrc; rep_type = M_TOPOLOGY_OK; rep_b = qb; break;
             case M_ECHO: rep = true; rep_dest = qsrc; rep_type = M_ECHO_OK; rep_a = qa; rep_b = qb; break;
+            case M_GENERATE: {  // flake_ids.clj:16-31: [max(now in s, last time), counter within that second, node]
+              u32 t = T / 1000000u;
+              if (t < flake_time) t = flake_time;
+              flake_count = t == flake_time ? flake_count + 1 : 0u; flake_time = t;
+              rep = true; rep_dest = qsrc; rep_type = M_GENERATE_OK; rep_a = (t << 20) | ((flake_count & 0x7FFFu) << 5) | lane; rep_b = qb;
+            } break;
             case M_READ:
               rep = true; rep_dest = qsrc; rep_type = M_READ_OK; rep_b = qb;
               if (IS_PN) { u32 v = 0; for (u32 i = 0; i < N; i++) v += my_seen[i] - my_seen[N + i]; rep_a = v; }  // increments - decrements
@@ -693,7 +703,7 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
           if (jcap) jwrite(n_ev + (u32)__popcll(dm & lt_mask), 1, q.y, qa, qb, q.w >> 24, lane);
           if (busy && qb == want) {  // else: stale reply, keep polling (client.clj:105-107)
             if (qtype == M_READ_OK) { if (IS_PN) complete(MSIM_T_OK, 0, qa, 0); else complete(MSIM_T_OK, 0, qa & 0xFFFFFFu, qa >> 24); }
-            else if (qtype == M_ECHO_OK) complete(MSIM_T_OK, 0, qa, 0);
+            else if (qtype == M_ECHO_OK || qtype == M_GENERATE_OK) complete(MSIM_T_OK, 0, qa, 0);
             else complete(MSIM_T_OK, 0, c_value, 0);
           }
           poll();
@@ -1011,6 +1021,7 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
       } else e = launch<MSIM_NODE_G_SET>(kp, n, lds, st);
       break;
     case MSIM_NODE_PN_COUNTER: e = launch<MSIM_NODE_PN_COUNTER>(kp, n, lds, st); break;
+    case MSIM_NODE_FLAKE_IDS: e = launch<MSIM_NODE_FLAKE_IDS>(kp, n, lds, st); break;
     case MSIM_NODE_RAFT: {
       const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
       if (c.nemesis_mask) { if (rnd) hipLaunchKernelGGL((raft_kernel<true, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((raft_kernel<true, false>), dim3(n), dim3(64), lds, st, kp); }
@@ -1053,6 +1064,7 @@ extern "C" int msim_check(msim_ctx *ctx) {
   if (ctx->cfg.workload == MSIM_WL_LIN_KV) return msim_check_lin_kv_host(ctx);
   if (ctx->cfg.workload == MSIM_WL_TXN_LIST_APPEND) return msim_check_txn_host(ctx);
   if (ctx->cfg.workload == MSIM_WL_PN_COUNTER || ctx->cfg.workload == MSIM_WL_G_COUNTER) return msim_check_pn_host(ctx);
+  if (ctx->cfg.workload == MSIM_WL_UNIQUE_IDS) return msim_check_unique_host(ctx);
   return msim_check_launch(ctx);
 }
 

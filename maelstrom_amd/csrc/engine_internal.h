@@ -52,6 +52,7 @@ int msim_check_lin_kv_host(msim_ctx *ctx);
 int msim_check_txn_host(msim_ctx *ctx);
 // pn_check.cpp
 int msim_check_pn_host(msim_ctx *ctx);
+int msim_check_unique_host(msim_ctx *ctx);
 
 #define MSIM_HIP_TRY(ctx, call)                                                        \
   do {                                                                                 \

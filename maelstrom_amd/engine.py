@@ -22,18 +22,18 @@ CHECK_DT = np.dtype([("valid", "<u4"), ("attempt_count", "<u4"), ("stable_count"
                      ("ok_count", "<u4"), ("fail_count", "<u4"), ("info_count", "<u4")])
 
 WORKLOADS = {"echo": A.WL_ECHO, "broadcast": A.WL_BROADCAST, "g-set": A.WL_G_SET, "lin-kv": A.WL_LIN_KV,
-             "txn-list-append": A.WL_TXN_LIST_APPEND, "pn-counter": A.WL_PN_COUNTER, "g-counter": A.WL_G_COUNTER}
+             "txn-list-append": A.WL_TXN_LIST_APPEND, "pn-counter": A.WL_PN_COUNTER, "g-counter": A.WL_G_COUNTER, "unique-ids": A.WL_UNIQUE_IDS}
 NODE_PROGRAMS = {"echo": A.NODE_ECHO, "broadcast-ff": A.NODE_BCAST_FF, "broadcast-ff-echoback": A.NODE_BCAST_FF_ECHOBACK,
                  "broadcast-ack-retry": A.NODE_BCAST_ACK_RETRY, "broadcast-rpc-all": A.NODE_BCAST_RPC_ALL,
                  "g-set": A.NODE_G_SET, "raft": A.NODE_RAFT, "single-key-txn": A.NODE_TXN_SINGLE_KEY,
-                 "pn-counter": A.NODE_PN_COUNTER}
+                 "pn-counter": A.NODE_PN_COUNTER, "flake-ids": A.NODE_FLAKE_IDS}
 TOPOLOGIES = {"grid": A.TOPO_GRID, "line": A.TOPO_LINE, "total": A.TOPO_TOTAL, "tree": A.TOPO_TREE2,
               "tree2": A.TOPO_TREE2, "tree3": A.TOPO_TREE3, "tree4": A.TOPO_TREE4}
 LATENCY_DISTS = {"constant": A.LAT_CONSTANT, "uniform": A.LAT_UNIFORM, "exponential": A.LAT_EXPONENTIAL}
 TYPE_KW = {A.T_INVOKE: ":invoke", A.T_OK: ":ok", A.T_FAIL: ":fail", A.T_INFO: ":info"}
 F_KW = {A.F_ECHO: ":echo", A.F_BROADCAST: ":broadcast", A.F_READ: ":read", A.F_ADD: ":add",
         A.F_START_PARTITION: ":start-partition", A.F_STOP_PARTITION: ":stop-partition", A.F_WRITE: ":write", A.F_CAS: ":cas",
-        A.F_TXN: ":txn"}
+        A.F_TXN: ":txn", A.F_GENERATE: ":generate"}
 ERR_KW = {A.ERR_NET_TIMEOUT: ":net-timeout", A.ERR_TEMPORARILY_UNAVAILABLE: [":temporarily-unavailable", "not a leader"],
           A.ERR_KEY_DOES_NOT_EXIST: [":key-does-not-exist", "not found"], A.ERR_PRECONDITION_FAILED: [":precondition-failed", "cas mismatch"],
           A.ERR_TXN_CONFLICT: [":txn-conflict", "root altered"]}
@@ -346,6 +346,8 @@ def decode_history(rows, payload, n_nodes, workload=A.WL_BROADCAST):
         if workload == A.WL_LIN_KV and f in (A.F_READ, A.F_WRITE, A.F_CAS):  # independent tuples, lin_kv.clj:53-67
             k, v1, v2 = value & 0xFF, _nil((value >> 8) & 0xFF), _nil((value >> 16) & 0xFF)
             op["value"] = [k, [v1, v2]] if f == A.F_CAS else [k, v1]
+        elif f == A.F_GENERATE:   # flake id [time count node-id], flake_ids.clj:30-31
+            op["value"] = [value >> 20, (value >> 5) & 0x7FFF, f"n{value & 31}"] if typ == A.T_OK else None
         elif f == A.F_TXN:
             op["value"] = decode_txn(payload[value:value + ln])
         elif workload in (A.WL_PN_COUNTER, A.WL_G_COUNTER) and f in (A.F_ADD, A.F_READ):  # pn_counter.clj:22-58: signed delta / counter value

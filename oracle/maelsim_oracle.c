@@ -58,7 +58,7 @@ enum { M_INIT = 1, M_INIT_OK, M_TOPOLOGY, M_TOPOLOGY_OK, M_ECHO, M_ECHO_OK, M_BR
        M_READ, M_READ_OK, M_ADD, M_ADD_OK, M_REPLICATE,
        M_WRITE, M_WRITE_OK, M_CAS, M_CAS_OK, M_ERROR,                                   /* lin-kv RPCs, doc/workloads.md */
        M_REQUEST_VOTE, M_REQUEST_VOTE_RES, M_APPEND_ENTRIES, M_APPEND_ENTRIES_RES,      /* raft.py:290-297,412-420 */
-       M_TXN, M_TXN_OK };                                                                /* txn_list_append.clj:73-80 */
+       M_TXN, M_TXN_OK, M_GENERATE, M_GENERATE_OK };                                                                /* txn_list_append.clj:73-80 */
 
 /* RNG streams */
 enum { S_GEN = 1, S_GEN2 = 2, S_GEN3 = 3, S_LATENCY = 4, S_LOSS = 5, S_NODE = 11,
@@ -97,6 +97,7 @@ typedef struct {
   u32 *unacked;         /* ack/retry: [node][value][MW] un-acked neighbour sets */
   u32 *timer_next;      /* g-set replicate timer */
   u32 *tick;            /* g-set: replicate ticks so far, per node */
+  u32 *flake;           /* flake ids: [node][2] = {last time (s), counter within it}, flake_ids.clj:10-14 */
   struct rnode_s *raft; /* raft: per-node state (raft_nodes.inc) */
   u32 cur_key, key_procs; u32 *key_reg; /* lin-kv generator: current key; per thread the process id it registered on that key (+1) */
   u32 **snap; u32 n_snap, cap_snap; /* replicate_full payload snapshots */
@@ -160,13 +161,13 @@ static void clrbit(u32 *m, u32 i) { m[i >> 5] &= ~(1u << (i & 31)); }
 static int is_client(const sim_t *s, u32 ep) { return ep >= s->N && ep < s->N + s->CS; }
 
 /* lin_kv.clj:74-76, txn_list_append.clj:124-126: Reusable clients are not re-opened after a crash */
-static int reusable_clients(const sim_t *s) { return s->cfg.workload == MSIM_WL_LIN_KV || s->cfg.workload == MSIM_WL_TXN_LIST_APPEND; }
+static int reusable_clients(const sim_t *s) { return s->cfg.workload == MSIM_WL_LIN_KV || s->cfg.workload == MSIM_WL_TXN_LIST_APPEND || s->cfg.workload == MSIM_WL_UNIQUE_IDS; }
 
 static void inbox_push(sim_t *s, u32 ep, qent q) {
   inbox_t *b = &s->inbox[ep];
   if (b->n == b->cap) { b->cap = b->cap ? b->cap * 2 : 8; b->v = (qent *)realloc(b->v, b->cap * sizeof(qent)); }
   b->v[b->n++] = q;
-  u32 lim = is_client(s, ep) ? (reusable_clients(s) ? 32u : 2u) /* Reusable clients collect late replies */
+  u32 lim = is_client(s, ep) ? (reusable_clients(s) && s->cfg.workload != MSIM_WL_UNIQUE_IDS ? 32u : 2u) /* Reusable clients collect late replies */
                              : s->cfg.inbox_capacity + s->cfg.spill_capacity; /* engine capacities: overflow is flagged, never silent */
   if (b->n > lim) s->meta.flags |= MSIM_FLAG_INBOX_OVERFLOW;
 }
@@ -369,6 +370,11 @@ static void node_handle(sim_t *s, u32 node, const qent *q) {
       out_send(s, node, q->src, M_INIT_OK, 0, q->b); break;
     case M_TOPOLOGY: s->nbr_known[node] = 1; out_send(s, node, q->src, M_TOPOLOGY_OK, 0, q->b); break;
     case M_ECHO: out_send(s, node, q->src, M_ECHO_OK, q->a, q->b); break; /* echo.rb:32-38 */
+    case M_GENERATE: { /* flake_ids.clj:16-31: time = max(now in s, last time); count = same second ? count + 1 : 0 */
+      u32 *f = s->flake + 2 * node, t = s->T / 1000000u;
+      if (t < f[0]) t = f[0];
+      f[1] = t == f[0] ? f[1] + 1 : 0; f[0] = t;
+      out_send(s, node, q->src, M_GENERATE_OK, (t << 20) | ((f[1] & 0x7FFFu) << 5) | node, q->b); } break;
     case M_BROADCAST: node_broadcast(s, node, q); break;
     case M_BROADCAST_OK: node_broadcast_ok(s, node, q); break;
     case M_READ:
@@ -422,7 +428,7 @@ static void client_deliver(sim_t *s, u32 slot, const qent *q) {
       else if (s->cfg.workload == MSIM_WL_PN_COUNTER || s->cfg.workload == MSIM_WL_G_COUNTER) client_complete(s, slot, MSIM_T_OK, 0, q->a, 0); /* (long (:value ..)), pn_counter.clj:52-55 */
       else client_complete(s, slot, MSIM_T_OK, 0, q->a & 0xFFFFFFu, q->a >> 24);
       break;
-    case M_ECHO_OK: client_complete(s, slot, MSIM_T_OK, 0, q->a, 0); break;
+    case M_ECHO_OK: case M_GENERATE_OK: client_complete(s, slot, MSIM_T_OK, 0, q->a, 0); break;
     case M_TXN_OK: client_complete(s, slot, MSIM_T_OK, 0, q->a & 0xFFFFFFu, q->a >> 24); break; /* txn_list_append.clj:109-117 */
     case M_ERROR: { /* client.clj:125-138 throw-errors!; every code the raft node emits is :definite? => :fail (errors.edn) */
       u32 err = q->a == 11 ? MSIM_ERR_TEMPORARILY_UNAVAILABLE : q->a == 20 ? MSIM_ERR_KEY_DOES_NOT_EXIST : q->a == 30 ? MSIM_ERR_TXN_CONFLICT : MSIM_ERR_PRECONDITION_FAILED;
@@ -458,6 +464,7 @@ static void client_invoke(sim_t *s, u32 slot) {
       case MSIM_F_WRITE: type = M_WRITE; a = c->value; break;
       case MSIM_F_CAS: type = M_CAS; a = c->value; break;
       case MSIM_F_TXN: type = M_TXN; a = c->value; break;
+      case MSIM_F_GENERATE: type = M_GENERATE; a = 0; break;
       default: type = M_READ; a = s->cfg.workload == MSIM_WL_LIN_KV ? c->value : 0; break;
     }
   }
@@ -576,6 +583,7 @@ static void sched_act(sim_t *s) {
             if (ref == INF) { c->mark = 0; s->phase = PH_DONE; return; }
             c->m_f = MSIM_F_TXN; c->m_value = ref;
           }
+          else if (s->cfg.workload == MSIM_WL_UNIQUE_IDS) { c->m_f = MSIM_F_GENERATE; c->m_value = MSIM_NO_VALUE; } /* (gen/repeat {:f :generate}) */
           else if (s->cfg.workload == MSIM_WL_ECHO) { c->m_f = MSIM_F_ECHO; c->m_value = (r_lo >> 4) & 127; } /* echo.clj:72-75 */
           else if (s->cfg.workload == MSIM_WL_G_COUNTER) { /* g_counter.clj:37-41: (gen/filter ...) skips negative adds, takes the next op of the mix at once */
             u32 rr = r_lo, a = 0;
@@ -751,6 +759,7 @@ static sim_t *sim_new(const msim_config *cfg, uint64_t instance, msim_op *rows, 
   if (cfg->node_program == MSIM_NODE_BCAST_ACK_RETRY) s->unacked = (u32 *)calloc((size_t)s->N * cfg->max_values * MW, 4);
   s->timer_next = (u32 *)malloc(s->N * 4);
   s->tick = (u32 *)calloc(s->N, 4);
+  s->flake = (u32 *)calloc(2 * s->N, 4);
   for (u32 i = 0; i < s->N; i++) s->timer_next[i] = INF;
   s->cl = (struct cl *)calloc(s->CS, sizeof(struct cl));
   s->pend = calloc(s->CS, sizeof(*s->pend));
@@ -788,7 +797,7 @@ static void sim_free(sim_t *s) {
   if (s->raft) { for (u32 i = 0; i < s->N; i++) free(s->raft[i].log); free(s->raft); }
   if (s->txn) { free(s->txn->slots); free(s->txn->kv); free(s->txn->kv_n); free(s->txn); }
   free(s->snap); free(s->inbox); free(s->committed); free(s->has_committed); free(s->deliver_at); free(s->seen);
-  free(s->unacked); free(s->node_msg_id); free(s->nbr_known); free(s->tasks); free(s->key_reg); free(s->timer_next); free(s->tick);
+  free(s->unacked); free(s->node_msg_id); free(s->nbr_known); free(s->tasks); free(s->key_reg); free(s->timer_next); free(s->tick); free(s->flake);
   free(s->cl); free(s->pend); free(s->out);
   free(s);
 }
@@ -854,7 +863,7 @@ int oracle_node_trace(const msim_config *cfg, uint32_t node, const uint32_t *in,
 uint32_t oracle_msg_type(const char *name) {
   static const char *names[] = {"", "init", "init_ok", "topology", "topology_ok", "echo", "echo_ok", "broadcast", "broadcast_ok",
                                 "read", "read_ok", "add", "add_ok", "replicate", "write", "write_ok", "cas", "cas_ok", "error",
-                                "request_vote", "request_vote_res", "append_entries", "append_entries_res", "txn", "txn_ok"};
+                                "request_vote", "request_vote_res", "append_entries", "append_entries_res", "txn", "txn_ok", "generate", "generate_ok"};
   for (u32 i = 1; i < sizeof(names) / sizeof(names[0]); i++) if (!strcmp(names[i], name)) return i;
   return 0;
 }

@@ -209,3 +209,14 @@ def test_g_counter_parity(lib):
     _compare(cfg, 0, 6)
     cfg = E.test_config("g-counter", node_count=7, concurrency=14, rate=50, time_limit=8, latency=30, latency_dist="exponential", p_loss=0.05, seed=73)
     _compare(cfg, 0, 4)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(concurrency=9, latency=20), dict(latency=30, latency_dist="exponential", p_loss=0.05, nemesis=["partition"], nemesis_interval=3)])
+def test_unique_ids_parity(lib, kw):
+    cfg = E.test_config("unique-ids", node_count=3, rate=200, time_limit=5, seed=81, **kw)
+    _compare(cfg, 0, 6)
+    with E.Engine(cfg) as eng:
+        eng.run(0, 6)
+        eng.check()
+        res = eng.check_results()
+        assert (res["valid"] == 1).all() and (res["duplicated_count"] == 0).all()
