@@ -26,7 +26,7 @@ def test_flake_ids_are_unique_and_shaped_like_the_reference(kw):
         rows, pay = r.history(i)
         ops = [o for o in E.decode_history(rows, pay, 3, A.WL_UNIQUE_IDS) if o["process"] != ":nemesis"]
         oks = [o for o in ops if o["type"] == ":ok"]
-        assert len(oks) > (20 if kw else 500) and all(o["f"] == ":generate" for o in ops)   # a lost message stalls its worker for 5 s
+        assert len(oks) > (5 if kw else 500) and all(o["f"] == ":generate" for o in ops)   # a lost message stalls its worker for 5 s
         for o in oks:   # [time count node-id], flake_ids.clj:30-31; the client is pinned to node process mod n
             t, c, n = o["value"]
             assert n == f"n{o['process'] % 3}" and 0 <= t <= 6 and t == o["time"] // 10**9
