@@ -59,6 +59,8 @@ enum {
   MSIM_NODE_TXN_SINGLE_KEY = 7, /* demo/clojure/single_key_txn.clj:116-180: whole database under one lin-kv key:
                                    read root -> apply txn -> cas root (create_if_not_exists), conflict => error 30.
                                    Brings the `lin-kv` service endpoint with it (service.clj:31-61,141-155,290-296) */
+  MSIM_NODE_LIN_KV_PROXY = 10,  /* demo/ruby/lin_kv_proxy.rb:8-43: every read / write / cas is proxied to the key-value service
+                                   named by msim_config.proxy_service (service.clj:31-114,141-243,290-296)                   */
   MSIM_NODE_FLAKE_IDS = 9,      /* demo/clojure/flake_ids.clj:10-33: id = [seconds, counter within that second, node id] */
   MSIM_NODE_PN_COUNTER = 8      /* demo/ruby/pn_counter.rb:8-121 == demo/js/crdt_pn_counter.js: increments and decrements in two
                                    per-node G-counters, merged by element-wise max, replicated to all others every 5 s      */
@@ -67,6 +69,7 @@ enum {
 enum { MSIM_LAT_CONSTANT = 0, MSIM_LAT_UNIFORM = 1, MSIM_LAT_EXPONENTIAL = 2 };  /* net.clj:65-77 */
 enum { MSIM_TOPO_GRID = 0, MSIM_TOPO_LINE = 1, MSIM_TOPO_TOTAL = 2,
        MSIM_TOPO_TREE2 = 3, MSIM_TOPO_TREE3 = 4, MSIM_TOPO_TREE4 = 5 };           /* broadcast.clj:171-179 */
+enum { MSIM_SVC_LIN_KV = 0, MSIM_SVC_SEQ_KV = 1, MSIM_SVC_LWW_KV = 2 };               /* service.clj:290-296 */
 enum { MSIM_NEMESIS_PARTITION = 1u };                                              /* core.clj:49-51 */
 
 typedef struct msim_config {
@@ -99,7 +102,8 @@ typedef struct msim_config {
   uint32_t key_count;            /* --key-count: keys worked on at once; 0 = 10 [upstream default, exponential key choice] */
   uint32_t max_txn_length;       /* --max-txn-length, default 4 (core.clj:191-194); min length is 1 [upstream]    */
   uint32_t max_writes_per_key;   /* --max-writes-per-key, default 16 (core.clj:196-199)                           */
-  uint32_t reserved[3];
+  uint32_t proxy_service;        /* MSIM_SVC_*: which service lin_kv_proxy.rb talks to (its line 35 invites swapping it)  */
+  uint32_t reserved[2];
 } msim_config;
 
 /* ---- outputs ------------------------------------------------------------------------------------- */

@@ -15,7 +15,8 @@ ABI_VERSION = 1
 # enums (include/maelsim.h)
 OK, E_INVALID, E_NO_DEVICE, E_HIP, E_NOMEM, E_RANGE, E_UNSUPPORTED, E_OVERFLOW = 0, -1, -2, -3, -4, -5, -6, -7
 WL_ECHO, WL_BROADCAST, WL_G_SET, WL_LIN_KV, WL_TXN_LIST_APPEND, WL_PN_COUNTER, WL_G_COUNTER, WL_UNIQUE_IDS = range(8)
-NODE_ECHO, NODE_BCAST_FF, NODE_BCAST_FF_ECHOBACK, NODE_BCAST_ACK_RETRY, NODE_BCAST_RPC_ALL, NODE_G_SET, NODE_RAFT, NODE_TXN_SINGLE_KEY, NODE_PN_COUNTER, NODE_FLAKE_IDS = range(10)
+NODE_ECHO, NODE_BCAST_FF, NODE_BCAST_FF_ECHOBACK, NODE_BCAST_ACK_RETRY, NODE_BCAST_RPC_ALL, NODE_G_SET, NODE_RAFT, NODE_TXN_SINGLE_KEY, NODE_PN_COUNTER, NODE_FLAKE_IDS, NODE_LIN_KV_PROXY = range(11)
+SVC_LIN_KV, SVC_SEQ_KV, SVC_LWW_KV = range(3)
 LAT_CONSTANT, LAT_UNIFORM, LAT_EXPONENTIAL = range(3)
 TOPO_GRID, TOPO_LINE, TOPO_TOTAL, TOPO_TREE2, TOPO_TREE3, TOPO_TREE4 = range(6)
 NEMESIS_PARTITION = 1
@@ -51,7 +52,7 @@ class Config(C.Structure):
         ("quiesce_ms", C.c_uint32), ("seed", C.c_uint64), ("max_values", C.c_uint32), ("max_rows", C.c_uint32),
         ("max_payload_words", C.c_uint32), ("inbox_capacity", C.c_uint32), ("spill_capacity", C.c_uint32),
         ("journal_capacity", C.c_uint32), ("key_count", C.c_uint32), ("max_txn_length", C.c_uint32),
-        ("max_writes_per_key", C.c_uint32), ("reserved", C.c_uint32 * 3),
+        ("max_writes_per_key", C.c_uint32), ("proxy_service", C.c_uint32), ("reserved", C.c_uint32 * 2),
     ]
 
 

@@ -92,7 +92,7 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
     case MSIM_WL_ECHO: ok = c->node_program == MSIM_NODE_ECHO; break;
     case MSIM_WL_BROADCAST: ok = c->node_program >= MSIM_NODE_BCAST_FF && c->node_program <= MSIM_NODE_BCAST_RPC_ALL; break;
     case MSIM_WL_G_SET: ok = c->node_program == MSIM_NODE_G_SET; break;
-    case MSIM_WL_LIN_KV: ok = c->node_program == MSIM_NODE_RAFT; break;
+    case MSIM_WL_LIN_KV: ok = c->node_program == MSIM_NODE_RAFT || c->node_program == MSIM_NODE_LIN_KV_PROXY; break;
     case MSIM_WL_TXN_LIST_APPEND: ok = c->node_program == MSIM_NODE_TXN_SINGLE_KEY; break;
     case MSIM_WL_PN_COUNTER: case MSIM_WL_G_COUNTER: ok = c->node_program == MSIM_NODE_PN_COUNTER; break;
     case MSIM_WL_UNIQUE_IDS: ok = c->node_program == MSIM_NODE_FLAKE_IDS; break;
@@ -100,6 +100,7 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
   }
   if (!ok) { set_err(err, errlen, "node_program does not implement this workload"); return MSIM_E_INVALID; }
 
+  if (c->proxy_service > MSIM_SVC_LWW_KV) { set_err(err, errlen, "proxy_service must be lin-kv, seq-kv or lww-kv"); return MSIM_E_INVALID; }
   const bool txn = c->workload == MSIM_WL_TXN_LIST_APPEND;
   if (txn) {
     if (c->key_count == 0) c->key_count = 10;
@@ -153,7 +154,8 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
     if (c->node_program == MSIM_NODE_BCAST_ACK_RETRY && c->nemesis_mask) depth += (deg < 4 ? deg : 4) * adds;
     if (c->node_program == MSIM_NODE_G_SET || c->node_program == MSIM_NODE_PN_COUNTER) depth = 16 + 2 * deg;  // one replicate_full per peer per 5 s tick (g_set.rb:33-38)
     if (c->node_program == MSIM_NODE_RAFT) depth = 24 + 1024;
-    if (txn) depth = 16 + 4 * c->n_nodes;                           // the service sees <= 2 requests per transaction in flight       // heartbeats / re-sent append_entries pile up behind a sleeping recv!
+    if (txn) depth = 16 + 4 * c->n_nodes;
+    if (c->node_program == MSIM_NODE_LIN_KV_PROXY) depth = 16 + 2 * c->concurrency;   // the service sees every worker's request at once                           // the service sees <= 2 requests per transaction in flight       // heartbeats / re-sent append_entries pile up behind a sleeping recv!
     const uint32_t lds_part = c->n_nodes > 32 ? 4 : 24;  // wide clusters keep 100+ queues in one CU's LDS
     if (c->inbox_capacity == 0) c->inbox_capacity = depth < lds_part ? depth : lds_part;
     if (c->spill_capacity == 0) c->spill_capacity = depth > c->inbox_capacity ? depth - c->inbox_capacity : 0;

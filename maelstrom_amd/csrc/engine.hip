@@ -823,6 +823,7 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
 #include "sim_kernel_raft.inc"
 #include "sim_kernel_wide.inc"
 #include "sim_kernel_txn.inc"
+#include "sim_kernel_svc.inc"
 
 // =====================================================================================================
 // Host runtime
@@ -872,7 +873,8 @@ extern "C" int msim_create(const msim_config *cfg, int device, msim_ctx **out, c
   const uint32_t slots = c.concurrency > c.n_nodes ? c.concurrency : c.n_nodes;
   // wide clusters (33..127 nodes): two node/client pairs per lane, built for the g-set CRDT with one worker per node
   const bool wide = c.n_nodes > 32 && c.node_program == MSIM_NODE_G_SET && c.concurrency == c.n_nodes && c.nemesis_mask == 0;
-  if (!wide && (c.n_nodes > 32 || c.n_nodes + slots > 64)) {
+  const uint32_t svc_lanes = c.node_program == MSIM_NODE_LIN_KV_PROXY ? 1 : 0;  // the service has a lane of its own after the client slots
+  if (!wide && (c.n_nodes > 32 || c.n_nodes + slots + svc_lanes > 64)) {
     set_err(err, errlen, "this build maps one cluster to one wavefront: n_nodes <= 32 and n_nodes + max(concurrency, n_nodes) <= 64 "
                          "(g-set with concurrency == n_nodes and no nemesis: up to 127 nodes)");
     return MSIM_E_UNSUPPORTED;
@@ -914,7 +916,7 @@ static uint64_t proto_scratch_words(const msim_config &c) {
   return (w + 3) & ~3ull;  // keep the spill area 16-byte aligned
 }
 static uint64_t scratch_words(const msim_config &c) {
-  const uint64_t queues = c.n_nodes + (c.node_program == MSIM_NODE_TXN_SINGLE_KEY ? 1 : 0);  // + the lin-kv service
+  const uint64_t queues = c.n_nodes + (c.node_program == MSIM_NODE_TXN_SINGLE_KEY || c.node_program == MSIM_NODE_LIN_KV_PROXY ? 1 : 0);  // + the service
   return proto_scratch_words(c) + queues * c.spill_capacity * 4;
 }
 
@@ -985,12 +987,13 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   kp.raft_log_cap = is_raft ? raft_log_cap(c) : 0;
   const bool wide = c.n_nodes > 32;
   size_t off = (wide ? WIDE_STAGE_ROWS : STAGE_ROWS) * 16;
-  const bool is_txn = c.node_program == MSIM_NODE_TXN_SINGLE_KEY;
+  const bool is_txn = c.node_program == MSIM_NODE_TXN_SINGLE_KEY, is_px = c.node_program == MSIM_NODE_LIN_KV_PROXY;
   kp.off_inbox = (u32)off;
-  off += is_txn ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16
+  off += is_px ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.CS * R_CLIENT_CAP) * 16 : is_txn ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16
                 : ((size_t)kp.N * kp.cap_node + (size_t)kp.CS * (is_raft ? R_CLIENT_CAP : CLIENT_INBOX_CAP)) * 16;
   kp.off_seen = (u32)off;
-  off += is_txn ? (size_t)kp.N * TXN_SLOTS * 16 + 36 * 4   // transactions in flight per node + the generator's key pool
+  off += is_px ? (size_t)kp.N * PX_SLOTS * 8 + 34 * 256 + 64 * 4   // callbacks per node + service states + seq-kv indices
+       : is_txn ? (size_t)kp.N * TXN_SLOTS * 16 + 36 * 4   // transactions in flight per node + the generator's key pool
        : is_raft ? (size_t)kp.N * 256 + (size_t)kp.N * kp.N * 3 * 4   // KV state + next/match index + append_entries refs
                  : (size_t)kp.N * kp.W * 4;
   off = (off + 15) & ~(size_t)15;
@@ -1026,6 +1029,12 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
       const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
       if (c.nemesis_mask) { if (rnd) hipLaunchKernelGGL((raft_kernel<true, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((raft_kernel<true, false>), dim3(n), dim3(64), lds, st, kp); }
       else { if (rnd) hipLaunchKernelGGL((raft_kernel<false, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((raft_kernel<false, false>), dim3(n), dim3(64), lds, st, kp); }
+      e = hipGetLastError();
+    } break;
+    case MSIM_NODE_LIN_KV_PROXY: {
+      const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
+      if (c.nemesis_mask) { if (rnd) hipLaunchKernelGGL((svc_kernel<true, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((svc_kernel<true, false>), dim3(n), dim3(64), lds, st, kp); }
+      else { if (rnd) hipLaunchKernelGGL((svc_kernel<false, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((svc_kernel<false, false>), dim3(n), dim3(64), lds, st, kp); }
       e = hipGetLastError();
     } break;
     case MSIM_NODE_TXN_SINGLE_KEY: {

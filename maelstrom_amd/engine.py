@@ -26,7 +26,8 @@ WORKLOADS = {"echo": A.WL_ECHO, "broadcast": A.WL_BROADCAST, "g-set": A.WL_G_SET
 NODE_PROGRAMS = {"echo": A.NODE_ECHO, "broadcast-ff": A.NODE_BCAST_FF, "broadcast-ff-echoback": A.NODE_BCAST_FF_ECHOBACK,
                  "broadcast-ack-retry": A.NODE_BCAST_ACK_RETRY, "broadcast-rpc-all": A.NODE_BCAST_RPC_ALL,
                  "g-set": A.NODE_G_SET, "raft": A.NODE_RAFT, "single-key-txn": A.NODE_TXN_SINGLE_KEY,
-                 "pn-counter": A.NODE_PN_COUNTER, "flake-ids": A.NODE_FLAKE_IDS}
+                 "pn-counter": A.NODE_PN_COUNTER, "flake-ids": A.NODE_FLAKE_IDS, "lin-kv-proxy": A.NODE_LIN_KV_PROXY}
+SERVICES = {"lin-kv": A.SVC_LIN_KV, "seq-kv": A.SVC_SEQ_KV, "lww-kv": A.SVC_LWW_KV}
 TOPOLOGIES = {"grid": A.TOPO_GRID, "line": A.TOPO_LINE, "total": A.TOPO_TOTAL, "tree": A.TOPO_TREE2,
               "tree2": A.TOPO_TREE2, "tree3": A.TOPO_TREE3, "tree4": A.TOPO_TREE4}
 LATENCY_DISTS = {"constant": A.LAT_CONSTANT, "uniform": A.LAT_UNIFORM, "exponential": A.LAT_EXPONENTIAL}
@@ -69,6 +70,8 @@ def test_config(workload="broadcast", bin=None, node_count=5, concurrency=None, 
     cfg.p_loss_q32 = min(int(p_loss * 2**32), 2**32 - 1)
     cfg.seed = int(seed)
     for k, v in capacities.items():
+        if k == "proxy_service" and isinstance(v, str):
+            v = SERVICES[v]
         if not hasattr(cfg, k):
             raise EngineError(f"unknown option {k}")
         setattr(cfg, k, int(v))

@@ -61,7 +61,7 @@ enum { M_INIT = 1, M_INIT_OK, M_TOPOLOGY, M_TOPOLOGY_OK, M_ECHO, M_ECHO_OK, M_BR
        M_TXN, M_TXN_OK, M_GENERATE, M_GENERATE_OK };                                                                /* txn_list_append.clj:73-80 */
 
 /* RNG streams */
-enum { S_GEN = 1, S_GEN2 = 2, S_GEN3 = 3, S_LATENCY = 4, S_LOSS = 5, S_NODE = 11,
+enum { S_GEN = 1, S_GEN2 = 2, S_GEN3 = 3, S_LATENCY = 4, S_LOSS = 5, S_NODE = 11, S_SVC = 12,
        S_NEM_STAGGER = 7, S_NEM_SPEC = 8, S_NEM_SHUFFLE = 9, S_NEM_PICK = 10 };
 
 enum { PH_INIT, PH_INIT_WAIT, PH_TOPO, PH_TOPO_WAIT, PH_MAIN_START, PH_MAIN, PH_DRAIN, PH_NEM_FINAL,
@@ -81,6 +81,7 @@ typedef struct {
   u32 N, C, CS, E, W; /* nodes, workers, client slots, endpoints, words per node set */
   u32 S;              /* services (endpoints after the client slots): 1 = lin-kv for the txn workload */
   struct txn_s *txn;  /* txn-list-append state (txn_nodes.inc) */
+  struct svc_s *svc;  /* proxy node + key-value services (svc_nodes.inc) */
   u64 key;
   u32 adj[MAXN][MW];
   /* net (net.clj:79-103) */
@@ -360,10 +361,12 @@ static void node_timer(sim_t *s, u32 node) {
 
 #include "raft_nodes.inc"
 #include "txn_nodes.inc"
+#include "svc_nodes.inc"
 
 static void node_handle(sim_t *s, u32 node, const qent *q) {
   if (s->cfg.node_program == MSIM_NODE_RAFT) { raft_handle(s, node, q); return; }
   if (s->cfg.node_program == MSIM_NODE_TXN_SINGLE_KEY) { txn_node_handle(s, node, q); return; }
+  if (s->cfg.node_program == MSIM_NODE_LIN_KV_PROXY) { px_node_handle(s, node, q); return; }
   switch (q->type) {
     case M_INIT: /* node.rb init handler -> init_ok; g-set starts its periodic task (node.rb:129-138) */
       if (s->cfg.node_program == MSIM_NODE_G_SET || s->cfg.node_program == MSIM_NODE_PN_COUNTER) s->timer_next[node] = s->T;
@@ -703,7 +706,7 @@ static void run_instance(sim_t *s) {
         qent q = s->committed[e]; s->has_committed[e] = 0;
         s->st.all_recv++; s->st.servers_recv++;
         jlog(s, 1, q.id, q.type, q.a, q.b, q.src, e);
-        svc_handle(s, &q);
+        if (s->svc) px_svc_handle(s, &q); else svc_handle(s, &q);
       }
     commit_sends(s);
     for (u32 e = 0; e < E; e++) poll_endpoint(s, e);
@@ -741,7 +744,7 @@ static sim_t *sim_new(const msim_config *cfg, uint64_t instance, msim_op *rows, 
   sim_t *s = (sim_t *)calloc(1, sizeof(sim_t));
   s->cfg = *cfg;
   s->N = cfg->n_nodes; s->C = cfg->concurrency; s->CS = s->C > s->N ? s->C : s->N;
-  s->S = cfg->node_program == MSIM_NODE_TXN_SINGLE_KEY ? 1 : 0;
+  s->S = cfg->node_program == MSIM_NODE_TXN_SINGLE_KEY || cfg->node_program == MSIM_NODE_LIN_KV_PROXY ? 1 : 0;
   s->E = s->N + s->CS + s->S;
   if (s->E > 255) { free(s); return NULL; }
   s->W = (cfg->max_values + 31) / 32;
@@ -769,7 +772,13 @@ static sim_t *sim_new(const msim_config *cfg, uint64_t instance, msim_op *rows, 
     for (u32 i = 0; i < s->N; i++) { rnode *r = &s->raft[i]; r->voted_for = -1; r->leader = -1; r->last_applied = 1; memset(r->kv, 0xFF, sizeof r->kv);
       rentry e0; memset(&e0, 0, sizeof e0); r_append(r, &e0, 1); }
   }
-  if (s->S) {
+  if (cfg->node_program == MSIM_NODE_LIN_KV_PROXY) {
+    svc_t *v = (svc_t *)calloc(1, sizeof(svc_t));
+    v->cb = (pslot *)calloc((size_t)s->N * PX_SLOTS, sizeof(pslot));
+    v->client_idx = (u32 *)calloc(s->E, 4);
+    memset(v->kv, 0xFF, 256); memset(v->ring, 0xFF, sizeof v->ring); memset(v->rep, 0xFF, sizeof v->rep);
+    s->svc = v;
+  } else if (s->S) {
     txn_t *t = (txn_t *)calloc(1, sizeof(txn_t));
     t->slots = (tslot *)calloc((size_t)s->N * TXN_SLOTS, sizeof(tslot));
     t->root = V_NIL;
@@ -795,6 +804,7 @@ static void sim_free(sim_t *s) {
   for (u32 n = 0; n < s->N; n++) free(s->tasks[n].v);
   for (u32 i = 0; i < s->n_snap; i++) free(s->snap[i]);
   if (s->raft) { for (u32 i = 0; i < s->N; i++) free(s->raft[i].log); free(s->raft); }
+  if (s->svc) { free(s->svc->cb); free(s->svc->client_idx); free(s->svc); }
   if (s->txn) { free(s->txn->slots); free(s->txn->kv); free(s->txn->kv_n); free(s->txn); }
   free(s->snap); free(s->inbox); free(s->committed); free(s->has_committed); free(s->deliver_at); free(s->seen);
   free(s->unacked); free(s->node_msg_id); free(s->nbr_known); free(s->tasks); free(s->key_reg); free(s->timer_next); free(s->tick); free(s->flake);

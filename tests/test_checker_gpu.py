@@ -120,3 +120,15 @@ def test_pn_counter_checker_on_engine_histories(lib):
         rows, _ = eng.raw_history(5)
         one = E.check_pn_history(rows)
         assert one["valid?"] is True and len(one["final-reads"]) == int(res["attempt_count"][5])
+
+
+def test_services_under_the_linearizability_checker(lib):
+    """lin_kv_proxy.rb:33-35: lin-kv passes, seq-kv / lww-kv show linearization failures (engine histories, msim_check)."""
+    out = {}
+    for service in ("lin-kv", "seq-kv", "lww-kv"):
+        cfg = E.test_config("lin-kv", bin="lin-kv-proxy", proxy_service=service, node_count=5, rate=100, time_limit=30, latency=5, seed=14)
+        with E.Engine(cfg) as eng:
+            eng.run(0, 32)
+            eng.check()
+            out[service] = int((eng.check_results()["valid"] == 1).sum())
+    assert out["lin-kv"] == 32 and out["seq-kv"] < 16 and out["lww-kv"] < 16, out

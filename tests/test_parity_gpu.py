@@ -220,3 +220,20 @@ def test_unique_ids_parity(lib, kw):
         eng.check()
         res = eng.check_results()
         assert (res["valid"] == 1).all() and (res["duplicated_count"] == 0).all()
+
+
+@pytest.mark.parametrize("service,kw", [
+    ("lin-kv", dict()),
+    ("lin-kv", dict(latency=20, latency_dist="exponential", p_loss=0.05)),
+    ("lin-kv", dict(nemesis=["partition"], nemesis_interval=4, journal_capacity=60000)),
+    ("seq-kv", dict(rate=100)),
+    ("seq-kv", dict(latency=30, latency_dist="uniform", node_count=3)),
+    ("lww-kv", dict(rate=100)),
+    ("lww-kv", dict(node_count=7, concurrency=28, latency=10)),
+])
+def test_lin_kv_proxy_and_services_parity(lib, service, kw):
+    """demo/ruby/lin_kv_proxy.rb over lin-kv / seq-kv / lww-kv (service.clj), svc_kernel<>."""
+    base = dict(node_count=5, rate=60, time_limit=12, latency=5, seed=91)
+    base.update(kw)
+    cfg = E.test_config("lin-kv", bin="lin-kv-proxy", proxy_service=service, **base)
+    _compare(cfg, 0, 6)
