@@ -59,6 +59,7 @@ struct KParams {
   u32 off_inbox, off_seen, off_misc;  // LDS byte offsets
   u32 gen_period2_us, nem_period2_us;
   u32 raft_log_cap;   // raft: entries per node log
+  u32 dev_flags;      // developer switches (env MSIM_DEV_FLAGS): 1 = cascade rounds inline, 2 = no lone-operation path
 };
 
 __constant__ u32 d_log2_q24[257];
@@ -985,6 +986,7 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   kp.nem_period2_us = (u32)(2000ull * c.nemesis_interval_ms);
   const bool is_raft = c.node_program == MSIM_NODE_RAFT;
   kp.raft_log_cap = is_raft ? raft_log_cap(c) : 0;
+  { static const char *df = std::getenv("MSIM_DEV_FLAGS"); kp.dev_flags = df ? (u32)std::atoi(df) : 0u; }
   const bool wide = c.n_nodes > 32;
   size_t off = (wide ? WIDE_STAGE_ROWS : STAGE_ROWS) * 16;
   const bool is_txn = c.node_program == MSIM_NODE_TXN_SINGLE_KEY, is_px = c.node_program == MSIM_NODE_LIN_KV_PROXY;
