@@ -92,10 +92,13 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
     u64 walk = __ballot(live && (my_f == MSIM_F_READ || my_f == MSIM_F_ECHO));
     const u32 v_base = v_cur;
     v_cur += (u32)__popcll(add_inv);  // values are handed out 0,1,2,... in invoke order
+    // the serial walk shares ONE scalar unit per CU among 16 histories: everything that can be computed per row is
+    // computed by the row's own lane first (the division by C above all) and read back with a single v_readlane
+    const u32 my_info = my_type | (my_f << 2) | ((my_proc % C) << 8) | ((r.y >> 16) << 16);   // type, f, worker thread, payload words
     while (walk) {
       const u32 j = (u32)__builtin_ctzll(walk); walk &= walk - 1;
-      const u32 packed = c_rdlane(r.z, j), value = c_rdlane(r.w, j), hi = c_rdlane(r.y, j);
-      const u32 type = packed & 3, f = (packed >> 2) & 31, tt = (packed >> 12) % C, t = tt & 63;
+      const u32 info = c_rdlane(my_info, j), value = c_rdlane(r.w, j);
+      const u32 type = info & 3, f = (info >> 2) & 31, tt = (info >> 8) & 0xFF, t = tt & 63, hi = info & 0xFFFF0000u;
       const bool hi_slot = tt >= 64;
       const u32 idx = base + j;
       if (f == MSIM_F_READ) {
@@ -124,6 +127,8 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
   if (n_ri > p.max_reads) n_ri = p.max_reads;
 
   // lane w owns word w of the read bitmaps, i.e. elements 32w .. 32w+31
+  // Both passes are bound by the latency of one dependent global load per read (its bitmap word); the loads of 8 reads
+  // are issued together before they are folded in.
   // ---- pass 2a: known by reads (completion order) ----
   {
     u32 unk = 0xFFFFFFFFu;
@@ -131,17 +136,24 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
       const u32 cn = min(64u, n_rc - cb);
       uint2 my_rec = make_uint2(0, 0);
       if (lane < cn) my_rec = rec_c[cb + lane];
-      u32 ref = c_rdlane(my_rec.x, 0);
-      u32 word = lane < (ref >> 24) ? pay[(ref & 0xFFFFFFu) + lane] : 0u;
-      for (u32 j = 0; j < cn; j++) {
-        const u32 idx = c_rdlane(my_rec.y, j);
-        const u32 w = word;
-        if (j + 1 < cn) { ref = c_rdlane(my_rec.x, j + 1); word = lane < (ref >> 24) ? pay[(ref & 0xFFFFFFu) + lane] : 0u; }  // prefetch
-        u32 hits = w & unk;
-        unk &= ~w;
-        while (hits) {
-          const u32 e = lane * 32 + (u32)__builtin_ctz(hits); hits &= hits - 1;
-          if (e < p.max_values && known[e] > idx) known[e] = (u16)idx;
+      for (u32 j0 = 0; j0 < cn; j0 += 8) {
+        u32 wv[8];
+#pragma unroll
+        for (u32 t = 0; t < 8; t++) {
+          const u32 jj = min(j0 + t, 63u);
+          const u32 ref = c_rdlane(my_rec.x, jj);
+          wv[t] = (j0 + t < cn && lane < (ref >> 24)) ? pay[(ref & 0xFFFFFFu) + lane] : 0u;
+        }
+#pragma unroll
+        for (u32 t = 0; t < 8; t++) {
+          const u32 idx = c_rdlane(my_rec.y, min(j0 + t, 63u));
+          const u32 w = wv[t];   // 0 beyond the chunk: nothing to fold
+          u32 hits = w & unk;
+          unk &= ~w;
+          while (hits) {
+            const u32 e = lane * 32 + (u32)__builtin_ctz(hits); hits &= hits - 1;
+            if (e < p.max_values && known[e] > idx) known[e] = (u16)idx;
+          }
         }
       }
     }
@@ -149,6 +161,7 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
   // ---- pass 2b: last-present / last-absent (invocation order, latest first) ----
   {
     u32 pend_p = 0xFFFFFFFFu, pend_a = 0xFFFFFFFFu;
+    const u32 lo = lane * 32;
     for (u32 cbp = (n_ri + 63) / 64; cbp > 0; cbp--) {
       const u32 cb = (cbp - 1) * 64, cn = min(64u, n_ri - cb);
       const u64 vmask = ((u64)valid[cb / 32 + 1] << 32 | valid[cb / 32]) & (cn >= 64 ? ~0ull : ((1ull << cn) - 1));
@@ -156,20 +169,27 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
       uint2 my_rec = make_uint2(0, 0);
       if ((vmask >> lane) & 1) my_rec = rec_i[cb + lane];
       u64 todo = vmask;
-      u32 j = 63 - (u32)__builtin_clzll(todo);
-      u32 ref = c_rdlane(my_rec.x, j);
-      u32 word = lane < (ref >> 24) ? pay[(ref & 0xFFFFFFu) + lane] : 0u;
       while (todo) {
-        todo &= ~(1ull << j);
-        const u32 iv = c_rdlane(my_rec.y, j), inv = iv & 0xFFFFu, v_here = iv >> 16;
-        const u32 w = word;
-        if (todo) { j = 63 - (u32)__builtin_clzll(todo); ref = c_rdlane(my_rec.x, j); word = lane < (ref >> 24) ? pay[(ref & 0xFFFFFFu) + lane] : 0u; }  // prefetch
-        const u32 lo = lane * 32;
-        const u32 ex = v_here >= lo + 32 ? 0xFFFFFFFFu : (v_here <= lo ? 0u : ((1u << (v_here - lo)) - 1));  // elements that exist at this read
-        u32 hp = w & pend_p; pend_p &= ~w;
-        u32 ha = ~w & ex & pend_a; pend_a &= ~(~w & ex);
-        while (hp) { const u32 e = lo + (u32)__builtin_ctz(hp); hp &= hp - 1; if (e < p.max_values) lp_idx[e] = (u16)inv; }
-        while (ha) { const u32 e = lo + (u32)__builtin_ctz(ha); ha &= ha - 1; if (e < p.max_values) la_idx[e] = (u16)inv; }
+        u32 jl[8], wv[8], nb = 0;
+#pragma unroll
+        for (u32 t = 0; t < 8; t++) {   // the next (up to) 8 valid ranks of this chunk, latest first
+          const bool have = todo != 0;
+          const u32 j = have ? 63 - (u32)__builtin_clzll(todo) : 0u;
+          if (have) { todo &= ~(1ull << j); nb = t + 1; }
+          jl[t] = j;
+          const u32 ref = c_rdlane(my_rec.x, j);
+          wv[t] = (have && lane < (ref >> 24)) ? pay[(ref & 0xFFFFFFu) + lane] : 0u;
+        }
+#pragma unroll
+        for (u32 t = 0; t < 8; t++) {
+          const u32 iv = t < nb ? c_rdlane(my_rec.y, jl[t]) : 0u, inv = iv & 0xFFFFu, v_here = iv >> 16;   // beyond nb: v_here = 0, w = 0: a no-op
+          const u32 w = wv[t];
+          const u32 ex = v_here >= lo + 32 ? 0xFFFFFFFFu : (v_here <= lo ? 0u : ((1u << (v_here - lo)) - 1));  // elements that exist at this read
+          u32 hp = w & pend_p; pend_p &= ~w;
+          u32 ha = ~w & ex & pend_a; pend_a &= ~(~w & ex);
+          while (hp) { const u32 e = lo + (u32)__builtin_ctz(hp); hp &= hp - 1; if (e < p.max_values) lp_idx[e] = (u16)inv; }
+          while (ha) { const u32 e = lo + (u32)__builtin_ctz(ha); ha &= ha - 1; if (e < p.max_values) la_idx[e] = (u16)inv; }
+        }
       }
     }
   }
