@@ -550,7 +550,7 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
             rq_dest = dest_node;
             inv_row = true; inv_packed = MSIM_T_INVOKE | (c_f << 2) | (c_final << 11) | (process << 12); inv_value = c_value;
             rq_type = c_f == MSIM_F_ECHO ? M_ECHO : c_f == MSIM_F_BROADCAST ? M_BROADCAST : c_f == MSIM_F_ADD ? M_ADD : c_f == MSIM_F_GENERATE ? M_GENERATE : M_READ;
-            rq_a = c_f == MSIM_F_READ ? 0u : c_value;
+            rq_a = (c_f == MSIM_F_READ || c_f == MSIM_F_GENERATE) ? 0u : c_value;
           }
           want = ++next_msg_id;
           timeout_at = T + (kind == K_OP ? p.cfg.client_timeout_ms : 10000u) * 1000u;

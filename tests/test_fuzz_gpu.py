@@ -1,0 +1,51 @@
+"""Seeded differential sweep: random test options (workload, node program, cluster size, topology, rate, latency model,
+loss, nemesis, concurrency) through the HIP engine and the CPU oracle, bit-compared.  The short paths of the headline
+kernel (lone operation, cascade_lean<>, quiet_run<>) only fire under particular conditions; this sweep crosses their
+boundaries (latency 0 / 1 ms, high rates that overlap operations with cascades, tiny queues that spill, journal on/off)."""
+import os
+import random
+
+import pytest
+
+from maelstrom_amd import engine as E
+from test_parity_gpu import _compare
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_case(rng):
+    wl = rng.choice(["broadcast"] * 6 + ["g-set", "pn-counter", "g-counter", "unique-ids", "echo"])
+    kw = dict(node_count=rng.choice([1, 2, 3, 5, 7, 9, 16, 25, 32]), rate=rng.choice([5, 20, 100, 400, 2000]),
+              time_limit=rng.choice([2, 3, 5]), seed=rng.randrange(1 << 40))
+    lat = rng.choice([0, 0, 0, 1, 2, 10, 50])
+    dist = rng.choice(["constant", "constant", "uniform", "exponential"]) if lat else "constant"
+    kw.update(latency=lat, latency_dist=dist)
+    if rng.random() < 0.2:
+        kw["p_loss"] = rng.choice([0.02, 0.2])
+    if rng.random() < 0.25 and kw["node_count"] >= 3:
+        kw.update(nemesis=["partition"], nemesis_interval=rng.choice([1, 2]))
+    if wl == "broadcast":
+        kw["bin"] = rng.choice(["broadcast-ff"] * 4 + ["broadcast-ff-echoback", "broadcast-ack-retry", "broadcast-rpc-all"])
+        kw["topology"] = rng.choice(["grid", "line", "total", "tree2", "tree3", "tree4"])
+        if kw["topology"] == "total" and kw["node_count"] > 16:
+            kw["rate"] = min(kw["rate"], 100)
+    if wl in ("g-set", "pn-counter", "g-counter"):
+        kw["time_limit"] = 6
+    if rng.random() < 0.25 and kw["node_count"] <= 16:
+        kw["concurrency"] = rng.choice([1, 2, 3]) * kw["node_count"] + rng.choice([0, 0, 1])
+    if rng.random() < 0.2:
+        kw["journal_capacity"] = 2000000
+    if rng.random() < 0.2:
+        kw["inbox_capacity"] = rng.choice([1, 2, 3])
+    return wl, kw
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("MSIM_FUZZ_CASES", "48"))))   # MSIM_FUZZ_CASES=N widens the sweep
+def test_random_options_engine_equals_oracle(lib, case):
+    rng = random.Random(0xC0FFEE + case)
+    wl, kw = _random_case(rng)
+    try:
+        cfg = E.test_config(wl, **kw)
+    except E.EngineError as e:   # an option combination the reference (or this build) rejects: not a parity case
+        pytest.skip(str(e))
+    _compare(cfg, rng.randrange(1 << 20), 3)
