@@ -133,7 +133,7 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
     uint32_t w = c->max_values / 32;
     uint64_t words = no_sets ? 16 : (uint64_t)(adds + c->concurrency) * w;
     // a transaction: <= L header words at :invoke, <= L x (1 + ceil((writes-per-key + L) / 4)) at completion
-    if (txn) words = (uint64_t)(ops_max + c->concurrency) * c->max_txn_length * (2 + (c->max_writes_per_key + c->max_txn_length + 3) / 4) / 2 + 64;
+    if (txn) words = (uint64_t)(ops_max + c->concurrency) * c->max_txn_length * (2 + (c->max_writes_per_key + c->max_txn_length + 3) / 4) + 64;  // worst case: all reads of full lists
     words += (uint64_t)nem_ops * c->n_nodes * MSIM_MASK_WORDS + 16;
     if (words > 0xFFFFFFu) { set_err(err, errlen, "payload area above 2^24 words per instance"); return MSIM_E_INVALID; }
     c->max_payload_words = (uint32_t)words;

@@ -48,4 +48,42 @@ def test_random_options_engine_equals_oracle(lib, case):
         cfg = E.test_config(wl, **kw)
     except E.EngineError as e:   # an option combination the reference (or this build) rejects: not a parity case
         pytest.skip(str(e))
+    first = rng.randrange(1 << 20)
+    try:
+        E.Engine(cfg).close()
+    except E.EngineError as e:   # e.g. more endpoints than one wavefront has lanes
+        pytest.skip(str(e))
+    _compare(cfg, first, 3)
+
+
+def _random_kv_case(rng):
+    kind = rng.choice(["raft", "raft", "proxy", "proxy", "txn", "txn"])
+    n = rng.choice([1, 3, 5, 7])
+    kw = dict(node_count=n, rate=rng.choice([10, 30, 100, 300]), time_limit=rng.choice([4, 8, 12]), seed=rng.randrange(1 << 40))
+    lat = rng.choice([0, 1, 5, 20])
+    kw.update(latency=lat, latency_dist=rng.choice(["constant", "uniform", "exponential"]) if lat else "constant")
+    if rng.random() < 0.25:
+        kw["p_loss"] = rng.choice([0.02, 0.1])
+    if rng.random() < 0.3 and n >= 3:
+        kw.update(nemesis=["partition"], nemesis_interval=rng.choice([1, 3]))
+    if rng.random() < 0.2:
+        kw["journal_capacity"] = 1000000
+    if kind == "raft":
+        return "lin-kv", dict(kw, bin="raft")
+    if kind == "proxy":
+        return "lin-kv", dict(kw, bin="lin-kv-proxy", proxy_service=rng.choice(["lin-kv", "seq-kv", "lww-kv"]))
+    kw.update(key_count=rng.choice([1, 3, 10]), max_txn_length=rng.choice([1, 4, 8]), max_writes_per_key=rng.choice([2, 16, 40]))
+    return "txn-list-append", kw
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("MSIM_FUZZ_CASES", "36"))))
+def test_random_kv_options_engine_equals_oracle(lib, case):
+    """The same sweep for the key-value programs: Raft, the proxy over the three services, single-root transactions."""
+    rng = random.Random(0xBADC0DE + case)
+    wl, kw = _random_kv_case(rng)
+    try:
+        cfg = E.test_config(wl, **kw)
+        E.Engine(cfg).close()
+    except E.EngineError as e:
+        pytest.skip(str(e))
     _compare(cfg, rng.randrange(1 << 20), 3)
