@@ -174,3 +174,53 @@ def test_checker_indeterminate_appends_may_be_observed():
     res = _check((":invoke", 0, [[A_, 1, 1]]), (":info", 0, [[A_, 1, 1]]),
                  (":invoke", 1, [[R_, 1, None]]), (":ok", 1, [[R_, 1, [1]]]))
     assert res["valid?"] is True and res["info-count"] == 1
+
+
+CYCLES = {"G0", "G1c", "G-single", "G2"}
+
+
+def _agree(ops):
+    import elle_ref
+    rows, pay = E.encode_txn_history([o for o in ops if o.get("process") != ":nemesis"])
+    got = E.check_txn_history(rows, pay)
+    ref = elle_ref.analyse(ops)
+    assert got["valid?"] == ref["valid?"], (got, ref)
+    assert bool(CYCLES & set(got["anomalies"])) == ("cycle" in ref["anomalies"]), (got, ref)
+    for a in ("G1a", "G1b", "internal", "incompatible-order", "duplicate-elements", "dirty-update", "realtime"):
+        assert (a in got["anomalies"]) == (a in ref["anomalies"]), (a, got, ref)
+    return got
+
+
+def test_checker_agrees_with_the_python_restatement_on_engine_and_mutated_histories():
+    """csrc/txn_check.cpp against tests/elle_ref.py (written independently): oracle histories (valid), then the same
+    histories with a read list corrupted in one of five ways — both must see the same classes of anomaly."""
+    import copy
+    import random
+    cfg = _cfg(rate=60, time_limit=8, latency=5, key_count=3)
+    r = O.run(cfg, 0, 3)
+    rng = random.Random(7)
+    n_bad = 0
+    for i in range(3):
+        rows, pay = r.history(i)
+        ops = [o for o in E.decode_history(rows, pay, cfg.n_nodes, A.WL_TXN_LIST_APPEND) if o["process"] != ":nemesis"]
+        assert _agree(ops)["valid?"] is True
+        reads = [(oi, mi) for oi, o in enumerate(ops) if o["type"] == ":ok" for mi, m in enumerate(o["value"]) if m[0] == ":r" and m[2] and len(m[2]) >= 2]
+        for trial in range(40):
+            oi, mi = rng.choice(reads)
+            mut = copy.deepcopy(ops)
+            lst = mut[oi]["value"][mi][2]
+            how = trial % 5
+            if how == 0:
+                lst.pop()                       # stale read: one version behind
+            elif how == 1:
+                lst[0], lst[-1] = lst[-1], lst[0]   # incompatible order
+            elif how == 2:
+                lst.append(lst[0])              # duplicate element
+            elif how == 3:
+                lst.append(61)                  # an element nobody appended
+            else:
+                del lst[:]                      # sees nothing although elements were visible
+                mut[oi]["value"][mi][2] = None
+            got = _agree(mut)
+            n_bad += got["valid?"] is False
+    assert n_bad > 60
