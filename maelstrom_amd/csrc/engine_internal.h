@@ -44,6 +44,18 @@ struct msim_ctx {
   std::string err;
 };
 
+// Host threads one engine context may use for its host-side checkers: the hardware threads divided by the ranks sharing
+// the node (LOCAL_WORLD_SIZE, set by torch.distributed.run), or MSIM_HOST_THREADS if set.
+#include <cstdlib>
+#include <thread>
+static inline unsigned msim_host_threads() {
+  if (const char *e = std::getenv("MSIM_HOST_THREADS")) { const int v = std::atoi(e); if (v > 0) return (unsigned)v; }
+  unsigned nt = std::thread::hardware_concurrency();
+  if (nt == 0) nt = 1;
+  if (const char *e = std::getenv("LOCAL_WORLD_SIZE")) { const int v = std::atoi(e); if (v > 1) nt = nt / (unsigned)v ? nt / (unsigned)v : 1; }
+  return nt;
+}
+
 // checker.hip
 int msim_check_launch(msim_ctx *ctx);
 // lin_check.cpp

@@ -300,8 +300,7 @@ int msim_check_txn_host(msim_ctx *ctx) {
   const uint32_t n = ctx->n_inst;
   if (ctx->h_check) { (void)hipHostFree(ctx->h_check); ctx->h_check = nullptr; }
   MSIM_HIP_TRY(ctx, hipHostMalloc(&ctx->h_check, (size_t)n * sizeof(msim_check_result)));
-  unsigned nt = std::thread::hardware_concurrency();
-  if (nt == 0) nt = 1;
+  unsigned nt = msim_host_threads();
   if (nt > n) nt = n;
   std::vector<std::thread> th;
   for (unsigned t = 0; t < nt; t++)
