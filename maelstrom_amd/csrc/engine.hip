@@ -127,6 +127,21 @@ __device__ __forceinline__ u32 scan32(u32 v) {
   return v;
 }
 // value of `v` in lane `l` (per-lane l; every lane must execute this: ds_bpermute_b32)
+// min (deadline, id) over the n envelopes of an HBM spill area.  The scan is latency-bound — with one dependent load per
+// step every queued envelope costs an L2/HBM round trip — so 8 independent loads are in flight per step.
+__device__ __forceinline__ void spill_min(const uint4 *q, u32 n, u64 &bk, u32 &best, bool &hit) {
+  for (u32 i0 = 0; i0 < n; i0 += 8) {
+    uint2 k[8];
+#pragma unroll
+    for (u32 t = 0; t < 8; t++) k[t] = *reinterpret_cast<const uint2 *>(&q[min(i0 + t, n - 1)]);
+#pragma unroll
+    for (u32 t = 0; t < 8; t++) {
+      const u64 kk = ((u64)k[t].x << 32) | k[t].y;
+      if (i0 + t < n && kk < bk) { bk = kk; best = i0 + t; hit = true; }
+    }
+  }
+}
+
 // tells the compiler a value is dead here (freeze of undef): a register that is only meaningful inside a round must not
 // be carried around the round loops as a PHI
 __device__ __forceinline__ void forget(u32 &v) { v = __builtin_nondeterministic_value(v); }
@@ -317,15 +332,13 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
     }
     while (elig && !has_c && (in_n | sp_n) != 0) {
       u32 best = 0; bool in_spill = false;
-      uint2 bk = make_uint2(INF, INF);
+      u64 bk = ~0ull;
       for (u32 i = 0; i < in_n; i++) {
         const uint2 kk = *reinterpret_cast<const uint2 *>(&my_inbox[i]);
-        if (kk.x < bk.x || (kk.x == bk.x && kk.y < bk.y)) { bk = kk; best = i; }
+        const u64 k2 = ((u64)kk.x << 32) | kk.y;
+        if (k2 < bk) { bk = k2; best = i; }
       }
-      for (u32 i = 0; i < sp_n; i++) {  // deep queues only (long head-of-line sleeps)
-        const uint2 kk = *reinterpret_cast<const uint2 *>(&my_spill[i]);
-        if (kk.x < bk.x || (kk.x == bk.x && kk.y < bk.y)) { bk = kk; best = i; in_spill = true; }
-      }
+      spill_min(my_spill, sp_n, bk, best, in_spill);  // deep queues only (long head-of-line sleeps)
       uint4 e;
       if (in_spill) { e = my_spill[best]; sp_n--; if (best != sp_n) my_spill[best] = my_spill[sp_n]; }
       else { e = my_inbox[best]; in_n--; if (best != in_n) my_inbox[best] = my_inbox[in_n]; }
