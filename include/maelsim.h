@@ -43,7 +43,8 @@ enum {
 /* ---- configuration (mirrors the CLI option map, core.clj:136-229, + ensemble/determinism fields) -- */
 enum { MSIM_WL_ECHO = 0, MSIM_WL_BROADCAST = 1, MSIM_WL_G_SET = 2, MSIM_WL_LIN_KV = 3, MSIM_WL_TXN_LIST_APPEND = 4,
        MSIM_WL_PN_COUNTER = 5 /* workload/pn_counter.clj */, MSIM_WL_G_COUNTER = 6 /* workload/g_counter.clj: pn-counter without negative adds */,
-       MSIM_WL_UNIQUE_IDS = 7 /* workload/unique_ids.clj */ };
+       MSIM_WL_UNIQUE_IDS = 7 /* workload/unique_ids.clj */,
+       MSIM_WL_TXN_RW_REGISTER = 8 /* workload/txn_rw_register.clj: transactions of reads / writes over registers */ };
 
 /* Built-in node programs (the `--bin` of the reference). */
 enum {
@@ -62,14 +63,21 @@ enum {
   MSIM_NODE_LIN_KV_PROXY = 10,  /* demo/ruby/lin_kv_proxy.rb:8-43: every read / write / cas is proxied to the key-value service
                                    named by msim_config.proxy_service (service.clj:31-114,141-243,290-296)                   */
   MSIM_NODE_FLAKE_IDS = 9,      /* demo/clojure/flake_ids.clj:10-33: id = [seconds, counter within that second, node id] */
-  MSIM_NODE_PN_COUNTER = 8      /* demo/ruby/pn_counter.rb:8-121 == demo/js/crdt_pn_counter.js: increments and decrements in two
+  MSIM_NODE_PN_COUNTER = 8,     /* demo/ruby/pn_counter.rb:8-121 == demo/js/crdt_pn_counter.js: increments and decrements in two
                                    per-node G-counters, merged by element-wise max, replicated to all others every 5 s      */
+  MSIM_NODE_TXN_RW_HAT = 11     /* demo/clojure/txn_rw_register_hat.clj:1-190: highly available transactions — every node applies a
+                                   txn locally at a Lamport timestamp (last write wins per key), then replicates it to the
+                                   others every 100 ms until they acknowledge (the demo of core.clj:115-121)                */
 };
 
 enum { MSIM_LAT_CONSTANT = 0, MSIM_LAT_UNIFORM = 1, MSIM_LAT_EXPONENTIAL = 2 };  /* net.clj:65-77 */
 enum { MSIM_TOPO_GRID = 0, MSIM_TOPO_LINE = 1, MSIM_TOPO_TOTAL = 2,
        MSIM_TOPO_TREE2 = 3, MSIM_TOPO_TREE3 = 4, MSIM_TOPO_TREE4 = 5 };           /* broadcast.clj:171-179 */
 enum { MSIM_SVC_LIN_KV = 0, MSIM_SVC_SEQ_KV = 1, MSIM_SVC_LWW_KV = 2 };               /* service.clj:290-296 */
+/* --consistency-models (core.clj:160-165, default strict-serializable; the txn-rw-register demo asks for read-committed,
+ * core.clj:118): which of the anomalies the transactional checkers find make a history invalid (see msim_check_txn_rows). */
+enum { MSIM_CM_STRICT_SERIALIZABLE = 0, MSIM_CM_SERIALIZABLE = 1, MSIM_CM_SNAPSHOT_ISOLATION = 2, MSIM_CM_READ_COMMITTED = 3,
+       MSIM_CM_READ_UNCOMMITTED = 4 };
 enum { MSIM_NEMESIS_PARTITION = 1u };                                              /* core.clj:49-51 */
 
 typedef struct msim_config {
@@ -103,7 +111,8 @@ typedef struct msim_config {
   uint32_t max_txn_length;       /* --max-txn-length, default 4 (core.clj:191-194); min length is 1 [upstream]    */
   uint32_t max_writes_per_key;   /* --max-writes-per-key, default 16 (core.clj:196-199)                           */
   uint32_t proxy_service;        /* MSIM_SVC_*: which service lin_kv_proxy.rb talks to (its line 35 invites swapping it)  */
-  uint32_t reserved[2];
+  uint32_t consistency_model;    /* MSIM_CM_*: --consistency-models for the transactional workloads (core.clj:160-165)            */
+  uint32_t replication_words;    /* txn-rw-register: u32 words per instance for the txn lists of replicate messages; 0 = derive   */
 } msim_config;
 
 /* ---- outputs ------------------------------------------------------------------------------------- */
@@ -181,7 +190,7 @@ enum { MSIM_M_INIT = 1, MSIM_M_INIT_OK, MSIM_M_TOPOLOGY, MSIM_M_TOPOLOGY_OK, MSI
        MSIM_M_BROADCAST_OK, MSIM_M_READ, MSIM_M_READ_OK, MSIM_M_ADD, MSIM_M_ADD_OK, MSIM_M_REPLICATE,
        MSIM_M_WRITE, MSIM_M_WRITE_OK, MSIM_M_CAS, MSIM_M_CAS_OK, MSIM_M_ERROR,
        MSIM_M_REQUEST_VOTE, MSIM_M_REQUEST_VOTE_RES, MSIM_M_APPEND_ENTRIES, MSIM_M_APPEND_ENTRIES_RES,
-       MSIM_M_TXN, MSIM_M_TXN_OK, MSIM_M_GENERATE, MSIM_M_GENERATE_OK };
+       MSIM_M_TXN, MSIM_M_TXN_OK, MSIM_M_GENERATE, MSIM_M_GENERATE_OK, MSIM_M_REPLICATE_ACK };
 
 /* Per-instance bookkeeping (not part of the algorithmic output bytes). */
 typedef struct msim_inst_meta {
@@ -263,8 +272,22 @@ int msim_check_lin_kv_rows(const msim_op *rows, uint32_t n_rows, msim_check_resu
 enum { MSIM_ANOMALY_G0 = 1u, MSIM_ANOMALY_G1A = 2u, MSIM_ANOMALY_G1B = 4u, MSIM_ANOMALY_G1C = 8u, MSIM_ANOMALY_G_SINGLE = 16u,
        MSIM_ANOMALY_G2 = 32u, MSIM_ANOMALY_INTERNAL = 64u, MSIM_ANOMALY_DUPLICATE_ELEMENTS = 128u,
        MSIM_ANOMALY_INCOMPATIBLE_ORDER = 256u, MSIM_ANOMALY_REALTIME = 512u /* cycle needs a realtime edge (G*-realtime) */,
-       MSIM_ANOMALY_DIRTY_UPDATE = 1024u };
+       MSIM_ANOMALY_DIRTY_UPDATE = 1024u, MSIM_ANOMALY_CYCLIC_VERSIONS = 2048u /* rw-register: a key's inferred version order has a cycle */ };
 int msim_check_txn_rows(const msim_op *rows, uint32_t n_rows, const uint32_t *payload, uint32_t n_words, msim_check_result *out);
+
+/* The anomalies (MSIM_ANOMALY_* bits) a consistency model forbids, after Adya's PL levels as elle.consistency-model
+ * arranges them [upstream, not vendored]: read-uncommitted G0; read-committed + G1a G1b G1c; snapshot-isolation + G-single
+ * and internal; serializable + G2; strict-serializable + the -realtime cycles.  Duplicate elements, incompatible orders,
+ * dirty updates and cyclic versions make a history invalid under every model. */
+uint32_t msim_proscribed_anomalies(uint32_t consistency_model);
+
+/* Host-only utility behind msim_check for txn-rw-register: the rw-register analysis of [upstream] elle
+ * (jepsen.tests.cycle.wr with :wfr-keys? true, txn_rw_register.clj:150-168): writes are unique per key; version orders come
+ * from the initial nil and from writes that follow a read of the same key inside one transaction; ww/wr/rw (+ realtime)
+ * dependency graph, cycle search, G1a / G1b / internal.  Micro-op words: bit 0 = write, bits 1-15 key, bits 16-23 value
+ * (0xFF = nil).  Same result fields as msim_check_txn_rows; valid is judged against `consistency_model`. */
+int msim_check_rw_rows(const msim_op *rows, uint32_t n_rows, const uint32_t *payload, uint32_t n_words, uint32_t consistency_model,
+                       msim_check_result *out);
 
 /* Host-only utility behind msim_check for pn-counter: the checker of workload/pn_counter.clj:84-123 — every :ok read
  * marked :final? must lie in the acceptable set = sum of the :ok adds plus any subset of the :info adds, kept as merged

@@ -14,9 +14,10 @@ ABI_VERSION = 1
 
 # enums (include/maelsim.h)
 OK, E_INVALID, E_NO_DEVICE, E_HIP, E_NOMEM, E_RANGE, E_UNSUPPORTED, E_OVERFLOW = 0, -1, -2, -3, -4, -5, -6, -7
-WL_ECHO, WL_BROADCAST, WL_G_SET, WL_LIN_KV, WL_TXN_LIST_APPEND, WL_PN_COUNTER, WL_G_COUNTER, WL_UNIQUE_IDS = range(8)
-NODE_ECHO, NODE_BCAST_FF, NODE_BCAST_FF_ECHOBACK, NODE_BCAST_ACK_RETRY, NODE_BCAST_RPC_ALL, NODE_G_SET, NODE_RAFT, NODE_TXN_SINGLE_KEY, NODE_PN_COUNTER, NODE_FLAKE_IDS, NODE_LIN_KV_PROXY = range(11)
+WL_ECHO, WL_BROADCAST, WL_G_SET, WL_LIN_KV, WL_TXN_LIST_APPEND, WL_PN_COUNTER, WL_G_COUNTER, WL_UNIQUE_IDS, WL_TXN_RW_REGISTER = range(9)
+NODE_ECHO, NODE_BCAST_FF, NODE_BCAST_FF_ECHOBACK, NODE_BCAST_ACK_RETRY, NODE_BCAST_RPC_ALL, NODE_G_SET, NODE_RAFT, NODE_TXN_SINGLE_KEY, NODE_PN_COUNTER, NODE_FLAKE_IDS, NODE_LIN_KV_PROXY, NODE_TXN_RW_HAT = range(12)
 SVC_LIN_KV, SVC_SEQ_KV, SVC_LWW_KV = range(3)
+CM_STRICT_SERIALIZABLE, CM_SERIALIZABLE, CM_SNAPSHOT_ISOLATION, CM_READ_COMMITTED, CM_READ_UNCOMMITTED = range(5)
 LAT_CONSTANT, LAT_UNIFORM, LAT_EXPONENTIAL = range(3)
 TOPO_GRID, TOPO_LINE, TOPO_TOTAL, TOPO_TREE2, TOPO_TREE3, TOPO_TREE4 = range(6)
 NEMESIS_PARTITION = 1
@@ -29,14 +30,14 @@ NO_VALUE = 0xFFFFFFFF
 FLAG_ROWS_OVERFLOW, FLAG_PAYLOAD_OVERFLOW, FLAG_INBOX_OVERFLOW, FLAG_VALUES_OVERFLOW, FLAG_ROUND_LIMIT, FLAG_JOURNAL_OVERFLOW, FLAG_ARENA_OVERRUN = 1, 2, 4, 8, 16, 32, 64
 MSG_TYPES = ["", "init", "init_ok", "topology", "topology_ok", "echo", "echo_ok", "broadcast", "broadcast_ok", "read", "read_ok",
              "add", "add_ok", "replicate", "write", "write_ok", "cas", "cas_ok", "error", "request_vote", "request_vote_res",
-             "append_entries", "append_entries_res", "txn", "txn_ok", "generate", "generate_ok"]
+             "append_entries", "append_entries_res", "txn", "txn_ok", "generate", "generate_ok", "replicate_ack"]
 ANOMALIES = {1: "G0", 2: "G1a", 4: "G1b", 8: "G1c", 16: "G-single", 32: "G2", 64: "internal", 128: "duplicate-elements",
-             256: "incompatible-order", 512: "realtime", 1024: "dirty-update"}
+             256: "incompatible-order", 512: "realtime", 1024: "dirty-update", 2048: "cyclic-versions"}
 MASK_WORDS = 4
 
 EXPORTS = [
     "msim_abi_version", "msim_device_count", "msim_config_defaults", "msim_config_finalize", "msim_create",
-    "msim_run", "msim_run_async", "msim_check", "msim_check_lin_kv_rows", "msim_check_txn_rows", "msim_check_pn_rows", "msim_check_unique_rows", "msim_fetch", "msim_history", "msim_net_stats_get", "msim_journal", "msim_meta",
+    "msim_run", "msim_run_async", "msim_check", "msim_check_lin_kv_rows", "msim_check_txn_rows", "msim_check_rw_rows", "msim_proscribed_anomalies", "msim_check_pn_rows", "msim_check_unique_rows", "msim_fetch", "msim_history", "msim_net_stats_get", "msim_journal", "msim_meta",
     "msim_check_results", "msim_device_buffers_get", "msim_last_kernel_ms", "msim_get_config",
     "msim_selftest_wave", "msim_last_error", "msim_destroy",
 ]
@@ -52,7 +53,7 @@ class Config(C.Structure):
         ("quiesce_ms", C.c_uint32), ("seed", C.c_uint64), ("max_values", C.c_uint32), ("max_rows", C.c_uint32),
         ("max_payload_words", C.c_uint32), ("inbox_capacity", C.c_uint32), ("spill_capacity", C.c_uint32),
         ("journal_capacity", C.c_uint32), ("key_count", C.c_uint32), ("max_txn_length", C.c_uint32),
-        ("max_writes_per_key", C.c_uint32), ("proxy_service", C.c_uint32), ("reserved", C.c_uint32 * 2),
+        ("max_writes_per_key", C.c_uint32), ("proxy_service", C.c_uint32), ("consistency_model", C.c_uint32), ("replication_words", C.c_uint32),
     ]
 
 

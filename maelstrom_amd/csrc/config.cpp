@@ -32,6 +32,7 @@ extern "C" int msim_config_defaults(msim_config *cfg, uint32_t workload, uint32_
     case MSIM_WL_TXN_LIST_APPEND: cfg->node_program = MSIM_NODE_TXN_SINGLE_KEY; break;
     case MSIM_WL_PN_COUNTER: case MSIM_WL_G_COUNTER: cfg->node_program = MSIM_NODE_PN_COUNTER; break;
     case MSIM_WL_UNIQUE_IDS: cfg->node_program = MSIM_NODE_FLAKE_IDS; break;
+    case MSIM_WL_TXN_RW_REGISTER: cfg->node_program = MSIM_NODE_TXN_RW_HAT; cfg->consistency_model = MSIM_CM_READ_COMMITTED; break;  // core.clj:115-121
     default: cfg->node_program = MSIM_NODE_RAFT; break;
   }
   cfg->n_nodes = n_nodes;
@@ -75,7 +76,7 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
   if (c->concurrency == 0) c->concurrency = c->n_nodes;
   uint32_t slots = c->concurrency > c->n_nodes ? c->concurrency : c->n_nodes;
   if (c->n_nodes + slots > 255) { set_err(err, errlen, "n_nodes + max(concurrency, n_nodes) must be <= 255"); return MSIM_E_INVALID; }
-  if (c->workload > MSIM_WL_UNIQUE_IDS) { set_err(err, errlen, "unknown workload"); return MSIM_E_INVALID; }
+  if (c->workload > MSIM_WL_TXN_RW_REGISTER) { set_err(err, errlen, "unknown workload"); return MSIM_E_INVALID; }
   if (c->latency_dist > MSIM_LAT_EXPONENTIAL) { set_err(err, errlen, "latency_dist must be constant, uniform, or exponential"); return MSIM_E_INVALID; }
   if (c->latency_dist == MSIM_LAT_EXPONENTIAL && c->latency_mean_ms == 0) {
     // net.clj:77 (exponential-distribution (/ mean)) throws "Divide by zero" for --latency 0
@@ -96,20 +97,25 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
     case MSIM_WL_TXN_LIST_APPEND: ok = c->node_program == MSIM_NODE_TXN_SINGLE_KEY; break;
     case MSIM_WL_PN_COUNTER: case MSIM_WL_G_COUNTER: ok = c->node_program == MSIM_NODE_PN_COUNTER; break;
     case MSIM_WL_UNIQUE_IDS: ok = c->node_program == MSIM_NODE_FLAKE_IDS; break;
+    case MSIM_WL_TXN_RW_REGISTER: ok = c->node_program == MSIM_NODE_TXN_RW_HAT; break;
     default: break;
   }
   if (!ok) { set_err(err, errlen, "node_program does not implement this workload"); return MSIM_E_INVALID; }
 
   if (c->proxy_service > MSIM_SVC_LWW_KV) { set_err(err, errlen, "proxy_service must be lin-kv, seq-kv or lww-kv"); return MSIM_E_INVALID; }
-  const bool txn = c->workload == MSIM_WL_TXN_LIST_APPEND;
+  if (c->consistency_model > MSIM_CM_READ_UNCOMMITTED) { set_err(err, errlen, "unknown consistency model"); return MSIM_E_INVALID; }
+  const bool hat = c->workload == MSIM_WL_TXN_RW_REGISTER;
+  const bool txn = c->workload == MSIM_WL_TXN_LIST_APPEND || hat;
   if (txn) {
     if (c->key_count == 0) c->key_count = 10;
     if (c->max_txn_length == 0) c->max_txn_length = 4;
     if (c->max_writes_per_key == 0) c->max_writes_per_key = 16;
     if (c->key_count > 16 || c->max_txn_length > 8 || c->max_writes_per_key > 63) {
-      set_err(err, errlen, "txn-list-append: key-count <= 16, max-txn-length <= 8, max-writes-per-key <= 63"); return MSIM_E_INVALID; }
+      set_err(err, errlen, "transactional workloads: key-count <= 16, max-txn-length <= 8, max-writes-per-key <= 63"); return MSIM_E_INVALID; }
     if (c->concurrency != c->n_nodes || c->n_nodes > 31) {
-      set_err(err, errlen, "txn-list-append: one worker per node (concurrency == node-count <= 31) in this build"); return MSIM_E_UNSUPPORTED; }
+      set_err(err, errlen, "transactional workloads: one worker per node (concurrency == node-count <= 31) in this build"); return MSIM_E_UNSUPPORTED; }
+    // txn_rw_register_hat.clj:85-90: with no other node the pending set of a txn is empty and replicate-step! sends to nil
+    if (hat && (c->n_nodes < 2 || c->n_nodes > 8)) { set_err(err, errlen, "txn-rw-register: 2..8 nodes in this build"); return MSIM_E_UNSUPPORTED; }
   }
   double expected = (double)c->rate_mhz * (double)c->time_limit_ms / 1e6;
   uint32_t ops_max = (uint32_t)(expected + expected / 8.0) + 64;
@@ -134,6 +140,7 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
     uint64_t words = no_sets ? 16 : (uint64_t)(adds + c->concurrency) * w;
     // a transaction: <= L header words at :invoke, <= L x (1 + ceil((writes-per-key + L) / 4)) at completion
     if (txn) words = (uint64_t)(ops_max + c->concurrency) * c->max_txn_length * (2 + (c->max_writes_per_key + c->max_txn_length + 3) / 4) + 64;  // worst case: all reads of full lists
+    if (hat) words = (uint64_t)(ops_max + c->concurrency) * c->max_txn_length * 2 + 64;  // one word per micro-op at :invoke and at completion
     words += (uint64_t)nem_ops * c->n_nodes * MSIM_MASK_WORDS + 16;
     if (words > 0xFFFFFFu) { set_err(err, errlen, "payload area above 2^24 words per instance"); return MSIM_E_INVALID; }
     c->max_payload_words = (uint32_t)words;
@@ -155,11 +162,27 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
     if (c->node_program == MSIM_NODE_G_SET || c->node_program == MSIM_NODE_PN_COUNTER) depth = 16 + 2 * deg;  // one replicate_full per peer per 5 s tick (g_set.rb:33-38)
     if (c->node_program == MSIM_NODE_RAFT) depth = 24 + 1024;
     if (txn) depth = 16 + 4 * c->n_nodes;
+    if (hat) depth = 16 + 4 * c->n_nodes + (uint32_t)(20.0 * c->n_nodes * lat_s);  // a replicate + n-1 acks per peer per 100 ms tick
     if (c->node_program == MSIM_NODE_LIN_KV_PROXY) depth = 16 + 2 * c->concurrency;   // the service sees every worker's request at once                           // the service sees <= 2 requests per transaction in flight       // heartbeats / re-sent append_entries pile up behind a sleeping recv!
     const uint32_t lds_part = c->n_nodes > 32 ? 4 : 24;  // wide clusters keep 100+ queues in one CU's LDS
     if (c->inbox_capacity == 0) c->inbox_capacity = depth < lds_part ? depth : lds_part;
     if (c->spill_capacity == 0) c->spill_capacity = depth > c->inbox_capacity ? depth - c->inbox_capacity : 0;
     if (c->spill_capacity > 65536) { set_err(err, errlen, "spill_capacity above 65536 envelopes per node"); return MSIM_E_INVALID; }
+  }
+  if (hat && c->replication_words == 0) {
+    // Every 100 ms a node with unacknowledged txns sends ALL of them again (txn_rw_register_hat.clj:92-118): one word per txn
+    // and message.  Healthy network: a txn is listed once per tick until its round trip completes, and with more than two
+    // nodes every receiver relays what is still pending elsewhere (:143-150) — measured ~n^2 / 2.5 words per txn.  Behind a
+    // partition the pending set grows for the whole partition (d <= 2 x interval): 10 ticks/s x (rate/n x t) txns, integrated
+    // = 5 x rate/n x d^2 per partition, and the sum of d^2 is at most d_max x time-limit.
+    const double n = c->n_nodes, tl = c->time_limit_ms / 1000.0, iv = c->nemesis_interval_ms / 1000.0;
+    const double ops = (double)c->rate_mhz / 1000.0 * tl + 64.0, r_n = (double)c->rate_mhz / 1000.0 / n;
+    const double lat_s = c->latency_mean_ms / 1000.0 * (c->latency_dist == MSIM_LAT_EXPONENTIAL ? 8.0 : 2.0);
+    double w = ops * (n * n / 2.0) * (1.0 + 2.0 * lat_s / 0.1) * (c->p_loss_q32 ? 2.0 : 1.0) * 1.5 + 1024.0;
+    // (with relays every node of a component holds everybody's txns for the nodes outside: the full rate, not rate/n)
+    if (c->nemesis_mask) w += n * 5.0 * (c->n_nodes > 2 ? r_n * n : r_n) * (2.0 * iv < tl ? 2.0 * iv : tl) * tl;
+    if (w > 16.0 * 1024 * 1024) { set_err(err, errlen, "txn-rw-register: replicate lists above 2^24 words per instance (lower rate / time-limit / latency / nemesis interval)"); return MSIM_E_INVALID; }
+    c->replication_words = ((uint32_t)w + 3u) & ~3u;
   }
   return MSIM_OK;
 }

@@ -126,7 +126,6 @@ __device__ __forceinline__ u32 scan32(u32 v) {
   v += dpp_mov<0x142, 0xA, 0xF, false>(0, v);  // row_bcast:15 -> row 1 (and 3)
   return v;
 }
-// value of `v` in lane `l` (per-lane l; every lane must execute this: ds_bpermute_b32)
 // min (deadline, id) over the n envelopes of an HBM spill area.  The scan is latency-bound — with one dependent load per
 // step every queued envelope costs an L2/HBM round trip — so 8 independent loads are in flight per step.
 __device__ __forceinline__ void spill_min(const uint4 *q, u32 n, u64 &bk, u32 &best, bool &hit) {
@@ -146,6 +145,7 @@ __device__ __forceinline__ void spill_min(const uint4 *q, u32 n, u64 &bk, u32 &b
 // be carried around the round loops as a PHI
 __device__ __forceinline__ void forget(u32 &v) { v = __builtin_nondeterministic_value(v); }
 __device__ __forceinline__ void forget(uint4 &v) { forget(v.x); forget(v.y); forget(v.z); forget(v.w); }
+// value of `v` in lane `l` (per-lane l; every lane must execute this: ds_bpermute_b32)
 __device__ __forceinline__ u32 lane_get(u32 v, u32 l) { return (u32)__builtin_amdgcn_ds_bpermute((int)(l << 2), (int)v); }
 
 // Reference (shuffle) versions, used only by the self-test to validate the DPP encodings on hardware.
@@ -837,6 +837,7 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
 #include "sim_kernel_raft.inc"
 #include "sim_kernel_wide.inc"
 #include "sim_kernel_txn.inc"
+#include "sim_kernel_hat.inc"
 #include "sim_kernel_svc.inc"
 
 // =====================================================================================================
@@ -922,6 +923,10 @@ static uint64_t proto_scratch_words(const msim_config &c) {
   if (c.node_program == MSIM_NODE_RAFT) w = (uint64_t)c.n_nodes * raft_log_cap(c) * 2 + (uint64_t)c.n_nodes * R_ARENA_WORDS;
   if (c.node_program == MSIM_NODE_BCAST_ACK_RETRY) w = (uint64_t)c.n_nodes * c.max_values * 3;
   if (c.node_program == MSIM_NODE_TXN_SINGLE_KEY) w = (uint64_t)c.max_values * (c.max_writes_per_key + 1);  // elements + counts per key
+  if (c.node_program == MSIM_NODE_TXN_RW_HAT) {  // registers per node + txn table + pending masks (bytes) + replicate lists
+    const uint64_t G = c.max_rows / 2;
+    w = (uint64_t)c.n_nodes * c.max_values + 2 * G + ((uint64_t)c.n_nodes * G + 3) / 4 + c.replication_words;
+  }
   if (c.node_program == MSIM_NODE_G_SET || c.node_program == MSIM_NODE_PN_COUNTER) {
     const uint64_t total_ms = (uint64_t)c.time_limit_ms + c.quiesce_ms + 2ull * c.client_timeout_ms;
     const uint64_t ticks = total_ms / 5000 + 3;
@@ -1003,11 +1008,13 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   const bool wide = c.n_nodes > 32;
   size_t off = (wide ? WIDE_STAGE_ROWS : STAGE_ROWS) * 16;
   const bool is_txn = c.node_program == MSIM_NODE_TXN_SINGLE_KEY, is_px = c.node_program == MSIM_NODE_LIN_KV_PROXY;
+  const bool is_hat = c.node_program == MSIM_NODE_TXN_RW_HAT;
   kp.off_inbox = (u32)off;
-  off += is_px ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.CS * R_CLIENT_CAP) * 16 : is_txn ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16
+  off += is_hat ? ((size_t)kp.N * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16 : is_px ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.CS * R_CLIENT_CAP) * 16 : is_txn ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16
                 : ((size_t)kp.N * kp.cap_node + (size_t)kp.CS * (is_raft ? R_CLIENT_CAP : CLIENT_INBOX_CAP)) * 16;
   kp.off_seen = (u32)off;
-  off += is_px ? (size_t)kp.N * PX_SLOTS * 8 + 34 * 256 + 64 * 4   // callbacks per node + service states + seq-kv indices
+  off += is_hat ? 36 * 4   // the generator's key pool
+       : is_px ? (size_t)kp.N * PX_SLOTS * 8 + 34 * 256 + 64 * 4   // callbacks per node + service states + seq-kv indices
        : is_txn ? (size_t)kp.N * TXN_SLOTS * 16 + 36 * 4   // transactions in flight per node + the generator's key pool
        : is_raft ? (size_t)kp.N * 256 + (size_t)kp.N * kp.N * 3 * 4   // KV state + next/match index + append_entries refs
                  : (size_t)kp.N * kp.W * 4;
@@ -1058,6 +1065,12 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
       else { if (rnd) hipLaunchKernelGGL((txn_kernel<false, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((txn_kernel<false, false>), dim3(n), dim3(64), lds, st, kp); }
       e = hipGetLastError();
     } break;
+    case MSIM_NODE_TXN_RW_HAT: {
+      const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
+      if (c.nemesis_mask) { if (rnd) hipLaunchKernelGGL((hat_kernel<true, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((hat_kernel<true, false>), dim3(n), dim3(64), lds, st, kp); }
+      else { if (rnd) hipLaunchKernelGGL((hat_kernel<false, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((hat_kernel<false, false>), dim3(n), dim3(64), lds, st, kp); }
+      e = hipGetLastError();
+    } break;
     default: ctx->err = "node program not built into this engine"; return MSIM_E_UNSUPPORTED;
   }
 #endif
@@ -1086,7 +1099,7 @@ extern "C" int msim_check(msim_ctx *ctx) {
   if (!ctx) return MSIM_E_INVALID;
   if (!ctx->ran) { ctx->err = "msim_check before msim_run"; return MSIM_E_RANGE; }
   if (ctx->cfg.workload == MSIM_WL_LIN_KV) return msim_check_lin_kv_host(ctx);
-  if (ctx->cfg.workload == MSIM_WL_TXN_LIST_APPEND) return msim_check_txn_host(ctx);
+  if (ctx->cfg.workload == MSIM_WL_TXN_LIST_APPEND || ctx->cfg.workload == MSIM_WL_TXN_RW_REGISTER) return msim_check_txn_host(ctx);
   if (ctx->cfg.workload == MSIM_WL_PN_COUNTER || ctx->cfg.workload == MSIM_WL_G_COUNTER) return msim_check_pn_host(ctx);
   if (ctx->cfg.workload == MSIM_WL_UNIQUE_IDS) return msim_check_unique_host(ctx);
   return msim_check_launch(ctx);

@@ -1,4 +1,4 @@
-// txn_check.cpp — host-side list-append transaction checker for the txn-list-append workload.
+// txn_check.cpp — host-side transaction checkers: list-append (txn-list-append) and rw-register (txn-rw-register).
 //
 // What the reference wires in at workload/txn_list_append.clj:142 is [upstream] jepsen.tests.cycle.append, i.e. elle's
 // list-append analysis, asked for --consistency-models strict-serializable by default (core.clj:160-165).  elle is not
@@ -41,16 +41,18 @@ struct Scratch {
   std::vector<int> writer;      // (key << 8 | element) -> txn
   std::vector<int> longest;     // key -> mop index of the longest read
   std::vector<Edge> edges; std::vector<uint32_t> adj_off; std::vector<Edge> adj;
+  std::vector<uint64_t> vsucc, vseen;  // rw-register: version graph per key
   std::vector<int> idx, low, comp; std::vector<char> on, seen; std::vector<uint32_t> st, work, pos, q;
 };
 
-void parse_txn(Scratch &S, const uint32_t *w, uint32_t n) {
+void parse_txn(Scratch &S, const uint32_t *w, uint32_t n, bool rw) {
   for (uint32_t i = 0; i < n;) {
     const uint32_t h = w[i++];
     Mop m; m.f = h & 1; m.key = (h >> 1) & 0x7FFF; m.val = 0; m.nil = 0; m.len = 0; m.off = (uint32_t)S.bytes.size();
     const uint32_t x = (h >> 16) & 0xFF;
     if (m.f) m.val = (uint8_t)x;
     else if (x == 0xFF) m.nil = 1;
+    else if (rw) m.val = (uint8_t)x;  // a register read: the value itself
     else {
       for (uint32_t e = 0; e < x && i + e / 4 < n; e++) S.bytes.push_back((uint8_t)(w[i + e / 4] >> (8 * (e % 4))));
       m.len = (uint8_t)(S.bytes.size() - m.off);
@@ -127,10 +129,12 @@ uint32_t classify(Scratch &S, uint32_t n, bool rt, uint32_t *in_cycles) {
   return bits;
 }
 
-void check_history(Scratch &S, const msim_op *rows, uint32_t n_rows, const uint32_t *payload, uint32_t n_words, uint32_t flags, msim_check_result *out) {
+// pairs invocations with completions: S.txns / S.mops (the completed form of :ok transactions) and the transitively
+// reduced realtime order; returns anomaly bits (a row whose payload lies outside the area)
+uint32_t collect(Scratch &S, const msim_op *rows, uint32_t n_rows, const uint32_t *payload, uint32_t n_words, bool rw, msim_check_result *out) {
   std::memset(out, 0, sizeof *out);
   S.txns.clear(); S.mops.clear(); S.bytes.clear(); S.rt.clear(); S.frontier.clear(); S.open.clear(); S.edges.clear();
-  uint32_t anomalies = 0, max_key = 0;
+  uint32_t anomalies = 0;
 
   for (uint32_t i = 0; i < n_rows; i++) {
     const msim_op &r = rows[i];
@@ -143,7 +147,7 @@ void check_history(Scratch &S, const msim_op *rows, uint32_t n_rows, const uint3
       out->op_count++;
       Txn t; t.process = proc; t.inv = (int)i; t.cmp = -1; t.type = MSIM_T_INFO;  // never completed = indeterminate
       t.mop0 = (uint32_t)S.mops.size();
-      parse_txn(S, payload + off, len);
+      parse_txn(S, payload + off, len, rw);
       t.n_mops = (uint32_t)S.mops.size() - t.mop0;
       t.rt0 = (uint32_t)S.rt.size(); t.n_rt = (uint32_t)S.frontier.size();   // realtime predecessors = the frontier now
       S.rt.insert(S.rt.end(), S.frontier.begin(), S.frontier.end());
@@ -158,7 +162,7 @@ void check_history(Scratch &S, const msim_op *rows, uint32_t n_rows, const uint3
       if (type == MSIM_T_OK) {
         out->ok_count++;
         t.mop0 = (uint32_t)S.mops.size();
-        parse_txn(S, payload + off, len);   // the completed form replaces the requested one (the old mops stay unused)
+        parse_txn(S, payload + off, len, rw);   // the completed form replaces the requested one (the old mops stay unused)
         t.n_mops = (uint32_t)S.mops.size() - t.mop0;
         // frontier := (frontier - predecessors of t) + t  (transitive reduction of the realtime order)
         S.nf.clear();
@@ -170,8 +174,45 @@ void check_history(Scratch &S, const msim_op *rows, uint32_t n_rows, const uint3
       else out->info_count++;
     }
   }
+  out->attempt_count = (uint32_t)S.txns.size(); out->stable_count = out->ok_count;
+  return anomalies;
+}
+
+uint32_t judge(uint32_t anomalies, uint32_t cm) {
+  const uint32_t cycles = MSIM_ANOMALY_G0 | MSIM_ANOMALY_G1C | MSIM_ANOMALY_G_SINGLE | MSIM_ANOMALY_G2;
+  if ((anomalies & MSIM_ANOMALY_REALTIME) && cm != MSIM_CM_STRICT_SERIALIZABLE) anomalies &= ~(cycles | MSIM_ANOMALY_REALTIME);  // only -realtime cycles were found
+  return anomalies & msim_proscribed_anomalies(cm);
+}
+
+// realtime edges, adjacency, cycle classification, verdict
+void finish(Scratch &S, uint32_t anomalies, uint32_t flags, uint32_t cm, msim_check_result *out) {
   const uint32_t n = (uint32_t)S.txns.size();
-  out->attempt_count = n; out->stable_count = out->ok_count;
+  auto add = [&](uint32_t a, uint32_t b2, uint8_t kind) { if (a != b2) S.edges.push_back(Edge{a, b2, kind}); };
+  for (uint32_t t = 0; t < n; t++) if (S.txns[t].type != MSIM_T_FAIL) for (uint32_t k = 0; k < S.txns[t].n_rt; k++) add(S.rt[S.txns[t].rt0 + k], t, E_RT);
+
+  // CSR adjacency
+  S.adj_off.assign(n + 1, 0);
+  for (const Edge &e : S.edges) S.adj_off[e.from + 1]++;
+  for (uint32_t v = 0; v < n; v++) S.adj_off[v + 1] += S.adj_off[v];
+  S.adj.resize(S.edges.size());
+  S.pos.assign(S.adj_off.begin(), S.adj_off.end() - 1);
+  for (const Edge &e : S.edges) S.adj[S.pos[e.from]++] = e;
+
+  uint32_t cyc = scc(S, n, E_WW | E_WR | E_RW | E_RT);  // acyclic over every edge kind (the common case): nothing to classify
+  if (cyc) {
+    uint32_t dep = classify(S, n, false, &cyc);
+    if (!dep) { const uint32_t with_rt = classify(S, n, true, &cyc); if (with_rt) dep = with_rt | MSIM_ANOMALY_REALTIME; }
+    anomalies |= dep;
+  }
+
+  out->lost_count = (uint32_t)S.edges.size(); out->stale_count = cyc; out->error_count = anomalies;
+  out->valid = flags ? 0u : judge(anomalies, cm) ? 0u : (out->ok_count == 0 ? 2u : 1u);
+}
+
+// ---- list-append -------------------------------------------------------------------------------------------------------
+void check_history(Scratch &S, const msim_op *rows, uint32_t n_rows, const uint32_t *payload, uint32_t n_words, uint32_t flags, uint32_t cm, msim_check_result *out) {
+  uint32_t anomalies = collect(S, rows, n_rows, payload, n_words, false, out), max_key = 0;
+  const uint32_t n = (uint32_t)S.txns.size();
   for (const Txn &t : S.txns) for (uint32_t k = 0; k < t.n_mops; k++) max_key = std::max<uint32_t>(max_key, S.mops[t.mop0 + k].key);
 
   // writers: (key, element) -> transaction
@@ -263,25 +304,119 @@ void check_history(Scratch &S, const msim_op *rows, uint32_t n_rows, const uint3
       if (m.len < lm.len) { const int w = S.writer[kv(m.key, ord[m.len])]; if (w >= 0 && S.txns[(size_t)w].type != MSIM_T_FAIL) add(t, (uint32_t)w, E_RW); }
     }
   }
-  for (uint32_t t = 0; t < n; t++) if (S.txns[t].type != MSIM_T_FAIL) for (uint32_t k = 0; k < S.txns[t].n_rt; k++) add(S.rt[S.txns[t].rt0 + k], t, E_RT);
+  finish(S, anomalies, flags, cm, out);
+}
 
-  // CSR adjacency
-  S.adj_off.assign(n + 1, 0);
-  for (const Edge &e : S.edges) S.adj_off[e.from + 1]++;
-  for (uint32_t v = 0; v < n; v++) S.adj_off[v + 1] += S.adj_off[v];
-  S.adj.resize(S.edges.size());
-  S.pos.assign(S.adj_off.begin(), S.adj_off.end() - 1);
-  for (const Edge &e : S.edges) S.adj[S.pos[e.from]++] = e;
+// ---- rw-register -------------------------------------------------------------------------------------------------------
+// [upstream] elle.rw-register as jepsen.tests.cycle.wr wires it for workload/txn_rw_register.clj:162-166 (:wfr-keys? true):
+//   * writes are unique per key, so a read of v names its writer: wr writer(v) -> reader;
+//   * version order of a key, from two sources only: the initial nil precedes every other version, and a transaction
+//     that reads v1 of a key and then writes v2 puts v1 before v2 (writes follow reads); a key whose version graph has a
+//     cycle is reported (cyclic-versions) and contributes no dependencies;
+//   * for every v1 -> v2 of that graph: ww writer(v1) -> writer(v2), rw each reader of v1 -> writer(v2);
+//   * only a transaction's external reads (before its own first write of the key) and final writes count; internal
+//     reads must agree with the transaction's own earlier micro-ops (internal); G1a / G1b as for list-append.
+void check_rw(Scratch &S, const msim_op *rows, uint32_t n_rows, const uint32_t *payload, uint32_t n_words, uint32_t flags, uint32_t cm, msim_check_result *out) {
+  uint32_t anomalies = collect(S, rows, n_rows, payload, n_words, true, out), max_key = 0;
+  const uint32_t n = (uint32_t)S.txns.size();
+  for (const Txn &t : S.txns) for (uint32_t k = 0; k < t.n_mops; k++) max_key = std::max<uint32_t>(max_key, S.mops[t.mop0 + k].key);
+  auto kv = [](uint32_t k, uint32_t v) { return (k << 8) | v; };
+  S.writer.assign((size_t)(max_key + 1) << 8, -1);
+  for (uint32_t t = 0; t < n; t++)
+    for (uint32_t k = 0; k < S.txns[t].n_mops; k++) {
+      const Mop &m = S.mops[S.txns[t].mop0 + k];
+      if (!m.f) continue;
+      if (S.writer[kv(m.key, m.val)] >= 0) anomalies |= MSIM_ANOMALY_DUPLICATE_ELEMENTS;  // the generator never repeats (k, v)
+      S.writer[kv(m.key, m.val)] = (int)t;
+    }
+  auto final_of = [&](uint32_t t, uint32_t key) -> int {
+    const Txn &x = S.txns[t]; int v = -1;
+    for (uint32_t k = 0; k < x.n_mops; k++) { const Mop &m = S.mops[x.mop0 + k]; if (m.f && m.key == key) v = m.val; }
+    return v;
+  };
+  // external read of `key` by :ok transaction t: -1 none, 0 nil, else the value (values are >= 1)
+  auto ext_read = [&](uint32_t t, uint32_t key) -> int {
+    const Txn &x = S.txns[t];
+    for (uint32_t k = 0; k < x.n_mops; k++) { const Mop &m = S.mops[x.mop0 + k]; if (m.key == key) return m.f ? -1 : m.nil ? 0 : (int)m.val; }
+    return -1;
+  };
+  auto add = [&](uint32_t a, uint32_t b2, uint8_t kind) { if (a != b2) S.edges.push_back(Edge{a, b2, kind}); };
 
-  uint32_t cyc = scc(S, n, E_WW | E_WR | E_RW | E_RT);  // acyclic over every edge kind (the common case): nothing to classify
-  if (cyc) {
-    uint32_t dep = classify(S, n, false, &cyc);
-    if (!dep) { const uint32_t with_rt = classify(S, n, true, &cyc); if (with_rt) dep = with_rt | MSIM_ANOMALY_REALTIME; }
-    anomalies |= dep;
+  // succ[key][v1] = bit set of versions v2 with v1 -> v2 (version 0 = nil, values 1..63)
+  S.vsucc.assign((size_t)(max_key + 1) * 64, 0);
+  S.vseen.assign(max_key + 1, 0);
+  for (uint32_t t = 0; t < n; t++) {
+    const Txn &x = S.txns[t];
+    for (uint32_t k = 0; k < x.n_mops; k++) { const Mop &m = S.mops[x.mop0 + k]; if (m.f && x.type != MSIM_T_FAIL) S.vseen[m.key] |= 1ull << (m.val & 63); }
+    if (x.type != MSIM_T_OK) continue;
+    for (uint32_t k = 0; k < x.n_mops; k++) {
+      const Mop &m = S.mops[x.mop0 + k];
+      if (m.f) continue;
+      // internal consistency: the latest earlier micro-op on this key decides what the read must return
+      int prev = -1;
+      for (uint32_t e = 0; e < k; e++) if (S.mops[x.mop0 + e].key == m.key) prev = (int)e;
+      if (prev >= 0) {
+        const Mop &p = S.mops[x.mop0 + (uint32_t)prev];
+        const bool same = p.f ? (!m.nil && m.val == p.val) : (m.nil == p.nil && (m.nil || m.val == p.val));
+        if (!same) anomalies |= MSIM_ANOMALY_INTERNAL;
+        continue;
+      }
+      if (m.nil) continue;
+      S.vseen[m.key] |= 1ull << (m.val & 63);
+      const int w = S.writer[kv(m.key, m.val)];
+      if (w < 0 || S.txns[(size_t)w].type == MSIM_T_FAIL) { anomalies |= MSIM_ANOMALY_G1A; continue; }  // garbage / aborted read
+      if ((uint32_t)w != t) {
+        if (final_of((uint32_t)w, m.key) != (int)m.val) anomalies |= MSIM_ANOMALY_G1B;
+        add((uint32_t)w, t, E_WR);
+      }
+      // writes follow reads
+      const int fw = final_of(t, m.key);
+      if (fw >= 0 && fw != (int)m.val) S.vsucc[(size_t)m.key * 64 + m.val] |= 1ull << (fw & 63);
+    }
   }
-
-  out->lost_count = (uint32_t)S.edges.size(); out->stale_count = cyc; out->error_count = anomalies;
-  out->valid = flags ? 0u : anomalies ? 0u : (out->ok_count == 0 ? 2u : 1u);
+  for (uint32_t key = 0; key <= max_key; key++) {
+    uint64_t *succ = S.vsucc.data() + (size_t)key * 64;
+    succ[0] |= S.vseen[key] & ~1ull;  // nil precedes every version
+    // cyclic version order?  reach[v] = transitive closure over <= 64 versions
+    uint64_t reach[64];
+    for (uint32_t v = 0; v < 64; v++) reach[v] = succ[v];
+    for (bool grown = true; grown;) {
+      grown = false;
+      for (uint32_t v = 0; v < 64; v++) {
+        uint64_t r = reach[v], add_ = 0;
+        for (uint64_t b = r; b; b &= b - 1) add_ |= reach[__builtin_ctzll(b)];
+        if (add_ & ~r) { reach[v] = r | add_; grown = true; }
+      }
+    }
+    bool cyclic = false;
+    for (uint32_t v = 0; v < 64; v++) if ((reach[v] >> v) & 1) cyclic = true;
+    if (cyclic) { anomalies |= MSIM_ANOMALY_CYCLIC_VERSIONS; for (uint32_t v = 0; v < 64; v++) succ[v] = 0; continue; }
+    for (uint32_t v1 = 1; v1 < 64; v1++) {
+      const int a = S.writer[kv(key, v1)];
+      if (a < 0 || S.txns[(size_t)a].type == MSIM_T_FAIL) continue;
+      for (uint64_t b = succ[v1]; b; b &= b - 1) {
+        const int b2 = S.writer[kv(key, (uint32_t)__builtin_ctzll(b))];
+        if (b2 >= 0 && S.txns[(size_t)b2].type != MSIM_T_FAIL) add((uint32_t)a, (uint32_t)b2, E_WW);
+      }
+    }
+  }
+  for (uint32_t t = 0; t < n; t++) {
+    const Txn &x = S.txns[t];
+    if (x.type != MSIM_T_OK) continue;
+    for (uint32_t k = 0; k < x.n_mops; k++) {
+      const Mop &m = S.mops[x.mop0 + k];
+      if (m.f || ext_read(t, m.key) < 0) continue;
+      bool first = true;
+      for (uint32_t e = 0; e < k; e++) if (S.mops[x.mop0 + e].key == m.key) first = false;
+      if (!first) continue;
+      const uint32_t v1 = m.nil ? 0u : m.val;
+      for (uint64_t b = S.vsucc[(size_t)m.key * 64 + v1]; b; b &= b - 1) {
+        const int w = S.writer[kv(m.key, (uint32_t)__builtin_ctzll(b))];
+        if (w >= 0 && S.txns[(size_t)w].type != MSIM_T_FAIL) add(t, (uint32_t)w, E_RW);
+      }
+    }
+  }
+  finish(S, anomalies, flags, cm, out);
 }
 
 }  // namespace
@@ -289,7 +424,24 @@ void check_history(Scratch &S, const msim_op *rows, uint32_t n_rows, const uint3
 extern "C" int msim_check_txn_rows(const msim_op *rows, uint32_t n_rows, const uint32_t *payload, uint32_t n_words, msim_check_result *out) {
   if (!rows || !out || (!payload && n_words)) return MSIM_E_INVALID;
   Scratch S;
-  check_history(S, rows, n_rows, payload, n_words, 0, out);
+  check_history(S, rows, n_rows, payload, n_words, 0, MSIM_CM_STRICT_SERIALIZABLE, out);
+  return MSIM_OK;
+}
+
+extern "C" uint32_t msim_proscribed_anomalies(uint32_t cm) {
+  uint32_t p = MSIM_ANOMALY_DUPLICATE_ELEMENTS | MSIM_ANOMALY_INCOMPATIBLE_ORDER | MSIM_ANOMALY_DIRTY_UPDATE | MSIM_ANOMALY_CYCLIC_VERSIONS | MSIM_ANOMALY_G0;
+  if (cm <= MSIM_CM_READ_COMMITTED) p |= MSIM_ANOMALY_G1A | MSIM_ANOMALY_G1B | MSIM_ANOMALY_G1C;
+  if (cm <= MSIM_CM_SNAPSHOT_ISOLATION) p |= MSIM_ANOMALY_G_SINGLE | MSIM_ANOMALY_INTERNAL;
+  if (cm <= MSIM_CM_SERIALIZABLE) p |= MSIM_ANOMALY_G2;
+  if (cm == MSIM_CM_STRICT_SERIALIZABLE) p |= MSIM_ANOMALY_REALTIME;
+  return p;
+}
+
+extern "C" int msim_check_rw_rows(const msim_op *rows, uint32_t n_rows, const uint32_t *payload, uint32_t n_words, uint32_t consistency_model,
+                                  msim_check_result *out) {
+  if (!rows || !out || (!payload && n_words) || consistency_model > MSIM_CM_READ_UNCOMMITTED) return MSIM_E_INVALID;
+  Scratch S;
+  check_rw(S, rows, n_rows, payload, n_words, 0, consistency_model, out);
   return MSIM_OK;
 }
 
@@ -306,9 +458,10 @@ int msim_check_txn_host(msim_ctx *ctx) {
   for (unsigned t = 0; t < nt; t++)
     th.emplace_back([ctx, n, nt, t]() {
       Scratch S;
+      const bool rw = ctx->cfg.workload == MSIM_WL_TXN_RW_REGISTER;
       for (uint32_t i = t; i < n; i += nt)
-        check_history(S, ctx->h_rows + ctx->h_row_off[i], ctx->h_meta[i].n_rows, ctx->h_payload + ctx->h_pay_off[i],
-                      ctx->h_meta[i].n_payload_words, ctx->h_meta[i].flags, &ctx->h_check[i]);
+        (rw ? check_rw : check_history)(S, ctx->h_rows + ctx->h_row_off[i], ctx->h_meta[i].n_rows, ctx->h_payload + ctx->h_pay_off[i],
+                                        ctx->h_meta[i].n_payload_words, ctx->h_meta[i].flags, ctx->cfg.consistency_model, &ctx->h_check[i]);
     });
   for (auto &x : th) x.join();
   MSIM_HIP_TRY(ctx, hipMemcpy(ctx->d_check, ctx->h_check, (size_t)n * sizeof(msim_check_result), hipMemcpyHostToDevice));

@@ -22,12 +22,17 @@ CHECK_DT = np.dtype([("valid", "<u4"), ("attempt_count", "<u4"), ("stable_count"
                      ("ok_count", "<u4"), ("fail_count", "<u4"), ("info_count", "<u4")])
 
 WORKLOADS = {"echo": A.WL_ECHO, "broadcast": A.WL_BROADCAST, "g-set": A.WL_G_SET, "lin-kv": A.WL_LIN_KV,
-             "txn-list-append": A.WL_TXN_LIST_APPEND, "pn-counter": A.WL_PN_COUNTER, "g-counter": A.WL_G_COUNTER, "unique-ids": A.WL_UNIQUE_IDS}
+             "txn-list-append": A.WL_TXN_LIST_APPEND, "pn-counter": A.WL_PN_COUNTER, "g-counter": A.WL_G_COUNTER, "unique-ids": A.WL_UNIQUE_IDS,
+             "txn-rw-register": A.WL_TXN_RW_REGISTER}
 NODE_PROGRAMS = {"echo": A.NODE_ECHO, "broadcast-ff": A.NODE_BCAST_FF, "broadcast-ff-echoback": A.NODE_BCAST_FF_ECHOBACK,
                  "broadcast-ack-retry": A.NODE_BCAST_ACK_RETRY, "broadcast-rpc-all": A.NODE_BCAST_RPC_ALL,
                  "g-set": A.NODE_G_SET, "raft": A.NODE_RAFT, "single-key-txn": A.NODE_TXN_SINGLE_KEY,
-                 "pn-counter": A.NODE_PN_COUNTER, "flake-ids": A.NODE_FLAKE_IDS, "lin-kv-proxy": A.NODE_LIN_KV_PROXY}
+                 "pn-counter": A.NODE_PN_COUNTER, "flake-ids": A.NODE_FLAKE_IDS, "lin-kv-proxy": A.NODE_LIN_KV_PROXY,
+                 "txn-rw-register-hat": A.NODE_TXN_RW_HAT}
 SERVICES = {"lin-kv": A.SVC_LIN_KV, "seq-kv": A.SVC_SEQ_KV, "lww-kv": A.SVC_LWW_KV}
+CONSISTENCY_MODELS = {"strict-serializable": A.CM_STRICT_SERIALIZABLE, "serializable": A.CM_SERIALIZABLE,
+                      "snapshot-isolation": A.CM_SNAPSHOT_ISOLATION, "read-committed": A.CM_READ_COMMITTED,
+                      "read-uncommitted": A.CM_READ_UNCOMMITTED}
 TOPOLOGIES = {"grid": A.TOPO_GRID, "line": A.TOPO_LINE, "total": A.TOPO_TOTAL, "tree": A.TOPO_TREE2,
               "tree2": A.TOPO_TREE2, "tree3": A.TOPO_TREE3, "tree4": A.TOPO_TREE4}
 LATENCY_DISTS = {"constant": A.LAT_CONSTANT, "uniform": A.LAT_UNIFORM, "exponential": A.LAT_EXPONENTIAL}
@@ -72,6 +77,8 @@ def test_config(workload="broadcast", bin=None, node_count=5, concurrency=None, 
     for k, v in capacities.items():
         if k == "proxy_service" and isinstance(v, str):
             v = SERVICES[v]
+        if k == "consistency_model" and isinstance(v, str):
+            v = CONSISTENCY_MODELS[v]
         if not hasattr(cfg, k):
             raise EngineError(f"unknown option {k}")
         setattr(cfg, k, int(v))
@@ -248,6 +255,16 @@ def _nil(x):
     return None if x == 0xFF else x
 
 
+def decode_rw_txn(words):
+    """Payload words of one rw-register transaction -> [[f k v] ...] (txn_rw_register.clj:82-84): one word per micro-op."""
+    return [[":w" if w & 1 else ":r", (w >> 1) & 0x7FFF, None if (w >> 16) & 0xFF == 0xFF else (w >> 16) & 0xFF] for w in (int(x) for x in words)]
+
+
+def encode_rw_txn(txn):
+    """[[f k v] ...] -> payload words (inverse of decode_rw_txn)."""
+    return [(1 if f == ":w" else 0) | (k << 1) | ((0xFF if v is None else v) << 16) for f, k, v in txn]
+
+
 def decode_txn(words):
     """Payload words of one transaction -> [[f k v] ...] (txn_list_append.clj:27-39; encoding: include/maelsim.h msim_op)."""
     out, i, words = [], 0, [int(w) for w in words]
@@ -280,14 +297,14 @@ def encode_txn(txn):
     return words
 
 
-def encode_txn_history(ops):
+def encode_txn_history(ops, rw=False):
     """Jepsen-shaped txn ops ({type, process, value[, time]}) -> (rows, payload) in the engine's binary layout, so that
-    externally produced list-append histories can be fed to msim_check_txn_rows."""
+    externally produced list-append (rw=True: rw-register) histories can be fed to msim_check_txn_rows / msim_check_rw_rows."""
     tkw = {v: k for k, v in TYPE_KW.items()}
     rows = np.zeros(len(ops), dtype=OP_DT)
     payload = []
     for i, op in enumerate(ops):
-        w = encode_txn(op["value"])
+        w = encode_rw_txn(op["value"]) if rw else encode_txn(op["value"])
         rows["time_len"][i] = int(op.get("time", i * 1000)) | (len(w) << 48)
         rows["packed"][i] = tkw[op["type"]] | (A.F_TXN << 2) | (int(op["process"]) << 12)
         rows["value"][i] = len(payload)
@@ -303,6 +320,20 @@ def check_txn_history(rows, payload):
     rc = lib.msim_check_txn_rows(rows.ctypes.data_as(C.c_void_p), len(rows), payload.ctypes.data_as(C.c_void_p), len(payload), C.byref(res))
     if rc:
         raise EngineError(f"msim_check_txn_rows: {rc}")
+    return {"valid?": {1: True, 0: False, 2: "unknown"}[res.valid], "anomalies": sorted(n for b, n in A.ANOMALIES.items() if res.error_count & b),
+            "txn-count": res.attempt_count, "ok-count": res.ok_count, "fail-count": res.fail_count, "info-count": res.info_count,
+            "edge-count": res.lost_count, "cycle-txns": res.stale_count}
+
+
+def check_rw_history(rows, payload, consistency_model="strict-serializable"):
+    """The host rw-register checker (msim_check_rw_rows) on one history -> dict like check_txn_history."""
+    lib = A.load()
+    res = A.CheckResult()
+    rows = np.ascontiguousarray(rows); payload = np.ascontiguousarray(payload, dtype=np.uint32)
+    rc = lib.msim_check_rw_rows(rows.ctypes.data_as(C.c_void_p), len(rows), payload.ctypes.data_as(C.c_void_p), len(payload),
+                                CONSISTENCY_MODELS[consistency_model], C.byref(res))
+    if rc:
+        raise EngineError(f"msim_check_rw_rows: {rc}")
     return {"valid?": {1: True, 0: False, 2: "unknown"}[res.valid], "anomalies": sorted(n for b, n in A.ANOMALIES.items() if res.error_count & b),
             "txn-count": res.attempt_count, "ok-count": res.ok_count, "fail-count": res.fail_count, "info-count": res.info_count,
             "edge-count": res.lost_count, "cycle-txns": res.stale_count}
@@ -352,7 +383,7 @@ def decode_history(rows, payload, n_nodes, workload=A.WL_BROADCAST):
         elif f == A.F_GENERATE:   # flake id [time count node-id], flake_ids.clj:30-31
             op["value"] = [value >> 20, (value >> 5) & 0x7FFF, f"n{value & 31}"] if typ == A.T_OK else None
         elif f == A.F_TXN:
-            op["value"] = decode_txn(payload[value:value + ln])
+            op["value"] = (decode_rw_txn if workload == A.WL_TXN_RW_REGISTER else decode_txn)(payload[value:value + ln])
         elif workload in (A.WL_PN_COUNTER, A.WL_G_COUNTER) and f in (A.F_ADD, A.F_READ):  # pn_counter.clj:22-58: signed delta / counter value
             signed = value - (1 << 32) if value & 0x80000000 else value
             op["value"] = signed if (f == A.F_ADD or typ == A.T_OK) else None

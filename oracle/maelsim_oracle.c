@@ -58,7 +58,7 @@ enum { M_INIT = 1, M_INIT_OK, M_TOPOLOGY, M_TOPOLOGY_OK, M_ECHO, M_ECHO_OK, M_BR
        M_READ, M_READ_OK, M_ADD, M_ADD_OK, M_REPLICATE,
        M_WRITE, M_WRITE_OK, M_CAS, M_CAS_OK, M_ERROR,                                   /* lin-kv RPCs, doc/workloads.md */
        M_REQUEST_VOTE, M_REQUEST_VOTE_RES, M_APPEND_ENTRIES, M_APPEND_ENTRIES_RES,      /* raft.py:290-297,412-420 */
-       M_TXN, M_TXN_OK, M_GENERATE, M_GENERATE_OK };                                                                /* txn_list_append.clj:73-80 */
+       M_TXN, M_TXN_OK, M_GENERATE, M_GENERATE_OK, M_REPLICATE_ACK };                                                                /* txn_list_append.clj:73-80 */
 
 /* RNG streams */
 enum { S_GEN = 1, S_GEN2 = 2, S_GEN3 = 3, S_LATENCY = 4, S_LOSS = 5, S_NODE = 11, S_SVC = 12,
@@ -82,6 +82,7 @@ typedef struct {
   u32 S;              /* services (endpoints after the client slots): 1 = lin-kv for the txn workload */
   struct txn_s *txn;  /* txn-list-append state (txn_nodes.inc) */
   struct svc_s *svc;  /* proxy node + key-value services (svc_nodes.inc) */
+  struct hat_s *hat;  /* txn-rw-register highly-available-transactions node (hat_nodes.inc) */
   u64 key;
   u32 adj[MAXN][MW];
   /* net (net.clj:79-103) */
@@ -162,7 +163,9 @@ static void clrbit(u32 *m, u32 i) { m[i >> 5] &= ~(1u << (i & 31)); }
 static int is_client(const sim_t *s, u32 ep) { return ep >= s->N && ep < s->N + s->CS; }
 
 /* lin_kv.clj:74-76, txn_list_append.clj:124-126: Reusable clients are not re-opened after a crash */
-static int reusable_clients(const sim_t *s) { return s->cfg.workload == MSIM_WL_LIN_KV || s->cfg.workload == MSIM_WL_TXN_LIST_APPEND || s->cfg.workload == MSIM_WL_UNIQUE_IDS; }
+static int txn_workload(const sim_t *s) { return s->cfg.workload == MSIM_WL_TXN_LIST_APPEND || s->cfg.workload == MSIM_WL_TXN_RW_REGISTER; }
+/* lin_kv.clj:74-76, txn_list_append.clj:124-126, txn_rw_register.clj:137-139 */
+static int reusable_clients(const sim_t *s) { return s->cfg.workload == MSIM_WL_LIN_KV || txn_workload(s) || s->cfg.workload == MSIM_WL_UNIQUE_IDS; }
 
 static void inbox_push(sim_t *s, u32 ep, qent q) {
   inbox_t *b = &s->inbox[ep];
@@ -342,7 +345,9 @@ static void snap_put(sim_t *s, u32 tick, u32 node, const u32 *words) {
   if (idx + 1 > s->n_snap) s->n_snap = idx + 1;
 }
 
+static void hat_tick(sim_t *s, u32 node);
 static void node_timer(sim_t *s, u32 node) {
+  if (s->hat) { hat_tick(s, node); return; }
   if (s->timer_next[node] <= s->T) { /* g_set.rb:33-38: every 5 s, replicate_full to all other nodes */
     s->timer_next[node] = s->T + 5000000u;
     u32 tick = s->tick[node]++;           /* the message carries (sender, tick): a reference to the sender's set then */
@@ -362,11 +367,13 @@ static void node_timer(sim_t *s, u32 node) {
 #include "raft_nodes.inc"
 #include "txn_nodes.inc"
 #include "svc_nodes.inc"
+#include "hat_nodes.inc"
 
 static void node_handle(sim_t *s, u32 node, const qent *q) {
   if (s->cfg.node_program == MSIM_NODE_RAFT) { raft_handle(s, node, q); return; }
   if (s->cfg.node_program == MSIM_NODE_TXN_SINGLE_KEY) { txn_node_handle(s, node, q); return; }
   if (s->cfg.node_program == MSIM_NODE_LIN_KV_PROXY) { px_node_handle(s, node, q); return; }
+  if (s->cfg.node_program == MSIM_NODE_TXN_RW_HAT) { hat_node_handle(s, node, q); return; }
   switch (q->type) {
     case M_INIT: /* node.rb init handler -> init_ok; g-set starts its periodic task (node.rb:129-138) */
       if (s->cfg.node_program == MSIM_NODE_G_SET || s->cfg.node_program == MSIM_NODE_PN_COUNTER) s->timer_next[node] = s->T;
@@ -435,7 +442,7 @@ static void client_deliver(sim_t *s, u32 slot, const qent *q) {
     case M_TXN_OK: client_complete(s, slot, MSIM_T_OK, 0, q->a & 0xFFFFFFu, q->a >> 24); break; /* txn_list_append.clj:109-117 */
     case M_ERROR: { /* client.clj:125-138 throw-errors!; every code the raft node emits is :definite? => :fail (errors.edn) */
       u32 err = q->a == 11 ? MSIM_ERR_TEMPORARILY_UNAVAILABLE : q->a == 20 ? MSIM_ERR_KEY_DOES_NOT_EXIST : q->a == 30 ? MSIM_ERR_TXN_CONFLICT : MSIM_ERR_PRECONDITION_FAILED;
-      if (s->cfg.workload == MSIM_WL_TXN_LIST_APPEND) client_complete(s, slot, MSIM_T_FAIL, err, c->value & 0xFFFFFFu, c->value >> 24); /* :value stays the requested txn */
+      if (txn_workload(s)) client_complete(s, slot, MSIM_T_FAIL, err, c->value & 0xFFFFFFu, c->value >> 24); /* :value stays the requested txn */
       else client_complete(s, slot, MSIM_T_FAIL, err, c->value, 0); } break;
     default: client_complete(s, slot, MSIM_T_OK, 0, c->value, 0); break;
   }
@@ -581,7 +588,7 @@ static void sched_act(sim_t *s) {
             else if (scale32((u32)h2, 3) == 0) { c->m_f = MSIM_F_WRITE; c->m_value = key | (v1 << 8) | 0xFF0000u; }
             else { c->m_f = MSIM_F_CAS; c->m_value = key | (v1 << 8) | (v2 << 16); }
           }
-          else if (s->cfg.workload == MSIM_WL_TXN_LIST_APPEND) {
+          else if (txn_workload(s)) {
             u32 ref = txn_generate(s, k);
             if (ref == INF) { c->mark = 0; s->phase = PH_DONE; return; }
             c->m_f = MSIM_F_TXN; c->m_value = ref;
@@ -778,8 +785,8 @@ static sim_t *sim_new(const msim_config *cfg, uint64_t instance, msim_op *rows, 
     v->client_idx = (u32 *)calloc(s->E, 4);
     memset(v->kv, 0xFF, 256); memset(v->ring, 0xFF, sizeof v->ring); memset(v->rep, 0xFF, sizeof v->rep);
     s->svc = v;
-  } else if (s->S) {
-    txn_t *t = (txn_t *)calloc(1, sizeof(txn_t));
+  } else if (s->S || cfg->node_program == MSIM_NODE_TXN_RW_HAT) {
+    txn_t *t = (txn_t *)calloc(1, sizeof(txn_t)); /* the rw-register workload only uses the generator state */
     t->slots = (tslot *)calloc((size_t)s->N * TXN_SLOTS, sizeof(tslot));
     t->root = V_NIL;
     t->kv = (u32 *)calloc((size_t)cfg->max_values * cfg->max_writes_per_key, 4);
@@ -788,6 +795,7 @@ static sim_t *sim_new(const msim_config *cfg, uint64_t instance, msim_op *rows, 
     t->next_key = cfg->key_count;
     s->txn = t;
   }
+  if (cfg->node_program == MSIM_NODE_TXN_RW_HAT) s->hat = hat_new(s);
   for (u32 i = 0; i < s->CS; i++) s->cl[i].process = i;
   s->rows = rows; s->payload = payload;
   s->phase = PH_INIT;
@@ -805,6 +813,7 @@ static void sim_free(sim_t *s) {
   for (u32 i = 0; i < s->n_snap; i++) free(s->snap[i]);
   if (s->raft) { for (u32 i = 0; i < s->N; i++) free(s->raft[i].log); free(s->raft); }
   if (s->svc) { free(s->svc->cb); free(s->svc->client_idx); free(s->svc); }
+  if (s->hat) hat_free(s->hat);
   if (s->txn) { free(s->txn->slots); free(s->txn->kv); free(s->txn->kv_n); free(s->txn); }
   free(s->snap); free(s->inbox); free(s->committed); free(s->has_committed); free(s->deliver_at); free(s->seen);
   free(s->unacked); free(s->node_msg_id); free(s->nbr_known); free(s->tasks); free(s->key_reg); free(s->timer_next); free(s->tick); free(s->flake);
@@ -873,7 +882,7 @@ int oracle_node_trace(const msim_config *cfg, uint32_t node, const uint32_t *in,
 uint32_t oracle_msg_type(const char *name) {
   static const char *names[] = {"", "init", "init_ok", "topology", "topology_ok", "echo", "echo_ok", "broadcast", "broadcast_ok",
                                 "read", "read_ok", "add", "add_ok", "replicate", "write", "write_ok", "cas", "cas_ok", "error",
-                                "request_vote", "request_vote_res", "append_entries", "append_entries_res", "txn", "txn_ok", "generate", "generate_ok"};
+                                "request_vote", "request_vote_res", "append_entries", "append_entries_res", "txn", "txn_ok", "generate", "generate_ok", "replicate_ack"};
   for (u32 i = 1; i < sizeof(names) / sizeof(names[0]); i++) if (!strcmp(names[i], name)) return i;
   return 0;
 }
@@ -978,5 +987,21 @@ int oracle_topology(uint32_t topology, uint32_t n, uint32_t *adj_out) {
   s->N = n; s->cfg.topology = topology; build_topology(s);
   memcpy(adj_out, s->adj, (size_t)n * MW * 4);
   free(s);
+  return 0;
+}
+
+/* Test hook for the txn-rw-register node: runs instance `instance` like oracle_run_instance and also returns the nodes'
+ * final registers (kv: n_nodes x max_values words, lamport << 11 | node << 8 | value), Lamport clocks and the number of
+ * txns each node still holds as unreplicated. */
+int oracle_hat_state(const msim_config *cfg, uint64_t instance, msim_op *rows, uint32_t *payload, msim_net_stats *stats,
+                     msim_inst_meta *meta, uint32_t *kv, uint32_t *lamport, uint32_t *npend) {
+  sim_t *s = sim_new(cfg, instance, rows, payload);
+  if (!s || !s->hat) return -1;
+  run_instance(s);
+  *stats = s->st; *meta = s->meta;
+  memcpy(kv, s->hat->kv, (size_t)s->N * cfg->max_values * 4);
+  memcpy(lamport, s->hat->lamport, s->N * 4);
+  memcpy(npend, s->hat->npend, s->N * 4);
+  sim_free(s);
   return 0;
 }

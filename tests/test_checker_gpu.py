@@ -109,6 +109,27 @@ def test_txn_list_append_checker_on_engine_histories(lib):
         assert one["valid?"] is True and one["txn-count"] == int(res["attempt_count"][3])
 
 
+def test_txn_rw_register_checker_on_engine_histories(lib):
+    """msim_check for txn-rw-register judges by the configured consistency model (core.clj:118,160-165): the HAT node's
+    histories are read-committed, and not serializable."""
+    kw = dict(node_count=2, rate=100, time_limit=15, nemesis=["partition"], nemesis_interval=5, seed=10)
+    cfg = E.test_config("txn-rw-register", **kw)
+    with E.Engine(cfg) as eng:
+        eng.run(0, 16)
+        eng.check()
+        eng.fetch()
+        res = eng.check_results()
+        assert (res["valid"] == 1).all() and (res["info_count"] == 0).all() and (res["ok_count"] > 1000).all()
+        assert ((res["error_count"] & ~np.uint32(16 | 32 | 512)) == 0).all()   # nothing but G-single / G2 (/ -realtime)
+        rows, pay = eng.raw_history(3)
+        one = E.check_rw_history(rows, pay, "read-committed")
+        assert one["valid?"] is True and one["txn-count"] == int(res["attempt_count"][3])
+    with E.Engine(E.test_config("txn-rw-register", consistency_model="serializable", **kw)) as eng:
+        eng.run(0, 16)
+        eng.check()
+        assert (eng.check_results()["valid"] == 0).sum() >= 12
+
+
 def test_pn_counter_checker_on_engine_histories(lib):
     cfg = E.test_config("pn-counter", node_count=5, rate=50, time_limit=10, latency=20, latency_dist="exponential", p_loss=0.05, seed=12)
     with E.Engine(cfg) as eng:

@@ -58,6 +58,8 @@ def test_random_options_engine_equals_oracle(lib, case):
 
 def _random_kv_case(rng):
     kind = rng.choice(["raft", "raft", "proxy", "proxy", "txn", "txn"])
+    if os.environ.get("MSIM_FUZZ_KIND"):   # focus a sweep on one program
+        kind = os.environ["MSIM_FUZZ_KIND"]
     n = rng.choice([1, 3, 5, 7])
     kw = dict(node_count=n, rate=rng.choice([10, 30, 100, 300]), time_limit=rng.choice([4, 8, 12]), seed=rng.randrange(1 << 40))
     lat = rng.choice([0, 1, 5, 20])
@@ -73,7 +75,29 @@ def _random_kv_case(rng):
     if kind == "proxy":
         return "lin-kv", dict(kw, bin="lin-kv-proxy", proxy_service=rng.choice(["lin-kv", "seq-kv", "lww-kv"]))
     kw.update(key_count=rng.choice([1, 3, 10]), max_txn_length=rng.choice([1, 4, 8]), max_writes_per_key=rng.choice([2, 16, 40]))
+    if kind == "hat":
+        kw["node_count"] = rng.choice([2, 2, 3, 5, 8])
+        if rng.random() < 0.5:
+            kw.update(nemesis=["partition"], nemesis_interval=rng.choice([1, 3]))
+        return "txn-rw-register", kw
     return "txn-list-append", kw
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("MSIM_FUZZ_CASES", "24"))))
+def test_random_rw_register_options_engine_equals_oracle(lib, case):
+    """The same sweep for txn-rw-register over the highly-available-transactions node."""
+    rng = random.Random(0xFEED + case)
+    os.environ["MSIM_FUZZ_KIND"] = "hat"
+    try:
+        wl, kw = _random_kv_case(rng)
+    finally:
+        del os.environ["MSIM_FUZZ_KIND"]
+    try:
+        cfg = E.test_config(wl, **kw)
+        E.Engine(cfg).close()
+    except E.EngineError as e:
+        pytest.skip(str(e))
+    _compare(cfg, rng.randrange(1 << 20), 3)
 
 
 @pytest.mark.parametrize("case", range(int(os.environ.get("MSIM_FUZZ_CASES", "36"))))

@@ -189,6 +189,26 @@ def test_txn_list_append_journal_parity(lib):
 
 @pytest.mark.parametrize("kw", [
     dict(),
+    dict(latency=5),
+    dict(nemesis=["partition"], nemesis_interval=2),                                   # the reference's demo shape (core.clj:115-121)
+    dict(latency=20, latency_dist="exponential", p_loss=0.05),
+    dict(node_count=3, latency=10, latency_dist="uniform", nemesis=["partition"], nemesis_interval=2),
+    dict(node_count=5, rate=200, latency=5, nemesis=["partition"], nemesis_interval=3),  # third parties relay (hat :143-150)
+    dict(node_count=8, rate=50, latency=30),
+    dict(journal_capacity=60000, latency=5, nemesis=["partition"], nemesis_interval=2),
+    dict(key_count=3, max_txn_length=8, max_writes_per_key=40, rate=300),
+])
+def test_txn_rw_register_parity(lib, kw):
+    """workload/txn_rw_register.clj over demo/clojure/txn_rw_register_hat.clj (hat_kernel<>)."""
+    base = dict(node_count=2, rate=100, time_limit=8, seed=101)
+    base.update(kw)
+    cfg = E.test_config("txn-rw-register", **base)
+    ora = _compare(cfg, 0, 6)
+    assert (ora.stats["servers_send"] > 0).all()   # replicate / replicate_ack traffic did flow
+
+
+@pytest.mark.parametrize("kw", [
+    dict(),
     dict(latency=20),
     dict(latency=50, latency_dist="exponential", p_loss=0.1),
     dict(latency=10, nemesis=["partition"], nemesis_interval=4, time_limit=20),
