@@ -8,10 +8,12 @@
   (:import (maelstrom.gpu Native)
            (java.nio ByteBuffer ByteOrder)))
 
-(def workloads {:echo 0 :broadcast 1 :g-set 2 :lin-kv 3 :txn-list-append 4 :pn-counter 5 :g-counter 6 :unique-ids 7})
+(def workloads {:echo 0 :broadcast 1 :g-set 2 :lin-kv 3 :txn-list-append 4 :pn-counter 5 :g-counter 6 :unique-ids 7
+                :txn-rw-register 8})
 (def node-programs {"builtin:echo" 0 "builtin:broadcast-ff" 1 "builtin:broadcast-ff-echoback" 2
                     "builtin:broadcast-ack-retry" 3 "builtin:broadcast-rpc-all" 4 "builtin:g-set" 5
-                    "builtin:raft" 6 "builtin:single-key-txn" 7 "builtin:pn-counter" 8 "builtin:flake-ids" 9 "builtin:lin-kv-proxy" 10})
+                    "builtin:raft" 6 "builtin:single-key-txn" 7 "builtin:pn-counter" 8 "builtin:flake-ids" 9 "builtin:lin-kv-proxy" 10
+                    "builtin:txn-rw-register-hat" 11})
 (def topologies {:grid 0 :line 1 :total 2 :tree 3 :tree2 3 :tree3 4 :tree4 5})
 (def fs [:echo :broadcast :read :add :start-partition :stop-partition])
 (def types [:invoke :ok :fail :info])
