@@ -43,7 +43,8 @@ def main():
         kw, n = CONFIGS[name]
         cfg = E.test_config(seed=99, **kw)
         with E.Engine(cfg) as eng:
-            eng.run(0, n)                      # warm-up (allocation, code load)
+            eng.run(0, n)                      # warm-up (allocation, code load, pinned host buffers of the host-side checkers)
+            eng.check()
             t0 = time.perf_counter()
             eng.run(n, n)
             eng.check()
