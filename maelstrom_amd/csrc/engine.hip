@@ -141,6 +141,20 @@ __device__ __forceinline__ void spill_min(const uint4 *q, u32 n, u64 &bk, u32 &b
   }
 }
 
+// merges a W-word replicate snapshot (HBM scratch) into a node's state (LDS): `or` for sets, element-wise max for counters.
+// Both merges are idempotent, so the tail of the last batch re-reads word W-1 instead of branching, and B independent loads
+// are in flight per step (one dependent load per word made every replicate delivery cost W HBM round trips).
+template <bool IS_MAX, int B = 16>
+__device__ __forceinline__ void merge_snapshot(u32 *mine, const u32 *snap, u32 W) {
+  for (u32 w0 = 0; w0 < W; w0 += B) {
+    u32 v[B];
+#pragma unroll
+    for (u32 t = 0; t < B; t++) v[t] = snap[min(w0 + t, W - 1)];
+#pragma unroll
+    for (u32 t = 0; t < B; t++) { const u32 i = min(w0 + t, W - 1); mine[i] = IS_MAX ? max(mine[i], v[t]) : (mine[i] | v[t]); }
+  }
+}
+
 // tells the compiler a value is dead here (freeze of undef): a register that is only meaningful inside a round must not
 // be carried around the round loops as a PHI
 __device__ __forceinline__ void forget(u32 &v) { v = __builtin_nondeterministic_value(v); }
@@ -632,8 +646,8 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
               rep = true; rep_dest = qsrc; rep_type = M_ADD_OK; rep_a = qa; rep_b = qb; break;
             case M_REPLICATE: {
               const u32 *snap = g_scr + ((size_t)qa * N + qsrc) * W;
-              if (IS_PN) { for (u32 w = 0; w < W; w++) my_seen[w] = max(my_seen[w], snap[w]); }  // element-wise max
-              else for (u32 w = 0; w < W; w++) my_seen[w] |= snap[w];
+              if (IS_PN) merge_snapshot<true>(my_seen, snap, W);  // element-wise max
+              else merge_snapshot<false>(my_seen, snap, W);
             } break;
             case M_BROADCAST: {
               const u32 v = qa, bitm = 1u << (v & 31);

@@ -19,6 +19,12 @@ def summarise(path):
          f"group by s.display_name order by 3 desc")
     for name, n, tot, avg, mn, mx, lds, vg, sg in con.execute(q):
         print(f"{name[:60]:60s} {n:6d} {tot/1e6:10.3f} {avg/1e6:10.4f} {mn/1e6:10.4f} {mx/1e6:10.4f} {lds:6d} {vg:5d} {sg:5d}")
+    try:  # private (scratch) memory per work-item, where the schema has it
+        for name, sc in con.execute(f"select s.display_name, max(d.private_segment_size) from '{kd}' d join '{ks}' s on d.kernel_id = s.id group by 1"):
+            if sc:
+                print(f"   scratch bytes/work-item: {name[:60]:60s} {sc}")
+    except Exception:
+        pass
     try:
         pe, pi = table(con, "rocpd_pmc_event"), table(con, "rocpd_info_pmc")
         q = (f"select s.display_name, i.name, count(*), sum(e.value), avg(e.value) from '{pe}' e join '{pi}' i on e.pmc_id = i.id "
