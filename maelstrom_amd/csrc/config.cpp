@@ -85,8 +85,9 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
   if (c->nemesis_mask & ~MSIM_NEMESIS_PARTITION) { set_err(err, errlen, "unknown nemesis fault (only partition, core.clj:49-51)"); return MSIM_E_INVALID; }
   if (c->nemesis_interval_ms == 0) { set_err(err, errlen, "nemesis interval must be positive"); return MSIM_E_INVALID; }
   if (c->latency_mean_ms > 60000) { set_err(err, errlen, "latency mean above 60 s is not supported"); return MSIM_E_INVALID; }
-  if ((uint64_t)c->time_limit_ms + c->quiesce_ms + 2ull * c->client_timeout_ms > 3600000ull) {
-    set_err(err, errlen, "time-limit + quiesce must fit in 1 h of virtual time (u32 microseconds)"); return MSIM_E_INVALID; }
+  // virtual time is u32 microseconds and the kernels order events by 2 x time (+ 1 for client timeouts): 2^31 us ~ 35 min
+  if ((uint64_t)c->time_limit_ms + c->quiesce_ms + 2ull * c->client_timeout_ms + 16ull * c->latency_mean_ms > 2000000ull) {
+    set_err(err, errlen, "time-limit + quiesce + timeouts must fit in 2000 s of virtual time (2 x time in u32 microseconds)"); return MSIM_E_INVALID; }
   // workload <-> node program compatibility
   bool ok = false;
   switch (c->workload) {

@@ -41,6 +41,8 @@ def test_finalize_derives_capacities_and_rejects_bad_options(lib):
     assert cfg.max_values % 32 == 0 and cfg.max_values >= 1100 and cfg.max_rows >= 2 * 2300 and cfg.inbox_capacity >= 8
     with pytest.raises(E.EngineError, match="divides by zero"):   # net.clj:77 with --latency 0
         E.test_config("broadcast", node_count=5, latency=0, latency_dist="exponential")
+    with pytest.raises(E.EngineError, match="2000 s of virtual time"):   # 2 x time must fit in u32 microseconds
+        E.test_config("echo", node_count=1, time_limit=2100)
     with pytest.raises(E.EngineError, match="node_program"):
         E.test_config("echo", bin="g-set", node_count=3)
     with pytest.raises(E.EngineError, match="n_nodes"):
