@@ -165,7 +165,9 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
     if (txn) depth = 16 + 4 * c->n_nodes;
     if (hat) depth = 16 + 4 * c->n_nodes + (uint32_t)(20.0 * c->n_nodes * lat_s);  // a replicate + n-1 acks per peer per 100 ms tick
     if (c->node_program == MSIM_NODE_LIN_KV_PROXY) depth = 16 + 2 * c->concurrency;   // the service sees every worker's request at once                           // the service sees <= 2 requests per transaction in flight       // heartbeats / re-sent append_entries pile up behind a sleeping recv!
-    const uint32_t lds_part = c->n_nodes > 32 ? 4 : 24;  // wide clusters keep 100+ queues in one CU's LDS
+    // wide clusters: 100+ queues would take a fifth of the LDS budget of a cluster; their queues live in the HBM spill area
+    // only (kept sorted, the head cached in registers: sim_kernel_wide.inc), which buys a sixth wavefront per CU
+    const uint32_t lds_part = c->n_nodes > 32 ? 0 : 24;
     if (c->inbox_capacity == 0) c->inbox_capacity = depth < lds_part ? depth : lds_part;
     if (c->spill_capacity == 0) c->spill_capacity = depth > c->inbox_capacity ? depth - c->inbox_capacity : 0;
     if (c->spill_capacity > 65536) { set_err(err, errlen, "spill_capacity above 65536 envelopes per node"); return MSIM_E_INVALID; }
