@@ -945,6 +945,7 @@ static uint64_t proto_scratch_words(const msim_config &c) {
     const uint64_t total_ms = (uint64_t)c.time_limit_ms + c.quiesce_ms + 2ull * c.client_timeout_ms;
     const uint64_t ticks = total_ms / 5000 + 3;
     w = ticks * c.n_nodes * (c.max_values / 32);
+    if (c.n_nodes > 32) w = ((w + 3) & ~3ull) + (((uint64_t)c.n_nodes * (c.max_values / 32) + 3) & ~3ull);  // wide clusters: + the nodes' sets
   }
   return (w + 3) & ~3ull;  // keep the spill area 16-byte aligned
 }
@@ -1031,6 +1032,7 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
        : is_px ? (size_t)kp.N * PX_SLOTS * 8 + 34 * 256 + 64 * 4   // callbacks per node + service states + seq-kv indices
        : is_txn ? (size_t)kp.N * TXN_SLOTS * 16 + 36 * 4   // transactions in flight per node + the generator's key pool
        : is_raft ? (size_t)kp.N * 256 + (size_t)kp.N * kp.N * 3 * 4   // KV state + next/match index + append_entries refs
+       : wide ? 0   // the sets of a wide cluster live in HBM scratch
                  : (size_t)kp.N * kp.W * 4;
   off = (off + 15) & ~(size_t)15;
   kp.off_misc = (u32)off; if (c.nemesis_mask) off += 64 * 4;  // shuffle scratch, only the partition nemesis needs it
