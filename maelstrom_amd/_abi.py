@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmaelsim.so")
+LIB_PATH = os.environ.get("MSIM_LIB") or os.path.join(HERE, "libmaelsim.so")   # MSIM_LIB: developer knob for A/B builds
 
 ABI_VERSION = 1
 
