@@ -33,7 +33,7 @@ CONFIGS = {
     "txn-rw-register hat n=2 rate100 30s + partitions": (dict(workload="txn-rw-register", node_count=2, rate=100, time_limit=30,
                                                                nemesis=["partition"], nemesis_interval=10), 16384),
     "txn-rw-register hat n=5 rate100 30s lat5 + partitions": (dict(workload="txn-rw-register", node_count=5, rate=100, time_limit=30, latency=5,
-                                                                    nemesis=["partition"], nemesis_interval=10), 8192),
+                                                                    nemesis=["partition"], nemesis_interval=10), 4096),
 }
 
 
