@@ -20,7 +20,10 @@
 // the simulation itself stays on the GPU.
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -213,11 +216,14 @@ void finish(Scratch &S, uint32_t anomalies, uint32_t flags, uint32_t cm, msim_ch
 void check_history(Scratch &S, const msim_op *rows, uint32_t n_rows, const uint32_t *payload, uint32_t n_words, uint32_t flags, uint32_t cm, msim_check_result *out) {
   uint32_t anomalies = collect(S, rows, n_rows, payload, n_words, false, out), max_key = 0;
   const uint32_t n = (uint32_t)S.txns.size();
-  for (const Txn &t : S.txns) for (uint32_t k = 0; k < t.n_mops; k++) max_key = std::max<uint32_t>(max_key, S.mops[t.mop0 + k].key);
+  uint32_t max_val = 0;
+  for (const Txn &t : S.txns) for (uint32_t k = 0; k < t.n_mops; k++) { const Mop &m = S.mops[t.mop0 + k]; max_key = std::max<uint32_t>(max_key, m.key); if (m.f) max_val = std::max<uint32_t>(max_val, m.val); }
+  for (uint8_t b : S.bytes) max_val = std::max<uint32_t>(max_val, b);   // elements that were read but never appended (garbage reads)
 
-  // writers: (key, element) -> transaction
-  auto kv = [](uint32_t k, uint32_t v) { return (k << 8) | v; };
-  S.writer.assign((size_t)(max_key + 1) << 8, -1);
+  // writers: (key, element) -> transaction; the table is as wide as the largest element (16 by default), not 256
+  const uint32_t stride = max_val + 1;
+  auto kv = [stride](uint32_t k, uint32_t v) { return k * stride + v; };
+  S.writer.assign((size_t)(max_key + 1) * stride, -1);
   for (uint32_t t = 0; t < n; t++)
     for (uint32_t k = 0; k < S.txns[t].n_mops; k++) {
       const Mop &m = S.mops[S.txns[t].mop0 + k];
@@ -319,9 +325,11 @@ void check_history(Scratch &S, const msim_op *rows, uint32_t n_rows, const uint3
 void check_rw(Scratch &S, const msim_op *rows, uint32_t n_rows, const uint32_t *payload, uint32_t n_words, uint32_t flags, uint32_t cm, msim_check_result *out) {
   uint32_t anomalies = collect(S, rows, n_rows, payload, n_words, true, out), max_key = 0;
   const uint32_t n = (uint32_t)S.txns.size();
-  for (const Txn &t : S.txns) for (uint32_t k = 0; k < t.n_mops; k++) max_key = std::max<uint32_t>(max_key, S.mops[t.mop0 + k].key);
-  auto kv = [](uint32_t k, uint32_t v) { return (k << 8) | v; };
-  S.writer.assign((size_t)(max_key + 1) << 8, -1);
+  uint32_t max_val = 0;
+  for (const Txn &t : S.txns) for (uint32_t k = 0; k < t.n_mops; k++) { const Mop &m = S.mops[t.mop0 + k]; max_key = std::max<uint32_t>(max_key, m.key); max_val = std::max<uint32_t>(max_val, m.val); }
+  const uint32_t stride = max_val < 64 ? 64u : max_val + 1;  // the version graphs below walk versions 0..63 of every key
+  auto kv = [stride](uint32_t k, uint32_t v) { return k * stride + v; };
+  S.writer.assign((size_t)(max_key + 1) * stride, -1);
   for (uint32_t t = 0; t < n; t++)
     for (uint32_t k = 0; k < S.txns[t].n_mops; k++) {
       const Mop &m = S.mops[S.txns[t].mop0 + k];
@@ -445,27 +453,45 @@ extern "C" int msim_check_rw_rows(const msim_op *rows, uint32_t n_rows, const ui
   return MSIM_OK;
 }
 
+// Checker threads keep their working storage across calls: a fresh Scratch per call would fault in (and give back) a few MB
+// per thread and history batch, and 256 threads doing that serialise in the kernel.
+static std::vector<Scratch *> &scratch_pool(unsigned nt) {
+  static std::vector<Scratch *> pool;  // one engine context checks at a time per process in practice; guarded by the caller's ctx use
+  while (pool.size() < nt) pool.push_back(new Scratch());
+  return pool;
+}
+static std::mutex g_check_mutex;
+
 int msim_check_txn_host(msim_ctx *ctx) {
   const auto t0 = std::chrono::steady_clock::now();
   int rc = msim_fetch(ctx);
   if (rc != MSIM_OK) return rc;
+  const auto t1 = std::chrono::steady_clock::now();
   const uint32_t n = ctx->n_inst;
   if (ctx->h_check) { (void)hipHostFree(ctx->h_check); ctx->h_check = nullptr; }
   MSIM_HIP_TRY(ctx, hipHostMalloc(&ctx->h_check, (size_t)n * sizeof(msim_check_result)));
   unsigned nt = msim_host_threads();
   if (nt > n) nt = n;
-  std::vector<std::thread> th;
-  for (unsigned t = 0; t < nt; t++)
-    th.emplace_back([ctx, n, nt, t]() {
-      Scratch S;
-      const bool rw = ctx->cfg.workload == MSIM_WL_TXN_RW_REGISTER;
-      for (uint32_t i = t; i < n; i += nt)
-        (rw ? check_rw : check_history)(S, ctx->h_rows + ctx->h_row_off[i], ctx->h_meta[i].n_rows, ctx->h_payload + ctx->h_pay_off[i],
-                                        ctx->h_meta[i].n_payload_words, ctx->h_meta[i].flags, ctx->cfg.consistency_model, &ctx->h_check[i]);
-    });
-  for (auto &x : th) x.join();
+  {
+    std::lock_guard<std::mutex> lock(g_check_mutex);
+    std::vector<Scratch *> &pool = scratch_pool(nt);
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++)
+      th.emplace_back([ctx, n, nt, t, &pool]() {
+        Scratch &S = *pool[t];
+        const bool rw = ctx->cfg.workload == MSIM_WL_TXN_RW_REGISTER;
+        for (uint32_t i = t; i < n; i += nt)
+          (rw ? check_rw : check_history)(S, ctx->h_rows + ctx->h_row_off[i], ctx->h_meta[i].n_rows, ctx->h_payload + ctx->h_pay_off[i],
+                                          ctx->h_meta[i].n_payload_words, ctx->h_meta[i].flags, ctx->cfg.consistency_model, &ctx->h_check[i]);
+      });
+    for (auto &x : th) x.join();
+  }
+  const auto t2 = std::chrono::steady_clock::now();
   MSIM_HIP_TRY(ctx, hipMemcpy(ctx->d_check, ctx->h_check, (size_t)n * sizeof(msim_check_result), hipMemcpyHostToDevice));
   ctx->checked = true; ctx->check_fetched = true;
   ctx->check_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  static const char *timing = std::getenv("MSIM_TIMING");  // developer knob: where the host check spends its time
+  if (timing) std::fprintf(stderr, "[msim] txn check: fetch %.1f ms, %u threads x graph work %.1f ms, total %.1f ms\n",
+                           std::chrono::duration<float, std::milli>(t1 - t0).count(), nt, std::chrono::duration<float, std::milli>(t2 - t1).count(), ctx->check_ms);
   return MSIM_OK;
 }
