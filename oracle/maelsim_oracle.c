@@ -992,11 +992,13 @@ int oracle_topology(uint32_t topology, uint32_t n, uint32_t *adj_out) {
 
 /* Test hook for the txn-rw-register node: runs instance `instance` like oracle_run_instance and also returns the nodes'
  * final registers (kv: n_nodes x max_values words, lamport << 11 | node << 8 | value), Lamport clocks and the number of
- * txns each node still holds as unreplicated. */
+ * txns each node still holds as unreplicated; `journal` as in oracle_run_instance. */
 int oracle_hat_state(const msim_config *cfg, uint64_t instance, msim_op *rows, uint32_t *payload, msim_net_stats *stats,
-                     msim_inst_meta *meta, uint32_t *kv, uint32_t *lamport, uint32_t *npend) {
+                     msim_inst_meta *meta, uint32_t *kv, uint32_t *lamport, uint32_t *npend, msim_event *journal) {
   sim_t *s = sim_new(cfg, instance, rows, payload);
   if (!s || !s->hat) return -1;
+  if (cfg->journal_capacity && !journal) { sim_free(s); return -1; }
+  s->journal = journal;
   run_instance(s);
   *stats = s->st; *meta = s->meta;
   memcpy(kv, s->hat->kv, (size_t)s->N * cfg->max_values * 4);

@@ -100,7 +100,7 @@ def test_replication_converges():
         stats = np.zeros(1, dtype=O.STATS_DT); meta = np.zeros(1, dtype=O.META_DT)
         kv = np.zeros((3, cfg.max_values), dtype=np.uint32); lam = np.zeros(3, dtype=np.uint32); npend = np.zeros(3, dtype=np.uint32)
         rc = lib.oracle_hat_state(C.byref(cfg), inst, rows.ctypes.data_as(C.c_void_p), pay.ctypes.data_as(C.c_void_p), stats.ctypes.data_as(C.c_void_p),
-                                  meta.ctypes.data_as(C.c_void_p), kv.ctypes.data_as(C.c_void_p), lam.ctypes.data_as(C.c_void_p), npend.ctypes.data_as(C.c_void_p))
+                                  meta.ctypes.data_as(C.c_void_p), kv.ctypes.data_as(C.c_void_p), lam.ctypes.data_as(C.c_void_p), npend.ctypes.data_as(C.c_void_p), None)
         assert rc == 0 and meta[0]["flags"] == 0
         if npend.sum() == 0:
             converged += 1
@@ -194,3 +194,77 @@ def test_proscribed_sets_nest():
     sets = [lib.msim_proscribed_anomalies(m) for m in (A.CM_READ_UNCOMMITTED, A.CM_READ_COMMITTED, A.CM_SNAPSHOT_ISOLATION, A.CM_SERIALIZABLE, A.CM_STRICT_SERIALIZABLE)]
     for weaker, stronger in zip(sets, sets[1:]):
         assert weaker & stronger == weaker and weaker != stronger
+
+
+# ---- the oracle's node against an independent transliteration of txn_rw_register_hat.clj ----
+def _replay_through_model(cfg, inst):
+    """Runs the oracle with the journal on, then replays its network schedule (what was sent, what was delivered and when,
+    journal.clj:220-239) through tests/hat_ref.py: every message a node emits must be the one the oracle's node emitted."""
+    import collections
+    import hat_ref
+    lib = O.load()
+    N = cfg.n_nodes
+    rows = np.zeros(cfg.max_rows, dtype=O.OP_DT); pay = np.zeros(cfg.max_payload_words, dtype=np.uint32)
+    stats = np.zeros(1, dtype=O.STATS_DT); meta = np.zeros(1, dtype=O.META_DT)
+    kv = np.zeros((N, cfg.max_values), dtype=np.uint32); lam = np.zeros(N, dtype=np.uint32); npend = np.zeros(N, dtype=np.uint32)
+    journal = np.zeros(cfg.journal_capacity, dtype=O.EVENT_DT)
+    rc = lib.oracle_hat_state(C.byref(cfg), inst, rows.ctypes.data_as(C.c_void_p), pay.ctypes.data_as(C.c_void_p), stats.ctypes.data_as(C.c_void_p),
+                              meta.ctypes.data_as(C.c_void_p), kv.ctypes.data_as(C.c_void_p), lam.ctypes.data_as(C.c_void_p), npend.ctypes.data_as(C.c_void_p),
+                              journal.ctypes.data_as(C.c_void_p))
+    assert rc == 0 and meta[0]["flags"] == 0 and meta[0]["n_events"] <= cfg.journal_capacity
+    T = {name: i for i, name in enumerate(A.MSG_TYPES)}
+    created = {}
+    nodes = [hat_ref.HatNode(i, range(N), created) for i in range(N)]
+    out = [collections.deque() for _ in range(N)]
+    content, next_tick, n_replicated = {}, 100000, 0
+    for ev in journal[: meta[0]["n_events"]]:
+        t, msg, a, route = int(ev["time_us"]), int(ev["msg"]), int(ev["a"]), int(ev["route"])
+        mid, recv, typ = msg >> 8, (msg >> 7) & 1, msg & 0x7F
+        src, dest, b = route & 0xFF, (route >> 8) & 0xFF, route >> 16
+        while next_tick <= t:   # the replication thread wakes every 100 ms (:107-118), before anything else at that instant
+            for n in range(N):
+                step = nodes[n].replicate_step()
+                if step:
+                    out[n].append(("replicate", step[0], step[1]))
+            next_tick += 100000
+        if not recv:
+            if src >= N:    # a client's request
+                content[mid] = ("txn", E.decode_rw_txn(pay[a & 0xFFFFFF:(a & 0xFFFFFF) + (a >> 24)])) if typ == T["txn"] else ("init", None)
+                continue
+            assert out[src], f"node {src} sent {A.MSG_TYPES[typ]} at {t} us, the model had nothing to send"
+            kind, to, body = out[src].popleft()
+            assert (kind, to) == (A.MSG_TYPES[typ], dest), (t, src, kind, to, A.MSG_TYPES[typ], dest)
+            if kind == "txn_ok":
+                got = E.decode_rw_txn(pay[a & 0xFFFFFF:(a & 0xFFFFFF) + (a >> 24)])
+                assert got == [[":" + f, k, v] for f, k, v in body], (t, src, got, body)
+            elif kind in ("replicate", "replicate_ack"):
+                assert len(body) & 0xFFFF == b, (t, src, kind, len(body), b)
+                n_replicated += kind == "replicate"
+            content[mid] = (kind, body)
+        elif dest < N:
+            kind, body = content[mid]
+            node = nodes[dest]
+            if kind == "init":
+                out[dest].append(("init_ok", src, None))
+            elif kind == "txn":
+                out[dest].append(("txn_ok", src, node.on_txn([[f[1:], k, v] for f, k, v in body])))
+            elif kind == "replicate":
+                for to, tss in node.on_replicate(body):
+                    out[dest].append(("replicate_ack", to, tss))
+            elif kind == "replicate_ack":
+                node.on_replicate_ack(src, body)
+    assert not any(out), [len(o) for o in out]
+    for n, node in enumerate(nodes):
+        assert node.lamport == lam[n] and len(node.unreplicated) == npend[n]
+        want = {k: (int(w) >> 11, (int(w) >> 8) & 7, int(w) & 0xFF) for k, w in enumerate(kv[n]) if w}
+        assert {k: (r["ts"][0], r["ts"][1], r["value"]) for k, r in node.kv.items()} == want
+    return n_replicated, len(created)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(nemesis=("partition",), nemesis_interval=1.5), dict(node_count=3, latency=30, latency_dist="exponential", p_loss=0.1),
+                                dict(node_count=5, latency=10, nemesis=("partition",), nemesis_interval=2.0), dict(node_count=8, rate=40.0, latency=40, latency_dist="uniform")])
+def test_oracle_node_equals_transliterated_reference_node(kw):
+    cfg = _cfg(journal_capacity=400000, **kw)
+    for inst in range(3):
+        n_rep, n_txn = _replay_through_model(cfg, inst)
+        assert n_txn > 20 and n_rep > 10
