@@ -161,10 +161,10 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
     // retrying gossip under partitions: at heal time every neighbour re-sends everything it could not deliver
     if (c->node_program == MSIM_NODE_BCAST_ACK_RETRY && c->nemesis_mask) depth += (deg < 4 ? deg : 4) * adds;
     if (c->node_program == MSIM_NODE_G_SET || c->node_program == MSIM_NODE_PN_COUNTER) depth = 16 + 2 * deg;  // one replicate_full per peer per 5 s tick (g_set.rb:33-38)
-    if (c->node_program == MSIM_NODE_RAFT) depth = 24 + 1024;
-    if (txn) depth = 16 + 4 * c->n_nodes;
+    if (c->node_program == MSIM_NODE_RAFT) depth = 24 + 1024;   // heartbeats / re-sent append_entries pile up behind a sleeping recv!
+    if (txn) depth = 16 + 4 * c->n_nodes;                       // the service sees <= 2 requests per transaction in flight
     if (hat) depth = 16 + 4 * c->n_nodes + (uint32_t)(20.0 * c->n_nodes * lat_s);  // a replicate + n-1 acks per peer per 100 ms tick
-    if (c->node_program == MSIM_NODE_LIN_KV_PROXY) depth = 16 + 2 * c->concurrency;   // the service sees every worker's request at once                           // the service sees <= 2 requests per transaction in flight       // heartbeats / re-sent append_entries pile up behind a sleeping recv!
+    if (c->node_program == MSIM_NODE_LIN_KV_PROXY) depth = 16 + 2 * c->concurrency;   // the service sees every worker's request at once
     // wide clusters: 100+ queues would take a fifth of the LDS budget of a cluster; their queues live in the HBM spill area
     // only (kept sorted, the head cached in registers: sim_kernel_wide.inc), which buys a sixth wavefront per CU
     const uint32_t lds_part = c->n_nodes > 32 ? 0 : 24;
