@@ -55,3 +55,84 @@ def test_weaker_services_are_caught_by_the_checker(service):
         rows, _ = r.history(i)
         bad += _lin(rows).valid == 0
     assert bad >= 4, bad     # stale reads from old states (seq-kv) / from the other replica (lww-kv)
+
+
+# ---- the oracle's proxy node and services against transliterations of service.clj / lin_kv_proxy.rb ----
+def _replay(cfg, service, inst):
+    import collections
+    import services_ref as R
+    lib = O.load()
+    r = O.run(cfg, inst, 1)
+    assert r.meta["flags"][0] == 0 and r.meta["n_events"][0] <= cfg.journal_capacity
+    N, SVC = cfg.n_nodes, cfg.n_nodes + max(cfg.concurrency, cfg.n_nodes)
+    T = {name: i for i, name in enumerate(A.MSG_TYPES)}
+    ctr = [0]
+
+    def rand_int(n):    # the service's rand-int draws: stream 12 of the instance, in request order
+        x = lib.oracle_draw32(cfg.seed, inst, 12, ctr[0]); ctr[0] += 1
+        return (x * n) >> 32
+    svc = {"lin-kv": R.Linearizable, "seq-kv": R.Sequential, "lww-kv": R.Eventual}[service]()
+    nodes = [R.ProxyNode(SVC) for _ in range(N)]
+    out = collections.defaultdict(collections.deque)   # endpoint -> bodies it still has to send, in order
+    content, n_req = {}, 0
+
+    def body_of(typ, a, b):    # envelope -> message body (lin-kv encoding: key | v << 8 | v' << 16, 0xFF = absent)
+        name = A.MSG_TYPES[typ]
+        k, v1, v2 = a & 0xFF, (a >> 8) & 0xFF, (a >> 16) & 0xFF
+        if name == "read":
+            return {"type": "read", "key": k, "msg_id": b}
+        if name == "write":
+            return {"type": "write", "key": k, "value": v1, "msg_id": b}
+        if name == "cas":
+            return {"type": "cas", "key": k, "from": v1, "to": v2, "msg_id": b}
+        return {"type": name, "msg_id": b}
+
+    def same(body, typ, a, b):  # does a body the model wants to send equal the envelope the oracle sent?
+        name = A.MSG_TYPES[typ]
+        if body["type"] != name:
+            return False
+        if name in ("read", "write", "cas"):
+            want = body["key"] | (body.get("value", body.get("from", 0xFF)) << 8) | (body.get("to", 0xFF) << 16)
+            return want == a and (body["msg_id"] & 0xFFFF) == b
+        val = {"read_ok": body.get("value"), "error": body.get("code")}.get(name, 0)
+        return val == a and (body.get("in_reply_to", 0) & 0xFFFF) == b
+    for ev in r.events(0):
+        msg, a, route = int(ev["msg"]), int(ev["a"]), int(ev["route"])
+        mid, recv, typ = msg >> 8, (msg >> 7) & 1, msg & 0x7F
+        src, dest, b = route & 0xFF, (route >> 8) & 0xFF, route >> 16
+        if not recv:
+            if N <= src < SVC:
+                content[mid] = body_of(typ, a, b)    # a client's request (or init)
+                continue
+            assert out[src], (src, A.MSG_TYPES[typ])
+            to, body = out[src].popleft()
+            assert to == dest and same(body, typ, a, b), (src, dest, to, body, A.MSG_TYPES[typ], a, b)
+            content[mid] = body
+        elif dest < N:
+            body = content[mid]
+            if body["type"] == "init":
+                out[dest].append((src, {"type": "init_ok", "in_reply_to": body["msg_id"]}))
+            elif "in_reply_to" in body:
+                fwd = nodes[dest].on_reply(body)
+                if fwd:
+                    out[dest].append(fwd)
+            else:
+                out[dest].append(nodes[dest].on_request(src, body)); n_req += 1   # noqa: E702
+        elif dest == SVC:
+            body = content[mid]
+            try:
+                res = svc.handle(src, body, rand_int)
+            except IndexError:
+                continue    # "Error in service worker!" (service.clj:259-260): no reply
+            out[SVC].append((src, dict(res, in_reply_to=body["msg_id"])))
+    assert not any(out.values())
+    return n_req
+
+
+@pytest.mark.parametrize("service,kw", [("lin-kv", dict()), ("lin-kv", dict(latency=20, latency_dist="exponential", p_loss=0.05)),
+                                        ("seq-kv", dict(rate=100)), ("seq-kv", dict(node_count=3, latency=30, latency_dist="uniform", nemesis=["partition"], nemesis_interval=3)),
+                                        ("lww-kv", dict(rate=100)), ("lww-kv", dict(node_count=7, concurrency=28, latency=10))])
+def test_oracle_proxy_and_services_equal_transliterated_reference(service, kw):
+    cfg = _cfg(service, time_limit=10, journal_capacity=200000, **kw)
+    for inst in range(3):
+        assert _replay(cfg, service, inst) > 100
