@@ -118,3 +118,49 @@ class ProxyNode:                                 # lin_kv_proxy.rb:8-43 over nod
             return None                          # "Ignoring reply ... with no callback"
         res = {k: v for k, v in body.items() if k not in ("msg_id", "in_reply_to")}
         return cb[0], dict(res, in_reply_to=cb[1])
+
+
+class SingleKeyTxnNode:                          # demo/clojure/single_key_txn.clj:116-180 (one future per request)
+    def __init__(self, service):
+        self.service, self.next_msg_id, self.pending = service, 0, {}
+
+    @staticmethod
+    def apply_txn(state, txn):                   # apply-txn, :118-131
+        state, out = dict(state), []
+        for f, k, v in txn:
+            if f == "r":
+                out.append([f, k, state.get(k)])
+            else:
+                state[k] = list(state.get(k, [])) + [v]
+                out.append([f, k, v])
+        return state, out
+
+    def rpc(self, body, cont):
+        self.next_msg_id += 1
+        self.pending[self.next_msg_id] = cont
+        return self.service, dict(body, msg_id=self.next_msg_id)
+
+    def on_txn(self, src, body):                 # handle-txn!: first the read of the root (read-service, :150-157)
+        return self.rpc({"type": "read", "key": "root"}, ("read", src, body))
+
+    def on_reply(self, body):                    # -> (dest, body) of the next message
+        cont = self.pending.pop(body["in_reply_to"], None)
+        if cont is None:
+            return None
+        if cont[0] == "read":
+            _, src, req = cont
+            if body["type"] == "read_ok":
+                state = body["value"]
+            elif body["type"] == "error" and body["code"] == 20:
+                state = None                     # not found => nil
+            else:
+                return src, {"type": "error", "code": body["code"], "in_reply_to": req["msg_id"]}
+            pairs = state or []
+            m = {pairs[i]: pairs[i + 1] for i in range(0, len(pairs), 2)}          # pairs->map
+            m2, txn2 = self.apply_txn(m, req["txn"])
+            to = [x for kv in m2.items() for x in kv]                               # map->pairs
+            return self.rpc({"type": "cas", "key": "root", "from": state, "to": to, "create_if_not_exists": True}, ("cas", src, req, txn2))
+        _, src, req, txn2 = cont
+        if body["type"] == "cas_ok":
+            return src, {"type": "txn_ok", "txn": txn2, "in_reply_to": req["msg_id"]}
+        return src, {"type": "error", "code": 30 if body["code"] == 22 else body["code"], "in_reply_to": req["msg_id"]}   # "root altered", :176-178

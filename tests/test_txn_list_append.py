@@ -224,3 +224,67 @@ def test_checker_agrees_with_the_python_restatement_on_engine_and_mutated_histor
             got = _agree(mut)
             n_bad += got["valid?"] is False
     assert n_bad > 60
+
+
+# ---- the oracle's node, service and its "a database state is a prefix of one append log" shortcut against a transliteration
+#      of single_key_txn.clj + service.clj that keeps the real values ----
+def _replay_real_values(cfg, inst):
+    import collections
+    import services_ref as R
+    r = O.run(cfg, inst, 1)
+    assert r.meta["flags"][0] == 0 and r.meta["n_events"][0] <= cfg.journal_capacity
+    rows, pay = r.history(0)
+    N = cfg.n_nodes
+    SVC = 2 * N
+    svc = R.Linearizable()
+    nodes = [R.SingleKeyTxnNode(SVC) for _ in range(N)]
+    out = collections.defaultdict(collections.deque)
+    content, n_ok, n_conflict = {}, 0, 0
+    for ev in r.events(0):
+        msg, a, route = int(ev["msg"]), int(ev["a"]), int(ev["route"])
+        mid, recv, typ = msg >> 8, (msg >> 7) & 1, A.MSG_TYPES[msg & 0x7F]
+        src, dest, b = route & 0xFF, (route >> 8) & 0xFF, route >> 16
+        if not recv:
+            if N <= src < SVC:
+                txn = [[f[1:], k, v] for f, k, v in E.decode_txn(pay[a & 0xFFFFFF:(a & 0xFFFFFF) + (a >> 24)])] if typ == "txn" else None
+                content[mid] = {"type": typ, "msg_id": b, "txn": txn}
+                continue
+            assert out[src], (src, typ)
+            to, body = out[src].popleft()
+            assert to == dest and body["type"] == typ and (body.get("msg_id", body.get("in_reply_to", 0)) & 0xFFFF) == b, (src, dest, to, body, typ, b)
+            if typ == "txn_ok":    # the completed transaction, reads filled in from the REAL lists
+                got = [[f[1:], k, v] for f, k, v in E.decode_txn(pay[a & 0xFFFFFF:(a & 0xFFFFFF) + (a >> 24)])]
+                assert got == body["txn"], (got, body["txn"])
+                n_ok += 1
+            elif typ == "error":
+                assert body["code"] == a
+                n_conflict += a == 30
+            content[mid] = body
+        elif dest < N:
+            body = content[mid]
+            if body["type"] == "init":
+                out[dest].append((src, {"type": "init_ok", "in_reply_to": body["msg_id"]}))
+            elif "in_reply_to" in body:
+                nxt = nodes[dest].on_reply(body)
+                if nxt:
+                    out[dest].append(nxt)
+            else:
+                out[dest].append(nodes[dest].on_txn(src, body))
+        elif dest == SVC:
+            body = content[mid]
+            out[SVC].append((src, dict(svc.handle(src, body, None), in_reply_to=body["msg_id"])))
+    assert not any(out.values())
+    return n_ok, n_conflict
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(latency=20, latency_dist="exponential", p_loss=0.05), dict(node_count=3, rate=200, latency=2),
+                                dict(nemesis=["partition"], nemesis_interval=2, latency=5), dict(key_count=2, max_txn_length=8, max_writes_per_key=40, rate=150)])
+def test_oracle_equals_transliterated_node_and_service_with_real_values(kw):
+    base = dict(node_count=5, rate=80, time_limit=8, latency=5, seed=77, journal_capacity=200000)
+    base.update(kw)
+    cfg = E.test_config("txn-list-append", **base)
+    ok = conflict = 0
+    for inst in range(3):
+        a, b = _replay_real_values(cfg, inst)
+        ok += a; conflict += b
+    assert ok > 50 and (conflict > 0 or kw.get("p_loss"))
