@@ -211,7 +211,7 @@ def main():
                                       "note": "quoted for scale only; vs_baseline stays null because BASELINE.json publishes no number for this metric"}
         if gather:
             out["history_gather"] = gather
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:   # the CPU leg is measured once, at N=1
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample)
         print(json.dumps(out), flush=True)
     if dist:
