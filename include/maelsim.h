@@ -302,6 +302,14 @@ int msim_check_unique_rows(const msim_op *rows, uint32_t n_rows, msim_check_resu
 
 int msim_check_pn_rows(const msim_op *rows, uint32_t n_rows, msim_check_result *out, int64_t *ranges, uint32_t cap, uint32_t *n_ranges);
 
+/* Host-only utility: one history as the text of Jepsen's history.edn — one op map per line,
+ * {:type :f :value :time :process :index [:error] [:final?]} with the :value shapes of the workload in cfg —
+ * for a JVM side that wants to hand the history to an unchanged checker without decoding rows itself.  Writes at most `cap`
+ * bytes including the terminating NUL; *needed (may be NULL) receives the size required; cap == 0 only queries it.
+ * Returns MSIM_E_RANGE if the buffer is too small or a row points outside the payload.  Needs no device. */
+int msim_history_edn_rows(const msim_config *cfg, const msim_op *rows, uint32_t n_rows, const uint32_t *payload, uint32_t n_words,
+                          char *out, size_t cap, size_t *needed);
+
 /* Copies the last run's outputs to host memory (pinned, owned by ctx, valid until next run/destroy). */
 int msim_fetch(msim_ctx *ctx);
 

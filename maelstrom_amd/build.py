@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmaelsim.so")
-SOURCES = ["config.cpp", "engine.hip", "checker.hip", "lin_check.cpp", "txn_check.cpp", "pn_check.cpp"]
+SOURCES = ["config.cpp", "engine.hip", "checker.hip", "lin_check.cpp", "txn_check.cpp", "pn_check.cpp", "edn.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 
 

@@ -410,6 +410,22 @@ def decode_history(rows, payload, n_nodes, workload=A.WL_BROADCAST):
     return ops
 
 
+def history_edn_native(cfg, rows, payload):
+    """history.edn text of one history straight from the binary rows (msim_history_edn_rows, csrc/edn.cpp)."""
+    lib = A.load()
+    rows = np.ascontiguousarray(rows); payload = np.ascontiguousarray(payload, dtype=np.uint32)
+    need = C.c_size_t()
+    args = (C.byref(cfg), rows.ctypes.data_as(C.c_void_p), len(rows), payload.ctypes.data_as(C.c_void_p), len(payload))
+    rc = lib.msim_history_edn_rows(*args, None, 0, C.byref(need))
+    if rc:
+        raise EngineError(f"msim_history_edn_rows: {rc}")
+    buf = C.create_string_buffer(need.value)
+    rc = lib.msim_history_edn_rows(*args, buf, need.value, None)
+    if rc:
+        raise EngineError(f"msim_history_edn_rows: {rc}")
+    return buf.value.decode()
+
+
 def history_edn(ops):
     """Jepsen history.edn text (one op map per line)."""
     def edn(v):
