@@ -5,6 +5,7 @@
  * Java side: class maelstrom.gpu.Native { static native long create(int[] cfg, long seed, int device); ... }
  * Buffers cross as direct ByteBuffers over the engine-owned pinned host memory (valid until the next run). */
 #include <jni.h>
+#include <stdlib.h>
 #include <string.h>
 #include "maelsim.h"
 
@@ -43,6 +44,20 @@ JNIEXPORT jobjectArray JNICALL Java_maelstrom_gpu_Native_history(JNIEnv *env, jc
   out = (*env)->NewObjectArray(env, 2, (*env)->FindClass(env, "java/nio/ByteBuffer"), NULL);
   (*env)->SetObjectArrayElement(env, out, 0, (*env)->NewDirectByteBuffer(env, (void *)ops, (jlong)n_ops * 16));
   (*env)->SetObjectArrayElement(env, out, 1, (*env)->NewDirectByteBuffer(env, (void *)pay, (jlong)n_words * 4));
+  return out;
+}
+
+/* the history of instance i as history.edn text (msim_history_edn_rows): (jepsen.history/parse ...) or a store file, no decoder needed */
+JNIEXPORT jstring JNICALL Java_maelstrom_gpu_Native_historyEdn(JNIEnv *env, jclass cls, jlong h, jint i) {
+  msim_ctx *ctx = (msim_ctx *)(intptr_t)h;
+  const msim_op *ops; const uint32_t *pay; uint32_t n_ops, n_words;
+  msim_config c; size_t need = 0; char *buf; jstring out;
+  (void)cls;
+  if (msim_history(ctx, (uint32_t)i, &ops, &n_ops, &pay, &n_words) || msim_get_config(ctx, &c)) { throw_msim(env, msim_last_error(ctx)); return NULL; }
+  if (msim_history_edn_rows(&c, ops, n_ops, pay, n_words, NULL, 0, &need) || !(buf = (char *)malloc(need))) { throw_msim(env, "history edn"); return NULL; }
+  msim_history_edn_rows(&c, ops, n_ops, pay, n_words, buf, need, NULL);
+  out = (*env)->NewStringUTF(env, buf);   /* the text is ASCII */
+  free(buf);
   return out;
 }
 
