@@ -34,6 +34,25 @@ def headline_config(E, seed):
                          latency_dist="constant", topology="grid", seed=seed, inbox_capacity=6)
 
 
+def host_cores():
+    """Threads worth starting: the CPUs this process may run on, capped by the container's CPU quota (cgroup v2 cpu.max /
+    v1 cfs quota) — a 256-thread box that grants a pod ten cores' worth of time is a ten-core baseline."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: (t.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()))):
+        try:
+            q, per = parse(open(path).read())
+            if q != "max" and int(q) > 0:
+                n = min(n, max(1, -(-int(q) // int(per))))
+            break
+        except (OSError, ValueError):
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(cfg, seconds):
     """The CPU oracle (a port with identical semantics) on the host cores, for ~`seconds` of wall time on all
     cores and on one core.  Every thread owns its output buffers and calls the C entry point directly in a
@@ -42,7 +61,7 @@ def cpu_baseline(cfg, seconds):
     import numpy as np
     import oracle_lib as O
     lib = O.load()
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     chunk = 16
 
     def worker(tid, budget):
