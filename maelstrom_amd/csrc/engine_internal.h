@@ -46,12 +46,19 @@ struct msim_ctx {
 
 // Host threads one engine context may use for its host-side checkers: the hardware threads divided by the ranks sharing
 // the node (LOCAL_WORLD_SIZE, set by torch.distributed.run), or MSIM_HOST_THREADS if set.
+#include <cstdio>
 #include <cstdlib>
 #include <thread>
 static inline unsigned msim_host_threads() {
   if (const char *e = std::getenv("MSIM_HOST_THREADS")) { const int v = std::atoi(e); if (v > 0) return (unsigned)v; }
   unsigned nt = std::thread::hardware_concurrency();
   if (nt == 0) nt = 1;
+  // a container's CPU quota (cgroup v2 cpu.max = "<quota> <period>"): more runnable threads than granted CPUs only get throttled
+  if (std::FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    long long q = 0, per = 0;
+    if (std::fscanf(f, "%lld %lld", &q, &per) == 2 && q > 0 && per > 0) { const unsigned lim = (unsigned)((q + per - 1) / per); if (lim >= 1 && lim < nt) nt = lim; }
+    std::fclose(f);
+  }
   if (const char *e = std::getenv("LOCAL_WORLD_SIZE")) { const int v = std::atoi(e); if (v > 1) nt = nt / (unsigned)v ? nt / (unsigned)v : 1; }
   return nt;
 }
