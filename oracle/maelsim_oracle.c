@@ -83,6 +83,7 @@ typedef struct {
   struct txn_s *txn;  /* txn-list-append state (txn_nodes.inc) */
   struct svc_s *svc;  /* proxy node + key-value services (svc_nodes.inc) */
   struct hat_s *hat;  /* txn-rw-register highly-available-transactions node (hat_nodes.inc) */
+  u32 *rtrace; u32 n_rtrace, cap_rtrace; /* test hook: what every Raft node did in every round (oracle_raft_schedule) */
   u64 key;
   u32 adj[MAXN][MW];
   /* net (net.clj:79-103) */
@@ -663,6 +664,12 @@ static void poll_endpoint(sim_t *s, u32 e) {
   }
 }
 
+static void rtrace(sim_t *s, u32 node, u32 what) { /* {time, node, message id or 0xFFFFFFFF = an action of the main loop} */
+  if (!s->rtrace) return;
+  if (s->n_rtrace < s->cap_rtrace) { u32 *e = s->rtrace + 3 * (size_t)s->n_rtrace; e[0] = s->T; e[1] = node; e[2] = what; }
+  s->n_rtrace++;
+}
+
 static void run_instance(sim_t *s) {
   u32 N = s->N, E = s->E;
   for (;;) {
@@ -699,11 +706,12 @@ static void run_instance(sim_t *s) {
       int msg_due = s->has_committed[n] && s->deliver_at[n] <= T;
       if (s->raft ? !msg_due : node_timer_time(s, n) <= T) {  /* raft.py's loop takes a message first (raft.py:577-585) */
         if (!s->raft) node_timer(s, n);
-        else if (raft_next_time(s, n) <= T) raft_act(s, n);
+        else if (raft_next_time(s, n) <= T) { rtrace(s, n, 0xFFFFFFFFu); raft_act(s, n); }
       } else if (msg_due) {
         qent q = s->committed[n]; s->has_committed[n] = 0;
         s->st.all_recv++; if (is_client(s, q.src)) s->st.clients_recv++; else s->st.servers_recv++; /* journal :recv */
         jlog(s, 1, q.id, q.type, q.a, q.b, q.src, n);
+        if (s->raft) rtrace(s, n, q.id);
         node_handle(s, n, &q);
         rext_free(q.r);
       }
@@ -1006,4 +1014,21 @@ int oracle_hat_state(const msim_config *cfg, uint64_t instance, msim_op *rows, u
   memcpy(npend, s->hat->npend, s->N * 4);
   sim_free(s);
   return 0;
+}
+
+/* Test hook for the Raft node: runs instance `instance` like oracle_run_instance and also returns, in order, what every node's
+ * main loop did in every round: {time us, node, id of the message it handled, or 0xFFFFFFFF for one of its timer / commit /
+ * apply actions} (raft.py:577-585).  tests/test_raft_reference_replay.py feeds that schedule to the reference's own raft.py.
+ * Returns the number of trace entries (may exceed trace_cap: then only the first trace_cap are stored), or -1. */
+int oracle_raft_schedule(const msim_config *cfg, uint64_t instance, msim_op *rows, uint32_t *payload, msim_net_stats *stats,
+                      msim_inst_meta *meta, msim_event *journal, uint32_t *trace, uint32_t trace_cap) {
+  sim_t *s = sim_new(cfg, instance, rows, payload);
+  if (!s || !s->raft) return -1;
+  if (cfg->journal_capacity && !journal) { sim_free(s); return -1; }
+  s->journal = journal; s->rtrace = trace; s->cap_rtrace = trace_cap;
+  run_instance(s);
+  *stats = s->st; *meta = s->meta;
+  int n = (int)s->n_rtrace;
+  sim_free(s);
+  return n;
 }

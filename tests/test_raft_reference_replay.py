@@ -1,0 +1,204 @@
+"""The oracle's Raft node against the reference's own code: demo/python/raft.py is loaded from /root/reference (this container
+only — the test skips elsewhere), its clock and random source replaced by the simulation's, its stdin / stdout by in-memory
+queues, and the oracle's complete schedule of a run — which node's main loop handled which message or took a timer / commit /
+apply action at which microsecond (oracle_raft_schedule) — is fed to five real RaftNode objects.  Every message they emit
+(votes, append_entries with their entries, acknowledgements, proxied client requests, client replies with their values and
+error codes) must be the message the oracle's node emitted, in order, and every action the oracle scheduled must have been
+something for raft.py to do at that instant.
+
+One line of raft.py is changed on load: the callback closure of replicate_log binds `_ni`, `_entries`, `_node` late, so every
+append_entries acknowledgement is credited to the LAST peer (raft.py:391-410) — demo/ruby/raft.rb, which the
+engine follows, does not have that slip; the three names are bound at definition time here.  Test infrastructure only."""
+import collections
+import ctypes as C
+import fractions
+import json
+import os
+
+import numpy as np
+import pytest
+
+from maelstrom_amd import _abi as A
+from maelstrom_amd import engine as E
+import oracle_lib as O
+
+REF = "/root/reference/demo/python/raft.py"
+needs_reference = pytest.mark.skipif(not os.path.exists(REF), reason="the reference tree is only mounted in the build container")
+ACTION = 0xFFFFFFFF
+
+
+class _Clock:
+    now = 0
+
+    def time(self):
+        return self.now
+
+    def sleep(self, _s):
+        pass
+
+
+class _Random:
+    """random.random() of node n = the oracle's election jitter draw (stream 11, counter per node), as an exact fraction"""
+    def __init__(self, lib, cfg, inst):
+        self.lib, self.cfg, self.inst, self.node, self.ctr = lib, cfg, inst, 0, collections.Counter()
+
+    def random(self):
+        k = self.ctr[self.node]
+        self.ctr[self.node] += 1
+        return fractions.Fraction(self.lib.oracle_draw32(self.cfg.seed, self.inst, 11, (self.node << 32) | k), 1 << 32)
+
+
+class _Stdin:
+    def __init__(self):
+        self.lines = collections.deque()
+
+    def readline(self):
+        return self.lines.popleft() if self.lines else ""
+
+
+def _load_reference(lib, cfg, inst):
+    src = open(REF).read()
+    assert src.rstrip().endswith("RaftNode().main()")
+    src = src.rstrip()[: -len("RaftNode().main()")]
+    late = "                    def handler(res):\n"
+    assert src.count(late) == 1
+    src = src.replace(late, "                    def handler(res, _ni=_ni, _entries=_entries, _node=_node):\n")
+    ns = {"__name__": "reference_raft"}
+    exec(compile(src, REF, "exec"), ns)
+    clock, rnd, stdin = _Clock(), _Random(lib, cfg, inst), _Stdin()
+    ns["time"], ns["random"], ns["log"] = clock, rnd, (lambda *a: None)
+    ns["sys"] = type("S", (), {"stdin": stdin, "stdout": None, "stderr": None})()
+    ns["select"] = type("Sel", (), {"select": staticmethod(lambda r, w, x, t: (r if stdin.lines else [], [], []))})()
+    sent = []
+    ns["Net"].send_msg = lambda self, msg: sent.append(json.loads(json.dumps(msg)))   # a copy, as the wire would make
+    return ns, clock, rnd, stdin, sent
+
+
+def _signature(node):
+    return (node.state, node.current_term, node.voted_for, node.commit_index, node.last_applied, node.leader, node.election_deadline,
+            node.step_down_deadline, node.last_replication, node.log.size())
+
+
+CASES = [dict(latency=0), dict(latency=10), dict(latency=20, latency_dist="exponential", p_loss=0.05),
+         dict(latency=10, nemesis=["partition"], nemesis_interval=3), dict(node_count=3, latency=5, nemesis=["partition"], nemesis_interval=2)]
+
+
+@needs_reference
+@pytest.mark.parametrize("kw", CASES)
+def test_reference_raft_py_emits_what_the_oracle_emits(kw):
+    lib = O.load()
+    base = dict(bin="raft", node_count=5, rate=30, time_limit=20, seed=57, journal_capacity=600000)
+    base.update(kw)
+    cfg = E.test_config("lin-kv", **base)
+    N = cfg.n_nodes
+    for inst in range(2):
+        rows = np.zeros(cfg.max_rows, dtype=O.OP_DT); pay = np.zeros(cfg.max_payload_words, dtype=np.uint32)
+        stats = np.zeros(1, dtype=O.STATS_DT); meta = np.zeros(1, dtype=O.META_DT)
+        journal = np.zeros(cfg.journal_capacity, dtype=O.EVENT_DT)
+        cap = 400000
+        trace = np.zeros((cap, 3), dtype=np.uint32)
+        n_trace = lib.oracle_raft_schedule(C.byref(cfg), inst, rows.ctypes.data_as(C.c_void_p), pay.ctypes.data_as(C.c_void_p), stats.ctypes.data_as(C.c_void_p),
+                                           meta.ctypes.data_as(C.c_void_p), journal.ctypes.data_as(C.c_void_p), trace.ctypes.data_as(C.c_void_p), cap)
+        assert 0 < n_trace <= cap and meta[0]["flags"] == 0 and meta[0]["n_events"] <= cfg.journal_capacity
+        ns, clock, rnd, stdin, sent = _load_reference(lib, cfg, inst)
+        nodes = []
+        for i in range(N):
+            rnd.node = i
+            nd = ns["RaftNode"]()
+            nd.election_timeout, nd.heartbeat_interval, nd.min_replication_interval = 2_000_000, 1_000_000, 50_000   # seconds -> integer us
+            nodes.append(nd)
+        name = lambda e: f"n{e}" if e < N else f"c{e}"
+        out = [collections.deque() for _ in range(N)]     # what each node still has to put on the wire, in order
+        content = {}                                      # message id -> the message as the receiver will parse it
+        events = journal[: meta[0]["n_events"]]
+        jp = 0
+        n_msgs = n_actions = n_client_replies = 0
+
+        def absorb_until(mid):
+            """walk the journal's send events, pairing each with the next message its sender's raft.py produced"""
+            nonlocal jp, n_client_replies
+            while mid not in content:
+                assert jp < len(events), f"message {mid} is never sent"
+                ev = events[jp]; jp += 1
+                msg, a, route = int(ev["msg"]), int(ev["a"]), int(ev["route"])
+                if (msg >> 7) & 1:
+                    continue
+                typ, src, dest, b = A.MSG_TYPES[msg & 0x7F], route & 0xFF, (route >> 8) & 0xFF, route >> 16
+                if src >= N and dest == (src - N) % N and not any(o and o[0]["src"] == name(src) for o in out):
+                    body = {"type": typ, "msg_id": b}      # a client's own request (lin_kv.clj:53-67 encoding of [k v] / [k [v v']])
+                    if typ == "init":
+                        body.update(node_id=name(dest), node_ids=[name(i) for i in range(N)])
+                    else:
+                        body["key"] = a & 0xFF
+                        if typ == "write":
+                            body["value"] = (a >> 8) & 0xFF
+                        if typ == "cas":
+                            body["from"], body["to"] = (a >> 8) & 0xFF, (a >> 16) & 0xFF
+                    content[msg >> 8] = {"src": name(src), "dest": name(dest), "body": body}
+                    continue
+                # emitted by a node: its own message, or a client's request passed on to the leader with :src unchanged
+                owner = src if src < N else next(i for i in range(N) if out[i] and out[i][0]["src"] == name(src))
+                assert out[owner], (typ, src, dest)
+                m = out[owner].popleft()
+                mb = m["body"]
+                assert (m["src"], m["dest"], mb["type"]) == (name(src), name(dest), typ), (m, typ, src, dest)
+                assert (mb.get("in_reply_to", mb.get("msg_id")) & 0xFFFF) == b, (m, b)
+                if dest >= N:                              # a reply to a client: the value read / the error code
+                    assert {"read_ok": mb.get("value"), "error": mb.get("code")}.get(typ, 0) == a, (m, a)
+                    n_client_replies += 1
+                content[msg >> 8] = m
+
+        for t, n, what in trace[:n_trace]:
+            t, n, what = int(t), int(n), int(what)
+            clock.now, rnd.node = t, n
+            node, before = nodes[n], len(sent)
+            if what != ACTION:
+                absorb_until(what)
+                stdin.lines.append(json.dumps(content[what]))
+                assert node.net.process_msg() is True
+                n_msgs += 1
+            else:
+                sig = _signature(node)
+                did = node.step_down_on_timeout() or node.replicate_log() or node.election() or node.advance_commit_index() or node.advance_state_machine()
+                assert did and (_signature(node) != sig or len(sent) > before), (t, n, "the oracle scheduled an action raft.py has no use for", sig)
+                n_actions += 1
+            out[n].extend(sent[before:])
+        while jp < len(events):                            # whatever was sent last and never delivered
+            ev = events[jp]
+            if not (int(ev["msg"]) >> 7) & 1:
+                absorb_until(int(ev["msg"]) >> 8)
+            else:
+                jp += 1
+        assert not any(out), [len(o) for o in out]
+        assert n_msgs > 500 and n_actions > 100 and n_client_replies > 50
+
+
+def run_digests(kw, n_inst=2):
+    """sha256 over everything that was put on the wire in a run (the journal's :send events): what the reference replay above
+    has vouched for."""
+    import hashlib
+    base = dict(bin="raft", node_count=5, rate=30, time_limit=20, seed=57, journal_capacity=600000)
+    base.update(kw)
+    cfg = E.test_config("lin-kv", **base)
+    out = []
+    for inst in range(n_inst):
+        r = O.run(cfg, inst, 1)
+        h = hashlib.sha256()
+        for ev in r.events(0):
+            if not (int(ev["msg"]) >> 7) & 1:
+                h.update(np.array([ev["time_us"], ev["msg"], ev["a"], ev["route"]], dtype=np.uint32).tobytes())
+        out.append(h.hexdigest())
+    return out
+
+
+_GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "raft_replay_digests.json")
+
+
+def test_runs_still_match_the_recorded_reference_replays():
+    """needs no reference tree: the runs whose every message raft.py reproduced (tests/golden/make_golden_raft_replay.py) are
+    still the runs the oracle produces"""
+    gold = json.load(open(_GOLD))
+    assert len(gold) == len(CASES)
+    for i, kw in enumerate(CASES):
+        assert gold[str(i)]["options"] == json.loads(json.dumps(kw))
+        assert run_digests(kw) == gold[str(i)]["digests"], f"case {i}: regenerate with tests/golden/make_golden_raft_replay.py after checking the replay"
