@@ -11,7 +11,14 @@
  *   - the reference docs' exact message-count known-answers KAT-1..KAT-5,
  *   - golden node-transition vectors recorded from the reference's own runnable node programs
  *     (demo/python/echo.py, demo/js/gossip.js, demo/js/crdt_gset.js; tests/golden/make_golden.py),
- *   - checker verdicts (set-full :valid? true) on every emitted history.
+ *   - checker verdicts (set-full :valid? true) on every emitted history,
+ *   - the Raft node: golden transitions from a real demo/python/raft.py process, and whole runs replayed through the
+ *     reference's own RaftNode objects (tests/test_raft_reference_replay.py; digests in tests/golden/raft_replay_digests.json),
+ *   - the transactional node + lin-kv service: golden conversation with real demo/js/single_key_txn.js processes,
+ *   - pn-counter: the reference's checker vectors (pn_counter_test.clj:10-36) and golden transitions from crdt_pn_counter.js,
+ *   - cross-checks by independent transliterations that replay this oracle's own journal: net.clj send!/recv!
+ *     (tests/test_net_semantics.py), client.clj (tests/test_client_semantics.py), service.clj + lin_kv_proxy.rb +
+ *     single_key_txn.clj with real values (tests/services_ref.py), txn_rw_register_hat.clj (tests/hat_ref.py).
  * Everything that comes from un-vendored upstream Jepsen (generator interpreter, partition-package)
  * is restated from its published behaviour and is "parity unpinned" (DESIGN.md §3).
  *
