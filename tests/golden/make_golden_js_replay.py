@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Records tests/golden/js_crdt_replay_digests.json: for every case of tests/test_js_reference_replay.py the real
+demo/js/crdt_gset.js / crdt_pn_counter.js processes must first reproduce the oracle's run message by message (needs node.js and
+/root/reference); then a digest of that run is stored so that the pinned behaviour travels.
+Run from the repository root: python tests/golden/make_golden_js_replay.py"""
+import json
+import os
+import pathlib
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, ".."))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+import test_js_reference_replay as T  # noqa: E402
+
+if __name__ == "__main__":
+    out = {}
+    fn = T.test_reference_js_crdt_processes_print_what_the_oracle_sends
+    for i, (workload, script, kw) in enumerate(T.CASES):
+        with tempfile.TemporaryDirectory() as d:
+            fn(workload, script, kw, pathlib.Path(d))      # raises if a process prints anything else than the oracle sent
+        out[str(i)] = {"workload": workload, "script": script, "options": kw, "digest": T.run_digest(workload, kw)}
+        print(i, workload, kw, out[str(i)]["digest"])
+    with open(os.path.join(HERE, "js_crdt_replay_digests.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)

@@ -1,0 +1,161 @@
+"""The oracle's CRDT nodes against the reference's own JavaScript: real `node demo/js/crdt_gset.js` / `crdt_pn_counter.js`
+processes (from /root/reference — this container only; the test skips elsewhere) are driven over their pipes with the oracle's
+complete network schedule of a run (its journal), and everything they print — add_ok, read_ok with the set / the counter
+value, the replicate messages with the whole state — must be what the oracle's node sent, in order.  The processes' only
+timer (setInterval 5 s, crdt_gset.js:50-58) is taken over by a preload shim and fired when the oracle's node ticks, so the
+run is in virtual time.  The engine follows demo/ruby/g_set.rb for WHEN the first tick happens (at start-up; the JS waits 5 s):
+the shim fires the callback whenever the oracle ticks, the payloads are the processes' own.  Test infrastructure only."""
+import json
+import os
+import select
+import shutil
+import signal
+import subprocess
+
+import numpy as np
+import pytest
+
+from maelstrom_amd import _abi as A
+from maelstrom_amd import engine as E
+import oracle_lib as O
+
+JS = "/root/reference/demo/js"
+needs_reference = pytest.mark.skipif(shutil.which("node") is None or not os.path.exists(JS), reason="needs node.js and the reference tree")
+
+SHIM = """
+const cbs = [];
+global.setInterval = (f, ms) => { cbs.push(f); return cbs.length; };   // virtual time: the harness says when
+process.on('SIGUSR1', () => { for (const f of cbs) f(); });
+"""
+
+
+class Proc:
+    def __init__(self, script, shim):
+        self.p = subprocess.Popen(["node", "-r", shim, os.path.join(JS, script)], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                  stderr=subprocess.DEVNULL, bufsize=0)
+        self.buf, self.ping = b"", 0
+
+    def write(self, msg):
+        self.p.stdin.write((json.dumps(msg) + "\n").encode())
+
+    def readline(self):
+        while b"\n" not in self.buf:
+            r, _, _ = select.select([self.p.stdout], [], [], 10.0)
+            assert r, "the node process printed nothing for 10 s"
+            chunk = os.read(self.p.stdout.fileno(), 65536)
+            assert chunk, "the node process exited"
+            self.buf += chunk
+        line, self.buf = self.buf.split(b"\n", 1)
+        return json.loads(line)
+
+    def barrier(self, me):
+        """everything written so far has been handled once a read from a made-up client is answered"""
+        self.ping += 1
+        self.write({"src": "c999", "dest": me, "body": {"type": "read", "msg_id": 1000000 + self.ping}})
+        m = self.readline()
+        assert m["body"]["type"] == "read_ok" and m["body"]["in_reply_to"] == 1000000 + self.ping
+
+    def tick(self):
+        self.p.send_signal(signal.SIGUSR1)
+
+    def close(self):
+        self.p.kill()
+        self.p.wait()
+
+
+def _bitmap(words):
+    return {w * 32 + b for w, x in enumerate(words) for b in range(32) if (int(x) >> b) & 1}
+
+
+@needs_reference
+@pytest.mark.parametrize("workload,script,kw", [
+    ("g-set", "crdt_gset.js", dict(node_count=5, rate=30, time_limit=12, latency=20, latency_dist="exponential", p_loss=0.05)),
+    ("g-set", "crdt_gset.js", dict(node_count=3, rate=40, time_limit=8)),
+    ("pn-counter", "crdt_pn_counter.js", dict(node_count=5, rate=30, time_limit=12, latency=30, latency_dist="uniform", p_loss=0.1)),
+    ("g-counter", "crdt_pn_counter.js", dict(node_count=3, rate=40, time_limit=8, latency=5)),
+])
+def test_reference_js_crdt_processes_print_what_the_oracle_sends(workload, script, kw, tmp_path):
+    shim = tmp_path / "shim.js"
+    shim.write_text(SHIM)
+    cfg = E.test_config(workload, seed=61, journal_capacity=400000, **kw)
+    N = cfg.n_nodes
+    name = lambda e: f"n{e}" if e < N else f"c{e}"
+    r = O.run(cfg, 0, 1)
+    assert r.meta["flags"][0] == 0 and r.meta["n_events"][0] <= cfg.journal_capacity
+    _, pay = r.history(0)
+    procs = [Proc(script, str(shim)) for _ in range(N)]
+    try:
+        content, owed = {}, [0] * N       # owed[n] = replicate lines process n has printed and the journal has not reached yet
+        n_rep = n_reads = 0
+        for ev in r.events(0):
+            msg, a, route = int(ev["msg"]), int(ev["a"]), int(ev["route"])
+            mid, recv, typ = msg >> 8, (msg >> 7) & 1, A.MSG_TYPES[msg & 0x7F]
+            src, dest, b = route & 0xFF, (route >> 8) & 0xFF, route >> 16
+            if recv:
+                if dest < N:
+                    procs[dest].write(content[mid])
+                continue
+            if src >= N:                                  # a client's request
+                body = {"type": typ, "msg_id": b}
+                if typ == "init":
+                    body.update(node_id=name(dest), node_ids=[name(i) for i in range(N)])
+                elif typ == "add" and workload == "g-set":
+                    body["element"] = a
+                elif typ == "add":
+                    body["delta"] = a - (1 << 32) if a & 0x80000000 else a
+                content[mid] = {"src": name(src), "dest": name(dest), "body": body}
+                continue
+            if typ == "replicate" and owed[src] == 0:     # the oracle's node ticks: so does the process
+                procs[src].barrier(name(src))
+                procs[src].tick()
+                owed[src] = N - 1
+            m = procs[src].readline()
+            mb = m["body"]
+            assert (m["src"], m["dest"], mb["type"]) == (name(src), name(dest), typ), (m, typ, src, dest)
+            if typ == "replicate":
+                owed[src] -= 1
+                n_rep += 1
+            else:
+                assert mb["in_reply_to"] == b
+            if typ == "read_ok":
+                n_reads += 1
+                if workload == "g-set":                   # the payload bitmap of the reply the oracle's node sent
+                    assert set(mb["value"]) == _bitmap(pay[a & 0xFFFFFF:(a & 0xFFFFFF) + (a >> 24)])
+                else:
+                    assert mb["value"] == (a - (1 << 32) if a & 0x80000000 else a)
+            content[mid] = m
+        assert all(o == 0 for o in owed) and n_rep >= 2 * N * (N - 1) and n_reads > 10
+    finally:
+        for p in procs:
+            p.close()
+
+
+CASES = [("g-set", "crdt_gset.js", dict(node_count=5, rate=30, time_limit=12, latency=20, latency_dist="exponential", p_loss=0.05)),
+         ("g-set", "crdt_gset.js", dict(node_count=3, rate=40, time_limit=8)),
+         ("pn-counter", "crdt_pn_counter.js", dict(node_count=5, rate=30, time_limit=12, latency=30, latency_dist="uniform", p_loss=0.1)),
+         ("g-counter", "crdt_pn_counter.js", dict(node_count=3, rate=40, time_limit=8, latency=5))]
+
+
+def run_digest(workload, kw):
+    """sha256 over all :send events and the payload area of the run the processes reproduced"""
+    import hashlib
+    cfg = E.test_config(workload, seed=61, journal_capacity=400000, **kw)
+    r = O.run(cfg, 0, 1)
+    ev = r.events(0)
+    sends = ev[((ev["msg"] >> 7) & 1) == 0]
+    h = hashlib.sha256(np.stack([sends["time_us"], sends["msg"], sends["a"], sends["route"]], axis=1).astype(np.uint32).tobytes())
+    h.update(r.history(0)[1].tobytes())
+    return h.hexdigest()
+
+
+_GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "js_crdt_replay_digests.json")
+
+
+def test_runs_still_match_the_recorded_js_replays():
+    """needs neither node.js nor the reference tree: the runs the real processes reproduced (tests/golden/make_golden_js_replay.py)
+    are still the runs the oracle produces"""
+    gold = json.load(open(_GOLD))
+    assert len(gold) == len(CASES)
+    for i, (workload, _script, kw) in enumerate(CASES):
+        assert gold[str(i)]["workload"] == workload and gold[str(i)]["options"] == json.loads(json.dumps(kw))
+        assert run_digest(workload, kw) == gold[str(i)]["digest"], f"case {i}: regenerate with tests/golden/make_golden_js_replay.py after checking the replay"
