@@ -159,3 +159,42 @@ def test_runs_still_match_the_recorded_js_replays():
     for i, (workload, _script, kw) in enumerate(CASES):
         assert gold[str(i)]["workload"] == workload and gold[str(i)]["options"] == json.loads(json.dumps(kw))
         assert run_digest(workload, kw) == gold[str(i)]["digest"], f"case {i}: regenerate with tests/golden/make_golden_js_replay.py after checking the replay"
+
+
+@needs_reference
+def test_reference_echo_js_process_prints_what_the_oracle_sends(tmp_path):
+    """demo/js/echo.js over a whole run of the echo workload (echo.clj:72-75 payloads), lossy network"""
+    shim = tmp_path / "shim.js"
+    shim.write_text(SHIM)
+    cfg = E.test_config("echo", seed=62, journal_capacity=100000, node_count=2, rate=60, time_limit=8, p_loss=0.1)
+    N = cfg.n_nodes
+    name = lambda e: f"n{e}" if e < N else f"c{e}"
+    r = O.run(cfg, 0, 1)
+    assert r.meta["flags"][0] == 0
+    procs = [Proc("echo.js", str(shim)) for _ in range(N)]
+    try:
+        content, n = {}, 0
+        for ev in r.events(0):
+            msg, a, route = int(ev["msg"]), int(ev["a"]), int(ev["route"])
+            mid, recv, typ = msg >> 8, (msg >> 7) & 1, A.MSG_TYPES[msg & 0x7F]
+            src, dest, b = route & 0xFF, (route >> 8) & 0xFF, route >> 16
+            if recv:
+                if dest < N:
+                    procs[dest].write(content[mid])
+            elif src >= N:
+                body = {"type": typ, "msg_id": b}
+                if typ == "init":
+                    body.update(node_id=name(dest), node_ids=[name(i) for i in range(N)])
+                else:
+                    body["echo"] = f"Please echo {a}"
+                content[mid] = {"src": name(src), "dest": name(dest), "body": body}
+            else:
+                m = procs[src].readline()
+                assert (m["src"], m["dest"], m["body"]["type"], m["body"]["in_reply_to"]) == (name(src), name(dest), typ, b)
+                if typ == "echo_ok":
+                    assert m["body"]["echo"] == f"Please echo {a}"
+                    n += 1
+        assert n > 15   # every lost message parks its worker for the 5 s timeout
+    finally:
+        for p in procs:
+            p.close()
