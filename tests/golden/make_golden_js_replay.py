@@ -22,5 +22,10 @@ if __name__ == "__main__":
             fn(workload, script, kw, pathlib.Path(d))      # raises if a process prints anything else than the oracle sent
         out[str(i)] = {"workload": workload, "script": script, "options": kw, "digest": T.run_digest(workload, kw)}
         print(i, workload, kw, out[str(i)]["digest"])
+    for j, kw in enumerate(T.TXN_CASES):
+        with tempfile.TemporaryDirectory() as d:
+            T.test_reference_single_key_txn_js_processes_print_what_the_oracle_sends(kw, pathlib.Path(d))
+        out[str(len(T.CASES) + j)] = {"workload": "txn-list-append", "script": "single_key_txn.js", "options": kw, "digest": T.run_digest("txn-list-append", kw)}
+        print("txn", j, kw, out[str(len(T.CASES) + j)]["digest"])
     with open(os.path.join(HERE, "js_crdt_replay_digests.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)

@@ -25,6 +25,7 @@ needs_reference = pytest.mark.skipif(shutil.which("node") is None or not os.path
 SHIM = """
 const cbs = [];
 global.setInterval = (f, ms) => { cbs.push(f); return cbs.length; };   // virtual time: the harness says when
+global.setTimeout = (f, ms) => 0;   // node.js' 1 s RPC timeout (node.js:85): never in virtual time — the Clojure node the engine follows has none
 process.on('SIGUSR1', () => { for (const f of cbs) f(); });
 """
 
@@ -136,10 +137,17 @@ CASES = [("g-set", "crdt_gset.js", dict(node_count=5, rate=30, time_limit=12, la
          ("g-counter", "crdt_pn_counter.js", dict(node_count=3, rate=40, time_limit=8, latency=5))]
 
 
+TXN_CASES = [dict(), dict(node_count=3, rate=150, latency=2), dict(latency=15, latency_dist="exponential"),
+             dict(key_count=2, max_txn_length=8, max_writes_per_key=40, rate=120)]
+TXN_BASE = dict(node_count=5, rate=80, time_limit=8, latency=5, seed=63, journal_capacity=300000)
+
+
 def run_digest(workload, kw):
     """sha256 over all :send events and the payload area of the run the processes reproduced"""
     import hashlib
-    cfg = E.test_config(workload, seed=61, journal_capacity=400000, **kw)
+    if workload == "txn-list-append":
+        kw = dict(TXN_BASE, **kw)
+    cfg = E.test_config(workload, **(kw if "seed" in kw else dict(kw, seed=61, journal_capacity=400000)))
     r = O.run(cfg, 0, 1)
     ev = r.events(0)
     sends = ev[((ev["msg"] >> 7) & 1) == 0]
@@ -155,7 +163,11 @@ def test_runs_still_match_the_recorded_js_replays():
     """needs neither node.js nor the reference tree: the runs the real processes reproduced (tests/golden/make_golden_js_replay.py)
     are still the runs the oracle produces"""
     gold = json.load(open(_GOLD))
-    assert len(gold) == len(CASES)
+    assert len(gold) == len(CASES) + len(TXN_CASES)
+    for j, kw in enumerate(TXN_CASES):
+        g = gold[str(len(CASES) + j)]
+        assert g["workload"] == "txn-list-append" and g["options"] == json.loads(json.dumps(kw))
+        assert run_digest("txn-list-append", kw) == g["digest"], f"txn case {j}: regenerate with tests/golden/make_golden_js_replay.py after checking the replay"
     for i, (workload, _script, kw) in enumerate(CASES):
         assert gold[str(i)]["workload"] == workload and gold[str(i)]["options"] == json.loads(json.dumps(kw))
         assert run_digest(workload, kw) == gold[str(i)]["digest"], f"case {i}: regenerate with tests/golden/make_golden_js_replay.py after checking the replay"
@@ -195,6 +207,78 @@ def test_reference_echo_js_process_prints_what_the_oracle_sends(tmp_path):
                     assert m["body"]["echo"] == f"Please echo {a}"
                     n += 1
         assert n > 15   # every lost message parks its worker for the 5 s timeout
+    finally:
+        for p in procs:
+            p.close()
+
+
+@needs_reference
+@pytest.mark.parametrize("kw", [dict(), dict(node_count=3, rate=150, latency=2), dict(latency=15, latency_dist="exponential"),
+                                dict(key_count=2, max_txn_length=8, max_writes_per_key=40, rate=120)])   # = TXN_CASES
+def test_reference_single_key_txn_js_processes_print_what_the_oracle_sends(kw, tmp_path):
+    """txn-list-append: real `node demo/js/single_key_txn.js` processes (the runnable twin of single_key_txn.clj) against a
+    transliteration of service.clj's lin-kv that keeps the REAL database value, driven with the oracle's schedule.  The two
+    known differences between the reference's own twins are mapped, not hidden: JS numbers its RPCs from 0, Clojure (and the
+    engine) from 1; for a missing root JS cas-es from [], Clojure from nil — both create it."""
+    import collections
+    import services_ref as R
+    shim = tmp_path / "shim.js"
+    shim.write_text(SHIM)
+    base = dict(node_count=5, rate=80, time_limit=8, latency=5, seed=63, journal_capacity=300000)
+    base.update(kw)
+    cfg = E.test_config("txn-list-append", **base)
+    N = cfg.n_nodes
+    SVC = 2 * N
+    name = lambda e: f"n{e}" if e < N else ("lin-kv" if e == SVC else f"c{e}")
+    r = O.run(cfg, 0, 1)
+    assert r.meta["flags"][0] == 0 and r.meta["n_events"][0] <= cfg.journal_capacity
+    _, pay = r.history(0)
+    procs = [Proc("single_key_txn.js", str(shim)) for _ in range(N)]
+    svc, svc_out = R.Linearizable(), collections.deque()
+    fname = {":r": "r", ":append": "append"}
+    try:
+        content, n_ok, n_conflict = {}, 0, 0
+        for ev in r.events(0):
+            msg, a, route = int(ev["msg"]), int(ev["a"]), int(ev["route"])
+            mid, recv, typ = msg >> 8, (msg >> 7) & 1, A.MSG_TYPES[msg & 0x7F]
+            src, dest, b = route & 0xFF, (route >> 8) & 0xFF, route >> 16
+            if recv:
+                if dest < N:
+                    procs[dest].write(content[mid])
+                elif dest == SVC:                          # the service handles the node's request with the real value
+                    req = content[mid]
+                    svc_out.append({"src": "lin-kv", "dest": req["src"], "body": dict(svc.handle(req["src"], req["body"], None), in_reply_to=req["body"]["msg_id"])})
+                continue
+            if N <= src < SVC:                            # a client's request
+                body = {"type": typ, "msg_id": b}
+                if typ == "init":
+                    body.update(node_id=name(dest), node_ids=[name(i) for i in range(N)])
+                else:
+                    body["txn"] = [[fname[f], k, v] for f, k, v in E.decode_txn(pay[a & 0xFFFFFF:(a & 0xFFFFFF) + (a >> 24)])]
+                content[mid] = {"src": name(src), "dest": name(dest), "body": body}
+            elif src == SVC:
+                m = svc_out.popleft()
+                assert (m["dest"], m["body"]["type"]) == (name(dest), typ), (m, typ, dest)
+                if typ == "error":
+                    assert m["body"]["code"] == a
+                content[mid] = m
+            else:
+                m = procs[src].readline()
+                mb = m["body"]
+                assert (m["src"], m["dest"], mb["type"]) == (name(src), name(dest), typ), (m, typ, src, dest)
+                if dest == SVC:
+                    assert mb["msg_id"] + 1 == b          # JS counts RPCs from 0, the Clojure node from 1
+                else:
+                    assert mb["in_reply_to"] == b
+                    if typ == "txn_ok":
+                        want = [[fname[f], k, v] for f, k, v in E.decode_txn(pay[a & 0xFFFFFF:(a & 0xFFFFFF) + (a >> 24)])]
+                        assert mb["txn"] == want, (mb["txn"], want)
+                        n_ok += 1
+                    elif typ == "error":
+                        assert mb["code"] == a == 30
+                        n_conflict += 1
+                content[mid] = m
+        assert not svc_out and n_ok > 100 and n_conflict > 0
     finally:
         for p in procs:
             p.close()
