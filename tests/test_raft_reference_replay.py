@@ -56,13 +56,14 @@ class _Stdin:
         return self.lines.popleft() if self.lines else ""
 
 
-def _load_reference(lib, cfg, inst):
+def _load_reference(lib, cfg, inst, patch=True):
     src = open(REF).read()
     assert src.rstrip().endswith("RaftNode().main()")
     src = src.rstrip()[: -len("RaftNode().main()")]
     late = "                    def handler(res):\n"
     assert src.count(late) == 1
-    src = src.replace(late, "                    def handler(res, _ni=_ni, _entries=_entries, _node=_node):\n")
+    if patch:
+        src = src.replace(late, "                    def handler(res, _ni=_ni, _entries=_entries, _node=_node):\n")
     ns = {"__name__": "reference_raft"}
     exec(compile(src, REF, "exec"), ns)
     clock, rnd, stdin = _Clock(), _Random(lib, cfg, inst), _Stdin()
@@ -85,7 +86,7 @@ CASES = [dict(latency=0), dict(latency=10), dict(latency=20, latency_dist="expon
 
 @needs_reference
 @pytest.mark.parametrize("kw", CASES)
-def test_reference_raft_py_emits_what_the_oracle_emits(kw):
+def test_reference_raft_py_emits_what_the_oracle_emits(kw, patch=True):
     lib = O.load()
     base = dict(bin="raft", node_count=5, rate=30, time_limit=20, seed=57, journal_capacity=600000)
     base.update(kw)
@@ -100,7 +101,7 @@ def test_reference_raft_py_emits_what_the_oracle_emits(kw):
         n_trace = lib.oracle_raft_schedule(C.byref(cfg), inst, rows.ctypes.data_as(C.c_void_p), pay.ctypes.data_as(C.c_void_p), stats.ctypes.data_as(C.c_void_p),
                                            meta.ctypes.data_as(C.c_void_p), journal.ctypes.data_as(C.c_void_p), trace.ctypes.data_as(C.c_void_p), cap)
         assert 0 < n_trace <= cap and meta[0]["flags"] == 0 and meta[0]["n_events"] <= cfg.journal_capacity
-        ns, clock, rnd, stdin, sent = _load_reference(lib, cfg, inst)
+        ns, clock, rnd, stdin, sent = _load_reference(lib, cfg, inst, patch)
         nodes = []
         for i in range(N):
             rnd.node = i
@@ -202,3 +203,12 @@ def test_runs_still_match_the_recorded_reference_replays():
     for i, kw in enumerate(CASES):
         assert gold[str(i)]["options"] == json.loads(json.dumps(kw))
         assert run_digests(kw) == gold[str(i)]["digests"], f"case {i}: regenerate with tests/golden/make_golden_raft_replay.py after checking the replay"
+
+
+@needs_reference
+def test_unpatched_raft_py_diverges_in_a_five_node_cluster():
+    """the reference quirk of DESIGN.md §2.4, as a test: raft.py as shipped credits every append_entries acknowledgement to the
+    LAST peer of the loop (late-bound closure, raft.py:391-410), so a 5-node cluster stops behaving like demo/ruby/raft.rb —
+    and like the engine — as soon as acknowledgements matter"""
+    with pytest.raises(AssertionError):
+        test_reference_raft_py_emits_what_the_oracle_emits(dict(latency=10), patch=False)
