@@ -74,6 +74,10 @@ def _bitmap(words):
     ("g-set", "crdt_gset.js", dict(node_count=3, rate=40, time_limit=8)),
     ("pn-counter", "crdt_pn_counter.js", dict(node_count=5, rate=30, time_limit=12, latency=30, latency_dist="uniform", p_loss=0.1)),
     ("g-counter", "crdt_pn_counter.js", dict(node_count=3, rate=40, time_limit=8, latency=5)),
+    # further shapes for the replay only (the recorded digests stay as they are)
+    ("g-set", "crdt_gset.js", dict(node_count=7, rate=40, time_limit=14, latency=40, latency_dist="exponential", nemesis=["partition"], nemesis_interval=2)),
+    ("pn-counter", "crdt_pn_counter.js", dict(node_count=4, concurrency=12, rate=60, time_limit=12, latency=10, nemesis=["partition"], nemesis_interval=3)),
+    ("g-set", "crdt_gset.js", dict(node_count=2, rate=20, time_limit=22, latency=300)),
 ])
 def test_reference_js_crdt_processes_print_what_the_oracle_sends(workload, script, kw, tmp_path):
     shim = tmp_path / "shim.js"

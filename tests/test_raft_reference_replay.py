@@ -84,8 +84,13 @@ CASES = [dict(latency=0), dict(latency=10), dict(latency=20, latency_dist="expon
          dict(latency=10, nemesis=["partition"], nemesis_interval=3), dict(node_count=3, latency=5, nemesis=["partition"], nemesis_interval=2)]
 
 
+# further shapes for the replay only (the recorded digests, which the GPU suite also checks, stay as they are)
+EXTRA_CASES = [dict(latency=30, latency_dist="uniform", p_loss=0.2), dict(latency=40, latency_dist="exponential", nemesis=["partition"], nemesis_interval=1),
+               dict(node_count=7, latency=5, rate=60), dict(latency=300, time_limit=30)]
+
+
 @needs_reference
-@pytest.mark.parametrize("kw", CASES)
+@pytest.mark.parametrize("kw", CASES + EXTRA_CASES)
 def test_reference_raft_py_emits_what_the_oracle_emits(kw, patch=True):
     lib = O.load()
     base = dict(bin="raft", node_count=5, rate=30, time_limit=20, seed=57, journal_capacity=600000)
