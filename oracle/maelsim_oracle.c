@@ -16,8 +16,9 @@
  *     reference's own RaftNode objects (tests/test_raft_reference_replay.py; digests in tests/golden/raft_replay_digests.json),
  *   - the transactional node + lin-kv service: golden conversation with real demo/js/single_key_txn.js processes,
  *   - pn-counter: the reference's checker vectors (pn_counter_test.clj:10-36) and golden transitions from crdt_pn_counter.js,
- *   - g-set / pn-counter / g-counter: whole runs reproduced line by line by real node.js processes of demo/js/crdt_gset.js and
- *     crdt_pn_counter.js (tests/test_js_reference_replay.py; digests in tests/golden/js_crdt_replay_digests.json),
+ *   - g-set / pn-counter / g-counter / echo / txn-list-append / the acknowledged retrying broadcast: whole runs reproduced line by
+ *     line by real node.js processes of demo/js/crdt_gset.js, crdt_pn_counter.js, echo.js, single_key_txn.js and gossip.js (the
+ *     latter with its RPC timers in virtual time; tests/test_js_reference_replay.py, digests in tests/golden/),
  *   - cross-checks by independent transliterations that replay this oracle's own journal: net.clj send!/recv!
  *     (tests/test_net_semantics.py), client.clj (tests/test_client_semantics.py), service.clj + lin_kv_proxy.rb +
  *     single_key_txn.clj with real values (tests/services_ref.py), txn_rw_register_hat.clj (tests/hat_ref.py).

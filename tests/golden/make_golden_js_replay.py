@@ -27,5 +27,11 @@ if __name__ == "__main__":
             T.test_reference_single_key_txn_js_processes_print_what_the_oracle_sends(kw, pathlib.Path(d))
         out[str(len(T.CASES) + j)] = {"workload": "txn-list-append", "script": "single_key_txn.js", "options": kw, "digest": T.run_digest("txn-list-append", kw)}
         print("txn", j, kw, out[str(len(T.CASES) + j)]["digest"])
+    base = len(T.CASES) + len(T.TXN_CASES)
+    for j, kw in enumerate(T.GOSSIP_CASES):
+        with tempfile.TemporaryDirectory() as d:
+            T.test_reference_gossip_js_processes_print_what_the_oracle_sends(kw, pathlib.Path(d))
+        out[str(base + j)] = {"workload": "broadcast", "script": "gossip.js", "options": kw, "digest": T.run_digest("broadcast", kw)}
+        print("gossip", j, kw, out[str(base + j)]["digest"])
     with open(os.path.join(HERE, "js_crdt_replay_digests.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)

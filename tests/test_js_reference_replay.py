@@ -151,6 +151,8 @@ def run_digest(workload, kw):
     import hashlib
     if workload == "txn-list-append":
         kw = dict(TXN_BASE, **kw)
+    if workload == "broadcast":
+        kw = dict(kw, bin="broadcast-ack-retry", seed=64, journal_capacity=600000)
     cfg = E.test_config(workload, **(kw if "seed" in kw else dict(kw, seed=61, journal_capacity=400000)))
     r = O.run(cfg, 0, 1)
     ev = r.events(0)
@@ -167,7 +169,11 @@ def test_runs_still_match_the_recorded_js_replays():
     """needs neither node.js nor the reference tree: the runs the real processes reproduced (tests/golden/make_golden_js_replay.py)
     are still the runs the oracle produces"""
     gold = json.load(open(_GOLD))
-    assert len(gold) == len(CASES) + len(TXN_CASES)
+    assert len(gold) == len(CASES) + len(TXN_CASES) + len(GOSSIP_CASES)
+    for j, kw in enumerate(GOSSIP_CASES):
+        g = gold[str(len(CASES) + len(TXN_CASES) + j)]
+        assert g["workload"] == "broadcast" and g["options"] == json.loads(json.dumps(kw))
+        assert run_digest("broadcast", kw) == g["digest"], f"gossip case {j}: regenerate with tests/golden/make_golden_js_replay.py after checking the replay"
     for j, kw in enumerate(TXN_CASES):
         g = gold[str(len(CASES) + j)]
         assert g["workload"] == "txn-list-append" and g["options"] == json.loads(json.dumps(kw))
@@ -283,6 +289,139 @@ def test_reference_single_key_txn_js_processes_print_what_the_oracle_sends(kw, t
                         n_conflict += 1
                 content[mid] = m
         assert not svc_out and n_ok > 100 and n_conflict > 0
+    finally:
+        for p in procs:
+            p.close()
+
+
+# ---- broadcast with acknowledgements and retries: real demo/js/gossip.js processes in virtual time ----
+CLOCK_SHIM = """
+const fs = require('fs');
+let now = 0, seq = 0, timers = [];
+global.setTimeout = (f, ms) => { timers.push({t: now + ms * 1000, s: seq++, f}); return seq; };   // node.js' 1 s RPC timeout, in virtual us
+global.setInterval = (f, ms) => 0;
+process.on('SIGUSR1', () => {          // the harness moved the clock: run what is due, then say so
+  now = parseInt(fs.readFileSync(process.env.MSIM_CLOCK_FILE, 'utf8'));
+  for (;;) {
+    timers.sort((a, b) => a.t - b.t || a.s - b.s);
+    if (!timers.length || timers[0].t > now) break;
+    timers.shift().f();
+  }
+  setImmediate(() => console.log(JSON.stringify({__clock__: now})));   // after the promise callbacks (the retries) have printed
+});
+"""
+
+
+class ClockedProc(Proc):
+    def __init__(self, script, shim, clock_file):
+        self.clock_file, self.now, self.lines = clock_file, 0, []
+        env = dict(os.environ, MSIM_CLOCK_FILE=clock_file)
+        self.p = subprocess.Popen(["node", "-r", shim, os.path.join(JS, script)], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                  stderr=subprocess.DEVNULL, bufsize=0, env=env)
+        self.buf, self.ping = b"", 0
+
+    def advance(self, t):
+        """virtual time reaches t: timers that are due fire (their output is kept in order), then the marker comes back"""
+        if t == self.now:
+            return
+        with open(self.clock_file, "w") as f:
+            f.write(str(t))
+        self.now = t
+        self.p.send_signal(signal.SIGUSR1)
+        while True:
+            m = Proc.readline(self)
+            if "__clock__" in m:
+                assert m["__clock__"] == t
+                return
+            self.lines.append(m)
+
+    def next_line(self):
+        return self.lines.pop(0) if self.lines else Proc.readline(self)
+
+
+GOSSIP_CASES = [dict(node_count=5, rate=30, time_limit=10, latency=20, latency_dist="exponential", p_loss=0.1),
+                dict(node_count=9, rate=40, time_limit=8, latency=5, nemesis=["partition"], nemesis_interval=2),
+                dict(node_count=5, rate=20, time_limit=10, latency=50, topology="line", p_loss=0.2)]
+
+
+@needs_reference
+@pytest.mark.parametrize("kw", GOSSIP_CASES)
+def test_reference_gossip_js_processes_print_what_the_oracle_sends(kw, tmp_path):
+    """The acknowledged, retrying broadcast node (doc/03-broadcast/02-performance.md:406-441 ≡ demo/js/gossip.js) against real
+    gossip.js processes whose RPC timeouts run in the oracle's virtual time.  Mapped differences: gossip.js gossips first and
+    acknowledges last, the tutorial's final version (which the engine follows) acknowledges first — what a node emits for one
+    input is compared as a set; JS numbers RPCs from 0, the engine from 1.  The shapes keep round trips far below the 1 s
+    retry timeout: beyond that gossip.js ignores a late acknowledgement of a timed-out attempt, the tutorial's node accepts it."""
+    import collections
+    shim = tmp_path / "clock_shim.js"
+    shim.write_text(CLOCK_SHIM)
+    cfg = E.test_config("broadcast", bin="broadcast-ack-retry", seed=64, journal_capacity=600000, **kw)
+    N = cfg.n_nodes
+    name = lambda e: f"n{e}" if e < N else f"c{e}"
+    adj = np.zeros((N, 4), dtype=np.uint32)
+    assert O.load().oracle_topology(cfg.topology, N, adj.ctypes.data) == 0
+    topo = {name(i): [name(j) for j in E.bitmap_to_list(adj[i])] for i in range(N)}
+    r = O.run(cfg, 0, 1)
+    assert r.meta["flags"][0] == 0 and r.meta["n_events"][0] <= cfg.journal_capacity
+    _, pay = r.history(0)
+    procs = [ClockedProc("gossip.js", str(shim), str(tmp_path / f"clock{i}")) for i in range(N)]
+    try:
+        content = {}
+        want = [collections.defaultdict(list) for _ in range(N)]    # key -> ids of the messages the oracle's node emitted for its current input
+        got = [collections.defaultdict(list) for _ in range(N)]     # key -> the lines the process printed for it
+        n_retry = n_gossip = n_reads = 0
+
+        def pair(n):
+            """a printed line and an emitted message with the same key are the same message, whatever their order"""
+            for key in list(want[n]):
+                while want[n][key] and got[n].get(key):
+                    content[want[n][key].pop(0)] = got[n][key].pop(0)
+                if not want[n][key]:
+                    del want[n][key]
+            for key in [k for k, v in got[n].items() if not v]:
+                del got[n][key]
+
+        def settle(n):
+            pair(n)
+            assert not want[n] and not got[n], (n, dict(want[n]), dict(got[n]))
+        for ev in r.events(0):
+            t, msg, a, route = int(ev["time_us"]), int(ev["msg"]), int(ev["a"]), int(ev["route"])
+            mid, recv, typ = msg >> 8, (msg >> 7) & 1, A.MSG_TYPES[msg & 0x7F]
+            src, dest, b = route & 0xFF, (route >> 8) & 0xFF, route >> 16
+            if recv:
+                if dest < N:
+                    settle(dest)
+                    procs[dest].advance(t)
+                    procs[dest].write(content[mid])
+                continue
+            if src >= N:                                  # a client's request
+                body = {"type": typ, "msg_id": b}
+                if typ == "init":
+                    body.update(node_id=name(dest), node_ids=[name(i) for i in range(N)])
+                elif typ == "topology":
+                    body["topology"] = topo
+                elif typ == "broadcast":
+                    body["message"] = a
+                content[mid] = {"src": name(src), "dest": name(dest), "body": body}
+                continue
+            if t != procs[src].now:                       # nothing was delivered to this node now: its retry timers are due
+                settle(src)
+                procs[src].advance(t)
+                n_retry += 1
+            m = procs[src].next_line()
+            mb = m["body"]
+            assert m["src"] == name(src)
+            want[src][(name(dest), typ, a if typ == "broadcast" else None, b)].append(mid)
+            got[src][(m["dest"], mb["type"], mb.get("message"), mb["msg_id"] + 1 if "msg_id" in mb else mb["in_reply_to"] + (1 if m["dest"].startswith("n") else 0))].append(m)   # RPC ids: JS from 0, engine from 1
+            pair(src)
+            if typ == "broadcast":
+                n_gossip += 1
+            if mb["type"] == "read_ok":                   # only one message per read: same line
+                n_reads += 1
+                assert typ == "read_ok" and set(mb["messages"]) == _bitmap(pay[a & 0xFFFFFF:(a & 0xFFFFFF) + (a >> 24)])
+        for n in range(N):
+            settle(n)
+        assert n_gossip > 100 and n_reads > 10 and (n_retry > 5 or not (cfg.p_loss_q32 or cfg.nemesis_mask))
     finally:
         for p in procs:
             p.close()
