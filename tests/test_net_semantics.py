@@ -30,6 +30,8 @@ CASES = [
     ("broadcast", dict(node_count=5, rate=40, time_limit=10, latency=25, latency_dist="uniform", nemesis=["partition"], nemesis_interval=2)),
     ("broadcast", dict(bin="broadcast-ack-retry", node_count=5, rate=30, time_limit=10, latency=30, p_loss=0.1, nemesis=["partition"], nemesis_interval=2)),
     ("broadcast", dict(node_count=25, rate=100, time_limit=5, topology="total")),
+    ("broadcast", dict(node_count=25, rate=100, time_limit=20)),                          # BASELINE configs[1], the headline shape
+    ("broadcast", dict(node_count=25, rate=100, time_limit=10, latency=100, latency_dist="exponential")),   # its latency sweep
     ("txn-rw-register", dict(node_count=3, rate=60, time_limit=8, latency=15, latency_dist="exponential", p_loss=0.05, nemesis=["partition"], nemesis_interval=2)),
     ("txn-list-append", dict(node_count=3, rate=60, time_limit=8, latency=10, latency_dist="uniform", p_loss=0.02)),
     ("lin-kv", dict(bin="lin-kv-proxy", proxy_service="seq-kv", node_count=3, rate=60, time_limit=8, latency=20, latency_dist="exponential")),
@@ -64,14 +66,17 @@ def test_every_delivery_follows_from_sends_rng_and_partitions(workload, kw):
             return src in cur.get(dest, ())
         # events with their poll slot: a round is [client sends][node recvs][node sends][client recvs]; receivers poll after
         # the client sends and after the node sends
-        events, rnd, phase, last_t, loss_on = [], 0, 0, -1, False
+        events, rnd, phase, last_t, last_ep, loss_on = [], 0, 0, -1, -1, False
         for ev in r.events(0):
             msg, route, t = int(ev["msg"]), int(ev["route"]), int(ev["time_us"])
             recv, src, dest = (msg >> 7) & 1, route & 0xFF, (route >> 8) & 0xFF
             kind = (3 if is_client(dest) else 1) if recv else (0 if is_client(src) else 2)
-            if t != last_t or kind < phase:
+            ep = dest if recv else src
+            # a new round: time moved, the phase went backwards, or — inside a phase — the endpoint order did (deliveries run
+            # in node order, one per node; sends in sender order)
+            if t != last_t or kind < phase or (kind == phase and (ep <= last_ep if kind == 1 else ep < last_ep)):
                 rnd += 1
-            phase, last_t = kind, t
+            phase, last_t, last_ep = kind, t, ep
             events.append((t, rnd * 2 + (0 if kind == 0 else 1), msg >> 8, recv, A.MSG_TYPES[msg & 0x7F], src, dest))
         queue = collections.defaultdict(list)          # dest -> [(deadline, id, src, arrival slot, arrival time)]
         free_slot = collections.defaultdict(lambda: (0, 0))   # dest -> (slot, time) of its last delivery
