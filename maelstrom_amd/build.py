@@ -2,31 +2,55 @@
 
     python -m maelstrom_amd.build [--force]
 
-hipcc cross-compiles without a GPU.  The library is the product; the oracle is built separately by
-oracle/Makefile (see __graft_entry__.build)."""
+hipcc cross-compiles without a GPU.  Every source is compiled to its own object (in parallel, rebuilt only when its
+content or a header changed) and the objects are linked into the library.  The library is the product; the oracle is
+built separately by oracle/Makefile (see __graft_entry__.build)."""
+import concurrent.futures as cf
+import hashlib
 import os
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
 OUT = os.path.join(HERE, "libmaelsim.so")
-SOURCES = ["config.cpp", "engine.hip", "checker.hip", "lin_check.cpp", "txn_check.cpp", "pn_check.cpp", "edn.cpp"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
-
+SOURCES = ["config.cpp", "engine.hip", "duo.hip", "raft4.hip", "checker.hip", "lin_check.cpp", "txn_check.cpp", "pn_check.cpp", "edn.cpp",
+           "fressian.cpp", "gather.cpp", "txn_check_dev.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+LINK_LIBS = ["-ldl"]
 
 STAMP = OUT + ".stamp"
 
 
-def _digest():
-    """Content hash of everything the library is built from (mtimes do not survive every copy of the tree)."""
-    import hashlib
+def _headers_digest():
     h = hashlib.sha256(" ".join(FLAGS).encode())
-    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(HERE, "..", "include", "maelsim.h")]
+    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))) + [os.path.join(HERE, "..", "include", "maelsim.h")]
     for d in deps:
         h.update(os.path.basename(d).encode())
         with open(d, "rb") as f:
             h.update(f.read())
+    return h.hexdigest()
+
+
+def _sources():
+    return [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def _src_digest(src, hd):
+    h = hashlib.sha256(hd.encode())
+    with open(os.path.join(CSRC, src), "rb") as f:
+        h.update(f.read())
+    return h.hexdigest()
+
+
+def _digest():
+    """Content hash of everything the library is built from (mtimes do not survive every copy of the tree)."""
+    hd = _headers_digest()
+    h = hashlib.sha256(hd.encode())
+    for s in _sources():
+        h.update(s.encode())
+        h.update(_src_digest(s, hd).encode())
     return h.hexdigest()
 
 
@@ -37,11 +61,30 @@ def _stale():
         return f.read().strip() != _digest()
 
 
+def _compile(src, hd, force, verbose):
+    obj = os.path.join(OBJ, src + ".o")
+    stamp = obj + ".stamp"
+    dg = _src_digest(src, hd)
+    if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read().strip() == dg:
+        return obj
+    cmd = ["hipcc"] + FLAGS + ["-c", "-o", obj, os.path.join(CSRC, src)]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    with open(stamp, "w") as f:
+        f.write(dg)
+    return obj
+
+
 def build(force=False, verbose=True):
     if not force and not _stale():
         return OUT
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = ["hipcc"] + FLAGS + ["-o", OUT] + srcs
+    os.makedirs(OBJ, exist_ok=True)
+    hd = _headers_digest()
+    srcs = _sources()
+    with cf.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(lambda s: _compile(s, hd, force, verbose), srcs))
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + LINK_LIBS
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -1,0 +1,505 @@
+// duo.hip — TWO clusters per wavefront: the headline layout of the simulation kernel.
+//
+// Same hot path as sim_kernel_colo<> (engine.hip): net.clj:189-247 (send!/recv!, per-destination queues ordered by
+// (deadline, id), head-of-line blocking), process.clj:136-166 (one input per node per round), client.clj:41-172 (sync RPC
+// clients), core.clj:67-80 (generator phases) and the fire-and-forget broadcast node (doc/03-broadcast/01-broadcast.md:
+// 525-547, 02-performance.md:61-67 and :22-28) — round for round what DESIGN.md §2 and the CPU oracle specify.
+//
+// Why a second layout.  A 25-node cluster fills 25 of a wavefront's 64 lanes, and everything that is uniform per cluster
+// (time, phase, generator, cursors) was scalar work paid once per cluster and round: the colocated kernel ran at the
+// CU's scalar issue limit.  Here lanes 0-31 simulate one cluster and lanes 32-63 another, and what is
+// uniform per CLUSTER lives in VGPRs (every lane of a half holds the same value): one instruction stream, vector
+// instructions, serves both clusters; a "ballot" is the cluster's 32-bit half of the wave ballot.  Nothing crosses
+// between the halves: the two clusters share the program counter and nothing else.
+//
+// Scope (the host picks this kernel when all of it holds, else the kernels of engine.hip run):
+//   * node program broadcast fire-and-forget (with or without skip-sender), colocated clients (concurrency == n_nodes <= 32);
+//   * constant latency (any mean below the RPC timeouts), no loss, no nemesis, net journal off.
+// Then message ids are unobservable (no per-message RNG draw, no journal, arrival order = id order), a node's queue is a
+// FIFO, no client can time out (an RPC completes within one latency of virtual time), a client's reply is handled by
+// the lane that sent the request, and a round is:
+//   R0  per-cluster time: stay at T while something is due, else jump to the next delivery / scheduler event;
+//   R1  generator (one op) / phase actions                          — GENERAL rounds only
+//   R2  marked clients invoke: the request reaches its own node     — GENERAL rounds only
+//   R3  every node with a due envelope handles it (dedup, fan-out);
+//       COMMIT: receivers PULL the senders' fan-outs with ds_bpermute (one per topology neighbour), append to their
+//       own LDS ring; idle receivers poll (pop the ring head / the pending client request);
+//   R4  completions -> history rows (staged in LDS, 1 KiB coalesced appends)   — GENERAL rounds only
+// A wave-round is GENERAL if either cluster needs it; pure gossip rounds of both clusters take the short body.
+#include <hip/hip_runtime.h>
+#include <type_traits>
+
+#include "wave_common.h"
+
+namespace {
+
+enum { DK_PLAIN = 0, DK_BCAST = 1, DK_READ = 2, DK_READ_FINAL = 3, DK_INIT = 4, DK_TOPO = 5 };  // kind of an envelope (bits 24-26)
+constexpr u32 DUO_STAGE_ROWS = 128u;
+
+struct DuoParams {
+  KParams k;
+  u32 n_inst;        // clusters in this launch (the last wavefront may hold one)
+  u32 R;             // LDS ring entries per node (power of two >= inbox_capacity)
+  u32 S;             // HBM spill entries per node behind the ring (R + S = inbox_capacity + spill_capacity)
+  u32 half_bytes;    // LDS bytes per cluster
+  u32 off_ring, off_seen;  // byte offsets inside a cluster's LDS region
+  u32 deg;           // maximum degree of the topology
+  u32 echoback;      // node program without skip-sender
+  u32 round_limit;
+};
+
+// the cluster's half of a wave ballot
+__device__ __forceinline__ u32 hb(bool pred, bool hi) {
+  const u64 b = __ballot(pred);
+  return hi ? (u32)(b >> 32) : (u32)b;
+}
+// min over the 32 lanes of the caller's half (result uniform per half)
+__device__ __forceinline__ u32 half_min(u32 v, bool hi) {
+  v = min(v, dpp_mov<0xB1, 0xF, 0xF, false>(v, v));   // quad_perm [1,0,3,2]
+  v = min(v, dpp_mov<0x4E, 0xF, 0xF, false>(v, v));   // quad_perm [2,3,0,1]
+  v = min(v, dpp_mov<0x141, 0xF, 0xF, false>(v, v));  // row_half_mirror
+  v = min(v, dpp_mov<0x140, 0xF, 0xF, false>(v, v));  // row_mirror
+  const u32 lo = min(rdlane(v, 0), rdlane(v, 16)), up = min(rdlane(v, 32), rdlane(v, 48));
+  return hi ? up : lo;
+}
+__device__ __forceinline__ u32 bperm(u32 byte_addr, u32 v) { return (u32)__builtin_amdgcn_ds_bpermute((int)byte_addr, (int)v); }
+
+template <bool LAT0, bool DEG4>
+__global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const KParams &p = dp.k;
+  const u32 lane = threadIdx.x, i = lane & 31u;
+  const bool hi = lane >= 32u;
+  const u32 N = p.N, W = p.W, R = dp.R, Rm = dp.R - 1u, S = dp.S;
+  const bool is_node = i < N;
+  const u32 inst_raw = blockIdx.x * 2u + (hi ? 1u : 0u);
+  const bool real = inst_raw < dp.n_inst;
+  const u32 inst = real ? inst_raw : dp.n_inst - 1u;
+  const u64 key = mix64(p.cfg.seed + 0x9E3779B97F4A7C15ull * (p.first_instance + inst + 1));
+  const u32 lt = (1u << i) - 1u;
+  const u32 all_nodes = N >= 32 ? 0xFFFFFFFFu : ((1u << N) - 1u);
+  const u32 max_values = p.cfg.max_values, max_rows = p.cfg.max_rows, max_pay = p.cfg.max_payload_words;
+  const u32 rate = p.cfg.rate_mhz;
+  const u32 lat_us = LAT0 ? 0u : p.cfg.latency_mean_ms * 1000u;
+  // a sender's "src to skip" field never equals 64: without skip-sender every neighbour takes the value
+  const u32 me16 = dp.echoback ? (64u << 16) : (i << 16);
+  const u32 round_limit = dp.round_limit;
+
+  msim_op *const g_rows = p.rows + (size_t)inst * max_rows;
+  u32 *const g_pay = p.payload + (size_t)inst * max_pay;
+  // HBM spill behind the LDS ring: {deadline, envelope} pairs in the node's slice of the spill area
+  uint2 *const my_spill = reinterpret_cast<uint2 *>(reinterpret_cast<uint4 *>(p.scratch + (size_t)inst * p.scratch_words + p.spill_off) +
+                                                    (size_t)(is_node ? i : 0) * p.spill_cap);
+
+  // LDS of one cluster: [row staging][32 rings][N node sets][32 dummy words for the lanes that hold no node]
+  unsigned char *const hmem = smem + (hi ? dp.half_bytes : 0u);
+  uint4 *const stage = reinterpret_cast<uint4 *>(hmem);
+  u32 *const seen = reinterpret_cast<u32 *>(hmem + dp.off_seen);
+  u32 *const my_seen = is_node ? seen + i * W : seen + N * W + i;
+  u32 *const ring32 = reinterpret_cast<u32 *>(hmem + dp.off_ring) + i * R;       // LAT0: the envelope word
+  uint2 *const ring64 = reinterpret_cast<uint2 *>(hmem + dp.off_ring) + i * R;   // else {deadline, envelope}
+
+  for (u32 k = i; k < N * W + 32u; k += 32) seen[k] = 0;
+  __syncthreads();
+
+  const u32 adj = is_node ? topo_adj(p.cfg.topology, N, i) : 0u;
+  const u32 hbase4 = (lane & 32u) << 2;  // byte address of the half's lane 0 for ds_bpermute
+  // DEG4 (every node has <= 4 neighbours, lane 31 holds no node): the neighbours in ascending order as bpermute addresses
+  // (an unused slot points at lane 31, which never publishes) and the constant part of an envelope received from each
+  u32 nbl[4] = {0, 0, 0, 0}, kc[4] = {0, 0, 0, 0};
+  if (DEG4) {
+    u32 rem = adj;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const u32 s = rem ? (u32)__builtin_ctz(rem) : 31u;
+      rem &= rem - 1u;
+      nbl[k] = hbase4 + (s << 2); kc[k] = s << 16;
+    }
+  }
+
+  // ---- per-lane state: node i and its client (u32 throughout: flags are 0 / 1) ----
+  u32 deliver_at = INF;      // INF = recv! holds no envelope (then the queue is empty too: idle receivers poll at once)
+  u32 cm = 0;                // the envelope recv! is sleeping on: value | src << 16 | kind << 24 (src 63 = the node's own client)
+  u32 in_n = 0, head = 0;    // LDS ring
+  u32 sp_n = 0, s_head = 0;  // HBM spill ring (rare)
+  u32 have_creq = 0, creq = 0, creq_t = 0;  // latency > 0: the client's request waits beside the FIFO of server envelopes
+  u32 busy = 0;              // the client has an RPC outstanding
+  u32 n_cl = 0, n_arr = 0, n_rsv = 0, my_flags = 0;  // client RPCs completed, server envelopes arrived / delivered
+  // ---- per-cluster state (uniform within a half) ----
+  u32 T = 0, phase = PH_INIT, cutoff = 0, gen_next = 0, gen_k = 0, next_value = 0, sleep_until = 0;
+  u32 n_rows = 0, n_payload = 0, flags = 0, rounds = 0;
+  u32 alive = real ? 1u : 0u;
+  // when the scheduler next acts (INF: it only waits), and whether every round has to be a GENERAL one until it says otherwise;
+  // both change in GENERAL rounds only
+  u32 sched_at = real ? 0u : INF, force_general = alive;
+
+  auto commit_time = [&](u32 dl) -> u32 {   // recv! took an envelope: (Thread/sleep (long dt)), net.clj:236-238
+    if (LAT0) return T;
+    return dl <= T ? T : T + ((dl - T) / 1000u) * 1000u;
+  };
+  auto ring_store = [&](u32 slot, u32 e, u32 dl) { if (LAT0) ring32[slot] = e; else ring64[slot] = make_uint2(dl, e); };
+  // slow, checked append: ring, then spill; used when a ring may fill up this round
+  auto push_checked = [&](bool got, u32 e, u32 dl) {
+    const bool fit = in_n < R && sp_n == 0;
+    if (got && fit) { ring_store((head + in_n) & Rm, e, dl); in_n++; }
+    if (got && !fit) {
+      if (sp_n >= S) my_flags |= MSIM_FLAG_INBOX_OVERFLOW;
+      else { u32 idx = s_head + sp_n; if (idx >= S) idx -= S; my_spill[idx] = make_uint2(dl, e); sp_n++; }
+    }
+  };
+  // idle receivers poll (net.clj:223-247): the minimum (deadline, id) = the FIFO head, or the client's request if its deadline
+  // (its send time) is earlier; equal deadlines go to the envelope sent first, which is the queued server envelope
+  auto poll = [&]() {
+    const bool idle = deliver_at == INF;
+    if (LAT0) {
+      const bool can = idle && in_n != 0;
+      const u32 e = ring32[head];
+      cm = can ? e : cm; deliver_at = can ? T : deliver_at;
+      head = (head + (can ? 1u : 0u)) & Rm; in_n -= can ? 1u : 0u;
+    } else {
+      const uint2 h = ring64[head];
+      const u32 hx = in_n != 0 ? h.x : INF;
+      const bool take_c = idle && have_creq != 0 && creq_t < hx;
+      const bool take_r = idle && !take_c && in_n != 0;
+      const bool any = take_c || take_r;
+      const u32 ex = take_c ? creq_t : h.x;
+      cm = any ? (take_c ? creq : h.y) : cm;
+      deliver_at = any ? commit_time(ex) : deliver_at;
+      have_creq = take_c ? 0u : have_creq;
+      head = (head + (take_r ? 1u : 0u)) & Rm; in_n -= take_r ? 1u : 0u;
+    }
+    // refill the ring from the spill so that "ring empty" always means "queue empty" (rare)
+    if (__ballot(sp_n != 0 && in_n < R)) {
+      while (sp_n != 0 && in_n < R) {
+        const uint2 e = my_spill[s_head];
+        s_head++; if (s_head >= S) s_head = 0; sp_n--;
+        ring_store((head + in_n) & Rm, e.y, e.x);
+        in_n++;
+      }
+    }
+  };
+  // R3 for a broadcast envelope (gossip or the client's own): dedup against the node's set; returns what the node publishes to
+  // its neighbours: bit 31 | value | src to skip << 16, or 0.  Unconditional read-modify-write of the lane's own set word.
+  auto r3_seen = [&](bool handle) -> u32 {
+    u32 *const wp = reinterpret_cast<u32 *>(reinterpret_cast<unsigned char *>(my_seen) + ((cm >> 3) & 0x1FFCu));   // word (value >> 5)
+    const u32 word = *wp;
+    const u32 bit = 1u << (cm & 31u);
+    const bool isnew = handle && (word & bit) == 0;
+    *wp = word | (isnew ? bit : 0u);
+    return isnew ? (0x80000000u | (cm & 0x3FFFFFu)) : 0u;
+  };
+  // COMMIT of the fan-outs, receiver side: every node pulls what its neighbours publish, in ascending sender order (= id order,
+  // net.clj:197), and appends it to its own queue.  got <=> the neighbour sends and does not skip this node:
+  // z = (x & 0x803F0000) ^ (0x80000000 | me << 16) is > 0 exactly then (negative: not sending; 0: sending, skipping me).
+  auto arrivals = [&](u32 pub) {
+    const u32 dl = T + lat_us;
+    const u32 zk = 0x80000000u | me16;
+    const bool roomy = __builtin_expect(!__ballot((in_n + 4u > R) | (sp_n != 0)), 1);
+    if (DEG4) {
+      const u32 x0 = bperm(nbl[0], pub), x1 = bperm(nbl[1], pub), x2 = bperm(nbl[2], pub), x3 = bperm(nbl[3], pub);
+      const u32 xs[4] = {x0, x1, x2, x3};
+      if (roomy) {   // every ring has room for a full round of arrivals: plain stores at the tail, the count decides what stays
+        const u32 in0 = in_n;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const bool got = (int)((xs[k] & 0x803F0000u) ^ zk) > 0;
+          ring_store((head + in_n) & Rm, (xs[k] & 0xFFFFu) | kc[k], dl);
+          in_n += got ? 1u : 0u;
+        }
+        n_arr += in_n - in0;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const bool got = (int)((xs[k] & 0x803F0000u) ^ zk) > 0;
+          n_arr += got ? 1u : 0u;
+          push_checked(got, (xs[k] & 0xFFFFu) | kc[k], dl);
+        }
+      }
+    } else {
+      u32 rem = adj;
+      for (u32 k = 0; k < dp.deg; k++) {
+        const bool has = rem != 0;
+        const u32 s = has ? (u32)__builtin_ctz(rem) : i;
+        rem &= rem - 1u;
+        const u32 x = bperm(hbase4 + (s << 2), pub);
+        const bool got = has && (int)((x & 0x803F0000u) ^ zk) > 0;
+        n_arr += got ? 1u : 0u;
+        push_checked(got, (x & 0xFFFFu) | (s << 16), dl);
+      }
+    }
+  };
+
+  // ---- a round in which both clusters only gossip ----
+  auto cascade_round = [&]() {
+    const bool due_n = deliver_at <= T;
+    const u32 pub = r3_seen(due_n);
+    deliver_at = due_n ? INF : deliver_at;
+    n_rsv += due_n ? 1u : 0u;
+    if (__ballot(pub != 0)) arrivals(pub);
+    poll();
+  };
+
+  // ---- a round in which a cluster's scheduler acts or a node handles its client's request ----
+  auto general_round = [&]() {
+    u32 inv_row = 0, inv_packed = 0, inv_value = 0;
+    u32 cmp_row = 0, cmp_packed = 0, cmp_value = 0, cmp_len = 0;
+    // ---- R1: scheduler (core.clj:67-80): phase actions, one generated op ----
+    u32 mark = 0, m_kind = 0, m_val = 0;
+    const bool act = alive != 0 && sched_at <= T;
+    if (__ballot(act && phase != PH_MAIN)) {   // rare: db setup, topology, final reads
+      if (act && phase == PH_INIT) { mark = is_node; m_kind = DK_INIT; phase = PH_INIT_WAIT; }
+      else if (act && phase == PH_TOPO) { mark = is_node; m_kind = DK_TOPO; phase = PH_TOPO_WAIT; }
+      else if (act && (phase == PH_SLEEP || phase == PH_FINAL)) { mark = is_node; m_kind = DK_READ_FINAL; phase = PH_FINAL_WAIT; }  // broadcast.clj:240
+    }
+    if (__ballot(act && phase == PH_MAIN)) {
+      const u32 free_mask = all_nodes & ~hb(busy != 0, hi);
+      const bool gen = act && phase == PH_MAIN && rate > 0 && gen_next < cutoff && gen_next <= T && free_mask != 0;
+      // one 64-bit draw per generated op: high word -> stagger, low word -> worker pick / gen/mix
+      const u64 h = draw64(key, S_GEN, gen_k);
+      const u32 r_hi = (u32)(h >> 32), r_lo = (u32)h;
+      const u32 pick = scale32(r_lo, __popc(free_mask));
+      const bool sel = gen && is_node && busy == 0 && (u32)__popc(free_mask & lt) == pick;
+      const bool is_rd = (r_lo & 1u) != 0;
+      const bool ovf = gen && !is_rd && next_value >= max_values;
+      if (ovf) { flags |= MSIM_FLAG_VALUES_OVERFLOW; alive = 0; }
+      mark = sel && !ovf ? 1u : mark;
+      m_kind = gen ? (is_rd ? DK_READ : DK_BCAST) : m_kind;
+      m_val = gen && !is_rd ? next_value : m_val;
+      next_value += gen && !is_rd && !ovf ? 1u : 0u;
+      gen_k += gen ? 1u : 0u;
+      gen_next = gen ? T + __umulhi(r_hi, p.gen_period2_us) : gen_next;
+    }
+    // ---- R2: marked clients invoke; the request reaches this lane's own node (no latency: a client is involved) ----
+    if (__ballot(mark != 0 && alive != 0)) {
+      const bool inv = mark != 0 && alive != 0;
+      busy = inv ? 1u : busy;
+      const bool is_op = inv && m_kind <= DK_READ_FINAL;
+      inv_row = is_op ? 1u : 0u;
+      inv_packed = MSIM_T_INVOKE | ((m_kind == DK_BCAST ? MSIM_F_BROADCAST : MSIM_F_READ) << 2) | ((m_kind == DK_READ_FINAL ? 1u : 0u) << 11) | (i << 12);
+      inv_value = m_kind == DK_BCAST ? m_val : MSIM_NO_VALUE;
+      const u32 e = (m_kind == DK_BCAST ? m_val : 0u) | (63u << 16) | (m_kind << 24);
+      if (LAT0) push_checked(inv, e, T);
+      else {
+        if (inv && have_creq != 0) my_flags |= MSIM_FLAG_INBOX_OVERFLOW;   // cannot happen without client timeouts
+        have_creq = inv ? 1u : have_creq; creq = inv ? e : creq; creq_t = inv ? T : creq_t;
+      }
+      poll();
+    }
+
+    // ---- R3: one input per node: the due envelope ----
+    const bool due_n = alive != 0 && deliver_at <= T;
+    const u32 kind = cm >> 24;
+    const u32 v = cm & 0xFFFFu;
+    const u32 pub = r3_seen(due_n && kind <= DK_BCAST);
+    deliver_at = due_n ? INF : deliver_at;
+    n_rsv += (due_n && kind == DK_PLAIN) ? 1u : 0u;
+    const bool req = due_n && kind != DK_PLAIN;   // a request of this lane's client: handled, answered and completed in this round
+    n_cl += req ? 1u : 0u;
+    busy = req ? 0u : busy;
+    const bool rd = req && (kind == DK_READ || kind == DK_READ_FINAL);
+    cmp_row = (req && kind == DK_BCAST) ? 1u : 0u;
+    cmp_packed = MSIM_T_OK | (MSIM_F_BROADCAST << 2) | (i << 12); cmp_value = v;
+    // read -> read_ok with the whole set: the cluster's lanes copy the node's set LDS -> HBM payload
+    if (__ballot(rd)) {
+      __syncthreads();
+      const u32 rdm = hb(rd, hi);
+      const u32 words = (next_value + 31u) >> 5;
+      const u32 my_rank = __popc(rdm & lt);
+      const bool ok = n_payload + (my_rank + 1u) * words <= max_pay;   // payload_alloc of the oracle, reader by reader
+      const u32 my_off = ok ? n_payload + my_rank * words : 0u;
+      if (rd) {
+        if (!ok) my_flags |= MSIM_FLAG_PAYLOAD_OVERFLOW;
+        cmp_row = 1; cmp_packed = MSIM_T_OK | (MSIM_F_READ << 2) | ((kind == DK_READ_FINAL ? 1u : 0u) << 11) | (i << 12);
+        cmp_value = my_off; cmp_len = words;
+      }
+      const u32 okm = hb(rd && ok, hi);
+      u32 m = okm;
+      while (__ballot(m != 0)) {
+        const bool on = m != 0;
+        const u32 r = on ? (u32)__builtin_ctz(m) : 0u;
+        m &= m - 1u;
+        const u32 r_off = bperm(hbase4 + (r << 2), my_off);
+        for (u32 w = i; __ballot(on && w < words); w += 32)
+          if (on && w < words) g_pay[r_off + w] = seen[r * W + w];
+      }
+      n_payload += __popc(okm) * words;
+    }
+
+    if (__ballot(pub != 0)) arrivals(pub);
+    poll();
+
+    // ---- R4 + history rows: invocations (slot order), then completions (slot order) ----
+    if (__ballot((inv_row | cmp_row) != 0)) {
+      const u32 imask = hb(inv_row != 0, hi), cmask = hb(cmp_row != 0, hi);
+      const u32 ni = __popc(imask), nr = ni + __popc(cmask);
+      const bool ovf = alive != 0 && nr != 0 && n_rows + nr > max_rows;
+      if (ovf) { flags |= MSIM_FLAG_ROWS_OVERFLOW; alive = 0; }
+      const u64 tns = (u64)T * 1000ull;
+      const u32 tlo = (u32)tns, thi = (u32)(tns >> 32);
+      if (inv_row != 0 && !ovf) stage[(n_rows + __popc(imask & lt)) % DUO_STAGE_ROWS] = make_uint4(tlo, thi, inv_packed, inv_value);
+      if (cmp_row != 0 && !ovf) stage[(n_rows + ni + __popc(cmask & lt)) % DUO_STAGE_ROWS] = make_uint4(tlo, thi | (cmp_len << 16), cmp_packed, cmp_value);
+      const u32 new_n = ovf ? n_rows : n_rows + nr;
+      const bool flush = (new_n >> 6) != (n_rows >> 6);   // a 64-row block completed (at most one per round: nr <= 64)
+      if (__ballot(flush)) {
+        __syncthreads();
+        if (flush) {
+          const u32 g0 = (n_rows >> 6) * 64u + i;
+          if (g0 < max_rows) reinterpret_cast<uint4 *>(g_rows)[g0] = stage[g0 % DUO_STAGE_ROWS];
+          if (g0 + 32u < max_rows) reinterpret_cast<uint4 *>(g_rows)[g0 + 32u] = stage[(g0 + 32u) % DUO_STAGE_ROWS];
+        }
+        __syncthreads();
+      }
+      n_rows = new_n;
+    }
+
+    // ---- the scheduler's view for the rounds to come: time-free phase transitions (oracle: sched_resolve), when it
+    //      acts next (sched_due), and whether plain gossip rounds may run meanwhile ----
+    const u32 hbusy = hb(busy != 0, hi);
+    if (__ballot(alive != 0 && (phase != PH_MAIN || !(rate > 0 && gen_next < cutoff) || rounds > round_limit))) {
+      for (;;) {
+        bool ch = false;
+        if (alive != 0) {
+          if (phase == PH_INIT_WAIT && hbusy == 0) { phase = PH_TOPO; ch = true; }
+          if (phase == PH_TOPO_WAIT && hbusy == 0) { phase = PH_MAIN_START; ch = true; }
+          if (phase == PH_MAIN_START) { cutoff = T + p.cfg.time_limit_ms * 1000u; gen_next = T; phase = PH_MAIN; ch = true; }
+          if (phase == PH_MAIN && !(rate > 0 && gen_next < cutoff) && !(rate == 0 && T < cutoff)) { phase = PH_DRAIN; ch = true; }
+          if (phase == PH_DRAIN && hbusy == 0) { phase = PH_SLEEP; sleep_until = T + p.cfg.quiesce_ms * 1000u; ch = true; }
+          if (phase == PH_FINAL_WAIT && hbusy == 0) { phase = PH_DONE; ch = true; }
+        }
+        if (!__ballot(ch)) break;
+      }
+      if (phase == PH_DONE) alive = 0;
+      if (alive != 0 && rounds > round_limit) { flags |= MSIM_FLAG_ROUND_LIMIT; alive = 0; }
+    }
+    const bool gen_live = rate > 0 && gen_next < cutoff;
+    u32 sa = INF;
+    if (phase == PH_MAIN) {
+      if (gen_live && (all_nodes & ~hbusy) != 0) sa = gen_next;
+      if (rate == 0) sa = min(sa, cutoff);
+    } else if (phase == PH_INIT || phase == PH_TOPO || phase == PH_FINAL) sa = T;
+    else if (phase == PH_SLEEP) sa = sleep_until;
+    sched_at = alive != 0 ? sa : INF;
+    force_general = (alive != 0 && !((phase == PH_MAIN && gen_live) || phase == PH_SLEEP)) ? 1u : 0u;
+    if (alive == 0) { deliver_at = INF; in_n = 0; sp_n = 0; have_creq = 0; }   // a finished cluster takes no further part
+  };
+
+  for (;;) {
+    // ---- gossip rounds of both clusters, until one of them needs a GENERAL round ----
+    for (;;) {
+      // R0: the cluster's time: stay at T while something is due, else jump to the next delivery / scheduler event
+      const u32 hdue = hb(deliver_at <= T, hi);
+      const bool idle_h = (alive != 0) & (sched_at > T) & (hdue == 0);
+      bool stuck_any = false;
+      if (__ballot(idle_h)) {
+        const u32 km = min(half_min(deliver_at, hi), sched_at);
+        const bool stuck = idle_h & (km == INF);   // nothing will ever happen (oracle: same flag, the round counts)
+        flags |= stuck ? (u32)MSIM_FLAG_ROUND_LIMIT : 0u;
+        alive = stuck ? 0u : alive; sched_at = stuck ? INF : sched_at; force_general = stuck ? 0u : force_general;
+        rounds += stuck ? 1u : 0u;
+        T = (idle_h & !stuck) ? km : T;
+        stuck_any = __ballot(stuck) != 0;
+      }
+      rounds += alive;
+      const bool due_n = deliver_at <= T;
+      const bool special = due_n & ((cm >> 24) != DK_PLAIN);
+      const bool gen = (alive != 0) & ((force_general != 0) | (sched_at <= T) | (rounds > round_limit) | special);
+      if (__ballot(gen) != 0 || stuck_any) break;   // (a GENERAL round is a superset of a gossip round: harmless for the other cluster)
+      cascade_round();
+    }
+    if (!__ballot(alive != 0)) break;
+    general_round();
+    if (!__ballot(alive != 0)) break;
+  }
+
+  // ---- epilogue: the partial row block, net stats, meta ----
+  __syncthreads();
+  {
+    const u32 g0 = (n_rows >> 6) * 64u + i;
+    if (real && g0 < n_rows) reinterpret_cast<uint4 *>(g_rows)[g0] = stage[g0 % DUO_STAGE_ROWS];
+    if (real && g0 + 32u < n_rows) reinterpret_cast<uint4 *>(g_rows)[g0 + 32u] = stage[(g0 + 32u) % DUO_STAGE_ROWS];
+  }
+  const u32 sc_cl = wave_incl_scan(n_cl), sc_arr = wave_incl_scan(n_arr), sc_rsv = wave_incl_scan(n_rsv);
+  const u32 lo_cl = rdlane(sc_cl, 31), lo_arr = rdlane(sc_arr, 31), lo_rsv = rdlane(sc_rsv, 31);
+  const u32 t_cl = hi ? rdlane(sc_cl, 63) - lo_cl : lo_cl;
+  const u32 t_arr = hi ? rdlane(sc_arr, 63) - lo_arr : lo_arr;
+  const u32 t_rsv = hi ? rdlane(sc_rsv, 63) - lo_rsv : lo_rsv;
+  for (u32 b = 1; b <= MSIM_FLAG_JOURNAL_OVERFLOW; b <<= 1) if (hb((my_flags & b) != 0, hi)) flags |= b;
+  if (real && i == 0) {
+    // every client RPC is a request and a reply, each sent and received once (no loss, no timeouts in this layout)
+    msim_net_stats st;
+    st.clients_send = 2ull * t_cl; st.clients_recv = 2ull * t_cl;
+    st.servers_send = t_arr; st.servers_recv = t_rsv;
+    st.all_send = st.clients_send + st.servers_send; st.all_recv = st.clients_recv + st.servers_recv;
+    p.stats[inst] = st;
+    msim_inst_meta m; m.n_rows = n_rows; m.n_payload_words = n_payload; m.flags = flags; m.n_rounds = rounds;
+    m.n_events = 0; m.reserved[0] = 0; m.reserved[1] = 0; m.reserved[2] = 0;
+    p.meta[inst] = m;
+  }
+}
+
+}  // namespace
+
+// Whether the duo layout simulates this configuration (see the header of this file).
+bool msim_duo_eligible(const msim_config &c) {
+  if (c.node_program != MSIM_NODE_BCAST_FF && c.node_program != MSIM_NODE_BCAST_FF_ECHOBACK) return false;
+  if (c.n_nodes > 32 || c.concurrency != c.n_nodes) return false;
+  if (c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0 || c.nemesis_mask != 0 || c.journal_capacity != 0) return false;
+  // an RPC completes within one latency of virtual time: no client timeout can fire (client.clj:96-103, db.clj:54)
+  if (c.latency_mean_ms >= c.client_timeout_ms || c.latency_mean_ms >= 10000u) return false;
+  if (c.max_values > 65536u) return false;   // a value travels in 16 bits of the envelope word
+  return true;
+}
+
+static uint32_t duo_degree(const msim_config &c) {
+  uint32_t d = 0;
+  for (uint32_t a = 0; a < c.n_nodes; a++) {
+    uint32_t m = 0, n = c.n_nodes;
+    switch (c.topology) {   // same shapes as topo_adj (broadcast.clj:40-185)
+      case MSIM_TOPO_GRID: { uint32_t side = 1; while (side * side < n) side++; const uint32_t i = a / side, j = a % side;
+        m = (j + 1 < side && a + 1 < n) + (j > 0) + (a + side < n) + (i > 0); } break;
+      case MSIM_TOPO_LINE: m = (a + 1 < n) + (a > 0); break;
+      case MSIM_TOPO_TOTAL: m = n - 1; break;
+      default: { const uint32_t b = c.topology == MSIM_TOPO_TREE2 ? 2 : c.topology == MSIM_TOPO_TREE3 ? 3 : 4;
+        m = a > 0; for (uint32_t k = 1; k <= b; k++) m += b * a + k < n; }
+    }
+    if (m > d) d = m;
+  }
+  return d;
+}
+
+// Launches the duo kernel for n clusters on `st`; returns hipErrorInvalidValue if the cluster state does not fit the LDS.
+hipError_t msim_launch_duo(const KParams &kp, uint32_t n, hipStream_t st) {
+  const msim_config &c = kp.cfg;
+  DuoParams dp;
+  dp.k = kp; dp.n_inst = n;
+  const bool lat0 = c.latency_mean_ms == 0;
+  const uint32_t esz = lat0 ? 4u : 8u;
+  const uint32_t cap_tot = c.inbox_capacity + c.spill_capacity;
+  uint32_t R = 8; while (R < c.inbox_capacity) R <<= 1;   // >= 8: room for a round of arrivals on the fast path
+  while (R > 4 && (size_t)32 * R * esz > 4096) R >>= 1;   // keep a cluster's 32 rings within 4 KiB of LDS
+  if (R > cap_tot) { R = 2; while (R * 2 <= cap_tot) R <<= 1; }
+  dp.R = R; dp.S = cap_tot > R ? cap_tot - R : 0;
+  if (dp.S > 2 * c.spill_capacity) return hipErrorInvalidValue;   // the spill area holds 2 x spill_capacity 8-byte entries per node
+  size_t off = DUO_STAGE_ROWS * 16;
+  dp.off_ring = (u32)off; off += (size_t)32 * R * esz;
+  off = (off + 15) & ~(size_t)15;
+  dp.off_seen = (u32)off; off += ((size_t)kp.N * kp.W + 32) * 4;   // + a dummy word per lane
+  off = (off + 15) & ~(size_t)15;
+  dp.half_bytes = (u32)off;
+  dp.deg = duo_degree(c);
+  dp.echoback = c.node_program == MSIM_NODE_BCAST_FF_ECHOBACK;
+  dp.round_limit = (kp.dev_flags & 0x100u) ? 2000000u : ROUND_LIMIT;
+  const size_t lds = 2 * off;
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  const bool deg4 = dp.deg <= 4 && kp.N <= 31;   // (lane 31 must hold no node: unused neighbour slots point at it)
+  const void *fn = lat0 ? (deg4 ? reinterpret_cast<const void *>(&sim_kernel_duo<true, true>) : reinterpret_cast<const void *>(&sim_kernel_duo<true, false>))
+                        : (deg4 ? reinterpret_cast<const void *>(&sim_kernel_duo<false, true>) : reinterpret_cast<const void *>(&sim_kernel_duo<false, false>));
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  const dim3 grid((n + 1) / 2), block(64);
+  if (lat0) { if (deg4) hipLaunchKernelGGL((sim_kernel_duo<true, true>), grid, block, lds, st, dp); else hipLaunchKernelGGL((sim_kernel_duo<true, false>), grid, block, lds, st, dp); }
+  else { if (deg4) hipLaunchKernelGGL((sim_kernel_duo<false, true>), grid, block, lds, st, dp); else hipLaunchKernelGGL((sim_kernel_duo<false, false>), grid, block, lds, st, dp); }
+  return hipGetLastError();
+}

@@ -25,57 +25,12 @@
 #include <new>
 
 #include "engine_internal.h"
+#include "wave_common.h"
 #include "log2_table.h"
 
-#define INF 0xFFFFFFFFu
-#define STAGE_ROWS 128u
-#define CLIENT_INBOX_CAP 2u
-#define ROUND_LIMIT 50000000u
-
-// message types (doc/protocol.md, doc/workloads.md)
-enum { M_INIT = 1, M_INIT_OK, M_TOPOLOGY, M_TOPOLOGY_OK, M_ECHO, M_ECHO_OK, M_BROADCAST, M_BROADCAST_OK,
-       M_READ, M_READ_OK, M_ADD, M_ADD_OK, M_REPLICATE };
-enum { M_GENERATE = 25, M_GENERATE_OK = 26 };  // unique-ids (after the raft and txn types, include/maelsim.h MSIM_M_*)
-// RNG streams
-enum { S_GEN = 1, S_GEN2 = 2, S_LATENCY = 4, S_LOSS = 5,
-       S_NEM_STAGGER = 7, S_NEM_SPEC = 8, S_NEM_SHUFFLE = 9, S_NEM_PICK = 10 };
-enum { PH_INIT, PH_INIT_WAIT, PH_TOPO, PH_TOPO_WAIT, PH_MAIN_START, PH_MAIN, PH_DRAIN, PH_NEM_FINAL,
-       PH_SLEEP, PH_FINAL, PH_FINAL_WAIT, PH_DONE };
-enum { K_NONE = 0, K_INIT, K_TOPO, K_OP };
-
-struct KParams {
-  msim_config cfg;
-  u64 first_instance;
-  msim_op *rows;
-  u32 *payload;
-  msim_net_stats *stats;
-  msim_inst_meta *meta;
-  u32 *scratch;
-  u64 scratch_words;  // per instance
-  uint4 *journal;     // n * journal_capacity events, or null
-  u32 N, C, CS, W;
-  u32 cap_node, spill_cap;
-  u64 spill_off;  // word offset of the spill area inside the per-instance scratch
-  u32 off_inbox, off_seen, off_misc;  // LDS byte offsets
-  u32 gen_period2_us, nem_period2_us;
-  u32 raft_log_cap;   // raft: entries per node log
-  u32 dev_flags;      // developer switches (env MSIM_DEV_FLAGS): 1 = cascade rounds inline, 2 = no lone-operation path
-};
 
 __constant__ u32 d_log2_q24[257];
 
-// ---- RNG (counter-based) ---------------------------------------------------------
-__device__ __host__ __forceinline__ u64 mix64(u64 z) {
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
-__device__ __forceinline__ u64 draw64(u64 key, u32 stream, u64 ctr) {
-  const u64 x = ((u64)stream << 48) | ctr;
-  return mix64(key + x * 0x9E3779B97F4A7C15ull);
-}
-__device__ __forceinline__ u32 draw32(u64 key, u32 stream, u64 ctr) { return (u32)(draw64(key, stream, ctr) >> 32); }
-__device__ __forceinline__ u32 scale32(u32 r, u32 n) { return __umulhi(r, n); }
 
 // -ln(u), u = (r+1)/2^32, Q16, integer only
 __device__ __forceinline__ u32 neg_ln_q16(u32 r) {
@@ -91,41 +46,6 @@ __device__ __forceinline__ u32 neg_ln_q16(u32 r) {
   return (u32)(((u64)d * 2977044472ull) >> 40);
 }
 
-// ---- wave primitives (64 lanes; DPP on gfx950) ---------------------------------------------------
-template <int CTRL, int ROW_MASK, int BANK_MASK, bool BOUND>
-__device__ __forceinline__ u32 dpp_mov(u32 old, u32 src) {
-  return (u32)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, ROW_MASK, BANK_MASK, BOUND);
-}
-__device__ __forceinline__ u32 rdlane(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
-
-// min over the 64 lanes, result uniform
-__device__ __forceinline__ u32 wave_min(u32 v) {
-  v = min(v, dpp_mov<0xB1, 0xF, 0xF, false>(v, v));   // quad_perm [1,0,3,2]
-  v = min(v, dpp_mov<0x4E, 0xF, 0xF, false>(v, v));   // quad_perm [2,3,0,1]
-  v = min(v, dpp_mov<0x141, 0xF, 0xF, false>(v, v));  // row_half_mirror
-  v = min(v, dpp_mov<0x140, 0xF, 0xF, false>(v, v));  // row_mirror
-  return min(min(rdlane(v, 0), rdlane(v, 16)), min(rdlane(v, 32), rdlane(v, 48)));
-}
-// inclusive prefix sum over the 64 lanes
-__device__ __forceinline__ u32 wave_incl_scan(u32 v) {
-  v += dpp_mov<0x111, 0xF, 0xF, true>(0, v);   // row_shr:1
-  v += dpp_mov<0x112, 0xF, 0xF, true>(0, v);   // row_shr:2
-  v += dpp_mov<0x114, 0xF, 0xF, true>(0, v);   // row_shr:4
-  v += dpp_mov<0x118, 0xF, 0xF, true>(0, v);   // row_shr:8
-  v += dpp_mov<0x142, 0xA, 0xF, false>(0, v);  // row_bcast:15 -> rows 1,3
-  v += dpp_mov<0x143, 0xC, 0xF, false>(0, v);  // row_bcast:31 -> rows 2,3
-  return v;
-}
-__device__ __forceinline__ u32 wave_sum(u32 v) { return rdlane(wave_incl_scan(v), 63); }
-// inclusive prefix sum over lanes 0..31 (node lanes); lanes >= 32 hold garbage
-__device__ __forceinline__ u32 scan32(u32 v) {
-  v += dpp_mov<0x111, 0xF, 0xF, true>(0, v);
-  v += dpp_mov<0x112, 0xF, 0xF, true>(0, v);
-  v += dpp_mov<0x114, 0xF, 0xF, true>(0, v);
-  v += dpp_mov<0x118, 0xF, 0xF, true>(0, v);
-  v += dpp_mov<0x142, 0xA, 0xF, false>(0, v);  // row_bcast:15 -> row 1 (and 3)
-  return v;
-}
 // min (deadline, id) over the n envelopes of an HBM spill area.  The scan is latency-bound — with one dependent load per
 // step every queued envelope costs an L2/HBM round trip — so 8 independent loads are in flight per step.
 __device__ __forceinline__ void spill_min(const uint4 *q, u32 n, u64 &bk, u32 &best, bool &hit) {
@@ -155,12 +75,6 @@ __device__ __forceinline__ void merge_snapshot(u32 *mine, const u32 *snap, u32 W
   }
 }
 
-// tells the compiler a value is dead here (freeze of undef): a register that is only meaningful inside a round must not
-// be carried around the round loops as a PHI
-__device__ __forceinline__ void forget(u32 &v) { v = __builtin_nondeterministic_value(v); }
-__device__ __forceinline__ void forget(uint4 &v) { forget(v.x); forget(v.y); forget(v.z); forget(v.w); }
-// value of `v` in lane `l` (per-lane l; every lane must execute this: ds_bpermute_b32)
-__device__ __forceinline__ u32 lane_get(u32 v, u32 l) { return (u32)__builtin_amdgcn_ds_bpermute((int)(l << 2), (int)v); }
 
 // Reference (shuffle) versions, used only by the self-test to validate the DPP encodings on hardware.
 __device__ u32 wave_min_ref(u32 v) { for (int o = 32; o; o >>= 1) v = min(v, (u32)__shfl_xor((int)v, o)); return v; }
@@ -181,31 +95,6 @@ __global__ void wave_selftest_kernel(const u32 *in, u32 *out) {
   out[blockIdx.x * 64 + lane] = bad;
 }
 
-// ---- topologies (broadcast.clj:40-185): adjacency mask of node a, N <= 32 -------------------------
-__device__ __forceinline__ u32 topo_adj(u32 topology, u32 n, u32 a) {
-  u32 m = 0;
-  switch (topology) {
-    case MSIM_TOPO_GRID: {
-      u32 side = 1; while (side * side < n) side++;
-      const u32 i = a / side, j = a % side;
-      if (j + 1 < side && a + 1 < n) m |= 1u << (a + 1);
-      if (j > 0) m |= 1u << (a - 1);
-      if (a + side < n) m |= 1u << (a + side);
-      if (i > 0) m |= 1u << (a - side);
-    } break;
-    case MSIM_TOPO_LINE:
-      if (a + 1 < n) m |= 1u << (a + 1);
-      if (a > 0) m |= 1u << (a - 1);
-      break;
-    case MSIM_TOPO_TOTAL: m = ((n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1)) & ~(1u << a)); break;
-    default: {
-      const u32 b = topology == MSIM_TOPO_TREE2 ? 2 : topology == MSIM_TOPO_TREE3 ? 3 : 4;
-      if (a > 0) m |= 1u << ((a - 1) / b);
-      for (u32 c = 1; c <= b; c++) if (b * a + c < n) m |= 1u << (b * a + c);
-    }
-  }
-  return m;
-}
 
 // =====================================================================================================
 // The simulation kernel: one wavefront = one cluster.  PROG = node program (MSIM_NODE_*), NEM = the
@@ -1045,7 +934,9 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   hipLaunchKernelGGL((sim_kernel_colo<MSIM_NODE_BCAST_FF, false, false, false>), dim3(n), dim3(64), lds, st, kp);
   e = hipGetLastError();
 #else
-  switch (c.node_program) {
+  // the headline layout: two clusters per wavefront (duo.hip); MSIM_DEV_FLAGS bit 9 keeps the one-cluster kernels
+  if (msim_duo_eligible(c) && !(kp.dev_flags & 0x200u)) e = msim_launch_duo(kp, n, st);
+  else switch (c.node_program) {
     case MSIM_NODE_ECHO: e = launch<MSIM_NODE_ECHO>(kp, n, lds, st); break;
     case MSIM_NODE_BCAST_FF: e = launch<MSIM_NODE_BCAST_FF>(kp, n, lds, st); break;
     case MSIM_NODE_BCAST_FF_ECHOBACK: e = launch<MSIM_NODE_BCAST_FF_ECHOBACK>(kp, n, lds, st); break;
