@@ -116,11 +116,17 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
           n_rc++;
         }
       } else {  // echo
-        if (type == MSIM_T_INVOKE) { if (lane == t) { if (hi_slot) my_val1 = value; else my_val = value; } }
-        else if (type == MSIM_T_OK) { if ((hi_slot ? c_rdlane(my_val1, t) : c_rdlane(my_val, t)) != value) errors++; }  // echo.clj:52-60
+        // echo.clj:44-63: every :invoke whose completion is not an :ok carrying the same :echo is an error — a :fail, an
+        // :info (its :value is the request string, (:echo "...") = nil) and an invocation that never completes included
+        if (type == MSIM_T_INVOKE) { if (lane == t) { if (hi_slot) { my_val1 = value; my_inv1 = idx; } else { my_val = value; my_inv = idx; } } }
+        else {
+          if (type != MSIM_T_OK || (hi_slot ? c_rdlane(my_val1, t) : c_rdlane(my_val, t)) != value) errors++;
+          if (lane == t) { if (hi_slot) my_inv1 = NONE; else my_inv = NONE; }
+        }
       }
     }
   }
+  if (!setfull) errors += (u32)__popcll(__ballot(my_inv != NONE)) + (u32)__popcll(__ballot(my_inv1 != NONE));   // invocations left without a completion
   __threadfence_block();
   __syncthreads();
   if (n_rc > p.max_reads) n_rc = p.max_reads;

@@ -53,6 +53,12 @@ __device__ __forceinline__ u32 hb(bool pred, bool hi) {
   const u64 b = __ballot(pred);
   return hi ? (u32)(b >> 32) : (u32)b;
 }
+// true in every lane of a half iff pred holds in some lane of that half; scalar work only (the result is a lane mask in SGPRs)
+__device__ __forceinline__ bool half_any(bool pred) {
+  const u64 b = __ballot(pred);
+  const u32 lo = (u32)b ? 0xFFFFFFFFu : 0u, up = (u32)(b >> 32) ? 0xFFFFFFFFu : 0u;
+  return __builtin_amdgcn_inverse_ballot_w64(((u64)up << 32) | lo);
+}
 // min over the 32 lanes of the caller's half (result uniform per half)
 __device__ __forceinline__ u32 half_min(u32 v, bool hi) {
   v = min(v, dpp_mov<0xB1, 0xF, 0xF, false>(v, v));   // quad_perm [1,0,3,2]
@@ -88,7 +94,7 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
   msim_op *const g_rows = p.rows + (size_t)inst * max_rows;
   u32 *const g_pay = p.payload + (size_t)inst * max_pay;
   // HBM spill behind the LDS ring: {deadline, envelope} pairs in the node's slice of the spill area
-  uint2 *const my_spill = reinterpret_cast<uint2 *>(reinterpret_cast<uint4 *>(p.scratch + (size_t)inst * p.scratch_words + p.spill_off) +
+  u64 *const my_spill = reinterpret_cast<u64 *>(reinterpret_cast<uint4 *>(p.scratch + (size_t)inst * p.scratch_words + p.spill_off) +
                                                     (size_t)(is_node ? i : 0) * p.spill_cap);
 
   // LDS of one cluster: [row staging][32 rings][N node sets][32 dummy words for the lanes that hold no node]
@@ -97,7 +103,7 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
   u32 *const seen = reinterpret_cast<u32 *>(hmem + dp.off_seen);
   u32 *const my_seen = is_node ? seen + i * W : seen + N * W + i;
   u32 *const ring32 = reinterpret_cast<u32 *>(hmem + dp.off_ring) + i * R;       // LAT0: the envelope word
-  uint2 *const ring64 = reinterpret_cast<uint2 *>(hmem + dp.off_ring) + i * R;   // else {deadline, envelope}
+  u64 *const ring64 = reinterpret_cast<u64 *>(hmem + dp.off_ring) + i * R;       // else deadline | envelope << 32
 
   for (u32 k = i; k < N * W + 32u; k += 32) seen[k] = 0;
   __syncthreads();
@@ -133,114 +139,153 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
   // both change in GENERAL rounds only
   u32 sched_at = real ? 0u : INF, force_general = alive;
 
-  auto commit_time = [&](u32 dl) -> u32 {   // recv! took an envelope: (Thread/sleep (long dt)), net.clj:236-238
-    if (LAT0) return T;
-    return dl <= T ? T : T + ((dl - T) / 1000u) * 1000u;
-  };
-  auto ring_store = [&](u32 slot, u32 e, u32 dl) { if (LAT0) ring32[slot] = e; else ring64[slot] = make_uint2(dl, e); };
+  // Two LDS reads are kept one round ahead of their use, so that a round's dependent chain holds one LDS round trip
+  // (the ds_bpermute exchange) instead of three:
+  //   sw = the word of the node's set that cm's value falls in (re-read after every change of cm or of the set);
+  //   nx = the head entry of the ring (valid while in_n != 0; an append to an empty ring sets it from registers).
+  u32 sw = 0;
+  u32 nx = 0, nx_dl = 0;
+  // The helpers below are macros on purpose: as lambdas capturing the state by reference they left the closures (and with
+  // them every captured variable) in scratch memory once the optimizer turned a select of two captured values into a select
+  // of their addresses.
+  // recv! took an envelope: (Thread/sleep (long dt)), net.clj:236-238
+#define DUO_COMMIT_TIME(dl_) (LAT0 ? T : ((dl_) <= T ? T : T + (((dl_) - T) / 1000u) * 1000u))
+#define DUO_RING_STORE(slot_, e_, dl_) do { if (LAT0) ring32[(slot_)] = (e_); else ring64[(slot_)] = (u64)(dl_) | ((u64)(e_) << 32); } while (0)
+#define DUO_SEEN_WORD() (reinterpret_cast<u32 *>(reinterpret_cast<unsigned char *>(my_seen) + ((cm >> 3) & 0x1FFCu)))   /* word (value >> 5) */
   // slow, checked append: ring, then spill; used when a ring may fill up this round
-  auto push_checked = [&](bool got, u32 e, u32 dl) {
-    const bool fit = in_n < R && sp_n == 0;
-    if (got && fit) { ring_store((head + in_n) & Rm, e, dl); in_n++; }
-    if (got && !fit) {
-      if (sp_n >= S) my_flags |= MSIM_FLAG_INBOX_OVERFLOW;
-      else { u32 idx = s_head + sp_n; if (idx >= S) idx -= S; my_spill[idx] = make_uint2(dl, e); sp_n++; }
-    }
-  };
+#define DUO_PUSH_CHECKED(got_, e_, dl_) do {                                                                              \
+    const bool pc_got = (got_); const u32 pc_e = (e_), pc_dl = (dl_);                                                     \
+    const bool pc_fit = (in_n < R) & (sp_n == 0);                                                                         \
+    if (pc_got & pc_fit) {                                                                                                \
+      DUO_RING_STORE((head + in_n) & Rm, pc_e, pc_dl);                                                                    \
+      if (in_n == 0) { nx = pc_e; nx_dl = pc_dl; }                                                                        \
+      in_n++;                                                                                                             \
+    }                                                                                                                     \
+    if (pc_got & !pc_fit) {                                                                                               \
+      if (sp_n >= S) my_flags |= MSIM_FLAG_INBOX_OVERFLOW;                                                                \
+      else { u32 pc_idx = s_head + sp_n; if (pc_idx >= S) pc_idx -= S; my_spill[pc_idx] = (u64)pc_dl | ((u64)pc_e << 32); sp_n++; } \
+    }                                                                                                                     \
+  } while (0)
   // idle receivers poll (net.clj:223-247): the minimum (deadline, id) = the FIFO head, or the client's request if its deadline
-  // (its send time) is earlier; equal deadlines go to the envelope sent first, which is the queued server envelope
-  auto poll = [&]() {
-    const bool idle = deliver_at == INF;
-    if (LAT0) {
-      const bool can = idle && in_n != 0;
-      const u32 e = ring32[head];
-      cm = can ? e : cm; deliver_at = can ? T : deliver_at;
-      head = (head + (can ? 1u : 0u)) & Rm; in_n -= can ? 1u : 0u;
-    } else {
-      const uint2 h = ring64[head];
-      const u32 hx = in_n != 0 ? h.x : INF;
-      const bool take_c = idle && have_creq != 0 && creq_t < hx;
-      const bool take_r = idle && !take_c && in_n != 0;
-      const bool any = take_c || take_r;
-      const u32 ex = take_c ? creq_t : h.x;
-      cm = any ? (take_c ? creq : h.y) : cm;
-      deliver_at = any ? commit_time(ex) : deliver_at;
-      have_creq = take_c ? 0u : have_creq;
-      head = (head + (take_r ? 1u : 0u)) & Rm; in_n -= take_r ? 1u : 0u;
-    }
-    // refill the ring from the spill so that "ring empty" always means "queue empty" (rare)
-    if (__ballot(sp_n != 0 && in_n < R)) {
-      while (sp_n != 0 && in_n < R) {
-        const uint2 e = my_spill[s_head];
-        s_head++; if (s_head >= S) s_head = 0; sp_n--;
-        ring_store((head + in_n) & Rm, e.y, e.x);
-        in_n++;
-      }
-    }
-  };
-  // R3 for a broadcast envelope (gossip or the client's own): dedup against the node's set; returns what the node publishes to
-  // its neighbours: bit 31 | value | src to skip << 16, or 0.  Unconditional read-modify-write of the lane's own set word.
-  auto r3_seen = [&](bool handle) -> u32 {
-    u32 *const wp = reinterpret_cast<u32 *>(reinterpret_cast<unsigned char *>(my_seen) + ((cm >> 3) & 0x1FFCu));   // word (value >> 5)
-    const u32 word = *wp;
-    const u32 bit = 1u << (cm & 31u);
-    const bool isnew = handle && (word & bit) == 0;
-    *wp = word | (isnew ? bit : 0u);
-    return isnew ? (0x80000000u | (cm & 0x3FFFFFu)) : 0u;
-  };
+  // (its send time) is earlier; equal deadlines go to the envelope sent first, which is the queued server envelope.
+  // Ends with the prefetch of the next head and of the set word of the (new) envelope.
+#define DUO_POLL() do {                                                                                                   \
+    const bool pl_idle = deliver_at == INF;                                                                               \
+    if (LAT0) {                                                                                                           \
+      const bool pl_can = pl_idle & (in_n != 0);                                                                          \
+      cm = pl_can ? nx : cm; deliver_at = pl_can ? T : deliver_at;                                                        \
+      head = (head + (pl_can ? 1u : 0u)) & Rm; in_n -= pl_can ? 1u : 0u;                                                  \
+    } else {                                                                                                              \
+      const u32 pl_hx = in_n != 0 ? nx_dl : INF;                                                                          \
+      const bool pl_c = pl_idle & (have_creq != 0) & (creq_t < pl_hx);                                                    \
+      const bool pl_r = pl_idle & !pl_c & (in_n != 0);                                                                    \
+      const u32 pl_ex = pl_c ? creq_t : nx_dl;                                                                            \
+      const u32 pl_e = pl_c ? creq : nx;                                                                                  \
+      const u32 pl_t = DUO_COMMIT_TIME(pl_ex);                                                                            \
+      cm = (pl_c | pl_r) ? pl_e : cm;                                                                                     \
+      deliver_at = (pl_c | pl_r) ? pl_t : deliver_at;                                                                     \
+      have_creq = pl_c ? 0u : have_creq;                                                                                  \
+      head = (head + (pl_r ? 1u : 0u)) & Rm; in_n -= pl_r ? 1u : 0u;                                                      \
+    }                                                                                                                     \
+    if (__ballot(sp_n != 0)) {   /* refill the ring from the spill: "ring empty" always means "queue empty" (rare) */      \
+      while (sp_n != 0 && in_n < R) {                                                                                     \
+        const u64 pl_s = my_spill[s_head];                                                                                \
+        s_head++; if (s_head >= S) s_head = 0; sp_n--;                                                                    \
+        DUO_RING_STORE((head + in_n) & Rm, (u32)(pl_s >> 32), (u32)pl_s);                                                 \
+        in_n++;                                                                                                           \
+      }                                                                                                                   \
+    }                                                                                                                     \
+    if (LAT0) nx = ring32[head]; else { const u64 pl_h = ring64[head]; nx_dl = (u32)pl_h; nx = (u32)(pl_h >> 32); }       \
+    sw = *DUO_SEEN_WORD();                                                                                                \
+  } while (0)
+  // R3 for a broadcast envelope (gossip or the client's own): dedup against the node's set; pub_ = what the node publishes
+  // to its neighbours: bit 31 | value | src to skip << 16, or 0
+#define DUO_R3_SEEN(handle_, pub_) do {                                                                                   \
+    const u32 r3_bit = 1u << (cm & 31u);                                                                                  \
+    const bool r3_new = (handle_) & ((sw & r3_bit) == 0);                                                                 \
+    if (r3_new) *DUO_SEEN_WORD() = sw | r3_bit;                                                                           \
+    pub_ = r3_new ? (0x80000000u | (cm & 0x3FFFFFu)) : 0u;                                                                \
+  } while (0)
   // COMMIT of the fan-outs, receiver side: every node pulls what its neighbours publish, in ascending sender order (= id order,
   // net.clj:197), and appends it to its own queue.  got <=> the neighbour sends and does not skip this node:
   // z = (x & 0x803F0000) ^ (0x80000000 | me << 16) is > 0 exactly then (negative: not sending; 0: sending, skipping me).
-  auto arrivals = [&](u32 pub) {
-    const u32 dl = T + lat_us;
-    const u32 zk = 0x80000000u | me16;
-    const bool roomy = __builtin_expect(!__ballot((in_n + 4u > R) | (sp_n != 0)), 1);
-    if (DEG4) {
-      const u32 x0 = bperm(nbl[0], pub), x1 = bperm(nbl[1], pub), x2 = bperm(nbl[2], pub), x3 = bperm(nbl[3], pub);
-      const u32 xs[4] = {x0, x1, x2, x3};
-      if (roomy) {   // every ring has room for a full round of arrivals: plain stores at the tail, the count decides what stays
-        const u32 in0 = in_n;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const bool got = (int)((xs[k] & 0x803F0000u) ^ zk) > 0;
-          ring_store((head + in_n) & Rm, (xs[k] & 0xFFFFu) | kc[k], dl);
-          in_n += got ? 1u : 0u;
-        }
-        n_arr += in_n - in0;
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const bool got = (int)((xs[k] & 0x803F0000u) ^ zk) > 0;
-          n_arr += got ? 1u : 0u;
-          push_checked(got, (xs[k] & 0xFFFFu) | kc[k], dl);
-        }
+#define DUO_ARRIVALS(pub_) do {                                                                                           \
+    const u32 ar_dl = T + lat_us;                                                                                         \
+    const u32 ar_zk = 0x80000000u | me16;                                                                                 \
+    if (DEG4) {                                                                                                           \
+      const u32 ar_x[4] = {bperm(nbl[0], pub_), bperm(nbl[1], pub_), bperm(nbl[2], pub_), bperm(nbl[3], pub_)};           \
+      if (__builtin_expect(!__ballot((in_n + 4u > R) | (sp_n != 0)), 1)) {                                                \
+        /* every ring has room for a full round of arrivals: plain stores at the tail, the count decides what stays */    \
+        const u32 ar_in0 = in_n;                                                                                          \
+        _Pragma("unroll") for (int ar_k = 0; ar_k < 4; ar_k++) {                                                          \
+          const bool ar_got = (int)((ar_x[ar_k] & 0x803F0000u) ^ ar_zk) > 0;                                              \
+          const u32 ar_e = (ar_x[ar_k] & 0xFFFFu) | kc[ar_k];                                                             \
+          DUO_RING_STORE((head + in_n) & Rm, ar_e, ar_dl);                                                                \
+          const bool ar_first = ar_got & (in_n == 0);                                                                     \
+          nx = ar_first ? ar_e : nx; if (!LAT0) nx_dl = ar_first ? ar_dl : nx_dl;                                         \
+          in_n += ar_got ? 1u : 0u;                                                                                       \
+        }                                                                                                                 \
+        n_arr += in_n - ar_in0;                                                                                           \
+      } else {                                                                                                            \
+        _Pragma("unroll") for (int ar_k = 0; ar_k < 4; ar_k++) {                                                          \
+          const bool ar_got = (int)((ar_x[ar_k] & 0x803F0000u) ^ ar_zk) > 0;                                              \
+          n_arr += ar_got ? 1u : 0u;                                                                                      \
+          DUO_PUSH_CHECKED(ar_got, (ar_x[ar_k] & 0xFFFFu) | kc[ar_k], ar_dl);                                             \
+        }                                                                                                                 \
+      }                                                                                                                   \
+    } else {                                                                                                              \
+      u32 ar_rem = adj;                                                                                                   \
+      for (u32 ar_k = 0; ar_k < dp.deg; ar_k++) {                                                                         \
+        const bool ar_has = ar_rem != 0;                                                                                  \
+        const u32 ar_s = ar_has ? (u32)__builtin_ctz(ar_rem) : i;                                                         \
+        ar_rem &= ar_rem - 1u;                                                                                            \
+        const u32 ar_xx = bperm(hbase4 + (ar_s << 2), pub_);                                                              \
+        const bool ar_got = ar_has & ((int)((ar_xx & 0x803F0000u) ^ ar_zk) > 0);                                          \
+        n_arr += ar_got ? 1u : 0u;                                                                                        \
+        DUO_PUSH_CHECKED(ar_got, (ar_xx & 0xFFFFu) | (ar_s << 16), ar_dl);                                                \
+      }                                                                                                                   \
+    }                                                                                                                     \
+  } while (0)
+
+#ifdef DUO_PROF   // developer build (tools/duo_prof.sh): wave-round counts and cycles of the two round bodies -> meta
+  u64 pf_t0 = __builtin_readcyclecounter(), pf_gen = 0; u32 pf_ngen = 0, pf_nwave = 0;
+#endif
+  for (;;) {
+    // ---- gossip rounds of both clusters, until one of them needs a GENERAL round ----
+    for (;;) {
+#ifdef DUO_PROF
+      pf_nwave++;
+#endif
+      // R0: the cluster's time: stay at T while something is due, else jump to the next delivery / scheduler event
+      const bool idle_h = (alive != 0) & (sched_at > T) & !half_any(deliver_at <= T);
+      bool stuck_any = false;
+      if (__ballot(idle_h)) {
+        const u32 km = min(half_min(deliver_at, hi), sched_at);
+        const bool stuck = idle_h & (km == INF);   // nothing will ever happen (oracle: same flag, the round counts)
+        flags |= stuck ? (u32)MSIM_FLAG_ROUND_LIMIT : 0u;
+        alive = stuck ? 0u : alive; sched_at = stuck ? INF : sched_at; force_general = stuck ? 0u : force_general;
+        rounds += stuck ? 1u : 0u;
+        T = (idle_h & !stuck) ? km : T;
+        stuck_any = __ballot(stuck) != 0;
       }
-    } else {
-      u32 rem = adj;
-      for (u32 k = 0; k < dp.deg; k++) {
-        const bool has = rem != 0;
-        const u32 s = has ? (u32)__builtin_ctz(rem) : i;
-        rem &= rem - 1u;
-        const u32 x = bperm(hbase4 + (s << 2), pub);
-        const bool got = has && (int)((x & 0x803F0000u) ^ zk) > 0;
-        n_arr += got ? 1u : 0u;
-        push_checked(got, (x & 0xFFFFu) | (s << 16), dl);
+      rounds += alive;
+      const bool due_n = deliver_at <= T;
+      const bool special = due_n & ((cm >> 24) != DK_PLAIN);
+      const bool gen = (alive != 0) & ((force_general != 0) | (sched_at <= T) | (rounds > round_limit) | special);
+      if (__ballot(gen) != 0 || stuck_any) break;   // (a GENERAL round is a superset of a gossip round: harmless for the other cluster)
+      {   // ---- a round in which both clusters only gossip ----
+        u32 pub; DUO_R3_SEEN(due_n, pub);
+        deliver_at = due_n ? INF : deliver_at;
+        n_rsv += due_n ? 1u : 0u;
+        if (__ballot(pub != 0)) DUO_ARRIVALS(pub);
+        DUO_POLL();
       }
     }
-  };
-
-  // ---- a round in which both clusters only gossip ----
-  auto cascade_round = [&]() {
-    const bool due_n = deliver_at <= T;
-    const u32 pub = r3_seen(due_n);
-    deliver_at = due_n ? INF : deliver_at;
-    n_rsv += due_n ? 1u : 0u;
-    if (__ballot(pub != 0)) arrivals(pub);
-    poll();
-  };
-
-  // ---- a round in which a cluster's scheduler acts or a node handles its client's request ----
-  auto general_round = [&]() {
+    if (!__ballot(alive != 0)) break;
+#ifdef DUO_PROF
+    const u64 pf_a = __builtin_readcyclecounter();
+#endif
+    {   // ---- a round in which a cluster's scheduler acts or a node handles its client's request ----
     u32 inv_row = 0, inv_packed = 0, inv_value = 0;
     u32 cmp_row = 0, cmp_packed = 0, cmp_value = 0, cmp_len = 0;
     // ---- R1: scheduler (core.clj:67-80): phase actions, one generated op ----
@@ -278,19 +323,22 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
       inv_packed = MSIM_T_INVOKE | ((m_kind == DK_BCAST ? MSIM_F_BROADCAST : MSIM_F_READ) << 2) | ((m_kind == DK_READ_FINAL ? 1u : 0u) << 11) | (i << 12);
       inv_value = m_kind == DK_BCAST ? m_val : MSIM_NO_VALUE;
       const u32 e = (m_kind == DK_BCAST ? m_val : 0u) | (63u << 16) | (m_kind << 24);
-      if (LAT0) push_checked(inv, e, T);
-      else {
+      if (LAT0) {
+        const bool direct = inv & (deliver_at == INF);   // an idle node's recv! takes the request at once (its queue is empty)
+        cm = direct ? e : cm; deliver_at = direct ? T : deliver_at;
+        DUO_PUSH_CHECKED(inv & !direct, e, T);
+      } else {
         if (inv && have_creq != 0) my_flags |= MSIM_FLAG_INBOX_OVERFLOW;   // cannot happen without client timeouts
         have_creq = inv ? 1u : have_creq; creq = inv ? e : creq; creq_t = inv ? T : creq_t;
       }
-      poll();
+      DUO_POLL();
     }
 
     // ---- R3: one input per node: the due envelope ----
     const bool due_n = alive != 0 && deliver_at <= T;
     const u32 kind = cm >> 24;
     const u32 v = cm & 0xFFFFu;
-    const u32 pub = r3_seen(due_n && kind <= DK_BCAST);
+    u32 pub; DUO_R3_SEEN(due_n & (kind <= DK_BCAST), pub);
     deliver_at = due_n ? INF : deliver_at;
     n_rsv += (due_n && kind == DK_PLAIN) ? 1u : 0u;
     const bool req = due_n && kind != DK_PLAIN;   // a request of this lane's client: handled, answered and completed in this round
@@ -325,8 +373,8 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
       n_payload += __popc(okm) * words;
     }
 
-    if (__ballot(pub != 0)) arrivals(pub);
-    poll();
+    if (__ballot(pub != 0)) DUO_ARRIVALS(pub);
+    DUO_POLL();
 
     // ---- R4 + history rows: invocations (slot order), then completions (slot order) ----
     if (__ballot((inv_row | cmp_row) != 0)) {
@@ -381,35 +429,15 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
     sched_at = alive != 0 ? sa : INF;
     force_general = (alive != 0 && !((phase == PH_MAIN && gen_live) || phase == PH_SLEEP)) ? 1u : 0u;
     if (alive == 0) { deliver_at = INF; in_n = 0; sp_n = 0; have_creq = 0; }   // a finished cluster takes no further part
-  };
-
-  for (;;) {
-    // ---- gossip rounds of both clusters, until one of them needs a GENERAL round ----
-    for (;;) {
-      // R0: the cluster's time: stay at T while something is due, else jump to the next delivery / scheduler event
-      const u32 hdue = hb(deliver_at <= T, hi);
-      const bool idle_h = (alive != 0) & (sched_at > T) & (hdue == 0);
-      bool stuck_any = false;
-      if (__ballot(idle_h)) {
-        const u32 km = min(half_min(deliver_at, hi), sched_at);
-        const bool stuck = idle_h & (km == INF);   // nothing will ever happen (oracle: same flag, the round counts)
-        flags |= stuck ? (u32)MSIM_FLAG_ROUND_LIMIT : 0u;
-        alive = stuck ? 0u : alive; sched_at = stuck ? INF : sched_at; force_general = stuck ? 0u : force_general;
-        rounds += stuck ? 1u : 0u;
-        T = (idle_h & !stuck) ? km : T;
-        stuck_any = __ballot(stuck) != 0;
-      }
-      rounds += alive;
-      const bool due_n = deliver_at <= T;
-      const bool special = due_n & ((cm >> 24) != DK_PLAIN);
-      const bool gen = (alive != 0) & ((force_general != 0) | (sched_at <= T) | (rounds > round_limit) | special);
-      if (__ballot(gen) != 0 || stuck_any) break;   // (a GENERAL round is a superset of a gossip round: harmless for the other cluster)
-      cascade_round();
     }
-    if (!__ballot(alive != 0)) break;
-    general_round();
+#ifdef DUO_PROF
+    pf_gen += __builtin_readcyclecounter() - pf_a; pf_ngen++;
+#endif
     if (!__ballot(alive != 0)) break;
   }
+#ifdef DUO_PROF
+  const u64 pf_tot = __builtin_readcyclecounter() - pf_t0;
+#endif
 
   // ---- epilogue: the partial row block, net stats, meta ----
   __syncthreads();
@@ -433,6 +461,9 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
     p.stats[inst] = st;
     msim_inst_meta m; m.n_rows = n_rows; m.n_payload_words = n_payload; m.flags = flags; m.n_rounds = rounds;
     m.n_events = 0; m.reserved[0] = 0; m.reserved[1] = 0; m.reserved[2] = 0;
+#ifdef DUO_PROF
+    m.n_events = pf_ngen; m.reserved[0] = pf_nwave; m.reserved[1] = (u32)(pf_gen >> 6); m.reserved[2] = (u32)(pf_tot >> 6);
+#endif
     p.meta[inst] = m;
   }
 }

@@ -254,13 +254,17 @@ void check_history(Scratch &S, const msim_op *rows, uint32_t n_rows, const uint3
       {
         int prev = -1;  // the latest earlier read of this key
         for (uint32_t e = 0; e < k; e++) { const Mop &p = S.mops[x.mop0 + e]; if (!p.f && p.key == m.key) prev = (int)e; }
-        uint32_t n_app = 0; uint8_t apps[8];
-        for (uint32_t e = prev < 0 ? 0 : (uint32_t)prev + 1; e < k; e++) { const Mop &p = S.mops[x.mop0 + e]; if (p.f && p.key == m.key && n_app < 8) apps[n_app++] = p.val; }
+        const uint32_t e0 = prev < 0 ? 0 : (uint32_t)prev + 1;
+        uint32_t n_app = 0;   // the transaction's own appends to this key since that read (any number: compared in place)
+        for (uint32_t e = e0; e < k; e++) { const Mop &p = S.mops[x.mop0 + e]; if (p.f && p.key == m.key) n_app++; }
         bool ok = true;
+        uint32_t at = 0;      // where the own appends must sit in this read
         if (prev >= 0) {  // must equal the earlier read followed by the appends since
           const Mop &p = S.mops[x.mop0 + (uint32_t)prev];
-          ok = len == (uint32_t)p.len + n_app && std::equal(l, l + p.len, S.bytes.data() + p.off) && std::equal(apps, apps + n_app, l + p.len);
-        } else ok = len >= n_app && std::equal(apps, apps + n_app, l + (len - n_app));  // must end with the own appends
+          ok = len == (uint32_t)p.len + n_app && std::equal(l, l + p.len, S.bytes.data() + p.off);
+          at = p.len;
+        } else { ok = len >= n_app; at = len - n_app; }  // must end with the own appends
+        if (ok) for (uint32_t e = e0, a = 0; e < k; e++) { const Mop &p = S.mops[x.mop0 + e]; if (p.f && p.key == m.key) { if (l[at + a] != p.val) ok = false; a++; } }
         if (!ok) anomalies |= MSIM_ANOMALY_INTERNAL;
       }
       // the externally visible part of the read: without the transaction's own appends at the tail
@@ -322,13 +326,16 @@ void check_history(Scratch &S, const msim_op *rows, uint32_t n_rows, const uint3
 //   * for every v1 -> v2 of that graph: ww writer(v1) -> writer(v2), rw each reader of v1 -> writer(v2);
 //   * only a transaction's external reads (before its own first write of the key) and final writes count; internal
 //     reads must agree with the transaction's own earlier micro-ops (internal); G1a / G1b as for list-append.
-void check_rw(Scratch &S, const msim_op *rows, uint32_t n_rows, const uint32_t *payload, uint32_t n_words, uint32_t flags, uint32_t cm, msim_check_result *out) {
+// Returns false (out->valid = 2, unknown) when a register value is >= 64: the version graphs below hold 64 versions per key
+// (the engine's generator stops at max-writes-per-key <= 63; externally produced histories may not).
+bool check_rw(Scratch &S, const msim_op *rows, uint32_t n_rows, const uint32_t *payload, uint32_t n_words, uint32_t flags, uint32_t cm, msim_check_result *out) {
   uint32_t anomalies = collect(S, rows, n_rows, payload, n_words, true, out), max_key = 0;
   const uint32_t n = (uint32_t)S.txns.size();
   uint32_t max_val = 0;
   for (const Txn &t : S.txns) for (uint32_t k = 0; k < t.n_mops; k++) { const Mop &m = S.mops[t.mop0 + k]; max_key = std::max<uint32_t>(max_key, m.key); max_val = std::max<uint32_t>(max_val, m.val); }
-  const uint32_t stride = max_val < 64 ? 64u : max_val + 1;  // the version graphs below walk versions 0..63 of every key
-  auto kv = [stride](uint32_t k, uint32_t v) { return k * stride + v; };
+  if (max_val >= 64) { out->valid = 2; return false; }
+  constexpr uint32_t stride = 64u;  // the version graphs below walk versions 0..63 of every key
+  auto kv = [](uint32_t k, uint32_t v) { return k * stride + v; };
   S.writer.assign((size_t)(max_key + 1) * stride, -1);
   for (uint32_t t = 0; t < n; t++)
     for (uint32_t k = 0; k < S.txns[t].n_mops; k++) {
@@ -425,6 +432,7 @@ void check_rw(Scratch &S, const msim_op *rows, uint32_t n_rows, const uint32_t *
     }
   }
   finish(S, anomalies, flags, cm, out);
+  return true;
 }
 
 }  // namespace
@@ -449,8 +457,7 @@ extern "C" int msim_check_rw_rows(const msim_op *rows, uint32_t n_rows, const ui
                                   msim_check_result *out) {
   if (!rows || !out || (!payload && n_words) || consistency_model > MSIM_CM_READ_UNCOMMITTED) return MSIM_E_INVALID;
   Scratch S;
-  check_rw(S, rows, n_rows, payload, n_words, 0, consistency_model, out);
-  return MSIM_OK;
+  return check_rw(S, rows, n_rows, payload, n_words, 0, consistency_model, out) ? MSIM_OK : MSIM_E_INVALID;
 }
 
 // Checker threads keep their working storage across calls: a fresh Scratch per call would fault in (and give back) a few MB
@@ -481,8 +488,10 @@ int msim_check_txn_host(msim_ctx *ctx) {
         Scratch &S = *pool[t];
         const bool rw = ctx->cfg.workload == MSIM_WL_TXN_RW_REGISTER;
         for (uint32_t i = t; i < n; i += nt)
-          (rw ? check_rw : check_history)(S, ctx->h_rows + ctx->h_row_off[i], ctx->h_meta[i].n_rows, ctx->h_payload + ctx->h_pay_off[i],
-                                          ctx->h_meta[i].n_payload_words, ctx->h_meta[i].flags, ctx->cfg.consistency_model, &ctx->h_check[i]);
+          if (rw) (void)check_rw(S, ctx->h_rows + ctx->h_row_off[i], ctx->h_meta[i].n_rows, ctx->h_payload + ctx->h_pay_off[i],
+                                 ctx->h_meta[i].n_payload_words, ctx->h_meta[i].flags, ctx->cfg.consistency_model, &ctx->h_check[i]);
+          else check_history(S, ctx->h_rows + ctx->h_row_off[i], ctx->h_meta[i].n_rows, ctx->h_payload + ctx->h_pay_off[i],
+                             ctx->h_meta[i].n_payload_words, ctx->h_meta[i].flags, ctx->cfg.consistency_model, &ctx->h_check[i]);
       });
     for (auto &x : th) x.join();
   }

@@ -74,6 +74,11 @@ def echo_check(history):
             pending[op["process"]] = op
         elif op["process"] in pending:
             inv = pending.pop(op["process"])
-            if op["type"] == ":ok" and inv["value"] != op["value"]["echo"]:
+            # echo.clj:52-60: (not= (:value invoke) (:echo (:value complete))) — an :info / :fail completion carries the request
+            # string as :value, so (:echo ...) is nil and the pair is an error
+            got = op["value"].get("echo") if (op["type"] == ":ok" and isinstance(op["value"], dict)) else None
+            if inv["value"] != got:
                 errs.append((inv["value"], op["value"]))
+    for inv in pending.values():   # pair-index maps an invocation without completion to nil
+        errs.append((inv["value"], None))
     return {"valid?": not errs, "errors": errs}

@@ -74,6 +74,26 @@ def test_echo_checker(lib):
             assert R.echo_check(eng.history(i))["valid?"] and int(res[i]["valid"]) == 1 and int(res[i]["error_count"]) == 0
 
 
+def test_echo_checker_counts_timeouts_and_unfinished_invocations(lib):
+    """workload/echo.clj:44-63 pairs every :invoke with its completion and requires (:echo (:value complete)) to equal the
+    request: a timed-out echo (:info, value = the request string) is an error, and so is an invocation with no completion."""
+    cfg = E.test_config("echo", node_count=3, rate=20, time_limit=8, p_loss=0.2, seed=5)
+    with E.Engine(cfg) as eng:
+        eng.run(0, 8)
+        eng.check()
+        eng.fetch()
+        res = eng.check_results()
+        lossy = 0
+        for i in range(8):
+            h = eng.history(i)
+            ref = R.echo_check(h)
+            infos = sum(1 for op in h if op["type"] == ":info" and op["process"] != ":nemesis")
+            assert len(ref["errors"]) >= infos
+            assert int(res[i]["error_count"]) == len(ref["errors"]) and (int(res[i]["valid"]) == 1) == ref["valid?"]
+            lossy += infos > 0
+        assert lossy >= 4   # 20 % loss over ~160 echoes: timeouts in (nearly) every instance
+
+
 def test_lin_kv_checker_on_raft_histories(lib):
     """msim_check for lin-kv = per-key linearizability (host side, csrc/lin_check.cpp) over the fetched histories."""
     import linearizable_ref as L
