@@ -336,6 +336,35 @@ typedef struct msim_device_buffers {
 } msim_device_buffers;
 int msim_device_buffers_get(msim_ctx *ctx, msim_device_buffers *out);
 
+/* ---- multi-GPU ensemble: variable-length history gather over RCCL / xGMI ------------------------------------
+ * Instances are independent, so an ensemble shards across the GPUs of a node with no collective on the data path: one engine
+ * context per device simulates its block of instances.  The one exchange step is the gather of the emitted histories to a root
+ * rank at the end of a batch — what `jepsen.store` collecting every test's history in one JVM amounts to.  It runs behind this
+ * ABI so that a JVM (or any) host gets it without torch:
+ *     rank 0: msim_comm_unique_id(id);   id reaches every rank through the host's own channel (files, sockets, JVM RPC)
+ *     every rank: msim_comm_init(ctx, id, rank, world);  ...  msim_run(ctx, first_of_rank, n);  msim_gather(ctx, root, &g);
+ * msim_gather = device-side compaction of the used prefix of every slab (the kernels behind msim_fetch) -> ncclAllGather of the
+ * four byte counts per rank -> ONE grouped ncclSend per slab kind from every peer / ncclRecv on the root: what crosses xGMI is
+ * the sum of the history bytes, once.  RCCL is loaded at the first call (librccl.so, dlopen): hosts that never gather need not
+ * have it.  With world == 1 (or without msim_comm_init) the gather is the compaction alone. */
+#define MSIM_COMM_ID_BYTES 128
+typedef struct msim_gathered {
+  /* on the root: device buffers owned by ctx (valid until the next msim_gather / msim_destroy), every rank's part in rank order,
+   * instances in run order inside a rank; NULL on the other ranks */
+  void *rows;      /* msim_op x total rows            */
+  void *payload;   /* u32 x total payload words       */
+  void *meta;      /* msim_inst_meta x n_instances    */
+  void *stats;     /* msim_net_stats x n_instances    */
+  uint64_t rows_bytes, payload_bytes, meta_bytes, stats_bytes;
+  uint64_t bytes_received;   /* bytes that crossed the links into the root (0 on the other ranks and at world == 1) */
+  uint32_t n_instances;      /* over all ranks */
+  uint32_t world, rank;
+  float ms;                  /* compaction + exchange on this rank, HIP events on the engine's stream */
+} msim_gathered;
+int msim_comm_unique_id(unsigned char id[MSIM_COMM_ID_BYTES]);
+int msim_comm_init(msim_ctx *ctx, const unsigned char id[MSIM_COMM_ID_BYTES], int rank, int world);
+int msim_gather(msim_ctx *ctx, int root, msim_gathered *out);
+
 /* Kernel time of the last msim_run in milliseconds, measured with HIP events on the engine's stream. */
 int msim_last_kernel_ms(msim_ctx *ctx, float *sim_ms, float *check_ms);
 

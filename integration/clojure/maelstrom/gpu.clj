@@ -2,8 +2,14 @@
   "Glue a maintainer would add next to maelstrom.core: runs an ensemble of built-in-node tests on the
   MI355X engine (libmaelsim.so through maelstrom.gpu.Native, integration/jni/maelsim_jni.c) and hands
   each history to the UNCHANGED workload checker, exactly where jepsen.core/run! would
-  (core.clj:91-100).  Not executable in the build image (no JVM); shown for the boundary."
-  (:require [jepsen [checker :as checker] [history :as h]]
+  (core.clj:91-100).  Not executable in the build image (no JVM); shown for the boundary.
+
+  The history crosses as history.edn text (Native/historyEdn = msim_history_edn_rows): one op map per line with the
+  reference's :value shapes for EVERY workload (echo maps, read vectors, lin-kv independent tuples, txn micro-op
+  vectors, counter longs, flake ids, nemesis grudges), so this side needs no per-workload row decoder."
+  (:require [clojure.edn :as edn]
+            [clojure.string :as str]
+            [jepsen [checker :as checker] [history :as h]]
             [maelstrom.core :as core])
   (:import (maelstrom.gpu Native)
            (java.nio ByteBuffer ByteOrder)))
@@ -15,42 +21,62 @@
                     "builtin:raft" 6 "builtin:single-key-txn" 7 "builtin:pn-counter" 8 "builtin:flake-ids" 9 "builtin:lin-kv-proxy" 10
                     "builtin:txn-rw-register-hat" 11})
 (def topologies {:grid 0 :line 1 :total 2 :tree 3 :tree2 3 :tree3 4 :tree4 5})
-(def fs [:echo :broadcast :read :add :start-partition :stop-partition])
-(def types [:invoke :ok :fail :info])
+(def latency-dists {:constant 0 :uniform 1 :exponential 2})
+(def services {"lin-kv" 0 "seq-kv" 1 "lww-kv" 2})
+(def consistency-models {:strict-serializable 0 :serializable 1 :snapshot-isolation 2 :read-committed 3 :read-uncommitted 4})
 
-(defn opts->fields
-  "core.clj:136-229 option map -> the 16 leading u32 fields of msim_config."
-  [{:keys [workload bin nodes concurrency rate time-limit latency nemesis nemesis-interval topology]}]
-  (int-array [0 0 (workloads workload) (node-programs bin) (count nodes) (or concurrency (count nodes))
-              (long (* 1000 rate)) (* 1000 time-limit) (:mean latency) ({:constant 0 :uniform 1 :exponential 2} (:dist latency))
-              0 (topologies topology) (if (:partition nemesis) 1 0) (long (* 1000 nemesis-interval)) 5000 10000]))
+; byte offsets of the msim_config fields (include/maelsim.h; checked against the header by tests/test_jni_stub.py)
+(def config-size 120)
+(def config-offsets
+  {:struct-size 0 :abi-version 4 :workload 8 :node-program 12 :n-nodes 16 :concurrency 20 :rate-mhz 24 :time-limit-ms 28
+   :latency-mean-ms 32 :latency-dist 36 :p-loss-q32 40 :topology 44 :nemesis-mask 48 :nemesis-interval-ms 52
+   :client-timeout-ms 56 :quiesce-ms 60 :seed 64 :max-values 72 :max-rows 76 :max-payload-words 80 :inbox-capacity 84
+   :spill-capacity 88 :journal-capacity 92 :key-count 96 :max-txn-length 100 :max-writes-per-key 104 :proxy-service 108
+   :consistency-model 112 :replication-words 116})
 
-(defn decode-op
-  "16-byte row -> Jepsen op map (SURVEY.md §8b history surface)."
-  [^ByteBuffer rows ^ByteBuffer payload i]
-  (let [tl (.getLong rows (* 16 i)) packed (.getInt rows (+ 8 (* 16 i))) value (.getInt rows (+ 12 (* 16 i)))
-        len (bit-and (unsigned-bit-shift-right tl 48) 0xffff)
-        f (fs (bit-and (bit-shift-right packed 2) 31))
-        process (unsigned-bit-shift-right packed 12)]
-    (cond-> {:index i :time (bit-and tl 0xffffffffffff) :type (types (bit-and packed 3)) :f f
-             :process (if (= process 0xfffff) :nemesis process)
-             :value (if (and (= f :read) (pos? len))
-                      (vec (for [w (range len) b (range 32)
-                                 :when (bit-test (.getInt payload (* 4 (+ value w))) b)] (+ (* 32 w) b)))
-                      (when (not= value -1) value))}
-      (= 1 (bit-and (bit-shift-right packed 7) 15)) (assoc :error :net-timeout)
-      (bit-test packed 11) (assoc :final? true))))
+(defn opts->config
+  "core.clj:136-229 option map -> msim_config bytes: the engine's defaults for the workload (Native/configDefaults =
+  msim_config_defaults), then every option the CLI carries."
+  ^bytes [{:keys [workload bin nodes concurrency rate time-limit latency nemesis nemesis-interval topology
+                  key-count max-txn-length max-writes-per-key consistency-models service journal-capacity]} seed]
+  (let [bytes (Native/configDefaults (workloads workload) (count nodes))
+        buf   (doto (ByteBuffer/wrap bytes) (.order ByteOrder/LITTLE_ENDIAN))
+        put!  (fn [k v] (when (some? v) (.putInt buf (config-offsets k) (unchecked-int v))))]
+    (assert (= config-size (alength bytes)))
+    (put! :node-program (node-programs bin))
+    (put! :concurrency concurrency)
+    (put! :rate-mhz (long (* 1000 rate)))
+    (put! :time-limit-ms (* 1000 time-limit))
+    (put! :latency-mean-ms (:mean latency))
+    (put! :latency-dist (latency-dists (:dist latency)))
+    (put! :topology (topologies topology))
+    (put! :nemesis-mask (if (:partition nemesis) 1 0))
+    (put! :nemesis-interval-ms (long (* 1000 nemesis-interval)))
+    (put! :key-count key-count)
+    (put! :max-txn-length max-txn-length)
+    (put! :max-writes-per-key max-writes-per-key)
+    (put! :consistency-model (some-> consistency-models first consistency-models))
+    (put! :proxy-service (services service))
+    (put! :journal-capacity journal-capacity)
+    (.putLong buf (config-offsets :seed) seed)
+    bytes))
+
+(defn parse-history
+  "history.edn text (one op map per line) -> jepsen.history"
+  [^String text]
+  (->> (str/split-lines text)
+       (remove str/blank?)
+       (mapv edn/read-string)
+       h/history))
 
 (defn run-ensemble
   "Runs n seeded instances of the test described by CLI `opts`; returns one checker result per instance."
   [opts seed n]
   (let [test (core/maelstrom-test opts)
-        ctx  (Native/create (opts->fields opts) seed 0)]
+        ctx  (Native/create (opts->config opts seed) 0)]
     (try
       (Native/run ctx 0 n)
       (vec (for [i (range n)]
-             (let [[^ByteBuffer rows ^ByteBuffer payload] (Native/history ctx i)
-                   _ (.order rows ByteOrder/LITTLE_ENDIAN) _ (.order payload ByteOrder/LITTLE_ENDIAN)
-                   history (h/history (mapv #(decode-op rows payload %) (range (quot (.capacity rows) 16))))]
+             (let [history (parse-history (Native/historyEdn ctx i))]
                (checker/check (:checker test) test history {}))))
       (finally (Native/destroy ctx)))))

@@ -2,7 +2,8 @@
  * NOT compiled in this image (no jni.h / JDK); build on a box with a JDK:
  *   cc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -Iinclude integration/jni/maelsim_jni.c \
  *      -Lmaelstrom_amd -lmaelsim -o libmaelsim_jni.so
- * Java side: class maelstrom.gpu.Native { static native long create(int[] cfg, long seed, int device); ... }
+ * Java side: class maelstrom.gpu.Native { static native byte[] configDefaults(int workload, int nNodes);
+ *                                         static native long create(byte[] cfg, int device); ... }
  * Buffers cross as direct ByteBuffers over the engine-owned pinned host memory (valid until the next run). */
 #include <jni.h>
 #include <stdlib.h>
@@ -13,17 +14,27 @@ static void throw_msim(JNIEnv *env, const char *msg) {
   (*env)->ThrowNew(env, (*env)->FindClass(env, "java/lang/RuntimeException"), msg);
 }
 
-/* cfg = the msim_config u32 fields in declaration order up to quiesce_ms (16 ints) */
-JNIEXPORT jlong JNICALL Java_maelstrom_gpu_Native_create(JNIEnv *env, jclass cls, jintArray cfg_fields, jlong seed, jint device) {
+/* The whole msim_config crosses as bytes (little-endian, the layout of include/maelsim.h: struct_size bytes), so every field —
+ * key_count, max_txn_length, proxy_service, consistency_model, journal_capacity, capacities — is reachable from the JVM side.
+ * configDefaults(workload, n_nodes) -> byte[struct_size] with the CLI defaults of core.clj:136-229 filled in. */
+JNIEXPORT jbyteArray JNICALL Java_maelstrom_gpu_Native_configDefaults(JNIEnv *env, jclass cls, jint workload, jint n_nodes) {
   msim_config c;
-  jint f[16];
+  jbyteArray out;
+  (void)cls;
+  if (msim_config_defaults(&c, (uint32_t)workload, (uint32_t)n_nodes) != MSIM_OK) { throw_msim(env, "msim_config_defaults"); return NULL; }
+  out = (*env)->NewByteArray(env, (jsize)sizeof c);
+  (*env)->SetByteArrayRegion(env, out, 0, (jsize)sizeof c, (const jbyte *)&c);
+  return out;
+}
+
+/* create(cfg bytes, device): validates and finalizes the config (msim_config_finalize) and builds the engine context */
+JNIEXPORT jlong JNICALL Java_maelstrom_gpu_Native_create(JNIEnv *env, jclass cls, jbyteArray cfg_bytes, jint device) {
+  msim_config c;
   char err[256];
   msim_ctx *ctx = NULL;
   (void)cls;
-  (*env)->GetIntArrayRegion(env, cfg_fields, 0, 16, f);
-  msim_config_defaults(&c, (uint32_t)f[2], (uint32_t)f[4]);
-  memcpy(&c.workload, &f[2], 14 * sizeof(uint32_t)); /* workload .. quiesce_ms */
-  c.seed = (uint64_t)seed;
+  if ((*env)->GetArrayLength(env, cfg_bytes) != (jsize)sizeof c) { throw_msim(env, "msim_config: wrong size (struct_size mismatch)"); return 0; }
+  (*env)->GetByteArrayRegion(env, cfg_bytes, 0, (jsize)sizeof c, (jbyte *)&c);
   if (msim_create(&c, device, &ctx, err, sizeof err) != MSIM_OK) { throw_msim(env, err); return 0; }
   return (jlong)(intptr_t)ctx;
 }

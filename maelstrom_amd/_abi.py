@@ -40,7 +40,9 @@ EXPORTS = [
     "msim_run", "msim_run_async", "msim_check", "msim_check_lin_kv_rows", "msim_check_txn_rows", "msim_check_rw_rows", "msim_proscribed_anomalies", "msim_check_pn_rows", "msim_check_unique_rows", "msim_history_edn_rows", "msim_fetch", "msim_history", "msim_net_stats_get", "msim_journal", "msim_meta",
     "msim_check_results", "msim_device_buffers_get", "msim_last_kernel_ms", "msim_get_config",
     "msim_selftest_wave", "msim_last_error", "msim_destroy",
+    "msim_comm_unique_id", "msim_comm_init", "msim_gather",
 ]
+COMM_ID_BYTES = 128
 
 
 class Config(C.Structure):
@@ -91,6 +93,12 @@ class DeviceBuffers(C.Structure):
                 ("max_payload_words", C.c_uint32), ("journal_capacity", C.c_uint32)]
 
 
+class Gathered(C.Structure):
+    _fields_ = [("rows", C.c_void_p), ("payload", C.c_void_p), ("meta", C.c_void_p), ("stats", C.c_void_p),
+                ("rows_bytes", C.c_uint64), ("payload_bytes", C.c_uint64), ("meta_bytes", C.c_uint64), ("stats_bytes", C.c_uint64),
+                ("bytes_received", C.c_uint64), ("n_instances", C.c_uint32), ("world", C.c_uint32), ("rank", C.c_uint32), ("ms", C.c_float)]
+
+
 assert C.sizeof(Config) == 120, C.sizeof(Config)
 assert C.sizeof(Op) == 16 and C.sizeof(NetStats) == 48 and C.sizeof(InstMeta) == 32 and C.sizeof(CheckResult) == 68 and C.sizeof(Event) == 16
 
@@ -134,6 +142,11 @@ def load():
     lib.msim_selftest_wave.restype = C.c_int
     lib.msim_destroy.argtypes = [C.c_void_p]
     lib.msim_destroy.restype = None
+    lib.msim_comm_unique_id.argtypes = [C.c_char_p]
+    lib.msim_comm_init.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
+    lib.msim_gather.argtypes = [C.c_void_p, C.c_int, P(Gathered)]
+    for name in ("msim_comm_unique_id", "msim_comm_init", "msim_gather"):
+        getattr(lib, name).restype = C.c_int
     for name in ("msim_config_defaults", "msim_config_finalize", "msim_create", "msim_run", "msim_run_async",
                  "msim_check", "msim_fetch", "msim_history", "msim_net_stats_get", "msim_journal", "msim_meta", "msim_check_results",
                  "msim_device_buffers_get", "msim_last_kernel_ms", "msim_get_config"):

@@ -196,11 +196,19 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
       }                                                                                                                   \
     }                                                                                                                     \
     if (LAT0) nx = ring32[head]; else { const u64 pl_h = ring64[head]; nx_dl = (u32)pl_h; nx = (u32)(pl_h >> 32); }       \
-    sw = *DUO_SEEN_WORD();                                                                                                \
+    DUO_SW_PREFETCH();                                                                                                    \
   } while (0)
   // R3 for a broadcast envelope (gossip or the client's own): dedup against the node's set; pub_ = what the node publishes
   // to its neighbours: bit 31 | value | src to skip << 16, or 0
+#ifdef DUO_NO_SWPF   /* A/B build: the set word is read where it is used */
+#define DUO_SW_PREFETCH() do { } while (0)
+#define DUO_SW_NOW() do { sw = *DUO_SEEN_WORD(); } while (0)
+#else
+#define DUO_SW_PREFETCH() do { sw = *DUO_SEEN_WORD(); } while (0)
+#define DUO_SW_NOW() do { } while (0)
+#endif
 #define DUO_R3_SEEN(handle_, pub_) do {                                                                                   \
+    DUO_SW_NOW();                                                                                                         \
     const u32 r3_bit = 1u << (cm & 31u);                                                                                  \
     const bool r3_new = (handle_) & ((sw & r3_bit) == 0);                                                                 \
     if (r3_new) *DUO_SEEN_WORD() = sw | r3_bit;                                                                           \
@@ -256,22 +264,32 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
 #ifdef DUO_PROF
       pf_nwave++;
 #endif
-      // R0: the cluster's time: stay at T while something is due, else jump to the next delivery / scheduler event
-      const bool idle_h = (alive != 0) & (sched_at > T) & !half_any(deliver_at <= T);
+      // R0: the cluster's time: stay at T while something is due, else jump to the next delivery / scheduler event.
+      // Only looked at when one of the two clusters has nothing due (a scalar test on the halves of one ballot).
+      bool due_n = deliver_at <= T;
       bool stuck_any = false;
-      if (__ballot(idle_h)) {
-        const u32 km = min(half_min(deliver_at, hi), sched_at);
-        const bool stuck = idle_h & (km == INF);   // nothing will ever happen (oracle: same flag, the round counts)
-        flags |= stuck ? (u32)MSIM_FLAG_ROUND_LIMIT : 0u;
-        alive = stuck ? 0u : alive; sched_at = stuck ? INF : sched_at; force_general = stuck ? 0u : force_general;
-        rounds += stuck ? 1u : 0u;
-        T = (idle_h & !stuck) ? km : T;
-        stuck_any = __ballot(stuck) != 0;
+      {
+        const u64 db = __ballot(due_n);
+        if (__builtin_expect((u32)db == 0 || (u32)(db >> 32) == 0, 0)) {
+          const bool none_due = hi ? (u32)(db >> 32) == 0 : (u32)db == 0;
+          const bool idle_h = (alive != 0) & (sched_at > T) & none_due;
+          if (__ballot(idle_h)) {
+            const u32 km = min(half_min(deliver_at, hi), sched_at);
+            const bool stuck = idle_h & (km == INF);   // nothing will ever happen (oracle: same flag, the round counts)
+            flags |= stuck ? (u32)MSIM_FLAG_ROUND_LIMIT : 0u;
+            alive = stuck ? 0u : alive; sched_at = stuck ? INF : sched_at; force_general = stuck ? 0u : force_general;
+            rounds += stuck ? 1u : 0u;
+            T = (idle_h & !stuck) ? km : T;
+            stuck_any = __ballot(stuck) != 0;
+            due_n = deliver_at <= T;
+          }
+          // the round limit is looked at here and in GENERAL rounds (a stretch of pure gossip always ends in one of the two)
+          force_general = (alive != 0 && rounds >= round_limit) ? 1u : force_general;
+        }
       }
       rounds += alive;
-      const bool due_n = deliver_at <= T;
       const bool special = due_n & ((cm >> 24) != DK_PLAIN);
-      const bool gen = (alive != 0) & ((force_general != 0) | (sched_at <= T) | (rounds > round_limit) | special);
+      const bool gen = (alive != 0) & ((force_general != 0) | (sched_at <= T) | special);
       if (__ballot(gen) != 0 || stuck_any) break;   // (a GENERAL round is a superset of a gossip round: harmless for the other cluster)
       {   // ---- a round in which both clusters only gossip ----
         u32 pub; DUO_R3_SEEN(due_n, pub);

@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "engine_internal.h"
 #include "wave_common.h"
@@ -772,6 +773,10 @@ static void free_buffers(msim_ctx *c) {
   c->d_check_scratch = nullptr; c->cap_check_scratch = 0;
   if (c->d_compact) (void)hipFree(c->d_compact);
   if (c->d_off) (void)hipFree(c->d_off);
+  if (c->d_grows) (void)hipFree(c->d_grows);
+  if (c->d_gpay) (void)hipFree(c->d_gpay);
+  if (c->d_goff) (void)hipFree(c->d_goff);
+  c->d_grows = c->d_gpay = nullptr; c->d_goff = nullptr; c->cap_grows = c->cap_gpay = c->cap_goff = 0;
   c->d_compact = nullptr; c->d_off = nullptr;
   c->cap_compact = c->cap_off = c->cap_h_rows = c->cap_h_payload = c->cap_h_journal = c->cap_h_meta = 0;
   delete[] c->h_row_off; delete[] c->h_pay_off; delete[] c->h_ev_off;
@@ -1069,6 +1074,47 @@ static int fetch_compacted(msim_ctx *ctx, const void *d_src, uint64_t stride_uni
   return MSIM_OK;
 }
 
+// Device-side compaction for the multi-GPU gather (gather.cpp): the same kernels msim_fetch uses, into buffers that stay on
+// the device.  Only the instance meta (32 B each) crosses PCIe, to size the buffers and build the offsets.
+template <typename T>
+static int grow_device(msim_ctx *ctx, T **buf, size_t *cap, size_t bytes) {
+  if (*buf && *cap >= bytes) return MSIM_OK;
+  if (*buf) { (void)hipFree(*buf); *buf = nullptr; *cap = 0; }
+  const size_t want = bytes + bytes / 8 + 256;
+  MSIM_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(buf), want));
+  *cap = want;
+  return MSIM_OK;
+}
+int msim_compact_on_device(msim_ctx *ctx, uint64_t *row_units, uint64_t *pay_words) {
+  if (!ctx->ran) { ctx->err = "gather before msim_run"; return MSIM_E_RANGE; }
+  MSIM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const msim_config &c = ctx->cfg;
+  const uint32_t n = ctx->n_inst;
+  std::vector<msim_inst_meta> meta(n);
+  MSIM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  MSIM_HIP_TRY(ctx, hipMemcpy(meta.data(), ctx->d_meta, (size_t)n * sizeof(msim_inst_meta), hipMemcpyDeviceToHost));
+  std::vector<uint64_t> off(2 * (size_t)(n + 1));
+  uint64_t ro = 0, po = 0;
+  for (uint32_t i = 0; i < n; i++) { off[i] = ro; off[n + 1 + i] = po; ro += meta[i].n_rows; po += meta[i].n_payload_words; }
+  off[n] = ro; off[2 * n + 1] = po;
+  int rc;
+  if ((rc = grow_device(ctx, &ctx->d_grows, &ctx->cap_grows, (size_t)ro * 16 + 16)) != MSIM_OK) return rc;
+  if ((rc = grow_device(ctx, &ctx->d_gpay, &ctx->cap_gpay, (size_t)po * 4 + 16)) != MSIM_OK) return rc;
+  if ((rc = grow_device(ctx, &ctx->d_goff, &ctx->cap_goff, off.size() * 8)) != MSIM_OK) return rc;
+  MSIM_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_goff, off.data(), off.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+  const auto gy = [n](uint64_t total) { const uint64_t a = (total / (n ? n : 1) + 1 + 1023) / 1024; return (unsigned)(a < 1 ? 1 : a > 64 ? 64 : a); };
+  if (ro) hipLaunchKernelGGL(compact_kernel, dim3(n, gy(ro)), dim3(256), 0, ctx->stream, reinterpret_cast<const uint4 *>(ctx->d_rows),
+                             static_cast<uint4 *>(ctx->d_grows), ctx->d_goff, (uint64_t)c.max_rows);
+  if (po) hipLaunchKernelGGL(compact_words_kernel, dim3(n, gy(po)), dim3(256), 0, ctx->stream, ctx->d_payload, static_cast<u32 *>(ctx->d_gpay),
+                             ctx->d_goff + (n + 1), (uint64_t)c.max_payload_words);
+  MSIM_HIP_TRY(ctx, hipGetLastError());
+  MSIM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the host-side offsets vector goes out of scope
+  ctx->g_row_units = ro; ctx->g_pay_words = po;
+  if (row_units) *row_units = ro;
+  if (pay_words) *pay_words = po;
+  return MSIM_OK;
+}
+
 extern "C" int msim_fetch(msim_ctx *ctx) {
   if (!ctx) return MSIM_E_INVALID;
   if (!ctx->ran) { ctx->err = "msim_fetch before msim_run"; return MSIM_E_RANGE; }
@@ -1190,6 +1236,7 @@ extern "C" void msim_destroy(msim_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   free_buffers(ctx);
+  msim_gather_free(ctx);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);

@@ -39,6 +39,12 @@ struct msim_ctx {
   void *d_check_scratch = nullptr; size_t cap_check_scratch = 0;  // checker.hip: read records per instance
   void *d_compact = nullptr; uint64_t *d_off = nullptr;
   size_t cap_compact = 0, cap_off = 0, cap_h_rows = 0, cap_h_payload = 0, cap_h_journal = 0, cap_h_meta = 0;
+  // multi-GPU gather (gather.cpp): RCCL communicator of this rank, the rank's compacted slabs, the root's receive buffers
+  void *comm = nullptr; int comm_rank = 0, comm_world = 1;
+  void *d_grows = nullptr, *d_gpay = nullptr; uint64_t *d_goff = nullptr; size_t cap_grows = 0, cap_gpay = 0, cap_goff = 0;
+  uint64_t g_row_units = 0, g_pay_words = 0;   // compacted sizes of the last msim_compact_on_device
+  void *d_all[4] = {nullptr, nullptr, nullptr, nullptr}; size_t cap_all[4] = {0, 0, 0, 0};   // rows, payload, meta, stats of every rank (root)
+  uint64_t *d_sizes = nullptr;   // world x 4 u64 for the size all-gather
   bool fetched = false, checked = false, check_fetched = false, ran = false;
   float sim_ms = 0.f, check_ms = 0.f;
   std::string err;
@@ -63,6 +69,11 @@ static inline unsigned msim_host_threads() {
   return nt;
 }
 
+// engine.hip: compacts the used prefix of every instance's row / payload slab into ctx->d_grows / ctx->d_gpay on the device
+// (instance order); *row_units = 16-byte rows, *pay_words = u32 words.  Synchronises ctx->stream.
+int msim_compact_on_device(msim_ctx *ctx, uint64_t *row_units, uint64_t *pay_words);
+// gather.cpp
+void msim_gather_free(msim_ctx *ctx);
 // checker.hip
 int msim_check_launch(msim_ctx *ctx);
 // lin_check.cpp

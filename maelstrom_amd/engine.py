@@ -143,6 +143,26 @@ class Engine:
         self._chk(self.lib.msim_last_kernel_ms(self._ctx, C.byref(a), C.byref(b)), "msim_last_kernel_ms")
         return a.value, b.value
 
+    # ---- multi-GPU ensemble (include/maelsim.h "multi-GPU ensemble"; maelstrom_amd/ensemble.py) ----
+    @staticmethod
+    def comm_unique_id():
+        """rank 0: the 128-byte RCCL id every rank passes to comm_init (the host moves it: torch.distributed, files, sockets)"""
+        buf = C.create_string_buffer(A.COMM_ID_BYTES)
+        rc = A.load().msim_comm_unique_id(buf)
+        if rc:
+            raise EngineError(f"msim_comm_unique_id failed ({rc}): RCCL not available")
+        return buf.raw
+
+    def comm_init(self, comm_id, rank, world):
+        self._chk(self.lib.msim_comm_init(self._ctx, bytes(comm_id), rank, world), "msim_comm_init")
+
+    def gather(self, root=0):
+        """Variable-length history gather of the last run to `root` (device-side compaction + RCCL send/recv); returns the
+        msim_gathered record (device pointers are valid on the root until the next gather)."""
+        g = A.Gathered()
+        self._chk(self.lib.msim_gather(self._ctx, root, C.byref(g)), "msim_gather")
+        return g
+
     def device_buffers(self):
         db = A.DeviceBuffers()
         self._chk(self.lib.msim_device_buffers_get(self._ctx, C.byref(db)), "msim_device_buffers_get")

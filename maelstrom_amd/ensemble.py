@@ -1,7 +1,13 @@
 """Multi-GPU ensemble plumbing: instances are independent, so the hot path shards with no
 data-path collective — rank r simulates a contiguous block of global instance ids.  The only exchange is
-the end-of-batch, variable-length gather of the emitted histories (RCCL over xGMI on GPUs; the same code
-runs over gloo on CPU tensors in tests/test_ensemble_gloo.py).
+the end-of-batch, variable-length gather of the emitted histories to a root rank.
+
+Two transports, one layout (every rank's part of every slab kind in rank order, `gather_layout`):
+  * "cabi"  — `msim_gather` behind the C-ABI (csrc/gather.cpp): device-side compaction, ncclAllGather of the byte counts,
+              one grouped ncclSend / ncclRecv per slab kind to the root over RCCL / xGMI.  What a JVM host would call; what
+              bench.py uses on GPUs.
+  * "torch" — the same exchange on torch.distributed tensors (`gather_to_root`): size all-gather + isend / irecv to the root.
+              Runs over gloo on CPU tensors (tests/test_ensemble_gloo.py), which is how the N > 1 path is covered without GPUs.
 """
 import torch
 
@@ -54,3 +60,49 @@ def gather_histories(crow, cpay, nr, nw, dist=None, world=1):
         res.append((bufs[0][r, :a], bufs[1][r, :b], bufs[2][r, :c], bufs[3][r, :c]))
     nbytes = sum(int(s[0]) * 16 + int(s[1]) * 4 for s in all_sizes)
     return res, nbytes
+
+
+def gather_layout(sizes):
+    """sizes[r] = (rows bytes, payload bytes, meta bytes, stats bytes) of rank r -> (offsets[kind][rank], totals[kind]):
+    where every rank's part lands in the root's buffers.  Mirrors msim_gather_layout (csrc/gather.cpp)."""
+    world = len(sizes)
+    offs, totals = [], []
+    for k in range(len(sizes[0])):
+        o, col = 0, []
+        for r in range(world):
+            col.append(o)
+            o += int(sizes[r][k])
+        offs.append(col)
+        totals.append(o)
+    return offs, totals
+
+
+def gather_to_root(parts, dist, world, rank, root=0):
+    """The exchange of msim_gather on torch tensors: `parts` = this rank's flat uint8 tensors, one per slab kind (compacted
+    rows, compacted payload, meta, stats).  All-gathers the byte counts, then every peer sends each part ONCE to the root,
+    which receives it at its place (gather_layout).  Returns (root: list of gathered uint8 tensors | None, bytes received)."""
+    dev = parts[0].device
+    mine = torch.tensor([p.numel() for p in parts], dtype=torch.int64, device=dev)
+    if dist is None or world == 1:
+        return [p.clone() for p in parts], 0
+    all_sizes = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(all_sizes, mine)
+    sizes = [[int(x) for x in s] for s in all_sizes]
+    offs, totals = gather_layout(sizes)
+    received = 0
+    if rank == root:
+        out = [torch.empty(t, dtype=torch.uint8, device=dev) for t in totals]
+        reqs = []
+        for k in range(len(parts)):
+            out[k][offs[k][root]: offs[k][root] + sizes[root][k]] = parts[k]
+            for p in range(world):
+                if p != root and sizes[p][k]:
+                    reqs.append(dist.irecv(out[k][offs[k][p]: offs[k][p] + sizes[p][k]], src=p))
+                    received += sizes[p][k]
+        for r in reqs:
+            r.wait()
+        return out, received
+    reqs = [dist.isend(parts[k], dst=root) for k in range(len(parts)) if parts[k].numel()]
+    for r in reqs:
+        r.wait()
+    return None, 0

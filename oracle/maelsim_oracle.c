@@ -981,6 +981,29 @@ int oracle_txn_trace(const msim_config *cfg, const uint32_t *in, uint32_t n_in, 
   return (int)n;
 }
 
+/* Test hook for the key-value services behind the proxy node (svc_nodes.inc): feeds `n_in` requests {client id, message type,
+ * a} straight to the service of cfg->proxy_service — what `(s/handle! kv {:src client :body ...})` does in the reference's own
+ * test/maelstrom/service_test.clj — and records {reply type, a} per request ({0, 0}: no reply).  Client ids are service-side
+ * "clients" (the :src of the request, service.clj:166): any value below 256.  `instance` seeds the service's rand-int stream. */
+int oracle_svc_trace(const msim_config *cfg, uint64_t instance, const uint32_t *in, uint32_t n_in, uint32_t *out) {
+  msim_op *rows = (msim_op *)calloc(cfg->max_rows, sizeof(msim_op));
+  uint32_t *payload = (uint32_t *)calloc(cfg->max_payload_words, 4);
+  sim_t *s = sim_new(cfg, instance, rows, payload);
+  if (!s || !s->svc) { if (s) sim_free(s); free(rows); free(payload); return -1; }
+  free(s->svc->client_idx);
+  s->svc->client_idx = (u32 *)calloc(256, 4);
+  for (u32 i = 0; i < n_in; i++) {
+    const u32 *m = in + 3 * i;
+    if (m[0] >= 256) { sim_free(s); free(rows); free(payload); return -1; }
+    s->n_out = 0;
+    qent q = {s->T, i, m[2], i + 1, (u8)m[0], (u8)m[1], NULL};
+    px_svc_handle(s, &q);
+    out[2 * i] = s->n_out ? s->out[0].type : 0; out[2 * i + 1] = s->n_out ? s->out[0].a : 0;
+  }
+  sim_free(s); free(rows); free(payload);
+  return (int)n_in;
+}
+
 /* Runs instances [first, first+n) into instance-major output slabs (same layout as the engine). */
 int oracle_run(const msim_config *cfg, uint64_t first, uint32_t n, msim_op *rows, uint32_t *payload,
                msim_net_stats *stats, msim_inst_meta *meta, msim_event *journal) {

@@ -7,7 +7,7 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["MSIM_LIB"] = os.path.join(ROOT, "maelstrom_amd", "libmaelsim_prof.so")
+os.environ.setdefault("MSIM_LIB", os.path.join(ROOT, "maelstrom_amd", "libmaelsim_prof.so"))
 sys.path.insert(0, ROOT)
 from maelstrom_amd import engine as E  # noqa: E402
 

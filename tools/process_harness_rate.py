@@ -3,7 +3,8 @@
 reference's own demo/js/gossip.js, one per node, JSON lines over pipes, routed by a trivial in-memory network as fast as
 possible — no JVM, no virtual time, no latency, no journal.  Prints the message rate one n=25 grid cluster sustains on this
 machine's cores, i.e. what process-per-node + JSON + pipes cost before Maelstrom itself adds its share.
-Needs node.js and /root/reference (build container only).  Usage: tools/process_harness_rate.py [n_nodes] [n_broadcasts]"""
+With node.js and /root/reference at hand (build container) the nodes are the reference's demo/js/gossip.js (acknowledged gossip);
+anywhere else they are tools/harness_node.py (python3, the fire-and-forget node).  Usage: tools/process_harness_rate.py [n_nodes] [n_broadcasts]"""
 import json
 import os
 import select
@@ -12,6 +13,15 @@ import sys
 import time
 
 JS = "/root/reference/demo/js/gossip.js"
+PY_NODE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "harness_node.py")
+
+
+def node_command(prefer_reference=True):
+    """(argv, description) of the node process: the reference's own gossip.js if it can run here, else this repository's python node"""
+    import shutil
+    if prefer_reference and os.path.exists(JS) and shutil.which("node"):
+        return ["node", JS], "node demo/js/gossip.js (reference demo, acknowledged gossip)"
+    return [sys.executable, PY_NODE], "python3 tools/harness_node.py (fire-and-forget broadcast node, one process per node)"
 
 
 def grid(n):
@@ -31,10 +41,9 @@ def grid(n):
     return nb
 
 
-def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 25
-    k = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
-    procs = [subprocess.Popen(["node", JS], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, bufsize=0) for _ in range(n)]
+def measure(n=25, k=2000, prefer_reference=True):
+    argv, what = node_command(prefer_reference)
+    procs = [subprocess.Popen(argv, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, bufsize=0) for _ in range(n)]
     fd2node = {p.stdout.fileno(): i for i, p in enumerate(procs)}
     bufs = {i: b"" for i in range(n)}
     names = [f"n{i}" for i in range(n)]
@@ -80,8 +89,16 @@ def main():
     dt = time.perf_counter() - t0 - 0.5
     for p in procs:
         p.kill()
-    print(json.dumps({"harness": "node demo/js/gossip.js x %d over pipes, grid" % n, "broadcasts": k, "messages": sent, "seconds": round(dt, 2),
-                      "msgs_per_s": round(sent / dt), "host_cpus": len(os.sched_getaffinity(0))}))
+    for p in procs:
+        p.wait()
+    return {"harness": "%s x %d over pipes, grid" % (what, n), "broadcasts": k, "messages": sent, "seconds": round(dt, 2),
+            "msgs_per_s": round(sent / dt), "host_cpus": len(os.sched_getaffinity(0))}
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 25
+    k = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+    print(json.dumps(measure(n, k, prefer_reference="--python-nodes" not in sys.argv)))
 
 
 if __name__ == "__main__":
