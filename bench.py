@@ -105,6 +105,12 @@ def main():
     ap.add_argument("--no-fetch", action="store_true", help="skip the PCIe-inclusive leg (value_incl_fetch)")
     args = ap.parse_args()
 
+    # ONE JSON line on stdout: libraries underneath (RCCL's version banner at communicator set-up, gloo's connection notes) write
+    # to file descriptor 1 — for the duration of the run it points at stderr; the result goes to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     from maelstrom_amd import build, engine as E
@@ -252,7 +258,8 @@ def main():
         if args.cpu_sample > 0 and world == 1:   # the CPU leg is measured once, at N=1
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample)
             out["cpu_baseline"]["process_harness"] = process_harness(min(20.0, 2 * args.cpu_sample))
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist:
         dist.barrier()
         dist.destroy_process_group()

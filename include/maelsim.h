@@ -310,6 +310,14 @@ int msim_check_pn_rows(const msim_op *rows, uint32_t n_rows, msim_check_result *
 int msim_history_edn_rows(const msim_config *cfg, const msim_op *rows, uint32_t n_rows, const uint32_t *payload, uint32_t n_words,
                           char *out, size_t cap, size_t *needed);
 
+/* Host-only utility: one instance's net journal in the reference's on-disk format — the bytes of a
+ * `store/<test>/net-journal/<stripe>.fressian` file as maelstrom.net.journal writes it (net/journal.clj:55-141,220-239: one
+ * Fressian "ev" struct per log-send! / log-recv!, "msg" structs with cached src / dest, bodies through write-body!), for the
+ * unchanged maelstrom.net.checker (net/checker.clj:28-70) and net/viz.clj.  `payload` = the instance's payload area (read_ok
+ * bodies refer to it).  Same calling convention as msim_history_edn_rows: cap == 0 only queries *needed.  Needs no device. */
+int msim_journal_fressian_rows(const msim_config *cfg, const msim_event *events, uint32_t n_events, const uint32_t *payload, uint32_t n_words,
+                               unsigned char *out, size_t cap, size_t *needed);
+
 /* Copies the last run's outputs to host memory (pinned, owned by ctx, valid until next run/destroy). */
 int msim_fetch(msim_ctx *ctx);
 

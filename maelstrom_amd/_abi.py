@@ -40,7 +40,7 @@ EXPORTS = [
     "msim_run", "msim_run_async", "msim_check", "msim_check_lin_kv_rows", "msim_check_txn_rows", "msim_check_rw_rows", "msim_proscribed_anomalies", "msim_check_pn_rows", "msim_check_unique_rows", "msim_history_edn_rows", "msim_fetch", "msim_history", "msim_net_stats_get", "msim_journal", "msim_meta",
     "msim_check_results", "msim_device_buffers_get", "msim_last_kernel_ms", "msim_get_config",
     "msim_selftest_wave", "msim_last_error", "msim_destroy",
-    "msim_comm_unique_id", "msim_comm_init", "msim_gather",
+    "msim_comm_unique_id", "msim_comm_init", "msim_gather", "msim_journal_fressian_rows",
 ]
 COMM_ID_BYTES = 128
 
@@ -142,6 +142,8 @@ def load():
     lib.msim_selftest_wave.restype = C.c_int
     lib.msim_destroy.argtypes = [C.c_void_p]
     lib.msim_destroy.restype = None
+    lib.msim_journal_fressian_rows.argtypes = [P(Config), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, P(C.c_size_t)]
+    lib.msim_journal_fressian_rows.restype = C.c_int
     lib.msim_comm_unique_id.argtypes = [C.c_char_p]
     lib.msim_comm_init.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
     lib.msim_gather.argtypes = [C.c_void_p, C.c_int, P(Gathered)]

@@ -430,6 +430,24 @@ def decode_history(rows, payload, n_nodes, workload=A.WL_BROADCAST):
     return ops
 
 
+def journal_fressian(cfg, events, payload):
+    """One instance's net journal as the bytes of a net-journal/<stripe>.fressian file (msim_journal_fressian_rows, csrc/fressian.cpp):
+    what maelstrom.net.journal writes (journal.clj:55-141) and maelstrom.net.checker / net.viz read."""
+    lib = A.load()
+    ev = np.ascontiguousarray(events)
+    pay = np.ascontiguousarray(payload, dtype=np.uint32)
+    args = (C.byref(cfg), ev.ctypes.data, len(ev), pay.ctypes.data, len(pay))
+    need = C.c_size_t()
+    rc = lib.msim_journal_fressian_rows(*args, None, 0, C.byref(need))
+    if rc:
+        raise EngineError(f"msim_journal_fressian_rows: {rc}")
+    buf = (C.c_ubyte * max(need.value, 1))()
+    rc = lib.msim_journal_fressian_rows(*args, buf, need.value, None)
+    if rc:
+        raise EngineError(f"msim_journal_fressian_rows: {rc}")
+    return bytes(buf[: need.value])
+
+
 def history_edn_native(cfg, rows, payload):
     """history.edn text of one history straight from the binary rows (msim_history_edn_rows, csrc/edn.cpp)."""
     lib = A.load()
