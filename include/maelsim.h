@@ -310,6 +310,19 @@ int msim_check_pn_rows(const msim_op *rows, uint32_t n_rows, msim_check_result *
 int msim_history_edn_rows(const msim_config *cfg, const msim_op *rows, uint32_t n_rows, const uint32_t *payload, uint32_t n_words,
                           char *out, size_t cap, size_t *needed);
 
+/* maelstrom.checker/availability-checker (checker.clj:6-39; part of every test's composed checker, core.clj:98): did the history
+ * meet `--availability` (core.clj:149)?  :ok-fraction = :ok ops / :invoke ops (1 for an empty history); :valid? = true for nil,
+ * fraction == 1 for :total, availability <= fraction for a number.  msim_check_availability judges every history of the last run
+ * on the device (out[n_out >= n_instances]); msim_check_availability_rows one history on the host. */
+enum { MSIM_AVAIL_NIL = 0, MSIM_AVAIL_TOTAL = 1, MSIM_AVAIL_FRACTION = 2 };
+typedef struct msim_availability {
+  uint32_t valid;          /* 1 / 0 */
+  float ok_fraction;       /* (float (/ ok-count invoke-count)) */
+  uint32_t ok_count, invoke_count;
+} msim_availability;
+int msim_check_availability(msim_ctx *ctx, uint32_t mode, double availability, msim_availability *out, uint32_t n_out);
+int msim_check_availability_rows(const msim_op *rows, uint32_t n_rows, uint32_t mode, double availability, msim_availability *out);
+
 /* Host-only utility: one instance's net journal in the reference's on-disk format — the bytes of a
  * `store/<test>/net-journal/<stripe>.fressian` file as maelstrom.net.journal writes it (net/journal.clj:55-141,220-239: one
  * Fressian "ev" struct per log-send! / log-recv!, "msg" structs with cached src / dest, bodies through write-body!), for the

@@ -41,7 +41,9 @@ EXPORTS = [
     "msim_check_results", "msim_device_buffers_get", "msim_last_kernel_ms", "msim_get_config",
     "msim_selftest_wave", "msim_last_error", "msim_destroy",
     "msim_comm_unique_id", "msim_comm_init", "msim_gather", "msim_journal_fressian_rows",
+    "msim_check_availability", "msim_check_availability_rows",
 ]
+AVAIL_NIL, AVAIL_TOTAL, AVAIL_FRACTION = range(3)
 COMM_ID_BYTES = 128
 
 
@@ -91,6 +93,10 @@ class DeviceBuffers(C.Structure):
                 ("meta_bytes", C.c_uint64), ("check_bytes", C.c_uint64), ("journal_bytes", C.c_uint64),
                 ("n_instances", C.c_uint32), ("max_rows", C.c_uint32),
                 ("max_payload_words", C.c_uint32), ("journal_capacity", C.c_uint32)]
+
+
+class Availability(C.Structure):
+    _fields_ = [("valid", C.c_uint32), ("ok_fraction", C.c_float), ("ok_count", C.c_uint32), ("invoke_count", C.c_uint32)]
 
 
 class Gathered(C.Structure):
@@ -144,6 +150,9 @@ def load():
     lib.msim_destroy.restype = None
     lib.msim_journal_fressian_rows.argtypes = [P(Config), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, P(C.c_size_t)]
     lib.msim_journal_fressian_rows.restype = C.c_int
+    lib.msim_check_availability.argtypes = [C.c_void_p, C.c_uint32, C.c_double, P(Availability), C.c_uint32]
+    lib.msim_check_availability_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_double, P(Availability)]
+    lib.msim_check_availability.restype = lib.msim_check_availability_rows.restype = C.c_int
     lib.msim_comm_unique_id.argtypes = [C.c_char_p]
     lib.msim_comm_init.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
     lib.msim_gather.argtypes = [C.c_void_p, C.c_int, P(Gathered)]

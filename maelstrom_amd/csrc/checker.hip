@@ -29,6 +29,8 @@
 // Per-element state: three u16 row indices in LDS (8.4 KB for 1408 elements keeps 4096 histories resident).
 #include <hip/hip_runtime.h>
 
+#include <vector>
+
 #include "engine_internal.h"
 
 #define NONE 0xFFFFu      /* per-element row index: none */
@@ -291,5 +293,55 @@ int msim_check_launch(msim_ctx *ctx) {
   MSIM_HIP_TRY(ctx, hipEventSynchronize(ctx->ev3));
   MSIM_HIP_TRY(ctx, hipEventElapsedTime(&ctx->check_ms, ctx->ev2, ctx->ev3));
   ctx->checked = true; ctx->check_fetched = false;
+  return MSIM_OK;
+}
+
+// ---- maelstrom.checker/availability-checker (checker.clj:6-39) ---------------------------------------------------------
+// :ok-fraction = (float (/ ok-count invoke-count)) over (h/oks history) and (h/invokes history) — every :ok and every :invoke row
+// (nemesis ops are :info) — 1 for an empty history; :valid? by --availability (core.clj:149): nil -> true, :total -> the
+// fraction == 1, a number a -> a <= fraction.  One wavefront per history counts the two row types from HBM; the verdicts are
+// formed on the host (n x 2 counters cross PCIe).
+__global__ void __launch_bounds__(64) availability_kernel(const msim_op *rows, const msim_inst_meta *meta, u32 max_rows, uint2 *out) {
+  const u32 lane = threadIdx.x, inst = blockIdx.x;
+  const u32 n = meta[inst].n_rows;
+  const uint4 *r = reinterpret_cast<const uint4 *>(rows + (size_t)inst * max_rows);
+  u32 ok = 0, inv = 0;
+  for (u32 i = lane; i < n; i += 64) { const u32 t = r[i].z & 3u; ok += t == MSIM_T_OK; inv += t == MSIM_T_INVOKE; }
+  ok = c_wave_sum(ok); inv = c_wave_sum(inv);
+  if (lane == 0) out[inst] = make_uint2(ok, inv);
+}
+
+static void availability_verdict(uint32_t ok, uint32_t inv, uint32_t mode, double a, msim_availability *o) {
+  o->ok_count = ok; o->invoke_count = inv;
+  o->ok_fraction = inv == 0 ? 1.0f : (float)((double)ok / (double)inv);   // (float (/ ok-count invoke-count)): a ratio rounded once
+  o->valid = mode == MSIM_AVAIL_NIL ? 1u : mode == MSIM_AVAIL_TOTAL ? (o->ok_fraction == 1.0f ? 1u : 0u) : (a <= (double)o->ok_fraction ? 1u : 0u);
+}
+
+extern "C" int msim_check_availability_rows(const msim_op *rows, uint32_t n_rows, uint32_t mode, double availability, msim_availability *out) {
+  if ((!rows && n_rows) || !out || mode > MSIM_AVAIL_FRACTION || (mode == MSIM_AVAIL_FRACTION && !(availability >= 0.0 && availability <= 1.0))) return MSIM_E_INVALID;
+  uint32_t ok = 0, inv = 0;
+  for (uint32_t i = 0; i < n_rows; i++) { const uint32_t t = MSIM_OP_TYPE(rows[i]); ok += t == MSIM_T_OK; inv += t == MSIM_T_INVOKE; }
+  availability_verdict(ok, inv, mode, availability, out);
+  return MSIM_OK;
+}
+
+extern "C" int msim_check_availability(msim_ctx *ctx, uint32_t mode, double availability, msim_availability *out, uint32_t n_out) {
+  if (!ctx || !out) return MSIM_E_INVALID;
+  if (!ctx->ran) { ctx->err = "msim_check_availability before msim_run"; return MSIM_E_RANGE; }
+  if (mode > MSIM_AVAIL_FRACTION || (mode == MSIM_AVAIL_FRACTION && !(availability >= 0.0 && availability <= 1.0))) {
+    ctx->err = "--availability is nil, total, or a number from 0 to 1 (core.clj:149, checker.clj:36-39)"; return MSIM_E_INVALID; }
+  if (n_out < ctx->n_inst) { ctx->err = "msim_check_availability: output array shorter than the run"; return MSIM_E_RANGE; }
+  MSIM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = (size_t)ctx->n_inst * sizeof(uint2);
+  uint2 *d = nullptr;
+  MSIM_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&d), bytes));
+  hipLaunchKernelGGL(availability_kernel, dim3(ctx->n_inst), dim3(64), 0, ctx->stream, ctx->d_rows, ctx->d_meta, ctx->cfg.max_rows, d);
+  std::vector<uint2> h(ctx->n_inst);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d, bytes, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) { ctx->err = std::string("msim_check_availability: ") + hipGetErrorString(e); return MSIM_E_HIP; }
+  for (uint32_t i = 0; i < ctx->n_inst; i++) availability_verdict(h[i].x, h[i].y, mode, availability, &out[i]);
   return MSIM_OK;
 }

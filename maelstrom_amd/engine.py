@@ -143,6 +143,14 @@ class Engine:
         self._chk(self.lib.msim_last_kernel_ms(self._ctx, C.byref(a), C.byref(b)), "msim_last_kernel_ms")
         return a.value, b.value
 
+    def check_availability(self, availability=None):
+        """maelstrom.checker/availability-checker (checker.clj:6-39) over every history of the last run: `availability` is None,
+        "total" or a number from 0 to 1 (--availability, core.clj:149).  Returns [{:valid? :ok-fraction}] (+ the two counts)."""
+        mode, a = _availability_mode(availability)
+        res = (A.Availability * self.n)()
+        self._chk(self.lib.msim_check_availability(self._ctx, mode, a, res, self.n), "msim_check_availability")
+        return [{"valid?": bool(r.valid), "ok-fraction": float(r.ok_fraction), "ok-count": r.ok_count, "invoke-count": r.invoke_count} for r in res]
+
     # ---- multi-GPU ensemble (include/maelsim.h "multi-GPU ensemble"; maelstrom_amd/ensemble.py) ----
     @staticmethod
     def comm_unique_id():
@@ -428,6 +436,27 @@ def decode_history(rows, payload, n_nodes, workload=A.WL_BROADCAST):
             op["final?"] = True
         ops.append(op)
     return ops
+
+
+def _availability_mode(availability):
+    if availability is None:
+        return A.AVAIL_NIL, 0.0
+    if availability in ("total", ":total"):
+        return A.AVAIL_TOTAL, 0.0
+    if isinstance(availability, (int, float)) and not isinstance(availability, bool):
+        return A.AVAIL_FRACTION, float(availability)
+    raise EngineError(f"Don't know how to handle :availability {availability!r}")   # checker.clj:36-39
+
+
+def check_availability_rows(rows, availability=None):
+    """The availability checker for one history on the host (msim_check_availability_rows)."""
+    mode, a = _availability_mode(availability)
+    r = A.Availability()
+    rows = np.ascontiguousarray(rows)
+    rc = A.load().msim_check_availability_rows(rows.ctypes.data, len(rows), mode, a, C.byref(r))
+    if rc:
+        raise EngineError(f"msim_check_availability_rows: {rc}")
+    return {"valid?": bool(r.valid), "ok-fraction": float(r.ok_fraction), "ok-count": r.ok_count, "invoke-count": r.invoke_count}
 
 
 def journal_fressian(cfg, events, payload):

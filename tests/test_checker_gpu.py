@@ -173,3 +173,18 @@ def test_services_under_the_linearizability_checker(lib):
             eng.check()
             out[service] = int((eng.check_results()["valid"] == 1).sum())
     assert out["lin-kv"] == 32 and out["seq-kv"] < 16 and out["lww-kv"] < 16, out
+
+
+def test_availability_checker_device_equals_host(lib):
+    """checker.clj:6-39 for a whole run on the device (msim_check_availability) = the host entry point history by history"""
+    for cfg in (E.test_config("echo", node_count=3, rate=20, time_limit=8, p_loss=0.2, seed=5),
+                E.test_config("lin-kv", bin="raft", node_count=5, rate=30, time_limit=10, latency=10, nemesis=["partition"], nemesis_interval=3, seed=6)):
+        with E.Engine(cfg) as eng:
+            eng.run(0, 12)
+            eng.fetch()
+            for a in (None, "total", 0.9):
+                dev = eng.check_availability(a)
+                for i in range(12):
+                    assert dev[i] == E.check_availability_rows(eng.raw_history(i)[0], a)
+            assert not all(r["valid?"] for r in eng.check_availability("total"))   # loss / partitions cost some operations
+            assert all(r["valid?"] for r in eng.check_availability(None))
