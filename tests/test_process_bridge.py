@@ -1,0 +1,115 @@
+"""The generic process bridge (maelstrom_amd/bridge.py; process.clj:136-215 on the deterministic scheduler): real node PROCESSES
+over pipes, in virtual time.  A run is reproducible from its seed, and — because the bridge restates the same rounds and draws the
+same random numbers as the engine's specification — a node program that behaves like a built-in node yields exactly the history
+the oracle (and therefore the GPU engine) emits: broadcast with this repository's fire-and-forget node process, echo with the
+REFERENCE's own demo/python/echo.py when the reference tree is present."""
+import os
+import sys
+
+import pytest
+
+from maelstrom_amd import bridge as B
+from maelstrom_amd import engine as E
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FF_NODE = [sys.executable, os.path.join(ROOT, "tools", "harness_node.py")]
+TSO_NODE = [sys.executable, os.path.join(ROOT, "tools", "harness_tso_node.py")]
+REF_ECHO = "/root/reference/demo/python/echo.py"
+
+
+def _norm(ops):
+    out = []
+    for op in ops:
+        o = {k: op[k] for k in ("index", "time", "type", "f", "process", "value") if k in op}
+        if "error" in op:
+            o["error"] = op["error"] if isinstance(op["error"], str) else op["error"][0]
+        if op.get("final?"):
+            o["final?"] = True
+        out.append(o)
+    return out
+
+
+def _against_oracle(workload, argv, **kw):
+    cfg = E.test_config(workload, **kw)
+    ora = O.run(cfg, 0, 1)
+    want = E.decode_history(*ora.history(0), cfg.n_nodes, cfg.workload)
+    b = B.Bridge(workload, argv, **kw)
+    got = b.run()
+    assert b.errors == []
+    assert _norm(got) == _norm(want)
+    assert b.rounds == int(ora.meta["n_rounds"][0])
+    st = ora.stats[0]
+    assert tuple(b.stats[k] for k in ("all_send", "all_recv", "clients_send", "clients_recv", "servers_send", "servers_recv")) == tuple(int(x) for x in st)
+    return b
+
+
+@pytest.mark.parametrize("kw", [
+    dict(node_count=5, rate=10, time_limit=5, seed=7),
+    dict(node_count=5, rate=20, time_limit=5, latency=20, latency_dist="exponential", p_loss=0.05, nemesis=["partition"], nemesis_interval=2, seed=8),
+    dict(node_count=9, rate=30, time_limit=4, latency=10, topology="tree3", seed=9),
+    dict(node_count=4, concurrency=8, rate=20, time_limit=4, latency=5, latency_dist="uniform", topology="line", seed=10),
+])
+def test_broadcast_node_processes_reproduce_the_oracle_history(kw):
+    b = _against_oracle("broadcast", FF_NODE, **kw)
+    m = b.net_stats()
+    assert m["all"]["send-count"] == b.stats["all_send"] and m["servers"]["msgs-per-op"] > 0
+
+
+@pytest.mark.skipif(not os.path.exists(REF_ECHO), reason="needs the reference tree (demo/python/echo.py)")
+def test_reference_echo_py_reproduces_the_oracle_history():
+    """BASELINE configs[0]: echo, 3 nodes, the reference's own demo binary"""
+    _against_oracle("echo", [sys.executable, REF_ECHO], node_count=3, rate=10, time_limit=5, seed=1)
+    _against_oracle("echo", [sys.executable, REF_ECHO], node_count=3, rate=20, time_limit=6, p_loss=0.1, seed=2)   # timeouts -> :info, new processes
+
+
+def test_runs_are_reproducible_and_journalled():
+    kw = dict(node_count=5, rate=20, time_limit=4, latency=10, latency_dist="exponential", seed=11)
+    a = B.Bridge("broadcast", FF_NODE, journal=True, **kw)
+    ha = a.run()
+    b = B.Bridge("broadcast", FF_NODE, journal=True, **kw)
+    hb = b.run()
+    assert ha == hb and a.journal == b.journal and len(a.journal) == a.stats["all_send"] + a.stats["all_recv"]
+    assert [e["id"] for e in a.journal] == list(range(len(a.journal)))
+    gossip = [e for e in a.journal if e["type"] == ":send" and e["message"]["src"].startswith("n") and e["message"]["dest"].startswith("n")]
+    assert gossip and all(e["message"]["body"] == {"type": "broadcast", "message": e["message"]["body"]["message"]} for e in gossip)
+
+
+def test_lin_tso_service_serves_a_unique_ids_node():
+    """service.clj:116-132: a monotonically increasing stream of integers from 0; ids handed out through it are unique, and every
+    client sees its own ids grow (lin-tso is linearizable)."""
+    b = B.Bridge("unique-ids", TSO_NODE, node_count=3, rate=100, time_limit=3, latency=5, seed=3)
+    hist = b.run()
+    assert b.errors == []
+    ids = [op["value"] for op in hist if op["type"] == ":ok"]
+    assert len(ids) > 200 and sorted(ids) == list(range(len(ids)))     # 0, 1, 2, ... each exactly once
+    per = {}
+    for op in hist:
+        if op["type"] == ":ok":
+            assert per.get(op["process"], -1) < op["value"]
+            per[op["process"]] = op["value"]
+    assert b.stats["servers_send"] == 2 * len(ids)                     # one ts / ts_ok pair per id
+
+
+def test_services_behind_the_bridge():
+    """service.clj:31-61,161-210 through the bridge's own service objects (what a --bin talking to seq-kv / lin-kv / lww-kv gets)"""
+    lin = B.default_services()["lin-kv"]
+    assert lin.handle("n0", {"type": "read", "key": "x"}, None)["code"] == 20
+    assert lin.handle("n0", {"type": "cas", "key": "x", "from": 1, "to": 2, "create_if_not_exists": True}, None)["type"] == "cas_ok"
+    assert lin.handle("n1", {"type": "cas", "key": "x", "from": 1, "to": 3}, None)["code"] == 22
+    assert lin.handle("n1", {"type": "read", "key": "x"}, None) == {"type": "read_ok", "value": 2}
+    seq = B.default_services()["seq-kv"]
+    for i in range(16):
+        assert seq.handle("c0", {"type": "write", "key": "x", "value": i}, lambda n: 0)["type"] == "write_ok"
+    vals = {seq.handle(f"fresh-{i}", {"type": "read", "key": "x"}, lambda n, i=i: i % n).get("value") for i in range(64)}
+    assert len(vals) > 1                                              # service_test.clj:20-28
+    seq.handle("me", {"type": "write", "key": "y", "value": 1}, lambda n: 0)
+    assert seq.handle("me", {"type": "read", "key": "x"}, lambda n: 0)["value"] == 15   # service_test.clj:30-38
+
+
+def test_cli(tmp_path):
+    rc = B.main(["test", "-w", "broadcast", "--bin", FF_NODE[0], "--node-count", "3", "--rate", "10", "--time-limit", "2", "--history",
+                 str(tmp_path / "history.edn"), "--", FF_NODE[1]])
+    assert rc == 0
+    lines = open(tmp_path / "history.edn").read().splitlines()
+    assert lines and lines[0].startswith("{:index 0, :time ") and ":f :broadcast" in "".join(lines)
