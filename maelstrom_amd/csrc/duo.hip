@@ -14,10 +14,13 @@
 //
 // Scope (the host picks this kernel when all of it holds, else the kernels of engine.hip run):
 //   * node program broadcast fire-and-forget (with or without skip-sender), colocated clients (concurrency == n_nodes <= 32);
-//   * constant latency (any mean below the RPC timeouts), no loss, no nemesis, net journal off.
-// Then message ids are unobservable (no per-message RNG draw, no journal, arrival order = id order), a node's queue is a
-// FIFO, no client can time out (an RPC completes within one latency of virtual time), a client's reply is handled by
-// the lane that sent the request, and a round is:
+//   * constant, uniform or exponential latency (bounded below the RPC timeouts), no loss, no nemesis, net journal off.
+// With constant latency message ids are unobservable (no per-message RNG draw, no journal, arrival order = id order) and a
+// node's queue is a FIFO.  With random latency (RND) every message's latency is drawn from its id (net.clj:178-187), so ids are
+// assigned in the canonical order (a prefix sum over the senders of a round) and a node's queue is a bag ordered by
+// (deadline, arrival sequence) — the arrival sequence at one node orders its envelopes exactly as their ids do.  No client can
+// time out (an RPC completes within one maximal latency of virtual time), a client's reply is handled by the lane that
+// sent the request, and a round is:
 //   R0  per-cluster time: stay at T while something is due, else jump to the next delivery / scheduler event;
 //   R1  generator (one op) / phase actions                          — GENERAL rounds only
 //   R2  marked clients invoke: the request reaches its own node     — GENERAL rounds only
@@ -30,8 +33,11 @@
 #include <type_traits>
 
 #include "wave_common.h"
+#include "log2_table.h"
 
 namespace {
+
+__constant__ u32 duo_log2_q24[257];
 
 enum { DK_PLAIN = 0, DK_BCAST = 1, DK_READ = 2, DK_READ_FINAL = 3, DK_INIT = 4, DK_TOPO = 5 };  // kind of an envelope (bits 24-26)
 constexpr u32 DUO_STAGE_ROWS = 128u;
@@ -46,7 +52,23 @@ struct DuoParams {
   u32 deg;           // maximum degree of the topology
   u32 echoback;      // node program without skip-sender
   u32 round_limit;
+  u32 off_seq;       // RND: byte offset of the arrival-sequence array (u16 per ring entry) inside a cluster's LDS region
+  u32 off_log2;      // RND: byte offset of the Q24 log2 table (one per wavefront, behind both clusters)
 };
+
+// -ln(u), u = (r+1)/2^32, Q16, integer only: the sampler of engine.hip / the oracle over a copy of the table in LDS
+__device__ __forceinline__ u32 duo_neg_ln_q16(u32 r, const u32 *tab) {
+  if (r == 0xFFFFFFFFu) return 0;
+  const u32 v = r + 1;
+  const u32 e = 31 - __clz(v);
+  const u32 m = v << (31 - e);
+  const u32 idx = (m >> 23) & 0xFF;
+  const u32 f = (m >> 7) & 0xFFFF;
+  const u32 l0 = tab[idx], l1 = tab[idx + 1];
+  const u32 lg = (e << 24) + l0 + (u32)(((u64)(l1 - l0) * f) >> 16);
+  const u32 d = (32u << 24) - lg;
+  return (u32)(((u64)d * 2977044472ull) >> 40);
+}
 
 // the cluster's half of a wave ballot
 __device__ __forceinline__ u32 hb(bool pred, bool hi) {
@@ -70,8 +92,9 @@ __device__ __forceinline__ u32 half_min(u32 v, bool hi) {
 }
 __device__ __forceinline__ u32 bperm(u32 byte_addr, u32 v) { return (u32)__builtin_amdgcn_ds_bpermute((int)byte_addr, (int)v); }
 
-template <bool LAT0, bool DEG4>
+template <bool LAT0, bool DEG4, bool RND>
 __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
+  static_assert(!(RND && LAT0), "random latency needs deadlines");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const KParams &p = dp.k;
   const u32 lane = threadIdx.x, i = lane & 31u;
@@ -101,18 +124,32 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
   unsigned char *const hmem = smem + (hi ? dp.half_bytes : 0u);
   uint4 *const stage = reinterpret_cast<uint4 *>(hmem);
   u32 *const seen = reinterpret_cast<u32 *>(hmem + dp.off_seen);
-  u32 *const my_seen = is_node ? seen + i * W : seen + N * W + i;
-  u32 *const ring32 = reinterpret_cast<u32 *>(hmem + dp.off_ring) + i * R;       // LAT0: the envelope word
-  u64 *const ring64 = reinterpret_cast<u64 *>(hmem + dp.off_ring) + i * R;       // else deadline | envelope << 32
+  const u32 Wp = W | 1u;   // odd stride between the nodes' sets: word w of every node sits on a different LDS bank
+  u32 *const my_seen = is_node ? seen + i * Wp : seen + N * Wp + i;
+  // slot-major rings: slot s of lane i at [s * 32 + i] (a wave-wide access to one slot position is contiguous)
+  u32 *const ring32 = reinterpret_cast<u32 *>(hmem + dp.off_ring) + i;       // LAT0: the envelope word
+  u64 *const ring64 = reinterpret_cast<u64 *>(hmem + dp.off_ring) + i;       // else deadline | envelope << 32
+  // RND: the node's queue is a bag of R entries (ring64[0 .. in_n)) with their arrival sequence numbers beside them; lanes that
+  // hold no node share one dummy bag; the spill holds {key, sequence} in 16 bytes
+  // (slot-major: slot j of node i at [j * (N + 1) + i] — a wave-wide access to one slot is contiguous, free of bank conflicts;
+  //  lane-major bags of 128 bytes put every lane on the same banks)
+  const u32 BS = N + 1u;   // lanes per slot: the nodes and one dummy shared by the lanes that hold no node
+  u64 *const bag = reinterpret_cast<u64 *>(hmem + dp.off_ring) + (is_node ? i : N);
+  unsigned short *const bag_seq = reinterpret_cast<unsigned short *>(hmem + dp.off_seq) + (is_node ? i : N);
+#define BAG(j_) bag[(j_) * BS]
+#define BAGSEQ(j_) bag_seq[(j_) * BS]
+  u32 *const my_spill12 = p.scratch + (size_t)inst * p.scratch_words + p.spill_off + (size_t)(is_node ? i : 0) * p.spill_cap * 4;   // {deadline, envelope, sequence} x S
+  u32 *const log2_tab = reinterpret_cast<u32 *>(smem + dp.off_log2);
 
-  for (u32 k = i; k < N * W + 32u; k += 32) seen[k] = 0;
+  for (u32 k = i; k < N * Wp + 32u; k += 32) seen[k] = 0;
+  if (RND) for (u32 k = lane; k < 257u; k += 64) log2_tab[k] = duo_log2_q24[k];
   __syncthreads();
 
   const u32 adj = is_node ? topo_adj(p.cfg.topology, N, i) : 0u;
   const u32 hbase4 = (lane & 32u) << 2;  // byte address of the half's lane 0 for ds_bpermute
   // DEG4 (every node has <= 4 neighbours, lane 31 holds no node): the neighbours in ascending order as bpermute addresses
   // (an unused slot points at lane 31, which never publishes) and the constant part of an envelope received from each
-  u32 nbl[4] = {0, 0, 0, 0}, kc[4] = {0, 0, 0, 0};
+  u32 nbl[4] = {0, 0, 0, 0}, kc[4] = {0, 0, 0, 0}, nb_adj[4] = {0, 0, 0, 0};   // nb_adj (RND): the neighbour's own adjacency mask
   if (DEG4) {
     u32 rem = adj;
 #pragma unroll
@@ -120,6 +157,7 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
       const u32 s = rem ? (u32)__builtin_ctz(rem) : 31u;
       rem &= rem - 1u;
       nbl[k] = hbase4 + (s << 2); kc[k] = s << 16;
+      if (RND) nb_adj[k] = s < N ? topo_adj(p.cfg.topology, N, s) : 0u;
     }
   }
 
@@ -134,6 +172,12 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
   // ---- per-cluster state (uniform within a half) ----
   u32 T = 0, phase = PH_INIT, cutoff = 0, gen_next = 0, gen_k = 0, next_value = 0, sleep_until = 0;
   u32 n_rows = 0, n_payload = 0, flags = 0, rounds = 0;
+  u32 next_id = 0;           // RND: message ids (net.clj:103,197), every send! of the cluster in canonical order
+  u32 my_seq = 0;            // RND (per lane): arrivals queued at this node so far
+  u32 spm_dl = INF, spm_seq = 0, spm_e = 0, spm_i = 0;   // RND: the minimum of the spilled part of the bag, cached in registers
+  u32 pbase = 0;             // RND (per lane): id of the first message this node sends in the current round
+  const u32 lat_mean = p.cfg.latency_mean_ms;
+  const bool lat_uniform = p.cfg.latency_dist == MSIM_LAT_UNIFORM;
   u32 alive = real ? 1u : 0u;
   // when the scheduler next acts (INF: it only waits), and whether every round has to be a GENERAL one until it says otherwise;
   // both change in GENERAL rounds only
@@ -150,20 +194,33 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
   // of their addresses.
   // recv! took an envelope: (Thread/sleep (long dt)), net.clj:236-238
 #define DUO_COMMIT_TIME(dl_) (LAT0 ? T : ((dl_) <= T ? T : T + (((dl_) - T) / 1000u) * 1000u))
-#define DUO_RING_STORE(slot_, e_, dl_) do { if (LAT0) ring32[(slot_)] = (e_); else ring64[(slot_)] = (u64)(dl_) | ((u64)(e_) << 32); } while (0)
+#define DUO_RING_STORE(slot_, e_, dl_) do { if (LAT0) ring32[(slot_) * 32u] = (e_); else ring64[(slot_) * 32u] = (u64)(dl_) | ((u64)(e_) << 32); } while (0)
 #define DUO_SEEN_WORD() (reinterpret_cast<u32 *>(reinterpret_cast<unsigned char *>(my_seen) + ((cm >> 3) & 0x1FFCu)))   /* word (value >> 5) */
   // slow, checked append: ring, then spill; used when a ring may fill up this round
 #define DUO_PUSH_CHECKED(got_, e_, dl_) do {                                                                              \
     const bool pc_got = (got_); const u32 pc_e = (e_), pc_dl = (dl_);                                                     \
-    const bool pc_fit = (in_n < R) & (sp_n == 0);                                                                         \
-    if (pc_got & pc_fit) {                                                                                                \
-      DUO_RING_STORE((head + in_n) & Rm, pc_e, pc_dl);                                                                    \
-      if (in_n == 0) { nx = pc_e; nx_dl = pc_dl; }                                                                        \
-      in_n++;                                                                                                             \
-    }                                                                                                                     \
-    if (pc_got & !pc_fit) {                                                                                               \
-      if (sp_n >= S) my_flags |= MSIM_FLAG_INBOX_OVERFLOW;                                                                \
-      else { u32 pc_idx = s_head + sp_n; if (pc_idx >= S) pc_idx -= S; my_spill[pc_idx] = (u64)pc_dl | ((u64)pc_e << 32); sp_n++; } \
+    if (RND) {   /* a bag: append with the node's arrival sequence number (orders equal deadlines like the ids do) */      \
+      if (pc_got) {                                                                                                       \
+        if (in_n < R) { BAG(in_n) = (u64)pc_dl | ((u64)pc_e << 32); BAGSEQ(in_n) = (unsigned short)my_seq; in_n++; }     \
+        else if (sp_n < S) {                                                                                              \
+          my_spill12[3 * sp_n] = pc_dl; my_spill12[3 * sp_n + 1] = pc_e; my_spill12[3 * sp_n + 2] = my_seq & 0xFFFFu;     \
+          if (sp_n == 0 || pc_dl < spm_dl) { spm_dl = pc_dl; spm_seq = my_seq & 0xFFFFu; spm_e = pc_e; spm_i = sp_n; }   /* (equal deadline: the older one stays) */ \
+          sp_n++;                                                                                                         \
+        }                                                                                                                 \
+        else my_flags |= MSIM_FLAG_INBOX_OVERFLOW;                                                                        \
+        my_seq++;                                                                                                         \
+      }                                                                                                                   \
+    } else {                                                                                                              \
+      const bool pc_fit = (in_n < R) & (sp_n == 0);                                                                       \
+      if (pc_got & pc_fit) {                                                                                              \
+        DUO_RING_STORE((head + in_n) & Rm, pc_e, pc_dl);                                                                  \
+        if (in_n == 0) { nx = pc_e; nx_dl = pc_dl; }                                                                      \
+        in_n++;                                                                                                           \
+      }                                                                                                                   \
+      if (pc_got & !pc_fit) {                                                                                             \
+        if (sp_n >= S) my_flags |= MSIM_FLAG_INBOX_OVERFLOW;                                                              \
+        else { u32 pc_idx = s_head + sp_n; if (pc_idx >= S) pc_idx -= S; my_spill[pc_idx] = (u64)pc_dl | ((u64)pc_e << 32); sp_n++; } \
+      }                                                                                                                   \
     }                                                                                                                     \
   } while (0)
   // idle receivers poll (net.clj:223-247): the minimum (deadline, id) = the FIFO head, or the client's request if its deadline
@@ -171,7 +228,48 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
   // Ends with the prefetch of the next head and of the set word of the (new) envelope.
 #define DUO_POLL() do {                                                                                                   \
     const bool pl_idle = deliver_at == INF;                                                                               \
-    if (LAT0) {                                                                                                           \
+    if (RND) {                                                                                                            \
+      /* recv! takes the minimum (deadline, id) of the bag — even if it is not due (net.clj:228-229) — and sleeps on it.  All 16   \
+         slots of the LDS bag are read in one go (ten 16-byte reads, one wait) and reduced as 64-bit keys                          \
+         deadline << 20 | arrival sequence relative to the newest (16 bits) << 4 | slot; free slots count as infinity. */          \
+      const bool pl_go = pl_idle & ((in_n | sp_n) != 0);                                                                  \
+      if (__ballot(pl_go)) {                                                                                              \
+        const u32 pl_sb = 32768u - my_seq;                                                                                \
+        u64 pl_m[16];                                                                                                     \
+        _Pragma("unroll") for (int pl_j = 0; pl_j < 16; pl_j++) {                                                         \
+          const u32 pl_d = (u32)BAG(pl_j); const u32 pl_q = BAGSEQ(pl_j);                                                 \
+          const u64 pl_k = ((u64)pl_d << 20) | (u64)((((pl_q + pl_sb) & 0xFFFFu) << 4) | (u32)pl_j);                      \
+          pl_m[pl_j] = (u32)pl_j < in_n ? pl_k : ~0ull;                                                                   \
+        }                                                                                                                 \
+        _Pragma("unroll") for (int pl_w = 8; pl_w >= 1; pl_w >>= 1)                                                       \
+          _Pragma("unroll") for (int pl_j = 0; pl_j < pl_w; pl_j++) pl_m[pl_j] = pl_m[pl_j] < pl_m[pl_j + pl_w] ? pl_m[pl_j] : pl_m[pl_j + pl_w]; \
+        u64 pl_best = pl_m[0];                                                                                            \
+        u32 pl_bi = (u32)pl_best & 15u, pl_be = 0; bool pl_sp = false;                                                    \
+        /* the spilled part of the bag (HBM) takes part through its cached minimum: no memory access unless it wins */      \
+        const u64 pl_sk = sp_n != 0 ? (((u64)spm_dl << 20) | (u64)(((spm_seq + pl_sb) & 0xFFFFu) << 4)) : ~0ull;           \
+        pl_sp = pl_go & (pl_sk < (pl_best & ~15ull));                                                                     \
+        if (pl_go) {                                                                                                      \
+          if (!pl_sp) {   /* remove it from the LDS bag: the last entry takes its place */                                 \
+            pl_be = (u32)(BAG(pl_bi) >> 32);                                                                              \
+            in_n--;                                                                                                       \
+            if (pl_bi != in_n) { BAG(pl_bi) = BAG(in_n); BAGSEQ(pl_bi) = BAGSEQ(in_n); }                                  \
+            cm = pl_be; const u32 pl_bd = (u32)(pl_best >> 20); deliver_at = DUO_COMMIT_TIME(pl_bd);                      \
+          } else { cm = spm_e; deliver_at = DUO_COMMIT_TIME(spm_dl); }                                                    \
+        }                                                                                                                 \
+        if (__ballot(pl_sp)) {   /* rare: a spilled envelope was taken — close the gap and find the new minimum of the spill */ \
+          if (pl_sp) {                                                                                                    \
+            sp_n--;                                                                                                       \
+            if (spm_i != sp_n) { my_spill12[3 * spm_i] = my_spill12[3 * sp_n]; my_spill12[3 * spm_i + 1] = my_spill12[3 * sp_n + 1]; my_spill12[3 * spm_i + 2] = my_spill12[3 * sp_n + 2]; } \
+            spm_dl = INF; u64 pl_mk = ~0ull;                                                                              \
+            for (u32 pl_j = 0; pl_j < sp_n; pl_j++) {                                                                     \
+              const u32 pl_d = my_spill12[3 * pl_j], pl_e2 = my_spill12[3 * pl_j + 1], pl_q = my_spill12[3 * pl_j + 2];   \
+              const u64 pl_k = ((u64)pl_d << 20) | (u64)(((pl_q + pl_sb) & 0xFFFFu) << 4);                                \
+              if (pl_k < pl_mk) { pl_mk = pl_k; spm_dl = pl_d; spm_seq = pl_q; spm_e = pl_e2; spm_i = pl_j; }             \
+            }                                                                                                             \
+          }                                                                                                               \
+        }                                                                                                                 \
+      }                                                                                                                   \
+    } else if (LAT0) {                                                                                                    \
       const bool pl_can = pl_idle & (in_n != 0);                                                                          \
       cm = pl_can ? nx : cm; deliver_at = pl_can ? T : deliver_at;                                                        \
       head = (head + (pl_can ? 1u : 0u)) & Rm; in_n -= pl_can ? 1u : 0u;                                                  \
@@ -187,15 +285,17 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
       have_creq = pl_c ? 0u : have_creq;                                                                                  \
       head = (head + (pl_r ? 1u : 0u)) & Rm; in_n -= pl_r ? 1u : 0u;                                                      \
     }                                                                                                                     \
-    if (__ballot(sp_n != 0)) {   /* refill the ring from the spill: "ring empty" always means "queue empty" (rare) */      \
-      while (sp_n != 0 && in_n < R) {                                                                                     \
-        const u64 pl_s = my_spill[s_head];                                                                                \
-        s_head++; if (s_head >= S) s_head = 0; sp_n--;                                                                    \
-        DUO_RING_STORE((head + in_n) & Rm, (u32)(pl_s >> 32), (u32)pl_s);                                                 \
-        in_n++;                                                                                                           \
+    if (!RND) {                                                                                                           \
+      if (__ballot(sp_n != 0)) {   /* refill the ring from the spill: "ring empty" always means "queue empty" (rare) */    \
+        while (sp_n != 0 && in_n < R) {                                                                                   \
+          const u64 pl_s = my_spill[s_head];                                                                              \
+          s_head++; if (s_head >= S) s_head = 0; sp_n--;                                                                  \
+          DUO_RING_STORE((head + in_n) & Rm, (u32)(pl_s >> 32), (u32)pl_s);                                               \
+          in_n++;                                                                                                         \
+        }                                                                                                                 \
       }                                                                                                                   \
+      if (LAT0) nx = ring32[head * 32u]; else { const u64 pl_h = ring64[head * 32u]; nx_dl = (u32)pl_h; nx = (u32)(pl_h >> 32); } \
     }                                                                                                                     \
-    if (LAT0) nx = ring32[head]; else { const u64 pl_h = ring64[head]; nx_dl = (u32)pl_h; nx = (u32)(pl_h >> 32); }       \
     DUO_SW_PREFETCH();                                                                                                    \
   } while (0)
   // R3 for a broadcast envelope (gossip or the client's own): dedup against the node's set; pub_ = what the node publishes
@@ -217,12 +317,44 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
   // COMMIT of the fan-outs, receiver side: every node pulls what its neighbours publish, in ascending sender order (= id order,
   // net.clj:197), and appends it to its own queue.  got <=> the neighbour sends and does not skip this node:
   // z = (x & 0x803F0000) ^ (0x80000000 | me << 16) is > 0 exactly then (negative: not sending; 0: sending, skipping me).
+  // RND: the message's id = the sender's first id of the round + the rank of this node in the sender's fan-out (ascending
+  // destination, net.clj:197); its latency is drawn from the id (net.clj:178-187: uniform int in [0, 2 mean) or floor(mean * -ln u))
+#define DUO_RND_DEADLINE(x_, base_, fanadj_, dl_) do {                                                                    \
+    const u32 rd_src = ((x_) >> 16) & 63u;                                                                                \
+    const u32 rd_fan = dp.echoback ? (fanadj_) : ((fanadj_) & ~(rd_src < 32u ? (1u << rd_src) : 0u));                      \
+    const u32 rd_id = (base_) + __popc(rd_fan & lt);                                                                      \
+    const u32 rd_r = draw32(key, S_LATENCY, rd_id);                                                                       \
+    const u32 rd_ms = lat_uniform ? scale32(rd_r, 2u * lat_mean) : (u32)(((u64)lat_mean * duo_neg_ln_q16(rd_r, log2_tab)) >> 16); \
+    dl_ = T + rd_ms * 1000u;                                                                                              \
+  } while (0)
 #define DUO_ARRIVALS(pub_) do {                                                                                           \
     const u32 ar_dl = T + lat_us;                                                                                         \
     const u32 ar_zk = 0x80000000u | me16;                                                                                 \
     if (DEG4) {                                                                                                           \
       const u32 ar_x[4] = {bperm(nbl[0], pub_), bperm(nbl[1], pub_), bperm(nbl[2], pub_), bperm(nbl[3], pub_)};           \
-      if (__builtin_expect(!__ballot((in_n + 4u > R) | (sp_n != 0)), 1)) {                                                \
+      if (RND) {                                                                                                          \
+        const u32 ar_b[4] = {bperm(nbl[0], pbase), bperm(nbl[1], pbase), bperm(nbl[2], pbase), bperm(nbl[3], pbase)};     \
+        bool ar_g[4]; u32 ar_cnt = 0;                                                                                     \
+        _Pragma("unroll") for (int ar_k = 0; ar_k < 4; ar_k++) { ar_g[ar_k] = (int)((ar_x[ar_k] & 0x803F0000u) ^ ar_zk) > 0; ar_cnt += ar_g[ar_k] ? 1u : 0u; } \
+        n_arr += ar_cnt;                                                                                                  \
+        if (!__ballot(ar_cnt > 1u)) {                                                                                     \
+          /* the usual round: no node receives two envelopes — one latency draw serves every lane */                       \
+          u32 ar_xx = 0, ar_bb = 0, ar_aa = 0, ar_cc = 0;                                                                 \
+          _Pragma("unroll") for (int ar_k = 0; ar_k < 4; ar_k++) {                                                        \
+            ar_xx = ar_g[ar_k] ? ar_x[ar_k] : ar_xx; ar_bb = ar_g[ar_k] ? ar_b[ar_k] : ar_bb;                             \
+            ar_aa = ar_g[ar_k] ? nb_adj[ar_k] : ar_aa; ar_cc = ar_g[ar_k] ? kc[ar_k] : ar_cc;                             \
+          }                                                                                                               \
+          u32 ar_d; DUO_RND_DEADLINE(ar_xx, ar_bb, ar_aa, ar_d);                                                          \
+          DUO_PUSH_CHECKED(ar_cnt != 0u, (ar_xx & 0xFFFFu) | ar_cc, ar_d);                                                \
+        } else {                                                                                                          \
+          _Pragma("unroll") for (int ar_k = 0; ar_k < 4; ar_k++) {                                                        \
+            if (__ballot(ar_g[ar_k])) {                                                                                   \
+              u32 ar_d; DUO_RND_DEADLINE(ar_x[ar_k], ar_b[ar_k], nb_adj[ar_k], ar_d);                                     \
+              DUO_PUSH_CHECKED(ar_g[ar_k], (ar_x[ar_k] & 0xFFFFu) | kc[ar_k], ar_d);                                      \
+            }                                                                                                             \
+          }                                                                                                               \
+        }                                                                                                                 \
+      } else if (__builtin_expect(!__ballot((in_n + 4u > R) | (sp_n != 0)), 1)) {                                         \
         /* every ring has room for a full round of arrivals: plain stores at the tail, the count decides what stays */    \
         const u32 ar_in0 = in_n;                                                                                          \
         _Pragma("unroll") for (int ar_k = 0; ar_k < 4; ar_k++) {                                                          \
@@ -249,10 +381,27 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
         ar_rem &= ar_rem - 1u;                                                                                            \
         const u32 ar_xx = bperm(hbase4 + (ar_s << 2), pub_);                                                              \
         const bool ar_got = ar_has & ((int)((ar_xx & 0x803F0000u) ^ ar_zk) > 0);                                          \
+        u32 ar_d = ar_dl;                                                                                                 \
+        if (RND) {                                                                                                        \
+          const u32 ar_bb = bperm(hbase4 + (ar_s << 2), pbase);                                                           \
+          const u32 ar_sadj = bperm(hbase4 + (ar_s << 2), adj);                                                           \
+          if (__ballot(ar_got)) DUO_RND_DEADLINE(ar_xx, ar_bb, ar_sadj, ar_d);                                            \
+        }                                                                                                                 \
         n_arr += ar_got ? 1u : 0u;                                                                                        \
-        DUO_PUSH_CHECKED(ar_got, (ar_xx & 0xFFFFu) | (ar_s << 16), ar_dl);                                                \
+        DUO_PUSH_CHECKED(ar_got, (ar_xx & 0xFFFFu) | (ar_s << 16), ar_d);                                                 \
       }                                                                                                                   \
     }                                                                                                                     \
+  } while (0)
+  // RND: ids of this round's sends in canonical order (node order; a node's fan-out in ascending destination, then its reply):
+  // pbase = the node's first id; the cluster's id counter moves past all of them
+#define DUO_RND_IDS(pub_, rep_) do {                                                                                      \
+    const u32 id_src = (cm >> 16) & 63u;                                                                             \
+    const u32 id_fan = (pub_) == 0 ? 0u : (dp.echoback ? adj : (adj & ~(id_src < 32u ? (1u << id_src) : 0u)));            \
+    const u32 id_cnt = __popc(id_fan) + ((rep_) ? 1u : 0u);                                                               \
+    const u32 id_incl = scan32(id_cnt);                                                                                   \
+    pbase = next_id + id_incl - id_cnt;                                                                                   \
+    const u32 id_lo = rdlane(id_incl, 31), id_up = rdlane(id_incl, 63);                                                   \
+    next_id += hi ? id_up : id_lo;                                                                                        \
   } while (0)
 
 #ifdef DUO_PROF   // developer build (tools/duo_prof.sh): wave-round counts and cycles of the two round bodies -> meta
@@ -295,7 +444,10 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
         u32 pub; DUO_R3_SEEN(due_n, pub);
         deliver_at = due_n ? INF : deliver_at;
         n_rsv += due_n ? 1u : 0u;
-        if (__ballot(pub != 0)) DUO_ARRIVALS(pub);
+        if (__ballot(pub != 0)) {
+          if (RND) DUO_RND_IDS(pub, false);
+          DUO_ARRIVALS(pub);
+        }
         DUO_POLL();
       }
     }
@@ -341,7 +493,8 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
       inv_packed = MSIM_T_INVOKE | ((m_kind == DK_BCAST ? MSIM_F_BROADCAST : MSIM_F_READ) << 2) | ((m_kind == DK_READ_FINAL ? 1u : 0u) << 11) | (i << 12);
       inv_value = m_kind == DK_BCAST ? m_val : MSIM_NO_VALUE;
       const u32 e = (m_kind == DK_BCAST ? m_val : 0u) | (63u << 16) | (m_kind << 24);
-      if (LAT0) {
+      if (RND) next_id += __popc(hb(inv, hi));   // the requests' ids, slot order (their latency is 0: no draw)
+      if (LAT0 || RND) {
         const bool direct = inv & (deliver_at == INF);   // an idle node's recv! takes the request at once (its queue is empty)
         cm = direct ? e : cm; deliver_at = direct ? T : deliver_at;
         DUO_PUSH_CHECKED(inv & !direct, e, T);
@@ -386,11 +539,12 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
         m &= m - 1u;
         const u32 r_off = bperm(hbase4 + (r << 2), my_off);
         for (u32 w = i; __ballot(on && w < words); w += 32)
-          if (on && w < words) g_pay[r_off + w] = seen[r * W + w];
+          if (on && w < words) g_pay[r_off + w] = seen[r * Wp + w];
       }
       n_payload += __popc(okm) * words;
     }
 
+    if (RND) { if (__ballot((pub != 0) | req)) DUO_RND_IDS(pub, req); }
     if (__ballot(pub != 0)) DUO_ARRIVALS(pub);
     DUO_POLL();
 
@@ -402,10 +556,15 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
       if (ovf) { flags |= MSIM_FLAG_ROWS_OVERFLOW; alive = 0; }
       const u64 tns = (u64)T * 1000ull;
       const u32 tlo = (u32)tns, thi = (u32)(tns >> 32);
-      if (inv_row != 0 && !ovf) stage[(n_rows + __popc(imask & lt)) % DUO_STAGE_ROWS] = make_uint4(tlo, thi, inv_packed, inv_value);
-      if (cmp_row != 0 && !ovf) stage[(n_rows + ni + __popc(cmask & lt)) % DUO_STAGE_ROWS] = make_uint4(tlo, thi | (cmp_len << 16), cmp_packed, cmp_value);
+      if (RND) {   // the bags of the random-latency layout take the LDS a staging area would need: rows go straight to HBM
+        if (inv_row != 0 && !ovf) reinterpret_cast<uint4 *>(g_rows)[n_rows + __popc(imask & lt)] = make_uint4(tlo, thi, inv_packed, inv_value);
+        if (cmp_row != 0 && !ovf) reinterpret_cast<uint4 *>(g_rows)[n_rows + ni + __popc(cmask & lt)] = make_uint4(tlo, thi | (cmp_len << 16), cmp_packed, cmp_value);
+      } else {
+        if (inv_row != 0 && !ovf) stage[(n_rows + __popc(imask & lt)) % DUO_STAGE_ROWS] = make_uint4(tlo, thi, inv_packed, inv_value);
+        if (cmp_row != 0 && !ovf) stage[(n_rows + ni + __popc(cmask & lt)) % DUO_STAGE_ROWS] = make_uint4(tlo, thi | (cmp_len << 16), cmp_packed, cmp_value);
+      }
       const u32 new_n = ovf ? n_rows : n_rows + nr;
-      const bool flush = (new_n >> 6) != (n_rows >> 6);   // a 64-row block completed (at most one per round: nr <= 64)
+      const bool flush = !RND && (new_n >> 6) != (n_rows >> 6);   // a 64-row block completed (at most one per round: nr <= 64)
       if (__ballot(flush)) {
         __syncthreads();
         if (flush) {
@@ -461,8 +620,8 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
   __syncthreads();
   {
     const u32 g0 = (n_rows >> 6) * 64u + i;
-    if (real && g0 < n_rows) reinterpret_cast<uint4 *>(g_rows)[g0] = stage[g0 % DUO_STAGE_ROWS];
-    if (real && g0 + 32u < n_rows) reinterpret_cast<uint4 *>(g_rows)[g0 + 32u] = stage[(g0 + 32u) % DUO_STAGE_ROWS];
+    if (!RND && real && g0 < n_rows) reinterpret_cast<uint4 *>(g_rows)[g0] = stage[g0 % DUO_STAGE_ROWS];
+    if (!RND && real && g0 + 32u < n_rows) reinterpret_cast<uint4 *>(g_rows)[g0 + 32u] = stage[(g0 + 32u) % DUO_STAGE_ROWS];
   }
   const u32 sc_cl = wave_incl_scan(n_cl), sc_arr = wave_incl_scan(n_arr), sc_rsv = wave_incl_scan(n_rsv);
   const u32 lo_cl = rdlane(sc_cl, 31), lo_arr = rdlane(sc_arr, 31), lo_rsv = rdlane(sc_rsv, 31);
@@ -492,9 +651,12 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
 bool msim_duo_eligible(const msim_config &c) {
   if (c.node_program != MSIM_NODE_BCAST_FF && c.node_program != MSIM_NODE_BCAST_FF_ECHOBACK) return false;
   if (c.n_nodes > 32 || c.concurrency != c.n_nodes) return false;
-  if (c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0 || c.nemesis_mask != 0 || c.journal_capacity != 0) return false;
-  // an RPC completes within one latency of virtual time: no client timeout can fire (client.clj:96-103, db.clj:54)
-  if (c.latency_mean_ms >= c.client_timeout_ms || c.latency_mean_ms >= 10000u) return false;
+  if (c.p_loss_q32 != 0 || c.nemesis_mask != 0 || c.journal_capacity != 0) return false;
+  // an RPC completes within one (maximal) latency of virtual time: no client timeout can fire (client.clj:96-103, db.clj:54).
+  // constant: the mean; uniform: below 2 x mean; exponential: mean x -ln(2^-32) < 22.2 x mean
+  const uint64_t worst = c.latency_dist == MSIM_LAT_CONSTANT ? c.latency_mean_ms : c.latency_dist == MSIM_LAT_UNIFORM ? 2ull * c.latency_mean_ms : 23ull * c.latency_mean_ms;
+  if (worst >= c.client_timeout_ms || worst >= 10000u) return false;
+  if (c.latency_dist != MSIM_LAT_CONSTANT && (uint64_t)c.inbox_capacity + c.spill_capacity >= 16384u) return false;   // 16-bit arrival sequence numbers
   if (c.max_values > 65536u) return false;   // a value travels in 16 bits of the envelope word
   return true;
 }
@@ -516,39 +678,56 @@ static uint32_t duo_degree(const msim_config &c) {
   return d;
 }
 
-// Launches the duo kernel for n clusters on `st`; returns hipErrorInvalidValue if the cluster state does not fit the LDS.
+template <bool LAT0, bool DEG4, bool RND>
+static hipError_t duo_launch(const DuoParams &dp, dim3 grid, size_t lds, hipStream_t st) {
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sim_kernel_duo<LAT0, DEG4, RND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL((sim_kernel_duo<LAT0, DEG4, RND>), grid, dim3(64), lds, st, dp);
+  return hipGetLastError();
+}
+
+// Launches the duo kernel for n clusters on `st`; returns hipErrorInvalidValue if the cluster state does not fit (the caller
+// then runs the one-cluster-per-wavefront kernels).
 hipError_t msim_launch_duo(const KParams &kp, uint32_t n, hipStream_t st) {
   const msim_config &c = kp.cfg;
   DuoParams dp;
   dp.k = kp; dp.n_inst = n;
-  const bool lat0 = c.latency_mean_ms == 0;
-  const uint32_t esz = lat0 ? 4u : 8u;
+  const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT;
+  const bool lat0 = !rnd && c.latency_mean_ms == 0;
   const uint32_t cap_tot = c.inbox_capacity + c.spill_capacity;
-  uint32_t R = 8; while (R < c.inbox_capacity) R <<= 1;   // >= 8: room for a round of arrivals on the fast path
-  while (R > 4 && (size_t)32 * R * esz > 4096) R >>= 1;   // keep a cluster's 32 rings within 4 KiB of LDS
-  if (R > cap_tot) { R = 2; while (R * 2 <= cap_tot) R <<= 1; }
-  dp.R = R; dp.S = cap_tot > R ? cap_tot - R : 0;
-  if (dp.S > 2 * c.spill_capacity) return hipErrorInvalidValue;   // the spill area holds 2 x spill_capacity 8-byte entries per node
-  size_t off = DUO_STAGE_ROWS * 16;
-  dp.off_ring = (u32)off; off += (size_t)32 * R * esz;
+  // LDS of one cluster = [row staging (not RND)] [queues] [node sets + a dummy word per lane].  The queues take what keeps EIGHT
+  // wavefronts on a CU (20 KiB each: BASELINE's 4096 clusters are 2048 wavefronts on 256 CUs — a ninth would run alone in a second
+  // pass), at least 8 entries per node; what does not fit goes to the HBM spill area.
+  const size_t seen_bytes = (((size_t)kp.N * (kp.W | 1u) + 32) * 4 + 15) & ~(size_t)15;   // odd stride between the nodes' sets
+  const size_t fixed = seen_bytes + (rnd ? 0 : DUO_STAGE_ROWS * 16);
+  const size_t per_entry = rnd ? 0 : (size_t)32 * (lat0 ? 4 : 8);   // (RND: bags of a fixed 16 entries)
+  const size_t budget = (20 * 1024 - (rnd ? 257 * 4 + 16 : 0)) / 2;
+  uint32_t R = rnd ? 16 : 8;
+  while (!rnd && R < 64 && R < cap_tot && fixed + ((per_entry * (R * 2) + 15) & ~(size_t)15) + 32 <= budget && (rnd || R < c.inbox_capacity)) R <<= 1;
+  if (!rnd && R > cap_tot) { R = 2; while (R * 2 <= cap_tot) R <<= 1; }
+  if (rnd && R > cap_tot) R = cap_tot ? cap_tot : 1;
+  dp.S = cap_tot > R ? cap_tot - R : 0;
+  // the spill area is spill_capacity x 16 bytes per node: 8-byte ring entries (constant latency) or 12-byte bag entries (RND)
+  if ((size_t)dp.S * (rnd ? 12 : 8) > (size_t)c.spill_capacity * 16) return hipErrorInvalidValue;
+  if (rnd) { hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(duo_log2_q24), msim_log2_q24, sizeof(msim_log2_q24)); if (e != hipSuccess) return e; }   // (per device; 1 KiB)
+  size_t off = rnd ? 0 : DUO_STAGE_ROWS * 16;
+  dp.off_ring = (u32)off; off += rnd ? (size_t)(kp.N + 1) * 16 * 8 : (size_t)32 * R * (lat0 ? 4 : 8);
+  dp.off_seq = (u32)off; if (rnd) off += (((size_t)(kp.N + 1) * 16 * 2) + 15) & ~(size_t)15;
+  dp.R = R;
   off = (off + 15) & ~(size_t)15;
-  dp.off_seen = (u32)off; off += ((size_t)kp.N * kp.W + 32) * 4;   // + a dummy word per lane
-  off = (off + 15) & ~(size_t)15;
+  dp.off_seen = (u32)off; off += seen_bytes;
   dp.half_bytes = (u32)off;
+  dp.off_log2 = (u32)(2 * off);
   dp.deg = duo_degree(c);
   dp.echoback = c.node_program == MSIM_NODE_BCAST_FF_ECHOBACK;
   dp.round_limit = (kp.dev_flags & 0x100u) ? 2000000u : ROUND_LIMIT;
-  const size_t lds = 2 * off;
+  const size_t lds = 2 * off + (rnd ? 257 * 4 + 12 : 0);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   const bool deg4 = dp.deg <= 4 && kp.N <= 31;   // (lane 31 must hold no node: unused neighbour slots point at it)
-  const void *fn = lat0 ? (deg4 ? reinterpret_cast<const void *>(&sim_kernel_duo<true, true>) : reinterpret_cast<const void *>(&sim_kernel_duo<true, false>))
-                        : (deg4 ? reinterpret_cast<const void *>(&sim_kernel_duo<false, true>) : reinterpret_cast<const void *>(&sim_kernel_duo<false, false>));
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-  }
-  const dim3 grid((n + 1) / 2), block(64);
-  if (lat0) { if (deg4) hipLaunchKernelGGL((sim_kernel_duo<true, true>), grid, block, lds, st, dp); else hipLaunchKernelGGL((sim_kernel_duo<true, false>), grid, block, lds, st, dp); }
-  else { if (deg4) hipLaunchKernelGGL((sim_kernel_duo<false, true>), grid, block, lds, st, dp); else hipLaunchKernelGGL((sim_kernel_duo<false, false>), grid, block, lds, st, dp); }
-  return hipGetLastError();
+  const dim3 grid((n + 1) / 2);
+  if (rnd) return deg4 ? duo_launch<false, true, true>(dp, grid, lds, st) : duo_launch<false, false, true>(dp, grid, lds, st);
+  if (lat0) return deg4 ? duo_launch<true, true, false>(dp, grid, lds, st) : duo_launch<true, false, false>(dp, grid, lds, st);
+  return deg4 ? duo_launch<false, true, false>(dp, grid, lds, st) : duo_launch<false, false, false>(dp, grid, lds, st);
 }

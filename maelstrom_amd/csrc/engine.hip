@@ -940,8 +940,12 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   e = hipGetLastError();
 #else
   // the headline layout: two clusters per wavefront (duo.hip); MSIM_DEV_FLAGS bit 9 keeps the one-cluster kernels
-  if (msim_duo_eligible(c) && !(kp.dev_flags & 0x200u)) e = msim_launch_duo(kp, n, st);
-  else switch (c.node_program) {
+  e = hipErrorInvalidValue;
+  if (msim_duo_eligible(c) && !(kp.dev_flags & 0x200u)) {
+    e = msim_launch_duo(kp, n, st);
+    if (e == hipErrorInvalidValue && (kp.dev_flags & 0x400u)) { ctx->err = "MSIM_DEV_FLAGS bit 10: the two-clusters-per-wavefront layout was required but this cluster state does not fit it"; return MSIM_E_UNSUPPORTED; }
+  }
+  if (e == hipErrorInvalidValue) switch (c.node_program) {   // not eligible, or the cluster state does not fit the duo layout
     case MSIM_NODE_ECHO: e = launch<MSIM_NODE_ECHO>(kp, n, lds, st); break;
     case MSIM_NODE_BCAST_FF: e = launch<MSIM_NODE_BCAST_FF>(kp, n, lds, st); break;
     case MSIM_NODE_BCAST_FF_ECHOBACK: e = launch<MSIM_NODE_BCAST_FF_ECHOBACK>(kp, n, lds, st); break;

@@ -26,6 +26,12 @@ CASES = {
     "n25-total": (dict(workload="broadcast", node_count=25, rate=20, time_limit=10, latency=20, topology="total", seed=123), 1000, 3),
     "n32-grid": (dict(workload="broadcast", node_count=32, rate=100, time_limit=10, latency=5, seed=123), 1000, 3),
     "n9-echoback": (dict(workload="broadcast", bin="broadcast-ff-echoback", node_count=9, rate=100, time_limit=10, seed=123), 1000, 3),
+    "n25-exp100": (dict(workload="broadcast", node_count=25, rate=100, time_limit=20, latency=100, latency_dist="exponential", seed=99), 0, 4),
+    "n25-uni50": (dict(workload="broadcast", node_count=25, rate=100, time_limit=20, latency=50, latency_dist="uniform", seed=42), 100, 4),
+    "n5-exp20": (dict(workload="broadcast", node_count=5, rate=20, time_limit=5, latency=20, latency_dist="exponential", seed=3), 0, 6),
+    "n25-total-exp": (dict(workload="broadcast", node_count=25, rate=20, time_limit=10, latency=20, latency_dist="exponential", topology="total", seed=123), 1000, 3),
+    "n5-exp200-tiny": (dict(workload="broadcast", node_count=5, rate=50, time_limit=5, latency=200, latency_dist="exponential", seed=9, inbox_capacity=2), 0, 6),
+    "n9-echoback-uni": (dict(workload="broadcast", bin="broadcast-ff-echoback", node_count=9, rate=100, time_limit=10, latency=30, latency_dist="uniform", seed=123), 1000, 3),
     "n12-spill": (dict(workload="broadcast", node_count=12, latency=30, rate=300, time_limit=10, inbox_capacity=2, spill_capacity=64, seed=123), 1000, 3),
 }
 
