@@ -845,7 +845,9 @@ static uint64_t proto_scratch_words(const msim_config &c) {
 }
 static uint64_t scratch_words(const msim_config &c) {
   const uint64_t queues = c.n_nodes + (c.node_program == MSIM_NODE_TXN_SINGLE_KEY || c.node_program == MSIM_NODE_LIN_KV_PROXY ? 1 : 0);  // + the service
-  return proto_scratch_words(c) + queues * c.spill_capacity * 4;
+  uint64_t w = proto_scratch_words(c) + queues * c.spill_capacity * 4;
+  if (msim_raft4_eligible(c)) w += msim_raft4_extra_scratch_words(c);   // raft4.hip keeps fewer envelopes in LDS
+  return w;
 }
 
 static int ensure_buffers(msim_ctx *ctx, uint32_t n) {
@@ -945,6 +947,9 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
     e = msim_launch_duo(kp, n, st);
     if (e == hipErrorInvalidValue && (kp.dev_flags & 0x400u)) { ctx->err = "MSIM_DEV_FLAGS bit 10: the two-clusters-per-wavefront layout was required but this cluster state does not fit it"; return MSIM_E_UNSUPPORTED; }
   }
+  // Raft: four clusters per wavefront (raft4.hip) when a cluster fits a 16-lane group
+  if (msim_raft4_eligible(c) && !(kp.dev_flags & 0x200u)) e = msim_launch_raft4(kp, n, st);
+  if (e == hipErrorInvalidValue && (kp.dev_flags & 0x400u) && is_raft) { ctx->err = "MSIM_DEV_FLAGS bit 10: the four-clusters-per-wavefront Raft layout was required but does not apply"; return MSIM_E_UNSUPPORTED; }
   if (e == hipErrorInvalidValue) switch (c.node_program) {   // not eligible, or the cluster state does not fit the duo layout
     case MSIM_NODE_ECHO: e = launch<MSIM_NODE_ECHO>(kp, n, lds, st); break;
     case MSIM_NODE_BCAST_FF: e = launch<MSIM_NODE_BCAST_FF>(kp, n, lds, st); break;

@@ -127,5 +127,9 @@ __device__ __forceinline__ u32 topo_adj(u32 topology, u32 n, u32 a) {
 // duo.hip: two clusters per wavefront (fire-and-forget broadcast, constant latency, colocated clients)
 bool msim_duo_eligible(const msim_config &c);
 hipError_t msim_launch_duo(const KParams &kp, uint32_t n, hipStream_t st);
+// raft4.hip: four Raft clusters per wavefront (lin-kv over the Raft node program, clusters of <= 16 endpoints)
+bool msim_raft4_eligible(const msim_config &c);
+uint64_t msim_raft4_extra_scratch_words(const msim_config &c);
+hipError_t msim_launch_raft4(const KParams &kp, uint32_t n, hipStream_t st);
 
 #endif

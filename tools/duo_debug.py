@@ -32,6 +32,13 @@ CASES = {
     "n25-total-exp": (dict(workload="broadcast", node_count=25, rate=20, time_limit=10, latency=20, latency_dist="exponential", topology="total", seed=123), 1000, 3),
     "n5-exp200-tiny": (dict(workload="broadcast", node_count=5, rate=50, time_limit=5, latency=200, latency_dist="exponential", seed=9, inbox_capacity=2), 0, 6),
     "n9-echoback-uni": (dict(workload="broadcast", bin="broadcast-ff-echoback", node_count=9, rate=100, time_limit=10, latency=30, latency_dist="uniform", seed=123), 1000, 3),
+    "raft": (dict(workload="lin-kv", bin="raft", node_count=5, rate=30, time_limit=20, seed=17), 0, 6),
+    "raft-lat10": (dict(workload="lin-kv", bin="raft", node_count=5, rate=30, time_limit=20, seed=17, latency=10), 0, 6),
+    "raft-exp-loss": (dict(workload="lin-kv", bin="raft", node_count=5, rate=30, time_limit=20, seed=17, latency=20, latency_dist="exponential", p_loss=0.02), 0, 6),
+    "raft-part": (dict(workload="lin-kv", bin="raft", node_count=5, rate=30, time_limit=20, seed=17, nemesis=["partition"], nemesis_interval=5, latency=5), 0, 6),
+    "raft-n3c6": (dict(workload="lin-kv", bin="raft", node_count=3, concurrency=6, nemesis=["partition"], nemesis_interval=4, time_limit=30, latency=10, latency_dist="uniform", rate=30, seed=17), 0, 7),
+    "raft-n1": (dict(workload="lin-kv", bin="raft", node_count=1, rate=50, time_limit=10, seed=5), 0, 5),
+    "raft-n4c8": (dict(workload="lin-kv", bin="raft", node_count=4, concurrency=8, rate=40, time_limit=15, latency=3, seed=5), 0, 5),
     "n12-spill": (dict(workload="broadcast", node_count=12, latency=30, rate=300, time_limit=10, inbox_capacity=2, spill_capacity=64, seed=123), 1000, 3),
 }
 
