@@ -254,9 +254,18 @@ int msim_run(msim_ctx *ctx, uint64_t first_instance, uint32_t n_instances);
  * and returns; the caller synchronises the stream. */
 int msim_run_async(msim_ctx *ctx, uint64_t first_instance, uint32_t n_instances, void *hip_stream);
 
-/* Runs the workload checker (set-full / echo) for every instance of the last run, on the device,
- * reading the HBM-resident histories.  Blocking.  Results via msim_check_results. */
+/* Runs the workload checker for every instance of the last run, reading the HBM-resident histories.  On the device:
+ * set-full (broadcast, g-set), echo, and lin-kv's per-key linearizability (one wavefront per history; a history that
+ * exceeds what a wavefront's registers hold is finished by the host search, see msim_check_host_rechecks).  On the host
+ * cores, after a fetch: list-append / rw-register (elle), pn-counter, unique-ids.  Blocking.  Results via msim_check_results. */
 int msim_check(msim_ctx *ctx);
+
+/* How many histories of the last msim_check the device handed to the host search (lin-kv only; else 0). */
+uint32_t msim_check_host_rechecks(const msim_ctx *ctx);
+
+/* lin-kv: checks `n_histories` histories given on the host — history i = rows[row_offsets[i] .. row_offsets[i + 1]) — with the
+ * device search of msim_check on HIP device `device`; out[i] is what msim_check_lin_kv_rows gives for history i. */
+int msim_check_lin_kv_batch(int device, const msim_op *rows, const uint64_t *row_offsets, uint32_t n_histories, msim_check_result *out);
 
 /* Host-only utility behind msim_check for lin-kv: per-key linearizability (CAS-register model) of ONE history given
  * as rows — what `independent/checker` + Knossos do for workload/lin_kv.clj:84.  out->valid: 1 linearizable, 0 not,

@@ -47,6 +47,7 @@ struct msim_ctx {
   uint64_t *d_sizes = nullptr;   // world x 4 u64 for the size all-gather
   bool fetched = false, checked = false, check_fetched = false, ran = false;
   float sim_ms = 0.f, check_ms = 0.f;
+  uint32_t lin_host_rechecks = 0;   // lin_check_dev.hip: histories of the last check the host search had to finish
   std::string err;
 };
 
@@ -76,8 +77,9 @@ int msim_compact_on_device(msim_ctx *ctx, uint64_t *row_units, uint64_t *pay_wor
 void msim_gather_free(msim_ctx *ctx);
 // checker.hip
 int msim_check_launch(msim_ctx *ctx);
-// lin_check.cpp
+// lin_check.cpp (host search) / lin_check_dev.hip (one wavefront per history)
 int msim_check_lin_kv_host(msim_ctx *ctx);
+int msim_check_lin_kv_device(msim_ctx *ctx);
 // txn_check.cpp
 int msim_check_txn_host(msim_ctx *ctx);
 // pn_check.cpp

@@ -7,7 +7,8 @@
 // linearized); when an op returns, every surviving configuration must have linearized it.  :fail ops never
 // happened; :info ops stay pending forever (they may take effect at any later time, or never).
 // Histories are small per key (process-limit 20 retires a key), so this runs on the host cores, one
-// thread per slice of instances.  A device version is future work.
+// thread per slice of instances.  msim_check runs the device version (lin_check_dev.hip, one wavefront per history) and
+// comes here only for histories that exceed it; MSIM_DEV_FLAGS bit 11 keeps everything on the host.
 #include <algorithm>
 #include <chrono>
 #include <cstring>
@@ -145,6 +146,9 @@ void check_instance(const msim_op *rows, uint32_t n_rows, uint32_t flags, msim_c
 
 }  // namespace
 
+// the host search for one history (lin_check_dev.hip hands over what exceeds the device's registers)
+void msim_lin_check_instance_host(const msim_op *rows, uint32_t n_rows, uint32_t flags, msim_check_result *res) { check_instance(rows, n_rows, flags, res); }
+
 // Host-only entry point: checks one lin-kv history given as rows (no device involved).
 extern "C" int msim_check_lin_kv_rows(const msim_op *rows, uint32_t n_rows, msim_check_result *out) {
   if (!rows || !out) return MSIM_E_INVALID;
@@ -170,7 +174,7 @@ int msim_check_lin_kv_host(msim_ctx *ctx) {
     });
   for (auto &x : th) x.join();
   MSIM_HIP_TRY(ctx, hipMemcpy(ctx->d_check, ctx->h_check, (size_t)n * sizeof(msim_check_result), hipMemcpyHostToDevice));
-  ctx->checked = true; ctx->check_fetched = true;
+  ctx->checked = true; ctx->check_fetched = true; ctx->lin_host_rechecks = n;
   ctx->check_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return MSIM_OK;
 }

@@ -135,6 +135,10 @@ class Engine:
     def check(self):
         self._chk(self.lib.msim_check(self._ctx), "msim_check")
 
+    def check_host_rechecks(self):
+        """lin-kv: how many histories of the last check() the device handed to the host search."""
+        return int(self.lib.msim_check_host_rechecks(self._ctx))
+
     def fetch(self):
         self._chk(self.lib.msim_fetch(self._ctx), "msim_fetch")
 
@@ -457,6 +461,20 @@ def check_availability_rows(rows, availability=None):
     if rc:
         raise EngineError(f"msim_check_availability_rows: {rc}")
     return {"valid?": bool(r.valid), "ok-fraction": float(r.ok_fraction), "ok-count": r.ok_count, "invoke-count": r.invoke_count}
+
+
+def check_lin_kv_batch(histories, device=0):
+    """lin-kv: per-key linearizability of several histories (each an array of rows) with the device search behind Engine.check()
+    (msim_check_lin_kv_batch).  Returns the CHECK_DT records, one per history."""
+    hs = [np.ascontiguousarray(h) for h in histories]
+    off = np.zeros(len(hs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(h) for h in hs])
+    rows = np.concatenate(hs) if hs else np.zeros(0, dtype=hs[0].dtype if hs else np.uint8)
+    out = np.zeros(len(hs), dtype=CHECK_DT)
+    rc = A.load().msim_check_lin_kv_batch(device, rows.ctypes.data, off.ctypes.data, len(hs), out.ctypes.data)
+    if rc:
+        raise EngineError(f"msim_check_lin_kv_batch: {rc}")
+    return out
 
 
 def journal_fressian(cfg, events, payload):

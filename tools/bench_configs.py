@@ -58,8 +58,9 @@ def main():
                 flag_or |= eng.meta(i).flags
             res = eng.check_results()
             valid = int((res["valid"] == 1).sum())
+            host_rechecks = eng.check_host_rechecks()
         print(json.dumps({"config": name, "instances": n, "msgs_per_s": msgs / dt, "histories_per_s": valid / dt, "valid": valid, "flagged": flagged, "flags_seen": flag_or,
-                          "msgs_per_instance": msgs / n, "sim_ms": sim_ms, "check_ms": chk_ms}), flush=True)
+                          "msgs_per_instance": msgs / n, "sim_ms": sim_ms, "check_ms": chk_ms, "check_host_rechecks": host_rechecks}), flush=True)
 
 
 if __name__ == "__main__":
