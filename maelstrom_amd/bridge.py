@@ -16,20 +16,26 @@ What it replaces, with the reference's own behaviour (file:line under /root/refe
   * service.clj:31-132,141-263,290-296 the built-in services lin-kv, seq-kv, lww-kv and lin-tso as endpoints any node may call.
 
 Virtual time and real programs.  A reactive node (everything it ever prints is the reaction to a line it just read) runs in
-virtual time: after the due envelopes of a round are written, the bridge reads until every node has been quiet for `settle_ms` of
-REAL time, and what was printed is the round's output — no wall-clock sleeps, thousands of virtual seconds per real second.  A
+virtual time: after the due envelopes of a round are written, the bridge reads what the nodes print until all of them are DONE —
+on Linux that is read off /proc (a node is done when it has consumed its stdin and every thread of it sleeps, twice in a row with
+no CPU time slice in between; NodeProcess.idle), which holds however loaded the machine is; without /proc, until every node has
+been quiet for `settle_ms` of real time.  What was printed is the round's output — no wall-clock sleeps, thousands of virtual
+seconds per real second.  A
 node with timers of its own (periodic replication, election timeouts) needs `clock="real"`: virtual microseconds then follow the
 wall clock, spontaneous output is sent at the instant it is seen — the reference's own behaviour (it has no other mode).
 
 Host-side tool: pure Python, no device.  `python -m maelstrom_amd.bridge test -w broadcast --bin ./node.py --node-count 5 ...`
 """
 import argparse
+import fcntl
 import json
 import math
 import os
 import select
+import struct
 import subprocess
 import sys
+import termios
 import time
 
 MASK64 = (1 << 64) - 1
@@ -245,6 +251,31 @@ class NodeProcess:
             if line.strip():
                 out.append(line)
         return out
+
+    def idle(self):
+        """(quiet?, activity counter) from /proc: quiet = the node has read all of its stdin and every thread of it (and of its
+        children) sleeps; the counter changes whenever one of them ran.  None where /proc does not tell (then only the quiet
+        period decides)."""
+        try:
+            pending = struct.unpack("i", fcntl.ioctl(self.p.stdin.fileno(), termios.FIONREAD, b"\0\0\0\0"))[0]
+            quiet, ticks, todo = pending == 0, 0, [self.p.pid]
+            while todo:
+                pid = todo.pop()
+                for tid in os.listdir(f"/proc/{pid}/task"):
+                    with open(f"/proc/{pid}/task/{tid}/stat", "rb") as f:
+                        st = f.read().rsplit(b")", 1)[1].split()   # fields after "(comm)": state ...
+                    if st[0] not in (b"S", b"I", b"Z", b"X"):
+                        quiet = False
+                    with open(f"/proc/{pid}/task/{tid}/schedstat", "rb") as f:
+                        ticks += int(f.read().split()[2])             # timeslices run on a CPU
+                    try:
+                        with open(f"/proc/{pid}/task/{tid}/children", "rb") as f:
+                            todo.extend(int(c) for c in f.read().split())
+                    except OSError:
+                        pass
+            return quiet, ticks
+        except (OSError, ValueError, IndexError):
+            return None
 
     def stop(self):   # process.clj:202-215 stop-node!
         try:
@@ -678,12 +709,26 @@ class Bridge:
         owed = set(must_answer)
         hard = time.monotonic() + 10.0
         deadline = time.monotonic() + (self.settle_s if wrote else 0.0)
+        probe = self.clock == "virtual" and wrote      # /proc says when the nodes are done, however loaded the machine is
+        last = None
         while True:
             now = time.monotonic()
             left = (hard - now) if owed else (deadline - now)
+            if probe and not owed:
+                left = min(max(left, 0.0), 0.0003) if last is None else 0.0003
             r, _, _ = select.select(list(fds), [], [], max(left, 0.0))
             if not r:
+                if probe and not owed and now < hard:
+                    cur = [self.procs[i].idle() for i in fds.values()]
+                    if any(c is None for c in cur):
+                        probe = False          # no /proc: the quiet period alone decides
+                        continue
+                    if all(c[0] for c in cur) and cur == last:
+                        return got             # twice the same: everybody asleep, nobody ran in between, nothing left to read
+                    last = cur
+                    continue
                 return got
+            last = None
             for fd in r:
                 i = fds[fd]
                 lines = self.procs[i].lines()
