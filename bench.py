@@ -237,17 +237,31 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                          "kernel": "sim_kernel_duo<LAT0, DEG4> (duo.hip: two clusters per wavefront)", "algorithmic_bytes_per_launch": b_alg},
         }
-        # HBM bytes per launch from the PMC passes of the committed profile (counters cannot be read inside this process):
-        # FETCH_SIZE x 2 + WRITE_SIZE, KiB -> bytes (tools/rocpd_summary.py --traffic); null if the profile is absent or was
-        # taken with a different batch size
-        tj = os.path.join(ROOT, "profiles", "r01_headline_traffic.json")
-        if os.path.exists(tj) and n == 4096:
+        # HBM bytes per launch and the instruction-issue picture from the PMC passes of the committed profile (counters cannot be
+        # read inside this process): FETCH_SIZE x 2 + WRITE_SIZE, KiB -> bytes; SQ_* per launch (tools/profile_headline.sh ->
+        # tools/rocpd_summary.py --counters).  null if the profile is absent or was taken with a different batch size.
+        cj = os.path.join(ROOT, "profiles", "r02_headline_counters.json")
+        if os.path.exists(cj) and n == 4096:
             try:
-                kern = json.load(open(tj))["kernels"]
-                b = [v["hbm_bytes_per_dispatch"] for kname, v in kern.items() if "sim_kernel_colo" in kname and "hbm_bytes_per_dispatch" in v]
-                if b:
-                    out["roofline"]["traffic"] = b[0]
-                    out["roofline"]["traffic_source"] = "profiles/r01_headline_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                kern = json.load(open(cj))["kernels"]
+                kd = [v for kname, v in kern.items() if "sim_kernel_duo" in kname]
+                if kd:
+                    kd, c = kd[0], kd[0]["counters_per_dispatch"]
+                    if "hbm_bytes_per_dispatch" in kd:
+                        out["roofline"]["traffic"] = kd["hbm_bytes_per_dispatch"]
+                        out["roofline"]["traffic_source"] = "profiles/r02_headline_counters.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                    # the kernel is not bound by HBM (frac above): what bounds it is instruction issue + LDS latency of 2 wavefronts per SIMD
+                    insts = sum(c.get(k, 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH", "SQ_INSTS_VMEM_WR", "SQ_INSTS_VMEM_RD", "SQ_INSTS_SMEM"))
+                    out["roofline"]["secondary"] = {
+                        "bound": "instruction issue / LDS latency at 2 wavefronts per SIMD (2048 wavefronts on 1024 SIMDs, LDS-limited)",
+                        "source": "profiles/r02_headline_counters.json (rocprofv3 --pmc SQ_* passes of `bench.py --steps 3`, same kernel, same batch)",
+                        "wavefronts": kd.get("wavefronts"), "lds_bytes_per_wavefront": kd.get("lds_bytes"),
+                        "insts_per_launch": {k[9:].lower(): c[k] for k in sorted(c) if k.startswith("SQ_INSTS_")},
+                        "insts_per_message": insts / (msgs_all / (k * world)) if msgs_all else None,
+                        "wave_cycles_per_launch": c.get("SQ_WAVE_CYCLES"),
+                        "frac_of_wave_cycles": kd.get("derived"),
+                        "profiled_kernel_ms": kd.get("avg_ms"),
+                    }
             except Exception:
                 pass
         # the reference's only published figure for this path (README.md:39-42; other hardware, not reproduced here: no JVM)

@@ -38,6 +38,56 @@ def summarise(path):
         print(f"-- no PMC data ({e.__class__.__name__}: {e})")
 
 
+OURS = ("sim_kernel", "check_kernel", "raft_kernel", "raft4_kernel", "txn_kernel", "hat_kernel", "svc_kernel", "compact_", "availability_kernel")
+
+
+def counters_json(paths, out):
+    """--counters OUT.json: per-kernel averages per dispatch of every PMC counter collected (all passes), plus the dispatch
+    statistics of the kernel trace, for the engine's own kernels — what bench.py's roofline.secondary quotes."""
+    import json
+    acc = {}
+    for path in paths:
+        con = sqlite3.connect(path)
+        try:
+            kd, ks = table(con, "rocpd_kernel_dispatch"), table(con, "rocpd_info_kernel_symbol")
+        except IndexError:
+            continue
+        q = (f"select s.display_name, count(*), avg(d.end-d.start), max(d.group_segment_size), max(s.arch_vgpr_count), max(s.sgpr_count), max(d.grid_size_x), max(d.workgroup_size_x) "
+             f"from '{kd}' d join '{ks}' s on d.kernel_id = s.id group by 1")
+        try:
+            rows = list(con.execute(q))
+        except sqlite3.OperationalError:
+            q = q.replace(", max(d.grid_size_x), max(d.workgroup_size_x)", ", 0, 0")
+            rows = list(con.execute(q))
+        for name, nd, avg, lds, vg, sg, gx, wx in rows:
+            if any(k in name for k in OURS):
+                a = acc.setdefault(name, {"counters_per_dispatch": {}})
+                a.setdefault("dispatches_seen", []).append(nd)
+                a["avg_ms"] = avg / 1e6 if "avg_ms" not in a else min(a["avg_ms"], avg / 1e6)   # the trace pass is the fastest (no counters)
+                a["lds_bytes"], a["arch_vgpr"], a["sgpr"] = lds, vg, sg
+                if gx and wx:
+                    a["wavefronts"] = gx // 64
+        try:
+            pe, pi = table(con, "rocpd_pmc_event"), table(con, "rocpd_info_pmc")
+        except IndexError:
+            continue
+        q = (f"select s.display_name, i.name, sum(e.value), count(distinct d.id) from '{pe}' e join '{pi}' i on e.pmc_id = i.id "
+             f"join '{kd}' d on e.event_id = d.event_id join '{ks}' s on d.kernel_id = s.id group by 1, 2")
+        for name, ctr, tot, nd in con.execute(q):
+            if any(k in name for k in OURS):
+                acc.setdefault(name, {"counters_per_dispatch": {}})["counters_per_dispatch"][ctr] = tot / max(nd, 1)
+    for name, a in acc.items():
+        c = a["counters_per_dispatch"]
+        if "SQ_WAVE_CYCLES" in c and c["SQ_WAVE_CYCLES"]:
+            wc = c["SQ_WAVE_CYCLES"]
+            a["derived"] = {k2: c[k1] / wc for k1, k2 in (("SQ_ACTIVE_INST_VALU", "valu_active_frac_of_wave_cycles"), ("SQ_INST_CYCLES_SALU", "salu_frac_of_wave_cycles"),
+                                                           ("SQ_WAIT_ANY", "wait_any_frac_of_wave_cycles"), ("SQ_WAIT_INST_ANY", "wait_inst_frac_of_wave_cycles"),
+                                                           ("SQ_ACTIVE_INST_ANY", "any_inst_active_frac_of_wave_cycles")) if k1 in c}
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            a["hbm_bytes_per_dispatch"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0   # see traffic_json
+    json.dump({"source": "rocprofv3 --kernel-trace --stats + separate --pmc passes (tools/profile_headline.sh / tools/profile_config.sh)", "kernels": acc}, open(out, "w"), indent=1)
+
+
 def traffic_json(paths, out):
     """--traffic OUT.json: per-kernel HBM traffic per dispatch from the FETCH_SIZE / WRITE_SIZE passes, corrected as
     /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes for gfx950: both counters are in KiB; FETCH_SIZE counts
@@ -55,7 +105,7 @@ def traffic_json(paths, out):
         q = (f"select s.display_name, i.name, sum(e.value), count(distinct d.id) from '{pe}' e join '{pi}' i on e.pmc_id = i.id "
              f"join '{kd}' d on e.event_id = d.event_id join '{ks}' s on d.kernel_id = s.id where i.name in ('FETCH_SIZE', 'WRITE_SIZE') group by 1, 2")
         for name, ctr, tot, nd in con.execute(q):
-            if not any(k in name for k in ("sim_kernel", "check_kernel", "raft_kernel", "txn_kernel", "compact_")):
+            if not any(k in name for k in OURS):
                 continue  # the engine's own kernels only (torch's reductions in bench.py are not the path)
             acc.setdefault(name, {})[ctr + "_KiB_per_dispatch"] = tot / max(nd, 1)
     for name, d in acc.items():
@@ -69,6 +119,8 @@ if __name__ == "__main__":
     args = sys.argv[1:]
     if args and args[0] == "--traffic":
         traffic_json(args[2:], args[1])
+    elif args and args[0] == "--counters":
+        counters_json(args[2:], args[1])
     else:
         for p in args:
             summarise(p)
