@@ -134,15 +134,18 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
   // (slot-major: slot j of node i at [j * (N + 1) + i] — a wave-wide access to one slot is contiguous, free of bank conflicts;
   //  lane-major bags of 128 bytes put every lane on the same banks)
   const u32 BS = N + 1u;   // lanes per slot: the nodes and one dummy shared by the lanes that hold no node
-  u64 *const bag = reinterpret_cast<u64 *>(hmem + dp.off_ring) + (is_node ? i : N);
+  u32 *const bag_dl = reinterpret_cast<u32 *>(hmem + dp.off_ring) + (is_node ? i : N);             // deadlines: what recv! scans
+  u32 *const bag_e = bag_dl + 16u * BS;                                                           // envelope words
   unsigned short *const bag_seq = reinterpret_cast<unsigned short *>(hmem + dp.off_seq) + (is_node ? i : N);
-#define BAG(j_) bag[(j_) * BS]
+#define BAGDL(j_) bag_dl[(j_) * BS]
+#define BAGE(j_) bag_e[(j_) * BS]
 #define BAGSEQ(j_) bag_seq[(j_) * BS]
   u32 *const my_spill12 = p.scratch + (size_t)inst * p.scratch_words + p.spill_off + (size_t)(is_node ? i : 0) * p.spill_cap * 4;   // {deadline, envelope, sequence} x S
   u32 *const log2_tab = reinterpret_cast<u32 *>(smem + dp.off_log2);
 
   for (u32 k = i; k < N * Wp + 32u; k += 32) seen[k] = 0;
   if (RND) for (u32 k = lane; k < 257u; k += 64) log2_tab[k] = duo_log2_q24[k];
+  if (RND) for (u32 k = i; k < 16u * BS; k += 32) reinterpret_cast<u32 *>(hmem + dp.off_ring)[k] = INF;   // every bag slot is free
   __syncthreads();
 
   const u32 adj = is_node ? topo_adj(p.cfg.topology, N, i) : 0u;
@@ -165,6 +168,7 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
   u32 deliver_at = INF;      // INF = recv! holds no envelope (then the queue is empty too: idle receivers poll at once)
   u32 cm = 0;                // the envelope recv! is sleeping on: value | src << 16 | kind << 24 (src 63 = the node's own client)
   u32 in_n = 0, head = 0;    // LDS ring
+  u32 bag_used = 0;          // RND: the slots of the LDS bag that hold an envelope (in_n = their number)
   u32 sp_n = 0, s_head = 0;  // HBM spill ring (rare)
   u32 have_creq = 0, creq = 0, creq_t = 0;  // latency > 0: the client's request waits beside the FIFO of server envelopes
   u32 busy = 0;              // the client has an RPC outstanding
@@ -201,7 +205,10 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
     const bool pc_got = (got_); const u32 pc_e = (e_), pc_dl = (dl_);                                                     \
     if (RND) {   /* a bag: append with the node's arrival sequence number (orders equal deadlines like the ids do) */      \
       if (pc_got) {                                                                                                       \
-        if (in_n < R) { BAG(in_n) = (u64)pc_dl | ((u64)pc_e << 32); BAGSEQ(in_n) = (unsigned short)my_seq; in_n++; }     \
+        if (in_n < R) {   /* any free slot will do: a free slot's deadline is INF, `bag_used` says which ones are taken */      \
+          const u32 pc_s = (u32)__builtin_ctz(~bag_used);                                                                 \
+          BAGDL(pc_s) = pc_dl; BAGE(pc_s) = pc_e; BAGSEQ(pc_s) = (unsigned short)my_seq; bag_used |= 1u << pc_s; in_n++;  \
+        }                                                                                                                 \
         else if (sp_n < S) {                                                                                              \
           my_spill12[3 * sp_n] = pc_dl; my_spill12[3 * sp_n + 1] = pc_e; my_spill12[3 * sp_n + 2] = my_seq & 0xFFFFu;     \
           if (sp_n == 0 || pc_dl < spm_dl) { spm_dl = pc_dl; spm_seq = my_seq & 0xFFFFu; spm_e = pc_e; spm_i = sp_n; }   /* (equal deadline: the older one stays) */ \
@@ -229,31 +236,39 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
 #define DUO_POLL() do {                                                                                                   \
     const bool pl_idle = deliver_at == INF;                                                                               \
     if (RND) {                                                                                                            \
-      /* recv! takes the minimum (deadline, id) of the bag — even if it is not due (net.clj:228-229) — and sleeps on it.  All 16   \
-         slots of the LDS bag are read in one go (ten 16-byte reads, one wait) and reduced as 64-bit keys                          \
-         deadline << 20 | arrival sequence relative to the newest (16 bits) << 4 | slot; free slots count as infinity. */          \
+      /* recv! takes the minimum (deadline, id) of the bag — even if it is not due (net.clj:228-229) — and sleeps on it.  The 16      \
+         deadlines of the LDS bag are read in one go (one wait) and reduced with 32-bit minima; only when the minimal deadline       \
+         occurs twice (rare) do the arrival sequence numbers (16 bits, relative to the newest) decide. */                            \
       const bool pl_go = pl_idle & ((in_n | sp_n) != 0);                                                                  \
       if (__ballot(pl_go)) {                                                                                              \
         const u32 pl_sb = 32768u - my_seq;                                                                                \
-        u64 pl_m[16];                                                                                                     \
-        _Pragma("unroll") for (int pl_j = 0; pl_j < 16; pl_j++) {                                                         \
-          const u32 pl_d = (u32)BAG(pl_j); const u32 pl_q = BAGSEQ(pl_j);                                                 \
-          const u64 pl_k = ((u64)pl_d << 20) | (u64)((((pl_q + pl_sb) & 0xFFFFu) << 4) | (u32)pl_j);                      \
-          pl_m[pl_j] = (u32)pl_j < in_n ? pl_k : ~0ull;                                                                   \
+        u32 pl_d[16];                                                                                                     \
+        _Pragma("unroll") for (int pl_j = 0; pl_j < 16; pl_j++) pl_d[pl_j] = BAGDL(pl_j);   /* (free slots hold INF) */          \
+        u32 pl_m[8];                                                                                                      \
+        _Pragma("unroll") for (int pl_j = 0; pl_j < 8; pl_j++) pl_m[pl_j] = min(pl_d[pl_j], pl_d[pl_j + 8]);              \
+        _Pragma("unroll") for (int pl_w = 4; pl_w >= 1; pl_w >>= 1)                                                       \
+          _Pragma("unroll") for (int pl_j = 0; pl_j < pl_w; pl_j++) pl_m[pl_j] = min(pl_m[pl_j], pl_m[pl_j + pl_w]);      \
+        const u32 pl_dmin = pl_m[0];                                                                                      \
+        u32 pl_bi = 0, pl_cnt = 0;                                                                                        \
+        _Pragma("unroll") for (int pl_j = 0; pl_j < 16; pl_j++) { const bool pl_eq = pl_d[pl_j] == pl_dmin; pl_bi = pl_eq ? (u32)pl_j : pl_bi; pl_cnt += pl_eq ? 1u : 0u; } \
+        u32 pl_bq = 0;   /* the winner's sequence number, relative; only read when it matters */                           \
+        const bool pl_tie = pl_go & (in_n != 0) & ((pl_cnt > 1u) | (sp_n != 0 && spm_dl == pl_dmin));                      \
+        if (__ballot(pl_tie)) {                                                                                           \
+          if (pl_tie) {                                                                                                   \
+            pl_bq = 0xFFFFFFFFu;                                                                                          \
+            for (u32 pl_j = 0; pl_j < 16u; pl_j++) {                                                                      \
+              if (BAGDL(pl_j) == pl_dmin) { const u32 pl_q = ((u32)BAGSEQ(pl_j) + pl_sb) & 0xFFFFu; if (pl_q < pl_bq) { pl_bq = pl_q; pl_bi = pl_j; } } \
+            }                                                                                                             \
+          }                                                                                                               \
         }                                                                                                                 \
-        _Pragma("unroll") for (int pl_w = 8; pl_w >= 1; pl_w >>= 1)                                                       \
-          _Pragma("unroll") for (int pl_j = 0; pl_j < pl_w; pl_j++) pl_m[pl_j] = pl_m[pl_j] < pl_m[pl_j + pl_w] ? pl_m[pl_j] : pl_m[pl_j + pl_w]; \
-        u64 pl_best = pl_m[0];                                                                                            \
-        u32 pl_bi = (u32)pl_best & 15u, pl_be = 0; bool pl_sp = false;                                                    \
+        u32 pl_be = 0; bool pl_sp = false;                                                                                \
         /* the spilled part of the bag (HBM) takes part through its cached minimum: no memory access unless it wins */      \
-        const u64 pl_sk = sp_n != 0 ? (((u64)spm_dl << 20) | (u64)(((spm_seq + pl_sb) & 0xFFFFu) << 4)) : ~0ull;           \
-        pl_sp = pl_go & (pl_sk < (pl_best & ~15ull));                                                                     \
+        pl_sp = pl_go & (sp_n != 0) & ((in_n == 0) | (spm_dl < pl_dmin) | ((spm_dl == pl_dmin) & (((spm_seq + pl_sb) & 0xFFFFu) < pl_bq))); \
         if (pl_go) {                                                                                                      \
-          if (!pl_sp) {   /* remove it from the LDS bag: the last entry takes its place */                                 \
-            pl_be = (u32)(BAG(pl_bi) >> 32);                                                                              \
-            in_n--;                                                                                                       \
-            if (pl_bi != in_n) { BAG(pl_bi) = BAG(in_n); BAGSEQ(pl_bi) = BAGSEQ(in_n); }                                  \
-            cm = pl_be; const u32 pl_bd = (u32)(pl_best >> 20); deliver_at = DUO_COMMIT_TIME(pl_bd);                      \
+          if (!pl_sp) {   /* take it out of the LDS bag: its slot is free again */                                         \
+            pl_be = BAGE(pl_bi);                                                                                          \
+            BAGDL(pl_bi) = INF; bag_used &= ~(1u << pl_bi); in_n--;                                                       \
+            cm = pl_be; deliver_at = DUO_COMMIT_TIME(pl_dmin);                                                            \
           } else { cm = spm_e; deliver_at = DUO_COMMIT_TIME(spm_dl); }                                                    \
         }                                                                                                                 \
         if (__ballot(pl_sp)) {   /* rare: a spilled envelope was taken — close the gap and find the new minimum of the spill */ \
@@ -407,6 +422,20 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
 #ifdef DUO_PROF   // developer build (tools/duo_prof.sh): wave-round counts and cycles of the two round bodies -> meta
   u64 pf_t0 = __builtin_readcyclecounter(), pf_gen = 0; u32 pf_ngen = 0, pf_nwave = 0;
 #endif
+#if defined(DUO_PROF2) || defined(DUO_PROF3)  // developer builds: cycles of the sections of the gossip round (PROF2) or of the GENERAL round (PROF3)
+  u64 p2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, p2_t = __builtin_readcyclecounter();   // -> meta of the wavefront's two instances (replaces DUO_PROF's numbers)
+#define PX_MARK(i_) { const u64 p2_n = __builtin_readcyclecounter(); p2[i_] += p2_n - p2_t; p2_t = p2_n; }
+#endif
+#ifdef DUO_PROF2
+#define P2_MARK(i_) PX_MARK(i_)
+#else
+#define P2_MARK(i_)
+#endif
+#ifdef DUO_PROF3
+#define P3_MARK(i_) PX_MARK(i_)
+#else
+#define P3_MARK(i_)
+#endif
   for (;;) {
     // ---- gossip rounds of both clusters, until one of them needs a GENERAL round ----
     for (;;) {
@@ -415,6 +444,7 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
 #endif
       // R0: the cluster's time: stay at T while something is due, else jump to the next delivery / scheduler event.
       // Only looked at when one of the two clusters has nothing due (a scalar test on the halves of one ballot).
+      P2_MARK(4)
       bool due_n = deliver_at <= T;
       bool stuck_any = false;
       {
@@ -441,13 +471,17 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
       const bool gen = (alive != 0) & ((force_general != 0) | (sched_at <= T) | special);
       if (__ballot(gen) != 0 || stuck_any) break;   // (a GENERAL round is a superset of a gossip round: harmless for the other cluster)
       {   // ---- a round in which both clusters only gossip ----
+        P2_MARK(0)
         u32 pub; DUO_R3_SEEN(due_n, pub);
         deliver_at = due_n ? INF : deliver_at;
         n_rsv += due_n ? 1u : 0u;
+        P2_MARK(1)
         if (__ballot(pub != 0)) {
           if (RND) DUO_RND_IDS(pub, false);
+          P2_MARK(2)
           DUO_ARRIVALS(pub);
         }
+        P2_MARK(3)
         DUO_POLL();
       }
     }
@@ -456,6 +490,7 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
     const u64 pf_a = __builtin_readcyclecounter();
 #endif
     {   // ---- a round in which a cluster's scheduler acts or a node handles its client's request ----
+    P3_MARK(0)   // [0] = the gossip rounds
     u32 inv_row = 0, inv_packed = 0, inv_value = 0;
     u32 cmp_row = 0, cmp_packed = 0, cmp_value = 0, cmp_len = 0;
     // ---- R1: scheduler (core.clj:67-80): phase actions, one generated op ----
@@ -484,6 +519,7 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
       gen_k += gen ? 1u : 0u;
       gen_next = gen ? T + __umulhi(r_hi, p.gen_period2_us) : gen_next;
     }
+    P3_MARK(1)   // [1] = R1 scheduler
     // ---- R2: marked clients invoke; the request reaches this lane's own node (no latency: a client is involved) ----
     if (__ballot(mark != 0 && alive != 0)) {
       const bool inv = mark != 0 && alive != 0;
@@ -505,6 +541,7 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
       DUO_POLL();
     }
 
+    P3_MARK(2)   // [2] = R2 invoke + poll
     // ---- R3: one input per node: the due envelope ----
     const bool due_n = alive != 0 && deliver_at <= T;
     const u32 kind = cm >> 24;
@@ -544,9 +581,12 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
       n_payload += __popc(okm) * words;
     }
 
+    P3_MARK(3)   // [3] = R3 (dedup, read copies)
     if (RND) { if (__ballot((pub != 0) | req)) DUO_RND_IDS(pub, req); }
     if (__ballot(pub != 0)) DUO_ARRIVALS(pub);
+    P3_MARK(4)   // [4] = ids + arrivals
     DUO_POLL();
+    P3_MARK(5)   // [5] = poll
 
     // ---- R4 + history rows: invocations (slot order), then completions (slot order) ----
     if (__ballot((inv_row | cmp_row) != 0)) {
@@ -577,6 +617,7 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
       n_rows = new_n;
     }
 
+    P3_MARK(6)   // [6] = rows
     // ---- the scheduler's view for the rounds to come: time-free phase transitions (oracle: sched_resolve), when it
     //      acts next (sched_due), and whether plain gossip rounds may run meanwhile ----
     const u32 hbusy = hb(busy != 0, hi);
@@ -605,7 +646,8 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
     else if (phase == PH_SLEEP) sa = sleep_until;
     sched_at = alive != 0 ? sa : INF;
     force_general = (alive != 0 && !((phase == PH_MAIN && gen_live) || phase == PH_SLEEP)) ? 1u : 0u;
-    if (alive == 0) { deliver_at = INF; in_n = 0; sp_n = 0; have_creq = 0; }   // a finished cluster takes no further part
+    if (alive == 0) { deliver_at = INF; in_n = 0; sp_n = 0; have_creq = 0; bag_used = 0; }   // a finished cluster takes no further part
+    P3_MARK(7)   // [7] = the scheduler's view
     }
 #ifdef DUO_PROF
     pf_gen += __builtin_readcyclecounter() - pf_a; pf_ngen++;
@@ -640,6 +682,10 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
     m.n_events = 0; m.reserved[0] = 0; m.reserved[1] = 0; m.reserved[2] = 0;
 #ifdef DUO_PROF
     m.n_events = pf_ngen; m.reserved[0] = pf_nwave; m.reserved[1] = (u32)(pf_gen >> 6); m.reserved[2] = (u32)(pf_tot >> 6);
+#endif
+#if defined(DUO_PROF2) || defined(DUO_PROF3)
+    if (!hi) { m.n_events = (u32)(p2[0] >> 6); m.reserved[0] = (u32)(p2[1] >> 6); m.reserved[1] = (u32)(p2[2] >> 6); m.reserved[2] = (u32)(p2[3] >> 6); }
+    else { m.n_events = (u32)(p2[4] >> 6); m.reserved[0] = (u32)(p2[5] >> 6); m.reserved[1] = (u32)(p2[6] >> 6); m.reserved[2] = (u32)(p2[7] >> 6); }
 #endif
     p.meta[inst] = m;
   }
