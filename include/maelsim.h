@@ -255,13 +255,22 @@ int msim_run(msim_ctx *ctx, uint64_t first_instance, uint32_t n_instances);
 int msim_run_async(msim_ctx *ctx, uint64_t first_instance, uint32_t n_instances, void *hip_stream);
 
 /* Runs the workload checker for every instance of the last run, reading the HBM-resident histories.  On the device:
- * set-full (broadcast, g-set), echo, and lin-kv's per-key linearizability (one wavefront per history; a history that
- * exceeds what a wavefront's registers hold is finished by the host search, see msim_check_host_rechecks).  On the host
- * cores, after a fetch: list-append / rw-register (elle), pn-counter, unique-ids.  Blocking.  Results via msim_check_results. */
+ * set-full (broadcast, g-set), echo, lin-kv's per-key linearizability (one wavefront per history; a history that
+ * exceeds what a wavefront's registers hold is finished by the host search) and the clean case of list-append (elle: no
+ * anomaly + acyclic dependency graph; a history that is not provably clean is analysed by the host) — see
+ * msim_check_host_rechecks.  On the host cores, after a fetch: rw-register (elle), pn-counter, unique-ids.  Blocking.  Results via msim_check_results. */
 int msim_check(msim_ctx *ctx);
 
-/* How many histories of the last msim_check the device handed to the host search (lin-kv only; else 0). */
+/* How many histories of the last msim_check the device handed to the host (lin-kv: the search needed more than 512
+ * configurations; txn-list-append: not provably clean, i.e. the host analysed and classified it; else 0). */
 uint32_t msim_check_host_rechecks(const msim_ctx *ctx);
+
+/* txn-list-append: checks `n_histories` histories given on the host — rows / payload words of history i at row_offsets[i] /
+ * payload_offsets[i] (n + 1 offsets each) — as msim_check does for the histories of a run: the device proves the clean ones clean
+ * (no anomaly, acyclic dependency graph incl. realtime edges), the host analysis of msim_check_txn_rows finishes the others
+ * (strict-serializable).  out[i] is what msim_check_txn_rows gives for history i. */
+int msim_check_txn_batch(int device, const msim_op *rows, const uint64_t *row_offsets, const uint32_t *payload, const uint64_t *payload_offsets,
+                         uint32_t n_histories, msim_check_result *out);
 
 /* lin-kv: checks `n_histories` histories given on the host — history i = rows[row_offsets[i] .. row_offsets[i + 1]) — with the
  * device search of msim_check on HIP device `device`; out[i] is what msim_check_lin_kv_rows gives for history i. */

@@ -437,6 +437,12 @@ bool check_rw(Scratch &S, const msim_op *rows, uint32_t n_rows, const uint32_t *
 
 }  // namespace
 
+// the host analysis of one list-append history (txn_check_dev.hip hands over what it cannot prove clean)
+void msim_txn_check_instance_host(const msim_op *rows, uint32_t n_rows, const uint32_t *payload, uint32_t n_words, uint32_t flags, uint32_t cm, msim_check_result *res) {
+  thread_local Scratch S;
+  check_history(S, rows, n_rows, payload, n_words, flags, cm, res);
+}
+
 extern "C" int msim_check_txn_rows(const msim_op *rows, uint32_t n_rows, const uint32_t *payload, uint32_t n_words, msim_check_result *out) {
   if (!rows || !out || (!payload && n_words)) return MSIM_E_INVALID;
   Scratch S;

@@ -1,0 +1,448 @@
+// txn_check_dev.hip — the list-append analysis of txn-list-append histories on the device (msim_check for MSIM_WL_TXN_LIST_APPEND;
+// SURVEY.md §8f).  What the reference wires in at workload/txn_list_append.clj:142 is [upstream] elle's list-append checker;
+// txn_check.cpp restates it on the host (version orders from the longest reads, ww / wr / rw + transitively reduced realtime
+// edges, cycle search and classification, the non-cycle anomalies).
+//
+// This file is the COMMON CASE of that analysis, one wavefront per history: it PROVES a history clean — no non-cycle anomaly, and
+// the dependency graph (every edge kind, realtime included) acyclic — and then the result is what the host computes for a clean
+// history: the counts, the number of edges, :valid? true.  Anything else (an anomaly of any kind, a cycle, a shape beyond the
+// capacities below) is handed to txn_check.cpp, which analyses, classifies and judges it by the consistency model; the device
+// never decides an unclean history.  So the verdicts are the host's by construction, and the work the host cores used to do for
+// every history (0.6 ms of pointer chasing each, after 5 GB over PCIe for cfg5) is left for the rare bad ones.
+//
+// Data-parallel restatement of the host's steps (lane = transaction unless said otherwise):
+//   A  rows -> transactions: invocations numbered by prefix sums; completions paired by process through a table of open calls
+//      in lane registers (the one serial walk);
+//   B  key / element ranges; C  writer table (key, element) -> transaction by compare-and-swap (a second writer = duplicate);
+//   D  per :ok read: duplicates (256-bit set in registers), internal consistency against the transaction's own earlier micro-ops,
+//      G1a / G1b through the writer table, the key's longest read by atomic max;
+//   E  edges, generated twice (count, then fill a CSR): ww along each key's longest read (lane = key), wr / rw per read, and the
+//      realtime order in closed form — an :ok transaction u stays on the host's "frontier" from its completion until the first
+//      completion of a transaction invoked after it, so its successors are the transactions invoked in between: a contiguous
+//      range found with two binary searches and a suffix minimum (the host walks the history and edits a frontier list);
+//   F  acyclicity by Kahn's algorithm: 64 ready transactions per step, in-degrees by atomics, the ready queue by ballots.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "engine_internal.h"
+
+void msim_txn_check_instance_host(const msim_op *rows, uint32_t n_rows, const uint32_t *payload, uint32_t n_words, uint32_t flags, uint32_t cm,
+                                  msim_check_result *res);   // txn_check.cpp
+
+namespace {
+
+constexpr u32 NEEDS_HOST = 3u;
+constexpr u32 NONE = 0xFFFFFFFFu;
+constexpr u32 KMAX = 4096u;      // keys per history
+constexpr u32 WMAX = 65536u;     // writer table entries (keys x elements)
+
+struct TParams {
+  const msim_op *rows; const u32 *payload; const msim_inst_meta *meta;
+  const uint64_t *row_off, *pay_off;   // (null: history i at i * max_rows / i * max_pay)
+  msim_check_result *out;
+  u32 *ws;                       // workspace, ws_words per history of this launch
+  uint64_t ws_words;
+  u32 max_rows, max_pay, nmax, emax, first;   // first: index of the launch's first history
+};
+
+__device__ __forceinline__ u32 t_rl(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ __forceinline__ u32 t_sum(u32 v) { for (int o = 32; o; o >>= 1) v += (u32)__shfl_xor((int)v, o); return v; }
+__device__ __forceinline__ u32 t_max(u32 v) { for (int o = 32; o; o >>= 1) v = max(v, (u32)__shfl_xor((int)v, o)); return v; }
+__device__ __forceinline__ u32 t_excl_scan(u32 v, u32 lane) {   // exclusive prefix sum over the wavefront
+  u32 x = v;
+  for (int o = 1; o < 64; o <<= 1) { const u32 y = (u32)__shfl_up((int)x, o); if (lane >= (u32)o) x += y; }
+  return x - v;
+}
+__device__ __forceinline__ u32 elem(const u32 *lw, u32 e) { return (lw[e >> 2] >> (8u * (e & 3u))) & 0xFFu; }
+
+// one micro-op of a transaction's payload words w[0 .. n): header, then the list of a read
+struct Mop { u32 f, key, val, len; const u32 *list; bool bad; };   // read of nil: len 0
+__device__ __forceinline__ Mop next_mop(const u32 *w, u32 n, u32 &i) {
+  Mop m; const u32 h = w[i++];
+  m.f = h & 1u; m.key = (h >> 1) & 0x7FFFu; m.val = 0; m.len = 0; m.list = w + i; m.bad = false;
+  const u32 x = (h >> 16) & 0xFFu;
+  if (m.f) m.val = x;
+  else if (x != 0xFFu) { m.len = x; const u32 words = (x + 3u) >> 2; if (i + words > n) m.bad = true; i += words; }
+  return m;
+}
+
+__global__ void __launch_bounds__(64) txn_check_kernel(const TParams p) {
+  const u32 lane = threadIdx.x, hist = p.first + blockIdx.x;
+  const u64 lt = (1ull << lane) - 1ull;
+  const uint4 *const r = reinterpret_cast<const uint4 *>(p.rows) + (p.row_off ? p.row_off[hist] : (u64)hist * p.max_rows);
+  const u32 *const pay = p.payload + (p.pay_off ? p.pay_off[hist] : (u64)hist * p.max_pay);
+  const u32 n_rows = p.meta ? p.meta[hist].n_rows : (u32)(p.row_off[hist + 1] - p.row_off[hist]);
+  const u32 n_words = p.meta ? p.meta[hist].n_payload_words : (u32)(p.pay_off[hist + 1] - p.pay_off[hist]);
+  const u32 flags = p.meta ? p.meta[hist].flags : 0u;
+  const u32 NM = p.nmax;
+  u32 *const ws = p.ws + (u64)blockIdx.x * p.ws_words;
+  u32 *const t_inv = ws, *const t_cmp = t_inv + NM, *const t_off = t_cmp + NM, *const t_lt = t_off + NM;   // t_lt: words | type << 16
+  u32 *const sm = t_lt + NM;                 // [NM + 1] suffix minimum of the :ok completions
+  u32 *const indeg = sm + NM + 1, *const off = indeg + NM;   // off [NM + 1]: out-degrees, then CSR offsets
+  u32 *const cur = off + NM + 1, *const queue = cur + NM;
+  u32 *const longest = queue + NM;           // [KMAX] (len + 1) << 24 | first payload word of the list
+  u32 *const writer = longest + KMAX;        // [WMAX]
+  u32 *const adj = writer + WMAX;            // [emax]
+
+  msim_check_result res;
+  res.valid = NEEDS_HOST; res.attempt_count = 0; res.stable_count = 0; res.lost_count = 0; res.never_read_count = 0; res.stale_count = 0;
+  res.duplicated_count = 0; res.error_count = 0;
+  for (int i = 0; i < 5; i++) res.stable_latency_ms[i] = 0;
+  res.op_count = 0; res.ok_count = 0; res.fail_count = 0; res.info_count = 0;
+#define TO_HOST() do { if (lane == 0) p.out[hist] = res; return; } while (0)
+  if (n_words >= (1u << 24)) TO_HOST();
+
+  // ---- A: transactions ---------------------------------------------------------------------------------------------------------
+  u32 n = 0, c_ok = 0, c_fail = 0, c_info = 0;
+  {
+    bool o_used = false; u32 o_proc = 0, o_txn = 0, o_len = 0; bool bad = false;   // lane = one open call (o_len: words of its request)
+    for (u32 base = 0; base < n_rows; base += 64) {
+      const u32 idx = base + lane;
+      uint4 row = make_uint4(0, 0, 0, 0);
+      if (idx < n_rows) row = r[idx];
+      const u32 type = row.z & 3u, f = (row.z >> 2) & 31u, proc = row.z >> 12, len = row.y >> 16, woff = row.w;
+      const bool is = idx < n_rows && proc != MSIM_PROCESS_NEMESIS && f == MSIM_F_TXN;
+      if (__ballot(is && (u64)woff + len > n_words)) { bad = true; break; }
+      const bool inv = is && type == MSIM_T_INVOKE;
+      const u64 im = __ballot(inv);
+      const u32 my_t = n + (u32)__popcll(im & lt);
+      if (n + (u32)__popcll(im) > NM) { bad = true; break; }
+      if (inv) { t_inv[my_t] = idx; t_cmp[my_t] = NONE; t_off[my_t] = woff; t_lt[my_t] = len | (MSIM_T_INFO << 16); }   // never completed = indeterminate
+      u64 m = __ballot(is);
+      while (m) {
+        const u32 j = (u32)__builtin_ctzll(m); m &= m - 1;
+        const u32 z = t_rl(row.z, j);
+        const u32 jt = z & 3u, jp = z >> 12;
+        const u64 hit = __ballot(o_used && o_proc == jp);
+        if (jt == MSIM_T_INVOKE) {
+          u32 s;
+          if (hit) s = (u32)__builtin_ctzll(hit);
+          else { const u64 used = __ballot(o_used); if (used == ~0ull) { bad = true; break; } s = (u32)__builtin_ctzll(~used); }
+          const u32 tj = n + (u32)__popcll(im & ((1ull << j) - 1ull));
+          const u32 jl = t_rl(row.y, j) >> 16;
+          if (lane == s) { o_used = true; o_proc = jp; o_txn = tj; o_len = jl; }
+        } else if (hit) {
+          const u32 s = (u32)__builtin_ctzll(hit);
+          const u32 id = t_rl(o_txn, s), ilen = t_rl(o_len, s);
+          if (lane == s) o_used = false;
+          if (lane == j) {
+            t_cmp[id] = idx;
+            if (jt == MSIM_T_OK) { t_off[id] = woff; t_lt[id] = len | (MSIM_T_OK << 16); }   // the completed form replaces the requested one
+            else t_lt[id] = ilen | (jt << 16);
+          }
+          c_ok += jt == MSIM_T_OK; c_fail += jt == MSIM_T_FAIL; c_info += jt == MSIM_T_INFO;
+        }
+      }
+      if (bad) break;
+      n += (u32)__popcll(im);
+    }
+    if (bad) TO_HOST();
+  }
+  __syncthreads();
+  res.op_count = n; res.attempt_count = n; res.ok_count = c_ok; res.stable_count = c_ok; res.fail_count = c_fail; res.info_count = c_info;
+
+  // ---- B: ranges, and the tables cleared ------------------------------------------------------------------------------------------
+  u32 max_key = 0, max_val = 0; bool bad = false;
+  for (u32 t = lane; t < n; t += 64) {
+    const u32 *w = pay + t_off[t]; const u32 wn = t_lt[t] & 0xFFFFu;
+    for (u32 i = 0; i < wn;) { const Mop m = next_mop(w, wn, i); bad |= m.bad; max_key = max(max_key, m.key); if (m.f) max_val = max(max_val, m.val); }
+  }
+  max_key = t_max(max_key); max_val = t_max(max_val);
+  const u32 stride = max_val + 1u;
+  if (__ballot(bad) || max_key >= KMAX || (u64)(max_key + 1u) * stride > WMAX) TO_HOST();
+  for (u32 k = lane; k <= max_key; k += 64) longest[k] = 0;
+  for (u32 k = lane; k < (max_key + 1u) * stride; k += 64) writer[k] = NONE;
+  for (u32 t = lane; t <= n; t += 64) { off[t] = 0; if (t < n) { indeg[t] = 0; cur[t] = 0; } }
+  __syncthreads();
+
+  // ---- C: writers (every transaction, whatever became of it) -------------------------------------------------------------------------
+  for (u32 t = lane; t < n; t += 64) {
+    const u32 *w = pay + t_off[t]; const u32 wn = t_lt[t] & 0xFFFFu;
+    for (u32 i = 0; i < wn;) { const Mop m = next_mop(w, wn, i); if (m.f && atomicCAS(&writer[m.key * stride + m.val], NONE, t) != NONE) bad = true; }   // the generator never repeats (k, v)
+  }
+  __syncthreads();
+  if (__ballot(bad)) TO_HOST();
+#define WRITER(k_, el_) ((el_) < stride ? writer[(k_) * stride + (el_)] : NONE)
+
+  // ---- D: the reads of :ok transactions ------------------------------------------------------------------------------------------------
+  for (u32 t = lane; t < n; t += 64) {
+    if ((t_lt[t] >> 16) != MSIM_T_OK) continue;
+    const u32 *w = pay + t_off[t]; const u32 wn = t_lt[t] & 0xFFFFu;
+    u32 k = 0;
+    for (u32 i = 0; i < wn; k++) {
+      const Mop m = next_mop(w, wn, i);
+      if (m.f) continue;
+      // duplicates
+      { u64 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        for (u32 e = 0; e < m.len; e++) { const u32 x = elem(m.list, e); const u64 b = 1ull << (x & 63u); u64 &s = x < 64 ? s0 : x < 128 ? s1 : x < 192 ? s2 : s3; if (s & b) bad = true; s |= b; } }
+      // internal consistency: what the transaction's own earlier micro-ops imply for this read
+      { int prev = -1; Mop pm = m; u32 e_i = 0, e_k = 0;
+        for (e_i = 0, e_k = 0; e_k < k; e_k++) { const Mop q = next_mop(w, wn, e_i); if (!q.f && q.key == m.key) { prev = (int)e_k; pm = q; } }
+        const u32 e0 = prev < 0 ? 0u : (u32)prev + 1u;
+        u32 n_app = 0;
+        for (e_i = 0, e_k = 0; e_k < k; e_k++) { const Mop q = next_mop(w, wn, e_i); if (e_k >= e0 && q.f && q.key == m.key) n_app++; }
+        bool ok = true; u32 at = 0;
+        if (prev >= 0) { ok = m.len == pm.len + n_app; if (ok) for (u32 e = 0; e < pm.len; e++) ok &= elem(m.list, e) == elem(pm.list, e); at = pm.len; }
+        else { ok = m.len >= n_app; at = m.len - n_app; }
+        if (ok) { u32 a = 0; for (e_i = 0, e_k = 0; e_k < k; e_k++) { const Mop q = next_mop(w, wn, e_i); if (e_k >= e0 && q.f && q.key == m.key) { if (elem(m.list, at + a) != q.val) ok = false; a++; } } }
+        if (!ok) bad = true; }
+      // the externally visible part: without the transaction's own appends at the tail
+      u32 ext = m.len;
+      while (ext > 0 && WRITER(m.key, elem(m.list, ext - 1)) == t) ext--;
+      for (u32 e = 0; e < ext; e++) { const u32 wr = WRITER(m.key, elem(m.list, e)); if (wr == NONE || (t_lt[wr] >> 16) == MSIM_T_FAIL) bad = true; }   // G1a
+      if (ext > 0) {   // G1b: the last visible element must be its writer's last append to the key
+        const u32 last = elem(m.list, ext - 1), wr = WRITER(m.key, last);
+        if (wr != NONE && wr != t) {
+          const u32 *w2 = pay + t_off[wr]; const u32 wn2 = t_lt[wr] & 0xFFFFu; u32 fin = NONE;
+          for (u32 i2 = 0; i2 < wn2;) { const Mop q = next_mop(w2, wn2, i2); if (q.f && q.key == m.key) fin = q.val; }
+          if (fin != last) bad = true;
+        }
+      }
+      atomicMax(&longest[m.key], ((m.len + 1u) << 24) | (u32)(m.list - pay));
+    }
+  }
+  __syncthreads();
+  if (__ballot(bad)) TO_HOST();
+
+  // realtime order in closed form: sm[j] = earliest :ok completion among transactions j .. n-1
+  {
+    u32 carry = NONE;
+    for (int b = (int)((n + 63u) / 64u) - 1; b >= 0; b--) {
+      const u32 t = (u32)b * 64u + lane;
+      u32 v = (t < n && (t_lt[t] >> 16) == MSIM_T_OK) ? t_cmp[t] : NONE;
+      for (int o = 1; o < 64; o <<= 1) { const u32 y = (u32)__shfl_down((int)v, o); if (lane + (u32)o < 64u) v = min(v, y); }
+      v = min(v, carry);
+      if (t < n) sm[t] = v;
+      carry = t_rl(v, 0);
+    }
+    if (lane == 0) sm[n] = NONE;
+  }
+  __syncthreads();
+  auto rank_of = [&](u32 row) -> u32 {   // number of transactions invoked before `row`
+    u32 lo = 0, hi = n;
+    while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (t_inv[mid] < row) lo = mid + 1; else hi = mid; }
+    return lo;
+  };
+
+  // ---- E: edges: pass 0 counts degrees, pass 1 fills the CSR ------------------------------------------------------------------------------
+  u32 n_edges = 0;
+  for (int pass = 0; pass < 2; pass++) {
+    u32 my_edges = 0;
+#define ADD(a_, b_) do { const u32 ea = (a_), eb = (b_); if (ea != eb) { if (pass == 0) { atomicAdd(&off[ea], 1u); atomicAdd(&indeg[eb], 1u); my_edges++; } \
+                                                                         else adj[off[ea] + atomicAdd(&cur[ea], 1u)] = eb; } } while (0)
+    // ww along each key's version order (lane = key)
+    for (u32 key = lane; key <= max_key; key += 64) {
+      const u32 L = longest[key];
+      if (L == 0) continue;
+      const u32 len = (L >> 24) - 1u; const u32 *ord = pay + (L & 0xFFFFFFu);
+      for (u32 i = 0; i + 1 < len; i++) {
+        const u32 a = WRITER(key, elem(ord, i)), b = WRITER(key, elem(ord, i + 1));
+        if (a == NONE || b == NONE) continue;
+        const bool fa = (t_lt[a] >> 16) == MSIM_T_FAIL, fb = (t_lt[b] >> 16) == MSIM_T_FAIL;
+        if (fa && !fb) bad = true;   // dirty update
+        if (!fa && !fb) ADD(a, b);
+      }
+    }
+    // wr / rw per read of an :ok transaction; realtime successors of an :ok transaction
+    for (u32 t = lane; t < n; t += 64) {
+      if ((t_lt[t] >> 16) != MSIM_T_OK) continue;
+      const u32 *w = pay + t_off[t]; const u32 wn = t_lt[t] & 0xFFFFu;
+      for (u32 i = 0; i < wn;) {
+        const Mop m = next_mop(w, wn, i);
+        if (m.f) continue;
+        const u32 L = longest[m.key];
+        const u32 llen = (L >> 24) - 1u; const u32 *ord = pay + (L & 0xFFFFFFu);
+        bool pre = m.len <= llen;
+        if (pre) for (u32 e = 0; e < m.len; e++) pre &= elem(m.list, e) == elem(ord, e);
+        if (!pre) { bad = true; continue; }   // incompatible order
+        u32 ext = m.len;
+        while (ext > 0 && WRITER(m.key, elem(m.list, ext - 1)) == t) ext--;
+        if (ext > 0) { const u32 wr = WRITER(m.key, elem(m.list, ext - 1)); if (wr != NONE && (t_lt[wr] >> 16) != MSIM_T_FAIL) ADD(wr, t); }
+        if (m.len < llen) { const u32 wr = WRITER(m.key, elem(ord, m.len)); if (wr != NONE && (t_lt[wr] >> 16) != MSIM_T_FAIL) ADD(t, wr); }   // anti-dependency
+      }
+      const u32 first = rank_of(t_cmp[t] + 1u);   // (a completion row is no invocation row: "+ 1" is immaterial, kept for clarity)
+      const u32 kill = sm[first];
+      const u32 last = kill == NONE ? n : rank_of(kill);
+      for (u32 v = first; v < last; v++) if ((t_lt[v] >> 16) != MSIM_T_FAIL) ADD(t, v);
+    }
+#undef ADD
+    __syncthreads();
+    if (__ballot(bad)) TO_HOST();
+    if (pass == 0) {
+      n_edges = t_sum(my_edges);
+      if (n_edges > p.emax) TO_HOST();
+      // out-degrees -> CSR offsets (exclusive prefix sums, 64 at a time)
+      u32 carry = 0;
+      for (u32 base = 0; base <= n; base += 64) {
+        const u32 t = base + lane;
+        const u32 d = t < n ? off[t] : 0u;
+        const u32 ex = t_excl_scan(d, lane);
+        if (t <= n) off[t] = carry + ex;
+        carry += t_sum(d);
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- F: acyclic?  Kahn's algorithm, 64 ready transactions per step -------------------------------------------------------------------------
+  u32 tail = 0;
+  for (u32 base = 0; base < n; base += 64) {
+    const u32 t = base + lane;
+    const bool z = t < n && indeg[t] == 0;
+    const u64 zm = __ballot(z);
+    if (z) queue[tail + (u32)__popcll(zm & lt)] = t;
+    tail += (u32)__popcll(zm);
+  }
+  __syncthreads();
+  u32 head = 0;
+  while (head < tail) {
+    const u32 snap = tail;
+    const u32 cnt = min(64u, snap - head);
+    const bool on = lane < cnt;
+    const u32 v = on ? queue[head + lane] : 0u;
+    const u32 a0 = on ? off[v] : 0u, a1 = on ? off[v + 1] : 0u;
+    for (u32 k = 0; __ballot(a0 + k < a1); k++) {
+      bool push = false; u32 wv = 0;
+      if (a0 + k < a1) { wv = adj[a0 + k]; push = atomicSub(&indeg[wv], 1u) == 1u; }
+      const u64 pm = __ballot(push);
+      if (push) queue[tail + (u32)__popcll(pm & lt)] = wv;
+      tail += (u32)__popcll(pm);
+    }
+    head += cnt;
+    __syncthreads();
+  }
+  if (tail != n) TO_HOST();   // a cycle: the host finds and classifies it
+
+  if (lane == 0) {
+    res.lost_count = n_edges;   // edges of the dependency graph
+    res.valid = flags ? 0u : (c_ok == 0 ? 2u : 1u);
+    p.out[hist] = res;
+  }
+#undef TO_HOST
+#undef WRITER
+}
+
+// words of workspace per history
+uint64_t ws_words_for(u32 nmax, u32 emax) { return (uint64_t)nmax * 9 + 3 + KMAX + WMAX + emax; }
+
+int txn_dev_run(msim_ctx *ctx, TParams tp, u32 n, u32 cm, const std::vector<msim_inst_meta> *hmeta, msim_check_result *h_out, hipStream_t st, u32 *n_host,
+                void **ws_buf, size_t *ws_cap) {
+  static const char *df = std::getenv("MSIM_DEV_FLAGS");
+  const bool trace = df && (std::atoi(df) & 0x1000);
+  const auto t0 = std::chrono::steady_clock::now();
+  auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+  tp.ws_words = ws_words_for(tp.nmax, tp.emax);
+  // as many histories per launch as a few GB of workspace hold (every one of them has its own slice)
+  const uint64_t budget = 6ull << 30;
+  u32 chunk = (u32)std::min<uint64_t>(n, std::max<uint64_t>(1, budget / (tp.ws_words * 4)));
+  const size_t need = (size_t)chunk * tp.ws_words * 4;
+  if (*ws_cap < need) {
+    if (*ws_buf) (void)hipFree(*ws_buf);
+    *ws_buf = nullptr; *ws_cap = 0;
+    MSIM_HIP_TRY(ctx, hipMalloc(ws_buf, need));
+    *ws_cap = need;
+  }
+  tp.ws = static_cast<u32 *>(*ws_buf);
+  for (u32 first = 0; first < n; first += chunk) {
+    tp.first = first;
+    const u32 cnt = std::min(chunk, n - first);
+    hipLaunchKernelGGL(txn_check_kernel, dim3(cnt), dim3(64), 0, st, tp);
+    MSIM_HIP_TRY(ctx, hipGetLastError());
+  }
+  MSIM_HIP_TRY(ctx, hipMemcpyAsync(h_out, tp.out, (size_t)n * sizeof(msim_check_result), hipMemcpyDeviceToHost, st));
+  MSIM_HIP_TRY(ctx, hipStreamSynchronize(st));
+  std::vector<u32> todo;
+  for (u32 i = 0; i < n; i++) if (h_out[i].valid == NEEDS_HOST) todo.push_back(i);
+  if (trace) std::fprintf(stderr, "[txn-check] device pass: %.2f ms, %zu of %u histories for the host\n", ms(), todo.size(), n);
+  if (!todo.empty()) {
+    std::vector<uint64_t> ro, po;
+    if (tp.row_off) { ro.resize(n + 1); po.resize(n + 1);
+      MSIM_HIP_TRY(ctx, hipMemcpy(ro.data(), tp.row_off, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost));
+      MSIM_HIP_TRY(ctx, hipMemcpy(po.data(), tp.pay_off, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost)); }
+    std::vector<std::vector<msim_op>> rows(todo.size());
+    std::vector<std::vector<u32>> pays(todo.size());
+    for (size_t k = 0; k < todo.size(); k++) {
+      const u32 i = todo[k];
+      const u32 nr = hmeta ? (*hmeta)[i].n_rows : (u32)(ro[i + 1] - ro[i]), nw = hmeta ? (*hmeta)[i].n_payload_words : (u32)(po[i + 1] - po[i]);
+      rows[k].resize(nr ? nr : 1); pays[k].resize(nw ? nw : 1);
+      if (nr) MSIM_HIP_TRY(ctx, hipMemcpy(rows[k].data(), tp.rows + (hmeta ? (uint64_t)i * tp.max_rows : ro[i]), (size_t)nr * sizeof(msim_op), hipMemcpyDeviceToHost));
+      if (nw) MSIM_HIP_TRY(ctx, hipMemcpy(pays[k].data(), tp.payload + (hmeta ? (uint64_t)i * tp.max_pay : po[i]), (size_t)nw * 4, hipMemcpyDeviceToHost));
+    }
+    unsigned nt = msim_host_threads();
+    if (nt > todo.size()) nt = (unsigned)todo.size();
+    std::vector<std::thread> th;
+    for (unsigned w = 0; w < nt; w++)
+      th.emplace_back([&, w]() {
+        for (size_t k = w; k < todo.size(); k += nt) {
+          const u32 i = todo[k];
+          msim_txn_check_instance_host(rows[k].data(), hmeta ? (*hmeta)[i].n_rows : (u32)(ro[i + 1] - ro[i]), pays[k].data(),
+                                       hmeta ? (*hmeta)[i].n_payload_words : (u32)(po[i + 1] - po[i]), hmeta ? (*hmeta)[i].flags : 0u, cm, &h_out[i]);
+        }
+      });
+    for (auto &x : th) x.join();
+    for (u32 i : todo) MSIM_HIP_TRY(ctx, hipMemcpy(tp.out + i, &h_out[i], sizeof(msim_check_result), hipMemcpyHostToDevice));
+    if (trace) std::fprintf(stderr, "[txn-check] host analysis of those: done at %.2f ms\n", ms());
+  }
+  if (n_host) *n_host = (u32)todo.size();
+  return MSIM_OK;
+}
+
+}  // namespace
+
+// msim_check for txn-list-append: the histories of the last run, where they lie in HBM.
+int msim_check_txn_device(msim_ctx *ctx) {
+  MSIM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const u32 n = ctx->n_inst;
+  if (ctx->h_check) { (void)hipHostFree(ctx->h_check); ctx->h_check = nullptr; }
+  MSIM_HIP_TRY(ctx, hipHostMalloc(&ctx->h_check, (size_t)n * sizeof(msim_check_result)));
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<msim_inst_meta> hm(n);
+  MSIM_HIP_TRY(ctx, hipMemcpy(hm.data(), ctx->d_meta, (size_t)n * sizeof(msim_inst_meta), hipMemcpyDeviceToHost));
+  TParams tp;
+  tp.rows = ctx->d_rows; tp.payload = ctx->d_payload; tp.meta = ctx->d_meta; tp.row_off = nullptr; tp.pay_off = nullptr; tp.out = ctx->d_check;
+  tp.max_rows = ctx->cfg.max_rows; tp.max_pay = ctx->cfg.max_payload_words;
+  tp.nmax = ctx->cfg.max_rows / 2 + 1; tp.emax = tp.nmax * 16; tp.first = 0; tp.ws = nullptr; tp.ws_words = 0;
+  u32 redone = 0;
+  int rc = txn_dev_run(ctx, tp, n, ctx->cfg.consistency_model, &hm, ctx->h_check, ctx->stream, &redone, &ctx->d_check_scratch, &ctx->cap_check_scratch);
+  if (rc != MSIM_OK) return rc;
+  ctx->check_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  ctx->lin_host_rechecks = redone;
+  ctx->checked = true; ctx->check_fetched = true;
+  return MSIM_OK;
+}
+
+// Checks `n_histories` list-append histories given on the host (rows / payload words of history i at row_offsets[i] /
+// payload_offsets[i]) with the device pass of msim_check on HIP device `device`; out[i] as msim_check_txn_rows would fill it.
+extern "C" int msim_check_txn_batch(int device, const msim_op *rows, const uint64_t *row_offsets, const uint32_t *payload, const uint64_t *payload_offsets,
+                                    uint32_t n_histories, msim_check_result *out) {
+  if (!rows || !row_offsets || !payload_offsets || !out || n_histories == 0) return MSIM_E_INVALID;
+  if (hipSetDevice(device) != hipSuccess) return MSIM_E_HIP;
+  msim_ctx tmp_ctx; msim_ctx *ctx = &tmp_ctx;   // only for error text
+  const uint64_t tr = row_offsets[n_histories], tw = payload_offsets[n_histories];
+  u32 max_r = 1;
+  for (u32 i = 0; i < n_histories; i++) { const uint64_t c = row_offsets[i + 1] - row_offsets[i]; if (c > 0x7FFFFFFFull) return MSIM_E_RANGE; if (c > max_r) max_r = (u32)c; }
+  msim_op *d_rows = nullptr; u32 *d_pay = nullptr; uint64_t *d_ro = nullptr, *d_po = nullptr; msim_check_result *d_out = nullptr; void *ws = nullptr; size_t ws_cap = 0;
+  int rc = MSIM_E_HIP;
+  do {
+    if (hipMalloc(&d_rows, (size_t)(tr ? tr : 1) * sizeof(msim_op)) != hipSuccess) break;
+    if (hipMalloc(&d_pay, (size_t)(tw ? tw : 1) * 4) != hipSuccess) break;
+    if (hipMalloc(&d_ro, (size_t)(n_histories + 1) * 8) != hipSuccess || hipMalloc(&d_po, (size_t)(n_histories + 1) * 8) != hipSuccess) break;
+    if (hipMalloc(&d_out, (size_t)n_histories * sizeof(msim_check_result)) != hipSuccess) break;
+    if (tr && hipMemcpy(d_rows, rows, (size_t)tr * sizeof(msim_op), hipMemcpyHostToDevice) != hipSuccess) break;
+    if (tw && hipMemcpy(d_pay, payload, (size_t)tw * 4, hipMemcpyHostToDevice) != hipSuccess) break;
+    if (hipMemcpy(d_ro, row_offsets, (size_t)(n_histories + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) break;
+    if (hipMemcpy(d_po, payload_offsets, (size_t)(n_histories + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) break;
+    TParams tp;
+    tp.rows = d_rows; tp.payload = d_pay; tp.meta = nullptr; tp.row_off = d_ro; tp.pay_off = d_po; tp.out = d_out;
+    tp.max_rows = 0; tp.max_pay = 0; tp.nmax = max_r / 2 + 65; tp.emax = tp.nmax * 16; tp.first = 0; tp.ws = nullptr; tp.ws_words = 0;
+    rc = txn_dev_run(ctx, tp, n_histories, MSIM_CM_STRICT_SERIALIZABLE, nullptr, out, nullptr, nullptr, &ws, &ws_cap);
+  } while (false);
+  for (void *q : {(void *)d_rows, (void *)d_pay, (void *)d_ro, (void *)d_po, (void *)d_out, ws}) if (q) (void)hipFree(q);
+  return rc;
+}

@@ -477,6 +477,24 @@ def check_lin_kv_batch(histories, device=0):
     return out
 
 
+def check_txn_batch(histories, device=0):
+    """txn-list-append: several histories, each (rows, payload), through the device pass behind Engine.check() with the host analysis
+    for what it cannot prove clean (msim_check_txn_batch).  Returns the CHECK_DT records, one per history."""
+    rs = [np.ascontiguousarray(h[0]) for h in histories]
+    ps = [np.ascontiguousarray(h[1], dtype=np.uint32) for h in histories]
+    ro = np.zeros(len(rs) + 1, dtype=np.uint64); ro[1:] = np.cumsum([len(x) for x in rs])
+    po = np.zeros(len(ps) + 1, dtype=np.uint64); po[1:] = np.cumsum([len(x) for x in ps])
+    rows = np.concatenate(rs) if rs else np.zeros(0, dtype=OP_DT)
+    pay = np.concatenate(ps) if ps else np.zeros(0, dtype=np.uint32)
+    if len(pay) == 0:
+        pay = np.zeros(1, dtype=np.uint32)
+    out = np.zeros(len(rs), dtype=CHECK_DT)
+    rc = A.load().msim_check_txn_batch(device, rows.ctypes.data, ro.ctypes.data, pay.ctypes.data, po.ctypes.data, len(rs), out.ctypes.data)
+    if rc:
+        raise EngineError(f"msim_check_txn_batch: {rc}")
+    return out
+
+
 def journal_fressian(cfg, events, payload):
     """One instance's net journal as the bytes of a net-journal/<stripe>.fressian file (msim_journal_fressian_rows, csrc/fressian.cpp):
     what maelstrom.net.journal writes (journal.clj:55-141) and maelstrom.net.checker / net.viz read."""
