@@ -180,7 +180,12 @@ __global__ void __launch_bounds__(64) txn_check_kernel(const TParams p) {
       if (m.f) continue;
       // duplicates
       { u64 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-        for (u32 e = 0; e < m.len; e++) { const u32 x = elem(m.list, e); const u64 b = 1ull << (x & 63u); u64 &s = x < 64 ? s0 : x < 128 ? s1 : x < 192 ? s2 : s3; if (s & b) bad = true; s |= b; } }
+        for (u32 e = 0; e < m.len; e++) {
+          const u32 x = elem(m.list, e); const u64 b = 1ull << (x & 63u); const u32 q = x >> 6;
+          const u64 s = q == 0 ? s0 : q == 1 ? s1 : q == 2 ? s2 : s3;
+          if (s & b) bad = true;
+          s0 |= q == 0 ? b : 0; s1 |= q == 1 ? b : 0; s2 |= q == 2 ? b : 0; s3 |= q == 3 ? b : 0;
+        } }
       // internal consistency: what the transaction's own earlier micro-ops imply for this read
       { int prev = -1; Mop pm = m; u32 e_i = 0, e_k = 0;
         for (e_i = 0, e_k = 0; e_k < k; e_k++) { const Mop q = next_mop(w, wn, e_i); if (!q.f && q.key == m.key) { prev = (int)e_k; pm = q; } }
