@@ -847,6 +847,7 @@ static uint64_t scratch_words(const msim_config &c) {
   const uint64_t queues = c.n_nodes + (c.node_program == MSIM_NODE_TXN_SINGLE_KEY || c.node_program == MSIM_NODE_LIN_KV_PROXY ? 1 : 0);  // + the service
   uint64_t w = proto_scratch_words(c) + queues * c.spill_capacity * 4;
   if (msim_raft4_eligible(c)) w += msim_raft4_extra_scratch_words(c);   // raft4.hip keeps fewer envelopes in LDS
+  if (msim_txn8_eligible(c)) w += msim_txn8_extra_scratch_words(c);     // txn8.hip likewise
   return w;
 }
 
@@ -949,6 +950,8 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   }
   // Raft: four clusters per wavefront (raft4.hip) when a cluster fits a 16-lane group
   if (msim_raft4_eligible(c) && !(kp.dev_flags & 0x200u)) e = msim_launch_raft4(kp, n, st);
+  // txn-list-append: eight clusters per wavefront (txn8.hip) when a cluster fits an 8-lane group
+  if (msim_txn8_eligible(c) && !(kp.dev_flags & 0x200u)) e = msim_launch_txn8(kp, n, st);
   if (e == hipErrorInvalidValue && (kp.dev_flags & 0x400u) && is_raft) { ctx->err = "MSIM_DEV_FLAGS bit 10: the four-clusters-per-wavefront Raft layout was required but does not apply"; return MSIM_E_UNSUPPORTED; }
   if (e == hipErrorInvalidValue) switch (c.node_program) {   // not eligible, or the cluster state does not fit the duo layout
     case MSIM_NODE_ECHO: e = launch<MSIM_NODE_ECHO>(kp, n, lds, st); break;

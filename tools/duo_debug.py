@@ -39,6 +39,13 @@ CASES = {
     "raft-n3c6": (dict(workload="lin-kv", bin="raft", node_count=3, concurrency=6, nemesis=["partition"], nemesis_interval=4, time_limit=30, latency=10, latency_dist="uniform", rate=30, seed=17), 0, 7),
     "raft-n1": (dict(workload="lin-kv", bin="raft", node_count=1, rate=50, time_limit=10, seed=5), 0, 5),
     "raft-n4c8": (dict(workload="lin-kv", bin="raft", node_count=4, concurrency=8, rate=40, time_limit=15, latency=3, seed=5), 0, 5),
+    "txn": (dict(workload="txn-list-append", node_count=5, rate=100, time_limit=10, seed=17), 0, 9),
+    "txn-lat5": (dict(workload="txn-list-append", node_count=5, rate=100, time_limit=10, seed=17, latency=5), 0, 9),
+    "txn-part": (dict(workload="txn-list-append", node_count=5, rate=100, time_limit=20, seed=17, latency=5, nemesis=["partition"], nemesis_interval=3), 0, 9),
+    "txn-exp-loss": (dict(workload="txn-list-append", node_count=5, rate=100, time_limit=10, seed=17, latency=20, latency_dist="exponential", p_loss=0.05), 0, 9),
+    "txn-n3": (dict(workload="txn-list-append", node_count=3, rate=200, time_limit=10, seed=17, latency=2), 0, 9),
+    "txn-n7": (dict(workload="txn-list-append", node_count=7, rate=150, time_limit=10, seed=17, latency=10, latency_dist="uniform", key_count=3, max_txn_length=6), 0, 9),
+    "txn-n1": (dict(workload="txn-list-append", node_count=1, rate=50, time_limit=5, seed=3), 0, 5),
     "n12-spill": (dict(workload="broadcast", node_count=12, latency=30, rate=300, time_limit=10, inbox_capacity=2, spill_capacity=64, seed=123), 1000, 3),
 }
 
