@@ -11,12 +11,14 @@
 // "ballot" is the group's 8 bits of the wave ballot, another lane's value comes by `ds_bpermute` within the group, the time
 // reduction is three DPP steps.
 //
-// Scope (engine.hip picks this kernel when all of it holds, else txn_kernel<> runs): n_nodes <= 7, net journal off.
+// Scope (engine.hip picks this kernel when all of it holds, else txn_kernel<> runs): n_nodes <= 7, net journal off,
+// max-txn-length <= 4 (the default), max-writes-per-key 4, 8, 12 or 16 (the default).
 //
 // LDS of a wavefront (slot-major: slot s of lane e at [s * 64 + e]): node / service queues (RQ envelopes, the rest spills to HBM:
 // inbox_capacity + spill_capacity in all, the oracle's limit), client inboxes (CQ envelopes + HBM spill: 32 in all), the nodes'
-// transactions in flight (8 x 16 B), per cluster the generator's key pool, the nemesis shuffle and a 32-row staging ring
-// (16-row coalesced appends).  The append log (elements per key) lives in HBM scratch as in txn_kernel<>; a key's row is read
+// transactions in flight (the first 4 of 8 x 16 B; the others in HBM), per cluster the generator's key pool and the nemesis shuffle:
+// 9.5 KiB, so that 16 wavefronts share a CU — this kernel waits for memory (scattered per-cluster pages), and wavefronts to switch
+// to are what hides that.  History rows go straight to HBM (a few 16-byte rows per round and cluster; the L2 merges them).  The append log (elements per key) lives in HBM scratch as in txn_kernel<>; a key's row is read
 // with independent loads (versions only grow along a row: "visible at version v" is a count, not a search).
 #include <hip/hip_runtime.h>
 
@@ -28,11 +30,12 @@ namespace {
 __constant__ u32 t8_log2_q24[257];
 
 constexpr u32 GS = 8u;            // lanes per cluster
-constexpr u32 RQ = 4u;            // LDS envelopes per node / service queue
-constexpr u32 CQ = 2u;            // LDS envelopes per client inbox
-constexpr u32 T8_STAGE = 32u;     // staged history rows per cluster
-constexpr u32 T8_SLOTS = 8u;      // transactions in flight per node
+constexpr u32 RQ = 3u;            // LDS envelopes per node / service queue
+constexpr u32 CQ = 1u;            // LDS envelopes per client inbox
+constexpr u32 T8_SLOTS = 8u;      // transactions in flight per node (the oracle's limit) ...
+constexpr u32 SL = 4u;            // ... of which in LDS; the others (in use only while clients time out) in HBM
 constexpr u32 T8_CLIENT_CAP = 32u;
+constexpr int MM = 4;             // micro-ops per transaction (--max-txn-length <= 4, the default)
 constexpr u32 V_NIL = 0xFFFFu;
 enum { M_WRITE = 14, M_WRITE_OK, M_CAS, M_CAS_OK, M_ERROR, M_TXN = 23, M_TXN_OK = 24 };
 enum { S_GEN3 = 3 };
@@ -40,7 +43,8 @@ enum { S_GEN3 = 3 };
 struct T8Params {
   KParams k;
   u32 n_inst;
-  u32 off_cq, off_slots, off_gen, off_stage, off_misc;   // LDS byte offsets (queues at 0)
+  u32 off_cq, off_slots, off_gen, off_misc;   // LDS byte offsets (queues at 0)
+  u64 xslots_off;                                        // word offset of the nodes' slots SL .. T8_SLOTS-1 inside the per-instance scratch
   u32 node_spill, client_spill;                          // HBM spill entries per node-or-service queue / client inbox
   u64 client_spill_off;                                  // word offset of the clients' spill area inside the per-instance scratch
   u32 round_limit;
@@ -97,13 +101,15 @@ __global__ void __launch_bounds__(64) txn8_kernel(const T8Params tp) {
 
   uint4 *const my_q = reinterpret_cast<uint4 *>(smem) + lane;                                   // node / service queue: slot s at my_q[s * 64]
   uint4 *const my_cq = reinterpret_cast<uint4 *>(smem + tp.off_cq) + lane;                      // client inbox
-  uint4 *const slots_g = reinterpret_cast<uint4 *>(smem + tp.off_slots) + grp * GS * T8_SLOTS;  // [lane of the group][T8_SLOTS] {client_msg, txn_ref, rpc_id, from | stage << 16 | used << 24}
-  uint4 *const my_slots = slots_g + l * T8_SLOTS;
+  uint4 *const slots_g = reinterpret_cast<uint4 *>(smem + tp.off_slots) + grp * GS * SL;       // [lane of the group][SL] {client_msg, txn_ref, rpc_id, from | stage << 16 | used << 24}
+  uint4 *const xslots = reinterpret_cast<uint4 *>(g_scr + tp.xslots_off);                       // [node][T8_SLOTS - SL]
+  // slot i of node nd (LDS for the first SL, HBM beyond: only reached while a node has more than SL transactions in flight)
+#define SLOT_PTR(nd_, i_) ((i_) < SL ? slots_g + (nd_) * SL + (i_) : xslots + (nd_) * (T8_SLOTS - SL) + ((i_) - SL))
   u32 *const gen = reinterpret_cast<u32 *>(smem + tp.off_gen) + grp * 36;                       // active[16], next_val[16], next_key
-  uint4 *const stage = reinterpret_cast<uint4 *>(smem + tp.off_stage) + grp * T8_STAGE;
   u32 *const misc = reinterpret_cast<u32 *>(smem + tp.off_misc) + grp * GS;
 
-  for (u32 i = lane; i < 8 * GS * T8_SLOTS; i += 64) reinterpret_cast<uint4 *>(smem + tp.off_slots)[i] = make_uint4(0, 0, 0, 0);
+  for (u32 i = lane; i < 8 * GS * SL; i += 64) reinterpret_cast<uint4 *>(smem + tp.off_slots)[i] = make_uint4(0, 0, 0, 0);
+  if (real && is_node) for (u32 i = 0; i < T8_SLOTS - SL; i++) xslots[l * (T8_SLOTS - SL) + i] = make_uint4(0, 0, 0, 0);
   for (u32 i = l; i < 16; i += GS) { gen[i] = i; gen[16 + i] = 1; }
   if (l == 0) gen[32] = p.cfg.key_count;
   if (real) for (u32 i = l; i < p.cfg.max_values; i += GS) g_kvn[i] = 0;
@@ -173,17 +179,64 @@ __global__ void __launch_bounds__(64) txn8_kernel(const T8Params tp) {
       try_commit(e);
     }
   };
-  // elements of `k` visible at version `from`: versions only grow along a key's row, so it is a count (independent loads)
-  auto visible = [&](u32 k, u32 from) -> u32 {
-    if (from == V_NIL) return 0u;
-    const u32 cnt = g_kvn[k];
-    u32 n = 0;
-    for (u32 i = 0; i < cnt; i++) n += (g_kv[k * mw + i] >> 8) <= from ? 1u : 0u;
-    return n;
-  };
-
+  // What a node needs from HBM to complete a transaction (its micro-ops, the element counts and rows of the keys it reads) and
+  // what the service needs to apply a cas (the micro-ops, the counts of the keys appended to): three dependent batches of
+  // independent loads, shared by every lane of the wavefront that needs any this round, kept in registers for the completion.
+  // (Issuing them rounds ahead — the plan is known when the envelope is committed to — was tried and bought nothing: with two
+  // wavefronts per SIMD the round trips of ~10^4 clusters' scattered pages stay longer than a round of other work.)
+  bool pf_valid = false, pf_done = false, pf_cas = false; u32 pf_off0 = 0, pf_n = 0, pf_from = V_NIL;
+  u32 pf_wv[MM], pf_cn[MM], pf_vis[MM]; uint4 pf_el[MM];
+#pragma unroll
+  for (int j = 0; j < MM; j++) { pf_wv[j] = 0; pf_cn[j] = 0; pf_vis[j] = 0; pf_el[j] = make_uint4(0, 0, 0, 0); }
+  u32 pf_stage = 0;   // batches done for the plan: 1 micro-ops, 2 element counts, 3 rows (complete)
+#define T8_STAGE_W(go_) do {                                                                                                        \
+    const bool tf_g = (go_);                                                                                                        \
+    /* (loads under the lanes' own predicate straight into the plan's registers: a select against the old value would wait for them) */ \
+    if (tf_g) { _Pragma("unroll") for (int j = 0; j < MM; j++) { pf_wv[j] = pf_cas ? 0u : 1u; if ((u32)j < pf_n) pf_wv[j] = g_pay[pf_off0 + (u32)j]; } } \
+    pf_stage = tf_g ? 1u : pf_stage;                                                                                                \
+  } while (0)
+  /* element counts: of the keys a completing node reads (none if it started from nil), of the keys the service appends to */
+#define T8_STAGE_C(go_) do {                                                                                                        \
+    const bool tf_g = (go_);                                                                                                        \
+    if (tf_g) { _Pragma("unroll") for (int j = 0; j < MM; j++) {                                                                    \
+      const bool tf_want = (u32)j < pf_n && (pf_cas ? (pf_wv[j] & 1u) != 0 : (!(pf_wv[j] & 1u) && pf_from != V_NIL));               \
+      pf_cn[j] = 0u; if (tf_want) pf_cn[j] = g_kvn[(pf_wv[j] >> 1) & 0x7FFFu];                                                      \
+    } }                                                                                                                             \
+    pf_stage = tf_g ? 2u : pf_stage;                                                                                                \
+  } while (0)
+  /* completing nodes: the rows of the keys they read -> number of visible elements and their values (16 bytes) */
+#define T8_STAGE_R(go_) do {                                                                                                        \
+    const bool tf_g = (go_);                                                                                                        \
+    _Pragma("unroll") for (int j = 0; j < MM; j++) {                                                                                \
+      if (tf_g) { pf_vis[j] = 0; pf_el[j] = make_uint4(0, 0, 0, 0); }                                                               \
+      if (tf_g && pf_done && (u32)j < pf_n && !(pf_wv[j] & 1u) && pf_cn[j] != 0) {                                                  \
+        const uint4 *tf_row = reinterpret_cast<const uint4 *>(g_kv + (size_t)((pf_wv[j] >> 1) & 0x7FFFu) * mw);                     \
+        uint4 tf_r[4];                                                                                                              \
+        _Pragma("unroll") for (int qq = 0; qq < 4; qq++) tf_r[qq] = 4u * (u32)qq < pf_cn[j] ? tf_row[qq] : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu); \
+        u32 tf_v = 0, tf_e[4];                                                                                                      \
+        _Pragma("unroll") for (int qq = 0; qq < 4; qq++) {                                                                          \
+          const u32 tf_b = 4u * (u32)qq;                                                                                            \
+          tf_v += (tf_b + 0 < pf_cn[j] && (tf_r[qq].x >> 8) <= pf_from) ? 1u : 0u; tf_v += (tf_b + 1 < pf_cn[j] && (tf_r[qq].y >> 8) <= pf_from) ? 1u : 0u; \
+          tf_v += (tf_b + 2 < pf_cn[j] && (tf_r[qq].z >> 8) <= pf_from) ? 1u : 0u; tf_v += (tf_b + 3 < pf_cn[j] && (tf_r[qq].w >> 8) <= pf_from) ? 1u : 0u; \
+          tf_e[qq] = (tf_r[qq].x & 0xFFu) | ((tf_r[qq].y & 0xFFu) << 8) | ((tf_r[qq].z & 0xFFu) << 16) | ((tf_r[qq].w & 0xFFu) << 24); \
+        }                                                                                                                           \
+        pf_vis[j] = tf_v; pf_el[j] = make_uint4(tf_e[0], tf_e[1], tf_e[2], tf_e[3]);                                                \
+      }                                                                                                                             \
+    }                                                                                                                               \
+    pf_stage = tf_g ? 3u : pf_stage;                                                                                                \
+  } while (0)
+#ifdef T8_PROF
+  u64 pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; u32 wave_rounds = 0;
+  u64 tprev = __builtin_readcyclecounter();
+#define T8_MARK(i) { const u64 now_ = __builtin_readcyclecounter(); pacc[i] += now_ - tprev; tprev = now_; }
+#else
+#define T8_MARK(i)
+#endif
   for (;;) {
     if (!__ballot(alive)) break;
+#ifdef T8_PROF
+    wave_rounds++;
+#endif
     const u32 busy_mask = GB(busy);
 
     // ---- time-free phase transitions ----
@@ -256,6 +309,7 @@ __global__ void __launch_bounds__(64) txn8_kernel(const T8Params tp) {
       if (busy && timeout_at <= T) complete(MSIM_T_INFO, MSIM_ERR_NET_TIMEOUT, c_value);
     }
     bool normal = alive && !timeout_round;   // this cluster runs R1-R4 in this wave-round
+    T8_MARK(0)
     if (__ballot(normal)) {
       // ---- R1: scheduler ----
       const bool act = normal && due <= T;
@@ -271,14 +325,14 @@ __global__ void __launch_bounds__(64) txn8_kernel(const T8Params tp) {
           if (nem_act) { nem_j++; nem_rows = 2; }
           if (__ballot(start)) {
             misc[l] = l;
-            __syncthreads();
+            wave_lds_fence();
             if (start && l == 0 && spec != MSIM_SPEC_ONE) {
               for (u32 i = N - 1; i >= 1; i--) {
                 const u32 kk = scale32(draw32(key, S_NEM_SHUFFLE, ((u64)j << 16) | i), i + 1);
                 const u32 t = misc[i]; misc[i] = misc[kk]; misc[kk] = t;
               }
             }
-            __syncthreads();
+            wave_lds_fence();
             u32 my_part = 0;
             if (start && is_node) {
               if (spec == MSIM_SPEC_ONE) {
@@ -361,6 +415,7 @@ __global__ void __launch_bounds__(64) txn8_kernel(const T8Params tp) {
         }
       }
 
+      T8_MARK(1)
       // ---- R2: marked clients invoke; the request goes to this lane's own node ----
       if (__ballot(mark && normal)) {
         const bool inv = mark && normal;
@@ -383,10 +438,15 @@ __global__ void __launch_bounds__(64) txn8_kernel(const T8Params tp) {
         poll();
       }
 
+      T8_MARK(2)
       // ---- R3: one input per node, then one for the service (endpoint order) ----
+      // Decisions first (registers and LDS only), then the HBM reads of every lane that needs any — a node completing a transaction,
+      // the service applying a cas — in three batches of independent loads: the micro-ops, the keys' element counts, the rows.
       bool to_svc = false, rep = false, svc_rep = false;   // node -> service, node -> own client, service -> node
       u32 o_type = 0, o_a = 0, o_b = 0, o_dest = 0, need_words = 0, done_slot = 0;
-      if (normal && l <= N && deliver_at <= T) {
+      bool do_done = false, do_cas = false; u32 m_off0 = 0, m_n = 0, m_from = V_NIL, cas_base = 0;
+      const bool take = normal && l <= N && deliver_at <= T;
+      if (take) {
         const uint4 q = cm; deliver_at = INF;
         const u32 qsrc = q.w >> 24, qb = q.w & 0xFFFFFFu, qtype = q.y & 0xFFu, qa = q.z;
         if (qsrc >= N && qsrc < SVC) s_recv_cl++; else s_recv_sv++;
@@ -394,41 +454,32 @@ __global__ void __launch_bounds__(64) txn8_kernel(const T8Params tp) {
           switch (qtype) {
             case M_INIT: rep = true; o_type = M_INIT_OK; o_b = qb; break;
             case M_TXN: {
-              u32 i = 0; while (i < T8_SLOTS && (my_slots[i].w >> 24)) i++;
+              u32 i = 0; while (i < T8_SLOTS && (SLOT_PTR(l, i)->w >> 24)) i++;
               if (i == T8_SLOTS) { my_flags |= MSIM_FLAG_ARENA_OVERRUN; break; }
               const u32 rid = ++node_msgid;
-              my_slots[i] = make_uint4(qb, qa, rid, (1u << 16) | (1u << 24));
+              *SLOT_PTR(l, i) = make_uint4(qb, qa, rid, (1u << 16) | (1u << 24));
               to_svc = true; o_type = M_READ; o_a = 0; o_b = rid;
             } break;
             case M_READ_OK: case M_CAS_OK: case M_ERROR: {
               u32 i = 0;
-              while (i < T8_SLOTS) { const uint4 s = my_slots[i]; if ((s.w >> 24) && s.z == qb) break; i++; }
+              while (i < T8_SLOTS) { const uint4 s = *SLOT_PTR(l, i); if ((s.w >> 24) && s.z == qb) break; i++; }
               if (i == T8_SLOTS) break;  // handle-reply!: no such rpc
-              uint4 s = my_slots[i];
+              uint4 s = *SLOT_PTR(l, i);
               if (((s.w >> 16) & 0xFF) == 1) {
                 u32 from;
                 if (qtype == M_READ_OK) from = qa;
                 else if (qtype == M_ERROR && qa == 20) from = V_NIL;
-                else { rep = true; o_type = M_ERROR; o_a = qa; o_b = s.x; my_slots[i] = make_uint4(0, 0, 0, 0); break; }
+                else { rep = true; o_type = M_ERROR; o_a = qa; o_b = s.x; *SLOT_PTR(l, i) = make_uint4(0, 0, 0, 0); break; }
                 const u32 rid = ++node_msgid;
                 s.z = rid; s.w = from | (2u << 16) | (1u << 24);
-                my_slots[i] = s;
+                *SLOT_PTR(l, i) = s;
                 to_svc = true; o_type = M_CAS; o_a = from | (i << 16); o_b = rid;
               } else {
                 rep = true; o_b = s.x;
-                if (qtype == M_CAS_OK) {  // the completed transaction goes into the payload area (sized here, written below)
-                  o_type = M_TXN_OK; done_slot = i;
-                  const u32 off0 = s.y & 0xFFFFFFu, n = s.y >> 24, from = s.w & 0xFFFFu;
-                  for (u32 j = 0; j < n; j++) {
-                    const u32 w = g_pay[off0 + j], k = (w >> 1) & 0x7FFFu;
-                    need_words++;
-                    if (!(w & 1)) {
-                      u32 len = visible(k, from);
-                      for (u32 e = 0; e < j; e++) { const u32 we = g_pay[off0 + e]; if ((we & 1) && ((we >> 1) & 0x7FFFu) == k) len++; }
-                      need_words += (len + 3) / 4;
-                    }
-                  }
-                } else { o_type = M_ERROR; o_a = qa == 22 ? 30u : qa; my_slots[i] = make_uint4(0, 0, 0, 0); }
+                if (qtype == M_CAS_OK) {  // the completed transaction goes into the payload area (sized and written below)
+                  o_type = M_TXN_OK; done_slot = i; do_done = true;
+                  m_off0 = s.y & 0xFFFFFFu; m_n = s.y >> 24; m_from = s.w & 0xFFFFu;
+                } else { o_type = M_ERROR; o_a = qa == 22 ? 30u : qa; *SLOT_PTR(l, i) = make_uint4(0, 0, 0, 0); }
               }
             } break;
             default: break;
@@ -441,53 +492,90 @@ __global__ void __launch_bounds__(64) txn8_kernel(const T8Params tp) {
             const u32 from = qa & 0xFFFFu, i = qa >> 16;
             if (root != V_NIL && root != from) { o_type = M_ERROR; o_a = 22; }
             else {
-              const u32 base = root == V_NIL ? 0u : root;
-              const u32 ref = slots_g[qsrc * T8_SLOTS + i].y, off0 = ref & 0xFFFFFFu, n = ref >> 24;
-              u32 na = 0;
-              for (u32 j = 0; j < n; j++) na += g_pay[off0 + j] & 1;
-              for (u32 j = 0; j < n; j++) {
-                const u32 w = g_pay[off0 + j];
-                if (w & 1) { const u32 k = (w >> 1) & 0x7FFFu; const u32 c = g_kvn[k]; g_kv[k * mw + c] = ((w >> 16) & 0xFFu) | ((base + na) << 8); g_kvn[k] = c + 1; }
-              }
-              root = base + na;
+              cas_base = root == V_NIL ? 0u : root;
+              const u32 ref = SLOT_PTR(qsrc, i)->y;
+              m_off0 = ref & 0xFFFFFFu; m_n = ref >> 24; do_cas = true;
               o_type = M_CAS_OK; o_a = 0;
             }
           }
         }
       }
+      T8_MARK(3)
+      if (__ballot(do_done || do_cas)) {
+        const bool have = pf_valid && pf_off0 == m_off0 && pf_n == m_n && ((do_done && pf_done && pf_from == m_from) || (do_cas && pf_cas));
+        const bool mem = do_done || do_cas;
+        if (mem && !have) { pf_valid = true; pf_done = do_done; pf_cas = do_cas; pf_off0 = m_off0; pf_n = m_n; pf_from = m_from; pf_stage = 0; }
+        if (__ballot(mem && pf_stage < 1u)) T8_STAGE_W(mem && pf_stage < 1u);
+        if (__ballot(mem && pf_stage < 2u)) T8_STAGE_C(mem && pf_stage < 2u);
+        if (__ballot(mem && pf_stage < 3u)) T8_STAGE_R(mem && pf_stage < 3u);
+        if (do_done) {   // size of the completed form
+#pragma unroll
+          for (int j = 0; j < MM; j++) if ((u32)j < m_n) {
+            need_words++;
+            if (!(pf_wv[j] & 1u)) {
+              u32 len = pf_vis[j];
+#pragma unroll
+              for (int e = 0; e < j; e++) if ((pf_wv[e] & 1u) && ((pf_wv[e] >> 1) & 0x7FFFu) == ((pf_wv[j] >> 1) & 0x7FFFu)) len++;
+              need_words += (len + 3) / 4;
+            }
+          }
+        }
+        if (do_cas) {   // the service appends: element | version << 8 at the end of each key's row
+          u32 na = 0;
+#pragma unroll
+          for (int j = 0; j < MM; j++) na += ((u32)j < m_n) ? (pf_wv[j] & 1u) : 0u;
+#pragma unroll
+          for (int j = 0; j < MM; j++) if ((u32)j < m_n && (pf_wv[j] & 1u)) {
+            const u32 w = pf_wv[j], k = (w >> 1) & 0x7FFFu;
+            u32 c = pf_cn[j];   // + this transaction's earlier appends to the same key
+#pragma unroll
+            for (int e = 0; e < j; e++) if ((pf_wv[e] & 1u) && ((pf_wv[e] >> 1) & 0x7FFFu) == k) c++;
+            g_kv[(size_t)k * mw + c] = ((w >> 16) & 0xFFu) | ((cas_base + na) << 8); g_kvn[k] = c + 1;
+          }
+          root = cas_base + na;
+        }
+      }
 
-      // completed transactions: payload words allocated in node order, each node writes its own
+      if (take) pf_valid = false;   // (the registers stay as they are for the completion below)
+
+      // completed transactions: payload words allocated in node order, each node writes its own (from the registers filled above)
       if (__ballot(need_words != 0)) {
-        __syncthreads();   // the service's appends of this round are visible to the nodes that complete (other lanes' global stores)
         u32 excl = 0, total = 0;
         for (u32 s = 0; s < N; s++) { const u32 v = GGET(need_words, s); excl += s < l ? v : 0u; total += v; }
         if (total) {
-          if (n_payload + total > max_pay) { flags |= MSIM_FLAG_PAYLOAD_OVERFLOW; if (need_words) { o_a = 0; my_slots[done_slot] = make_uint4(0, 0, 0, 0); } }
+          if (n_payload + total > max_pay) { flags |= MSIM_FLAG_PAYLOAD_OVERFLOW; if (need_words) { o_a = 0; *SLOT_PTR(l, done_slot) = make_uint4(0, 0, 0, 0); } }
           else {
             if (need_words) {
-              const uint4 s = my_slots[done_slot];
-              const u32 off0 = s.y & 0xFFFFFFu, n = s.y >> 24, from = s.w & 0xFFFFu;
               u32 pp = n_payload + excl;
               o_a = pp | (need_words << 24);
-              for (u32 j = 0; j < n; j++) {
-                const u32 w = g_pay[off0 + j], k = (w >> 1) & 0x7FFFu;
+#pragma unroll
+              for (int j = 0; j < MM; j++) if ((u32)j < m_n) {
+                const u32 w = pf_wv[j], k = (w >> 1) & 0x7FFFu;
                 if (w & 1) { g_pay[pp++] = w; continue; }
-                const u32 vis = visible(k, from);
+                const u32 vis = pf_vis[j];
                 u32 e = 0, acc = 0;
                 const u32 hdr = pp++;
-                for (u32 i = 0; i < vis; i++) { acc |= (g_kv[k * mw + i] & 0xFFu) << (8 * (e & 3)); if ((++e & 3) == 0) { g_pay[pp++] = acc; acc = 0; } }
-                for (u32 i = 0; i < j; i++) { const u32 wi = g_pay[off0 + i];
+                const u32 ew[4] = {pf_el[j].x, pf_el[j].y, pf_el[j].z, pf_el[j].w};
+#pragma unroll
+                for (int qq = 0; qq < 4; qq++) {   // the visible prefix of the row, 4 elements per word as the payload packs them
+                  if (4u * (u32)qq + 4u <= vis) { g_pay[pp++] = ew[qq]; e += 4; }
+                  else if (4u * (u32)qq < vis) { const u32 r = vis - 4u * (u32)qq; acc = ew[qq] & ((1u << (8u * r)) - 1u); e += r; }
+                }
+#pragma unroll
+                for (int i = 0; i < j; i++) { const u32 wi = pf_wv[i];
                   if ((wi & 1) && ((wi >> 1) & 0x7FFFu) == k) { acc |= ((wi >> 16) & 0xFFu) << (8 * (e & 3)); if ((++e & 3) == 0) { g_pay[pp++] = acc; acc = 0; } } }
                 if (e & 3) g_pay[pp++] = acc;
                 g_pay[hdr] = (k << 1) | ((e ? e : 0xFFu) << 16);  // a key without elements reads nil
               }
-              my_slots[done_slot] = make_uint4(0, 0, 0, 0);
+              *SLOT_PTR(l, done_slot) = make_uint4(0, 0, 0, 0);
             }
             n_payload += total;
           }
         }
       }
 
+
+      T8_MARK(4)
       // COMMIT: ids in lane order (nodes, then the service)
       bool c_arr = false; u32 ca_y = 0, ca_a = 0, ca_b = 0;
       {
@@ -520,6 +608,7 @@ __global__ void __launch_bounds__(64) txn8_kernel(const T8Params tp) {
         poll();
       }
 
+      T8_MARK(5)
       // ---- R4: the clients' recv! loops (client.clj:94-107) ----
       if (__ballot(c_arr || (busy && (cin_n | csp_n) != 0))) {
         for (;;) {
@@ -555,6 +644,7 @@ __global__ void __launch_bounds__(64) txn8_kernel(const T8Params tp) {
       }
     }
 
+    T8_MARK(6)
     // ---- history rows: nemesis rows, invocations (lane order), completions (lane order) ----
     {
       const u32 imask = GB(inv_row), cmask = GB(cmp_row);
@@ -566,36 +656,22 @@ __global__ void __launch_bounds__(64) txn8_kernel(const T8Params tp) {
         const bool wr = alive && nr != 0;
         const u64 tns = (u64)T * 1000ull;
         const u32 tlo = (u32)tns, thi = (u32)(tns >> 32);
+        uint4 *const out = reinterpret_cast<uint4 *>(g_rows) + n_rows;   // (no staging: a few 16-byte rows per round; the L2 merges them into lines)
         if (NEM && wr && nem_rows && l == 0) {
           const u32 pk = MSIM_T_INFO | (nem_f << 2) | (MSIM_PROCESS_NEMESIS << 12);
-          stage[n_rows % T8_STAGE] = make_uint4(tlo, thi, pk, nem_v1);
-          stage[(n_rows + 1) % T8_STAGE] = make_uint4(tlo, thi | (nem_len2 << 16), pk, nem_v2);
+          out[0] = make_uint4(tlo, thi, pk, nem_v1);
+          out[1] = make_uint4(tlo, thi | (nem_len2 << 16), pk, nem_v2);
         }
-        if (wr && inv_row) stage[(n_rows + nem_rows + __popc(imask & lt)) % T8_STAGE] = make_uint4(tlo, thi | (inv_len << 16), inv_packed, inv_value);
-        if (wr && cmp_row) stage[(n_rows + nem_rows + ni + __popc(cmask & lt)) % T8_STAGE] = make_uint4(tlo, thi | (cmp_len << 16), cmp_packed, cmp_value);
+        if (wr && inv_row) out[nem_rows + __popc(imask & lt)] = make_uint4(tlo, thi | (inv_len << 16), inv_packed, inv_value);
+        if (wr && cmp_row) out[nem_rows + ni + __popc(cmask & lt)] = make_uint4(tlo, thi | (cmp_len << 16), cmp_packed, cmp_value);
         const u32 new_n = wr ? n_rows + nr : n_rows;
-        const bool flush = (new_n >> 4) != (n_rows >> 4);   // a 16-row block completed (at most one per round: nr <= 16)
-        if (__ballot(flush)) {
-          __syncthreads();
-          if (flush) {
-            const u32 g0 = (n_rows >> 4) * 16u + l;
-            if (g0 < max_rows) reinterpret_cast<uint4 *>(g_rows)[g0] = stage[g0 % T8_STAGE];
-            if (g0 + 8u < max_rows) reinterpret_cast<uint4 *>(g_rows)[g0 + 8u] = stage[(g0 + 8u) % T8_STAGE];
-          }
-          __syncthreads();
-        }
         n_rows = new_n;
       }
     }
+    T8_MARK(7)
   }
 
   // ---- epilogue ----
-  __syncthreads();
-  {
-    const u32 g0 = (n_rows >> 4) * 16u + l;
-    if (real && g0 < n_rows) reinterpret_cast<uint4 *>(g_rows)[g0] = stage[g0 % T8_STAGE];
-    if (real && g0 + 8u < n_rows) reinterpret_cast<uint4 *>(g_rows)[g0 + 8u] = stage[(g0 + 8u) % T8_STAGE];
-  }
   u32 t_send_cl = 0, t_send_sv = 0, t_recv_cl = 0, t_recv_sv = 0;
   for (u32 s = 0; s < GS; s++) { t_send_cl += GGET(s_send_cl, s); t_send_sv += GGET(s_send_sv, s); t_recv_cl += GGET(s_recv_cl, s); t_recv_sv += GGET(s_recv_sv, s); }
   for (u32 b = 1; b <= MSIM_FLAG_ARENA_OVERRUN; b <<= 1) if (GB((my_flags & b) != 0)) flags |= b;
@@ -607,6 +683,11 @@ __global__ void __launch_bounds__(64) txn8_kernel(const T8Params tp) {
     p.stats[inst] = st;
     msim_inst_meta m; m.n_rows = n_rows; m.n_payload_words = n_payload; m.flags = flags; m.n_rounds = rounds;
     m.n_events = 0; m.reserved[0] = 0; m.reserved[1] = 0; m.reserved[2] = 0;
+#ifdef T8_PROF   // developer build (tools/txn8_prof.sh): cycle counters of the round's sections in the meta of the wavefront's first three clusters
+    if (grp == 0) { m.n_events = (u32)(pacc[0] >> 6); m.reserved[0] = (u32)(pacc[1] >> 6); m.reserved[1] = (u32)(pacc[2] >> 6); m.reserved[2] = (u32)(pacc[3] >> 6); }
+    if (grp == 1) { m.n_events = (u32)(pacc[4] >> 6); m.reserved[0] = (u32)(pacc[5] >> 6); m.reserved[1] = (u32)(pacc[6] >> 6); m.reserved[2] = (u32)(pacc[7] >> 6); }
+    if (grp == 2) { m.n_events = wave_rounds; }
+#endif
     p.meta[inst] = m;
   }
 }
@@ -615,13 +696,14 @@ __global__ void __launch_bounds__(64) txn8_kernel(const T8Params tp) {
 
 // Whether eight clusters per wavefront simulate this configuration (see the header of this file).
 bool msim_txn8_eligible(const msim_config &c) {
-  return c.node_program == MSIM_NODE_TXN_SINGLE_KEY && c.journal_capacity == 0 && c.n_nodes >= 1 && c.n_nodes <= GS - 1u && c.concurrency == c.n_nodes;
+  return c.node_program == MSIM_NODE_TXN_SINGLE_KEY && c.journal_capacity == 0 && c.n_nodes >= 1 && c.n_nodes <= GS - 1u && c.concurrency == c.n_nodes &&
+         c.max_txn_length <= (uint32_t)MM && c.max_writes_per_key % 4 == 0 && c.max_writes_per_key <= 16;   // micro-ops and rows in registers
 }
 
 // Extra per-instance scratch words behind the queues' spill area: the clients' spill, and what of the LDS queues of txn_kernel<>
 // does not fit this kernel's RQ slots.
 uint64_t msim_txn8_extra_scratch_words(const msim_config &c) {
-  return ((uint64_t)(c.n_nodes + 1) * c.inbox_capacity + (uint64_t)c.n_nodes * T8_CLIENT_CAP) * 4;
+  return ((uint64_t)(c.n_nodes + 1) * c.inbox_capacity + (uint64_t)c.n_nodes * T8_CLIENT_CAP + (uint64_t)c.n_nodes * (T8_SLOTS - SL)) * 4;
 }
 
 hipError_t msim_launch_txn8(const KParams &kp, uint32_t n, hipStream_t st) {
@@ -634,11 +716,11 @@ hipError_t msim_launch_txn8(const KParams &kp, uint32_t n, hipStream_t st) {
   tp.client_spill_off = kp.spill_off + (uint64_t)(kp.N + 1) * tp.node_spill * 4;
   size_t off = (size_t)RQ * 64 * 16;
   tp.off_cq = (u32)off; off += (size_t)CQ * 64 * 16;
-  tp.off_slots = (u32)off; off += (size_t)8 * GS * T8_SLOTS * 16;
+  tp.off_slots = (u32)off; off += (size_t)8 * GS * SL * 16;
   tp.off_gen = (u32)off; off += (size_t)8 * 36 * 4;
   off = (off + 15) & ~(size_t)15;
-  tp.off_stage = (u32)off; off += (size_t)8 * T8_STAGE * 16;
   tp.off_misc = (u32)off; off += 64 * 4;
+  tp.xslots_off = tp.client_spill_off + (uint64_t)kp.N * tp.client_spill * 4;
   tp.round_limit = (kp.dev_flags & 0x100u) ? 4000000u : ROUND_LIMIT;
   const size_t lds = off;
   const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;

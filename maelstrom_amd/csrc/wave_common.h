@@ -124,6 +124,16 @@ __device__ __forceinline__ u32 topo_adj(u32 topology, u32 n, u32 a) {
   return m;
 }
 
+// Orders this wavefront's LDS traffic across its lanes (a lane reads what another lane of the SAME wavefront wrote): LDS operations
+// of one wavefront execute in order, so all it takes is to keep the compiler from moving them — no s_barrier, and above all no
+// s_waitcnt vmcnt(0), which `__syncthreads()` implies and which would wait for every global load still in flight (prefetches).
+// Only for kernels whose workgroup is one wavefront.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // duo.hip: two clusters per wavefront (fire-and-forget broadcast, constant latency, colocated clients)
 bool msim_duo_eligible(const msim_config &c);
 hipError_t msim_launch_duo(const KParams &kp, uint32_t n, hipStream_t st);

@@ -44,7 +44,8 @@ CASES = {
     "txn-part": (dict(workload="txn-list-append", node_count=5, rate=100, time_limit=20, seed=17, latency=5, nemesis=["partition"], nemesis_interval=3), 0, 9),
     "txn-exp-loss": (dict(workload="txn-list-append", node_count=5, rate=100, time_limit=10, seed=17, latency=20, latency_dist="exponential", p_loss=0.05), 0, 9),
     "txn-n3": (dict(workload="txn-list-append", node_count=3, rate=200, time_limit=10, seed=17, latency=2), 0, 9),
-    "txn-n7": (dict(workload="txn-list-append", node_count=7, rate=150, time_limit=10, seed=17, latency=10, latency_dist="uniform", key_count=3, max_txn_length=6), 0, 9),
+    "txn-n7": (dict(workload="txn-list-append", node_count=7, rate=150, time_limit=10, seed=17, latency=10, latency_dist="uniform", key_count=3, max_txn_length=4), 0, 9),
+    "txn-len6": (dict(workload="txn-list-append", node_count=5, rate=100, time_limit=10, seed=17, latency=5, key_count=3, max_txn_length=6), 0, 6),
     "txn-n1": (dict(workload="txn-list-append", node_count=1, rate=50, time_limit=5, seed=3), 0, 5),
     "n12-spill": (dict(workload="broadcast", node_count=12, latency=30, rate=300, time_limit=10, inbox_capacity=2, spill_capacity=64, seed=123), 1000, 3),
 }

@@ -38,7 +38,7 @@ def summarise(path):
         print(f"-- no PMC data ({e.__class__.__name__}: {e})")
 
 
-OURS = ("sim_kernel", "check_kernel", "raft_kernel", "raft4_kernel", "txn_kernel", "hat_kernel", "svc_kernel", "compact_", "availability_kernel")
+OURS = ("sim_kernel", "check_kernel", "raft_kernel", "raft4_kernel", "txn_kernel", "txn8_kernel", "hat_kernel", "svc_kernel", "compact_", "availability_kernel")
 
 
 def counters_json(paths, out):
