@@ -557,7 +557,7 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
     cmp_packed = MSIM_T_OK | (MSIM_F_BROADCAST << 2) | (i << 12); cmp_value = v;
     // read -> read_ok with the whole set: the cluster's lanes copy the node's set LDS -> HBM payload
     if (__ballot(rd)) {
-      __syncthreads();
+      wave_lds_fence();
       const u32 rdm = hb(rd, hi);
       const u32 words = (next_value + 31u) >> 5;
       const u32 my_rank = __popc(rdm & lt);
@@ -606,13 +606,13 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
       const u32 new_n = ovf ? n_rows : n_rows + nr;
       const bool flush = !RND && (new_n >> 6) != (n_rows >> 6);   // a 64-row block completed (at most one per round: nr <= 64)
       if (__ballot(flush)) {
-        __syncthreads();
+        wave_lds_fence();
         if (flush) {
           const u32 g0 = (n_rows >> 6) * 64u + i;
           if (g0 < max_rows) reinterpret_cast<uint4 *>(g_rows)[g0] = stage[g0 % DUO_STAGE_ROWS];
           if (g0 + 32u < max_rows) reinterpret_cast<uint4 *>(g_rows)[g0 + 32u] = stage[(g0 + 32u) % DUO_STAGE_ROWS];
         }
-        __syncthreads();
+        wave_lds_fence();
       }
       n_rows = new_n;
     }

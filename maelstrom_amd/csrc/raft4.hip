@@ -397,14 +397,14 @@ __global__ void __launch_bounds__(64) raft4_kernel(const R4Params rp) {
           if (nem_act) { nem_j++; nem_rows = 2; }
           if (__ballot(start)) {
             misc[l] = l;
-            __syncthreads();
+            wave_lds_fence();
             if (start && l == 0 && spec != MSIM_SPEC_ONE) {
               for (u32 i = N - 1; i >= 1; i--) {
                 const u32 kk = scale32(draw32(key, S_NEM_SHUFFLE, ((u64)j << 16) | i), i + 1);
                 const u32 t = misc[i]; misc[i] = misc[kk]; misc[kk] = t;
               }
             }
-            __syncthreads();
+            wave_lds_fence();
             u32 my_part = 0;
             if (start && is_node) {
               if (spec == MSIM_SPEC_ONE) {
@@ -680,7 +680,7 @@ __global__ void __launch_bounds__(64) raft4_kernel(const R4Params rp) {
         const u32 fan_cnt = __popc(fan_mask);
         const u32 cnt = fan_cnt + (rep ? 1u : 0u);
         if (__ballot(cnt != 0)) {
-          __syncthreads();  // aeref[] written above is read by other lanes
+          wave_lds_fence();  // aeref[] written above is read by other lanes
           // backlogs: the cluster's lanes copy entries next_index .. log_n of the leader's log into the body
           u32 bl = GB(bulk_mask != 0);
           while (__ballot(bl != 0)) {
@@ -783,13 +783,13 @@ __global__ void __launch_bounds__(64) raft4_kernel(const R4Params rp) {
         const u32 new_n = wr ? n_rows + nr : n_rows;
         const bool flush = (new_n >> 5) != (n_rows >> 5);   // a 32-row block completed (at most one per round: nr <= 22)
         if (__ballot(flush)) {
-          __syncthreads();
+          wave_lds_fence();
           if (flush) {
             const u32 g0 = (n_rows >> 5) * 32u + l;
             if (g0 < max_rows) reinterpret_cast<uint4 *>(g_rows)[g0] = stage[g0 % R4_STAGE];
             if (g0 + 16u < max_rows) reinterpret_cast<uint4 *>(g_rows)[g0 + 16u] = stage[(g0 + 16u) % R4_STAGE];
           }
-          __syncthreads();
+          wave_lds_fence();
         }
         n_rows = new_n;
       }
