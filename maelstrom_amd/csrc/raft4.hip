@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(64) raft4_kernel(const R4Params rp) {
     if (alive && timeout_round) {
       if (busy && timeout_at <= T) complete(c_f == MSIM_F_READ ? MSIM_T_FAIL : MSIM_T_INFO, MSIM_ERR_NET_TIMEOUT, c_value);  // lin_kv.clj:52
     }
-    const bool normal = alive && !timeout_round;   // this cluster runs R1-R4 in this wave-round
+    bool normal = alive && !timeout_round;   // this cluster runs R1-R4 in this wave-round
     // an append_entries a node has committed to and is due is what it handles in R3 (R2 commits client requests only, and only to
     // nodes without one): fetch header and first entries of its body now, use them in R3
     uint4 dh = make_uint4(0, 0, 0, 0), de0 = dh, de1 = dh;
@@ -458,22 +458,26 @@ __global__ void __launch_bounds__(64) raft4_kernel(const R4Params rp) {
           const u32 selm = GB(sel);
           const u32 sl = selm ? (u32)__builtin_ctz(selm) : 0u;                       // the chosen lane of my group
           const u32 s_proc = GGET(process, sl), s_reg = GGET(key_reg, sl);
-          bool fresh_key = false;
+          bool fresh_key = false, key_ovf = false;
           if (gen && s_reg != s_proc) {  // this process has not used the current key yet
-            if (key_procs == 20) { cur_key++; key_procs = 0; fresh_key = true; }
-            key_procs++;
+            if (key_procs == 20) {
+              if (cur_key >= 255) key_ovf = true;   // keys travel in 8 bits (oracle: same flag, same stop)
+              else { cur_key++; key_procs = 0; fresh_key = true; }
+            }
+            if (!key_ovf) key_procs++;
           }
+          if (key_ovf) { flags |= MSIM_FLAG_VALUES_OVERFLOW; phase = PH_DONE; alive = false; normal = false; }
           if (fresh_key) key_reg = INF;
           const u64 h2 = draw64(key, S_GEN2, kk);
           const u32 v1 = scale32((u32)(h2 >> 32), 5), v2 = (((u32)(h2 >> 20) & 0xFFFu) * 5u) >> 12, kx = cur_key & 0xFFu;
-          if (sel) {
+          if (sel && !key_ovf) {
             key_reg = process;
             mark = true; kind = K_OP;
             if (slot < N) { m_f = MSIM_F_READ; m_value = kx | 0xFFFF00u; }
             else if (scale32((u32)h2, 3) == 0) { m_f = MSIM_F_WRITE; m_value = kx | (v1 << 8) | 0xFF0000u; }
             else { m_f = MSIM_F_CAS; m_value = kx | (v1 << 8) | (v2 << 16); }
           }
-          if (gen) { gen_k++; gen_next = T + __umulhi(r_hi, p.gen_period2_us); }
+          if (gen && !key_ovf) { gen_k++; gen_next = T + __umulhi(r_hi, p.gen_period2_us); }
         }
       }
 

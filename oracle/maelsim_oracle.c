@@ -590,7 +590,11 @@ static void sched_act(sim_t *s) {
              * first n threads read, the others mix [w cas cas]; values 0..4; (gen/process-limit 20) retires a key
              * once 20 distinct processes have used it */
             if (s->key_reg[slot] != 1 + c->process) {
-              if (s->key_procs == 20) { s->cur_key++; s->key_procs = 0; memset(s->key_reg, 0, s->CS * 4); }
+              if (s->key_procs == 20) {
+                /* keys travel in 8 bits of the op's value: a 257th key would alias the first (and the checker would merge their histories) */
+                if (s->cur_key >= 255) { s->meta.flags |= MSIM_FLAG_VALUES_OVERFLOW; c->mark = 0; s->phase = PH_DONE; return; }
+                s->cur_key++; s->key_procs = 0; memset(s->key_reg, 0, s->CS * 4);
+              }
               s->key_reg[slot] = 1 + c->process; s->key_procs++;
             }
             u64 h2 = draw64(s, S_GEN2, k);

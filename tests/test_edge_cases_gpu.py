@@ -70,6 +70,26 @@ def test_capacity_overflows_are_flagged_not_truncated(lib):
     assert (ora.meta["flags"] & A.FLAG_INBOX_OVERFLOW).all()
 
 
+@pytest.mark.parametrize("kw", [dict(bin="raft", p_loss=0.97), dict(bin="raft", p_loss=0.97, concurrency=12), dict(p_loss=0.95)])
+def test_lin_kv_runs_out_of_keys_after_256(lib, kw):
+    """lin-kv keys travel in 8 bits of an op's value; [upstream] jepsen.tests.linearizable-register retires a key after 20 processes,
+    and a process is retired by every :info.  Nearly total loss for half an hour of virtual time uses up 256 keys: the run stops with
+    VALUES_OVERFLOW instead of aliasing key 256 onto key 0 — in the oracle, in the Raft kernels (four clusters per wavefront, and one:
+    12 clients do not fit a 16-lane group) and in the proxy kernel alike, histories identical up to that point."""
+    kw = dict(dict(node_count=3, concurrency=6, rate=200, time_limit=1700, seed=3, max_rows=40000), **kw)
+    cfg = E.test_config("lin-kv", **kw)
+    ora = _flags_agree(cfg, 3)
+    assert (ora.meta["flags"] == A.FLAG_VALUES_OVERFLOW).all()
+    with E.Engine(cfg) as eng:   # and everything up to the stop is the oracle's
+        eng.run(0, 3)
+        eng.fetch()
+        for i in range(3):
+            m, om = eng.meta(i), ora.meta[i]
+            assert (m.n_rows, m.n_payload_words, m.n_rounds) == (om["n_rows"], om["n_payload_words"], om["n_rounds"])
+            assert eng.raw_history(i)[0].tobytes() == ora.history(i)[0].tobytes()
+    assert all(int((ora.history(i)[0]["value"] & 0xFF).max()) == 255 for i in range(3))
+
+
 def test_repeated_runs_reuse_the_context(lib):
     cfg = E.test_config("g-set", node_count=5, rate=20, time_limit=6, latency=10, seed=5)
     ora = O.run(cfg, 0, 12)
