@@ -272,6 +272,10 @@ uint32_t msim_check_host_rechecks(const msim_ctx *ctx);
 int msim_check_txn_batch(int device, const msim_op *rows, const uint64_t *row_offsets, const uint32_t *payload, const uint64_t *payload_offsets,
                          uint32_t n_histories, msim_check_result *out);
 
+/* unique-ids: checks `n_histories` histories given on the host — history i in the slab rows + i * max_rows, n_rows[i] rows used —
+ * with the device checker of msim_check ([upstream] jepsen.checker/unique-ids); out[i] is what msim_check_unique_rows gives. */
+int msim_check_unique_batch(int device, const msim_op *rows, const uint32_t *n_rows, uint32_t max_rows, uint32_t n_histories, msim_check_result *out);
+
 /* lin-kv: checks `n_histories` histories given on the host — history i = rows[row_offsets[i] .. row_offsets[i + 1]) — with the
  * device search of msim_check on HIP device `device`; out[i] is what msim_check_lin_kv_rows gives for history i. */
 int msim_check_lin_kv_batch(int device, const msim_op *rows, const uint64_t *row_offsets, uint32_t n_histories, msim_check_result *out);

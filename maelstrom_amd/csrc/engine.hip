@@ -1032,7 +1032,10 @@ extern "C" int msim_check(msim_ctx *ctx) {
   }
   if (ctx->cfg.workload == MSIM_WL_TXN_RW_REGISTER) return msim_check_txn_host(ctx);
   if (ctx->cfg.workload == MSIM_WL_PN_COUNTER || ctx->cfg.workload == MSIM_WL_G_COUNTER) return msim_check_pn_host(ctx);
-  if (ctx->cfg.workload == MSIM_WL_UNIQUE_IDS) return msim_check_unique_host(ctx);
+  if (ctx->cfg.workload == MSIM_WL_UNIQUE_IDS) {
+    static const char *df = std::getenv("MSIM_DEV_FLAGS");   // bit 11: keep the check on the host cores
+    return (df && (std::atoi(df) & 0x800)) ? msim_check_unique_host(ctx) : msim_check_unique_device(ctx);
+  }
   return msim_check_launch(ctx);
 }
 

@@ -477,6 +477,21 @@ def check_lin_kv_batch(histories, device=0):
     return out
 
 
+def check_unique_batch(histories, device=0):
+    """unique-ids: several histories (arrays of rows) through the device checker behind Engine.check() (msim_check_unique_batch)."""
+    hs = [np.ascontiguousarray(h) for h in histories]
+    mr = max(1, max(len(h) for h in hs))
+    slab = np.zeros((len(hs), mr), dtype=OP_DT)
+    for i, h in enumerate(hs):
+        slab[i, :len(h)] = h
+    nr = np.asarray([len(h) for h in hs], dtype=np.uint32)
+    out = np.zeros(len(hs), dtype=CHECK_DT)
+    rc = A.load().msim_check_unique_batch(device, slab.ctypes.data, nr.ctypes.data, mr, len(hs), out.ctypes.data)
+    if rc:
+        raise EngineError(f"msim_check_unique_batch: {rc}")
+    return out
+
+
 def check_txn_batch(histories, device=0):
     """txn-list-append: several histories, each (rows, payload), through the device pass behind Engine.check() with the host analysis
     for what it cannot prove clean (msim_check_txn_batch).  Returns the CHECK_DT records, one per history."""

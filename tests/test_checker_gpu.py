@@ -188,3 +188,48 @@ def test_availability_checker_device_equals_host(lib):
                     assert dev[i] == E.check_availability_rows(eng.raw_history(i)[0], a)
             assert not all(r["valid?"] for r in eng.check_availability("total"))   # loss / partitions cost some operations
             assert all(r["valid?"] for r in eng.check_availability(None))
+
+
+def test_unique_ids_device_checker_equals_host(lib):
+    """[upstream] jepsen.checker/unique-ids on the device (csrc/unique_check_dev.hip) against the host checker (csrc/pn_check.cpp):
+    engine histories (flake ids under partitions: never duplicated), then the same histories with ids copied over other ids."""
+    import ctypes as C
+    from maelstrom_amd import _abi as A
+
+    def host(rows):
+        res = A.CheckResult()
+        rows = np.ascontiguousarray(rows)
+        assert A.load().msim_check_unique_rows(rows.ctypes.data_as(C.c_void_p), len(rows), C.byref(res)) == 0
+        return res
+
+    fields = ("valid", "attempt_count", "duplicated_count", "op_count", "ok_count", "fail_count", "info_count")
+    cfg = E.test_config("unique-ids", node_count=3, rate=500, time_limit=6, latency=5, nemesis=["partition"], nemesis_interval=2, seed=12)
+    n = 12
+    with E.Engine(cfg) as eng:
+        eng.run(0, n)
+        eng.check()
+        res = eng.check_results()
+        eng.fetch()
+        hs = [eng.raw_history(i)[0].copy() for i in range(n)]
+    for i in range(n):
+        h = host(hs[i])
+        for f in fields:
+            assert int(res[i][f]) == int(getattr(h, f)), (i, f)
+        assert [int(x) for x in res[i]["stable_latency_ms"][:2]] == [int(h.stable_latency_ms[0]), int(h.stable_latency_ms[1])]
+    assert (res["valid"] == 1).all() and (res["ok_count"] > 100).all()
+    rng = np.random.default_rng(2)
+    bad = []
+    for k, rows in enumerate(hs):
+        rows = rows.copy()
+        oks = np.flatnonzero(((rows["packed"] & 3) == A.T_OK) & (((rows["packed"] >> 2) & 31) == A.F_GENERATE))
+        for _ in range(k):   # k duplicated acknowledgements (some of the same value)
+            a, b = rng.choice(oks, size=2, replace=False)
+            rows["value"][a] = rows["value"][b]
+        bad.append(rows)
+    bad.append(np.zeros(0, dtype=E.OP_DT))
+    dev = E.check_unique_batch(bad)
+    for i, rows in enumerate(bad):
+        h = host(rows)
+        for f in fields:
+            assert int(dev[i][f]) == int(getattr(h, f)), (i, f, int(dev[i][f]), int(getattr(h, f)))
+    assert int(dev[0]["valid"]) == 1 and (dev["valid"][1:n] == 0).all()
