@@ -190,21 +190,46 @@ def main():
     elapsed = float(tmax.item())
     msgs_all, valid_all, flagged_all = int(agg[0]), int(agg[1]), int(agg[2])
 
-    gather = None
+    # The two secondary measurements involve collectives of their own (the RCCL history gather) and a second engine context; they run
+    # under a watchdog so that whatever happens to them the headline line above them is printed: a leg that does not finish is
+    # reported as such, and the process then leaves without the final barrier (the other ranks are in the same position).
+    import threading
+    stuck = []
+
+    def guarded(label, seconds, fn):
+        box = {}
+
+        def run():
+            try:
+                torch.cuda.set_device(local_rank)   # the current device is per thread
+                box["v"] = fn()
+            except Exception as ex:   # reported, not raised: the headline measurement stands
+                box["e"] = f"{type(ex).__name__}: {ex}"
+        th = threading.Thread(target=run, daemon=True)
+        th.start()
+        th.join(seconds)
+        if th.is_alive():
+            stuck.append(label)
+            return None, f"{label}: not finished after {seconds:.0f} s"
+        return box.get("v"), box.get("e")
+
+    gather = gather_err = None
     if not args.no_gather:
-        gather = history_gather(eng, torch, dist, dev, world, rank, torch_view)
-    incl = None
-    if not args.no_fetch:
-        first0 = (args.warmup + args.steps + 2) * world * n + EN.shard(world * n, rank, world)[0] * 4
-        im, idt, ibytes = fetch_inclusive(E, cfg, torch, dev, local_rank, n, args.steps, first0, torch_view)
-        it = torch.tensor([float(im), idt], dtype=torch.float64, device=dev)
-        if dist:
-            tm = it[1:].clone()
-            dist.all_reduce(it[:1])
-            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-            it[1] = tm[0]
-        incl = {"value": float(it[0]) / float(it[1]), "ms_per_step": float(it[1]) / args.steps * 1e3, "bytes_fetched_per_batch": ibytes,
-                "how": "two engine contexts alternate: batch k simulates + checks while batch k-1 is compacted on the device and copied to pinned host memory (msim_fetch)"}
+        gather, gather_err = guarded("history_gather", 180.0, lambda: history_gather(eng, torch, dist, dev, world, rank, torch_view))
+    incl = incl_err = None
+    if not args.no_fetch and not stuck:
+        def incl_leg():
+            first0 = (args.warmup + args.steps + 2) * world * n + EN.shard(world * n, rank, world)[0] * 4
+            im, idt, ibytes = fetch_inclusive(E, cfg, torch, dev, local_rank, n, args.steps, first0, torch_view)
+            it = torch.tensor([float(im), idt], dtype=torch.float64, device=dev)
+            if dist:
+                tm = it[1:].clone()
+                dist.all_reduce(it[:1])
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                it[1] = tm[0]
+            return {"value": float(it[0]) / float(it[1]), "ms_per_step": float(it[1]) / args.steps * 1e3, "bytes_fetched_per_batch": ibytes,
+                    "how": "two engine contexts alternate: batch k simulates + checks while batch k-1 is compacted on the device and copied to pinned host memory (msim_fetch)"}
+        incl, incl_err = guarded("incl_fetch", 240.0, incl_leg)
 
     if rank == 0:
         k = args.steps
@@ -269,11 +294,19 @@ def main():
                                       "note": "quoted for scale only; vs_baseline stays null because BASELINE.json publishes no number for this metric"}
         if gather:
             out["history_gather"] = gather
+        if gather_err:
+            out["history_gather_error"] = gather_err
+        if incl_err:
+            out["incl_fetch_error"] = incl_err
         if args.cpu_sample > 0 and world == 1:   # the CPU leg is measured once, at N=1
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample)
             out["cpu_baseline"]["process_harness"] = process_harness(min(20.0, 2 * args.cpu_sample))
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if stuck:   # a leg is still inside a collective: no barrier, no teardown that could wait for it
+        sys.stderr.write(f"[bench] rank {rank}: {', '.join(stuck)} did not finish; leaving without the final barrier\n")
+        sys.stderr.flush()
+        os._exit(0)
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -7,6 +7,6 @@ cd "$(dirname "$0")/.."
 TAG=${1:-prof}; shift || true
 python -m maelstrom_amd.build > /dev/null
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "${@:--DDUO_PROF}" -c -o maelstrom_amd/build/duo_$TAG.o maelstrom_amd/csrc/duo.hip
-OBJS=$(ls maelstrom_amd/build/*.o | grep -v "/duo\|/raft4_")
+OBJS=$(ls maelstrom_amd/build/*.o | grep -v "/duo\|/raft4_\|/txn8_")
 hipcc --offload-arch=gfx950 -shared -fPIC -o maelstrom_amd/libmaelsim_$TAG.so $OBJS maelstrom_amd/build/duo_$TAG.o -ldl
 echo built maelstrom_amd/libmaelsim_$TAG.so
