@@ -18,6 +18,8 @@
 // host search of lin_check.cpp (lin_check_dev_run below) — never silently approximated.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -264,49 +266,75 @@ int lin_check_dev_run(msim_ctx *ctx, const LParams &lp0, u32 n, u32 max_rows_any
   std::vector<u32> todo;
   for (u32 i = 0; i < n; i++) if (h_out[i].valid == NEEDS_HOST) todo.push_back(i);
   if (trace) std::fprintf(stderr, "[lin-check] pass 1 (64 configurations): %.2f ms, %zu of %u histories marked\n", ms(), todo.size(), n);
-  if (!todo.empty()) {   // second pass: eight configurations per lane
+  if (!todo.empty()) {
+    // Second pass on the device: eight configurations per lane.  While it runs, the host cores already search marked histories
+    // — those with the most indeterminate calls first: they are the likeliest to exceed 512 configurations too — so that what the
+    // second pass leaves over is mostly done by the time it is known.  Whichever side finishes a history first, the result is the
+    // same (both searches are exact).
+    std::vector<msim_inst_meta> hm;
+    std::vector<uint64_t> ho;
+    if (lp.meta) { hm.resize(n); MSIM_HIP_TRY(ctx, hipMemcpy(hm.data(), lp.meta, (size_t)n * sizeof(msim_inst_meta), hipMemcpyDeviceToHost)); }
+    else { ho.resize(n + 1); MSIM_HIP_TRY(ctx, hipMemcpy(ho.data(), lp.off, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost)); }
+    std::vector<msim_check_result> h2(n);           // the second pass's results (h_out keeps pass 1's until merged)
+    std::vector<msim_check_result> hh(todo.size()); // the host's results, by position in `order`
+    std::vector<u32> order(todo);
+    std::stable_sort(order.begin(), order.end(), [&](u32 x, u32 y) { return h_out[x].info_count > h_out[y].info_count; });
+    std::vector<char> host_done(todo.size(), 0);
+    std::atomic<size_t> next{0};
+    std::atomic<bool> device_done{false};
+    std::atomic<int> copy_err{0};
+    std::vector<char> wanted;                       // after the second pass: which histories the host still has to do
+    auto host_one = [&](size_t k) {
+      const u32 i = order[k];
+      const u32 nr = lp.meta ? hm[i].n_rows : (u32)(ho[i + 1] - ho[i]);
+      const uint64_t first = lp.meta ? (uint64_t)i * lp.stride : ho[i];
+      std::vector<msim_op> rows(nr ? nr : 1);
+      if (nr && hipMemcpy(rows.data(), lp.rows + first, (size_t)nr * sizeof(msim_op), hipMemcpyDeviceToHost) != hipSuccess) { copy_err = 1; return; }
+      msim_lin_check_instance_host(rows.data(), nr, lp.meta ? hm[i].flags : 0u, &hh[k]);
+      host_done[k] = 1;
+    };
+    unsigned nt = msim_host_threads();
+    if (nt > todo.size()) nt = (unsigned)todo.size();
+    std::vector<std::thread> th;
+    const int dev_id = ctx->device;
+    for (unsigned w = 0; w < nt; w++)
+      th.emplace_back([&]() {
+        (void)hipSetDevice(dev_id);
+        for (;;) {   // phase 1: speculative, hardest first, until the device is done; phase 2: what the device left over
+          const size_t k = next.fetch_add(1);
+          if (k >= order.size()) break;
+          if (device_done.load() && !wanted[k]) continue;
+          host_one(k);
+        }
+      });
     u32 *d_list = nullptr;
-    MSIM_HIP_TRY(ctx, hipMalloc(&d_list, todo.size() * 4));
-    hipError_t e = hipMemcpyAsync(d_list, todo.data(), todo.size() * 4, hipMemcpyHostToDevice, st);
+    hipError_t e = hipMalloc(&d_list, todo.size() * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_list, todo.data(), todo.size() * 4, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
       lp.list = d_list;
       hipLaunchKernelGGL((lin_check_kernel<8>), dim3((u32)todo.size()), dim3(64), lds, st, lp);
       e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(h_out, lp.out, (size_t)n * sizeof(msim_check_result), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(h2.data(), lp.out, (size_t)n * sizeof(msim_check_result), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(d_list);
-    if (e != hipSuccess) { ctx->err = std::string("lin-kv device check: ") + hipGetErrorString(e); return MSIM_E_HIP; }
-    std::vector<u32> rest;
-    for (u32 i : todo) if (h_out[i].valid == NEEDS_HOST) rest.push_back(i);
-    todo.swap(rest);
-    if (trace) std::fprintf(stderr, "[lin-check] pass 2 (512 configurations): done at %.2f ms, %zu histories left for the host\n", ms(), todo.size());
-  }
-  if (!todo.empty()) {   // the host search for the rest: rows of those histories only
-    std::vector<msim_inst_meta> hm;
-    std::vector<uint64_t> ho;
-    if (lp.meta) { hm.resize(n); MSIM_HIP_TRY(ctx, hipMemcpy(hm.data(), lp.meta, (size_t)n * sizeof(msim_inst_meta), hipMemcpyDeviceToHost)); }
-    else { ho.resize(n + 1); MSIM_HIP_TRY(ctx, hipMemcpy(ho.data(), lp.off, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost)); }
-    std::vector<std::vector<msim_op>> rows(todo.size());
-    for (size_t t = 0; t < todo.size(); t++) {
-      const u32 i = todo[t];
-      const u32 nr = lp.meta ? hm[i].n_rows : (u32)(ho[i + 1] - ho[i]);
-      const uint64_t first = lp.meta ? (uint64_t)i * lp.stride : ho[i];
-      rows[t].resize(nr ? nr : 1);
-      if (nr) MSIM_HIP_TRY(ctx, hipMemcpy(rows[t].data(), lp.rows + first, (size_t)nr * sizeof(msim_op), hipMemcpyDeviceToHost));
-    }
-    unsigned nt = msim_host_threads();
-    if (nt > todo.size()) nt = (unsigned)todo.size();
-    std::vector<std::thread> th;
-    for (unsigned w = 0; w < nt; w++)
-      th.emplace_back([&, w]() {
-        for (size_t t = w; t < todo.size(); t += nt) {
-          const u32 i = todo[t];
-          msim_lin_check_instance_host(rows[t].data(), lp.meta ? hm[i].n_rows : (u32)(ho[i + 1] - ho[i]), lp.meta ? hm[i].flags : 0u, &h_out[i]);
-        }
-      });
+    wanted.assign(order.size(), 0);
+    if (e == hipSuccess) for (size_t k = 0; k < order.size(); k++) wanted[k] = h2[order[k]].valid == NEEDS_HOST;
+    else std::fill(wanted.begin(), wanted.end(), 1);   // (the host can still do everything)
+    device_done = true;
+    const double t_dev = ms();
     for (auto &x : th) x.join();
-    for (u32 i : todo) MSIM_HIP_TRY(ctx, hipMemcpy(lp.out + i, &h_out[i], sizeof(msim_check_result), hipMemcpyHostToDevice));
+    if (d_list) (void)hipFree(d_list);
+    if (copy_err) { ctx->err = "lin-kv check: copying a history to the host failed"; return MSIM_E_HIP; }
+    // a history the host threads skipped in phase 1 order but the device could not finish either (taken by no one): do it now
+    u32 n_host_needed = 0;
+    for (size_t k = 0; k < order.size(); k++) {
+      const u32 i = order[k];
+      if (wanted[k]) { n_host_needed++; if (!host_done[k]) host_one(k); h_out[i] = hh[k]; MSIM_HIP_TRY(ctx, hipMemcpy(lp.out + i, &h_out[i], sizeof(msim_check_result), hipMemcpyHostToDevice)); }
+      else h_out[i] = h2[i];
+    }
+    if (copy_err) { ctx->err = "lin-kv check: copying a history to the host failed"; return MSIM_E_HIP; }
+    if (trace) std::fprintf(stderr, "[lin-check] pass 2 (512 configurations) done at %.2f ms, %u histories needed the host search (overlapped)\n", t_dev, n_host_needed);
+    todo.resize(n_host_needed);
   }
   if (trace) std::fprintf(stderr, "[lin-check] done at %.2f ms\n", ms());
   if (n_host) *n_host = (u32)todo.size();
