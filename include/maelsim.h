@@ -272,6 +272,9 @@ uint32_t msim_check_host_rechecks(const msim_ctx *ctx);
 int msim_check_txn_batch(int device, const msim_op *rows, const uint64_t *row_offsets, const uint32_t *payload, const uint64_t *payload_offsets,
                          uint32_t n_histories, msim_check_result *out);
 
+/* pn-counter / g-counter: the same for the counter checker (workload/pn_counter.clj:84-123); out[i] is what msim_check_pn_rows gives. */
+int msim_check_pn_batch(int device, const msim_op *rows, const uint32_t *n_rows, uint32_t max_rows, uint32_t n_histories, msim_check_result *out);
+
 /* unique-ids: checks `n_histories` histories given on the host — history i in the slab rows + i * max_rows, n_rows[i] rows used —
  * with the device checker of msim_check ([upstream] jepsen.checker/unique-ids); out[i] is what msim_check_unique_rows gives. */
 int msim_check_unique_batch(int device, const msim_op *rows, const uint32_t *n_rows, uint32_t max_rows, uint32_t n_histories, msim_check_result *out);

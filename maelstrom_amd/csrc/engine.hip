@@ -1031,7 +1031,10 @@ extern "C" int msim_check(msim_ctx *ctx) {
     return (df && (std::atoi(df) & 0x800)) ? msim_check_txn_host(ctx) : msim_check_txn_device(ctx);
   }
   if (ctx->cfg.workload == MSIM_WL_TXN_RW_REGISTER) return msim_check_txn_host(ctx);
-  if (ctx->cfg.workload == MSIM_WL_PN_COUNTER || ctx->cfg.workload == MSIM_WL_G_COUNTER) return msim_check_pn_host(ctx);
+  if (ctx->cfg.workload == MSIM_WL_PN_COUNTER || ctx->cfg.workload == MSIM_WL_G_COUNTER) {
+    static const char *df = std::getenv("MSIM_DEV_FLAGS");   // bit 11: keep the check on the host cores
+    return (df && (std::atoi(df) & 0x800)) ? msim_check_pn_host(ctx) : msim_check_pn_device(ctx);
+  }
   if (ctx->cfg.workload == MSIM_WL_UNIQUE_IDS) {
     static const char *df = std::getenv("MSIM_DEV_FLAGS");   // bit 11: keep the check on the host cores
     return (df && (std::atoi(df) & 0x800)) ? msim_check_unique_host(ctx) : msim_check_unique_device(ctx);
@@ -1209,7 +1212,7 @@ extern "C" int msim_meta(msim_ctx *ctx, uint32_t inst, msim_inst_meta *out) {
   return MSIM_OK;
 }
 
-extern "C" uint32_t msim_check_host_rechecks(const msim_ctx *ctx) { return ctx && ctx->checked && (ctx->cfg.workload == MSIM_WL_LIN_KV || ctx->cfg.workload == MSIM_WL_TXN_LIST_APPEND) ? ctx->lin_host_rechecks : 0u; }
+extern "C" uint32_t msim_check_host_rechecks(const msim_ctx *ctx) { return ctx && ctx->checked && (ctx->cfg.workload == MSIM_WL_LIN_KV || ctx->cfg.workload == MSIM_WL_TXN_LIST_APPEND || ctx->cfg.workload == MSIM_WL_PN_COUNTER || ctx->cfg.workload == MSIM_WL_G_COUNTER) ? ctx->lin_host_rechecks : 0u; }
 
 extern "C" int msim_check_results(msim_ctx *ctx, const msim_check_result **results, uint32_t *n) {
   if (!ctx) return MSIM_E_INVALID;

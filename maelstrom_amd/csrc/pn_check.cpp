@@ -87,6 +87,9 @@ void check_unique(const msim_op *rows, uint32_t n_rows, uint32_t flags, msim_che
 
 }  // namespace
 
+// the host checker for one pn-counter / g-counter history (pn_check_dev.hip hands over what its bitmap does not cover)
+void msim_pn_check_instance_host(const msim_op *rows, uint32_t n_rows, uint32_t flags, msim_check_result *res) { Ranges acc; check_history(rows, n_rows, flags, res, acc); }
+
 extern "C" int msim_check_unique_rows(const msim_op *rows, uint32_t n_rows, msim_check_result *out) {
   if ((!rows && n_rows) || !out) return MSIM_E_INVALID;
   std::vector<uint32_t> ids;

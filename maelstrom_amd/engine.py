@@ -477,8 +477,9 @@ def check_lin_kv_batch(histories, device=0):
     return out
 
 
-def check_unique_batch(histories, device=0):
-    """unique-ids: several histories (arrays of rows) through the device checker behind Engine.check() (msim_check_unique_batch)."""
+def check_unique_batch(histories, device=0, fn="msim_check_unique_batch"):
+    """unique-ids (or, with fn="msim_check_pn_batch", pn-counter / g-counter): several histories (arrays of rows) through the device
+    checker behind Engine.check()."""
     hs = [np.ascontiguousarray(h) for h in histories]
     mr = max(1, max(len(h) for h in hs))
     slab = np.zeros((len(hs), mr), dtype=OP_DT)
@@ -486,10 +487,15 @@ def check_unique_batch(histories, device=0):
         slab[i, :len(h)] = h
     nr = np.asarray([len(h) for h in hs], dtype=np.uint32)
     out = np.zeros(len(hs), dtype=CHECK_DT)
-    rc = A.load().msim_check_unique_batch(device, slab.ctypes.data, nr.ctypes.data, mr, len(hs), out.ctypes.data)
+    rc = getattr(A.load(), fn)(device, slab.ctypes.data, nr.ctypes.data, mr, len(hs), out.ctypes.data)
     if rc:
-        raise EngineError(f"msim_check_unique_batch: {rc}")
+        raise EngineError(f"{fn}: {rc}")
     return out
+
+
+def check_pn_batch(histories, device=0):
+    """pn-counter / g-counter: several histories through the device checker behind Engine.check() (msim_check_pn_batch)."""
+    return check_unique_batch(histories, device, fn="msim_check_pn_batch")
 
 
 def check_txn_batch(histories, device=0):

@@ -233,3 +233,59 @@ def test_unique_ids_device_checker_equals_host(lib):
         for f in fields:
             assert int(dev[i][f]) == int(getattr(h, f)), (i, f, int(dev[i][f]), int(getattr(h, f)))
     assert int(dev[0]["valid"]) == 1 and (dev["valid"][1:n] == 0).all()
+
+
+def test_pn_counter_device_checker_equals_host(lib):
+    """The counter checker on the device (csrc/pn_check_dev.hip: a 4096-value bitmap of acceptable sums) against the host checker
+    (csrc/pn_check.cpp) — on the reference's own vectors (pn_counter_test.clj:10-36, KAT-9), on engine histories with lost acks
+    (indeterminate adds), on corrupted final reads and on a window wider than the bitmap (host fallback)."""
+    import ctypes as C
+    from maelstrom_amd import _abi as A
+
+    def host(rows):
+        res = A.CheckResult()
+        rows = np.ascontiguousarray(rows)
+        assert A.load().msim_check_pn_rows(rows.ctypes.data_as(C.c_void_p), len(rows), C.byref(res), None, 0, None) == 0
+        return res
+
+    fields = ("valid", "attempt_count", "error_count", "stable_count", "op_count", "ok_count", "fail_count", "info_count")
+    kat = [
+        [],
+        [{"type": ":ok", "f": ":add", "value": 2}, {"type": ":ok", "f": ":add", "value": 3}, {"type": ":ok", "f": ":read", "final?": True, "value": 5},
+         {"type": ":ok", "f": ":read", "final?": True, "value": 4}],
+        [{"type": ":ok", "f": ":add", "value": 10}, {"type": ":info", "f": ":add", "value": 5}, {"type": ":info", "f": ":add", "value": -1},
+         {"type": ":info", "f": ":add", "value": -1}, {"type": ":ok", "f": ":read", "final?": True, "value": 11}, {"type": ":ok", "f": ":read", "final?": True, "value": 15}],
+        [{"type": ":ok", "f": ":add", "value": 4}, {"type": ":fail", "f": ":add", "value": 100}, {"type": ":ok", "f": ":read", "value": 0},
+         {"type": ":ok", "f": ":read", "final?": True, "value": 4}],
+        [{"type": ":info", "f": ":add", "value": 3000}, {"type": ":info", "f": ":add", "value": -2000}, {"type": ":info", "f": ":add", "value": 70},
+         {"type": ":ok", "f": ":read", "final?": True, "value": 1070}, {"type": ":ok", "f": ":read", "final?": True, "value": 1069}],   # window 5071 > 4096: host
+        [{"type": ":info", "f": ":add", "value": 64}, {"type": ":info", "f": ":add", "value": 128}, {"type": ":info", "f": ":add", "value": -65},
+         {"type": ":ok", "f": ":add", "value": -7}] + [{"type": ":ok", "f": ":read", "final?": True, "value": v} for v in (-72, -8, -7, 57, 121, 120, 185, 186, -73)],
+    ]
+    hs = [E.encode_pn_history(ops) for ops in kat]
+    cfg = E.test_config("pn-counter", node_count=5, rate=100, time_limit=10, latency=50, latency_dist="exponential", p_loss=0.15, seed=17)
+    n = 16
+    with E.Engine(cfg) as eng:
+        eng.run(0, n)
+        eng.check()
+        res = eng.check_results()
+        eng.fetch()
+        eh = [eng.raw_history(i)[0].copy() for i in range(n)]
+    for i in range(n):
+        h = host(eh[i])
+        for f in fields:
+            assert int(res[i][f]) == int(getattr(h, f)), (i, f, int(res[i][f]), int(getattr(h, f)))
+    assert (res["info_count"] > 0).any() and (res["valid"] == 1).all()
+    rng = np.random.default_rng(4)
+    for rows in eh[:8]:   # corrupt a final read
+        rows = rows.copy()
+        fin = np.flatnonzero(((rows["packed"] >> 11) & 1 == 1) & ((rows["packed"] & 3) == A.T_OK))
+        j = rng.choice(fin)
+        rows["value"][j] = np.uint32((int(np.int32(rows["value"][j])) + int(rng.choice([-40, -3, 7, 1000]))) & 0xFFFFFFFF)
+        hs.append(rows)
+    dev = E.check_pn_batch(hs)
+    for i, rows in enumerate(hs):
+        h = host(rows)
+        for f in fields:
+            assert int(dev[i][f]) == int(getattr(h, f)), (i, f, int(dev[i][f]), int(getattr(h, f)))
+    assert [int(v) for v in dev["valid"][:5]] == [1, 0, 0, 1, 0] and int(dev[2]["stable_count"]) == 2
