@@ -11,6 +11,7 @@ from maelstrom_amd import engine as E
 from test_parity_gpu import _compare
 
 pytestmark = pytest.mark.gpu
+N_INST = int(os.environ.get("MSIM_FUZZ_INSTANCES", "3"))   # (9 or 17 put several clusters into the wavefronts of the multi-cluster layouts)
 
 
 def _random_case(rng):
@@ -53,7 +54,7 @@ def test_random_options_engine_equals_oracle(lib, case):
         E.Engine(cfg).close()
     except E.EngineError as e:   # e.g. more endpoints than one wavefront has lanes
         pytest.skip(str(e))
-    _compare(cfg, first, 3)
+    _compare(cfg, first, N_INST)
 
 
 def _random_kv_case(rng):
@@ -97,7 +98,7 @@ def test_random_rw_register_options_engine_equals_oracle(lib, case):
         E.Engine(cfg).close()
     except E.EngineError as e:
         pytest.skip(str(e))
-    _compare(cfg, rng.randrange(1 << 20), 3)
+    _compare(cfg, rng.randrange(1 << 20), N_INST)
 
 
 @pytest.mark.parametrize("case", range(int(os.environ.get("MSIM_FUZZ_CASES", "36"))))
@@ -110,4 +111,4 @@ def test_random_kv_options_engine_equals_oracle(lib, case):
         E.Engine(cfg).close()
     except E.EngineError as e:
         pytest.skip(str(e))
-    _compare(cfg, rng.randrange(1 << 20), 3)
+    _compare(cfg, rng.randrange(1 << 20), N_INST)
