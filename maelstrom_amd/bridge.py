@@ -12,7 +12,7 @@ What it replaces, with the reference's own behaviour (file:line under /root/refe
     poll time, head-of-line blocking with ms-truncated sleeps) — restated in Python below, as the oracle restates it in C;
   * client.clj:41-172 sync RPC clients (5 s timeout, stale replies skipped, `with-errors` definite / indefinite mapping from
     resources/errors.edn), db.clj:46-69 the init handshake, core.clj:67-80 generator phases, the workloads' request bodies
-    (doc/workloads.md) for echo, broadcast, g-set, g-counter, pn-counter, unique-ids and lin-kv;
+    (doc/workloads.md) for echo, broadcast, g-set, g-counter, pn-counter, unique-ids, lin-kv and txn-list-append;
   * service.clj:31-132,141-263,290-296 the built-in services lin-kv, seq-kv, lww-kv and lin-tso as endpoints any node may call.
 
 Virtual time and real programs.  A reactive node (everything it ever prints is the reaction to a line it just read) runs in
@@ -41,7 +41,7 @@ import time
 MASK64 = (1 << 64) - 1
 PHI = 0x9E3779B97F4A7C15
 INF = 0xFFFFFFFF
-S_GEN, S_GEN2, S_LATENCY, S_LOSS, S_NEM_STAGGER, S_NEM_SPEC, S_NEM_SHUFFLE, S_NEM_PICK, S_SVC = 1, 2, 4, 5, 7, 8, 9, 10, 12
+S_GEN, S_GEN2, S_GEN3, S_LATENCY, S_LOSS, S_NEM_STAGGER, S_NEM_SPEC, S_NEM_SHUFFLE, S_NEM_PICK, S_SVC = 1, 2, 3, 4, 5, 7, 8, 9, 10, 12
 LOG2_Q24 = [int(round(math.log2(1.0 + i / 256.0) * (1 << 24))) for i in range(257)]   # tools/gen_log2_table.py
 
 # resources/errors.edn: code -> (name, definite?)
@@ -291,8 +291,8 @@ class NodeProcess:
 
 PH_INIT, PH_INIT_WAIT, PH_TOPO, PH_TOPO_WAIT, PH_MAIN_START, PH_MAIN, PH_DRAIN, PH_NEM_FINAL, PH_SLEEP, PH_FINAL, PH_FINAL_WAIT, PH_DONE = range(12)
 TOPOLOGIES = {"grid": 0, "line": 1, "total": 2, "tree": 3, "tree2": 3, "tree3": 4, "tree4": 5}
-WORKLOADS = ("echo", "broadcast", "g-set", "pn-counter", "g-counter", "unique-ids", "lin-kv")
-REUSABLE = ("lin-kv", "unique-ids")   # lin_kv.clj:74-76, unique_ids.clj:59-61
+WORKLOADS = ("echo", "broadcast", "g-set", "pn-counter", "g-counter", "unique-ids", "lin-kv", "txn-list-append")
+REUSABLE = ("lin-kv", "unique-ids", "txn-list-append")   # lin_kv.clj:74-76, unique_ids.clj:59-61, txn_list_append.clj:94-99
 HAS_FINAL = ("broadcast", "g-set", "pn-counter", "g-counter")
 IDEMPOTENT = {"broadcast": ("read",), "lin-kv": ("read",)}   # the with-errors sets: broadcast.clj:200, lin_kv.clj:52
 
@@ -336,7 +336,7 @@ class Bridge:
 
     def __init__(self, workload, bin, node_count=5, concurrency=None, rate=5.0, time_limit=60.0, latency=0, latency_dist="constant",
                  topology="grid", nemesis=(), nemesis_interval=10.0, p_loss=0.0, seed=0, instance=0, client_timeout_ms=5000, quiesce_ms=10000,
-                 settle_ms=3.0, clock="virtual", log_dir=None, journal=False):
+                 settle_ms=3.0, clock="virtual", log_dir=None, journal=False, key_count=10, max_txn_length=4, max_writes_per_key=16):
         if workload not in WORKLOADS:
             raise ValueError(f"workload {workload!r} is not bridged (one of {WORKLOADS})")
         if latency_dist == "exponential" and latency == 0:
@@ -353,6 +353,10 @@ class Bridge:
         self.timeout_ms = client_timeout_ms
         if workload == "lin-kv":
             self.timeout_ms = max(10 * self.lat_ms, 1000)   # lin_kv.clj:54
+        # txn-list-append ([upstream] elle list-append generator as DESIGN.md §2.4 restates it): a pool of key-count active keys,
+        # exponentially more traffic on the later ones, a key retires after max-writes-per-key appends (core.clj:167-169,191-199)
+        self.key_count, self.max_txn_length, self.max_writes = key_count, max_txn_length, max_writes_per_key
+        self.t_active, self.t_next_val, self.t_next_key = list(range(16)), [1] * 16, key_count
         self.rng = Rng(seed, instance)
         self.settle_s, self.clock = settle_ms / 1000.0, clock
         self.names = [f"n{i}" for i in range(self.N)] + [f"c{k}" for k in range(self.CS)] + list(SERVICES)
@@ -458,6 +462,8 @@ class Bridge:
             return {"type": "write", "key": v[0], "value": v[1]}
         if f == ":cas":
             return {"type": "cas", "key": v[0], "from": v[1][0], "to": v[1][1]}
+        if f == ":txn":   # txn_list_append.clj:101-113: micro-ops [f k v] with f "r" / "append"
+            return {"type": "txn", "txn": [[m[0][1:], m[1], m[2]] for m in v]}
         return {"type": "read", "key": v[0]} if wl == "lin-kv" else {"type": "read"}
 
     def client_invoke(self, slot):
@@ -520,6 +526,8 @@ class Bridge:
             self.client_complete(slot, ":ok", body.get("value"))
         elif f == ":generate":
             self.client_complete(slot, ":ok", body.get("id"))
+        elif f == ":txn":   # the completed transaction, reads filled in (txn_list_append.clj:40-52,114-119)
+            self.client_complete(slot, ":ok", [[":" + str(m[0]), m[1], m[2]] for m in body.get("txn", [])])
         else:
             self.client_complete(slot, ":ok", c["value"])
 
@@ -667,6 +675,23 @@ class Bridge:
                             c["m_f"], c["m_value"] = ":write", [key, v1]
                         else:
                             c["m_f"], c["m_value"] = ":cas", [key, [v1, v2]]
+                    elif wl == "txn-list-append":
+                        n_mops = 1 + scale32(self.rng.draw64(S_GEN2, k) >> 32, self.max_txn_length)
+                        txn = []
+                        for j in range(n_mops):
+                            h3 = self.rng.draw64(S_GEN3, k * 8 + j)
+                            ki = (scale32(h3 >> 32, (1 << self.key_count) - 1) + 1).bit_length() - 1   # P(ki) = 2^ki / (2^kc - 1)
+                            key = self.t_active[ki]
+                            if h3 & 1:
+                                v = self.t_next_val[ki]
+                                self.t_next_val[ki] += 1
+                                txn.append([":append", key, v])
+                                if self.t_next_val[ki] > self.max_writes:   # key used up: a fresh one takes its place in the pool
+                                    self.t_active[ki], self.t_next_val[ki] = self.t_next_key, 1
+                                    self.t_next_key += 1
+                            else:
+                                txn.append([":r", key, None])
+                        c["m_f"], c["m_value"] = ":txn", txn
                     elif wl == "unique-ids":
                         c["m_f"], c["m_value"] = ":generate", None
                     elif wl == "echo":

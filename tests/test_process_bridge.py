@@ -4,6 +4,7 @@ same random numbers as the engine's specification — a node program that behave
 the oracle (and therefore the GPU engine) emits: broadcast with this repository's fire-and-forget node process, echo with the
 REFERENCE's own demo/python/echo.py when the reference tree is present."""
 import os
+import shutil
 import sys
 
 import pytest
@@ -113,3 +114,46 @@ def test_cli(tmp_path):
     assert rc == 0
     lines = open(tmp_path / "history.edn").read().splitlines()
     assert lines and lines[0].startswith("{:index 0, :time ") and ":f :broadcast" in "".join(lines)
+
+
+REF_JS = "/root/reference/demo/js"
+_NODE = shutil.which("node")
+needs_js = pytest.mark.skipif(not (_NODE and os.path.exists(os.path.join(REF_JS, "single_key_txn.js"))), reason="needs node.js and the reference tree (demo/js)")
+
+
+@needs_js
+@pytest.mark.parametrize("kw", [
+    dict(node_count=3, rate=20, time_limit=4, seed=5),
+    dict(node_count=5, rate=50, time_limit=8, latency=5, nemesis=["partition"], nemesis_interval=2, seed=8),
+    dict(node_count=3, rate=100, time_limit=5, latency=20, latency_dist="exponential", p_loss=0.05, seed=9),
+    dict(node_count=2, rate=200, time_limit=3, latency=2, key_count=3, max_txn_length=4, max_writes_per_key=8, seed=10),
+])
+def test_reference_single_key_txn_js_reproduces_the_oracle_history(kw):
+    """BASELINE configs[4]'s node program: the REFERENCE's own demo/js/single_key_txn.js as real node.js processes, with the bridge's
+    lin-kv service, yields the history, round count and net stats of the oracle's txn-list-append (restated from
+    demo/clojure/single_key_txn.clj) — over whole runs, under partitions and loss.  (One corner is the two demos' own: when the
+    root does not exist yet, the JS node compares `[]` and the Clojure node `nil` against a root another read-only transaction has
+    just created as `[]` — the JS cas succeeds, the Clojure one, and the oracle, report a conflict.  The seeds here do not start
+    with such a race.)"""
+    _against_oracle("txn-list-append", [_NODE, os.path.join(REF_JS, "single_key_txn.js")], **kw)
+
+
+@needs_js
+def test_reference_multi_key_txn_js_runs_strict_serializably_on_the_bridge():
+    """demo/js/multi_key_txn.js (thunks in lww-kv, the root map in lin-kv, retry on a lost root cas) is not a built-in node of the
+    GPU engine; on the bridge it runs as it is, against the bridge's lin-kv and eventually consistent lww-kv services, and the
+    list-append analysis finds its histories clean — also under partitions; runs are reproducible from the seed."""
+    for kw in (dict(node_count=3, rate=20, time_limit=5, latency=2, seed=5),
+               dict(node_count=5, rate=40, time_limit=6, latency=5, nemesis=["partition"], nemesis_interval=2, seed=8)):
+        hist = []
+        for _ in range(2):
+            b = B.Bridge("txn-list-append", [_NODE, os.path.join(REF_JS, "multi_key_txn.js")], **kw)
+            h = b.run()
+            assert b.errors == []
+            hist.append(h)
+        assert hist[0] == hist[1]
+        ops = [o for o in hist[0] if o["process"] != ":nemesis"]
+        assert sum(o["type"] == ":ok" for o in ops) > 50
+        res = E.check_txn_history(*E.encode_txn_history(ops))
+        assert res["valid?"] is True and res["anomalies"] == [], res
+        assert b.stats["servers_send"] > 6 * res["ok-count"]   # per transaction: root read / cas + thunk reads and writes
