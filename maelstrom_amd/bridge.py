@@ -934,6 +934,9 @@ def main(argv=None):
     ap.add_argument("--nemesis", action="append", default=[], choices=["partition"])
     ap.add_argument("--nemesis-interval", type=float, default=10.0)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--key-count", type=int, default=10)              # core.clj:167-169
+    ap.add_argument("--max-txn-length", type=int, default=4)          # core.clj:191-194
+    ap.add_argument("--max-writes-per-key", type=int, default=16)     # core.clj:196-199
     ap.add_argument("--clock", default="virtual", choices=["virtual", "real"])
     ap.add_argument("--settle-ms", type=float, default=3.0)
     ap.add_argument("--log-dir")
@@ -949,7 +952,8 @@ def main(argv=None):
         os.makedirs(a.log_dir, exist_ok=True)
     b = Bridge(a.workload, [a.bin] + a.bin_args, node_count=a.node_count, concurrency=a.concurrency, rate=a.rate, time_limit=a.time_limit,
                latency=a.latency, latency_dist=a.latency_dist, topology=a.topology, nemesis=a.nemesis, nemesis_interval=a.nemesis_interval,
-               seed=a.seed, clock=a.clock, settle_ms=a.settle_ms, log_dir=a.log_dir)
+               seed=a.seed, clock=a.clock, settle_ms=a.settle_ms, log_dir=a.log_dir, key_count=a.key_count, max_txn_length=a.max_txn_length,
+               max_writes_per_key=a.max_writes_per_key)
     t0 = time.time()
     hist = b.run()
     if a.history:
