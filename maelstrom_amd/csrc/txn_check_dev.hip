@@ -19,7 +19,8 @@
 //   E  edges, generated twice (count, then fill a CSR): ww along each key's longest read (lane = key), wr / rw per read, and the
 //      realtime order in closed form — an :ok transaction u stays on the host's "frontier" from its completion until the first
 //      completion of a transaction invoked after it, so its successors are the transactions invoked in between: a contiguous
-//      range found with two binary searches and a suffix minimum (the host walks the history and edits a frontier list);
+//      index range read off two prefix counts taken while pairing and a suffix minimum (the host walks the history and edits a
+//      frontier list);
 //   F  acyclicity by Kahn's algorithm: 64 ready transactions per step, in-degrees by atomics, the ready queue by ballots.
 #include <hip/hip_runtime.h>
 
@@ -83,8 +84,10 @@ __global__ void __launch_bounds__(64) txn_check_kernel(const TParams p) {
   const u32 NM = p.nmax;
   u32 *const ws = p.ws + (u64)blockIdx.x * p.ws_words;
   u32 *const t_inv = ws, *const t_cmp = t_inv + NM, *const t_off = t_cmp + NM, *const t_lt = t_off + NM;   // t_lt: words | type << 16
-  u32 *const sm = t_lt + NM;                 // [NM + 1] suffix minimum of the :ok completions
-  u32 *const indeg = sm + NM + 1, *const off = indeg + NM;   // off [NM + 1]: out-degrees, then CSR offsets
+  u32 *const t_first = t_lt + NM;            // transactions invoked before this one's completion row (= index of the first one after it)
+  u32 *const sm = t_first + NM;              // [NM + 1] suffix minimum of the :ok completions ...
+  u32 *const smf = sm + NM + 1;              // [NM + 1] ... and t_first of the transaction that attains it
+  u32 *const indeg = smf + NM + 1, *const off = indeg + NM;   // off [NM + 1]: out-degrees, then CSR offsets
   u32 *const cur = off + NM + 1, *const queue = cur + NM;
   u32 *const longest = queue + NM;           // [KMAX] (len + 1) << 24 | first payload word of the list
   u32 *const writer = longest + KMAX;        // [WMAX]
@@ -96,6 +99,12 @@ __global__ void __launch_bounds__(64) txn_check_kernel(const TParams p) {
   for (int i = 0; i < 5; i++) res.stable_latency_ms[i] = 0;
   res.op_count = 0; res.ok_count = 0; res.fail_count = 0; res.info_count = 0;
 #define TO_HOST() do { if (lane == 0) p.out[hist] = res; return; } while (0)
+#ifdef TC_PROF   // developer build: cycles per phase in the result's unused fields
+  u64 tc_prev = __builtin_readcyclecounter(); u32 tc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define TC_MARK(i_) { const u64 now_ = __builtin_readcyclecounter(); tc[i_] += (u32)((now_ - tc_prev) >> 6); tc_prev = now_; }
+#else
+#define TC_MARK(i_)
+#endif
   if (n_words >= (1u << 24)) TO_HOST();
 
   // ---- A: transactions ---------------------------------------------------------------------------------------------------------
@@ -132,7 +141,7 @@ __global__ void __launch_bounds__(64) txn_check_kernel(const TParams p) {
           const u32 id = t_rl(o_txn, s), ilen = t_rl(o_len, s);
           if (lane == s) o_used = false;
           if (lane == j) {
-            t_cmp[id] = idx;
+            t_cmp[id] = idx; t_first[id] = n + (u32)__popcll(im & ((1ull << j) - 1ull));
             if (jt == MSIM_T_OK) { t_off[id] = woff; t_lt[id] = len | (MSIM_T_OK << 16); }   // the completed form replaces the requested one
             else t_lt[id] = ilen | (jt << 16);
           }
@@ -147,6 +156,7 @@ __global__ void __launch_bounds__(64) txn_check_kernel(const TParams p) {
   __syncthreads();
   res.op_count = n; res.attempt_count = n; res.ok_count = c_ok; res.stable_count = c_ok; res.fail_count = c_fail; res.info_count = c_info;
 
+  TC_MARK(0)
   // ---- B: ranges, and the tables cleared ------------------------------------------------------------------------------------------
   u32 max_key = 0, max_val = 0; bool bad = false;
   for (u32 t = lane; t < n; t += 64) {
@@ -161,6 +171,7 @@ __global__ void __launch_bounds__(64) txn_check_kernel(const TParams p) {
   for (u32 t = lane; t <= n; t += 64) { off[t] = 0; if (t < n) { indeg[t] = 0; cur[t] = 0; } }
   __syncthreads();
 
+  TC_MARK(1)
   // ---- C: writers (every transaction, whatever became of it) -------------------------------------------------------------------------
   for (u32 t = lane; t < n; t += 64) {
     const u32 *w = pay + t_off[t]; const u32 wn = t_lt[t] & 0xFFFFu;
@@ -170,6 +181,7 @@ __global__ void __launch_bounds__(64) txn_check_kernel(const TParams p) {
   if (__ballot(bad)) TO_HOST();
 #define WRITER(k_, el_) ((el_) < stride ? writer[(k_) * stride + (el_)] : NONE)
 
+  TC_MARK(2)
   // ---- D: the reads of :ok transactions ------------------------------------------------------------------------------------------------
   for (u32 t = lane; t < n; t += 64) {
     if ((t_lt[t] >> 16) != MSIM_T_OK) continue;
@@ -215,26 +227,28 @@ __global__ void __launch_bounds__(64) txn_check_kernel(const TParams p) {
   __syncthreads();
   if (__ballot(bad)) TO_HOST();
 
-  // realtime order in closed form: sm[j] = earliest :ok completion among transactions j .. n-1
+  TC_MARK(3)
+  // realtime order in closed form: sm[j] = earliest :ok completion among transactions j .. n-1 (smf[j]: how many transactions were
+  // invoked before that completion)
   {
-    u32 carry = NONE;
+    u64 carry = ~0ull;
     for (int b = (int)((n + 63u) / 64u) - 1; b >= 0; b--) {
       const u32 t = (u32)b * 64u + lane;
-      u32 v = (t < n && (t_lt[t] >> 16) == MSIM_T_OK) ? t_cmp[t] : NONE;
-      for (int o = 1; o < 64; o <<= 1) { const u32 y = (u32)__shfl_down((int)v, o); if (lane + (u32)o < 64u) v = min(v, y); }
+      u64 v = (t < n && (t_lt[t] >> 16) == MSIM_T_OK) ? (((u64)t_cmp[t] << 32) | t_first[t]) : ~0ull;
+      for (int o = 1; o < 64; o <<= 1) {
+        const u32 ylo = (u32)__shfl_down((int)(u32)v, o), yhi = (u32)__shfl_down((int)(u32)(v >> 32), o);
+        const u64 y = ((u64)yhi << 32) | ylo;
+        if (lane + (u32)o < 64u) v = min(v, y);
+      }
       v = min(v, carry);
-      if (t < n) sm[t] = v;
-      carry = t_rl(v, 0);
+      if (t < n) { sm[t] = (u32)(v >> 32); smf[t] = (u32)v; }
+      carry = ((u64)t_rl((u32)(v >> 32), 0) << 32) | t_rl((u32)v, 0);
     }
-    if (lane == 0) sm[n] = NONE;
+    if (lane == 0) { sm[n] = NONE; smf[n] = n; }
   }
   __syncthreads();
-  auto rank_of = [&](u32 row) -> u32 {   // number of transactions invoked before `row`
-    u32 lo = 0, hi = n;
-    while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (t_inv[mid] < row) lo = mid + 1; else hi = mid; }
-    return lo;
-  };
 
+  TC_MARK(4)
   // ---- E: edges: pass 0 counts degrees, pass 1 fills the CSR ------------------------------------------------------------------------------
   u32 n_edges = 0;
   for (int pass = 0; pass < 2; pass++) {
@@ -271,9 +285,8 @@ __global__ void __launch_bounds__(64) txn_check_kernel(const TParams p) {
         if (ext > 0) { const u32 wr = WRITER(m.key, elem(m.list, ext - 1)); if (wr != NONE && (t_lt[wr] >> 16) != MSIM_T_FAIL) ADD(wr, t); }
         if (m.len < llen) { const u32 wr = WRITER(m.key, elem(ord, m.len)); if (wr != NONE && (t_lt[wr] >> 16) != MSIM_T_FAIL) ADD(t, wr); }   // anti-dependency
       }
-      const u32 first = rank_of(t_cmp[t] + 1u);   // (a completion row is no invocation row: "+ 1" is immaterial, kept for clarity)
-      const u32 kill = sm[first];
-      const u32 last = kill == NONE ? n : rank_of(kill);
+      const u32 first = t_first[t];                      // the transactions invoked after t completed start here ...
+      const u32 last = sm[first] == NONE ? n : smf[first];   // ... and end where the first of them to complete :ok did
       for (u32 v = first; v < last; v++) if ((t_lt[v] >> 16) != MSIM_T_FAIL) ADD(t, v);
     }
 #undef ADD
@@ -295,6 +308,7 @@ __global__ void __launch_bounds__(64) txn_check_kernel(const TParams p) {
     }
   }
 
+  TC_MARK(5)
   // ---- F: acyclic?  Kahn's algorithm, 64 ready transactions per step -------------------------------------------------------------------------
   u32 tail = 0;
   for (u32 base = 0; base < n; base += 64) {
@@ -322,11 +336,16 @@ __global__ void __launch_bounds__(64) txn_check_kernel(const TParams p) {
     head += cnt;
     __syncthreads();
   }
+  TC_MARK(6)
   if (tail != n) TO_HOST();   // a cycle: the host finds and classifies it
 
   if (lane == 0) {
     res.lost_count = n_edges;   // edges of the dependency graph
     res.valid = flags ? 0u : (c_ok == 0 ? 2u : 1u);
+#ifdef TC_PROF
+    for (int i = 0; i < 5; i++) res.stable_latency_ms[i] = tc[i];
+    res.never_read_count = tc[5]; res.duplicated_count = tc[6];
+#endif
     p.out[hist] = res;
   }
 #undef TO_HOST
@@ -334,7 +353,7 @@ __global__ void __launch_bounds__(64) txn_check_kernel(const TParams p) {
 }
 
 // words of workspace per history
-uint64_t ws_words_for(u32 nmax, u32 emax) { return (uint64_t)nmax * 9 + 3 + KMAX + WMAX + emax; }
+uint64_t ws_words_for(u32 nmax, u32 emax) { return (uint64_t)nmax * 11 + 4 + KMAX + WMAX + emax; }
 
 int txn_dev_run(msim_ctx *ctx, TParams tp, u32 n, u32 cm, const std::vector<msim_inst_meta> *hmeta, msim_check_result *h_out, hipStream_t st, u32 *n_host,
                 void **ws_buf, size_t *ws_cap) {
