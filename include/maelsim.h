@@ -261,6 +261,11 @@ int msim_run_async(msim_ctx *ctx, uint64_t first_instance, uint32_t n_instances,
  * msim_check_host_rechecks.  On the host cores, after a fetch: rw-register (elle), pn-counter, unique-ids.  Blocking.  Results via msim_check_results. */
 int msim_check(msim_ctx *ctx);
 
+/* Developer switches of a context (A/B comparisons, tracing; never needed for normal use) — the same bits the environment variable
+ * MSIM_DEV_FLAGS carries, which is ORed in: 0x100 round limit x 20, 0x200 run the one-cluster-per-wavefront kernels, 0x400 fail
+ * instead of falling back to them, 0x800 keep the workload checkers on the host cores, 0x1000 time the checkers' passes on stderr. */
+int msim_set_dev_flags(msim_ctx *ctx, uint32_t flags);
+
 /* How many histories of the last msim_check the device handed to the host (lin-kv: the search needed more than 512
  * configurations; txn-list-append: not provably clean, i.e. the host analysed and classified it; else 0). */
 uint32_t msim_check_host_rechecks(const msim_ctx *ctx);

@@ -916,7 +916,7 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   kp.nem_period2_us = (u32)(2000ull * c.nemesis_interval_ms);
   const bool is_raft = c.node_program == MSIM_NODE_RAFT;
   kp.raft_log_cap = is_raft ? raft_log_cap(c) : 0;
-  { static const char *df = std::getenv("MSIM_DEV_FLAGS"); kp.dev_flags = df ? (u32)std::atoi(df) : 0u; }
+  kp.dev_flags = msim_dev_flags(ctx);
   const bool wide = c.n_nodes > 32;
   size_t off = (wide ? WIDE_STAGE_ROWS : STAGE_ROWS) * 16;
   const bool is_txn = c.node_program == MSIM_NODE_TXN_SINGLE_KEY, is_px = c.node_program == MSIM_NODE_LIN_KV_PROXY;
@@ -1023,21 +1023,21 @@ extern "C" int msim_check(msim_ctx *ctx) {
   if (!ctx) return MSIM_E_INVALID;
   if (!ctx->ran) { ctx->err = "msim_check before msim_run"; return MSIM_E_RANGE; }
   if (ctx->cfg.workload == MSIM_WL_LIN_KV) {
-    static const char *df = std::getenv("MSIM_DEV_FLAGS");   // bit 11: keep the lin-kv search on the host cores
-    return (df && (std::atoi(df) & 0x800)) ? msim_check_lin_kv_host(ctx) : msim_check_lin_kv_device(ctx);
+    return (msim_dev_flags(ctx) & 0x800u) ?   // bit 11: keep the check on the host cores
+           msim_check_lin_kv_host(ctx) : msim_check_lin_kv_device(ctx);
   }
   if (ctx->cfg.workload == MSIM_WL_TXN_LIST_APPEND) {
-    static const char *df = std::getenv("MSIM_DEV_FLAGS");   // bit 11: keep the analysis on the host cores
-    return (df && (std::atoi(df) & 0x800)) ? msim_check_txn_host(ctx) : msim_check_txn_device(ctx);
+    return (msim_dev_flags(ctx) & 0x800u) ?   // bit 11: keep the check on the host cores
+           msim_check_txn_host(ctx) : msim_check_txn_device(ctx);
   }
   if (ctx->cfg.workload == MSIM_WL_TXN_RW_REGISTER) return msim_check_txn_host(ctx);
   if (ctx->cfg.workload == MSIM_WL_PN_COUNTER || ctx->cfg.workload == MSIM_WL_G_COUNTER) {
-    static const char *df = std::getenv("MSIM_DEV_FLAGS");   // bit 11: keep the check on the host cores
-    return (df && (std::atoi(df) & 0x800)) ? msim_check_pn_host(ctx) : msim_check_pn_device(ctx);
+    return (msim_dev_flags(ctx) & 0x800u) ?   // bit 11: keep the check on the host cores
+           msim_check_pn_host(ctx) : msim_check_pn_device(ctx);
   }
   if (ctx->cfg.workload == MSIM_WL_UNIQUE_IDS) {
-    static const char *df = std::getenv("MSIM_DEV_FLAGS");   // bit 11: keep the check on the host cores
-    return (df && (std::atoi(df) & 0x800)) ? msim_check_unique_host(ctx) : msim_check_unique_device(ctx);
+    return (msim_dev_flags(ctx) & 0x800u) ?   // bit 11: keep the check on the host cores
+           msim_check_unique_host(ctx) : msim_check_unique_device(ctx);
   }
   return msim_check_launch(ctx);
 }
@@ -1209,6 +1209,12 @@ extern "C" int msim_meta(msim_ctx *ctx, uint32_t inst, msim_inst_meta *out) {
   if (!ctx || !out) return MSIM_E_INVALID;
   if (!ctx->fetched || inst >= ctx->n_inst) { ctx->err = "msim_meta: not fetched or instance out of range"; return MSIM_E_RANGE; }
   *out = ctx->h_meta[inst];
+  return MSIM_OK;
+}
+
+extern "C" int msim_set_dev_flags(msim_ctx *ctx, uint32_t flags) {
+  if (!ctx) return MSIM_E_INVALID;
+  ctx->dev_flags = flags;
   return MSIM_OK;
 }
 

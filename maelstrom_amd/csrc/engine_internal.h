@@ -47,6 +47,7 @@ struct msim_ctx {
   uint64_t *d_sizes = nullptr;   // world x 4 u64 for the size all-gather
   bool fetched = false, checked = false, check_fetched = false, ran = false;
   float sim_ms = 0.f, check_ms = 0.f;
+  uint32_t dev_flags = 0;           // msim_set_dev_flags: ORed with the MSIM_DEV_FLAGS of the environment (developer switches)
   uint32_t lin_host_rechecks = 0;   // lin_check_dev.hip: histories of the last check the host search had to finish
   std::string err;
 };
@@ -68,6 +69,14 @@ static inline unsigned msim_host_threads() {
   }
   if (const char *e = std::getenv("LOCAL_WORLD_SIZE")) { const int v = std::atoi(e); if (v > 1) nt = nt / (unsigned)v ? nt / (unsigned)v : 1; }
   return nt;
+}
+
+// The developer switches in force for a context: those set through msim_set_dev_flags ORed with MSIM_DEV_FLAGS of the environment
+// (read once per process).  0x100 round limit x20, 0x200 one cluster per wavefront, 0x400 fail instead of falling back to it,
+// 0x800 checkers on the host cores, 0x1000 time the checkers' passes on stderr.
+static inline uint32_t msim_dev_flags(const msim_ctx *ctx) {
+  static const uint32_t env = []() { const char *e = std::getenv("MSIM_DEV_FLAGS"); return e ? (uint32_t)std::atoi(e) : 0u; }();
+  return env | (ctx ? ctx->dev_flags : 0u);
 }
 
 // engine.hip: compacts the used prefix of every instance's row / payload slab into ctx->d_grows / ctx->d_gpay on the device

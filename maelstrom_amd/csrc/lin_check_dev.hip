@@ -251,8 +251,7 @@ __global__ void __launch_bounds__(64) lin_check_kernel(const LParams p) {
 // (all host threads) finishes what is left
 int lin_check_dev_run(msim_ctx *ctx, const LParams &lp0, u32 n, u32 max_rows_any, msim_check_result *h_out, hipStream_t st, u32 *n_host) {
   LParams lp = lp0;
-  static const char *df = std::getenv("MSIM_DEV_FLAGS");
-  const bool trace = df && (std::atoi(df) & 0x1000);   // developer: time the passes
+  const bool trace = (msim_dev_flags(ctx) & 0x1000u) != 0;   // developer: time the passes
   const auto t0 = std::chrono::steady_clock::now();
   auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
   const u32 table_cap = (60u * 1024u - 2048u) / 4u;

@@ -357,8 +357,7 @@ uint64_t ws_words_for(u32 nmax, u32 emax) { return (uint64_t)nmax * 11 + 4 + KMA
 
 int txn_dev_run(msim_ctx *ctx, TParams tp, u32 n, u32 cm, const std::vector<msim_inst_meta> *hmeta, msim_check_result *h_out, hipStream_t st, u32 *n_host,
                 void **ws_buf, size_t *ws_cap) {
-  static const char *df = std::getenv("MSIM_DEV_FLAGS");
-  const bool trace = df && (std::atoi(df) & 0x1000);
+  const bool trace = (msim_dev_flags(ctx) & 0x1000u) != 0;   // developer: time the passes
   const auto t0 = std::chrono::steady_clock::now();
   auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
   tp.ws_words = ws_words_for(tp.nmax, tp.emax);

@@ -135,6 +135,10 @@ class Engine:
     def check(self):
         self._chk(self.lib.msim_check(self._ctx), "msim_check")
 
+    def set_dev_flags(self, flags):
+        """Developer switches of this context (msim_set_dev_flags): e.g. 0x200 one cluster per wavefront, 0x800 checkers on the host."""
+        self._chk(self.lib.msim_set_dev_flags(self._ctx, int(flags)), "msim_set_dev_flags")
+
     def check_host_rechecks(self):
         """lin-kv: how many histories of the last check() the device handed to the host search."""
         return int(self.lib.msim_check_host_rechecks(self._ctx))

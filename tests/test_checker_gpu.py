@@ -289,3 +289,27 @@ def test_pn_counter_device_checker_equals_host(lib):
         for f in fields:
             assert int(dev[i][f]) == int(getattr(h, f)), (i, f, int(dev[i][f]), int(getattr(h, f)))
     assert [int(v) for v in dev["valid"][:5]] == [1, 0, 0, 1, 0] and int(dev[2]["stable_count"]) == 2
+
+
+@pytest.mark.parametrize("wl,kw", [
+    ("lin-kv", dict(bin="raft", node_count=5, rate=30, time_limit=20, latency=10, nemesis=["partition"], nemesis_interval=5)),
+    ("txn-list-append", dict(node_count=5, rate=100, time_limit=10, latency=5, nemesis=["partition"], nemesis_interval=3)),
+    ("unique-ids", dict(node_count=3, rate=300, time_limit=5, latency=5)),
+    ("pn-counter", dict(node_count=5, rate=50, time_limit=8, latency=30, p_loss=0.1)),
+])
+def test_device_and_host_checkers_give_the_same_results_through_msim_check(lib, wl, kw):
+    """msim_check with the checkers where the histories are (default) and on the host cores (msim_set_dev_flags 0x800): every field
+    of every result record equal — and the one-cluster-per-wavefront kernels (0x200) emit the same histories as the packed ones."""
+    cfg = E.test_config(wl, seed=31, **kw)
+    n = 24
+    out = []
+    for flags in (0, 0x800, 0x200):
+        with E.Engine(cfg) as eng:
+            eng.set_dev_flags(flags)
+            eng.run(0, n)
+            eng.check()
+            res = eng.check_results()
+            eng.fetch()
+            out.append((res, [eng.raw_history(i)[0].tobytes() for i in range(n)]))
+    assert out[0][0].tobytes() == out[1][0].tobytes() == out[2][0].tobytes()
+    assert out[0][1] == out[2][1]
