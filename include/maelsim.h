@@ -364,6 +364,12 @@ int msim_journal_fressian_rows(const msim_config *cfg, const msim_event *events,
 /* Copies the last run's outputs to host memory (pinned, owned by ctx, valid until next run/destroy). */
 int msim_fetch(msim_ctx *ctx);
 
+/* The first half of msim_fetch for callers that keep the GPU busy meanwhile: copies meta and stats, compacts rows and payload on the
+ * device and queues the two PCIe copies, then returns; a later msim_fetch waits for them.  Called right after msim_check and before
+ * the next batch is started on another context, the compaction kernels sit in the queue ahead of that batch's simulation and the
+ * copies run beside it (bench.py's value_incl_fetch). */
+int msim_fetch_begin(msim_ctx *ctx);
+
 /* Per-instance views into the fetched outputs (require msim_fetch). `inst` is 0-based within the run. */
 int msim_history(msim_ctx *ctx, uint32_t inst, const msim_op **ops, uint32_t *n_ops,
                  const uint32_t **payload, uint32_t *n_words);

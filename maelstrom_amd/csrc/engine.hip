@@ -773,6 +773,9 @@ static void free_buffers(msim_ctx *c) {
   c->d_check_scratch = nullptr; c->cap_check_scratch = 0;
   if (c->d_compact) (void)hipFree(c->d_compact);
   if (c->d_off) (void)hipFree(c->d_off);
+  if (c->d_compact2) (void)hipFree(c->d_compact2);
+  if (c->d_off2) (void)hipFree(c->d_off2);
+  c->d_compact2 = nullptr; c->d_off2 = nullptr; c->cap_compact2 = c->cap_off2 = 0;
   if (c->d_grows) (void)hipFree(c->d_grows);
   if (c->d_gpay) (void)hipFree(c->d_gpay);
   if (c->d_goff) (void)hipFree(c->d_goff);
@@ -1000,7 +1003,7 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
 #endif
   if (e != hipSuccess) { ctx->err = std::string("kernel launch: ") + hipGetErrorString(e); return MSIM_E_HIP; }
   ctx->n_inst = n; ctx->first_instance = first;
-  ctx->fetched = false; ctx->checked = false; ctx->check_fetched = false; ctx->ran = true;
+  ctx->fetched = false; ctx->fetch_pending = false; ctx->checked = false; ctx->check_fetched = false; ctx->ran = true;
   if (blocking) {
     MSIM_HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
     MSIM_HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
@@ -1071,31 +1074,35 @@ static int grow_pinned(msim_ctx *ctx, T **buf, size_t *cap, size_t bytes) {
 }
 
 // one slab kind: compact on the device, then ONE device-to-host copy
-static int fetch_compacted(msim_ctx *ctx, const void *d_src, uint64_t stride_units, bool units16, const uint64_t *h_off, void *h_dst) {
+// One slab kind to the host: the used prefix of every instance's slab is compacted on the device (phase 0) and crosses PCIe as ONE
+// copy (phase 1).  Asynchronous on the context's stream; rows and payload have their own compaction buffer and offset table (pair
+// 0 / 1), so that both compactions are queued before the first copy; the caller synchronises.
+static int fetch_compacted(msim_ctx *ctx, const void *d_src, uint64_t stride_units, bool units16, const uint64_t *h_off, void *h_dst, int pair, int phase) {
   const uint32_t n = ctx->n_inst;
   const uint64_t total = h_off[n];
   if (!total) return MSIM_OK;
+  void **d_compact = pair ? &ctx->d_compact2 : &ctx->d_compact; size_t *cap_compact = pair ? &ctx->cap_compact2 : &ctx->cap_compact;
+  uint64_t **d_off = pair ? &ctx->d_off2 : &ctx->d_off; size_t *cap_off = pair ? &ctx->cap_off2 : &ctx->cap_off;
   const size_t unit = units16 ? 16 : 4, bytes = (size_t)total * unit;
-  if (ctx->cap_compact < bytes) {
-    if (ctx->d_compact) (void)hipFree(ctx->d_compact);
-    ctx->d_compact = nullptr; ctx->cap_compact = 0;
-    MSIM_HIP_TRY(ctx, hipMalloc(&ctx->d_compact, bytes + bytes / 8));
-    ctx->cap_compact = bytes + bytes / 8;
+  if (phase == 1) { MSIM_HIP_TRY(ctx, hipMemcpyAsync(h_dst, *d_compact, bytes, hipMemcpyDeviceToHost, ctx->stream)); return MSIM_OK; }
+  if (*cap_compact < bytes) {
+    if (*d_compact) (void)hipFree(*d_compact);
+    *d_compact = nullptr; *cap_compact = 0;
+    MSIM_HIP_TRY(ctx, hipMalloc(d_compact, bytes + bytes / 8));
+    *cap_compact = bytes + bytes / 8;
   }
-  if (ctx->cap_off < (size_t)(n + 1) * 8) {
-    if (ctx->d_off) (void)hipFree(ctx->d_off);
-    ctx->d_off = nullptr; ctx->cap_off = 0;
-    MSIM_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_off), (size_t)(n + 1) * 8));
-    ctx->cap_off = (size_t)(n + 1) * 8;
+  if (*cap_off < (size_t)(n + 1) * 8) {
+    if (*d_off) (void)hipFree(*d_off);
+    *d_off = nullptr; *cap_off = 0;
+    MSIM_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(d_off), (size_t)(n + 1) * 8));
+    *cap_off = (size_t)(n + 1) * 8;
   }
-  MSIM_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_off, h_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  MSIM_HIP_TRY(ctx, hipMemcpyAsync(*d_off, h_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
   const uint64_t avg = total / n + 1;
   const unsigned gy = (unsigned)((avg + 1023) / 1024 < 1 ? 1 : ((avg + 1023) / 1024 > 64 ? 64 : (avg + 1023) / 1024));
-  if (units16) hipLaunchKernelGGL(compact_kernel, dim3(n, gy), dim3(256), 0, ctx->stream, static_cast<const uint4 *>(d_src), static_cast<uint4 *>(ctx->d_compact), ctx->d_off, stride_units);
-  else hipLaunchKernelGGL(compact_words_kernel, dim3(n, gy), dim3(256), 0, ctx->stream, static_cast<const u32 *>(d_src), static_cast<u32 *>(ctx->d_compact), ctx->d_off, stride_units);
+  if (units16) hipLaunchKernelGGL(compact_kernel, dim3(n, gy), dim3(256), 0, ctx->stream, static_cast<const uint4 *>(d_src), static_cast<uint4 *>(*d_compact), *d_off, stride_units);
+  else hipLaunchKernelGGL(compact_words_kernel, dim3(n, gy), dim3(256), 0, ctx->stream, static_cast<const u32 *>(d_src), static_cast<u32 *>(*d_compact), *d_off, stride_units);
   MSIM_HIP_TRY(ctx, hipGetLastError());
-  MSIM_HIP_TRY(ctx, hipMemcpyAsync(h_dst, ctx->d_compact, bytes, hipMemcpyDeviceToHost, ctx->stream));
-  MSIM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // d_compact / h_off are reused by the next slab kind
   return MSIM_OK;
 }
 
@@ -1140,10 +1147,14 @@ int msim_compact_on_device(msim_ctx *ctx, uint64_t *row_units, uint64_t *pay_wor
   return MSIM_OK;
 }
 
-extern "C" int msim_fetch(msim_ctx *ctx) {
+// The histories' way to the host in two halves: msim_fetch_begin copies meta / stats (small), compacts rows and payload on the
+// device and QUEUES the two big copies; msim_fetch waits for them (and fetches the journal).  A caller that has other work for the
+// GPU — the next batch on another context — calls _begin right after the checker and _fetch when it needs the data: the
+// compaction kernels are in the queue before the next batch's simulation, the copies run beside it.  msim_fetch alone does both.
+extern "C" int msim_fetch_begin(msim_ctx *ctx) {
   if (!ctx) return MSIM_E_INVALID;
   if (!ctx->ran) { ctx->err = "msim_fetch before msim_run"; return MSIM_E_RANGE; }
-  if (ctx->fetched) return MSIM_OK;
+  if (ctx->fetched || ctx->fetch_pending) return MSIM_OK;
   MSIM_HIP_TRY(ctx, hipSetDevice(ctx->device));
   const msim_config &c = ctx->cfg;
   const uint32_t n = ctx->n_inst;
@@ -1171,10 +1182,33 @@ extern "C" int msim_fetch(msim_ctx *ctx) {
   if ((rc = grow_pinned(ctx, &ctx->h_rows, &ctx->cap_h_rows, (size_t)(ro + 1) * sizeof(msim_op))) != MSIM_OK) return rc;
   if ((rc = grow_pinned(ctx, &ctx->h_payload, &ctx->cap_h_payload, (size_t)(po + 1) * 4)) != MSIM_OK) return rc;
   if (c.journal_capacity && (rc = grow_pinned(ctx, &ctx->h_journal, &ctx->cap_h_journal, (size_t)(eo + 1) * sizeof(msim_event))) != MSIM_OK) return rc;
-  // only the used prefix of every instance's slab crosses PCIe, as one copy per slab kind
-  if ((rc = fetch_compacted(ctx, ctx->d_rows, c.max_rows, true, ctx->h_row_off, ctx->h_rows)) != MSIM_OK) return rc;
-  if ((rc = fetch_compacted(ctx, ctx->d_payload, c.max_payload_words, false, ctx->h_pay_off, ctx->h_payload)) != MSIM_OK) return rc;
-  if (c.journal_capacity && (rc = fetch_compacted(ctx, ctx->d_journal, c.journal_capacity, true, ctx->h_ev_off, ctx->h_journal)) != MSIM_OK) return rc;
+  // only the used prefix of every instance's slab crosses PCIe, as one copy per slab kind: both compactions, then both copies
+  for (int phase = 0; phase < 2; phase++) {
+    if ((rc = fetch_compacted(ctx, ctx->d_rows, c.max_rows, true, ctx->h_row_off, ctx->h_rows, 0, phase)) != MSIM_OK) return rc;
+    if ((rc = fetch_compacted(ctx, ctx->d_payload, c.max_payload_words, false, ctx->h_pay_off, ctx->h_payload, 1, phase)) != MSIM_OK) return rc;
+    // the compaction kernels are off the CUs before this returns: a simulation launched while they still hold wave slots is
+    // placed unevenly over the SIMDs and runs 25 % longer (measured); the copies behind them are DMA and disturb nothing
+    if (phase == 0) MSIM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  ctx->fetch_pending = true;
+  return MSIM_OK;
+}
+
+extern "C" int msim_fetch(msim_ctx *ctx) {
+  if (!ctx) return MSIM_E_INVALID;
+  if (!ctx->ran) { ctx->err = "msim_fetch before msim_run"; return MSIM_E_RANGE; }
+  if (ctx->fetched) return MSIM_OK;
+  int rc = msim_fetch_begin(ctx);
+  if (rc != MSIM_OK) return rc;
+  MSIM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  MSIM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const msim_config &c = ctx->cfg;
+  if (c.journal_capacity) {
+    for (int phase = 0; phase < 2; phase++)
+      if ((rc = fetch_compacted(ctx, ctx->d_journal, c.journal_capacity, true, ctx->h_ev_off, ctx->h_journal, 0, phase)) != MSIM_OK) return rc;
+    MSIM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  ctx->fetch_pending = false;
   ctx->fetched = true;
   return MSIM_OK;
 }

@@ -38,6 +38,8 @@ struct msim_ctx {
   // fetch path: device-side compaction buffers + grow-only capacities (bytes) of the pinned mirrors
   void *d_check_scratch = nullptr; size_t cap_check_scratch = 0;  // checker.hip: read records per instance
   void *d_compact = nullptr; uint64_t *d_off = nullptr;
+  void *d_compact2 = nullptr; uint64_t *d_off2 = nullptr; size_t cap_compact2 = 0, cap_off2 = 0;   // the payload's own pair (both compactions are queued before the first copy)
+  bool fetch_pending = false;      // msim_fetch_begin has queued the copies; msim_fetch waits for them
   size_t cap_compact = 0, cap_off = 0, cap_h_rows = 0, cap_h_payload = 0, cap_h_journal = 0, cap_h_meta = 0;
   // multi-GPU gather (gather.cpp): RCCL communicator of this rank, the rank's compacted slabs, the root's receive buffers
   void *comm = nullptr; int comm_rank = 0, comm_world = 1;

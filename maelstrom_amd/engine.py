@@ -146,6 +146,10 @@ class Engine:
     def fetch(self):
         self._chk(self.lib.msim_fetch(self._ctx), "msim_fetch")
 
+    def fetch_begin(self):
+        """Compacts the histories on the device and queues their copies to the host; fetch() waits for them (msim_fetch_begin)."""
+        self._chk(self.lib.msim_fetch_begin(self._ctx), "msim_fetch_begin")
+
     def kernel_ms(self):
         a, b = C.c_float(), C.c_float()
         self._chk(self.lib.msim_last_kernel_ms(self._ctx, C.byref(a), C.byref(b)), "msim_last_kernel_ms")
