@@ -797,12 +797,13 @@ extern "C" int msim_create(const msim_config *cfg, int device, msim_ctx **out, c
   int rc = msim_config_finalize(&c, err, errlen);
   if (rc != MSIM_OK) return rc;
   const uint32_t slots = c.concurrency > c.n_nodes ? c.concurrency : c.n_nodes;
-  // wide clusters (33..127 nodes): two node/client pairs per lane, built for the g-set CRDT with one worker per node
-  const bool wide = c.n_nodes > 32 && c.node_program == MSIM_NODE_G_SET && c.concurrency == c.n_nodes && c.nemesis_mask == 0;
+  // wide clusters (33..127 nodes): two node/client pairs per lane, one worker per node: the g-set CRDT and fire-and-forget broadcast
+  const bool wide_prog = c.node_program == MSIM_NODE_G_SET || c.node_program == MSIM_NODE_BCAST_FF || c.node_program == MSIM_NODE_BCAST_FF_ECHOBACK;
+  const bool wide = c.n_nodes > 32 && c.n_nodes <= 127 && wide_prog && c.concurrency == c.n_nodes && c.nemesis_mask == 0;
   const uint32_t svc_lanes = c.node_program == MSIM_NODE_LIN_KV_PROXY ? 1 : 0;  // the service has a lane of its own after the client slots
   if (!wide && (c.n_nodes > 32 || c.n_nodes + slots + svc_lanes > 64)) {
     set_err(err, errlen, "this build maps one cluster to one wavefront: n_nodes <= 32 and n_nodes + max(concurrency, n_nodes) <= 64 "
-                         "(g-set with concurrency == n_nodes and no nemesis: up to 127 nodes)");
+                         "(g-set and fire-and-forget broadcast with concurrency == n_nodes and no nemesis: up to 127 nodes)");
     return MSIM_E_UNSUPPORTED;
   }
   int ndev = 0;
@@ -844,6 +845,8 @@ static uint64_t proto_scratch_words(const msim_config &c) {
     w = ticks * c.n_nodes * (c.max_values / 32);
     if (c.n_nodes > 32) w = ((w + 3) & ~3ull) + (((uint64_t)c.n_nodes * (c.max_values / 32) + 3) & ~3ull);  // wide clusters: + the nodes' sets
   }
+  const bool bcast_ff = c.node_program == MSIM_NODE_BCAST_FF || c.node_program == MSIM_NODE_BCAST_FF_ECHOBACK;
+  if (bcast_ff && c.n_nodes > 32) w = 4 + (((uint64_t)c.n_nodes * (c.max_values / 32) + 3) & ~3ull);  // wide clusters: the nodes' sets
   return (w + 3) & ~3ull;  // keep the spill area 16-byte aligned
 }
 static uint64_t scratch_words(const msim_config &c) {
@@ -958,17 +961,27 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   if (e == hipErrorInvalidValue && (kp.dev_flags & 0x400u) && is_raft) { ctx->err = "MSIM_DEV_FLAGS bit 10: the four-clusters-per-wavefront Raft layout was required but does not apply"; return MSIM_E_UNSUPPORTED; }
   if (e == hipErrorInvalidValue) switch (c.node_program) {   // not eligible, or the cluster state does not fit the duo layout
     case MSIM_NODE_ECHO: e = launch<MSIM_NODE_ECHO>(kp, n, lds, st); break;
-    case MSIM_NODE_BCAST_FF: e = launch<MSIM_NODE_BCAST_FF>(kp, n, lds, st); break;
-    case MSIM_NODE_BCAST_FF_ECHOBACK: e = launch<MSIM_NODE_BCAST_FF_ECHOBACK>(kp, n, lds, st); break;
+    case MSIM_NODE_BCAST_FF:
+    case MSIM_NODE_BCAST_FF_ECHOBACK:
+      if (wide) {
+        const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
+        const void *fn = rnd ? reinterpret_cast<const void *>(&sim_kernel_wide<true, true>) : reinterpret_cast<const void *>(&sim_kernel_wide<false, true>);
+        if (lds > 64 * 1024) MSIM_HIP_TRY(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (rnd) hipLaunchKernelGGL((sim_kernel_wide<true, true>), dim3(n), dim3(64), lds, st, kp);
+        else hipLaunchKernelGGL((sim_kernel_wide<false, true>), dim3(n), dim3(64), lds, st, kp);
+        e = hipGetLastError();
+      } else if (c.node_program == MSIM_NODE_BCAST_FF) e = launch<MSIM_NODE_BCAST_FF>(kp, n, lds, st);
+      else e = launch<MSIM_NODE_BCAST_FF_ECHOBACK>(kp, n, lds, st);
+      break;
     case MSIM_NODE_BCAST_ACK_RETRY: e = launch<MSIM_NODE_BCAST_ACK_RETRY>(kp, n, lds, st); break;
     case MSIM_NODE_BCAST_RPC_ALL: e = launch<MSIM_NODE_BCAST_RPC_ALL>(kp, n, lds, st); break;
     case MSIM_NODE_G_SET:
       if (wide) {
         const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
-        const void *fn = rnd ? reinterpret_cast<const void *>(&sim_kernel_wide<true>) : reinterpret_cast<const void *>(&sim_kernel_wide<false>);
+        const void *fn = rnd ? reinterpret_cast<const void *>(&sim_kernel_wide<true, false>) : reinterpret_cast<const void *>(&sim_kernel_wide<false, false>);
         if (lds > 64 * 1024) MSIM_HIP_TRY(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (rnd) hipLaunchKernelGGL((sim_kernel_wide<true>), dim3(n), dim3(64), lds, st, kp);
-        else hipLaunchKernelGGL((sim_kernel_wide<false>), dim3(n), dim3(64), lds, st, kp);
+        if (rnd) hipLaunchKernelGGL((sim_kernel_wide<true, false>), dim3(n), dim3(64), lds, st, kp);
+        else hipLaunchKernelGGL((sim_kernel_wide<false, false>), dim3(n), dim3(64), lds, st, kp);
         e = hipGetLastError();
       } else e = launch<MSIM_NODE_G_SET>(kp, n, lds, st);
       break;

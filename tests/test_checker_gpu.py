@@ -63,6 +63,12 @@ def test_wide_g_set_checker(lib):
     _check(E.test_config("g-set", node_count=100, rate=100, time_limit=10, latency=100, latency_dist="exponential", p_loss=0.05, seed=4), 3)
 
 
+def test_wide_broadcast_checker(lib):
+    """set-full over 100 nodes' reads (broadcast.clj:216-228)."""
+    res = _check(E.test_config("broadcast", node_count=100, rate=100, time_limit=10, latency=20, seed=5), 3)
+    assert (res["valid"] == 1).all() and (res["lost_count"] == 0).all()
+
+
 def test_echo_checker(lib):
     cfg = E.test_config("echo", node_count=3, rate=10, time_limit=5, seed=2)
     with E.Engine(cfg) as eng:

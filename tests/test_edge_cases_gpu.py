@@ -37,6 +37,7 @@ def test_widest_clusters_of_each_layout(lib):
     _compare(E.test_config("broadcast", node_count=16, concurrency=48, rate=100, time_limit=3, latency=10, seed=3), 0, 2)   # 16 + 48 = 64 lanes
     _compare(E.test_config("txn-list-append", node_count=31, rate=200, time_limit=3, latency=2, seed=3), 0, 2)             # 31 nodes + the service
     _compare(E.test_config("g-set", node_count=127, rate=100, time_limit=6, latency=20, latency_dist="uniform", seed=3), 0, 1)
+    _compare(E.test_config("broadcast", node_count=127, rate=100, time_limit=4, latency=20, latency_dist="uniform", seed=3), 0, 1)
 
 
 def test_far_away_instance_ids_and_large_seeds(lib):
@@ -116,4 +117,4 @@ def test_api_misuse_is_reported(lib):
         with pytest.raises(E.EngineError):
             eng.raw_history(2)     # out of range
     with pytest.raises(E.EngineError, match="one wavefront"):
-        E.Engine(E.test_config("broadcast", node_count=40, rate=5, time_limit=2))
+        E.Engine(E.test_config("broadcast", bin="broadcast-ack-retry", node_count=40, rate=5, time_limit=2))   # (fire-and-forget broadcast and g-set go up to 127 nodes)

@@ -102,6 +102,31 @@ def test_wide_g_set_parity(lib, n, kw):
     _compare(cfg, 0, 3)
 
 
+@pytest.mark.parametrize("n,kw", [
+    (33, dict(latency=0)),
+    (36, dict(latency=10, topology="line")),
+    (64, dict(latency=20, latency_dist="uniform", topology="tree4")),
+    (65, dict(latency=50, latency_dist="exponential", p_loss=0.05)),
+    (100, dict(latency=100, latency_dist="exponential")),
+    (100, dict(latency=0, bin="broadcast-ff-echoback")),
+    (50, dict(latency=5, topology="total", rate=20, time_limit=4)),
+    (127, dict(latency=10, topology="tree2")),
+])
+def test_wide_broadcast_parity(lib, n, kw):
+    """Fire-and-forget broadcast on clusters wider than 32 nodes (the reference advertises "25+ nodes", README.md:40): every
+    topology of broadcast.clj:40-185, both gossip variants, randomized latency and loss — sim_kernel_wide<NET_RANDOM, BCAST>."""
+    kw = dict(dict(rate=100, time_limit=8), **kw)
+    cfg = E.test_config("broadcast", node_count=n, seed=79, **kw)
+    _compare(cfg, 0, 3)
+
+
+def test_wide_broadcast_journal_parity(lib):
+    cfg = E.test_config("broadcast", node_count=70, rate=50, time_limit=6, latency=30, latency_dist="exponential", p_loss=0.05,
+                        seed=80, journal_capacity=400000)
+    ora = _compare(cfg, 0, 2)
+    assert (ora.meta["n_events"] > 10000).all()
+
+
 def test_wide_g_set_journal_parity(lib):
     cfg = E.test_config("g-set", node_count=70, rate=50, time_limit=6, latency=30, latency_dist="exponential", p_loss=0.05,
                         seed=78, journal_capacity=200000)
