@@ -799,11 +799,11 @@ extern "C" int msim_create(const msim_config *cfg, int device, msim_ctx **out, c
   const uint32_t slots = c.concurrency > c.n_nodes ? c.concurrency : c.n_nodes;
   // wide clusters (33..127 nodes): two node/client pairs per lane, one worker per node: the g-set CRDT and fire-and-forget broadcast
   const bool wide_prog = c.node_program == MSIM_NODE_G_SET || c.node_program == MSIM_NODE_BCAST_FF || c.node_program == MSIM_NODE_BCAST_FF_ECHOBACK;
-  const bool wide = c.n_nodes > 32 && c.n_nodes <= 127 && wide_prog && c.concurrency == c.n_nodes && c.nemesis_mask == 0;
+  const bool wide = c.n_nodes > 32 && c.n_nodes <= 127 && wide_prog && c.concurrency == c.n_nodes;
   const uint32_t svc_lanes = c.node_program == MSIM_NODE_LIN_KV_PROXY ? 1 : 0;  // the service has a lane of its own after the client slots
   if (!wide && (c.n_nodes > 32 || c.n_nodes + slots + svc_lanes > 64)) {
     set_err(err, errlen, "this build maps one cluster to one wavefront: n_nodes <= 32 and n_nodes + max(concurrency, n_nodes) <= 64 "
-                         "(g-set and fire-and-forget broadcast with concurrency == n_nodes and no nemesis: up to 127 nodes)");
+                         "(g-set and fire-and-forget broadcast with concurrency == n_nodes: up to 127 nodes)");
     return MSIM_E_UNSUPPORTED;
   }
   int ndev = 0;
@@ -823,6 +823,24 @@ extern "C" int msim_create(const msim_config *cfg, int device, msim_ctx **out, c
   if (e != hipSuccess) { set_err(err, errlen, hipGetErrorString(e)); delete ctx; return MSIM_E_HIP; }
   *out = ctx;
   return MSIM_OK;
+}
+
+// sim_kernel_wide<NET_RANDOM, BCAST, NEM> for this configuration
+template <bool NR, bool BC, bool NM>
+static hipError_t launch_wide_one(const KParams &kp, uint32_t n, size_t lds, hipStream_t st) {
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sim_kernel_wide<NR, BC, NM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL((sim_kernel_wide<NR, BC, NM>), dim3(n), dim3(64), lds, st, kp);
+  return hipGetLastError();
+}
+template <bool BC>
+static hipError_t launch_wide(msim_ctx *, const KParams &kp, uint32_t n, size_t lds, hipStream_t st) {
+  const msim_config &c = kp.cfg;
+  const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0, nem = c.nemesis_mask != 0;
+  if (nem) return rnd ? launch_wide_one<true, BC, true>(kp, n, lds, st) : launch_wide_one<false, BC, true>(kp, n, lds, st);
+  return rnd ? launch_wide_one<true, BC, false>(kp, n, lds, st) : launch_wide_one<false, BC, false>(kp, n, lds, st);
 }
 
 // per-instance scratch = [protocol scratch][spill area: n_nodes x spill_capacity envelopes]
@@ -938,7 +956,7 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
        : wide ? 0   // the sets of a wide cluster live in HBM scratch
                  : (size_t)kp.N * kp.W * 4;
   off = (off + 15) & ~(size_t)15;
-  kp.off_misc = (u32)off; if (c.nemesis_mask) off += 64 * 4;  // shuffle scratch, only the partition nemesis needs it
+  kp.off_misc = (u32)off; if (c.nemesis_mask) off += (wide ? 128 : 64) * 4;  // shuffle scratch, only the partition nemesis needs it
   const size_t lds = off;
   if (lds > 160 * 1024) { ctx->err = "cluster state exceeds the 160 KiB LDS of a CU (lower inbox_capacity / max_values)"; return MSIM_E_INVALID; }
 
@@ -964,12 +982,7 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
     case MSIM_NODE_BCAST_FF:
     case MSIM_NODE_BCAST_FF_ECHOBACK:
       if (wide) {
-        const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
-        const void *fn = rnd ? reinterpret_cast<const void *>(&sim_kernel_wide<true, true>) : reinterpret_cast<const void *>(&sim_kernel_wide<false, true>);
-        if (lds > 64 * 1024) MSIM_HIP_TRY(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (rnd) hipLaunchKernelGGL((sim_kernel_wide<true, true>), dim3(n), dim3(64), lds, st, kp);
-        else hipLaunchKernelGGL((sim_kernel_wide<false, true>), dim3(n), dim3(64), lds, st, kp);
-        e = hipGetLastError();
+        e = launch_wide<true>(ctx, kp, n, lds, st);
       } else if (c.node_program == MSIM_NODE_BCAST_FF) e = launch<MSIM_NODE_BCAST_FF>(kp, n, lds, st);
       else e = launch<MSIM_NODE_BCAST_FF_ECHOBACK>(kp, n, lds, st);
       break;
@@ -977,12 +990,7 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
     case MSIM_NODE_BCAST_RPC_ALL: e = launch<MSIM_NODE_BCAST_RPC_ALL>(kp, n, lds, st); break;
     case MSIM_NODE_G_SET:
       if (wide) {
-        const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
-        const void *fn = rnd ? reinterpret_cast<const void *>(&sim_kernel_wide<true, false>) : reinterpret_cast<const void *>(&sim_kernel_wide<false, false>);
-        if (lds > 64 * 1024) MSIM_HIP_TRY(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (rnd) hipLaunchKernelGGL((sim_kernel_wide<true, false>), dim3(n), dim3(64), lds, st, kp);
-        else hipLaunchKernelGGL((sim_kernel_wide<false, false>), dim3(n), dim3(64), lds, st, kp);
-        e = hipGetLastError();
+        e = launch_wide<false>(ctx, kp, n, lds, st);
       } else e = launch<MSIM_NODE_G_SET>(kp, n, lds, st);
       break;
     case MSIM_NODE_PN_COUNTER: e = launch<MSIM_NODE_PN_COUNTER>(kp, n, lds, st); break;

@@ -120,6 +120,30 @@ def test_wide_broadcast_parity(lib, n, kw):
     _compare(cfg, 0, 3)
 
 
+@pytest.mark.parametrize("wl,n,kw", [
+    ("g-set", 33, dict(latency=0)),
+    ("g-set", 70, dict(latency=30, latency_dist="exponential", p_loss=0.05)),
+    ("g-set", 127, dict(latency=10, nemesis_interval=1)),
+    ("broadcast", 40, dict(latency=5)),
+    ("broadcast", 64, dict(latency=20, latency_dist="uniform", topology="tree3", nemesis_interval=1)),
+    ("broadcast", 100, dict(latency=50, latency_dist="exponential", p_loss=0.02)),
+    ("broadcast", 127, dict(latency=0, topology="line", bin="broadcast-ff-echoback")),
+])
+def test_wide_partition_parity(lib, wl, n, kw):
+    """The partition nemesis on clusters wider than 32 nodes: 128-bit grudges (all four specs come up over 16 seeds x several
+    partitions), drops at poll time, the heal before the final reads — sim_kernel_wide<.., NEM = true>."""
+    kw = dict(dict(rate=60, time_limit=10, nemesis=["partition"], nemesis_interval=2), **kw)
+    cfg = E.test_config(wl, node_count=n, seed=81, **kw)
+    ora = _compare(cfg, 0, 4)
+    specs = set()
+    for i in range(4):
+        rows, _ = ora.history(i)
+        nem = rows[(rows["packed"] >> 12) == A.PROCESS_NEMESIS]
+        assert len(nem) >= 4
+        specs |= {int(v) for v, pk in zip(nem["value"][::2], nem["packed"][::2]) if ((pk >> 2) & 31) == A.F_START_PARTITION}
+    assert len(specs) >= 2
+
+
 def test_wide_broadcast_journal_parity(lib):
     cfg = E.test_config("broadcast", node_count=70, rate=50, time_limit=6, latency=30, latency_dist="exponential", p_loss=0.05,
                         seed=80, journal_capacity=400000)
