@@ -798,12 +798,13 @@ extern "C" int msim_create(const msim_config *cfg, int device, msim_ctx **out, c
   if (rc != MSIM_OK) return rc;
   const uint32_t slots = c.concurrency > c.n_nodes ? c.concurrency : c.n_nodes;
   // wide clusters (33..127 nodes): two node/client pairs per lane, one worker per node: the g-set CRDT and fire-and-forget broadcast
-  const bool wide_prog = c.node_program == MSIM_NODE_G_SET || c.node_program == MSIM_NODE_BCAST_FF || c.node_program == MSIM_NODE_BCAST_FF_ECHOBACK;
+  const bool wide_prog = c.node_program == MSIM_NODE_G_SET || c.node_program == MSIM_NODE_BCAST_FF || c.node_program == MSIM_NODE_BCAST_FF_ECHOBACK ||
+                         c.node_program == MSIM_NODE_BCAST_ACK_RETRY || c.node_program == MSIM_NODE_BCAST_RPC_ALL;
   const bool wide = c.n_nodes > 32 && c.n_nodes <= 127 && wide_prog && c.concurrency == c.n_nodes;
   const uint32_t svc_lanes = c.node_program == MSIM_NODE_LIN_KV_PROXY ? 1 : 0;  // the service has a lane of its own after the client slots
   if (!wide && (c.n_nodes > 32 || c.n_nodes + slots + svc_lanes > 64)) {
     set_err(err, errlen, "this build maps one cluster to one wavefront: n_nodes <= 32 and n_nodes + max(concurrency, n_nodes) <= 64 "
-                         "(g-set and fire-and-forget broadcast with concurrency == n_nodes: up to 127 nodes)");
+                         "(g-set and the broadcast programs with concurrency == n_nodes: up to 127 nodes)");
     return MSIM_E_UNSUPPORTED;
   }
   int ndev = 0;
@@ -826,7 +827,7 @@ extern "C" int msim_create(const msim_config *cfg, int device, msim_ctx **out, c
 }
 
 // sim_kernel_wide<NET_RANDOM, BCAST, NEM> for this configuration
-template <bool NR, bool BC, bool NM>
+template <bool NR, int BC, bool NM>
 static hipError_t launch_wide_one(const KParams &kp, uint32_t n, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sim_kernel_wide<NR, BC, NM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -835,7 +836,7 @@ static hipError_t launch_wide_one(const KParams &kp, uint32_t n, size_t lds, hip
   hipLaunchKernelGGL((sim_kernel_wide<NR, BC, NM>), dim3(n), dim3(64), lds, st, kp);
   return hipGetLastError();
 }
-template <bool BC>
+template <int BC>
 static hipError_t launch_wide(msim_ctx *, const KParams &kp, uint32_t n, size_t lds, hipStream_t st) {
   const msim_config &c = kp.cfg;
   const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0, nem = c.nemesis_mask != 0;
@@ -864,7 +865,10 @@ static uint64_t proto_scratch_words(const msim_config &c) {
     if (c.n_nodes > 32) w = ((w + 3) & ~3ull) + (((uint64_t)c.n_nodes * (c.max_values / 32) + 3) & ~3ull);  // wide clusters: + the nodes' sets
   }
   const bool bcast_ff = c.node_program == MSIM_NODE_BCAST_FF || c.node_program == MSIM_NODE_BCAST_FF_ECHOBACK;
+  const bool bcast_rpc = c.node_program == MSIM_NODE_BCAST_ACK_RETRY || c.node_program == MSIM_NODE_BCAST_RPC_ALL;
   if (bcast_ff && c.n_nodes > 32) w = 4 + (((uint64_t)c.n_nodes * (c.max_values / 32) + 3) & ~3ull);  // wide clusters: the nodes' sets
+  // wide clusters, acknowledged gossip: 128-bit unacked masks per (node, value), the retry FIFO, the nodes' sets
+  if (bcast_rpc && c.n_nodes > 32) w = (uint64_t)c.n_nodes * c.max_values * 6 + (((uint64_t)c.n_nodes * (c.max_values / 32) + 3) & ~3ull);
   return (w + 3) & ~3ull;  // keep the spill area 16-byte aligned
 }
 static uint64_t scratch_words(const msim_config &c) {
@@ -982,15 +986,15 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
     case MSIM_NODE_BCAST_FF:
     case MSIM_NODE_BCAST_FF_ECHOBACK:
       if (wide) {
-        e = launch_wide<true>(ctx, kp, n, lds, st);
+        e = launch_wide<1>(ctx, kp, n, lds, st);
       } else if (c.node_program == MSIM_NODE_BCAST_FF) e = launch<MSIM_NODE_BCAST_FF>(kp, n, lds, st);
       else e = launch<MSIM_NODE_BCAST_FF_ECHOBACK>(kp, n, lds, st);
       break;
-    case MSIM_NODE_BCAST_ACK_RETRY: e = launch<MSIM_NODE_BCAST_ACK_RETRY>(kp, n, lds, st); break;
-    case MSIM_NODE_BCAST_RPC_ALL: e = launch<MSIM_NODE_BCAST_RPC_ALL>(kp, n, lds, st); break;
+    case MSIM_NODE_BCAST_ACK_RETRY: e = wide ? launch_wide<2>(ctx, kp, n, lds, st) : launch<MSIM_NODE_BCAST_ACK_RETRY>(kp, n, lds, st); break;
+    case MSIM_NODE_BCAST_RPC_ALL: e = wide ? launch_wide<3>(ctx, kp, n, lds, st) : launch<MSIM_NODE_BCAST_RPC_ALL>(kp, n, lds, st); break;
     case MSIM_NODE_G_SET:
       if (wide) {
-        e = launch_wide<false>(ctx, kp, n, lds, st);
+        e = launch_wide<0>(ctx, kp, n, lds, st);
       } else e = launch<MSIM_NODE_G_SET>(kp, n, lds, st);
       break;
     case MSIM_NODE_PN_COUNTER: e = launch<MSIM_NODE_PN_COUNTER>(kp, n, lds, st); break;

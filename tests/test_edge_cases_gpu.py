@@ -116,5 +116,5 @@ def test_api_misuse_is_reported(lib):
         eng.run(0, 2)
         with pytest.raises(E.EngineError):
             eng.raw_history(2)     # out of range
-    with pytest.raises(E.EngineError, match="one wavefront"):
-        E.Engine(E.test_config("broadcast", bin="broadcast-ack-retry", node_count=40, rate=5, time_limit=2))   # (fire-and-forget broadcast and g-set go up to 127 nodes)
+    with pytest.raises(E.EngineError, match="one wavefront|at most 32 nodes"):
+        E.Engine(E.test_config("pn-counter", node_count=40, rate=5, time_limit=2))   # (the broadcast programs and g-set go up to 127 nodes)

@@ -144,6 +144,24 @@ def test_wide_partition_parity(lib, wl, n, kw):
     assert len(specs) >= 2
 
 
+@pytest.mark.parametrize("prog,n,kw", [
+    ("broadcast-ack-retry", 33, dict(latency=0)),
+    ("broadcast-ack-retry", 50, dict(latency=20, latency_dist="exponential", p_loss=0.1)),
+    ("broadcast-ack-retry", 64, dict(latency=10, topology="tree4", nemesis=["partition"], nemesis_interval=2)),
+    ("broadcast-ack-retry", 100, dict(latency=50, latency_dist="uniform", p_loss=0.05, nemesis=["partition"], nemesis_interval=3)),
+    ("broadcast-ack-retry", 127, dict(latency=5, topology="line", rate=20)),
+    ("broadcast-rpc-all", 40, dict(latency=10, rate=20)),
+    ("broadcast-rpc-all", 100, dict(latency=20, latency_dist="exponential", p_loss=0.05, rate=10, time_limit=5)),
+    ("broadcast-rpc-all", 70, dict(latency=5, rate=10, time_limit=6, nemesis=["partition"], nemesis_interval=2)),
+])
+def test_wide_acknowledged_broadcast_parity(lib, prog, n, kw):
+    """The acknowledged variants on clusters wider than 32 nodes: 128-bit unacked sets per (node, value), the 1 s retry FIFO, node
+    msg_ids, acknowledgements crossing lanes (02-performance.md:406-441; demo/ruby/broadcast.rb:29-47) — sim_kernel_wide<.., WP 2 / 3, ..>."""
+    kw = dict(dict(rate=40, time_limit=8), **kw)
+    cfg = E.test_config("broadcast", bin=prog, node_count=n, seed=83, **kw)
+    _compare(cfg, 0, 3)
+
+
 def test_wide_broadcast_journal_parity(lib):
     cfg = E.test_config("broadcast", node_count=70, rate=50, time_limit=6, latency=30, latency_dist="exponential", p_loss=0.05,
                         seed=80, journal_capacity=400000)
