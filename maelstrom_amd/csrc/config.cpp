@@ -126,7 +126,7 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
   if (c->workload == MSIM_WL_LIN_KV && c->concurrency % (2 * c->n_nodes)) {
     set_err(err, errlen, "lin-kv: concurrency must be a multiple of 2 x node-count ([upstream] independent/concurrent-generator)"); return MSIM_E_INVALID; }
   const bool pn = c->workload == MSIM_WL_PN_COUNTER || c->workload == MSIM_WL_G_COUNTER;
-  if (pn && c->n_nodes > 32) { set_err(err, errlen, "pn-counter: at most 32 nodes in this build"); return MSIM_E_UNSUPPORTED; }
+  if (pn && c->n_nodes > 127) { set_err(err, errlen, "pn-counter: at most 127 nodes in this build"); return MSIM_E_UNSUPPORTED; }
   // pn-counter: a node's state is 2 x n_nodes counters (one G-counter for increments, one for decrements): max_values / 32 words
   if (pn) c->max_values = 64 * c->n_nodes;
   const bool no_sets = c->workload == MSIM_WL_UNIQUE_IDS || c->workload == MSIM_WL_ECHO || c->workload == MSIM_WL_LIN_KV || txn || pn;

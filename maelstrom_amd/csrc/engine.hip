@@ -799,12 +799,12 @@ extern "C" int msim_create(const msim_config *cfg, int device, msim_ctx **out, c
   const uint32_t slots = c.concurrency > c.n_nodes ? c.concurrency : c.n_nodes;
   // wide clusters (33..127 nodes): two node/client pairs per lane, one worker per node: the g-set CRDT and fire-and-forget broadcast
   const bool wide_prog = c.node_program == MSIM_NODE_G_SET || c.node_program == MSIM_NODE_BCAST_FF || c.node_program == MSIM_NODE_BCAST_FF_ECHOBACK ||
-                         c.node_program == MSIM_NODE_BCAST_ACK_RETRY || c.node_program == MSIM_NODE_BCAST_RPC_ALL;
+                         c.node_program == MSIM_NODE_BCAST_ACK_RETRY || c.node_program == MSIM_NODE_BCAST_RPC_ALL || c.node_program == MSIM_NODE_PN_COUNTER;
   const bool wide = c.n_nodes > 32 && c.n_nodes <= 127 && wide_prog && c.concurrency == c.n_nodes;
   const uint32_t svc_lanes = c.node_program == MSIM_NODE_LIN_KV_PROXY ? 1 : 0;  // the service has a lane of its own after the client slots
   if (!wide && (c.n_nodes > 32 || c.n_nodes + slots + svc_lanes > 64)) {
     set_err(err, errlen, "this build maps one cluster to one wavefront: n_nodes <= 32 and n_nodes + max(concurrency, n_nodes) <= 64 "
-                         "(g-set and the broadcast programs with concurrency == n_nodes: up to 127 nodes)");
+                         "(g-set, the counters and the broadcast programs with concurrency == n_nodes: up to 127 nodes)");
     return MSIM_E_UNSUPPORTED;
   }
   int ndev = 0;
@@ -997,7 +997,7 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
         e = launch_wide<0>(ctx, kp, n, lds, st);
       } else e = launch<MSIM_NODE_G_SET>(kp, n, lds, st);
       break;
-    case MSIM_NODE_PN_COUNTER: e = launch<MSIM_NODE_PN_COUNTER>(kp, n, lds, st); break;
+    case MSIM_NODE_PN_COUNTER: e = wide ? launch_wide<4>(ctx, kp, n, lds, st) : launch<MSIM_NODE_PN_COUNTER>(kp, n, lds, st); break;
     case MSIM_NODE_FLAKE_IDS: e = launch<MSIM_NODE_FLAKE_IDS>(kp, n, lds, st); break;
     case MSIM_NODE_RAFT: {
       const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;

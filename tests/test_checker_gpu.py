@@ -69,6 +69,20 @@ def test_wide_broadcast_checker(lib):
     assert (res["valid"] == 1).all() and (res["lost_count"] == 0).all()
 
 
+def test_wide_pn_counter_checker(lib):
+    """100 nodes' final reads against the acceptable sums (pn_counter.clj:84-123): device verdict, and the host checker on one history."""
+    cfg = E.test_config("pn-counter", node_count=100, rate=100, time_limit=10, latency=20, seed=6)
+    with E.Engine(cfg) as eng:
+        eng.run(0, 4)
+        eng.check()
+        eng.fetch()
+        res = eng.check_results()
+        assert (res["valid"] == 1).all() and (res["error_count"] == 0).all() and (res["attempt_count"] == 100).all()
+        rows, _ = eng.raw_history(2)
+        one = E.check_pn_history(rows)
+        assert one["valid?"] is True and len(one["final-reads"]) == 100
+
+
 def test_echo_checker(lib):
     cfg = E.test_config("echo", node_count=3, rate=10, time_limit=5, seed=2)
     with E.Engine(cfg) as eng:

@@ -117,4 +117,4 @@ def test_api_misuse_is_reported(lib):
         with pytest.raises(E.EngineError):
             eng.raw_history(2)     # out of range
     with pytest.raises(E.EngineError, match="one wavefront|at most 32 nodes"):
-        E.Engine(E.test_config("pn-counter", node_count=40, rate=5, time_limit=2))   # (the broadcast programs and g-set go up to 127 nodes)
+        E.Engine(E.test_config("echo", node_count=40, rate=5, time_limit=2))   # (the broadcast programs, g-set and the counters go up to 127 nodes)

@@ -162,6 +162,21 @@ def test_wide_acknowledged_broadcast_parity(lib, prog, n, kw):
     _compare(cfg, 0, 3)
 
 
+@pytest.mark.parametrize("wl,n,kw", [
+    ("pn-counter", 33, dict(latency=0)),
+    ("pn-counter", 64, dict(latency=20, latency_dist="exponential", p_loss=0.05)),
+    ("pn-counter", 100, dict(latency=50, latency_dist="uniform", nemesis=["partition"], nemesis_interval=3)),
+    ("g-counter", 40, dict(latency=10)),
+    ("g-counter", 127, dict(latency=30, latency_dist="exponential", p_loss=0.02, nemesis=["partition"], nemesis_interval=4)),
+])
+def test_wide_counter_parity(lib, wl, n, kw):
+    """The PN / G counter CRDT (demo/ruby/pn_counter.rb) on clusters wider than 32 nodes: 2 N counters per node in HBM scratch, merged by
+    maximum by the whole wavefront, reads summed by it — sim_kernel_wide<.., WP 4, ..>."""
+    kw = dict(dict(rate=60, time_limit=12), **kw)
+    cfg = E.test_config(wl, node_count=n, seed=85, **kw)
+    _compare(cfg, 0, 3)
+
+
 def test_wide_broadcast_journal_parity(lib):
     cfg = E.test_config("broadcast", node_count=70, rate=50, time_limit=6, latency=30, latency_dist="exponential", p_loss=0.05,
                         seed=80, journal_capacity=400000)
