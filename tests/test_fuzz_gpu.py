@@ -112,3 +112,38 @@ def test_random_kv_options_engine_equals_oracle(lib, case):
     except E.EngineError as e:
         pytest.skip(str(e))
     _compare(cfg, rng.randrange(1 << 20), N_INST)
+
+
+def _random_wide_case(rng):
+    wl = rng.choice(["broadcast"] * 5 + ["g-set", "g-set", "pn-counter", "g-counter"])
+    n = rng.choice([33, 34, 48, 63, 64, 65, 96, 97, 100, 127])
+    kw = dict(node_count=n, rate=rng.choice([5, 20, 60, 200]), time_limit=rng.choice([2, 3, 5]), seed=rng.randrange(1 << 40))
+    lat = rng.choice([0, 0, 1, 5, 20, 80])
+    kw.update(latency=lat, latency_dist=rng.choice(["constant", "uniform", "exponential"]) if lat else "constant")
+    if rng.random() < 0.3:
+        kw["p_loss"] = rng.choice([0.02, 0.2])
+    if rng.random() < 0.35:
+        kw.update(nemesis=["partition"], nemesis_interval=rng.choice([1, 2]))
+    if wl == "broadcast":
+        kw["bin"] = rng.choice(["broadcast-ff", "broadcast-ff", "broadcast-ff-echoback", "broadcast-ack-retry", "broadcast-ack-retry", "broadcast-rpc-all"])
+        kw["topology"] = rng.choice(["grid", "grid", "line", "total", "tree2", "tree3", "tree4"])
+        if kw["topology"] == "total" or kw["bin"] == "broadcast-rpc-all":
+            kw["rate"] = min(kw["rate"], 20)
+    else:
+        kw["time_limit"] = 6
+    if rng.random() < 0.2:
+        kw["journal_capacity"] = 4000000
+    return wl, kw
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("MSIM_FUZZ_CASES", "24"))))
+def test_random_wide_options_engine_equals_oracle(lib, case):
+    """The same sweep over clusters of 33..127 nodes (sim_kernel_wide<>): g-set, the counters and the four broadcast programs."""
+    rng = random.Random(0x51DE + case)
+    wl, kw = _random_wide_case(rng)
+    try:
+        cfg = E.test_config(wl, **kw)
+        E.Engine(cfg).close()
+    except E.EngineError as e:
+        pytest.skip(str(e))
+    _compare(cfg, rng.randrange(1 << 20), 2)

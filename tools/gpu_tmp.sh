@@ -1,4 +1,4 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/wide; mkdir -p $O
-timeout 300 python -m pytest tests/test_parity_gpu.py tests/test_checker_gpu.py tests/test_edge_cases_gpu.py -m gpu -q -k "wide or widest or misuse" --timeout 120 > $O/pytest.log 2>&1; grep -E "passed|failed|Error|assert|differ|^FAILED" $O/pytest.log | head -30
+MSIM_FUZZ_CASES=400 timeout 420 python -m pytest tests/test_fuzz_gpu.py -m gpu -q -k "wide" --timeout 60 -x > $O/fuzz.log 2>&1; grep -E "passed|failed|Error|assert|differ|^FAILED" $O/fuzz.log | head -20
