@@ -65,9 +65,13 @@ enum {
   MSIM_NODE_FLAKE_IDS = 9,      /* demo/clojure/flake_ids.clj:10-33: id = [seconds, counter within that second, node id] */
   MSIM_NODE_PN_COUNTER = 8,     /* demo/ruby/pn_counter.rb:8-121 == demo/js/crdt_pn_counter.js: increments and decrements in two
                                    per-node G-counters, merged by element-wise max, replicated to all others every 5 s      */
-  MSIM_NODE_TXN_RW_HAT = 11     /* demo/clojure/txn_rw_register_hat.clj:1-190: highly available transactions — every node applies a
+  MSIM_NODE_TXN_RW_HAT = 11,    /* demo/clojure/txn_rw_register_hat.clj:1-190: highly available transactions — every node applies a
                                    txn locally at a Lamport timestamp (last write wins per key), then replicates it to the
                                    others every 100 ms until they acknowledge (the demo of core.clj:115-121)                */
+  MSIM_NODE_TXN_MULTI_KEY = 12  /* demo/js/multi_key_txn.js:1-246 == demo/clojure/multi_key_txn.clj: thunks in lww-kv, the root map in
+                                   lin-kv, retry when the root cas is lost.  Restated in the CPU oracle (oracle/mk_nodes.inc, pinned by
+                                   the real program on the process bridge); NOT a built-in of the GPU engine yet: msim_create
+                                   answers MSIM_E_UNSUPPORTED for it                                                         */
 };
 
 enum { MSIM_LAT_CONSTANT = 0, MSIM_LAT_UNIFORM = 1, MSIM_LAT_EXPONENTIAL = 2 };  /* net.clj:65-77 */

@@ -95,7 +95,7 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
     case MSIM_WL_BROADCAST: ok = c->node_program >= MSIM_NODE_BCAST_FF && c->node_program <= MSIM_NODE_BCAST_RPC_ALL; break;
     case MSIM_WL_G_SET: ok = c->node_program == MSIM_NODE_G_SET; break;
     case MSIM_WL_LIN_KV: ok = c->node_program == MSIM_NODE_RAFT || c->node_program == MSIM_NODE_LIN_KV_PROXY; break;
-    case MSIM_WL_TXN_LIST_APPEND: ok = c->node_program == MSIM_NODE_TXN_SINGLE_KEY; break;
+    case MSIM_WL_TXN_LIST_APPEND: ok = c->node_program == MSIM_NODE_TXN_SINGLE_KEY || c->node_program == MSIM_NODE_TXN_MULTI_KEY; break;
     case MSIM_WL_PN_COUNTER: case MSIM_WL_G_COUNTER: ok = c->node_program == MSIM_NODE_PN_COUNTER; break;
     case MSIM_WL_UNIQUE_IDS: ok = c->node_program == MSIM_NODE_FLAKE_IDS; break;
     case MSIM_WL_TXN_RW_REGISTER: ok = c->node_program == MSIM_NODE_TXN_RW_HAT; break;

@@ -796,6 +796,10 @@ extern "C" int msim_create(const msim_config *cfg, int device, msim_ctx **out, c
   msim_config c = *cfg;
   int rc = msim_config_finalize(&c, err, errlen);
   if (rc != MSIM_OK) return rc;
+  if (c.node_program == MSIM_NODE_TXN_MULTI_KEY) {
+    set_err(err, errlen, "multi_key_txn: restated in the CPU oracle and runnable on the process bridge; the GPU engine has no kernel for it in this build");
+    return MSIM_E_UNSUPPORTED;
+  }
   const uint32_t slots = c.concurrency > c.n_nodes ? c.concurrency : c.n_nodes;
   // wide clusters (33..127 nodes): two node/client pairs per lane, one worker per node: the g-set CRDT and fire-and-forget broadcast
   const bool wide_prog = c.node_program == MSIM_NODE_G_SET || c.node_program == MSIM_NODE_BCAST_FF || c.node_program == MSIM_NODE_BCAST_FF_ECHOBACK ||

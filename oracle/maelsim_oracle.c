@@ -93,6 +93,7 @@ typedef struct {
   struct txn_s *txn;  /* txn-list-append state (txn_nodes.inc) */
   struct svc_s *svc;  /* proxy node + key-value services (svc_nodes.inc) */
   struct hat_s *hat;  /* txn-rw-register highly-available-transactions node (hat_nodes.inc) */
+  struct mk_s *mk;    /* txn-list-append over thunks in lww-kv and a root map in lin-kv (mk_nodes.inc) */
   u32 *rtrace; u32 n_rtrace, cap_rtrace; /* test hook: what every Raft node did in every round (oracle_raft_schedule) */
   u64 key;
   u32 adj[MAXN][MW];
@@ -377,12 +378,14 @@ static void node_timer(sim_t *s, u32 node) {
 
 #include "raft_nodes.inc"
 #include "txn_nodes.inc"
+#include "mk_nodes.inc"
 #include "svc_nodes.inc"
 #include "hat_nodes.inc"
 
 static void node_handle(sim_t *s, u32 node, const qent *q) {
   if (s->cfg.node_program == MSIM_NODE_RAFT) { raft_handle(s, node, q); return; }
   if (s->cfg.node_program == MSIM_NODE_TXN_SINGLE_KEY) { txn_node_handle(s, node, q); return; }
+  if (s->cfg.node_program == MSIM_NODE_TXN_MULTI_KEY) { mk_node_handle(s, node, q); return; }
   if (s->cfg.node_program == MSIM_NODE_LIN_KV_PROXY) { px_node_handle(s, node, q); return; }
   if (s->cfg.node_program == MSIM_NODE_TXN_RW_HAT) { hat_node_handle(s, node, q); return; }
   switch (q->type) {
@@ -735,7 +738,7 @@ static void run_instance(sim_t *s) {
         qent q = s->committed[e]; s->has_committed[e] = 0;
         s->st.all_recv++; s->st.servers_recv++;
         jlog(s, 1, q.id, q.type, q.a, q.b, q.src, e);
-        if (s->svc) px_svc_handle(s, &q); else svc_handle(s, &q);
+        if (s->mk) mk_svc_handle(s, e, &q); else if (s->svc) px_svc_handle(s, &q); else svc_handle(s, &q);
       }
     commit_sends(s);
     for (u32 e = 0; e < E; e++) poll_endpoint(s, e);
@@ -773,7 +776,7 @@ static sim_t *sim_new(const msim_config *cfg, uint64_t instance, msim_op *rows, 
   sim_t *s = (sim_t *)calloc(1, sizeof(sim_t));
   s->cfg = *cfg;
   s->N = cfg->n_nodes; s->C = cfg->concurrency; s->CS = s->C > s->N ? s->C : s->N;
-  s->S = cfg->node_program == MSIM_NODE_TXN_SINGLE_KEY || cfg->node_program == MSIM_NODE_LIN_KV_PROXY ? 1 : 0;
+  s->S = cfg->node_program == MSIM_NODE_TXN_SINGLE_KEY || cfg->node_program == MSIM_NODE_LIN_KV_PROXY ? 1 : cfg->node_program == MSIM_NODE_TXN_MULTI_KEY ? 2 : 0; /* lin-kv (+ lww-kv) */
   s->E = s->N + s->CS + s->S;
   if (s->E > 255) { free(s); return NULL; }
   s->W = (cfg->max_values + 31) / 32;
@@ -807,7 +810,7 @@ static sim_t *sim_new(const msim_config *cfg, uint64_t instance, msim_op *rows, 
     v->client_idx = (u32 *)calloc(s->E, 4);
     memset(v->kv, 0xFF, 256); memset(v->ring, 0xFF, sizeof v->ring); memset(v->rep, 0xFF, sizeof v->rep);
     s->svc = v;
-  } else if (s->S || cfg->node_program == MSIM_NODE_TXN_RW_HAT) {
+  } else if (s->S || cfg->node_program == MSIM_NODE_TXN_RW_HAT) { /* (the multi-key node too: generator state + the elements' versions) */
     txn_t *t = (txn_t *)calloc(1, sizeof(txn_t)); /* the rw-register workload only uses the generator state */
     t->slots = (tslot *)calloc((size_t)s->N * TXN_SLOTS, sizeof(tslot));
     t->root = V_NIL;
@@ -818,6 +821,7 @@ static sim_t *sim_new(const msim_config *cfg, uint64_t instance, msim_op *rows, 
     s->txn = t;
   }
   if (cfg->node_program == MSIM_NODE_TXN_RW_HAT) s->hat = hat_new(s);
+  if (cfg->node_program == MSIM_NODE_TXN_MULTI_KEY) s->mk = mk_new(s);
   for (u32 i = 0; i < s->CS; i++) s->cl[i].process = i;
   s->rows = rows; s->payload = payload;
   s->phase = PH_INIT;
@@ -836,6 +840,7 @@ static void sim_free(sim_t *s) {
   if (s->raft) { for (u32 i = 0; i < s->N; i++) free(s->raft[i].log); free(s->raft); }
   if (s->svc) { free(s->svc->cb); free(s->svc->client_idx); free(s->svc); }
   if (s->hat) hat_free(s->hat);
+  mk_free(s->mk, s->N);
   if (s->txn) { free(s->txn->slots); free(s->txn->kv); free(s->txn->kv_n); free(s->txn); }
   free(s->snap); free(s->inbox); free(s->committed); free(s->has_committed); free(s->deliver_at); free(s->seen);
   free(s->unacked); free(s->node_msg_id); free(s->nbr_known); free(s->tasks); free(s->key_reg); free(s->timer_next); free(s->tick); free(s->flake);

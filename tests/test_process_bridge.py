@@ -31,8 +31,8 @@ def _norm(ops):
     return out
 
 
-def _against_oracle(workload, argv, **kw):
-    cfg = E.test_config(workload, **kw)
+def _against_oracle(workload, argv, oracle_bin=None, **kw):
+    cfg = E.test_config(workload, bin=oracle_bin, **kw)
     ora = O.run(cfg, 0, 1)
     want = E.decode_history(*ora.history(0), cfg.n_nodes, cfg.workload)
     b = B.Bridge(workload, argv, **kw)
@@ -139,12 +139,28 @@ def test_reference_single_key_txn_js_reproduces_the_oracle_history(kw):
 
 
 @needs_js
+@pytest.mark.parametrize("kw", [
+    dict(node_count=2, rate=20, time_limit=2, latency=2, key_count=3, seed=5),
+    dict(node_count=3, rate=50, time_limit=3, latency=5, seed=6),
+    dict(node_count=5, rate=60, time_limit=3, latency=10, latency_dist="exponential", nemesis=["partition"], nemesis_interval=1, seed=7),
+    dict(node_count=3, rate=150, time_limit=2, latency=3, latency_dist="uniform", key_count=2, max_txn_length=8, max_writes_per_key=32, seed=8),
+    dict(node_count=7, rate=100, time_limit=2, latency=0, seed=9),
+])
+def test_reference_multi_key_txn_js_reproduces_the_oracle_history(kw):
+    """The canonical txn-list-append node (row a18): the REFERENCE's own demo/js/multi_key_txn.js as real node.js processes — thunks in
+    the bridge's lww-kv, the root map in its lin-kv, retries after a lost root cas, thunk reads repeated while the other lww-kv replica
+    answers — yields the history, the round count and the net stats of the oracle's restatement (oracle/mk_nodes.inc) over whole runs:
+    contended keys, long transactions, partitions between the nodes, random latency.  Loss-free on purpose: node.js's rpc() gives up
+    after one second of wall-clock time, which no virtual-time run can share."""
+    _against_oracle("txn-list-append", [_NODE, os.path.join(REF_JS, "multi_key_txn.js")], oracle_bin="multi-key-txn", **kw)
+
+
+@needs_js
 def test_reference_multi_key_txn_js_runs_strict_serializably_on_the_bridge():
     """demo/js/multi_key_txn.js (thunks in lww-kv, the root map in lin-kv, retry on a lost root cas) is not a built-in node of the
     GPU engine; on the bridge it runs as it is, against the bridge's lin-kv and eventually consistent lww-kv services, and the
     list-append analysis finds its histories clean — also under partitions; runs are reproducible from the seed."""
-    for kw in (dict(node_count=3, rate=20, time_limit=5, latency=2, seed=5),
-               dict(node_count=5, rate=40, time_limit=6, latency=5, nemesis=["partition"], nemesis_interval=2, seed=8)):
+    for kw in (dict(node_count=5, rate=40, time_limit=4, latency=5, nemesis=["partition"], nemesis_interval=2, seed=8),):
         hist = []
         for _ in range(2):
             b = B.Bridge("txn-list-append", [_NODE, os.path.join(REF_JS, "multi_key_txn.js")], **kw)

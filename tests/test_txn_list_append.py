@@ -53,6 +53,30 @@ def test_messages_per_transaction_and_verdict(kw):
         assert res["txn-count"] == len(inv)
 
 
+@pytest.mark.parametrize("kw", [dict(latency=2), dict(latency=20, latency_dist="exponential", rate=100),
+                                dict(latency=5, nemesis=["partition"], nemesis_interval=2), dict(node_count=3, rate=200, latency=1, key_count=2),
+                                dict(latency=10, p_loss=0.02)])
+def test_multi_key_node_histories_are_strict_serializable(kw):
+    """oracle/mk_nodes.inc (demo/js/multi_key_txn.js): whatever the schedule, a transaction only completes through a root cas against
+    the exact map it read, so the list-append analysis finds nothing; several messages per transaction, retries included; a transaction
+    that keeps losing the root under contention, or whose message vanished, outlives the client's timeout (:info)."""
+    cfg = _cfg(bin="multi-key-txn", **kw)
+    r = O.run(cfg, 0, 4)
+    for i in range(4):
+        assert r.meta["flags"][i] == 0
+        rows, pay = r.history(i)
+        ops = [o for o in E.decode_history(rows, pay, cfg.n_nodes, A.WL_TXN_LIST_APPEND) if o["process"] != ":nemesis"]
+        inv = [o for o in ops if o["type"] == ":invoke"]
+        done = [o for o in ops if o["type"] != ":invoke"]
+        assert len(inv) == len(done) > 20
+        assert not any(o["type"] == ":fail" for o in done)             # a lost root cas is retried, never reported
+        assert sum(o["type"] == ":ok" for o in done) > 20              # (:info = the client gave up on a transaction still retrying, or lost)
+        st = r.stats[i]
+        assert int(st["servers_send"]) >= 2 * len(inv)                 # at least the root cas and its reply
+        res = E.check_txn_history(rows, pay)
+        assert res["valid?"] is True and res["anomalies"] == [], res
+
+
 def test_conflicts_need_concurrency():
     """With one node there is one worker: no cas can lose the race."""
     cfg = _cfg(node_count=1, rate=50, latency=5)
