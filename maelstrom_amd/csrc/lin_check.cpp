@@ -28,7 +28,7 @@ struct Cfg { uint64_t lin; uint32_t val; };
 // The configurations seen while one operation returns, grouped by (register value, linearized RETURNING ops); per group the
 // minimal sets of linearized never-returning ops.  Open addressing with a generation stamp and one node pool: clearing it is O(1)
 // and nothing is allocated per event (the std::unordered_map<Cfg, std::vector<..>> it replaces spent most of the search in
-// malloc / free: 15 -> 4 ms per 12 000-row history with partitions).
+// malloc / free: 15 -> 9 ms per 12 000-row history with partitions).
 struct Seen {
   struct Slot { uint64_t base; uint32_t val, gen; int head; };
   struct Node { uint64_t ib; int next; bool dead; };
