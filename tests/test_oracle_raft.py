@@ -23,7 +23,7 @@ def _histories(cfg, n):
     dict(latency=10),
     dict(latency=20, latency_dist="exponential"),
     dict(nemesis=["partition"], nemesis_interval=5, latency=5),
-    dict(nemesis=["partition"], nemesis_interval=10, time_limit=60, latency=10, latency_dist="uniform"),
+    dict(nemesis=["partition"], nemesis_interval=10, time_limit=40, latency=10, latency_dist="uniform"),
     dict(node_count=3, concurrency=12, nemesis=["partition"], nemesis_interval=4, time_limit=30),   # 04-committing.md:418 shape
 ])
 def test_raft_histories_are_linearizable(lib, kw):

@@ -160,7 +160,7 @@ def test_reference_multi_key_txn_js_runs_strict_serializably_on_the_bridge():
     """demo/js/multi_key_txn.js (thunks in lww-kv, the root map in lin-kv, retry on a lost root cas) is not a built-in node of the
     GPU engine; on the bridge it runs as it is, against the bridge's lin-kv and eventually consistent lww-kv services, and the
     list-append analysis finds its histories clean — also under partitions; runs are reproducible from the seed."""
-    for kw in (dict(node_count=5, rate=40, time_limit=4, latency=5, nemesis=["partition"], nemesis_interval=2, seed=8),):
+    for kw in (dict(node_count=5, rate=40, time_limit=3, latency=5, nemesis=["partition"], nemesis_interval=1, seed=8),):
         hist = []
         for _ in range(2):
             b = B.Bridge("txn-list-append", [_NODE, os.path.join(REF_JS, "multi_key_txn.js")], **kw)
