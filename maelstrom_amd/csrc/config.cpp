@@ -163,6 +163,7 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
     if (c->node_program == MSIM_NODE_G_SET || c->node_program == MSIM_NODE_PN_COUNTER) depth = 16 + 2 * deg;  // one replicate_full per peer per 5 s tick (g_set.rb:33-38)
     if (c->node_program == MSIM_NODE_RAFT) depth = 24 + 1024;   // heartbeats / re-sent append_entries pile up behind a sleeping recv!
     if (txn) depth = 16 + 4 * c->n_nodes;                       // the service sees <= 2 requests per transaction in flight
+    if (c->node_program == MSIM_NODE_TXN_MULTI_KEY) depth = 16 + 16 * c->n_nodes;   // lww-kv: up to max-txn-length thunk reads / writes per transaction
     if (hat) depth = 16 + 4 * c->n_nodes + (uint32_t)(20.0 * c->n_nodes * lat_s);  // a replicate + n-1 acks per peer per 100 ms tick
     if (c->node_program == MSIM_NODE_LIN_KV_PROXY) depth = 16 + 2 * c->concurrency;   // the service sees every worker's request at once
     // wide clusters: 100+ queues would take a fifth of the LDS budget of a cluster; their queues live in the HBM spill area

@@ -741,6 +741,7 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
 #include "sim_kernel_raft.inc"
 #include "sim_kernel_wide.inc"
 #include "sim_kernel_txn.inc"
+#include "sim_kernel_mk.inc"
 #include "sim_kernel_hat.inc"
 #include "sim_kernel_svc.inc"
 
@@ -796,8 +797,8 @@ extern "C" int msim_create(const msim_config *cfg, int device, msim_ctx **out, c
   msim_config c = *cfg;
   int rc = msim_config_finalize(&c, err, errlen);
   if (rc != MSIM_OK) return rc;
-  if (c.node_program == MSIM_NODE_TXN_MULTI_KEY) {
-    set_err(err, errlen, "multi_key_txn: restated in the CPU oracle and runnable on the process bridge; the GPU engine has no kernel for it in this build");
+  if (c.node_program == MSIM_NODE_TXN_MULTI_KEY && (c.concurrency != c.n_nodes || c.n_nodes > 30)) {
+    set_err(err, errlen, "multi_key_txn: one worker per node and at most 30 nodes (two service lanes) in this build");
     return MSIM_E_UNSUPPORTED;
   }
   const uint32_t slots = c.concurrency > c.n_nodes ? c.concurrency : c.n_nodes;
@@ -848,6 +849,15 @@ static hipError_t launch_wide(msim_ctx *, const KParams &kp, uint32_t n, size_t 
   return rnd ? launch_wide_one<true, BC, false>(kp, n, lds, st) : launch_wide_one<false, BC, false>(kp, n, lds, st);
 }
 
+// multi-key transactional node: thunk ids a node may hand out (every attempt of a transaction writes its keys again: x4 for the
+// retries) and the slots of its thunk cache (what it wrote + what it read: twice that, load factor 1/2)
+static uint32_t mk_tcap(const msim_config &c) {
+  const double ops = (double)c.rate_mhz * (double)c.time_limit_ms / 1e6 * 1.125 + 64.0;
+  uint32_t t = 64; while (t < 4.0 * ops * c.max_txn_length / c.n_nodes + 64.0) t <<= 1;
+  return t;
+}
+static uint32_t mk_ccap(const msim_config &c) { return 4 * mk_tcap(c); }
+
 // per-instance scratch = [protocol scratch][spill area: n_nodes x spill_capacity envelopes]
 static uint32_t raft_log_cap(const msim_config &c) {  // every client op is appended at most once, by the leader that takes it
   const double expected = (double)c.rate_mhz * (double)c.time_limit_ms / 1e6;
@@ -858,6 +868,8 @@ static uint64_t proto_scratch_words(const msim_config &c) {
   if (c.node_program == MSIM_NODE_RAFT) w = (uint64_t)c.n_nodes * raft_log_cap(c) * 2 + (uint64_t)c.n_nodes * R_ARENA_WORDS;
   if (c.node_program == MSIM_NODE_BCAST_ACK_RETRY) w = (uint64_t)c.n_nodes * c.max_values * 3;
   if (c.node_program == MSIM_NODE_TXN_SINGLE_KEY) w = (uint64_t)c.max_values * (c.max_writes_per_key + 1);  // elements + counts per key
+  if (c.node_program == MSIM_NODE_TXN_MULTI_KEY)   // elements, counts, map position, entry version, thunk counts, thunk versions + ids, the nodes' caches, the replica bytes
+    w = (uint64_t)c.max_values * (c.max_writes_per_key + 4 + 2 * (c.max_writes_per_key + 1)) + (uint64_t)c.n_nodes * mk_ccap(c) + (uint64_t)c.n_nodes * mk_tcap(c) / 4;
   if (c.node_program == MSIM_NODE_TXN_RW_HAT) {  // registers per node + txn table + pending masks (bytes) + replicate lists
     const uint64_t G = c.max_rows / 2;
     w = (uint64_t)c.n_nodes * c.max_values + 2 * G + ((uint64_t)c.n_nodes * G + 3) / 4 + c.replication_words;
@@ -876,7 +888,7 @@ static uint64_t proto_scratch_words(const msim_config &c) {
   return (w + 3) & ~3ull;  // keep the spill area 16-byte aligned
 }
 static uint64_t scratch_words(const msim_config &c) {
-  const uint64_t queues = c.n_nodes + (c.node_program == MSIM_NODE_TXN_SINGLE_KEY || c.node_program == MSIM_NODE_LIN_KV_PROXY ? 1 : 0);  // + the service
+  const uint64_t queues = c.n_nodes + (c.node_program == MSIM_NODE_TXN_SINGLE_KEY || c.node_program == MSIM_NODE_LIN_KV_PROXY ? 1 : c.node_program == MSIM_NODE_TXN_MULTI_KEY ? 2 : 0);  // + the services
   uint64_t w = proto_scratch_words(c) + queues * c.spill_capacity * 4;
   if (msim_raft4_eligible(c)) w += msim_raft4_extra_scratch_words(c);   // raft4.hip keeps fewer envelopes in LDS
   if (msim_txn8_eligible(c)) w += msim_txn8_extra_scratch_words(c);     // txn8.hip likewise
@@ -952,12 +964,14 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   const bool wide = c.n_nodes > 32;
   size_t off = (wide ? WIDE_STAGE_ROWS : STAGE_ROWS) * 16;
   const bool is_txn = c.node_program == MSIM_NODE_TXN_SINGLE_KEY, is_px = c.node_program == MSIM_NODE_LIN_KV_PROXY;
-  const bool is_hat = c.node_program == MSIM_NODE_TXN_RW_HAT;
+  const bool is_hat = c.node_program == MSIM_NODE_TXN_RW_HAT, is_mk = c.node_program == MSIM_NODE_TXN_MULTI_KEY;
+  kp.mk_tcap = is_mk ? mk_tcap(c) : 0; kp.mk_ccap = is_mk ? mk_ccap(c) : 0;
   kp.off_inbox = (u32)off;
-  off += is_hat ? ((size_t)kp.N * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16 : is_px ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.CS * R_CLIENT_CAP) * 16 : is_txn ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16
+  off += is_mk ? ((size_t)(kp.N + 2) * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16 : is_hat ? ((size_t)kp.N * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16 : is_px ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.CS * R_CLIENT_CAP) * 16 : is_txn ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16
                 : ((size_t)kp.N * kp.cap_node + (size_t)kp.CS * (is_raft ? R_CLIENT_CAP : CLIENT_INBOX_CAP)) * 16;
   kp.off_seen = (u32)off;
-  off += is_hat ? 36 * 4   // the generator's key pool
+  off += is_mk ? ((size_t)kp.N * MK_SLOTS * MKW + (size_t)kp.N * MK_KEYS * 3 + 36) * 4   // transactions in flight, a round's messages per node, the generator's key pool
+       : is_hat ? 36 * 4   // the generator's key pool
        : is_px ? (size_t)kp.N * PX_SLOTS * 8 + 34 * 256 + 64 * 4   // callbacks per node + service states + seq-kv indices
        : is_txn ? (size_t)kp.N * TXN_SLOTS * 16 + 36 * 4   // transactions in flight per node + the generator's key pool
        : is_raft ? (size_t)kp.N * 256 + (size_t)kp.N * kp.N * 3 * 4   // KV state + next/match index + append_entries refs
@@ -1019,6 +1033,12 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
       const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
       if (c.nemesis_mask) { if (rnd) hipLaunchKernelGGL((txn_kernel<true, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((txn_kernel<true, false>), dim3(n), dim3(64), lds, st, kp); }
       else { if (rnd) hipLaunchKernelGGL((txn_kernel<false, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((txn_kernel<false, false>), dim3(n), dim3(64), lds, st, kp); }
+      e = hipGetLastError();
+    } break;
+    case MSIM_NODE_TXN_MULTI_KEY: {
+      const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
+      if (c.nemesis_mask) { if (rnd) hipLaunchKernelGGL((mk_kernel<true, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((mk_kernel<true, false>), dim3(n), dim3(64), lds, st, kp); }
+      else { if (rnd) hipLaunchKernelGGL((mk_kernel<false, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((mk_kernel<false, false>), dim3(n), dim3(64), lds, st, kp); }
       e = hipGetLastError();
     } break;
     case MSIM_NODE_TXN_RW_HAT: {

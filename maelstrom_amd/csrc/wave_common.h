@@ -40,6 +40,7 @@ struct KParams {
   u32 gen_period2_us, nem_period2_us;
   u32 raft_log_cap;   // raft: entries per node log
   u32 dev_flags;      // developer switches (env MSIM_DEV_FLAGS): 1 = cascade rounds inline, 2 = no lone-operation path
+  u32 mk_tcap, mk_ccap;   // multi-key transactional node: thunks a node may create; slots of a node's thunk cache (power of two)
 };
 
 // ---- RNG (counter-based) ---------------------------------------------------------

@@ -69,14 +69,6 @@ def test_engine_fails_loudly_without_a_gpu(lib):
         E.Engine(E.test_config("echo", node_count=3))
 
 
-def test_multi_key_txn_is_refused_by_the_engine(lib):
-    """MSIM_NODE_TXN_MULTI_KEY exists for the oracle and the process bridge; the GPU engine has no kernel for it and says so (no
-    quiet fallback to the single-root node)."""
-    cfg = E.test_config("txn-list-append", bin="multi-key-txn", node_count=3)
-    with pytest.raises(E.EngineError, match="multi_key_txn"):
-        E.Engine(cfg)
-
-
 def test_product_never_touches_the_oracle():
     """The oracle is test infrastructure: nothing under maelstrom_amd/ or include/ may import, include, load or link it."""
     bad = re.compile(r"^\s*(?:import|from)\s+\S*oracle|#\s*include\s+\S*oracle|oracle_lib|libmaelsim_oracle|oracle_run|CDLL\([^)]*oracle", re.M)

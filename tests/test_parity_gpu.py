@@ -201,6 +201,21 @@ def test_general_layout_parity_when_concurrency_differs_from_nodes(lib, conc):
     _compare(cfg, 0, 8)
 
 
+@pytest.mark.parametrize("kw", [
+    dict(node_count=2, rate=20, time_limit=2, latency=2, key_count=3),
+    dict(node_count=3, rate=50, time_limit=4, latency=5),
+    dict(node_count=5, rate=100, time_limit=8, latency=10, latency_dist="exponential", nemesis=["partition"], nemesis_interval=2),
+    dict(node_count=3, rate=200, time_limit=3, latency=3, latency_dist="uniform", key_count=2, max_txn_length=8, max_writes_per_key=32),
+    dict(node_count=7, rate=100, time_limit=4, latency=0),
+    dict(node_count=5, rate=100, time_limit=6, latency=5, p_loss=0.05, journal_capacity=400000),
+])
+def test_multi_key_txn_parity(lib, kw):
+    """The canonical txn-list-append node (thunks in lww-kv, root map in lin-kv): mk_kernel<> against oracle/mk_nodes.inc, which the
+    reference's own multi_key_txn.js pins on the process bridge (tests/test_process_bridge.py)."""
+    cfg = E.test_config("txn-list-append", bin="multi-key-txn", seed=91, **kw)
+    _compare(cfg, 0, 4)
+
+
 def test_deep_queues_spill_to_hbm(lib):
     """Exponential latency => long head-of-line sleeps => queues far deeper than the LDS part: the HBM spill area
     behind each node's queue keeps the result bit-identical (and unflagged)."""
