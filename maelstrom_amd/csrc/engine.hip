@@ -1037,9 +1037,9 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
     } break;
     case MSIM_NODE_TXN_MULTI_KEY: {
       const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
-      if (c.nemesis_mask) { if (rnd) hipLaunchKernelGGL((mk_kernel<true, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((mk_kernel<true, false>), dim3(n), dim3(64), lds, st, kp); }
-      else { if (rnd) hipLaunchKernelGGL((mk_kernel<false, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((mk_kernel<false, false>), dim3(n), dim3(64), lds, st, kp); }
-      e = hipGetLastError();
+      void (*fn)(const KParams) = c.nemesis_mask ? (rnd ? mk_kernel<true, true> : mk_kernel<true, false>) : (rnd ? mk_kernel<false, true> : mk_kernel<false, false>);
+      e = lds > 64 * 1024 ? hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) : hipSuccess;   // (above ~17 nodes)
+      if (e == hipSuccess) { hipLaunchKernelGGL(fn, dim3(n), dim3(64), lds, st, kp); e = hipGetLastError(); }
     } break;
     case MSIM_NODE_TXN_RW_HAT: {
       const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;

@@ -81,7 +81,27 @@ def _random_kv_case(rng):
         if rng.random() < 0.5:
             kw.update(nemesis=["partition"], nemesis_interval=rng.choice([1, 3]))
         return "txn-rw-register", kw
+    if kind == "mk":
+        kw["bin"] = "multi-key-txn"
+        kw["node_count"] = rng.choice([1, 2, 3, 5, 6, 7, 12])
     return "txn-list-append", kw
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("MSIM_FUZZ_CASES", "24"))))
+def test_random_multi_key_txn_options_engine_equals_oracle(lib, case):
+    """The same sweep for the canonical txn-list-append node (multi_key_txn: thunks in lww-kv, the root map in lin-kv)."""
+    rng = random.Random(0xD47A + case)
+    os.environ["MSIM_FUZZ_KIND"] = "mk"
+    try:
+        wl, kw = _random_kv_case(rng)
+    finally:
+        del os.environ["MSIM_FUZZ_KIND"]
+    try:
+        cfg = E.test_config(wl, **kw)
+        E.Engine(cfg).close()
+    except E.EngineError as e:
+        pytest.skip(str(e))
+    _compare(cfg, rng.randrange(1 << 20), N_INST)
 
 
 @pytest.mark.parametrize("case", range(int(os.environ.get("MSIM_FUZZ_CASES", "24"))))

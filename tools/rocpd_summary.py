@@ -38,7 +38,8 @@ def summarise(path):
         print(f"-- no PMC data ({e.__class__.__name__}: {e})")
 
 
-OURS = ("sim_kernel", "check_kernel", "raft_kernel", "raft4_kernel", "txn_kernel", "txn8_kernel", "hat_kernel", "svc_kernel", "compact_", "availability_kernel")
+OURS = ("sim_kernel", "check_kernel", "raft_kernel", "raft4_kernel", "txn_kernel", "txn8_kernel", "mk_kernel", "mk8_kernel", "hat_kernel", "svc_kernel", "compact_", "availability_kernel",
+        "txn_check_kernel", "rw_check_kernel", "lin_check_kernel", "unique_check_kernel", "pn_check_kernel")
 
 
 def counters_json(paths, out):
