@@ -314,6 +314,11 @@ int msim_check_txn_rows(const msim_op *rows, uint32_t n_rows, const uint32_t *pa
  * and internal; serializable + G2; strict-serializable + the -realtime cycles.  Duplicate elements, incompatible orders,
  * dirty updates and cyclic versions make a history invalid under every model. */
 uint32_t msim_proscribed_anomalies(uint32_t consistency_model);
+/* The subset of `anomalies` (an error_count of msim_check_txn_rows / msim_check_rw_rows) that makes a history invalid under
+ * `consistency_model` — what `--consistency-models` (core.clj:160-165) decides in the reference: a cycle that only closes through a
+ * realtime edge (MSIM_ANOMALY_REALTIME: the G*-realtime anomalies) counts against strict-serializable alone
+ * (doc/05-datomic/04-optimization.md:311-345: G-single-realtime, "Everything looks good" under serializable). */
+uint32_t msim_violated_anomalies(uint32_t anomalies, uint32_t consistency_model);
 
 /* Host-only utility behind msim_check for txn-rw-register: the rw-register analysis of [upstream] elle
  * (jepsen.tests.cycle.wr with :wfr-keys? true, txn_rw_register.clj:150-168): writes are unique per key; version orders come

@@ -37,7 +37,7 @@ MASK_WORDS = 4
 
 EXPORTS = [
     "msim_abi_version", "msim_device_count", "msim_config_defaults", "msim_config_finalize", "msim_create",
-    "msim_run", "msim_run_async", "msim_check", "msim_check_host_rechecks", "msim_set_dev_flags", "msim_check_lin_kv_batch", "msim_check_txn_batch", "msim_check_unique_batch", "msim_check_pn_batch", "msim_check_lin_kv_rows", "msim_check_txn_rows", "msim_check_rw_rows", "msim_proscribed_anomalies", "msim_check_pn_rows", "msim_check_unique_rows", "msim_history_edn_rows", "msim_fetch", "msim_fetch_begin", "msim_history", "msim_net_stats_get", "msim_journal", "msim_meta",
+    "msim_run", "msim_run_async", "msim_check", "msim_check_host_rechecks", "msim_set_dev_flags", "msim_check_lin_kv_batch", "msim_check_txn_batch", "msim_check_unique_batch", "msim_check_pn_batch", "msim_check_lin_kv_rows", "msim_check_txn_rows", "msim_check_rw_rows", "msim_proscribed_anomalies", "msim_violated_anomalies", "msim_check_pn_rows", "msim_check_unique_rows", "msim_history_edn_rows", "msim_fetch", "msim_fetch_begin", "msim_history", "msim_net_stats_get", "msim_journal", "msim_meta",
     "msim_check_results", "msim_device_buffers_get", "msim_last_kernel_ms", "msim_get_config",
     "msim_selftest_wave", "msim_last_error", "msim_destroy",
     "msim_comm_unique_id", "msim_comm_init", "msim_gather", "msim_journal_fressian_rows",

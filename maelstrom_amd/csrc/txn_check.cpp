@@ -459,6 +459,8 @@ extern "C" uint32_t msim_proscribed_anomalies(uint32_t cm) {
   return p;
 }
 
+extern "C" uint32_t msim_violated_anomalies(uint32_t anomalies, uint32_t cm) { return cm > MSIM_CM_READ_UNCOMMITTED ? anomalies : judge(anomalies, cm); }
+
 extern "C" int msim_check_rw_rows(const msim_op *rows, uint32_t n_rows, const uint32_t *payload, uint32_t n_words, uint32_t consistency_model,
                                   msim_check_result *out) {
   if (!rows || !out || (!payload && n_words) || consistency_model > MSIM_CM_READ_UNCOMMITTED) return MSIM_E_INVALID;
