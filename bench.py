@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark: simulated msgs/sec (+ histories/sec passing the checker), broadcast n=25.
 
-    python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg4]
+    (N>1: either under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...` — the driver's
+    way — or plainly as `python bench.py --gpus N`, which starts those N ranks itself; it refuses to run on fewer devices than N
+    and never reports an n_gpus other than --gpus.)
 
 One "step" = one pass of the hot path over one batch: every rank simulates `--instances` (default 4096,
 BASELINE.json configs[1]) independent broadcast test instances (25 nodes, grid topology, --rate 100,
@@ -32,6 +34,43 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICR
 def headline_config(E, seed):
     return E.test_config("broadcast", bin="broadcast-ff", node_count=25, rate=100, time_limit=20, latency=0,
                          latency_dist="constant", topology="grid", seed=seed, inbox_capacity=6)
+
+
+def cfg4_config(E, seed):
+    """BASELINE.json configs[3]: lin-kv over 5-node Raft, concurrency 10 (core.clj:111), rate 30/s, 60 s (doc/06-raft/04-committing.md:418)."""
+    return E.test_config("lin-kv", bin="raft", node_count=5, rate=30, time_limit=60, seed=seed)
+
+
+CONFIGS = {
+    # name: (config builder, instances over the whole job or None = --instances per GPU, description, dominant kernel)
+    "cfg2": (headline_config, None, "broadcast n=25 x %d instances/GPU (grid, rate 100/s, time-limit 20 s + 10 s quiesce + final reads, latency 0, fire-and-forget gossip)",
+             "sim_kernel_duo<LAT0, DEG4> (duo.hip: two clusters per wavefront)", "sim_kernel_duo", "r02_headline_counters.json"),
+    "cfg4": (cfg4_config, 65536, "lin-kv over 5-node Raft x %d instances/GPU (65536 over the job; concurrency 10, rate 30/s, time-limit 60 s, latency 0), histories gathered to rank 0 over RCCL",
+             "raft4_kernel<> (raft4.hip: four clusters per wavefront)", "raft4_kernel", "r02_cfg4_raft_counters.json"),
+}
+
+
+def respawn_if_needed(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks (one per GPU) under it and become that job."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:
+        if int(env_world) != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={env_world} ranks; n_gpus must be what was asked for")
+        return
+    if args.gpus <= 1:
+        return
+    import socket
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus and not os.environ.get("MSIM_BENCH_ONE_DEVICE"):
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} HIP device(s) visible; one rank per GPU is the only layout (SURVEY.md §8e)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execv(sys.executable, cmd)
 
 
 def host_cores():
@@ -98,12 +137,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--instances", type=int, default=4096, help="test instances per GPU per step")
+    ap.add_argument("--instances", type=int, default=0, help="test instances per GPU per step (default: 4096 for cfg2; 65536 / --gpus for cfg4)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2", help="BASELINE.json config: cfg2 = the headline (broadcast n=25), cfg4 = lin-kv over Raft, 65536 instances over the job + RCCL history gather")
     ap.add_argument("--cpu-sample", type=float, default=10.0, help="seconds of CPU-oracle work for cpu_baseline (0 = skip)")
     ap.add_argument("--seed", type=int, default=2026)
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-fetch", action="store_true", help="skip the PCIe-inclusive leg (value_incl_fetch)")
     args = ap.parse_args()
+    respawn_if_needed(args)
 
     # ONE JSON line on stdout: libraries underneath (RCCL's version banner at communicator set-up, gloo's connection notes) write
     # to file descriptor 1 — for the duration of the run it points at stderr; the result goes to the saved descriptor.
@@ -117,6 +158,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, (world, args.gpus)
     if rank == 0:
         build.build(verbose=False)
     dist = None
@@ -138,9 +180,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    cfg = headline_config(E, args.seed)
+    make_cfg, job_instances, workload_text, kernel_text, kernel_key, counters_file = CONFIGS[args.config]
+    cfg = make_cfg(E, args.seed)
     eng = E.Engine(cfg, device=local_rank)
-    n = args.instances
+    n = args.instances or (job_instances // world if job_instances else 4096)
 
     def torch_view(ptr, nbytes, dtype, device):
         class _W:  # zero-copy view of engine-owned HBM through __cuda_array_interface__
@@ -156,7 +199,7 @@ def main():
     def step(k):
         first = k * world * n + EN.shard(world * n, rank, world)[0]  # distinct instances for every (step, rank)
         eng.run(first, n)     # simulate (blocking; kernel time from HIP events inside the library)
-        eng.check()           # set-full over the HBM-resident histories
+        eng.check()           # the workload checker over the HBM-resident histories (cfg2: set-full; cfg4: per-key linearizability)
         db = eng.device_buffers()
         stats = torch_view(db.stats, db.stats_bytes, torch.int64, dev).view(-1, 6)
         meta = torch_view(db.meta, db.meta_bytes, torch.int32, dev).view(-1, 8)
@@ -217,7 +260,7 @@ def main():
     if not args.no_gather:
         gather, gather_err = guarded("history_gather", 180.0, lambda: history_gather(eng, torch, dist, dev, world, rank, torch_view))
     incl = incl_err = None
-    if not args.no_fetch and not stuck:
+    if not args.no_fetch and not stuck and args.config == "cfg2":   # (the PCIe-inclusive leg is defined for the headline)
         def incl_leg():
             first0 = (args.warmup + args.steps + 2) * world * n + EN.shard(world * n, rank, world)[0] * 4
             isteps = max(args.steps, 100)   # a pipeline's rate is its steady state: enough batches that filling and draining it do not show
@@ -245,48 +288,60 @@ def main():
             "unit": "msgs/s",
             "n_gpus": world, "steps": k, "warmup": args.warmup,
             "ms_per_step": elapsed / k * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if job_instances and not args.instances else "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "broadcast n=25 x %d instances/GPU (grid, rate 100/s, time-limit 20 s + 10 s quiesce + final reads, latency 0, fire-and-forget gossip)" % n,
+            "config": {"workload": workload_text % n, "name": args.config,
                        "instances_per_gpu": n, "parallelism": "ensemble-dp%d" % world},
             # the metric as SURVEY.md §8(d)(i) words it: simulate + check + the histories' way to host memory (PCIe) in the timed region
             "value_incl_fetch": incl["value"] if incl else None,
             "incl_fetch": incl,
             "histories_per_sec": valid_all / elapsed,
-            # the set-full checker behind histories_per_sec restates [upstream] jepsen.checker/set-full from its published
-            # description: no JVM here to pin it against; verdict parity with Jepsen is unpinned
-            "checker_parity": "unpinned",
+            # the checkers behind histories_per_sec restate [upstream] Jepsen / Knossos / Elle from their published descriptions: no JVM
+            # here to pin them against.  Reference-held vectors: pn_counter_test.clj (the counter checker) and the
+            # anomalies doc/05-datomic prints (the list-append checker, tests/test_elle_reference_vectors.py); set-full (this line's
+            # checker) and the linearizability search have none in the reference tree
+            "checker_parity": "unpinned for set-full / linearizability; partial (doc vectors) for list-append; pinned (pn_counter_test.clj) for the counters",
             "histories_checked": n * k * world, "histories_valid": valid_all, "instances_flagged": flagged_all,
             "msgs_per_instance": msgs_all / (n * k * world),
             "kernel_ms": {"sim": sim_avg, "check": chk_avg},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "sim_kernel_duo<LAT0, DEG4> (duo.hip: two clusters per wavefront)", "algorithmic_bytes_per_launch": b_alg},
+                         "kernel": kernel_text, "algorithmic_bytes_per_launch": b_alg},
         }
         # HBM bytes per launch and the instruction-issue picture from the PMC passes of the committed profile (counters cannot be
         # read inside this process): FETCH_SIZE x 2 + WRITE_SIZE, KiB -> bytes; SQ_* per launch (tools/profile_headline.sh ->
         # tools/rocpd_summary.py --counters).  null if the profile is absent or was taken with a different batch size.
-        cj = os.path.join(ROOT, "profiles", "r02_headline_counters.json")
-        if os.path.exists(cj) and n == 4096:
+        cj = os.path.join(ROOT, "profiles", counters_file)
+        if os.path.exists(cj) and n == (4096 if args.config == "cfg2" else 8192):
             try:
                 kern = json.load(open(cj))["kernels"]
-                kd = [v for kname, v in kern.items() if "sim_kernel_duo" in kname]
+                kd = [v for kname, v in kern.items() if kernel_key in kname]
                 if kd:
                     kd, c = kd[0], kd[0]["counters_per_dispatch"]
                     if "hbm_bytes_per_dispatch" in kd:
                         out["roofline"]["traffic"] = kd["hbm_bytes_per_dispatch"]
-                        out["roofline"]["traffic_source"] = "profiles/r02_headline_counters.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-                    # the kernel is not bound by HBM (frac above): what bounds it is instruction issue + LDS latency of 2 wavefronts per SIMD
+                        out["roofline"]["traffic_source"] = f"profiles/{counters_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                    # The kernel is not bound by HBM (frac above): what bounds it is VALU issue.  A VALU instruction of a 64-lane wavefront
+                    # occupies its SIMD's 16-lane vector pipe for 4 cycles, so the pipes of the chip are busy for 4 x SQ_INSTS_VALU cycles out
+                    # of n_SIMD x kernel cycles (SQ_BUSY_CYCLES counts every cycle once per shader engine: 32 of them on MI355X).
                     insts = sum(c.get(k, 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH", "SQ_INSTS_VMEM_WR", "SQ_INSTS_VMEM_RD", "SQ_INSTS_SMEM"))
+                    n_simd, n_se = 1024.0, 32.0
+                    kcycles = c.get("SQ_BUSY_CYCLES", 0.0) / n_se
+                    live_lanes = 2 * cfg.n_nodes if args.config == "cfg2" else 4 * (cfg.n_nodes + cfg.concurrency)
                     out["roofline"]["secondary"] = {
-                        "bound": "instruction issue / LDS latency at 2 wavefronts per SIMD (2048 wavefronts on 1024 SIMDs, LDS-limited)",
-                        "source": "profiles/r02_headline_counters.json (rocprofv3 --pmc SQ_* passes of `bench.py --steps 3`, same kernel, same batch)",
+                        "bound": "VALU issue: the vector pipes are busy valu_issue_frac of the kernel's cycles with lane_utilisation of the lanes carrying a cluster's endpoints; "
+                                 "the batch (%d wavefronts on %d SIMDs) gives every SIMD %.1f wavefronts to hide LDS / ds_bpermute round trips with" % (int(kd.get("wavefronts") or 0), int(n_simd), (kd.get("wavefronts") or 0) / n_simd),
+                        "source": f"profiles/{counters_file} (rocprofv3 --pmc SQ_* passes of the same kernel at the same batch)",
+                        "valu_issue_frac": 4.0 * c.get("SQ_INSTS_VALU", 0.0) / (n_simd * kcycles) if kcycles else None,
+                        "lane_utilisation": live_lanes / 64.0,
+                        "kernel_cycles": kcycles,
                         "wavefronts": kd.get("wavefronts"), "lds_bytes_per_wavefront": kd.get("lds_bytes"),
                         "insts_per_launch": {k[9:].lower(): c[k] for k in sorted(c) if k.startswith("SQ_INSTS_")},
                         "insts_per_message": insts / (msgs_all / (k * world)) if msgs_all else None,
                         "wave_cycles_per_launch": c.get("SQ_WAVE_CYCLES"),
                         "frac_of_wave_cycles": kd.get("derived"),
                         "profiled_kernel_ms": kd.get("avg_ms"),
+                        "batch_sweep": "profiles/r03a_headline_batch_sweep.jsonl (4096 / 8192 / 16384 instances: 9.8 / 22.0 / 39.1 ms, 2.2e10 msgs/s at saturation)" if args.config == "cfg2" else None,
                     }
             except Exception:
                 pass

@@ -734,7 +734,7 @@ static hipError_t duo_launch(const DuoParams &dp, dim3 grid, size_t lds, hipStre
   return hipGetLastError();
 }
 
-// Launches the duo kernel for n clusters on `st`; returns hipErrorInvalidValue if the cluster state does not fit (the caller
+// Launches the duo kernel for n clusters on `st`; returns MSIM_LAYOUT_DOES_NOT_FIT if the cluster state does not fit (the caller
 // then runs the one-cluster-per-wavefront kernels).
 hipError_t msim_launch_duo(const KParams &kp, uint32_t n, hipStream_t st) {
   const msim_config &c = kp.cfg;
@@ -756,8 +756,8 @@ hipError_t msim_launch_duo(const KParams &kp, uint32_t n, hipStream_t st) {
   if (rnd && R > cap_tot) R = cap_tot ? cap_tot : 1;
   dp.S = cap_tot > R ? cap_tot - R : 0;
   // the spill area is spill_capacity x 16 bytes per node: 8-byte ring entries (constant latency) or 12-byte bag entries (RND)
-  if ((size_t)dp.S * (rnd ? 12 : 8) > (size_t)c.spill_capacity * 16) return hipErrorInvalidValue;
-  if (rnd) { hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(duo_log2_q24), msim_log2_q24, sizeof(msim_log2_q24)); if (e != hipSuccess) return e; }   // (per device; 1 KiB)
+  if ((size_t)dp.S * (rnd ? 12 : 8) > (size_t)c.spill_capacity * 16) return MSIM_LAYOUT_DOES_NOT_FIT;
+  if (rnd) MSIM_UPLOAD_ONCE(duo_log2_q24, msim_log2_q24, sizeof(msim_log2_q24));   // (1 KiB, once per device)
   size_t off = rnd ? 0 : DUO_STAGE_ROWS * 16;
   dp.off_ring = (u32)off; off += rnd ? (size_t)(kp.N + 1) * 16 * 8 : (size_t)32 * R * (lat0 ? 4 : 8);
   dp.off_seq = (u32)off; if (rnd) off += (((size_t)(kp.N + 1) * 16 * 2) + 15) & ~(size_t)15;
@@ -770,7 +770,7 @@ hipError_t msim_launch_duo(const KParams &kp, uint32_t n, hipStream_t st) {
   dp.echoback = c.node_program == MSIM_NODE_BCAST_FF_ECHOBACK;
   dp.round_limit = (kp.dev_flags & 0x100u) ? 2000000u : ROUND_LIMIT;
   const size_t lds = 2 * off + (rnd ? 257 * 4 + 12 : 0);
-  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  if (lds > 160 * 1024) return MSIM_LAYOUT_DOES_NOT_FIT;
   const bool deg4 = dp.deg <= 4 && kp.N <= 31;   // (lane 31 must hold no node: unused neighbour slots point at it)
   const dim3 grid((n + 1) / 2);
   if (rnd) return deg4 ? duo_launch<false, true, true>(dp, grid, lds, st) : duo_launch<false, false, true>(dp, grid, lds, st);

@@ -989,17 +989,17 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   e = hipGetLastError();
 #else
   // the headline layout: two clusters per wavefront (duo.hip); MSIM_DEV_FLAGS bit 9 keeps the one-cluster kernels
-  e = hipErrorInvalidValue;
+  e = MSIM_LAYOUT_DOES_NOT_FIT;
   if (msim_duo_eligible(c) && !(kp.dev_flags & 0x200u)) {
     e = msim_launch_duo(kp, n, st);
-    if (e == hipErrorInvalidValue && (kp.dev_flags & 0x400u)) { ctx->err = "MSIM_DEV_FLAGS bit 10: the two-clusters-per-wavefront layout was required but this cluster state does not fit it"; return MSIM_E_UNSUPPORTED; }
+    if (e == MSIM_LAYOUT_DOES_NOT_FIT && (kp.dev_flags & 0x400u)) { ctx->err = "MSIM_DEV_FLAGS bit 10: the two-clusters-per-wavefront layout was required but this cluster state does not fit it"; return MSIM_E_UNSUPPORTED; }
   }
   // Raft: four clusters per wavefront (raft4.hip) when a cluster fits a 16-lane group
   if (msim_raft4_eligible(c) && !(kp.dev_flags & 0x200u)) e = msim_launch_raft4(kp, n, st);
   // txn-list-append: eight clusters per wavefront (txn8.hip) when a cluster fits an 8-lane group
   if (msim_txn8_eligible(c) && !(kp.dev_flags & 0x200u)) e = msim_launch_txn8(kp, n, st);
-  if (e == hipErrorInvalidValue && (kp.dev_flags & 0x400u) && is_raft) { ctx->err = "MSIM_DEV_FLAGS bit 10: the four-clusters-per-wavefront Raft layout was required but does not apply"; return MSIM_E_UNSUPPORTED; }
-  if (e == hipErrorInvalidValue) switch (c.node_program) {   // not eligible, or the cluster state does not fit the duo layout
+  if (e == MSIM_LAYOUT_DOES_NOT_FIT && (kp.dev_flags & 0x400u) && is_raft) { ctx->err = "MSIM_DEV_FLAGS bit 10: the four-clusters-per-wavefront Raft layout was required but does not apply"; return MSIM_E_UNSUPPORTED; }
+  if (e == MSIM_LAYOUT_DOES_NOT_FIT) switch (c.node_program) {   // not eligible, or the cluster state does not fit the duo layout
     case MSIM_NODE_ECHO: e = launch<MSIM_NODE_ECHO>(kp, n, lds, st); break;
     case MSIM_NODE_BCAST_FF:
     case MSIM_NODE_BCAST_FF_ECHOBACK:

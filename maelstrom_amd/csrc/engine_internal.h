@@ -16,6 +16,7 @@ struct msim_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+  hipEvent_t ev_g0 = nullptr, ev_g1 = nullptr;   // gather.cpp's own timing events
   // device buffers of the last run
   uint32_t n_inst = 0, cap_inst = 0;
   uint64_t first_instance = 0;

@@ -19,8 +19,11 @@
 //   cache       first use 0xCD + object, later 0x80+index (< 32) or 0xCC + int index; an object takes its index BEFORE its
 //               components are written; nil, booleans, one-byte ints and "" are never cached
 // Bodies are rebuilt from the 16-byte journal events (include/maelsim.h msim_event) and the instance's payload area:
-// echo / broadcast / g-set / counter / unique-ids traffic with the fields of doc/protocol.md and doc/workloads.md; the Raft,
-// transaction and replicate messages, whose contents live in engine scratch, carry {:type ..., :a <payload word>} plus ids.
+// echo / broadcast / g-set / counter / unique-ids traffic, lin-kv reads / writes / cas and the client <-> node `txn` / `txn_ok`
+// messages with the fields of doc/protocol.md and doc/workloads.md; messages whose contents the engine never materialises (Raft's
+// request_vote / append_entries, replicate snapshots, the transactional nodes' traffic with their storage services, where a value is
+// a version number) are written as {:type ..., :elided true, :a <the envelope's payload word>} plus ids — counts and Lamport
+// diagrams stay right, the bodies say that they are abbreviated.
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -79,11 +82,18 @@ struct FW {
   void list_header(size_t n) { if (n < 8) raw((uint8_t)(0xE4 + n)); else { raw(0xEC); integer((int64_t)n); } }
 };
 
-std::string endpoint(uint32_t e, uint32_t n_nodes, uint32_t slots) {
+// endpoints behind the client slots are services (service.clj:290-296): the proxy's is the one it was pointed at, the single-root
+// transactional node uses lin-kv, the multi-key one lin-kv then lww-kv
+std::string endpoint(uint32_t e, uint32_t n_nodes, uint32_t slots, const msim_config *cfg) {
   char b[16];
   if (e < n_nodes) std::snprintf(b, sizeof b, "n%u", e);
   else if (e < n_nodes + slots) std::snprintf(b, sizeof b, "c%u", e - n_nodes);
-  else std::snprintf(b, sizeof b, "%s", "lin-kv");   // the service endpoint behind the client slots (service.clj:290-296)
+  else {
+    const char *name = "lin-kv";
+    if (cfg->node_program == MSIM_NODE_LIN_KV_PROXY) name = cfg->proxy_service == MSIM_SVC_SEQ_KV ? "seq-kv" : cfg->proxy_service == MSIM_SVC_LWW_KV ? "lww-kv" : "lin-kv";
+    else if (cfg->node_program == MSIM_NODE_TXN_MULTI_KEY && e == n_nodes + slots + 1) name = "lww-kv";
+    std::snprintf(b, sizeof b, "%s", name);
+  }
   return b;
 }
 
@@ -144,13 +154,13 @@ extern "C" int msim_journal_fressian_rows(const msim_config *cfg, const msim_eve
     const bool recv = (e.msg & 0x80u) != 0;
     if (type == 0 || type >= sizeof MSG_TYPES / sizeof MSG_TYPES[0]) return MSIM_E_RANGE;
     w.tag("ev", 4);
-    w.integer(i);                                    // :id = position (journal.clj:225-239)
+    w.integer(i);                                    // :id = position: next-id starts at -1 and is pre-incremented (journal.clj:195,225-239)
     w.integer((int64_t)e.time_us * 1000);            // :time in ns
     w.keyword(recv ? "recv" : "send", true);
     w.tag("msg", 4);
     w.integer(id);
-    w.str(endpoint(src, N, slots), true);
-    w.str(endpoint(dest, N, slots), true);
+    w.str(endpoint(src, N, slots, cfg), true);
+    w.str(endpoint(dest, N, slots, cfg), true);
     // ---- body ----
     w.raw(0xC0);   // tag "map"
     w.raw(0xED);   // begin closed list
@@ -159,17 +169,17 @@ extern "C" int msim_journal_fressian_rows(const msim_config *cfg, const msim_eve
     kv_type(MSG_TYPES[type]);
     switch (type) {
       case MSIM_M_INIT:
-        w.keyword("node_id", true); w.str(endpoint(dest, N, slots), false);
-        w.keyword("node_ids", true); w.list_header(N); for (uint32_t k = 0; k < N; k++) w.str(endpoint(k, N, slots), false);
+        w.keyword("node_id", true); w.str(endpoint(dest, N, slots, cfg), false);
+        w.keyword("node_ids", true); w.list_header(N); for (uint32_t k = 0; k < N; k++) w.str(endpoint(k, N, slots, cfg), false);
         break;
       case MSIM_M_TOPOLOGY:
         w.keyword("topology", true);
         w.raw(0xC0); w.list_header(2 * (size_t)N);   // an ordinary map: tag "map" + a list of keys and values
         for (uint32_t a = 0; a < N; a++) {
-          w.keyword(endpoint(a, N, slots), false);
+          w.keyword(endpoint(a, N, slots, cfg), false);
           const std::vector<uint32_t> nb = neighbours(cfg->topology, N, a);
           w.list_header(nb.size());
-          for (uint32_t b : nb) w.str(endpoint(b, N, slots), false);
+          for (uint32_t b : nb) w.str(endpoint(b, N, slots, cfg), false);
         }
         break;
       case MSIM_M_ECHO: case MSIM_M_ECHO_OK: { char b[32]; std::snprintf(b, sizeof b, "Please echo %u", e.a); w.keyword("echo", true); w.str(b, false); } break;
@@ -181,16 +191,43 @@ extern "C" int msim_journal_fressian_rows(const msim_config *cfg, const msim_eve
           if ((uint64_t)off + words > n_words) return MSIM_E_RANGE;
           w.keyword(wl == MSIM_WL_BROADCAST ? "messages" : "value", true);
           int_list_from_bitmap(w, payload + off, words);
-        } else kv_int("value", wl == MSIM_WL_PN_COUNTER || wl == MSIM_WL_G_COUNTER ? (int64_t)(int32_t)e.a : (int64_t)e.a);
+        } else if (wl == MSIM_WL_TXN_LIST_APPEND) { w.keyword("elided", true); w.raw(0xF5); kv_int("a", e.a); }   // a root version / a thunk id
+        else kv_int("value", wl == MSIM_WL_PN_COUNTER || wl == MSIM_WL_G_COUNTER ? (int64_t)(int32_t)e.a : (int64_t)e.a);
         break;
       case MSIM_M_ERROR: kv_int("code", e.a); break;
       case MSIM_M_GENERATE_OK:
-        w.keyword("id", true); w.list_header(3); w.integer(e.a >> 20); w.integer((e.a >> 5) & 0x7FFF); w.str(endpoint(e.a & 31, N, slots), false);
+        w.keyword("id", true); w.list_header(3); w.integer(e.a >> 20); w.integer((e.a >> 5) & 0x7FFF); w.str(endpoint(e.a & 31, N, slots, cfg), false);
         break;
       case MSIM_M_INIT_OK: case MSIM_M_TOPOLOGY_OK: case MSIM_M_BROADCAST_OK: case MSIM_M_ADD_OK: case MSIM_M_READ: case MSIM_M_GENERATE:
         if (type == MSIM_M_READ && wl == MSIM_WL_LIN_KV) kv_int("key", e.a & 0xFF);
+        else if (type == MSIM_M_READ && wl == MSIM_WL_TXN_LIST_APPEND) { w.keyword("elided", true); w.raw(0xF5); kv_int("a", e.a); }   // the root / a thunk, by id
         break;
-      default: kv_int("a", e.a); break;   // contents live in engine scratch (raft entries, transactions, replicate snapshots)
+      case MSIM_M_TXN: case MSIM_M_TXN_OK: {   // [[f k v] ...] (doc/workloads.md txn-list-append / txn-rw-register); micro-ops in the payload area
+        const uint32_t off = e.a & 0xFFFFFFu, nw = e.a >> 24;
+        if ((uint64_t)off + nw > n_words) return MSIM_E_RANGE;
+        const bool rw = wl == MSIM_WL_TXN_RW_REGISTER;
+        size_t n_mops = 0;
+        for (uint32_t k = 0; k < nw;) { const uint32_t h = payload[off + k++], x = (h >> 16) & 0xFFu; n_mops++; if (!rw && !(h & 1u) && x != 0xFFu) k += (x + 3) / 4; }
+        w.keyword("txn", true);
+        w.list_header(n_mops);
+        for (uint32_t k = 0; k < nw;) {
+          const uint32_t h = payload[off + k++], key = (h >> 1) & 0x7FFFu, x = (h >> 16) & 0xFFu;
+          w.list_header(3);
+          if (h & 1u) { w.str(rw ? "w" : "append", true); w.integer(key); w.integer(x); continue; }
+          w.str("r", true); w.integer(key);
+          if (x == 0xFFu) { w.raw(0xF7); continue; }   // nil
+          if (rw) { w.integer(x); continue; }
+          w.list_header(x);
+          for (uint32_t el = 0; el < x; el++) w.integer((payload[off + k + el / 4] >> (8 * (el % 4))) & 0xFFu);
+          k += (x + 3) / 4;
+        }
+      } break;
+      case MSIM_M_WRITE: case MSIM_M_CAS: case MSIM_M_WRITE_OK: case MSIM_M_CAS_OK:
+        if (wl == MSIM_WL_LIN_KV && type == MSIM_M_WRITE) { kv_int("key", e.a & 0xFF); kv_int("value", (e.a >> 8) & 0xFF); }
+        else if (wl == MSIM_WL_LIN_KV && type == MSIM_M_CAS) { kv_int("key", e.a & 0xFF); kv_int("from", (e.a >> 8) & 0xFF); kv_int("to", (e.a >> 16) & 0xFF); }
+        else if (wl != MSIM_WL_LIN_KV) { w.keyword("elided", true); w.raw(0xF5); kv_int("a", e.a); }   // storage traffic of the transactional nodes: versions, not values
+        break;
+      default: w.keyword("elided", true); w.raw(0xF5); kv_int("a", e.a); break;   // contents live in engine scratch (raft entries, replicate snapshots)
     }
     if (mid) kv_int(is_reply(type) ? "in_reply_to" : "msg_id", mid);
     w.raw(0xFD);   // end of the closed list

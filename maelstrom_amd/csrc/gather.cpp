@@ -81,6 +81,7 @@ void msim_gather_layout(const uint64_t *sizes, int world, std::vector<uint64_t> 
 void msim_gather_free(msim_ctx *ctx) {
   for (int k = 0; k < 4; k++) { if (ctx->d_all[k]) (void)hipFree(ctx->d_all[k]); ctx->d_all[k] = nullptr; ctx->cap_all[k] = 0; }
   if (ctx->d_sizes) { (void)hipFree(ctx->d_sizes); ctx->d_sizes = nullptr; }
+  if (ctx->ev_g0) { (void)hipEventDestroy(ctx->ev_g0); (void)hipEventDestroy(ctx->ev_g1); ctx->ev_g0 = ctx->ev_g1 = nullptr; }
   if (ctx->comm && rccl().ok) (void)rccl().CommDestroy(static_cast<ncclComm_t>(ctx->comm));
   ctx->comm = nullptr;
 }
@@ -101,6 +102,7 @@ extern "C" int msim_comm_init(msim_ctx *ctx, const unsigned char id[MSIM_COMM_ID
   if (!r.ok) { ctx->err = r.err; return MSIM_E_UNSUPPORTED; }
   MSIM_HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (ctx->comm) { (void)r.CommDestroy(static_cast<ncclComm_t>(ctx->comm)); ctx->comm = nullptr; }
+  if (ctx->d_sizes) { (void)hipFree(ctx->d_sizes); ctx->d_sizes = nullptr; }   // sized for the previous world
   ncclUniqueId u;
   std::memcpy(u.internal, id, MSIM_COMM_ID_BYTES);
   ncclComm_t comm = nullptr;
@@ -115,7 +117,8 @@ extern "C" int msim_gather(msim_ctx *ctx, int root, msim_gathered *out) {
   const int world = ctx->comm ? ctx->comm_world : 1, rank = ctx->comm ? ctx->comm_rank : 0;
   if (root < 0 || root >= world) { ctx->err = "msim_gather: root out of range"; return MSIM_E_INVALID; }
   MSIM_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  MSIM_HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
+  if (!ctx->ev_g0) { MSIM_HIP_TRY(ctx, hipEventCreate(&ctx->ev_g0)); MSIM_HIP_TRY(ctx, hipEventCreate(&ctx->ev_g1)); }   // (the checkers time themselves with ev2 / ev3)
+  MSIM_HIP_TRY(ctx, hipEventRecord(ctx->ev_g0, ctx->stream));
   uint64_t row_units = 0, pay_words = 0;
   int rc = msim_compact_on_device(ctx, &row_units, &pay_words);
   if (rc != MSIM_OK) return rc;
@@ -145,24 +148,27 @@ extern "C" int msim_gather(msim_ctx *ctx, int root, msim_gathered *out) {
     Rccl &r = rccl();
     ncclComm_t comm = static_cast<ncclComm_t>(ctx->comm);
     MSIM_NCCL_TRY(ctx, r.GroupStart());
-    for (int k = 0; k < 4; k++) {
+    ncclResult_t bad = ncclSuccess;   // a failing call must not leave the group open on this thread
+    for (int k = 0; k < 4 && bad == ncclSuccess; k++) {
       if (rank == root) {
-        for (int p = 0; p < world; p++) {
+        for (int p = 0; p < world && bad == ncclSuccess; p++) {
           const uint64_t sz = sizes[(size_t)p * 4 + k];
           if (p == root || sz == 0) continue;
-          MSIM_NCCL_TRY(ctx, r.Recv(static_cast<unsigned char *>(ctx->d_all[k]) + offs[k][(size_t)p], sz, ncclUint8, p, comm, ctx->stream));
+          bad = r.Recv(static_cast<unsigned char *>(ctx->d_all[k]) + offs[k][(size_t)p], sz, ncclUint8, p, comm, ctx->stream);
           received += sz;
         }
-      } else if (mine[k]) MSIM_NCCL_TRY(ctx, r.Send(src[k], mine[k], ncclUint8, root, comm, ctx->stream));
+      } else if (mine[k]) bad = r.Send(src[k], mine[k], ncclUint8, root, comm, ctx->stream);
     }
-    MSIM_NCCL_TRY(ctx, r.GroupEnd());
+    const ncclResult_t ended = r.GroupEnd();
+    MSIM_NCCL_TRY(ctx, bad);
+    MSIM_NCCL_TRY(ctx, ended);
   }
   if (rank == root)   // the root's own part: device-to-device
     for (int k = 0; k < 4; k++)
       if (mine[k]) MSIM_HIP_TRY(ctx, hipMemcpyAsync(static_cast<unsigned char *>(ctx->d_all[k]) + offs[k][(size_t)root], src[k], mine[k], hipMemcpyDeviceToDevice, ctx->stream));
-  MSIM_HIP_TRY(ctx, hipEventRecord(ctx->ev3, ctx->stream));
-  MSIM_HIP_TRY(ctx, hipEventSynchronize(ctx->ev3));
-  MSIM_HIP_TRY(ctx, hipEventElapsedTime(&out->ms, ctx->ev2, ctx->ev3));
+  MSIM_HIP_TRY(ctx, hipEventRecord(ctx->ev_g1, ctx->stream));
+  MSIM_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_g1));
+  MSIM_HIP_TRY(ctx, hipEventElapsedTime(&out->ms, ctx->ev_g0, ctx->ev_g1));
   if (rank == root) {
     out->rows = ctx->d_all[0]; out->payload = ctx->d_all[1]; out->meta = ctx->d_all[2]; out->stats = ctx->d_all[3];
     out->rows_bytes = totals[0]; out->payload_bytes = totals[1]; out->meta_bytes = totals[2]; out->stats_bytes = totals[3];

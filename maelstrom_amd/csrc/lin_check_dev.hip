@@ -366,7 +366,8 @@ int msim_check_lin_kv_device(msim_ctx *ctx) {
 extern "C" int msim_check_lin_kv_batch(int device, const msim_op *rows, const uint64_t *row_offsets, uint32_t n_histories, msim_check_result *out) {
   if (!rows || !row_offsets || !out || n_histories == 0) return MSIM_E_INVALID;
   if (hipSetDevice(device) != hipSuccess) return MSIM_E_HIP;
-  msim_ctx tmp_ctx;   // only for error reporting in the HIP_TRY macro
+  msim_ctx tmp_ctx;   // error reporting in the HIP_TRY macro; the device the host worker threads select
+  tmp_ctx.device = device;
   msim_ctx *ctx = &tmp_ctx;
   const uint64_t total = row_offsets[n_histories];
   u32 max_n = 1;

@@ -166,6 +166,7 @@ extern "C" int msim_check_pn_batch(int device, const msim_op *rows, const uint32
   if (!rows || !n_rows || !out || n_histories == 0 || max_rows == 0) return MSIM_E_INVALID;
   if (hipSetDevice(device) != hipSuccess) return MSIM_E_HIP;
   msim_ctx tmp_ctx; msim_ctx *ctx = &tmp_ctx;   // only for error text
+  tmp_ctx.device = device;
   std::vector<msim_inst_meta> hm(n_histories);
   for (u32 i = 0; i < n_histories; i++) { std::memset(&hm[i], 0, sizeof hm[i]); if (n_rows[i] > max_rows) return MSIM_E_RANGE; hm[i].n_rows = n_rows[i]; }
   msim_op *d_rows = nullptr; msim_inst_meta *d_meta = nullptr; msim_check_result *d_out = nullptr;

@@ -857,7 +857,7 @@ static void raft4_launch(const R4Params &rp, bool nem, bool rnd, dim3 grid, size
 
 hipError_t msim_launch_raft4(const KParams &kp, uint32_t n, hipStream_t st) {
   const msim_config &c = kp.cfg;
-  if (kp.raft_log_cap > 0xFFFFu) return hipErrorInvalidValue;   // log indices travel in 16 bits
+  if (kp.raft_log_cap > 0xFFFFu) return MSIM_LAYOUT_DOES_NOT_FIT;   // log indices travel in 16 bits
   R4Params rp;
   rp.k = kp; rp.n_inst = n;
   const uint32_t cap_tot = c.inbox_capacity + c.spill_capacity;
@@ -875,9 +875,9 @@ hipError_t msim_launch_raft4(const KParams &kp, uint32_t n, hipStream_t st) {
   rp.off_misc = (u32)off; off += 64 * 4;
   rp.round_limit = (kp.dev_flags & 0x100u) ? 4000000u : ROUND_LIMIT;
   const size_t lds = off;
-  if (lds > 64 * 1024) return hipErrorInvalidValue;
+  if (lds > 64 * 1024) return MSIM_LAYOUT_DOES_NOT_FIT;
   const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
-  if (rnd) { hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(r4_log2_q24), msim_log2_q24, sizeof(msim_log2_q24)); if (e != hipSuccess) return e; }
+  if (rnd) MSIM_UPLOAD_ONCE(r4_log2_q24, msim_log2_q24, sizeof(msim_log2_q24));   // (1 KiB, once per device)
   const dim3 grid((n + 3) / 4);
   if (kp.N <= 5) raft4_launch<5>(rp, c.nemesis_mask != 0, rnd, grid, lds, st);
   else raft4_launch<8>(rp, c.nemesis_mask != 0, rnd, grid, lds, st);

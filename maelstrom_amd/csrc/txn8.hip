@@ -724,7 +724,7 @@ hipError_t msim_launch_txn8(const KParams &kp, uint32_t n, hipStream_t st) {
   tp.round_limit = (kp.dev_flags & 0x100u) ? 4000000u : ROUND_LIMIT;
   const size_t lds = off;
   const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
-  if (rnd) { hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(t8_log2_q24), msim_log2_q24, sizeof(msim_log2_q24)); if (e != hipSuccess) return e; }
+  if (rnd) MSIM_UPLOAD_ONCE(t8_log2_q24, msim_log2_q24, sizeof(msim_log2_q24));   // (1 KiB, once per device)
   const dim3 grid((n + 7) / 8), block(64);
   if (c.nemesis_mask) { if (rnd) hipLaunchKernelGGL((txn8_kernel<true, true>), grid, block, lds, st, tp); else hipLaunchKernelGGL((txn8_kernel<true, false>), grid, block, lds, st, tp); }
   else { if (rnd) hipLaunchKernelGGL((txn8_kernel<false, true>), grid, block, lds, st, tp); else hipLaunchKernelGGL((txn8_kernel<false, false>), grid, block, lds, st, tp); }

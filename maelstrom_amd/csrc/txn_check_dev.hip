@@ -447,6 +447,7 @@ extern "C" int msim_check_txn_batch(int device, const msim_op *rows, const uint6
   if (!rows || !row_offsets || !payload_offsets || !out || n_histories == 0) return MSIM_E_INVALID;
   if (hipSetDevice(device) != hipSuccess) return MSIM_E_HIP;
   msim_ctx tmp_ctx; msim_ctx *ctx = &tmp_ctx;   // only for error text
+  tmp_ctx.device = device;
   const uint64_t tr = row_offsets[n_histories], tw = payload_offsets[n_histories];
   u32 max_r = 1;
   for (u32 i = 0; i < n_histories; i++) { const uint64_t c = row_offsets[i + 1] - row_offsets[i]; if (c > 0x7FFFFFFFull) return MSIM_E_RANGE; if (c > max_r) max_r = (u32)c; }

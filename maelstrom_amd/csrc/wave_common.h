@@ -135,6 +135,25 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// What a multi-cluster launcher returns when the cluster state does not fit its layout (the caller then runs the one-cluster
+// kernels): NOT a HIP error code, so that a genuine hipErrorInvalidValue of a launch is reported instead of silently falling back.
+static const hipError_t MSIM_LAYOUT_DOES_NOT_FIT = static_cast<hipError_t>(0x7F01);
+// Uploads a __constant__ table once per device and process: hipMemcpyToSymbol synchronises with the null stream, which a launch on
+// a caller's stream (msim_run_async) must not do for every batch.
+#include <atomic>
+#define MSIM_UPLOAD_ONCE(sym, src, bytes)                                                                        \
+  do {                                                                                                           \
+    static std::atomic<unsigned long long> done_{0};                                                             \
+    int d_ = 0;                                                                                                  \
+    hipError_t e_ = hipGetDevice(&d_);                                                                           \
+    if (e_ != hipSuccess) return e_;                                                                             \
+    if (!((done_.load(std::memory_order_acquire) >> (d_ & 63)) & 1ull)) {                                        \
+      e_ = hipMemcpyToSymbol(HIP_SYMBOL(sym), src, bytes);                                                       \
+      if (e_ != hipSuccess) return e_;                                                                           \
+      done_.fetch_or(1ull << (d_ & 63), std::memory_order_release);                                              \
+    }                                                                                                            \
+  } while (0)
+
 // duo.hip: two clusters per wavefront (fire-and-forget broadcast, constant latency, colocated clients)
 bool msim_duo_eligible(const msim_config &c);
 hipError_t msim_launch_duo(const KParams &kp, uint32_t n, hipStream_t st);

@@ -125,3 +125,43 @@ def test_wide_ints_and_long_caches_round_trip():
     evs = F.read_journal(E.journal_fressian(cfg, events, payload))
     assert len(evs) == len(events) and evs[-1]["time"] == int(events["time_us"][-1]) * 1000 > 2 ** 33   # 5-byte packed ints
     assert {e["message"]["src"] for e in evs} >= {f"n{i}" for i in range(40)}
+
+
+def test_transaction_and_key_value_bodies_are_real_and_engine_abstractions_say_so():
+    """txn / txn_ok carry the micro-ops of doc/workloads.md, lin-kv reads / writes / cas their key / value / from / to; what the
+    engine never materialises (Raft's internal RPCs, the transactional nodes' storage traffic, replicate snapshots) is marked
+    `:elided true`; the service endpoints carry the names of service.clj:290-296."""
+    cfg = E.test_config("txn-list-append", bin="multi-key-txn", node_count=3, rate=40, time_limit=4, latency=2, seed=8, journal_capacity=200000)
+    ora, events, payload = _journal(cfg)
+    evs = F.read_journal(E.journal_fressian(cfg, events, payload))
+    names = {e["message"]["src"] for e in evs} | {e["message"]["dest"] for e in evs}
+    assert {"lin-kv", "lww-kv", "n0", "c0"} <= names
+    decoded = [o for o in E.decode_history(*ora.history(0), cfg.n_nodes, cfg.workload)]
+    want_ok = [[[f[1:], k, v] for f, k, v in o["value"]] for o in decoded if o["type"] == ":ok"]
+    got_ok = [e["message"]["body"]["txn"] for e in evs if e["type"] == "recv" and e["message"]["body"]["type"] == "txn_ok"]
+    assert got_ok == want_ok and len(got_ok) > 20
+    want_inv = [[[f[1:], k, v] for f, k, v in o["value"]] for o in decoded if o["type"] == ":invoke"]
+    got_inv = [e["message"]["body"]["txn"] for e in evs if e["type"] == "send" and e["message"]["body"]["type"] == "txn"]
+    assert got_inv == want_inv
+    storage = [e["message"]["body"] for e in evs if e["message"]["dest"] in ("lin-kv", "lww-kv")]
+    assert storage and all(b.get("elided") is True for b in storage)
+
+    cfg = E.test_config("lin-kv", bin="lin-kv-proxy", proxy_service="seq-kv", node_count=3, concurrency=6, rate=40, time_limit=4, seed=8, journal_capacity=200000)
+    ora, events, payload = _journal(cfg)
+    evs = F.read_journal(E.journal_fressian(cfg, events, payload))
+    assert "seq-kv" in {e["message"]["dest"] for e in evs}
+    bodies = [e["message"]["body"] for e in evs if e["type"] == "send" and e["message"]["src"].startswith("c")]
+    ops = [o for o in E.decode_history(*ora.history(0), cfg.n_nodes, cfg.workload) if o["type"] == ":invoke"]
+    assert len(bodies) == len(ops) + cfg.n_nodes
+    for b, o in zip([b for b in bodies if b["type"] != "init"], ops):
+        k, v = o["value"]
+        assert b["key"] == k and b["type"] == o["f"][1:]
+        if o["f"] == ":write":
+            assert b["value"] == v
+        if o["f"] == ":cas":
+            assert [b["from"], b["to"]] == v
+
+    cfg = E.test_config("lin-kv", bin="raft", node_count=3, concurrency=6, rate=10, time_limit=5, seed=5, journal_capacity=200000)
+    ora, events, payload = _journal(cfg)
+    evs = F.read_journal(E.journal_fressian(cfg, events, payload))
+    assert all(e["message"]["body"].get("elided") is True for e in evs if e["message"]["body"]["type"] in ("request_vote", "append_entries", "append_entries_res"))
