@@ -68,16 +68,20 @@ enum {
   MSIM_NODE_TXN_RW_HAT = 11,    /* demo/clojure/txn_rw_register_hat.clj:1-190: highly available transactions — every node applies a
                                    txn locally at a Lamport timestamp (last write wins per key), then replicates it to the
                                    others every 100 ms until they acknowledge (the demo of core.clj:115-121)                */
-  MSIM_NODE_TXN_MULTI_KEY = 12  /* demo/js/multi_key_txn.js:1-246 == demo/clojure/multi_key_txn.clj: thunks in lww-kv, the root map in
-                                   lin-kv, retry when the root cas is lost.  Restated in the CPU oracle (oracle/mk_nodes.inc, pinned by
-                                   the real program on the process bridge); NOT a built-in of the GPU engine yet: msim_create
-                                   answers MSIM_E_UNSUPPORTED for it                                                         */
+  MSIM_NODE_TXN_MULTI_KEY = 12, /* demo/js/multi_key_txn.js:1-246 == demo/clojure/multi_key_txn.clj (the JS / Clojure form of
+                                   demo/ruby/datomic_list_append.rb, the workload's demo at core.clj:113-114): thunks in lww-kv, the root
+                                   map in lin-kv, retry when the root cas is lost (oracle/mk_nodes.inc, pinned by the real program on
+                                   the process bridge; csrc/sim_kernel_mk.inc).  One worker per node, at most 30 nodes               */
+  MSIM_NODE_TSO_IDS = 13        /* unique-ids over the `lin-tso` timestamp oracle (service.clj:116-132,290-296; doc/services.md): every
+                                   `generate` becomes a {type "ts"} RPC to lin-tso, the timestamp is the id.  The reference ships the
+                                   service but no demo that uses it; this node (tools/harness_tso_node.py is its process form) is what
+                                   exercises it                                                                                  */
 };
 
 enum { MSIM_LAT_CONSTANT = 0, MSIM_LAT_UNIFORM = 1, MSIM_LAT_EXPONENTIAL = 2 };  /* net.clj:65-77 */
 enum { MSIM_TOPO_GRID = 0, MSIM_TOPO_LINE = 1, MSIM_TOPO_TOTAL = 2,
        MSIM_TOPO_TREE2 = 3, MSIM_TOPO_TREE3 = 4, MSIM_TOPO_TREE4 = 5 };           /* broadcast.clj:171-179 */
-enum { MSIM_SVC_LIN_KV = 0, MSIM_SVC_SEQ_KV = 1, MSIM_SVC_LWW_KV = 2 };               /* service.clj:290-296 */
+enum { MSIM_SVC_LIN_KV = 0, MSIM_SVC_SEQ_KV = 1, MSIM_SVC_LWW_KV = 2, MSIM_SVC_LIN_TSO = 3 };   /* service.clj:290-296 */
 /* --consistency-models (core.clj:160-165, default strict-serializable; the txn-rw-register demo asks for read-committed,
  * core.clj:118): which of the anomalies the transactional checkers find make a history invalid (see msim_check_txn_rows). */
 enum { MSIM_CM_STRICT_SERIALIZABLE = 0, MSIM_CM_SERIALIZABLE = 1, MSIM_CM_SNAPSHOT_ISOLATION = 2, MSIM_CM_READ_COMMITTED = 3,
@@ -194,7 +198,8 @@ enum { MSIM_M_INIT = 1, MSIM_M_INIT_OK, MSIM_M_TOPOLOGY, MSIM_M_TOPOLOGY_OK, MSI
        MSIM_M_BROADCAST_OK, MSIM_M_READ, MSIM_M_READ_OK, MSIM_M_ADD, MSIM_M_ADD_OK, MSIM_M_REPLICATE,
        MSIM_M_WRITE, MSIM_M_WRITE_OK, MSIM_M_CAS, MSIM_M_CAS_OK, MSIM_M_ERROR,
        MSIM_M_REQUEST_VOTE, MSIM_M_REQUEST_VOTE_RES, MSIM_M_APPEND_ENTRIES, MSIM_M_APPEND_ENTRIES_RES,
-       MSIM_M_TXN, MSIM_M_TXN_OK, MSIM_M_GENERATE, MSIM_M_GENERATE_OK, MSIM_M_REPLICATE_ACK };
+       MSIM_M_TXN, MSIM_M_TXN_OK, MSIM_M_GENERATE, MSIM_M_GENERATE_OK, MSIM_M_REPLICATE_ACK,
+       MSIM_M_TS, MSIM_M_TS_OK /* lin-tso, service.clj:121-123 */ };
 
 /* Per-instance bookkeeping (not part of the algorithmic output bytes). */
 typedef struct msim_inst_meta {

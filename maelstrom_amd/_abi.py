@@ -15,7 +15,7 @@ ABI_VERSION = 1
 # enums (include/maelsim.h)
 OK, E_INVALID, E_NO_DEVICE, E_HIP, E_NOMEM, E_RANGE, E_UNSUPPORTED, E_OVERFLOW = 0, -1, -2, -3, -4, -5, -6, -7
 WL_ECHO, WL_BROADCAST, WL_G_SET, WL_LIN_KV, WL_TXN_LIST_APPEND, WL_PN_COUNTER, WL_G_COUNTER, WL_UNIQUE_IDS, WL_TXN_RW_REGISTER = range(9)
-NODE_ECHO, NODE_BCAST_FF, NODE_BCAST_FF_ECHOBACK, NODE_BCAST_ACK_RETRY, NODE_BCAST_RPC_ALL, NODE_G_SET, NODE_RAFT, NODE_TXN_SINGLE_KEY, NODE_PN_COUNTER, NODE_FLAKE_IDS, NODE_LIN_KV_PROXY, NODE_TXN_RW_HAT, NODE_TXN_MULTI_KEY = range(13)
+NODE_ECHO, NODE_BCAST_FF, NODE_BCAST_FF_ECHOBACK, NODE_BCAST_ACK_RETRY, NODE_BCAST_RPC_ALL, NODE_G_SET, NODE_RAFT, NODE_TXN_SINGLE_KEY, NODE_PN_COUNTER, NODE_FLAKE_IDS, NODE_LIN_KV_PROXY, NODE_TXN_RW_HAT, NODE_TXN_MULTI_KEY, NODE_TSO_IDS = range(14)
 SVC_LIN_KV, SVC_SEQ_KV, SVC_LWW_KV = range(3)
 CM_STRICT_SERIALIZABLE, CM_SERIALIZABLE, CM_SNAPSHOT_ISOLATION, CM_READ_COMMITTED, CM_READ_UNCOMMITTED = range(5)
 LAT_CONSTANT, LAT_UNIFORM, LAT_EXPONENTIAL = range(3)
@@ -30,7 +30,7 @@ NO_VALUE = 0xFFFFFFFF
 FLAG_ROWS_OVERFLOW, FLAG_PAYLOAD_OVERFLOW, FLAG_INBOX_OVERFLOW, FLAG_VALUES_OVERFLOW, FLAG_ROUND_LIMIT, FLAG_JOURNAL_OVERFLOW, FLAG_ARENA_OVERRUN = 1, 2, 4, 8, 16, 32, 64
 MSG_TYPES = ["", "init", "init_ok", "topology", "topology_ok", "echo", "echo_ok", "broadcast", "broadcast_ok", "read", "read_ok",
              "add", "add_ok", "replicate", "write", "write_ok", "cas", "cas_ok", "error", "request_vote", "request_vote_res",
-             "append_entries", "append_entries_res", "txn", "txn_ok", "generate", "generate_ok", "replicate_ack"]
+             "append_entries", "append_entries_res", "txn", "txn_ok", "generate", "generate_ok", "replicate_ack", "ts", "ts_ok"]
 ANOMALIES = {1: "G0", 2: "G1a", 4: "G1b", 8: "G1c", 16: "G-single", 32: "G2", 64: "internal", 128: "duplicate-elements",
              256: "incompatible-order", 512: "realtime", 1024: "dirty-update", 2048: "cyclic-versions"}
 MASK_WORDS = 4

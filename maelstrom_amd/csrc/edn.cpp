@@ -74,6 +74,8 @@ extern "C" int msim_history_edn_rows(const msim_config *cfg, const msim_op *rows
       if (f == MSIM_F_CAS) { o += '['; nil_or(o, (v >> 8) & 0xFF); o += ' '; nil_or(o, (v >> 16) & 0xFF); o += ']'; }
       else nil_or(o, (v >> 8) & 0xFF);
       o += ']';
+    } else if (f == MSIM_F_GENERATE && cfg->node_program == MSIM_NODE_TSO_IDS) {   // a lin-tso timestamp
+      if (typ == MSIM_T_OK) num(o, v); else o += "nil";
     } else if (f == MSIM_F_GENERATE) {
       if (typ == MSIM_T_OK) { o += '['; num(o, v >> 20); o += ' '; num(o, (v >> 5) & 0x7FFF); o += " \"n"; num(o, v & 31); o += "\"]"; }
       else o += "nil";

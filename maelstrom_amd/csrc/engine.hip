@@ -806,7 +806,7 @@ extern "C" int msim_create(const msim_config *cfg, int device, msim_ctx **out, c
   const bool wide_prog = c.node_program == MSIM_NODE_G_SET || c.node_program == MSIM_NODE_BCAST_FF || c.node_program == MSIM_NODE_BCAST_FF_ECHOBACK ||
                          c.node_program == MSIM_NODE_BCAST_ACK_RETRY || c.node_program == MSIM_NODE_BCAST_RPC_ALL || c.node_program == MSIM_NODE_PN_COUNTER;
   const bool wide = c.n_nodes > 32 && c.n_nodes <= 127 && wide_prog && c.concurrency == c.n_nodes;
-  const uint32_t svc_lanes = c.node_program == MSIM_NODE_LIN_KV_PROXY ? 1 : 0;  // the service has a lane of its own after the client slots
+  const uint32_t svc_lanes = c.node_program == MSIM_NODE_LIN_KV_PROXY || c.node_program == MSIM_NODE_TSO_IDS ? 1 : 0;  // the service has a lane of its own after the client slots
   if (!wide && (c.n_nodes > 32 || c.n_nodes + slots + svc_lanes > 64)) {
     set_err(err, errlen, "this build maps one cluster to one wavefront: n_nodes <= 32 and n_nodes + max(concurrency, n_nodes) <= 64 "
                          "(g-set, the counters and the broadcast programs with concurrency == n_nodes: up to 127 nodes)");
@@ -888,7 +888,7 @@ static uint64_t proto_scratch_words(const msim_config &c) {
   return (w + 3) & ~3ull;  // keep the spill area 16-byte aligned
 }
 static uint64_t scratch_words(const msim_config &c) {
-  const uint64_t queues = c.n_nodes + (c.node_program == MSIM_NODE_TXN_SINGLE_KEY || c.node_program == MSIM_NODE_LIN_KV_PROXY ? 1 : c.node_program == MSIM_NODE_TXN_MULTI_KEY ? 2 : 0);  // + the services
+  const uint64_t queues = c.n_nodes + (c.node_program == MSIM_NODE_TXN_SINGLE_KEY || c.node_program == MSIM_NODE_LIN_KV_PROXY || c.node_program == MSIM_NODE_TSO_IDS ? 1 : c.node_program == MSIM_NODE_TXN_MULTI_KEY ? 2 : 0);  // + the services
   uint64_t w = proto_scratch_words(c) + queues * c.spill_capacity * 4;
   if (msim_raft4_eligible(c)) w += msim_raft4_extra_scratch_words(c);   // raft4.hip keeps fewer envelopes in LDS
   if (msim_txn8_eligible(c)) w += msim_txn8_extra_scratch_words(c);     // txn8.hip likewise
@@ -963,7 +963,7 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   kp.dev_flags = msim_dev_flags(ctx);
   const bool wide = c.n_nodes > 32;
   size_t off = (wide ? WIDE_STAGE_ROWS : STAGE_ROWS) * 16;
-  const bool is_txn = c.node_program == MSIM_NODE_TXN_SINGLE_KEY, is_px = c.node_program == MSIM_NODE_LIN_KV_PROXY;
+  const bool is_txn = c.node_program == MSIM_NODE_TXN_SINGLE_KEY, is_px = c.node_program == MSIM_NODE_LIN_KV_PROXY || c.node_program == MSIM_NODE_TSO_IDS;
   const bool is_hat = c.node_program == MSIM_NODE_TXN_RW_HAT, is_mk = c.node_program == MSIM_NODE_TXN_MULTI_KEY;
   kp.mk_tcap = is_mk ? mk_tcap(c) : 0; kp.mk_ccap = is_mk ? mk_ccap(c) : 0;
   kp.off_inbox = (u32)off;
@@ -1025,8 +1025,14 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
     } break;
     case MSIM_NODE_LIN_KV_PROXY: {
       const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
-      if (c.nemesis_mask) { if (rnd) hipLaunchKernelGGL((svc_kernel<true, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((svc_kernel<true, false>), dim3(n), dim3(64), lds, st, kp); }
-      else { if (rnd) hipLaunchKernelGGL((svc_kernel<false, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((svc_kernel<false, false>), dim3(n), dim3(64), lds, st, kp); }
+      if (c.nemesis_mask) { if (rnd) hipLaunchKernelGGL((svc_kernel<true, true, false>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((svc_kernel<true, false, false>), dim3(n), dim3(64), lds, st, kp); }
+      else { if (rnd) hipLaunchKernelGGL((svc_kernel<false, true, false>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((svc_kernel<false, false, false>), dim3(n), dim3(64), lds, st, kp); }
+      e = hipGetLastError();
+    } break;
+    case MSIM_NODE_TSO_IDS: {   // unique-ids over the lin-tso service: the proxy's layout with the timestamp oracle on the service lane
+      const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
+      if (c.nemesis_mask) { if (rnd) hipLaunchKernelGGL((svc_kernel<true, true, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((svc_kernel<true, false, true>), dim3(n), dim3(64), lds, st, kp); }
+      else { if (rnd) hipLaunchKernelGGL((svc_kernel<false, true, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((svc_kernel<false, false, true>), dim3(n), dim3(64), lds, st, kp); }
       e = hipGetLastError();
     } break;
     case MSIM_NODE_TXN_SINGLE_KEY: {

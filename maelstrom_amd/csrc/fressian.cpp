@@ -92,6 +92,7 @@ std::string endpoint(uint32_t e, uint32_t n_nodes, uint32_t slots, const msim_co
     const char *name = "lin-kv";
     if (cfg->node_program == MSIM_NODE_LIN_KV_PROXY) name = cfg->proxy_service == MSIM_SVC_SEQ_KV ? "seq-kv" : cfg->proxy_service == MSIM_SVC_LWW_KV ? "lww-kv" : "lin-kv";
     else if (cfg->node_program == MSIM_NODE_TXN_MULTI_KEY && e == n_nodes + slots + 1) name = "lww-kv";
+    else if (cfg->node_program == MSIM_NODE_TSO_IDS) name = "lin-tso";
     std::snprintf(b, sizeof b, "%s", name);
   }
   return b;
@@ -99,13 +100,13 @@ std::string endpoint(uint32_t e, uint32_t n_nodes, uint32_t slots, const msim_co
 
 const char *const MSG_TYPES[] = {"", "init", "init_ok", "topology", "topology_ok", "echo", "echo_ok", "broadcast", "broadcast_ok", "read", "read_ok",
                                  "add", "add_ok", "replicate", "write", "write_ok", "cas", "cas_ok", "error", "request_vote", "request_vote_res",
-                                 "append_entries", "append_entries_res", "txn", "txn_ok", "generate", "generate_ok", "replicate_ack"};
+                                 "append_entries", "append_entries_res", "txn", "txn_ok", "generate", "generate_ok", "replicate_ack", "ts", "ts_ok"};
 
 bool is_reply(uint32_t t) {
   switch (t) {
     case MSIM_M_INIT_OK: case MSIM_M_TOPOLOGY_OK: case MSIM_M_ECHO_OK: case MSIM_M_BROADCAST_OK: case MSIM_M_READ_OK: case MSIM_M_ADD_OK:
     case MSIM_M_WRITE_OK: case MSIM_M_CAS_OK: case MSIM_M_ERROR: case MSIM_M_REQUEST_VOTE_RES: case MSIM_M_APPEND_ENTRIES_RES: case MSIM_M_TXN_OK:
-    case MSIM_M_GENERATE_OK: return true;
+    case MSIM_M_GENERATE_OK: case MSIM_M_TS_OK: return true;
     default: return false;
   }
 }
@@ -195,7 +196,10 @@ extern "C" int msim_journal_fressian_rows(const msim_config *cfg, const msim_eve
         else kv_int("value", wl == MSIM_WL_PN_COUNTER || wl == MSIM_WL_G_COUNTER ? (int64_t)(int32_t)e.a : (int64_t)e.a);
         break;
       case MSIM_M_ERROR: kv_int("code", e.a); break;
+      case MSIM_M_TS: break;
+      case MSIM_M_TS_OK: kv_int("ts", e.a); break;   // service.clj:123
       case MSIM_M_GENERATE_OK:
+        if (cfg->node_program == MSIM_NODE_TSO_IDS) { kv_int("id", e.a); break; }
         w.keyword("id", true); w.list_header(3); w.integer(e.a >> 20); w.integer((e.a >> 5) & 0x7FFF); w.str(endpoint(e.a & 31, N, slots, cfg), false);
         break;
       case MSIM_M_INIT_OK: case MSIM_M_TOPOLOGY_OK: case MSIM_M_BROADCAST_OK: case MSIM_M_ADD_OK: case MSIM_M_READ: case MSIM_M_GENERATE:

@@ -29,7 +29,7 @@ NODE_PROGRAMS = {"echo": A.NODE_ECHO, "broadcast-ff": A.NODE_BCAST_FF, "broadcas
                  "g-set": A.NODE_G_SET, "raft": A.NODE_RAFT, "single-key-txn": A.NODE_TXN_SINGLE_KEY,
                  "pn-counter": A.NODE_PN_COUNTER, "flake-ids": A.NODE_FLAKE_IDS, "lin-kv-proxy": A.NODE_LIN_KV_PROXY,
                  "txn-rw-register-hat": A.NODE_TXN_RW_HAT,
-                 "multi-key-txn": A.NODE_TXN_MULTI_KEY}   # (oracle + process bridge only: Engine() answers MSIM_E_UNSUPPORTED)
+                 "multi-key-txn": A.NODE_TXN_MULTI_KEY, "tso-ids": A.NODE_TSO_IDS}
 SERVICES = {"lin-kv": A.SVC_LIN_KV, "seq-kv": A.SVC_SEQ_KV, "lww-kv": A.SVC_LWW_KV}
 CONSISTENCY_MODELS = {"strict-serializable": A.CM_STRICT_SERIALIZABLE, "serializable": A.CM_SERIALIZABLE,
                       "snapshot-isolation": A.CM_SNAPSHOT_ISOLATION, "read-committed": A.CM_READ_COMMITTED,
@@ -409,8 +409,8 @@ def encode_pn_history(ops):
     return rows
 
 
-def decode_history(rows, payload, n_nodes, workload=A.WL_BROADCAST):
-    """Binary rows -> list of Jepsen op maps (SURVEY.md §8b 'History surface')."""
+def decode_history(rows, payload, n_nodes, workload=A.WL_BROADCAST, node_program=None):
+    """Binary rows -> list of Jepsen op maps (SURVEY.md §8b 'History surface').  `node_program` matters for unique-ids only (what an id is)."""
     ops = []
     for idx in range(len(rows)):
         tl, packed, value = int(rows["time_len"][idx]), int(rows["packed"][idx]), int(rows["value"][idx])
@@ -421,6 +421,8 @@ def decode_history(rows, payload, n_nodes, workload=A.WL_BROADCAST):
         if workload == A.WL_LIN_KV and f in (A.F_READ, A.F_WRITE, A.F_CAS):  # independent tuples, lin_kv.clj:53-67
             k, v1, v2 = value & 0xFF, _nil((value >> 8) & 0xFF), _nil((value >> 16) & 0xFF)
             op["value"] = [k, [v1, v2]] if f == A.F_CAS else [k, v1]
+        elif f == A.F_GENERATE and node_program == A.NODE_TSO_IDS:   # a lin-tso timestamp (service.clj:121-123)
+            op["value"] = value if typ == A.T_OK else None
         elif f == A.F_GENERATE:   # flake id [time count node-id], flake_ids.clj:30-31
             op["value"] = [value >> 20, (value >> 5) & 0x7FFF, f"n{value & 31}"] if typ == A.T_OK else None
         elif f == A.F_TXN:

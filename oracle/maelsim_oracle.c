@@ -68,7 +68,7 @@ enum { M_INIT = 1, M_INIT_OK, M_TOPOLOGY, M_TOPOLOGY_OK, M_ECHO, M_ECHO_OK, M_BR
        M_READ, M_READ_OK, M_ADD, M_ADD_OK, M_REPLICATE,
        M_WRITE, M_WRITE_OK, M_CAS, M_CAS_OK, M_ERROR,                                   /* lin-kv RPCs, doc/workloads.md */
        M_REQUEST_VOTE, M_REQUEST_VOTE_RES, M_APPEND_ENTRIES, M_APPEND_ENTRIES_RES,      /* raft.py:290-297,412-420 */
-       M_TXN, M_TXN_OK, M_GENERATE, M_GENERATE_OK, M_REPLICATE_ACK };                                                                /* txn_list_append.clj:73-80 */
+       M_TXN, M_TXN_OK, M_GENERATE, M_GENERATE_OK, M_REPLICATE_ACK, M_TS, M_TS_OK };                                                                /* txn_list_append.clj:73-80 */
 
 /* RNG streams */
 enum { S_GEN = 1, S_GEN2 = 2, S_GEN3 = 3, S_LATENCY = 4, S_LOSS = 5, S_NODE = 11, S_SVC = 12,
@@ -183,7 +183,7 @@ static void inbox_push(sim_t *s, u32 ep, qent q) {
   inbox_t *b = &s->inbox[ep];
   if (b->n == b->cap) { b->cap = b->cap ? b->cap * 2 : 8; b->v = (qent *)realloc(b->v, b->cap * sizeof(qent)); }
   b->v[b->n++] = q;
-  u32 lim = is_client(s, ep) ? (reusable_clients(s) && s->cfg.workload != MSIM_WL_UNIQUE_IDS ? 32u : 2u) /* Reusable clients collect late replies */
+  u32 lim = is_client(s, ep) ? (reusable_clients(s) && (s->cfg.workload != MSIM_WL_UNIQUE_IDS || s->cfg.node_program == MSIM_NODE_TSO_IDS) ? 32u : 2u) /* Reusable clients collect late replies */
                              : s->cfg.inbox_capacity + s->cfg.spill_capacity; /* engine capacities: overflow is flagged, never silent */
   if (b->n > lim) s->meta.flags |= MSIM_FLAG_INBOX_OVERFLOW;
 }
@@ -387,6 +387,7 @@ static void node_handle(sim_t *s, u32 node, const qent *q) {
   if (s->cfg.node_program == MSIM_NODE_TXN_SINGLE_KEY) { txn_node_handle(s, node, q); return; }
   if (s->cfg.node_program == MSIM_NODE_TXN_MULTI_KEY) { mk_node_handle(s, node, q); return; }
   if (s->cfg.node_program == MSIM_NODE_LIN_KV_PROXY) { px_node_handle(s, node, q); return; }
+  if (s->cfg.node_program == MSIM_NODE_TSO_IDS) { tso_node_handle(s, node, q); return; }
   if (s->cfg.node_program == MSIM_NODE_TXN_RW_HAT) { hat_node_handle(s, node, q); return; }
   switch (q->type) {
     case M_INIT: /* node.rb init handler -> init_ok; g-set starts its periodic task (node.rb:129-138) */
@@ -738,7 +739,7 @@ static void run_instance(sim_t *s) {
         qent q = s->committed[e]; s->has_committed[e] = 0;
         s->st.all_recv++; s->st.servers_recv++;
         jlog(s, 1, q.id, q.type, q.a, q.b, q.src, e);
-        if (s->mk) mk_svc_handle(s, e, &q); else if (s->svc) px_svc_handle(s, &q); else svc_handle(s, &q);
+        if (s->mk) mk_svc_handle(s, e, &q); else if (s->cfg.node_program == MSIM_NODE_TSO_IDS) tso_svc_handle(s, &q); else if (s->svc) px_svc_handle(s, &q); else svc_handle(s, &q);
       }
     commit_sends(s);
     for (u32 e = 0; e < E; e++) poll_endpoint(s, e);
@@ -776,7 +777,7 @@ static sim_t *sim_new(const msim_config *cfg, uint64_t instance, msim_op *rows, 
   sim_t *s = (sim_t *)calloc(1, sizeof(sim_t));
   s->cfg = *cfg;
   s->N = cfg->n_nodes; s->C = cfg->concurrency; s->CS = s->C > s->N ? s->C : s->N;
-  s->S = cfg->node_program == MSIM_NODE_TXN_SINGLE_KEY || cfg->node_program == MSIM_NODE_LIN_KV_PROXY ? 1 : cfg->node_program == MSIM_NODE_TXN_MULTI_KEY ? 2 : 0; /* lin-kv (+ lww-kv) */
+  s->S = cfg->node_program == MSIM_NODE_TXN_SINGLE_KEY || cfg->node_program == MSIM_NODE_LIN_KV_PROXY || cfg->node_program == MSIM_NODE_TSO_IDS ? 1 : cfg->node_program == MSIM_NODE_TXN_MULTI_KEY ? 2 : 0; /* lin-kv (+ lww-kv) */
   s->E = s->N + s->CS + s->S;
   if (s->E > 255) { free(s); return NULL; }
   s->W = (cfg->max_values + 31) / 32;
@@ -804,7 +805,7 @@ static sim_t *sim_new(const msim_config *cfg, uint64_t instance, msim_op *rows, 
     for (u32 i = 0; i < s->N; i++) { rnode *r = &s->raft[i]; r->voted_for = -1; r->leader = -1; r->last_applied = 1; memset(r->kv, 0xFF, sizeof r->kv);
       rentry e0; memset(&e0, 0, sizeof e0); r_append(r, &e0, 1); }
   }
-  if (cfg->node_program == MSIM_NODE_LIN_KV_PROXY) {
+  if (cfg->node_program == MSIM_NODE_LIN_KV_PROXY || cfg->node_program == MSIM_NODE_TSO_IDS) {
     svc_t *v = (svc_t *)calloc(1, sizeof(svc_t));
     v->cb = (pslot *)calloc((size_t)s->N * PX_SLOTS, sizeof(pslot));
     v->client_idx = (u32 *)calloc(s->E, 4);

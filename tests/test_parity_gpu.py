@@ -377,3 +377,30 @@ def test_raft_runs_match_the_recorded_reference_replays(lib):
                 sends = ev[((ev["msg"] >> 7) & 1) == 0]
                 h = hashlib.sha256(np.stack([sends["time_us"], sends["msg"], sends["a"], sends["route"]], axis=1).astype(np.uint32).tobytes())
                 assert h.hexdigest() == want
+
+
+@pytest.mark.parametrize("kw", [
+    dict(node_count=3, rate=100, time_limit=3, latency=5),
+    dict(node_count=5, concurrency=10, rate=300, time_limit=3, latency=10, latency_dist="exponential"),
+    dict(node_count=3, rate=200, time_limit=6, latency=3, nemesis=["partition"], nemesis_interval=2, journal_capacity=200000),
+    dict(node_count=4, concurrency=12, rate=500, time_limit=4, latency=20, latency_dist="uniform", p_loss=0.05),
+    dict(node_count=1, rate=50, time_limit=2),
+])
+def test_unique_ids_over_lin_tso_parity(lib, kw):
+    """unique-ids served through the lin-tso timestamp oracle (service.clj:116-132): svc_kernel<.., TSO> against oracle/svc_nodes.inc,
+    which the process bridge pins with a real node process (tests/test_process_bridge.py)."""
+    cfg = E.test_config("unique-ids", bin="tso-ids", seed=17, **kw)
+    ora = _compare(cfg, 0, 6)
+    for i in range(6):
+        ops = E.decode_history(*ora.history(i), cfg.n_nodes, cfg.workload, cfg.node_program)
+        ids = sorted(o["value"] for o in ops if o["type"] == ":ok")
+        assert len(set(ids)) == len(ids) > 20
+
+
+def test_unique_ids_over_lin_tso_pass_the_device_checker(lib):
+    cfg = E.test_config("unique-ids", bin="tso-ids", node_count=3, rate=300, time_limit=5, latency=5, nemesis=["partition"], nemesis_interval=2, seed=18)
+    with E.Engine(cfg) as eng:
+        eng.run(0, 32)
+        eng.check()
+        res = eng.check_results()
+        assert (res["valid"] == 1).all() and (res["duplicated_count"] == 0).all() and (res["ok_count"] > 100).all()

@@ -34,7 +34,7 @@ def _norm(ops):
 def _against_oracle(workload, argv, oracle_bin=None, **kw):
     cfg = E.test_config(workload, bin=oracle_bin, **kw)
     ora = O.run(cfg, 0, 1)
-    want = E.decode_history(*ora.history(0), cfg.n_nodes, cfg.workload)
+    want = E.decode_history(*ora.history(0), cfg.n_nodes, cfg.workload, cfg.node_program)
     b = B.Bridge(workload, argv, **kw)
     got = b.run()
     assert b.errors == []
@@ -90,6 +90,15 @@ def test_lin_tso_service_serves_a_unique_ids_node():
             assert per.get(op["process"], -1) < op["value"]
             per[op["process"]] = op["value"]
     assert b.stats["servers_send"] == 2 * len(ids)                     # one ts / ts_ok pair per id
+
+
+@pytest.mark.parametrize("kw", [dict(node_count=3, rate=100, time_limit=3, latency=5, seed=3),
+                                dict(node_count=5, concurrency=10, rate=200, time_limit=2, latency=10, latency_dist="exponential", seed=4),
+                                dict(node_count=3, rate=100, time_limit=6, latency=3, nemesis=["partition"], nemesis_interval=2, seed=6)])
+def test_oracle_tso_node_and_service_equal_the_process_node_over_the_bridges_lin_tso(kw):
+    """oracle/svc_nodes.inc's lin-tso service and its unique-ids node against the real node process (tools/harness_tso_node.py)
+    talking to the bridge's lin-tso (a transliteration of service.clj:116-132): same history, rounds and net statistics."""
+    _against_oracle("unique-ids", TSO_NODE, oracle_bin="tso-ids", **kw)
 
 
 def test_services_behind_the_bridge():

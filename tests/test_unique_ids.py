@@ -51,3 +51,32 @@ def test_checker_finds_duplicates():
     res = _check_rows(rows)
     assert res.valid == 0 and res.duplicated_count == 2 and res.ok_count == 6 and res.attempt_count == 1   # 5 and 7 repeat
     assert list(res.stable_latency_ms)[:2] == [5, 9]
+
+
+def test_lin_tso_hands_out_every_integer_once_in_completion_order_per_client():
+    """service.clj:116-132 through the oracle's node + service (pinned by a real node process on the bridge, tests/test_process_bridge.py):
+    the ids of a run are 0, 1, 2, ... without gaps while nothing is lost, each client sees its own ids grow, one ts / ts_ok pair per id."""
+    cfg = E.test_config("unique-ids", bin="tso-ids", node_count=3, rate=200, time_limit=5, latency=5, seed=3)
+    r = O.run(cfg, 0, 3)
+    for i in range(3):
+        assert r.meta["flags"][i] == 0
+        ops = E.decode_history(*r.history(i), cfg.n_nodes, cfg.workload, cfg.node_program)
+        ids = [o["value"] for o in ops if o["type"] == ":ok"]
+        assert len(ids) > 500 and sorted(ids) == list(range(len(ids)))
+        per = {}
+        for o in ops:
+            if o["type"] == ":ok":
+                assert per.get(o["process"], -1) < o["value"]
+                per[o["process"]] = o["value"]
+        assert int(r.stats[i]["servers_send"]) == 2 * len(ids)
+        res = E.check_unique_history(r.history(i)[0]) if hasattr(E, "check_unique_history") else None
+        assert res is None or res["valid?"] is True
+
+
+def test_lin_tso_under_loss_still_never_repeats_an_id():
+    cfg = E.test_config("unique-ids", bin="tso-ids", node_count=4, concurrency=8, rate=300, time_limit=6, latency=10, latency_dist="exponential", p_loss=0.1, seed=4)
+    r = O.run(cfg, 0, 2)
+    for i in range(2):
+        ops = E.decode_history(*r.history(i), cfg.n_nodes, cfg.workload, cfg.node_program)
+        ids = [o["value"] for o in ops if o["type"] == ":ok"]
+        assert len(set(ids)) == len(ids) > 100 and any(o["type"] == ":info" for o in ops)
