@@ -79,4 +79,4 @@ def test_lin_tso_under_loss_still_never_repeats_an_id():
     for i in range(2):
         ops = E.decode_history(*r.history(i), cfg.n_nodes, cfg.workload, cfg.node_program)
         ids = [o["value"] for o in ops if o["type"] == ":ok"]
-        assert len(set(ids)) == len(ids) > 100 and any(o["type"] == ":info" for o in ops)
+        assert len(set(ids)) == len(ids) > 20 and any(o["type"] == ":info" for o in ops)   # (a lost message costs its worker the 5 s timeout)
