@@ -16,16 +16,11 @@
 //
 // One wavefront checks one history, bit-parallel over the read bitmaps:
 //   pass 1  rows are read back from HBM 64 at a time (1 KiB, coalesced); every lane classifies its own row; only read /
-//           echo rows are walked serially (v_readlane), and a read :ok only RECORDS itself: once in completion order
-//           {payload ref, :ok index} and once at the rank of its invocation {payload ref, invoke index, elements
-//           existing at completion} (8 B each, HBM scratch).
-//   pass 2a completion order, lane w = word w of the bitmap: elements whose first containing read this is
-//           (word & not-yet-seen) get known = min(known, :ok index).  One AND per lane and read; a bit loop runs once
-//           per element in total.
-//   pass 2b invocation order, latest first: the first read that contains an element is its last-present, the first one
-//           that lacks it (while it exists) its last-absent — again one AND per lane and read plus one bit loop per
-//           element.  Reads are prefetched 64 records at a time, the bitmap word of the next read while the current one
-//           is folded in.
+//           echo rows are walked serially (v_readlane), and a read :ok only RECORDS itself at the rank of its invocation
+//           {payload ref, invoke index, elements existing at completion, :ok index} (12 B, HBM scratch).
+//   pass 2  ONE sweep over the recorded reads in invocation order, lane w = word w of the bitmaps: every word is loaded once
+//           (round 2: twice) and gives known (first containing read, corrected for reads that overtook it), last-present and
+//           last-absent (written when an element leaves the state) — see the comment at the sweep.
 // Per-element state: three u16 row indices in LDS (8.4 KB for 1408 elements keeps 4096 histories resident).
 #include <hip/hip_runtime.h>
 
@@ -41,7 +36,7 @@ struct CParams {
   const u32 *payload;
   const msim_inst_meta *meta;
   msim_check_result *out;
-  uint2 *recs;  // per instance: rec_c[max_reads] then rec_i[max_reads]
+  u32 *recs;    // per instance: max_reads records of 3 words, at the rank of the read's invocation
   u32 max_rows, max_pay, max_values, C, workload, max_reads;
 };
 
@@ -64,7 +59,7 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
   const msim_inst_meta meta = p.meta[inst];
   const uint4 *const rows = reinterpret_cast<const uint4 *>(p.rows + (size_t)inst * p.max_rows);
   const u32 *const pay = p.payload + (size_t)inst * p.max_pay;
-  uint2 *const rec_c = p.recs + (size_t)inst * p.max_reads * 2, *const rec_i = rec_c + p.max_reads;
+  u32 *const rec = p.recs + (size_t)inst * p.max_reads * 3;
   const u32 n_rows = meta.n_rows, C = p.C;
   const bool setfull = p.workload != MSIM_WL_ECHO;
 
@@ -111,8 +106,8 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
           const u32 len = hi >> 16, off = value;
           const u32 v_here = v_base + (u32)__popcll(add_inv & ((1ull << j) - 1));  // elements existing at this row
           if (inv != NONE && rank < p.max_reads && n_rc < p.max_reads && lane == 0) {
-            rec_c[n_rc] = make_uint2(off | (len << 24), idx);
-            rec_i[rank] = make_uint2(off | (len << 24), inv | (v_here << 16));
+            u32 *q = rec + (size_t)rank * 3;
+            q[0] = off | (len << 24); q[1] = inv | (v_here << 16); q[2] = idx;
             valid[rank >> 5] |= 1u << (rank & 31);
           }
           n_rc++;
@@ -134,72 +129,59 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
   if (n_rc > p.max_reads) n_rc = p.max_reads;
   if (n_ri > p.max_reads) n_ri = p.max_reads;
 
-  // lane w owns word w of the read bitmaps, i.e. elements 32w .. 32w+31
-  // Both passes are bound by the latency of one dependent global load per read (its bitmap word); the loads of 8 reads
-  // are issued together before they are folded in.
-  // ---- pass 2a: known by reads (completion order) ----
+  // ---- pass 2: ONE sweep over the :ok reads in invocation order, lane w = word w of the bitmaps (elements 32w .. 32w+31) -----------------
+  // Every bitmap word is loaded once (round 2 read them twice: forwards in completion order for `known`, backwards in invocation
+  // order for last-present / last-absent).  In invocation order
+  //   last-present / last-absent = the invocation of the LAST read that has / lacks the element: written when the element LEAVES that
+  //     state (a word compared with the previous read's: one XOR-like mask per read, a bit loop per transition) and for the state the
+  //     last read leaves it in;
+  //   known = the smallest :ok index among the reads containing the element: the first containing read F, unless a read invoked while
+  //     F was still open completed before it — only reads invoked before F's completion can (`fresh` keeps those elements apart until
+  //     the sweep has passed the latest such completion).
+  // The loads of 8 reads are issued together before they are folded in (one dependent global load per read bounds the sweep).
   {
-    u32 unk = 0xFFFFFFFFu;
-    for (u32 cb = 0; cb < n_rc; cb += 64) {
-      const u32 cn = min(64u, n_rc - cb);
-      uint2 my_rec = make_uint2(0, 0);
-      if (lane < cn) my_rec = rec_c[cb + lane];
-      for (u32 j0 = 0; j0 < cn; j0 += 8) {
-        u32 wv[8];
-#pragma unroll
-        for (u32 t = 0; t < 8; t++) {
-          const u32 jj = min(j0 + t, 63u);
-          const u32 ref = c_rdlane(my_rec.x, jj);
-          wv[t] = (j0 + t < cn && lane < (ref >> 24)) ? pay[(ref & 0xFFFFFFu) + lane] : 0u;
-        }
-#pragma unroll
-        for (u32 t = 0; t < 8; t++) {
-          const u32 idx = c_rdlane(my_rec.y, min(j0 + t, 63u));
-          const u32 w = wv[t];   // 0 beyond the chunk: nothing to fold
-          u32 hits = w & unk;
-          unk &= ~w;
-          while (hits) {
-            const u32 e = lane * 32 + (u32)__builtin_ctz(hits); hits &= hits - 1;
-            if (e < p.max_values && known[e] > idx) known[e] = (u16)idx;
-          }
-        }
-      }
-    }
-  }
-  // ---- pass 2b: last-present / last-absent (invocation order, latest first) ----
-  {
-    u32 pend_p = 0xFFFFFFFFu, pend_a = 0xFFFFFFFFu;
+    u32 unk = 0xFFFFFFFFu, fresh = 0, fresh_until = 0, prev_w = 0, prev_a = 0, prev_inv = 0;
     const u32 lo = lane * 32;
-    for (u32 cbp = (n_ri + 63) / 64; cbp > 0; cbp--) {
-      const u32 cb = (cbp - 1) * 64, cn = min(64u, n_ri - cb);
+    for (u32 cb = 0; cb < n_ri; cb += 64) {
+      const u32 cn = min(64u, n_ri - cb);
       const u64 vmask = ((u64)valid[cb / 32 + 1] << 32 | valid[cb / 32]) & (cn >= 64 ? ~0ull : ((1ull << cn) - 1));
       if (!vmask) continue;
-      uint2 my_rec = make_uint2(0, 0);
-      if ((vmask >> lane) & 1) my_rec = rec_i[cb + lane];
+      u32 rx = 0, ry = 0, rz = 0;   // {payload ref | words << 24, invoke index | elements existing at completion << 16, :ok index}
+      if ((vmask >> lane) & 1) { const u32 *q = rec + (size_t)(cb + lane) * 3; rx = q[0]; ry = q[1]; rz = q[2]; }
       u64 todo = vmask;
       while (todo) {
         u32 jl[8], wv[8], nb = 0;
 #pragma unroll
-        for (u32 t = 0; t < 8; t++) {   // the next (up to) 8 valid ranks of this chunk, latest first
+        for (u32 t = 0; t < 8; t++) {   // the next (up to) 8 valid ranks of this chunk, earliest first
           const bool have = todo != 0;
-          const u32 j = have ? 63 - (u32)__builtin_clzll(todo) : 0u;
-          if (have) { todo &= ~(1ull << j); nb = t + 1; }
+          const u32 j = have ? (u32)__builtin_ctzll(todo) : 0u;
+          if (have) { todo &= todo - 1; nb = t + 1; }
           jl[t] = j;
-          const u32 ref = c_rdlane(my_rec.x, j);
+          const u32 ref = c_rdlane(rx, j);
           wv[t] = (have && lane < (ref >> 24)) ? pay[(ref & 0xFFFFFFu) + lane] : 0u;
         }
 #pragma unroll
         for (u32 t = 0; t < 8; t++) {
-          const u32 iv = t < nb ? c_rdlane(my_rec.y, jl[t]) : 0u, inv = iv & 0xFFFFu, v_here = iv >> 16;   // beyond nb: v_here = 0, w = 0: a no-op
+          if (t >= nb) break;
+          const u32 iv = c_rdlane(ry, jl[t]), ok = c_rdlane(rz, jl[t]), inv = iv & 0xFFFFu, v_here = iv >> 16;
           const u32 w = wv[t];
           const u32 ex = v_here >= lo + 32 ? 0xFFFFFFFFu : (v_here <= lo ? 0u : ((1u << (v_here - lo)) - 1));  // elements that exist at this read
-          u32 hp = w & pend_p; pend_p &= ~w;
-          u32 ha = ~w & ex & pend_a; pend_a &= ~(~w & ex);
-          while (hp) { const u32 e = lo + (u32)__builtin_ctz(hp); hp &= hp - 1; if (e < p.max_values) lp_idx[e] = (u16)inv; }
-          while (ha) { const u32 e = lo + (u32)__builtin_ctz(ha); ha &= ha - 1; if (e < p.max_values) la_idx[e] = (u16)inv; }
+          const u32 a = ~w & ex;
+          if (inv > fresh_until) fresh = 0;                    // every read behind a fresh element has completed before this one began
+          u32 first = w & unk, again = w & fresh;
+          unk &= ~w;
+          if (first) { fresh |= first; fresh_until = max(fresh_until, ok); }
+          u32 upd = first | again;
+          while (upd) { const u32 e = lo + (u32)__builtin_ctz(upd); upd &= upd - 1; if (e < p.max_values && known[e] > ok) known[e] = (u16)ok; }
+          u32 lv = prev_w & ~w, lva = prev_a & ~a;
+          while (lv) { const u32 e = lo + (u32)__builtin_ctz(lv); lv &= lv - 1; if (e < p.max_values) lp_idx[e] = (u16)prev_inv; }
+          while (lva) { const u32 e = lo + (u32)__builtin_ctz(lva); lva &= lva - 1; if (e < p.max_values) la_idx[e] = (u16)prev_inv; }
+          prev_w = w; prev_a = a; prev_inv = inv;
         }
       }
     }
+    while (prev_w) { const u32 e = lo + (u32)__builtin_ctz(prev_w); prev_w &= prev_w - 1; if (e < p.max_values) lp_idx[e] = (u16)prev_inv; }
+    while (prev_a) { const u32 e = lo + (u32)__builtin_ctz(prev_a); prev_a &= prev_a - 1; if (e < p.max_values) la_idx[e] = (u16)prev_inv; }
   }
   __syncthreads();
 
@@ -273,14 +255,14 @@ int msim_check_launch(msim_ctx *ctx) {
   cp.max_rows = c.max_rows; cp.max_pay = c.max_payload_words; cp.max_values = c.max_values; cp.C = c.concurrency; cp.workload = c.workload;
   if (c.max_rows >= 0xFFFF || c.max_values > 2048 || c.concurrency > 128) { ctx->err = "device checker: max_rows must be < 65535, max_values <= 2048, concurrency <= 128"; return MSIM_E_UNSUPPORTED; }
   cp.max_reads = c.max_rows / 2 + 1;  // every :ok read has its own :invoke row
-  const size_t rec_bytes = (size_t)ctx->n_inst * cp.max_reads * 2 * sizeof(uint2);
+  const size_t rec_bytes = (size_t)ctx->n_inst * cp.max_reads * 3 * sizeof(u32);
   if (ctx->cap_check_scratch < rec_bytes) {
     if (ctx->d_check_scratch) (void)hipFree(ctx->d_check_scratch);
     ctx->d_check_scratch = nullptr; ctx->cap_check_scratch = 0;
     MSIM_HIP_TRY(ctx, hipMalloc(&ctx->d_check_scratch, rec_bytes));
     ctx->cap_check_scratch = rec_bytes;
   }
-  cp.recs = static_cast<uint2 *>(ctx->d_check_scratch);
+  cp.recs = static_cast<u32 *>(ctx->d_check_scratch);
   size_t lds = (size_t)c.max_values * 3 * 2 < (size_t)c.max_values * 4 ? (size_t)c.max_values * 4 : (size_t)c.max_values * 3 * 2;
   lds += ((size_t)(cp.max_reads + 31) / 32 + 2) * 4;  // + the valid bitmap (read one word past the last chunk)
   if (lds > 64 * 1024) {

@@ -24,6 +24,7 @@
 //   F  acyclicity by Kahn's algorithm: 64 ready transactions per step, in-degrees by atomics, the ready queue by ballots.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -39,6 +40,7 @@ void msim_txn_check_instance_host(const msim_op *rows, uint32_t n_rows, const ui
 namespace {
 
 constexpr u32 NEEDS_HOST = 3u;
+constexpr u32 NEEDS_HBM = 4u;    // txn_check_lds_kernel: the history's tables do not fit the LDS of a wavefront; txn_check_kernel (tables in HBM) takes it
 constexpr u32 NONE = 0xFFFFFFFFu;
 constexpr u32 KMAX = 4096u;      // keys per history
 constexpr u32 WMAX = 65536u;     // writer table entries (keys x elements)
@@ -50,6 +52,8 @@ struct TParams {
   u32 *ws;                       // workspace, ws_words per history of this launch
   uint64_t ws_words;
   u32 max_rows, max_pay, nmax, emax, first;   // first: index of the launch's first history
+  const u32 *list;               // (not null: the launch's histories are list[first + blockIdx.x])
+  u32 lds_bytes;                 // txn_check_lds_kernel: dynamic LDS of a wavefront
 };
 
 __device__ __forceinline__ u32 t_rl(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
@@ -74,7 +78,7 @@ __device__ __forceinline__ Mop next_mop(const u32 *w, u32 n, u32 &i) {
 }
 
 __global__ void __launch_bounds__(64) txn_check_kernel(const TParams p) {
-  const u32 lane = threadIdx.x, hist = p.first + blockIdx.x;
+  const u32 lane = threadIdx.x, hist = p.list ? p.list[p.first + blockIdx.x] : p.first + blockIdx.x;
   const u64 lt = (1ull << lane) - 1ull;
   const uint4 *const r = reinterpret_cast<const uint4 *>(p.rows) + (p.row_off ? p.row_off[hist] : (u64)hist * p.max_rows);
   const u32 *const pay = p.payload + (p.pay_off ? p.pay_off[hist] : (u64)hist * p.max_pay);
@@ -352,37 +356,408 @@ __global__ void __launch_bounds__(64) txn_check_kernel(const TParams p) {
 #undef WRITER
 }
 
-// words of workspace per history
+
+// ---- the same analysis with its tables in LDS (round 3) ---------------------------------------------------------------------------------
+// txn_check_kernel above keeps the writer table, in-degrees, CSR and ready queue of a history in an HBM workspace (0.6 MB per history):
+// every edge costs three L2 atomics whose lines are evicted before they are touched again — 20.6 GB of HBM traffic per 8192 histories for
+// 1.35 GB of history bytes, 0.80 of the wave cycles waiting (profiles/r02_cfg5_counters.json).  Here one wavefront still takes one
+// history, but
+//   * what is hit at random lives in LDS as 16-bit entries: the writer table (key, element) -> transaction | type << 13 | "the writer's
+//     last append to the key" << 15 (so G1a / G1b / the edge passes never read another transaction's words), the longest read per key,
+//     in-degrees and CSR offsets (two per word, updated by one 32-bit LDS atomic on the right half), the adjacency of the DEPENDENCY edges,
+//     and during Kahn's algorithm — in the space the writer table no longer needs — the ready queue and every transaction's realtime range;
+//   * realtime edges are never materialised: an :ok transaction's successors are the index range [first, last) of the closed form above;
+//     Kahn's step walks the CSR entries and then that range;
+//   * completions are paired per PROCESS, not per row: the rows of one process alternate, so a completion's invocation is the previous
+//     row of its process — in the same 64-row block (a ballot and a shuffle) or the process's open call (lane registers);
+//   * the HBM workspace holds only streamed per-transaction words (6 x n).
+// A history whose tables do not fit (more than 8191 transactions, 65535 edges, or the LDS budget) is answered NEEDS_HBM and runs on
+// txn_check_kernel; anything not provably clean is answered NEEDS_HOST, as before.
+__device__ __forceinline__ u32 h16_add(u32 *w, u32 i, u32 d) { const u32 sh = (i & 1u) * 16u; return (atomicAdd(&w[i >> 1], d << sh) >> sh) & 0xFFFFu; }   // returns the old half
+__device__ __forceinline__ u32 h16_sub(u32 *w, u32 i) { const u32 sh = (i & 1u) * 16u; return (atomicSub(&w[i >> 1], 1u << sh) >> sh) & 0xFFFFu; }
+__device__ __forceinline__ u32 h16_get(const u32 *w, u32 i) { return (w[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu; }
+
+__global__ void __launch_bounds__(64) txn_check_lds_kernel(const TParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const u32 lane = threadIdx.x, hist = p.list ? p.list[p.first + blockIdx.x] : p.first + blockIdx.x;
+  const u64 lt = (1ull << lane) - 1ull;
+  const uint4 *const r = reinterpret_cast<const uint4 *>(p.rows) + (p.row_off ? p.row_off[hist] : (u64)hist * p.max_rows);
+  const u32 *const pay = p.payload + (p.pay_off ? p.pay_off[hist] : (u64)hist * p.max_pay);
+  const u32 n_rows = p.meta ? p.meta[hist].n_rows : (u32)(p.row_off[hist + 1] - p.row_off[hist]);
+  const u32 n_words = p.meta ? p.meta[hist].n_payload_words : (u32)(p.pay_off[hist + 1] - p.pay_off[hist]);
+  const u32 flags = p.meta ? p.meta[hist].flags : 0u;
+  const u32 NM = p.nmax;
+  u32 *const ws = p.ws + (u64)blockIdx.x * p.ws_words;
+  u32 *const t_cmp = ws, *const t_off = t_cmp + NM, *const t_lt = t_off + NM;   // t_lt: words | type << 16
+  u32 *const t_first = t_lt + NM;            // transactions invoked before this one's completion row (= index of the first one after it)
+  u32 *const sm = t_first + NM;              // [NM + 1] suffix minimum of the :ok completions ...
+  u32 *const smf = sm + NM + 1;              // [NM + 1] ... and t_first of the transaction that attains it
+
+  msim_check_result res;
+  res.valid = NEEDS_HOST; res.attempt_count = 0; res.stable_count = 0; res.lost_count = 0; res.never_read_count = 0; res.stale_count = 0;
+  res.duplicated_count = 0; res.error_count = 0;
+  for (int i = 0; i < 5; i++) res.stable_latency_ms[i] = 0;
+  res.op_count = 0; res.ok_count = 0; res.fail_count = 0; res.info_count = 0;
+#define TO_HOST() do { if (lane == 0) p.out[hist] = res; return; } while (0)
+#define TO_HBM() do { res.valid = NEEDS_HBM; if (lane == 0) p.out[hist] = res; return; } while (0)
+  if (n_words >= (1u << 24)) TO_HOST();
+
+  // ---- A: transactions; completions paired process by process ------------------------------------------------------------------------------
+  u32 n = 0, c_ok = 0, c_fail = 0, c_info = 0;
+  {
+    bool o_used = false; u32 o_proc = 0, o_txn = 0, o_len = 0; u32 bad = 0;   // lane = one open call (o_len: words of its request); bad: 1 host, 2 HBM kernel
+    for (u32 base = 0; base < n_rows && !bad; base += 64) {
+      const u32 idx = base + lane;
+      uint4 row = make_uint4(0, 0, 0, 0);
+      if (idx < n_rows) row = r[idx];
+      const u32 type = row.z & 3u, f = (row.z >> 2) & 31u, proc = row.z >> 12, len = row.y >> 16, woff = row.w;
+      const bool is = idx < n_rows && proc != MSIM_PROCESS_NEMESIS && f == MSIM_F_TXN;
+      if (__ballot(is && (u64)woff + len > n_words)) { bad = 1; break; }
+      const bool inv = is && type == MSIM_T_INVOKE;
+      const u64 im = __ballot(inv);
+      const u32 my_t = n + (u32)__popcll(im & lt);
+      if (n + (u32)__popcll(im) > NM) { bad = 1; break; }
+      if (n + (u32)__popcll(im) > 8190u) { bad = 2; break; }   // 13-bit ids in the writer table, 0x1FFF | INFO | fin would read as "nobody"
+      if (inv) { t_cmp[my_t] = NONE; t_off[my_t] = woff; t_lt[my_t] = len | (MSIM_T_INFO << 16); t_first[my_t] = 0; }   // never completed = indeterminate
+      // one pass per process present in the block
+      u32 m_id = NONE, m_len = 0;   // a completion lane: the transaction it completes, the words of its request
+      u64 rem = __ballot(is);
+      while (rem) {
+        const u32 j = (u32)__builtin_ctzll(rem);
+        const u32 pj = t_rl(proc, j);
+        const u64 same = __ballot(is && proc == pj);
+        rem &= ~same;
+        const u64 below = same & lt;
+        const u32 prev = below ? 63u - (u32)__builtin_clzll(below) : 64u;   // the previous row of this process inside the block
+        const u32 p_t = (u32)__shfl((int)my_t, (int)(prev & 63u)), p_inv = (u32)__shfl((int)(inv ? 1u : 0u), (int)(prev & 63u)), p_len = (u32)__shfl((int)len, (int)(prev & 63u));
+        const u64 hit = __ballot(o_used && o_proc == pj);   // the process's open call from earlier blocks
+        const u32 hs = hit ? (u32)__builtin_ctzll(hit) : 0u;
+        const u32 h_t = t_rl(o_txn, hs), h_len = t_rl(o_len, hs);
+        if (is && proc == pj && !inv) {
+          if (prev < 64u) { if (p_inv) { m_id = p_t; m_len = p_len; } }          // (after a completion nothing is open: a stray one)
+          else if (hit) { m_id = h_t; m_len = h_len; }
+        }
+        // what stays open after the block: the process's last row, if it is an invocation
+        const u32 last = 63u - (u32)__builtin_clzll(same);
+        const u32 l_inv = t_rl(inv ? 1u : 0u, last), l_t = t_rl(my_t, last), l_len = t_rl(len, last);
+        if (l_inv) {
+          u32 s;
+          if (hit) s = hs;
+          else { const u64 used = __ballot(o_used); if (used == ~0ull) { bad = 1; break; } s = (u32)__builtin_ctzll(~used); }
+          if (lane == s) { o_used = true; o_proc = pj; o_txn = l_t; o_len = l_len; }
+        } else if (hit && lane == hs) o_used = false;
+      }
+      if (bad) break;
+      const bool matched = m_id != NONE;
+      if (matched) {
+        t_cmp[m_id] = idx; t_first[m_id] = n + (u32)__popcll(im & lt);
+        if (type == MSIM_T_OK) { t_off[m_id] = woff; t_lt[m_id] = len | (MSIM_T_OK << 16); }   // the completed form replaces the requested one
+        else t_lt[m_id] = m_len | (type << 16);
+      }
+      c_ok += (u32)__popcll(__ballot(matched && type == MSIM_T_OK));
+      c_fail += (u32)__popcll(__ballot(matched && type == MSIM_T_FAIL));
+      c_info += (u32)__popcll(__ballot(matched && type == MSIM_T_INFO));
+      n += (u32)__popcll(im);
+    }
+    if (bad == 2) TO_HBM();
+    if (bad) TO_HOST();
+  }
+  __syncthreads();
+  res.op_count = n; res.attempt_count = n; res.ok_count = c_ok; res.stable_count = c_ok; res.fail_count = c_fail; res.info_count = c_info;
+
+  // ---- B: ranges; the LDS tables laid out and cleared ----------------------------------------------------------------------------------------
+  u32 max_key = 0, max_val = 0; bool bad = false;
+  for (u32 t = lane; t < n; t += 64) {
+    const u32 *w = pay + t_off[t]; const u32 wn = t_lt[t] & 0xFFFFu;
+    for (u32 i = 0; i < wn;) { const Mop m = next_mop(w, wn, i); bad |= m.bad; max_key = max(max_key, m.key); if (m.f) max_val = max(max_val, m.val); }
+  }
+  max_key = t_max(max_key); max_val = t_max(max_val);
+  const u32 stride = max_val + 1u, K = max_key + 1u;
+  if (__ballot(bad)) TO_HOST();
+  if (max_key >= KMAX || (u64)K * stride > WMAX) TO_HBM();
+  // LDS (bytes): in-degrees [n] and CSR offsets [n + 1] as halves of words | R1 = writer [K x stride] u16 + longest [K] u32, later the
+  // ready queue [n] u16 + realtime ranges [n] 2 x u16 | adjacency of the dependency edges, u16, whatever is left
+  const u32 hw = (n + 2u) >> 1;                                   // words for n + 1 halves
+  const u32 r1_a = ((K * stride + 1u) >> 1) + K, r1_b = ((n + 1u) >> 1) + n;
+  const u32 r1_words = max(r1_a, r1_b);
+  if ((u64)(2u * hw + r1_words) * 4u + 64u > p.lds_bytes) TO_HBM();
+  u32 *const l_indeg = reinterpret_cast<u32 *>(smem), *const l_off = l_indeg + hw, *const l_r1 = l_off + hw;
+  unsigned short *const l_writer = reinterpret_cast<unsigned short *>(l_r1);
+  u32 *const l_longest = l_r1 + ((K * stride + 1u) >> 1);
+  unsigned short *const l_adj = reinterpret_cast<unsigned short *>(l_r1 + r1_words);
+  const u32 adj_cap = (p.lds_bytes - (2u * hw + r1_words) * 4u) / 2u;
+  for (u32 i = lane; i < 2u * hw; i += 64) l_indeg[i] = 0;        // (indeg and off are adjacent)
+  for (u32 i = lane; i < ((K * stride + 1u) >> 1); i += 64) l_r1[i] = 0xFFFFFFFFu;
+  for (u32 k = lane; k < K; k += 64) l_longest[k] = 0;
+  __syncthreads();
+#define WENT(k_, el_) ((el_) < stride ? (u32)l_writer[(k_) * stride + (el_)] : 0xFFFFu)   // 0xFFFF: nobody wrote it
+#define W_TXN(e_) ((e_) & 0x1FFFu)
+#define W_TYPE(e_) (((e_) >> 13) & 3u)
+#define W_FIN(e_) ((e_) >> 15)
+
+  // ---- C: writers (every transaction, whatever became of it); a second writer of a (key, element) finds the slot taken over ------------------
+  for (int pass = 0; pass < 2; pass++) {
+    for (u32 t = lane; t < n; t += 64) {
+      const u32 *w = pay + t_off[t]; const u32 wn = t_lt[t] & 0xFFFFu, ty = (t_lt[t] >> 16) & 3u;
+      for (u32 i = 0; i < wn;) {
+        const Mop m = next_mop(w, wn, i);
+        if (!m.f) continue;
+        u32 fin = 1u;   // no later append of this transaction to the key
+        for (u32 i2 = i; i2 < wn;) { const Mop q = next_mop(w, wn, i2); if (q.f && q.key == m.key) fin = 0u; }
+        const u32 ent = t | (ty << 13) | (fin << 15);
+        if (pass == 0) l_writer[m.key * stride + m.val] = (unsigned short)ent;
+        else if (l_writer[m.key * stride + m.val] != ent) bad = true;   // the generator never repeats (k, v)
+      }
+    }
+    __syncthreads();
+  }
+  if (__ballot(bad)) TO_HOST();
+
+  // ---- D: the reads of :ok transactions ----------------------------------------------------------------------------------------------------------
+  for (u32 t = lane; t < n; t += 64) {
+    if ((t_lt[t] >> 16) != MSIM_T_OK) continue;
+    const u32 *w = pay + t_off[t]; const u32 wn = t_lt[t] & 0xFFFFu;
+    u32 k = 0;
+    for (u32 i = 0; i < wn; k++) {
+      const Mop m = next_mop(w, wn, i);
+      if (m.f) continue;
+      { u64 s0 = 0, s1 = 0, s2 = 0, s3 = 0;   // duplicates
+        for (u32 e = 0; e < m.len; e++) {
+          const u32 x = elem(m.list, e); const u64 b = 1ull << (x & 63u); const u32 q = x >> 6;
+          const u64 s = q == 0 ? s0 : q == 1 ? s1 : q == 2 ? s2 : s3;
+          if (s & b) bad = true;
+          s0 |= q == 0 ? b : 0; s1 |= q == 1 ? b : 0; s2 |= q == 2 ? b : 0; s3 |= q == 3 ? b : 0;
+        } }
+      { int prev = -1; Mop pm = m; u32 e_i = 0, e_k = 0;   // internal consistency: what the transaction's own earlier micro-ops imply for this read
+        for (e_i = 0, e_k = 0; e_k < k; e_k++) { const Mop q = next_mop(w, wn, e_i); if (!q.f && q.key == m.key) { prev = (int)e_k; pm = q; } }
+        const u32 e0 = prev < 0 ? 0u : (u32)prev + 1u;
+        u32 n_app = 0;
+        for (e_i = 0, e_k = 0; e_k < k; e_k++) { const Mop q = next_mop(w, wn, e_i); if (e_k >= e0 && q.f && q.key == m.key) n_app++; }
+        bool ok = true; u32 at = 0;
+        if (prev >= 0) { ok = m.len == pm.len + n_app; if (ok) for (u32 e = 0; e < pm.len; e++) ok &= elem(m.list, e) == elem(pm.list, e); at = pm.len; }
+        else { ok = m.len >= n_app; at = m.len - n_app; }
+        if (ok) { u32 a = 0; for (e_i = 0, e_k = 0; e_k < k; e_k++) { const Mop q = next_mop(w, wn, e_i); if (e_k >= e0 && q.f && q.key == m.key) { if (elem(m.list, at + a) != q.val) ok = false; a++; } } }
+        if (!ok) bad = true; }
+      u32 ext = m.len;   // the externally visible part: without the transaction's own appends at the tail
+      while (ext > 0) { const u32 we = WENT(m.key, elem(m.list, ext - 1)); if (we != 0xFFFFu && W_TXN(we) == t) ext--; else break; }
+      for (u32 e = 0; e < ext; e++) { const u32 we = WENT(m.key, elem(m.list, e)); if (we == 0xFFFFu || W_TYPE(we) == MSIM_T_FAIL) bad = true; }   // G1a
+      if (ext > 0) { const u32 we = WENT(m.key, elem(m.list, ext - 1)); if (we != 0xFFFFu && W_TXN(we) != t && !W_FIN(we)) bad = true; }              // G1b
+      atomicMax(&l_longest[m.key], ((m.len + 1u) << 24) | (u32)(m.list - pay));
+    }
+  }
+  __syncthreads();
+  if (__ballot(bad)) TO_HOST();
+
+  // realtime order in closed form (see txn_check_kernel)
+  {
+    u64 carry = ~0ull;
+    for (int b = (int)((n + 63u) / 64u) - 1; b >= 0; b--) {
+      const u32 t = (u32)b * 64u + lane;
+      u64 v = (t < n && (t_lt[t] >> 16) == MSIM_T_OK) ? (((u64)t_cmp[t] << 32) | t_first[t]) : ~0ull;
+      for (int o = 1; o < 64; o <<= 1) {
+        const u32 ylo = (u32)__shfl_down((int)(u32)v, o), yhi = (u32)__shfl_down((int)(u32)(v >> 32), o);
+        const u64 y = ((u64)yhi << 32) | ylo;
+        if (lane + (u32)o < 64u) v = min(v, y);
+      }
+      v = min(v, carry);
+      if (t < n) { sm[t] = (u32)(v >> 32); smf[t] = (u32)v; }
+      carry = ((u64)t_rl((u32)(v >> 32), 0) << 32) | t_rl((u32)v, 0);
+    }
+    if (lane == 0) { sm[n] = NONE; smf[n] = n; }
+  }
+  __syncthreads();
+
+  // ---- E: edges: pass 0 counts degrees, pass 1 fills the CSR of the dependency edges (realtime successors stay a range) -----------------------------
+  u32 n_edges = 0, n_dep = 0;
+  for (int pass = 0; pass < 2; pass++) {
+    u32 my_edges = 0, my_dep = 0;
+#define ADD(a_, b_) do { const u32 ea = (a_), eb = (b_); if (ea != eb) { if (pass == 0) { h16_add(l_off, ea, 1u); h16_add(l_indeg, eb, 1u); my_edges++; my_dep++; } \
+                                                                         else l_adj[h16_add(l_off, ea, 1u)] = (unsigned short)eb; } } while (0)
+    for (u32 key = lane; key < K; key += 64) {   // ww along each key's version order (lane = key)
+      const u32 L = l_longest[key];
+      if (L == 0) continue;
+      const u32 len = (L >> 24) - 1u; const u32 *ord = pay + (L & 0xFFFFFFu);
+      for (u32 i = 0; i + 1 < len; i++) {
+        const u32 a = WENT(key, elem(ord, i)), b = WENT(key, elem(ord, i + 1));
+        if (a == 0xFFFFu || b == 0xFFFFu) continue;
+        const bool fa = W_TYPE(a) == MSIM_T_FAIL, fb = W_TYPE(b) == MSIM_T_FAIL;
+        if (fa && !fb) bad = true;   // dirty update
+        if (!fa && !fb) ADD(W_TXN(a), W_TXN(b));
+      }
+    }
+    for (u32 t = lane; t < n; t += 64) {   // wr / rw per read of an :ok transaction; its realtime successors
+      if ((t_lt[t] >> 16) != MSIM_T_OK) continue;
+      const u32 *w = pay + t_off[t]; const u32 wn = t_lt[t] & 0xFFFFu;
+      for (u32 i = 0; i < wn;) {
+        const Mop m = next_mop(w, wn, i);
+        if (m.f) continue;
+        const u32 L = l_longest[m.key];
+        const u32 llen = (L >> 24) - 1u; const u32 *ord = pay + (L & 0xFFFFFFu);
+        bool pre = m.len <= llen;
+        if (pre) for (u32 e = 0; e < m.len; e++) pre &= elem(m.list, e) == elem(ord, e);
+        if (!pre) { bad = true; continue; }   // incompatible order
+        u32 ext = m.len;
+        while (ext > 0) { const u32 we = WENT(m.key, elem(m.list, ext - 1)); if (we != 0xFFFFu && W_TXN(we) == t) ext--; else break; }
+        if (ext > 0) { const u32 we = WENT(m.key, elem(m.list, ext - 1)); if (we != 0xFFFFu && W_TYPE(we) != MSIM_T_FAIL) ADD(W_TXN(we), t); }
+        if (m.len < llen) { const u32 we = WENT(m.key, elem(ord, m.len)); if (we != 0xFFFFu && W_TYPE(we) != MSIM_T_FAIL) ADD(t, W_TXN(we)); }   // anti-dependency
+      }
+      if (pass == 0) {
+        const u32 first = t_first[t];                          // the transactions invoked after t completed start here ...
+        const u32 last = sm[first] == NONE ? n : smf[first];   // ... and end where the first of them to complete :ok did
+        for (u32 v = first; v < last; v++) {
+          h16_add(l_indeg, v, 1u);                             // (a :fail transaction has no edges of its own: counting this one in keeps Kahn's bookkeeping uniform)
+          if ((t_lt[v] >> 16) != MSIM_T_FAIL) my_edges++;      // ... but it is not an edge of the graph the host counts
+        }
+      }
+    }
+#undef ADD
+    __syncthreads();
+    if (__ballot(bad)) TO_HOST();
+    if (pass == 0) {
+      n_edges = t_sum(my_edges); n_dep = t_sum(my_dep);
+      if (n_edges > p.emax) TO_HOST();
+      if (n_dep > adj_cap || n_dep > 65535u || n_edges > 65535u) TO_HBM();
+      // out-degrees -> CSR offsets (exclusive prefix sums, 64 at a time); pass 1 advances off[a] to the END of a's entries
+      u32 carry = 0;
+      for (u32 base = 0; base <= n; base += 64) {
+        const u32 t = base + lane;
+        const u32 d = t < n ? h16_get(l_off, t) : 0u;
+        const u32 ex = t_excl_scan(d, lane);
+        const u32 tot = t_sum(d);
+        __syncthreads();
+        // two lanes share a word: the even one writes both halves
+        const u32 mine = carry + ex, next = (u32)__shfl_down((int)mine, 1);
+        if (t <= n && !(t & 1u)) l_off[t >> 1] = mine | ((lane < 63u && t + 1u <= n ? next : 0u) << 16);
+        carry += tot;
+        __syncthreads();
+      }
+    }
+  }
+#undef WENT
+#undef W_TXN
+#undef W_TYPE
+#undef W_FIN
+
+  // ---- F: acyclic?  Kahn's algorithm, 64 ready transactions per step; queue and realtime ranges where the writer table was --------------------------
+  unsigned short *const l_queue = reinterpret_cast<unsigned short *>(l_r1);
+  u32 *const l_rt = l_r1 + ((n + 1u) >> 1);   // first | last << 16
+  for (u32 t = lane; t < n; t += 64) {
+    u32 first = 0, last = 0;
+    if ((t_lt[t] >> 16) == MSIM_T_OK) { first = t_first[t]; last = sm[first] == NONE ? n : smf[first]; }
+    l_rt[t] = first | (last << 16);
+  }
+  __syncthreads();
+  u32 tail = 0;
+  for (u32 base = 0; base < n; base += 64) {
+    const u32 t = base + lane;
+    const bool z = t < n && h16_get(l_indeg, t) == 0;
+    const u64 zm = __ballot(z);
+    if (z) l_queue[tail + (u32)__popcll(zm & lt)] = (unsigned short)t;
+    tail += (u32)__popcll(zm);
+  }
+  __syncthreads();
+  u32 head = 0;
+  while (head < tail) {
+    const u32 cnt = min(64u, tail - head);
+    const bool on = lane < cnt;
+    const u32 v = on ? (u32)l_queue[head + lane] : 0u;
+    const u32 a1 = on ? h16_get(l_off, v) : 0u, a0 = on ? (v ? h16_get(l_off, v - 1u) : 0u) : 0u;   // (after pass 1 off[v] is the end of v's entries)
+    const u32 rt = on ? l_rt[v] : 0u, r0 = rt & 0xFFFFu, r1 = rt >> 16;
+    const u32 deg = (a1 - a0) + (r1 - r0);
+    for (u32 k = 0; __ballot(k < deg); k++) {
+      bool push = false; u32 wv = 0;
+      if (k < deg) { wv = k < a1 - a0 ? (u32)l_adj[a0 + k] : r0 + (k - (a1 - a0)); push = h16_sub(l_indeg, wv) == 1u; }
+      const u64 pm = __ballot(push);
+      if (push) l_queue[tail + (u32)__popcll(pm & lt)] = (unsigned short)wv;
+      tail += (u32)__popcll(pm);
+    }
+    head += cnt;
+    __syncthreads();
+  }
+  if (tail != n) TO_HOST();   // a cycle: the host finds and classifies it
+
+  if (lane == 0) {
+    res.lost_count = n_edges;   // edges of the dependency graph
+    res.valid = flags ? 0u : (c_ok == 0 ? 2u : 1u);
+    p.out[hist] = res;
+  }
+#undef TO_HOST
+#undef TO_HBM
+}
+
+// words of workspace per history: the tables of txn_check_kernel / the per-transaction words of txn_check_lds_kernel
 uint64_t ws_words_for(u32 nmax, u32 emax) { return (uint64_t)nmax * 11 + 4 + KMAX + WMAX + emax; }
+uint64_t ws_words_lds(u32 nmax) { return (uint64_t)nmax * 6 + 8; }
+
+// LDS of a wavefront of txn_check_lds_kernel: what a history of `nmax` transactions over `keys` keys with elements below `stride`
+// needs with 4.5 dependency edges per transaction, at most 78 KiB (two wavefronts per CU)
+u32 lds_bytes_for(u32 nmax, u32 keys, u32 stride) {
+  const uint64_t hw = (nmax + 2u) / 2, r1 = std::max<uint64_t>(((uint64_t)keys * stride + 1) / 2 + keys, (nmax + 1u) / 2 + nmax);
+  const uint64_t need = (2 * hw + r1) * 4 + (uint64_t)nmax * 9 + 256;
+  return (u32)std::min<uint64_t>(78 * 1024, std::max<uint64_t>(8 * 1024, (need + 255) & ~255ull));
+}
+
+int grow_ws(msim_ctx *ctx, void **ws_buf, size_t *ws_cap, size_t need) {
+  if (*ws_cap >= need) return MSIM_OK;
+  if (*ws_buf) (void)hipFree(*ws_buf);
+  *ws_buf = nullptr; *ws_cap = 0;
+  MSIM_HIP_TRY(ctx, hipMalloc(ws_buf, need));
+  *ws_cap = need;
+  return MSIM_OK;
+}
 
 int txn_dev_run(msim_ctx *ctx, TParams tp, u32 n, u32 cm, const std::vector<msim_inst_meta> *hmeta, msim_check_result *h_out, hipStream_t st, u32 *n_host,
                 void **ws_buf, size_t *ws_cap) {
   const bool trace = (msim_dev_flags(ctx) & 0x1000u) != 0;   // developer: time the passes
+  const bool hbm_only = (msim_dev_flags(ctx) & 0x2000u) != 0;   // developer: the round-2 kernel (tables in HBM) for every history
   const auto t0 = std::chrono::steady_clock::now();
   auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
-  tp.ws_words = ws_words_for(tp.nmax, tp.emax);
-  // as many histories per launch as a few GB of workspace hold (every one of them has its own slice)
-  const uint64_t budget = 6ull << 30;
-  u32 chunk = (u32)std::min<uint64_t>(n, std::max<uint64_t>(1, budget / (tp.ws_words * 4)));
-  const size_t need = (size_t)chunk * tp.ws_words * 4;
-  if (*ws_cap < need) {
-    if (*ws_buf) (void)hipFree(*ws_buf);
-    *ws_buf = nullptr; *ws_cap = 0;
-    MSIM_HIP_TRY(ctx, hipMalloc(ws_buf, need));
-    *ws_cap = need;
+  const uint64_t budget = 6ull << 30;   // as many histories per launch as a few GB of workspace hold (every one of them has its own slice)
+  int rc;
+  std::vector<u32> big;   // histories for txn_check_kernel
+  if (!hbm_only) {
+    // pass 1: tables in LDS
+    tp.ws_words = ws_words_lds(tp.nmax); tp.list = nullptr;
+    const u32 chunk = (u32)std::min<uint64_t>(n, std::max<uint64_t>(1, budget / (tp.ws_words * 4)));
+    if ((rc = grow_ws(ctx, ws_buf, ws_cap, (size_t)chunk * tp.ws_words * 4)) != MSIM_OK) return rc;
+    tp.ws = static_cast<u32 *>(*ws_buf);
+    if (tp.lds_bytes > 64 * 1024) MSIM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(txn_check_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tp.lds_bytes));
+    for (u32 first = 0; first < n; first += chunk) {
+      tp.first = first;
+      hipLaunchKernelGGL(txn_check_lds_kernel, dim3(std::min(chunk, n - first)), dim3(64), tp.lds_bytes, st, tp);
+      MSIM_HIP_TRY(ctx, hipGetLastError());
+    }
+    MSIM_HIP_TRY(ctx, hipMemcpyAsync(h_out, tp.out, (size_t)n * sizeof(msim_check_result), hipMemcpyDeviceToHost, st));
+    MSIM_HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (u32 i = 0; i < n; i++) if (h_out[i].valid == NEEDS_HBM) big.push_back(i);
+    if (trace) std::fprintf(stderr, "[txn-check] LDS pass (%u B per wavefront): %.2f ms, %zu of %u histories do not fit\n", tp.lds_bytes, ms(), big.size(), n);
+  } else { big.resize(n); for (u32 i = 0; i < n; i++) big[i] = i; }
+  if (!big.empty()) {
+    // pass 2: the histories whose tables do not fit LDS, tables in an HBM workspace
+    u32 *d_list = nullptr;
+    MSIM_HIP_TRY(ctx, hipMalloc(&d_list, big.size() * 4));
+    MSIM_HIP_TRY(ctx, hipMemcpy(d_list, big.data(), big.size() * 4, hipMemcpyHostToDevice));
+    tp.ws_words = ws_words_for(tp.nmax, tp.emax); tp.list = d_list;
+    const u32 nb = (u32)big.size();
+    const u32 chunk = (u32)std::min<uint64_t>(nb, std::max<uint64_t>(1, budget / (tp.ws_words * 4)));
+    rc = grow_ws(ctx, ws_buf, ws_cap, (size_t)chunk * tp.ws_words * 4);
+    if (rc == MSIM_OK) {
+      tp.ws = static_cast<u32 *>(*ws_buf);
+      for (u32 first = 0; first < nb; first += chunk) {
+        tp.first = first;
+        hipLaunchKernelGGL(txn_check_kernel, dim3(std::min(chunk, nb - first)), dim3(64), 0, st, tp);
+        if (hipGetLastError() != hipSuccess) { rc = MSIM_E_HIP; ctx->err = "txn_check_kernel launch"; break; }
+      }
+    }
+    if (rc == MSIM_OK && (hipMemcpyAsync(h_out, tp.out, (size_t)n * sizeof(msim_check_result), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) { rc = MSIM_E_HIP; ctx->err = "txn check: copy of the results"; }
+    (void)hipFree(d_list);
+    if (rc != MSIM_OK) return rc;
+    if (trace) std::fprintf(stderr, "[txn-check] HBM-table pass over %u histories: done at %.2f ms\n", nb, ms());
   }
-  tp.ws = static_cast<u32 *>(*ws_buf);
-  for (u32 first = 0; first < n; first += chunk) {
-    tp.first = first;
-    const u32 cnt = std::min(chunk, n - first);
-    hipLaunchKernelGGL(txn_check_kernel, dim3(cnt), dim3(64), 0, st, tp);
-    MSIM_HIP_TRY(ctx, hipGetLastError());
-  }
-  MSIM_HIP_TRY(ctx, hipMemcpyAsync(h_out, tp.out, (size_t)n * sizeof(msim_check_result), hipMemcpyDeviceToHost, st));
-  MSIM_HIP_TRY(ctx, hipStreamSynchronize(st));
+  if (ctx) ctx->txn_big = (u32)big.size();
   std::vector<u32> todo;
-  for (u32 i = 0; i < n; i++) if (h_out[i].valid == NEEDS_HOST) todo.push_back(i);
-  if (trace) std::fprintf(stderr, "[txn-check] device pass: %.2f ms, %zu of %u histories for the host\n", ms(), todo.size(), n);
+  for (u32 i = 0; i < n; i++) if (h_out[i].valid == NEEDS_HOST || h_out[i].valid == NEEDS_HBM) todo.push_back(i);
+  if (trace) std::fprintf(stderr, "[txn-check] device passes: %.2f ms, %zu of %u histories for the host\n", ms(), todo.size(), n);
   if (!todo.empty()) {
     std::vector<uint64_t> ro, po;
     if (tp.row_off) { ro.resize(n + 1); po.resize(n + 1);
@@ -430,7 +805,8 @@ int msim_check_txn_device(msim_ctx *ctx) {
   TParams tp;
   tp.rows = ctx->d_rows; tp.payload = ctx->d_payload; tp.meta = ctx->d_meta; tp.row_off = nullptr; tp.pay_off = nullptr; tp.out = ctx->d_check;
   tp.max_rows = ctx->cfg.max_rows; tp.max_pay = ctx->cfg.max_payload_words;
-  tp.nmax = ctx->cfg.max_rows / 2 + 1; tp.emax = tp.nmax * 16; tp.first = 0; tp.ws = nullptr; tp.ws_words = 0;
+  tp.nmax = ctx->cfg.max_rows / 2 + 1; tp.emax = tp.nmax * 16; tp.first = 0; tp.ws = nullptr; tp.ws_words = 0; tp.list = nullptr;
+  tp.lds_bytes = lds_bytes_for(tp.nmax, ctx->cfg.max_values, ctx->cfg.max_writes_per_key + 1);
   u32 redone = 0;
   int rc = txn_dev_run(ctx, tp, n, ctx->cfg.consistency_model, &hm, ctx->h_check, ctx->stream, &redone, &ctx->d_check_scratch, &ctx->cap_check_scratch);
   if (rc != MSIM_OK) return rc;
@@ -464,7 +840,8 @@ extern "C" int msim_check_txn_batch(int device, const msim_op *rows, const uint6
     if (hipMemcpy(d_po, payload_offsets, (size_t)(n_histories + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) break;
     TParams tp;
     tp.rows = d_rows; tp.payload = d_pay; tp.meta = nullptr; tp.row_off = d_ro; tp.pay_off = d_po; tp.out = d_out;
-    tp.max_rows = 0; tp.max_pay = 0; tp.nmax = max_r / 2 + 65; tp.emax = tp.nmax * 16; tp.first = 0; tp.ws = nullptr; tp.ws_words = 0;
+    tp.max_rows = 0; tp.max_pay = 0; tp.nmax = max_r / 2 + 65; tp.emax = tp.nmax * 16; tp.first = 0; tp.ws = nullptr; tp.ws_words = 0; tp.list = nullptr;
+    tp.lds_bytes = lds_bytes_for(tp.nmax, std::min<u32>(KMAX, tp.nmax * 2 + 16), 17);
     rc = txn_dev_run(ctx, tp, n_histories, MSIM_CM_STRICT_SERIALIZABLE, nullptr, out, nullptr, nullptr, &ws, &ws_cap);
   } while (false);
   for (void *q : {(void *)d_rows, (void *)d_pay, (void *)d_ro, (void *)d_po, (void *)d_out, ws}) if (q) (void)hipFree(q);

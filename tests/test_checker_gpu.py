@@ -333,3 +333,18 @@ def test_device_and_host_checkers_give_the_same_results_through_msim_check(lib, 
             out.append((res, [eng.raw_history(i)[0].tobytes() for i in range(n)]))
     assert out[0][0].tobytes() == out[1][0].tobytes() == out[2][0].tobytes()
     assert out[0][1] == out[2][1]
+
+
+@pytest.mark.parametrize("kw", [
+    dict(workload="g-set", node_count=5, concurrency=15, rate=1000, time_limit=2, latency=20, latency_dist="exponential", seed=31),
+    dict(workload="broadcast", bin="broadcast-ack-retry", node_count=5, concurrency=20, rate=800, time_limit=3, latency=10, p_loss=0.1, seed=32),
+    dict(workload="broadcast", bin="broadcast-ff", node_count=7, concurrency=21, rate=700, time_limit=3, latency=30, latency_dist="uniform",
+         nemesis=["partition"], nemesis_interval=1, seed=33),
+    dict(workload="g-set", node_count=3, concurrency=30, rate=1500, time_limit=1, seed=34),
+])
+def test_set_full_when_reads_overtake_each_other(lib, kw):
+    """Many workers per node at a high rate: reads queue behind one another at the nodes (one input per node and round), so reads
+    invoked later complete earlier — the case the single sweep of check_kernel corrects `known` for — and elements come and go between
+    reads at different nodes (many last-present / last-absent transitions)."""
+    res = _check(E.test_config(**kw), 6)
+    assert (res["attempt_count"] > 20).all()
