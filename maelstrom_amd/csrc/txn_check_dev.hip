@@ -709,7 +709,12 @@ int grow_ws(msim_ctx *ctx, void **ws_buf, size_t *ws_cap, size_t need) {
 int txn_dev_run(msim_ctx *ctx, TParams tp, u32 n, u32 cm, const std::vector<msim_inst_meta> *hmeta, msim_check_result *h_out, hipStream_t st, u32 *n_host,
                 void **ws_buf, size_t *ws_cap) {
   const bool trace = (msim_dev_flags(ctx) & 0x1000u) != 0;   // developer: time the passes
-  const bool hbm_only = (msim_dev_flags(ctx) & 0x2000u) != 0;   // developer: the round-2 kernel (tables in HBM) for every history
+  // Which kernel takes the first pass.  Measured on cfg5 (32768 histories, profiles/r03b_cfg5_txn_check_*): tables in LDS = 22 GB of HBM
+  // traffic, 270 ms; tables in HBM = 82 GB, 131 ms.  78 KiB of LDS per history leave a CU two wavefronts where the HBM-table kernel
+  // keeps 64 in flight, and what both kernels spend their time on — dependent payload loads, a lane per transaction — is latency that
+  // only wavefronts in flight hide.  Until the LDS kernel's streaming passes are split off the faster one is the
+  // default; MSIM_DEV_FLAGS bit 13 (0x2000) selects the LDS kernel.
+  const bool hbm_only = (msim_dev_flags(ctx) & 0x2000u) == 0;
   const auto t0 = std::chrono::steady_clock::now();
   auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
   const uint64_t budget = 6ull << 30;   // as many histories per launch as a few GB of workspace hold (every one of them has its own slice)
