@@ -289,6 +289,14 @@ int msim_check_txn_batch(int device, const msim_op *rows, const uint64_t *row_of
 /* pn-counter / g-counter: the same for the counter checker (workload/pn_counter.clj:84-123); out[i] is what msim_check_pn_rows gives. */
 int msim_check_pn_batch(int device, const msim_op *rows, const uint32_t *n_rows, uint32_t max_rows, uint32_t n_histories, msim_check_result *out);
 
+/* broadcast / g-set (set-full) and echo: checks `n_histories` histories given on the host with the device checker of msim_check
+ * (csrc/checker.hip: [upstream] jepsen.checker/set-full as workload/broadcast.clj:216-228 and workload/g_set.clj:62 use it; the pair
+ * comparison of workload/echo.clj:44-63).  History i lies in the slabs rows + i * max_rows (n_rows[i] rows used) and
+ * payload + i * max_payload_words; `workload` is MSIM_WL_BROADCAST / MSIM_WL_G_SET / MSIM_WL_ECHO, `concurrency` the number of worker
+ * threads (process mod concurrency pairs a completion with its invocation), `max_values` bounds the elements (<= 2048). */
+int msim_check_set_full_batch(int device, uint32_t workload, uint32_t concurrency, const msim_op *rows, const uint32_t *n_rows, uint32_t max_rows,
+                              const uint32_t *payload, uint32_t max_payload_words, uint32_t max_values, uint32_t n_histories, msim_check_result *out);
+
 /* unique-ids: checks `n_histories` histories given on the host — history i in the slab rows + i * max_rows, n_rows[i] rows used —
  * with the device checker of msim_check ([upstream] jepsen.checker/unique-ids); out[i] is what msim_check_unique_rows gives. */
 int msim_check_unique_batch(int device, const msim_op *rows, const uint32_t *n_rows, uint32_t max_rows, uint32_t n_histories, msim_check_result *out);

@@ -15,20 +15,27 @@
 //   :stable-latencies = points {0 .5 .95 .99 1} -> sorted[min(n-1, floor(n*q))]
 //
 // One wavefront checks one history, bit-parallel over the read bitmaps:
-//   pass 1  rows are read back from HBM 64 at a time (1 KiB, coalesced); every lane classifies its own row; only read /
-//           echo rows are walked serially (v_readlane), and a read :ok only RECORDS itself at the rank of its invocation
-//           {payload ref, invoke index, elements existing at completion, :ok index} (12 B, HBM scratch).
+//   pass 1  rows are read back from HBM 64 at a time (1 KiB, coalesced, the next chunk in flight); every lane classifies its own
+//           row.  A completion is paired with its invocation — the previous row of the same worker thread — without a serial walk
+//           (round 2 walked the read rows one by one with v_readlane: 2/3 of the kernel's instructions were scalar): the read rows of
+//           a chunk are taken in rounds, in each round the EARLIEST pending row of every worker thread (ds_min over the thread's
+//           slot) acts on the thread's table entry in LDS — an invocation leaves {row, rank}, a completion takes it — so a chunk costs
+//           as many rounds as its busiest thread has read rows in it (2-3), not one step per row.  A read :ok RECORDS itself at the
+//           rank of its invocation {payload ref, invoke index, elements existing at completion, :ok index} (12 B, HBM scratch).
 //   pass 2  ONE sweep over the recorded reads in invocation order, lane w = word w of the bitmaps: every word is loaded once
 //           (round 2: twice) and gives known (first containing read, corrected for reads that overtook it), last-present and
-//           last-absent (written when an element leaves the state) — see the comment at the sweep.
+//           last-absent (written when an element leaves the state) — see the comment at the sweep.  Two batches of 8 bitmap loads
+//           are kept in flight.
 // Per-element state: three u16 row indices in LDS (8.4 KB for 1408 elements keeps 4096 histories resident).
 #include <hip/hip_runtime.h>
 
+#include <cstring>
 #include <vector>
 
 #include "engine_internal.h"
 
 #define NONE 0xFFFFu      /* per-element row index: none */
+#define NONE32 0xFFFFFFFFu /* per-thread table entry: no invocation pending */
 #define NOLAT 0xFFFFFFFFu  /* per-element latency: not stable */
 
 struct CParams {
@@ -38,6 +45,8 @@ struct CParams {
   msim_check_result *out;
   u32 *recs;    // per instance: max_reads records of 3 words, at the rank of the read's invocation
   u32 max_rows, max_pay, max_values, C, workload, max_reads;
+  u32 off_valid, off_tbl;   // LDS offsets (bytes): the valid bitmap, the per-thread tables
+  float rcp_C;
 };
 
 __device__ __forceinline__ u32 c_rdlane(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
@@ -53,7 +62,10 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
   u16 *const lp_idx = known + p.max_values;
   u16 *const la_idx = lp_idx + p.max_values;
   u32 *const lat = reinterpret_cast<u32 *>(csmem);  // reused after the walk: stable latency per element (needs 4 B each)
-  u32 *const valid = reinterpret_cast<u32 *>(csmem + (size_t)p.max_values * 6);  // bitmap over invocation ranks: read completed :ok
+  u32 *const valid = reinterpret_cast<u32 *>(csmem + p.off_valid);  // bitmap over invocation ranks: read completed :ok
+  u32 *const slot = reinterpret_cast<u32 *>(csmem + p.off_tbl);     // [C] the worker thread's pending invocation: row | rank << 16 (echo: row)
+  u32 *const first = slot + p.C;                                     // [C] ds_min target: (round, lane) of the thread's earliest pending row
+  u32 *const slotv = first + p.C;                                    // [C] echo: the :value of the thread's last invocation
 
   const u32 lane = threadIdx.x, inst = blockIdx.x;
   const msim_inst_meta meta = p.meta[inst];
@@ -62,71 +74,87 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
   u32 *const rec = p.recs + (size_t)inst * p.max_reads * 3;
   const u32 n_rows = meta.n_rows, C = p.C;
   const bool setfull = p.workload != MSIM_WL_ECHO;
+  const u64 lt = lane ? (~0ull >> (64 - lane)) : 0ull;   // lanes below this one
 
   for (u32 i = lane; i < p.max_values; i += 64) { known[i] = NONE; lp_idx[i] = NONE; la_idx[i] = NONE; }
-  for (u32 i = lane; i < (p.max_reads + 31) / 32; i += 64) valid[i] = 0;
+  for (u32 i = lane; i < (p.max_reads + 31) / 32 + 2; i += 64) valid[i] = 0;
+  for (u32 i = lane; i < C; i += 64) { slot[i] = NONE32; first[i] = 0xFFFFFFFFu; slotv[i] = 0; }
   __syncthreads();
 
-  // worker thread t lives in lane t % 64, slot t / 64 (up to 128 workers): its pending invoke (reads / echo)
-  u32 my_inv = NONE, my_inv1 = NONE, my_val = 0, my_val1 = 0, my_rank = 0, my_rank1 = 0;
-  u32 v_cur = 0, op_count = 0, n_ok = 0, n_fail = 0, n_info = 0, errors = 0, n_ri = 0, n_rc = 0;
+  u32 v_cur = 0, n_ri = 0, errors = 0;
+  u32 cnt_lo = 0, cnt_hi = 0;    // per lane: rows of type :invoke | :ok << 16, :fail | :info << 16 (summed over the wavefront at the end)
+  u32 round_key = 0x3FFFFFFu;    // decreases with every pairing round: a later round's ds_min beats whatever an earlier one left
 
   // ---- pass 1 ----
+  uint4 r_next = make_uint4(0, 0, 0, 0);
+  if (lane < n_rows) r_next = rows[lane];
   for (u32 base = 0; base < n_rows; base += 64) {
     const u32 cnt = min(64u, n_rows - base);
-    uint4 r = make_uint4(0, 0, 0, 0);
-    if (lane < cnt) r = rows[base + lane];
-    const u32 my_type = r.z & 3, my_f = (r.z >> 2) & 31, my_proc = r.z >> 12;
+    const uint4 r = r_next;
+    r_next = make_uint4(0, 0, 0, 0);
+    if (base + 64 + lane < n_rows) r_next = rows[base + 64 + lane];
+    const u32 my_type = r.z & 3, my_f = (r.z >> 2) & 31, my_proc = r.z >> 12, idx = base + lane;
     const bool live = lane < cnt && my_proc != MSIM_PROCESS_NEMESIS;  // (r/filter (comp number? :process))
     const bool add_like = my_f == MSIM_F_ADD || my_f == MSIM_F_BROADCAST;
-    op_count += (u32)__popcll(__ballot(live && my_type == MSIM_T_INVOKE));
-    n_ok += (u32)__popcll(__ballot(live && my_type == MSIM_T_OK));
-    n_fail += (u32)__popcll(__ballot(live && my_type == MSIM_T_FAIL));
-    n_info += (u32)__popcll(__ballot(live && my_type == MSIM_T_INFO));
+    if (live) { const u32 one = 1u << ((my_type & 1) * 16); if (my_type & 2) cnt_hi += one; else cnt_lo += one; }
     // add :ok -> known (first of add-ok / first containing read, by :index): order-free as a minimum; one add per element
-    if (live && add_like && my_type == MSIM_T_OK && r.w < p.max_values && known[r.w] > base + lane) known[r.w] = (u16)(base + lane);
+    if (live && add_like && my_type == MSIM_T_OK && r.w < p.max_values && known[r.w] > idx) known[r.w] = (u16)idx;
     const u64 add_inv = __ballot(live && add_like && my_type == MSIM_T_INVOKE);  // elements come into existence
-    u64 walk = __ballot(live && (my_f == MSIM_F_READ || my_f == MSIM_F_ECHO));
-    const u32 v_base = v_cur;
+    const u32 v_here = v_cur + (u32)__popcll(add_inv & lt);                      // elements existing at this row
     v_cur += (u32)__popcll(add_inv);  // values are handed out 0,1,2,... in invoke order
-    // the serial walk shares ONE scalar unit per CU among 16 histories: everything that can be computed per row is
-    // computed by the row's own lane first (the division by C above all) and read back with a single v_readlane
-    const u32 my_info = my_type | (my_f << 2) | ((my_proc % C) << 8) | ((r.y >> 16) << 16);   // type, f, worker thread, payload words
-    while (walk) {
-      const u32 j = (u32)__builtin_ctzll(walk); walk &= walk - 1;
-      const u32 info = c_rdlane(my_info, j), value = c_rdlane(r.w, j);
-      const u32 type = info & 3, f = (info >> 2) & 31, tt = (info >> 8) & 0xFF, t = tt & 63, hi = info & 0xFFFF0000u;
-      const bool hi_slot = tt >= 64;
-      const u32 idx = base + j;
-      if (f == MSIM_F_READ) {
-        if (type == MSIM_T_INVOKE) { if (lane == t) { if (hi_slot) { my_inv1 = idx; my_rank1 = n_ri; } else { my_inv = idx; my_rank = n_ri; } } n_ri++; }
-        else if (type == MSIM_T_FAIL) { if (lane == t) { if (hi_slot) my_inv1 = NONE; else my_inv = NONE; } }
-        else if (type == MSIM_T_OK) {
-          const u32 inv = hi_slot ? c_rdlane(my_inv1, t) : c_rdlane(my_inv, t), rank = hi_slot ? c_rdlane(my_rank1, t) : c_rdlane(my_rank, t);
-          const u32 len = hi >> 16, off = value;
-          const u32 v_here = v_base + (u32)__popcll(add_inv & ((1ull << j) - 1));  // elements existing at this row
-          if (inv != NONE && rank < p.max_reads && n_rc < p.max_reads && lane == 0) {
-            u32 *q = rec + (size_t)rank * 3;
-            q[0] = off | (len << 24); q[1] = inv | (v_here << 16); q[2] = idx;
-            valid[rank >> 5] |= 1u << (rank & 31);
+    const bool is_r = live && my_f == (setfull ? MSIM_F_READ : MSIM_F_ECHO);
+    const u64 ri = __ballot(is_r && my_type == MSIM_T_INVOKE);
+    const u32 rank = n_ri + (u32)__popcll(ri & lt);                                // invocation order of the reads
+    n_ri += (u32)__popcll(ri);
+    // worker thread = process mod C ([upstream] jepsen's interpreter): one float multiply and a correction instead of a division
+    u32 tt = 0;
+    if (is_r) {
+      const u32 qd = (u32)((float)my_proc * p.rcp_C);
+      int rem = (int)(my_proc - qd * C);
+      if (rem < 0) rem += (int)C;
+      if (rem >= (int)C) rem -= (int)C;
+      tt = (u32)rem;
+    }
+    bool pend = is_r;
+    u64 pm = __ballot(pend);
+    while (pm) {   // rounds: the earliest pending read row of every worker thread acts on the thread's table entry
+      const u32 key = (round_key << 6) | lane;
+      if (pend) atomicMin(&first[tt], key);
+      __syncthreads();
+      if (pend && first[tt] == key) {
+        pend = false;
+        const u32 s = slot[tt];
+        if (my_type == MSIM_T_INVOKE) {
+          slot[tt] = setfull ? (idx | (rank << 16)) : idx;
+          if (!setfull) slotv[tt] = r.w;
+        } else {
+          slot[tt] = NONE32;
+          if (setfull) {
+            if (my_type == MSIM_T_OK && s != NONE32 && (s >> 16) < p.max_reads) {
+              const u32 rk = s >> 16;
+              u32 *q = rec + (size_t)rk * 3;
+              q[0] = r.w | ((r.y >> 16) << 24); q[1] = (s & 0xFFFFu) | (v_here << 16); q[2] = idx;
+              atomicOr(&valid[rk >> 5], 1u << (rk & 31));
+            }
+          } else {
+            // echo.clj:44-63: every :invoke whose completion is not an :ok carrying the same :echo is an error — a :fail, an
+            // :info (its :value is the request string, (:echo "...") = nil) and an invocation that never completes included
+            if (my_type != MSIM_T_OK || slotv[tt] != r.w) errors++;
           }
-          n_rc++;
-        }
-      } else {  // echo
-        // echo.clj:44-63: every :invoke whose completion is not an :ok carrying the same :echo is an error — a :fail, an
-        // :info (its :value is the request string, (:echo "...") = nil) and an invocation that never completes included
-        if (type == MSIM_T_INVOKE) { if (lane == t) { if (hi_slot) { my_val1 = value; my_inv1 = idx; } else { my_val = value; my_inv = idx; } } }
-        else {
-          if (type != MSIM_T_OK || (hi_slot ? c_rdlane(my_val1, t) : c_rdlane(my_val, t)) != value) errors++;
-          if (lane == t) { if (hi_slot) my_inv1 = NONE; else my_inv = NONE; }
         }
       }
+      round_key--;
+      __syncthreads();
+      pm = __ballot(pend);
     }
   }
-  if (!setfull) errors += (u32)__popcll(__ballot(my_inv != NONE)) + (u32)__popcll(__ballot(my_inv1 != NONE));   // invocations left without a completion
+  if (!setfull) { for (u32 i = lane; i < C; i += 64) errors += slot[i] != NONE32 ? 1u : 0u; }   // invocations left without a completion
+  errors = c_wave_sum(errors);
+  cnt_lo = c_wave_sum(cnt_lo & 0xFFFFu) | (c_wave_sum(cnt_lo >> 16) << 16);   // (at most 65534 rows: every count fits 16 bits)
+  cnt_hi = c_wave_sum(cnt_hi & 0xFFFFu) | (c_wave_sum(cnt_hi >> 16) << 16);
+  const u32 op_count = cnt_lo & 0xFFFFu, n_ok = cnt_lo >> 16, n_fail = cnt_hi & 0xFFFFu, n_info = cnt_hi >> 16;
   __threadfence_block();
   __syncthreads();
-  if (n_rc > p.max_reads) n_rc = p.max_reads;
   if (n_ri > p.max_reads) n_ri = p.max_reads;
 
   // ---- pass 2: ONE sweep over the :ok reads in invocation order, lane w = word w of the bitmaps (elements 32w .. 32w+31) -----------------
@@ -138,46 +166,71 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
   //   known = the smallest :ok index among the reads containing the element: the first containing read F, unless a read invoked while
   //     F was still open completed before it — only reads invoked before F's completion can (`fresh` keeps those elements apart until
   //     the sweep has passed the latest such completion).
-  // The loads of 8 reads are issued together before they are folded in (one dependent global load per read bounds the sweep).
+  // The loads of 8 reads are issued together, and the next 8 before those are folded in (one dependent global load per read
+  // would bound the sweep; so would one exposed round trip per batch).
   {
     u32 unk = 0xFFFFFFFFu, fresh = 0, fresh_until = 0, prev_w = 0, prev_a = 0, prev_inv = 0;
     const u32 lo = lane * 32;
-    for (u32 cb = 0; cb < n_ri; cb += 64) {
+    u32 rx = 0, ry = 0, rz = 0;   // {payload ref | words << 24, invoke index | elements existing at completion << 16, :ok index}
+    u64 todo = 0;
+    // the next (up to) 8 valid ranks of this chunk, earliest first: their bitmap words are requested
+    auto issue = [&](u32 (&jl)[8], u32 (&wv)[8], u32 &nb) {
+      nb = 0;
+#pragma unroll
+      for (u32 t = 0; t < 8; t++) {
+        const bool have = todo != 0;
+        const u32 j = have ? (u32)__builtin_ctzll(todo) : 0u;
+        if (have) { todo &= todo - 1; nb = t + 1; }
+        jl[t] = j;
+        const u32 ref = c_rdlane(rx, j);
+        wv[t] = (have && lane < (ref >> 24)) ? pay[(ref & 0xFFFFFFu) + lane] : 0u;
+      }
+    };
+    auto fold = [&](const u32 (&jl)[8], const u32 (&wv)[8], const u32 nb) {
+#pragma unroll
+      for (u32 t = 0; t < 8; t++) {
+        if (t >= nb) break;
+        const u32 iv = c_rdlane(ry, jl[t]), ok = c_rdlane(rz, jl[t]), inv = iv & 0xFFFFu, v_here = iv >> 16;
+        const u32 w = wv[t];
+        const u32 ex = v_here >= lo + 32 ? 0xFFFFFFFFu : (v_here <= lo ? 0u : ((1u << (v_here - lo)) - 1));  // elements that exist at this read
+        const u32 a = ~w & ex;
+        if (inv > fresh_until) fresh = 0;                    // every read behind a fresh element has completed before this one began
+        u32 first = w & unk, again = w & fresh;
+        unk &= ~w;
+        if (first) { fresh |= first; fresh_until = max(fresh_until, ok); }
+        u32 upd = first | again;
+        while (upd) { const u32 e = lo + (u32)__builtin_ctz(upd); upd &= upd - 1; if (e < p.max_values && known[e] > ok) known[e] = (u16)ok; }
+        u32 lv = prev_w & ~w, lva = prev_a & ~a;
+        while (lv) { const u32 e = lo + (u32)__builtin_ctz(lv); lv &= lv - 1; if (e < p.max_values) lp_idx[e] = (u16)prev_inv; }
+        while (lva) { const u32 e = lo + (u32)__builtin_ctz(lva); lva &= lva - 1; if (e < p.max_values) la_idx[e] = (u16)prev_inv; }
+        prev_w = w; prev_a = a; prev_inv = inv;
+      }
+    };
+    auto chunk_mask = [&](u32 cb) -> u64 {
+      if (cb >= n_ri) return 0ull;
       const u32 cn = min(64u, n_ri - cb);
-      const u64 vmask = ((u64)valid[cb / 32 + 1] << 32 | valid[cb / 32]) & (cn >= 64 ? ~0ull : ((1ull << cn) - 1));
+      return ((u64)valid[cb / 32 + 1] << 32 | valid[cb / 32]) & (cn >= 64 ? ~0ull : ((1ull << cn) - 1));
+    };
+    // the records of the next chunk are requested while this one is swept
+    u32 nx = 0, ny = 0, nz = 0;
+    u64 nmask = chunk_mask(0);
+    if ((nmask >> lane) & 1) { const u32 *q = rec + (size_t)lane * 3; nx = q[0]; ny = q[1]; nz = q[2]; }
+    for (u32 cb = 0; cb < n_ri; cb += 64) {
+      const u64 vmask = nmask;
+      rx = nx; ry = ny; rz = nz;
+      nmask = chunk_mask(cb + 64);
+      nx = ny = nz = 0;
+      if ((nmask >> lane) & 1) { const u32 *q = rec + (size_t)(cb + 64 + lane) * 3; nx = q[0]; ny = q[1]; nz = q[2]; }
       if (!vmask) continue;
-      u32 rx = 0, ry = 0, rz = 0;   // {payload ref | words << 24, invoke index | elements existing at completion << 16, :ok index}
-      if ((vmask >> lane) & 1) { const u32 *q = rec + (size_t)(cb + lane) * 3; rx = q[0]; ry = q[1]; rz = q[2]; }
-      u64 todo = vmask;
-      while (todo) {
-        u32 jl[8], wv[8], nb = 0;
-#pragma unroll
-        for (u32 t = 0; t < 8; t++) {   // the next (up to) 8 valid ranks of this chunk, earliest first
-          const bool have = todo != 0;
-          const u32 j = have ? (u32)__builtin_ctzll(todo) : 0u;
-          if (have) { todo &= todo - 1; nb = t + 1; }
-          jl[t] = j;
-          const u32 ref = c_rdlane(rx, j);
-          wv[t] = (have && lane < (ref >> 24)) ? pay[(ref & 0xFFFFFFu) + lane] : 0u;
-        }
-#pragma unroll
-        for (u32 t = 0; t < 8; t++) {
-          if (t >= nb) break;
-          const u32 iv = c_rdlane(ry, jl[t]), ok = c_rdlane(rz, jl[t]), inv = iv & 0xFFFFu, v_here = iv >> 16;
-          const u32 w = wv[t];
-          const u32 ex = v_here >= lo + 32 ? 0xFFFFFFFFu : (v_here <= lo ? 0u : ((1u << (v_here - lo)) - 1));  // elements that exist at this read
-          const u32 a = ~w & ex;
-          if (inv > fresh_until) fresh = 0;                    // every read behind a fresh element has completed before this one began
-          u32 first = w & unk, again = w & fresh;
-          unk &= ~w;
-          if (first) { fresh |= first; fresh_until = max(fresh_until, ok); }
-          u32 upd = first | again;
-          while (upd) { const u32 e = lo + (u32)__builtin_ctz(upd); upd &= upd - 1; if (e < p.max_values && known[e] > ok) known[e] = (u16)ok; }
-          u32 lv = prev_w & ~w, lva = prev_a & ~a;
-          while (lv) { const u32 e = lo + (u32)__builtin_ctz(lv); lv &= lv - 1; if (e < p.max_values) lp_idx[e] = (u16)prev_inv; }
-          while (lva) { const u32 e = lo + (u32)__builtin_ctz(lva); lva &= lva - 1; if (e < p.max_values) la_idx[e] = (u16)prev_inv; }
-          prev_w = w; prev_a = a; prev_inv = inv;
-        }
+      todo = vmask;
+      u32 jA[8], wA[8], nA, jB[8], wB[8], nB;
+      issue(jA, wA, nA);
+      while (nA) {
+        issue(jB, wB, nB);
+        fold(jA, wA, nA);
+        if (!nB) break;
+        issue(jA, wA, nA);
+        fold(jB, wB, nB);
       }
     }
     while (prev_w) { const u32 e = lo + (u32)__builtin_ctz(prev_w); prev_w &= prev_w - 1; if (e < p.max_values) lp_idx[e] = (u16)prev_inv; }
@@ -247,15 +300,45 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
   }
 }
 
+// LDS of one wavefront: three u16 indices per element (reused as one u32 latency per element), the valid bitmap over the read
+// ranks (read one word past the last chunk), the per-thread tables slot / first / slotv
+static size_t check_lds_layout(CParams &cp) {
+  size_t lds = (size_t)cp.max_values * 3 * 2 < (size_t)cp.max_values * 4 ? (size_t)cp.max_values * 4 : (size_t)cp.max_values * 3 * 2;
+  lds = (lds + 3) & ~(size_t)3;
+  cp.off_valid = (u32)lds;
+  lds += ((size_t)(cp.max_reads + 31) / 32 + 2) * 4;
+  cp.off_tbl = (u32)lds;
+  lds += (size_t)cp.C * 3 * 4;
+  return lds;
+}
+
+static const char *check_limits(u32 max_rows, u32 max_values, u32 concurrency) {
+  if (max_rows >= 0xFFFF || max_values > 2048 || concurrency > 128 || concurrency == 0) return "device checker: max_rows must be < 65535, max_values <= 2048, concurrency 1..128";
+  return nullptr;
+}
+
+// one wavefront per history over n slabs; the caller owns the buffers and the stream
+static hipError_t check_dispatch(CParams &cp, u32 n, hipStream_t st) {
+  cp.max_reads = cp.max_rows / 2 + 1;  // every :ok read has its own :invoke row
+  cp.rcp_C = 1.0f / (float)cp.C;
+  const size_t lds = check_lds_layout(cp);
+  if (lds > 64 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&check_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(check_kernel, dim3(n), dim3(64), lds, st, cp);
+  return hipGetLastError();
+}
+
 int msim_check_launch(msim_ctx *ctx) {
   MSIM_HIP_TRY(ctx, hipSetDevice(ctx->device));
   const msim_config &c = ctx->cfg;
   CParams cp;
+  std::memset(&cp, 0, sizeof cp);
   cp.rows = ctx->d_rows; cp.payload = ctx->d_payload; cp.meta = ctx->d_meta; cp.out = ctx->d_check;
   cp.max_rows = c.max_rows; cp.max_pay = c.max_payload_words; cp.max_values = c.max_values; cp.C = c.concurrency; cp.workload = c.workload;
-  if (c.max_rows >= 0xFFFF || c.max_values > 2048 || c.concurrency > 128) { ctx->err = "device checker: max_rows must be < 65535, max_values <= 2048, concurrency <= 128"; return MSIM_E_UNSUPPORTED; }
-  cp.max_reads = c.max_rows / 2 + 1;  // every :ok read has its own :invoke row
-  const size_t rec_bytes = (size_t)ctx->n_inst * cp.max_reads * 3 * sizeof(u32);
+  if (const char *why = check_limits(c.max_rows, c.max_values, c.concurrency)) { ctx->err = why; return MSIM_E_UNSUPPORTED; }
+  const size_t rec_bytes = (size_t)ctx->n_inst * (c.max_rows / 2 + 1) * 3 * sizeof(u32);
   if (ctx->cap_check_scratch < rec_bytes) {
     if (ctx->d_check_scratch) (void)hipFree(ctx->d_check_scratch);
     ctx->d_check_scratch = nullptr; ctx->cap_check_scratch = 0;
@@ -263,19 +346,48 @@ int msim_check_launch(msim_ctx *ctx) {
     ctx->cap_check_scratch = rec_bytes;
   }
   cp.recs = static_cast<u32 *>(ctx->d_check_scratch);
-  size_t lds = (size_t)c.max_values * 3 * 2 < (size_t)c.max_values * 4 ? (size_t)c.max_values * 4 : (size_t)c.max_values * 3 * 2;
-  lds += ((size_t)(cp.max_reads + 31) / 32 + 2) * 4;  // + the valid bitmap (read one word past the last chunk)
-  if (lds > 64 * 1024) {
-    MSIM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&check_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  }
   MSIM_HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
-  hipLaunchKernelGGL(check_kernel, dim3(ctx->n_inst), dim3(64), lds, ctx->stream, cp);
-  MSIM_HIP_TRY(ctx, hipGetLastError());
+  MSIM_HIP_TRY(ctx, check_dispatch(cp, ctx->n_inst, ctx->stream));
   MSIM_HIP_TRY(ctx, hipEventRecord(ctx->ev3, ctx->stream));
   MSIM_HIP_TRY(ctx, hipEventSynchronize(ctx->ev3));
   MSIM_HIP_TRY(ctx, hipEventElapsedTime(&ctx->check_ms, ctx->ev2, ctx->ev3));
   ctx->checked = true; ctx->check_fetched = false;
   return MSIM_OK;
+}
+
+// Checks `n_histories` broadcast / g-set (set-full) or echo histories given on the host with the device checker of msim_check:
+// history i lies in the slabs rows + i * max_rows (n_rows[i] rows used) and payload + i * max_payload_words.
+extern "C" int msim_check_set_full_batch(int device, uint32_t workload, uint32_t concurrency, const msim_op *rows, const uint32_t *n_rows, uint32_t max_rows,
+                                         const uint32_t *payload, uint32_t max_payload_words, uint32_t max_values, uint32_t n_histories, msim_check_result *out) {
+  if (!rows || !n_rows || !out || n_histories == 0 || max_rows == 0 || (!payload && max_payload_words)) return MSIM_E_INVALID;
+  if (workload != MSIM_WL_ECHO && workload != MSIM_WL_BROADCAST && workload != MSIM_WL_G_SET) return MSIM_E_INVALID;
+  if (check_limits(max_rows, max_values, concurrency)) return MSIM_E_UNSUPPORTED;
+  if (hipSetDevice(device) != hipSuccess) return MSIM_E_HIP;
+  std::vector<msim_inst_meta> hm(n_histories);
+  for (u32 i = 0; i < n_histories; i++) { std::memset(&hm[i], 0, sizeof hm[i]); if (n_rows[i] > max_rows) return MSIM_E_RANGE; hm[i].n_rows = n_rows[i]; }
+  CParams cp;
+  std::memset(&cp, 0, sizeof cp);
+  cp.max_rows = max_rows; cp.max_pay = max_payload_words; cp.max_values = max_values; cp.C = concurrency; cp.workload = workload;
+  msim_op *d_rows = nullptr; u32 *d_pay = nullptr; msim_inst_meta *d_meta = nullptr; msim_check_result *d_out = nullptr; u32 *d_rec = nullptr;
+  const size_t pay_bytes = (size_t)n_histories * (max_payload_words ? max_payload_words : 1) * sizeof(u32);
+  int rc = MSIM_E_HIP;
+  do {
+    if (hipMalloc(&d_rows, (size_t)n_histories * max_rows * sizeof(msim_op)) != hipSuccess) break;
+    if (hipMalloc(&d_pay, pay_bytes) != hipSuccess) break;
+    if (hipMalloc(&d_meta, (size_t)n_histories * sizeof(msim_inst_meta)) != hipSuccess) break;
+    if (hipMalloc(&d_out, (size_t)n_histories * sizeof(msim_check_result)) != hipSuccess) break;
+    if (hipMalloc(&d_rec, (size_t)n_histories * (max_rows / 2 + 1) * 3 * sizeof(u32)) != hipSuccess) break;
+    if (hipMemcpy(d_rows, rows, (size_t)n_histories * max_rows * sizeof(msim_op), hipMemcpyHostToDevice) != hipSuccess) break;
+    if (max_payload_words && hipMemcpy(d_pay, payload, pay_bytes, hipMemcpyHostToDevice) != hipSuccess) break;
+    if (hipMemcpy(d_meta, hm.data(), (size_t)n_histories * sizeof(msim_inst_meta), hipMemcpyHostToDevice) != hipSuccess) break;
+    cp.rows = d_rows; cp.payload = d_pay; cp.meta = d_meta; cp.out = d_out; cp.recs = d_rec;
+    if (check_dispatch(cp, n_histories, nullptr) != hipSuccess) break;
+    if (hipDeviceSynchronize() != hipSuccess) break;
+    if (hipMemcpy(out, d_out, (size_t)n_histories * sizeof(msim_check_result), hipMemcpyDeviceToHost) != hipSuccess) break;
+    rc = MSIM_OK;
+  } while (false);
+  for (void *q : {(void *)d_rows, (void *)d_pay, (void *)d_meta, (void *)d_out, (void *)d_rec}) if (q) (void)hipFree(q);
+  return rc;
 }
 
 // ---- maelstrom.checker/availability-checker (checker.clj:6-39) ---------------------------------------------------------

@@ -504,6 +504,29 @@ def check_unique_batch(histories, device=0, fn="msim_check_unique_batch"):
     return out
 
 
+def check_set_full_batch(histories, concurrency, workload=A.WL_BROADCAST, max_values=None, device=0):
+    """broadcast / g-set (set-full) or echo: several histories — (rows, payload words) pairs — through the device checker behind
+    Engine.check() (msim_check_set_full_batch)."""
+    hs = [(np.ascontiguousarray(r), np.ascontiguousarray(p, dtype=np.uint32)) for r, p in histories]
+    mr = max(1, max(len(r) for r, _ in hs))
+    mp = max(1, max(len(p) for _, p in hs))
+    rows = np.zeros((len(hs), mr), dtype=OP_DT)
+    pay = np.zeros((len(hs), mp), dtype=np.uint32)
+    for i, (r, p) in enumerate(hs):
+        rows[i, :len(r)] = r
+        pay[i, :len(p)] = p
+    nr = np.asarray([len(r) for r, _ in hs], dtype=np.uint32)
+    if max_values is None:   # every add / broadcast invocation creates one element
+        f = (rows["packed"] >> 2) & 31
+        adds = (((f == A.F_ADD) | (f == A.F_BROADCAST)) & ((rows["packed"] & 3) == 0)).sum(axis=1).max() if len(hs) else 0
+        max_values = max(32, (int(adds) + 31) // 32 * 32)
+    out = np.zeros(len(hs), dtype=CHECK_DT)
+    rc = A.load().msim_check_set_full_batch(device, workload, concurrency, rows.ctypes.data, nr.ctypes.data, mr, pay.ctypes.data, mp, max_values, len(hs), out.ctypes.data)
+    if rc:
+        raise EngineError(f"msim_check_set_full_batch: {rc}")
+    return out
+
+
 def check_pn_batch(histories, device=0):
     """pn-counter / g-counter: several histories through the device checker behind Engine.check() (msim_check_pn_batch)."""
     return check_unique_batch(histories, device, fn="msim_check_pn_batch")
