@@ -115,7 +115,29 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
       if (rem >= (int)C) rem -= (int)C;
       tt = (u32)rem;
     }
-    bool pend = is_r;
+    // what a read :ok leaves behind: its record at the rank of its invocation `sv` = row | rank << 16
+    auto record = [&](u32 sv) {
+      const u32 rk = sv >> 16;
+      if (rk < p.max_reads) {
+        u32 *q = rec + (size_t)rk * 3;
+        q[0] = r.w | ((r.y >> 16) << 24); q[1] = (sv & 0xFFFFu) | (v_here << 16); q[2] = idx;
+        atomicOr(&valid[rk >> 5], 1u << (rk & 31));
+      }
+    };
+    // A completion that directly follows its invocation (all but a few: the rows of one operation are only separated when another
+    // worker thread's row falls between them) is settled from the lane below; the pair never touches the thread's table entry.
+    const u32 mine = (is_r && my_type == MSIM_T_INVOKE ? 0x80000000u : 0u) | (tt << 16) | (rank & 0xFFFFu);
+    const u32 below = (u32)__shfl_up((int)mine, 1);
+    const u32 below_v = setfull ? 0u : (u32)__shfl_up((int)r.w, 1);
+    const bool adj = is_r && my_type != MSIM_T_INVOKE && lane > 0 && (below >> 31) && ((below >> 16) & 0x7FFFu) == tt;
+    const u64 adj_m = __ballot(adj);
+    if (adj) {
+      if (setfull) { if (my_type == MSIM_T_OK) record((idx - 1) | (below << 16)); }
+      // echo.clj:44-63: every :invoke whose completion is not an :ok carrying the same :echo is an error — a :fail, an
+      // :info (its :value is the request string, (:echo "...") = nil) and an invocation that never completes included
+      else if (my_type != MSIM_T_OK || below_v != r.w) errors++;
+    }
+    bool pend = is_r && !adj && !((adj_m >> 1 >> lane) & 1);
     u64 pm = __ballot(pend);
     while (pm) {   // rounds: the earliest pending read row of every worker thread acts on the thread's table entry
       const u32 key = (round_key << 6) | lane;
@@ -129,18 +151,8 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
           if (!setfull) slotv[tt] = r.w;
         } else {
           slot[tt] = NONE32;
-          if (setfull) {
-            if (my_type == MSIM_T_OK && s != NONE32 && (s >> 16) < p.max_reads) {
-              const u32 rk = s >> 16;
-              u32 *q = rec + (size_t)rk * 3;
-              q[0] = r.w | ((r.y >> 16) << 24); q[1] = (s & 0xFFFFu) | (v_here << 16); q[2] = idx;
-              atomicOr(&valid[rk >> 5], 1u << (rk & 31));
-            }
-          } else {
-            // echo.clj:44-63: every :invoke whose completion is not an :ok carrying the same :echo is an error — a :fail, an
-            // :info (its :value is the request string, (:echo "...") = nil) and an invocation that never completes included
-            if (my_type != MSIM_T_OK || slotv[tt] != r.w) errors++;
-          }
+          if (setfull) { if (my_type == MSIM_T_OK && s != NONE32) record(s); }
+          else if (my_type != MSIM_T_OK || slotv[tt] != r.w) errors++;
         }
       }
       round_key--;
@@ -169,40 +181,49 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
   // The loads of 8 reads are issued together, and the next 8 before those are folded in (one dependent global load per read
   // would bound the sweep; so would one exposed round trip per batch).
   {
-    u32 unk = 0xFFFFFFFFu, fresh = 0, fresh_until = 0, prev_w = 0, prev_a = 0, prev_inv = 0;
+    u32 unk = 0xFFFFFFFFu, fresh = 0, fresh_until = 0 /* wave-uniform */, prev_w = 0, prev_a = 0, prev_inv = 0;
     const u32 lo = lane * 32;
     u32 rx = 0, ry = 0, rz = 0;   // {payload ref | words << 24, invoke index | elements existing at completion << 16, :ok index}
     u64 todo = 0;
     // the next (up to) 8 valid ranks of this chunk, earliest first: their bitmap words are requested
-    auto issue = [&](u32 (&jl)[8], u32 (&wv)[8], u32 &nb) {
+    auto issue = [&](u32 (&wv)[8], u32 &nb) {
       nb = 0;
 #pragma unroll
       for (u32 t = 0; t < 8; t++) {
         const bool have = todo != 0;
         const u32 j = have ? (u32)__builtin_ctzll(todo) : 0u;
         if (have) { todo &= todo - 1; nb = t + 1; }
-        jl[t] = j;
         const u32 ref = c_rdlane(rx, j);
-        wv[t] = (have && lane < (ref >> 24)) ? pay[(ref & 0xFFFFFFu) + lane] : 0u;
+        const bool mine = have && lane < (ref >> 24);                 // (the other lanes load word 0 of the slab: no branch around the load)
+        const u32 got = pay[mine ? (ref & 0xFFFFFFu) + lane : 0u];
+        wv[t] = mine ? got : 0u;
       }
     };
-    auto fold = [&](const u32 (&jl)[8], const u32 (&wv)[8], const u32 nb) {
+    // `tf` = the ranks the batch was issued for (todo as it was then).  Everything a read usually changes is straight-line; ONE
+    // wave-wide test guards the bit loops (an element seen for the first time, or leaving present / absent).  `fresh_until` is kept
+    // wave-uniform (the latest completion behind ANY fresh element): elements stay in `fresh` a little longer than they have to,
+    // which only repeats a minimum.
+    auto fold = [&](u64 tf, const u32 (&wv)[8], const u32 nb) {
 #pragma unroll
       for (u32 t = 0; t < 8; t++) {
         if (t >= nb) break;
-        const u32 iv = c_rdlane(ry, jl[t]), ok = c_rdlane(rz, jl[t]), inv = iv & 0xFFFFu, v_here = iv >> 16;
+        const u32 j = (u32)__builtin_ctzll(tf); tf &= tf - 1;
+        const u32 iv = c_rdlane(ry, j), ok = c_rdlane(rz, j), inv = iv & 0xFFFFu, v_here = iv >> 16;
         const u32 w = wv[t];
-        const u32 ex = v_here >= lo + 32 ? 0xFFFFFFFFu : (v_here <= lo ? 0u : ((1u << (v_here - lo)) - 1));  // elements that exist at this read
+        const int d = (int)v_here - (int)lo;
+        const u32 ex = d >= 32 ? 0xFFFFFFFFu : (d <= 0 ? 0u : ((1u << d) - 1));  // elements that exist at this read
         const u32 a = ~w & ex;
         if (inv > fresh_until) fresh = 0;                    // every read behind a fresh element has completed before this one began
-        u32 first = w & unk, again = w & fresh;
+        const u32 first = w & unk, again = w & fresh;
         unk &= ~w;
-        if (first) { fresh |= first; fresh_until = max(fresh_until, ok); }
-        u32 upd = first | again;
-        while (upd) { const u32 e = lo + (u32)__builtin_ctz(upd); upd &= upd - 1; if (e < p.max_values && known[e] > ok) known[e] = (u16)ok; }
-        u32 lv = prev_w & ~w, lva = prev_a & ~a;
-        while (lv) { const u32 e = lo + (u32)__builtin_ctz(lv); lv &= lv - 1; if (e < p.max_values) lp_idx[e] = (u16)prev_inv; }
-        while (lva) { const u32 e = lo + (u32)__builtin_ctz(lva); lva &= lva - 1; if (e < p.max_values) la_idx[e] = (u16)prev_inv; }
+        fresh |= first;
+        if (__ballot(first != 0)) fresh_until = max(fresh_until, ok);
+        u32 upd = first | again, lv = prev_w & ~w, lva = prev_a & ~a;
+        if (__ballot((upd | lv | lva) != 0)) {
+          while (upd) { const u32 e = lo + (u32)__builtin_ctz(upd); upd &= upd - 1; if (e < p.max_values && known[e] > ok) known[e] = (u16)ok; }
+          while (lv) { const u32 e = lo + (u32)__builtin_ctz(lv); lv &= lv - 1; if (e < p.max_values) lp_idx[e] = (u16)prev_inv; }
+          while (lva) { const u32 e = lo + (u32)__builtin_ctz(lva); lva &= lva - 1; if (e < p.max_values) la_idx[e] = (u16)prev_inv; }
+        }
         prev_w = w; prev_a = a; prev_inv = inv;
       }
     };
@@ -223,14 +244,17 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
       if ((nmask >> lane) & 1) { const u32 *q = rec + (size_t)(cb + 64 + lane) * 3; nx = q[0]; ny = q[1]; nz = q[2]; }
       if (!vmask) continue;
       todo = vmask;
-      u32 jA[8], wA[8], nA, jB[8], wB[8], nB;
-      issue(jA, wA, nA);
+      u32 wA[8], nA, wB[8], nB;
+      u64 tA = todo, tB;
+      issue(wA, nA);
       while (nA) {
-        issue(jB, wB, nB);
-        fold(jA, wA, nA);
+        tB = todo;
+        issue(wB, nB);
+        fold(tA, wA, nA);
         if (!nB) break;
-        issue(jA, wA, nA);
-        fold(jB, wB, nB);
+        tA = todo;
+        issue(wA, nA);
+        fold(tB, wB, nB);
       }
     }
     while (prev_w) { const u32 e = lo + (u32)__builtin_ctz(prev_w); prev_w &= prev_w - 1; if (e < p.max_values) lp_idx[e] = (u16)prev_inv; }
