@@ -286,6 +286,13 @@ uint32_t msim_check_host_rechecks(const msim_ctx *ctx);
 int msim_check_txn_batch(int device, const msim_op *rows, const uint64_t *row_offsets, const uint32_t *payload, const uint64_t *payload_offsets,
                          uint32_t n_histories, msim_check_result *out);
 
+/* txn-rw-register: the same for the rw-register analysis under `consistency_model` (MSIM_CM_*): the device proves a history free of
+ * everything the model proscribes (csrc/rw_check_dev.hip), the host analysis of msim_check_rw_rows finishes the others; *n_host (may be
+ * null) = how many went to the host.  For a history the device proves valid, out[i] carries :valid?, the counts, the non-cycle anomalies
+ * seen (none proscribed) in error_count and the edges built in lost_count; the allowed cycle classes are not searched for. */
+int msim_check_rw_batch(int device, const msim_op *rows, const uint64_t *row_offsets, const uint32_t *payload, const uint64_t *payload_offsets,
+                        uint32_t n_histories, uint32_t consistency_model, msim_check_result *out, uint32_t *n_host);
+
 /* pn-counter / g-counter: the same for the counter checker (workload/pn_counter.clj:84-123); out[i] is what msim_check_pn_rows gives. */
 int msim_check_pn_batch(int device, const msim_op *rows, const uint32_t *n_rows, uint32_t max_rows, uint32_t n_histories, msim_check_result *out);
 

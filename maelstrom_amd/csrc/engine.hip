@@ -1088,7 +1088,10 @@ extern "C" int msim_check(msim_ctx *ctx) {
     return (msim_dev_flags(ctx) & 0x800u) ?   // bit 11: keep the check on the host cores
            msim_check_txn_host(ctx) : msim_check_txn_device(ctx);
   }
-  if (ctx->cfg.workload == MSIM_WL_TXN_RW_REGISTER) return msim_check_txn_host(ctx);
+  if (ctx->cfg.workload == MSIM_WL_TXN_RW_REGISTER) {
+    return (msim_dev_flags(ctx) & 0x800u) ?   // bit 11: keep the check on the host cores
+           msim_check_txn_host(ctx) : msim_check_rw_device(ctx);
+  }
   if (ctx->cfg.workload == MSIM_WL_PN_COUNTER || ctx->cfg.workload == MSIM_WL_G_COUNTER) {
     return (msim_dev_flags(ctx) & 0x800u) ?   // bit 11: keep the check on the host cores
            msim_check_pn_host(ctx) : msim_check_pn_device(ctx);
@@ -1307,7 +1310,7 @@ extern "C" int msim_set_dev_flags(msim_ctx *ctx, uint32_t flags) {
   return MSIM_OK;
 }
 
-extern "C" uint32_t msim_check_host_rechecks(const msim_ctx *ctx) { return ctx && ctx->checked && (ctx->cfg.workload == MSIM_WL_LIN_KV || ctx->cfg.workload == MSIM_WL_TXN_LIST_APPEND || ctx->cfg.workload == MSIM_WL_PN_COUNTER || ctx->cfg.workload == MSIM_WL_G_COUNTER) ? ctx->lin_host_rechecks : 0u; }
+extern "C" uint32_t msim_check_host_rechecks(const msim_ctx *ctx) { return ctx && ctx->checked && (ctx->cfg.workload == MSIM_WL_LIN_KV || ctx->cfg.workload == MSIM_WL_TXN_LIST_APPEND || ctx->cfg.workload == MSIM_WL_TXN_RW_REGISTER || ctx->cfg.workload == MSIM_WL_PN_COUNTER || ctx->cfg.workload == MSIM_WL_G_COUNTER) ? ctx->lin_host_rechecks : 0u; }
 
 extern "C" int msim_check_results(msim_ctx *ctx, const msim_check_result **results, uint32_t *n) {
   if (!ctx) return MSIM_E_INVALID;

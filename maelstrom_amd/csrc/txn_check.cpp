@@ -443,6 +443,12 @@ void msim_txn_check_instance_host(const msim_op *rows, uint32_t n_rows, const ui
   check_history(S, rows, n_rows, payload, n_words, flags, cm, res);
 }
 
+// the host analysis of one rw-register history (rw_check_dev.hip hands over what it cannot prove valid)
+void msim_rw_check_instance_host(const msim_op *rows, uint32_t n_rows, const uint32_t *payload, uint32_t n_words, uint32_t flags, uint32_t cm, msim_check_result *res) {
+  thread_local Scratch S;
+  (void)check_rw(S, rows, n_rows, payload, n_words, flags, cm, res);
+}
+
 extern "C" int msim_check_txn_rows(const msim_op *rows, uint32_t n_rows, const uint32_t *payload, uint32_t n_words, msim_check_result *out) {
   if (!rows || !out || (!payload && n_words)) return MSIM_E_INVALID;
   Scratch S;

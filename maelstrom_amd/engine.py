@@ -363,7 +363,7 @@ def check_txn_history(rows, payload):
         raise EngineError(f"msim_check_txn_rows: {rc}")
     return {"valid?": {1: True, 0: False, 2: "unknown"}[res.valid], "anomalies": sorted(n for b, n in A.ANOMALIES.items() if res.error_count & b),
             "txn-count": res.attempt_count, "ok-count": res.ok_count, "fail-count": res.fail_count, "info-count": res.info_count,
-            "edge-count": res.lost_count, "cycle-txns": res.stale_count}
+            "edge-count": res.lost_count, "cycle-txns": res.stale_count, "anomaly-bits": res.error_count}
 
 
 def check_rw_history(rows, payload, consistency_model="strict-serializable"):
@@ -377,7 +377,7 @@ def check_rw_history(rows, payload, consistency_model="strict-serializable"):
         raise EngineError(f"msim_check_rw_rows: {rc}")
     return {"valid?": {1: True, 0: False, 2: "unknown"}[res.valid], "anomalies": sorted(n for b, n in A.ANOMALIES.items() if res.error_count & b),
             "txn-count": res.attempt_count, "ok-count": res.ok_count, "fail-count": res.fail_count, "info-count": res.info_count,
-            "edge-count": res.lost_count, "cycle-txns": res.stale_count}
+            "edge-count": res.lost_count, "cycle-txns": res.stale_count, "anomaly-bits": res.error_count}
 
 
 def check_pn_history(rows):
@@ -548,6 +548,26 @@ def check_txn_batch(histories, device=0):
     if rc:
         raise EngineError(f"msim_check_txn_batch: {rc}")
     return out
+
+
+def check_rw_batch(histories, consistency_model="read-committed", device=0):
+    """txn-rw-register: several histories, each (rows, payload), through the device pass behind Engine.check() with the host analysis for
+    what it cannot prove valid (msim_check_rw_batch).  Returns (CHECK_DT records, how many histories went to the host)."""
+    rs = [np.ascontiguousarray(h[0]) for h in histories]
+    ps = [np.ascontiguousarray(h[1], dtype=np.uint32) for h in histories]
+    ro = np.zeros(len(rs) + 1, dtype=np.uint64); ro[1:] = np.cumsum([len(x) for x in rs])
+    po = np.zeros(len(ps) + 1, dtype=np.uint64); po[1:] = np.cumsum([len(x) for x in ps])
+    rows = np.concatenate(rs) if rs else np.zeros(0, dtype=OP_DT)
+    pay = np.concatenate(ps) if ps else np.zeros(0, dtype=np.uint32)
+    if len(pay) == 0:
+        pay = np.zeros(1, dtype=np.uint32)
+    out = np.zeros(len(rs), dtype=CHECK_DT)
+    n_host = C.c_uint32()
+    rc = A.load().msim_check_rw_batch(device, rows.ctypes.data, ro.ctypes.data, pay.ctypes.data, po.ctypes.data, len(rs),
+                                      CONSISTENCY_MODELS[consistency_model], out.ctypes.data, C.byref(n_host))
+    if rc:
+        raise EngineError(f"msim_check_rw_batch: {rc}")
+    return out, n_host.value
 
 
 def journal_fressian(cfg, events, payload):
