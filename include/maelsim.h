@@ -44,7 +44,8 @@ enum {
 enum { MSIM_WL_ECHO = 0, MSIM_WL_BROADCAST = 1, MSIM_WL_G_SET = 2, MSIM_WL_LIN_KV = 3, MSIM_WL_TXN_LIST_APPEND = 4,
        MSIM_WL_PN_COUNTER = 5 /* workload/pn_counter.clj */, MSIM_WL_G_COUNTER = 6 /* workload/g_counter.clj: pn-counter without negative adds */,
        MSIM_WL_UNIQUE_IDS = 7 /* workload/unique_ids.clj */,
-       MSIM_WL_TXN_RW_REGISTER = 8 /* workload/txn_rw_register.clj: transactions of reads / writes over registers */ };
+       MSIM_WL_TXN_RW_REGISTER = 8 /* workload/txn_rw_register.clj: transactions of reads / writes over registers */,
+       MSIM_WL_KAFKA = 9 /* workload/kafka.clj: append-only logs per key: send / poll / assign / crash, committed offsets */ };
 
 /* Built-in node programs (the `--bin` of the reference). */
 enum {
@@ -72,6 +73,9 @@ enum {
                                    demo/ruby/datomic_list_append.rb, the workload's demo at core.clj:113-114): thunks in lww-kv, the root
                                    map in lin-kv, retry when the root cas is lost (oracle/mk_nodes.inc, pinned by the real program on
                                    the process bridge; csrc/sim_kernel_mk.inc).  One worker per node, at most 30 nodes               */
+  MSIM_NODE_KAFKA = 14,         /* demo/clojure/kafka.clj:1-172: logs in 32-message chunks under lin-kv keys (read + cas per send), committed
+                                   offsets under one lin-kv key; brings the `lin-kv` service endpoint with it.  One worker per node, at most
+                                   8 keys per test (oracle/kafka_nodes.inc, csrc/sim_kernel_kafka.inc; parity unpinned: babashka only)      */
   MSIM_NODE_TSO_IDS = 13        /* unique-ids over the `lin-tso` timestamp oracle (service.clj:116-132,290-296; doc/services.md): every
                                    `generate` becomes a {type "ts"} RPC to lin-tso, the timestamp is the id.  The reference ships the
                                    service but no demo that uses it; this node (tools/harness_tso_node.py is its process form) is what
@@ -143,7 +147,15 @@ typedef struct msim_config {
  * txn ops (txn_list_append.clj:27-39,54-60): `value` = payload offset, len = words of the transaction
  * [[f k v] ...].  One header word per micro-op: bit 0 f (0 = :r, 1 = :append), bits 1-15 key, bits 16-23 the appended
  * element (:append) or the length n of the list read (:r; 0xFF = nil, i.e. an :invoke or a key that does not exist);
- * a read of n elements is followed by ceil(n/4) words holding them one per byte, first element in the low byte. */
+ * a read of n elements is followed by ceil(n/4) words holding them one per byte, first element in the low byte.
+ * kafka ops (workload/kafka.clj:203-232; keys 0..7, message values and offsets below 2047):
+ *   :send   `value` = key | msg << 6 | offset << 17 — [[:send k msg]] while the offset field is 0x7FF (:invoke, :fail, :info),
+ *           [[:send k [offset msg]]] for an :ok;
+ *   :poll   :invoke (and :fail / :info): the {key offset} map the client asked with, `value` = payload offset, len = its entries
+ *           (key | offset << 8 each; MSIM_NO_VALUE / 0 = the client has no assignment) — an engine abstraction, the op's :value is
+ *           [[:poll]]; :ok: `value` / len = the poll_ok block: per requested key a header key | n << 8 | first offset << 16 followed
+ *           by its n messages two per word (low half first): [[:poll {k [[offset msg] ...]}]];
+ *   :assign `value` = payload offset, len = keys, one word per key (bit 31: :seek-to-beginning? true);  :crash carries no value. */
 typedef struct msim_op {
   uint64_t time_len;
   uint32_t packed;
@@ -153,7 +165,8 @@ typedef struct msim_op {
 enum { MSIM_T_INVOKE = 0, MSIM_T_OK = 1, MSIM_T_FAIL = 2, MSIM_T_INFO = 3 };
 enum { MSIM_F_ECHO = 0, MSIM_F_BROADCAST = 1, MSIM_F_READ = 2, MSIM_F_ADD = 3,
        MSIM_F_START_PARTITION = 4, MSIM_F_STOP_PARTITION = 5,
-       MSIM_F_WRITE = 6, MSIM_F_CAS = 7, MSIM_F_TXN = 8, MSIM_F_GENERATE = 9 };
+       MSIM_F_WRITE = 6, MSIM_F_CAS = 7, MSIM_F_TXN = 8, MSIM_F_GENERATE = 9,
+       MSIM_F_SEND = 10, MSIM_F_POLL = 11, MSIM_F_ASSIGN = 12, MSIM_F_CRASH = 13 /* workload/kafka.clj:203-232 */ };
 enum { MSIM_ERR_NONE = 0, MSIM_ERR_NET_TIMEOUT = 1 /* client.clj:158-162 */, MSIM_ERR_RPC = 2,
        /* RPC errors of resources/errors.edn, as :error [name text] (client.clj:163-172) */
        MSIM_ERR_TEMPORARILY_UNAVAILABLE = 3 /* code 11 */, MSIM_ERR_KEY_DOES_NOT_EXIST = 4 /* code 20 */,
@@ -199,7 +212,9 @@ enum { MSIM_M_INIT = 1, MSIM_M_INIT_OK, MSIM_M_TOPOLOGY, MSIM_M_TOPOLOGY_OK, MSI
        MSIM_M_WRITE, MSIM_M_WRITE_OK, MSIM_M_CAS, MSIM_M_CAS_OK, MSIM_M_ERROR,
        MSIM_M_REQUEST_VOTE, MSIM_M_REQUEST_VOTE_RES, MSIM_M_APPEND_ENTRIES, MSIM_M_APPEND_ENTRIES_RES,
        MSIM_M_TXN, MSIM_M_TXN_OK, MSIM_M_GENERATE, MSIM_M_GENERATE_OK, MSIM_M_REPLICATE_ACK,
-       MSIM_M_TS, MSIM_M_TS_OK /* lin-tso, service.clj:121-123 */ };
+       MSIM_M_TS, MSIM_M_TS_OK /* lin-tso, service.clj:121-123 */,
+       MSIM_M_SEND, MSIM_M_SEND_OK, MSIM_M_POLL, MSIM_M_POLL_OK, MSIM_M_LIST_COMMITTED_OFFSETS, MSIM_M_LIST_COMMITTED_OFFSETS_OK,
+       MSIM_M_COMMIT_OFFSETS, MSIM_M_COMMIT_OFFSETS_OK /* workload/kafka.clj:89-139 */ };
 
 /* Per-instance bookkeeping (not part of the algorithmic output bytes). */
 typedef struct msim_inst_meta {

@@ -33,6 +33,7 @@ extern "C" int msim_config_defaults(msim_config *cfg, uint32_t workload, uint32_
     case MSIM_WL_PN_COUNTER: case MSIM_WL_G_COUNTER: cfg->node_program = MSIM_NODE_PN_COUNTER; break;
     case MSIM_WL_UNIQUE_IDS: cfg->node_program = MSIM_NODE_FLAKE_IDS; break;
     case MSIM_WL_TXN_RW_REGISTER: cfg->node_program = MSIM_NODE_TXN_RW_HAT; cfg->consistency_model = MSIM_CM_READ_COMMITTED; break;  // core.clj:115-121
+    case MSIM_WL_KAFKA: cfg->node_program = MSIM_NODE_KAFKA; break;
     default: cfg->node_program = MSIM_NODE_RAFT; break;
   }
   cfg->n_nodes = n_nodes;
@@ -52,6 +53,7 @@ extern "C" int msim_config_defaults(msim_config *cfg, uint32_t workload, uint32_
   cfg->key_count = 0;                   // core.clj:167-169: no default here; [upstream] elle picks 10 for the exponential key choice
   cfg->max_txn_length = 4;              // core.clj:191-194
   cfg->max_writes_per_key = 16;         // core.clj:196-199
+  if (workload == MSIM_WL_KAFKA) { cfg->key_count = 4; cfg->max_writes_per_key = 1024; }   // [upstream] jepsen.tests.kafka: a few long-lived keys
   return MSIM_OK;
 }
 
@@ -76,7 +78,7 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
   if (c->concurrency == 0) c->concurrency = c->n_nodes;
   uint32_t slots = c->concurrency > c->n_nodes ? c->concurrency : c->n_nodes;
   if (c->n_nodes + slots > 255) { set_err(err, errlen, "n_nodes + max(concurrency, n_nodes) must be <= 255"); return MSIM_E_INVALID; }
-  if (c->workload > MSIM_WL_TXN_RW_REGISTER) { set_err(err, errlen, "unknown workload"); return MSIM_E_INVALID; }
+  if (c->workload > MSIM_WL_KAFKA) { set_err(err, errlen, "unknown workload"); return MSIM_E_INVALID; }
   if (c->latency_dist > MSIM_LAT_EXPONENTIAL) { set_err(err, errlen, "latency_dist must be constant, uniform, or exponential"); return MSIM_E_INVALID; }
   if (c->latency_dist == MSIM_LAT_EXPONENTIAL && c->latency_mean_ms == 0) {
     // net.clj:77 (exponential-distribution (/ mean)) throws "Divide by zero" for --latency 0
@@ -99,6 +101,7 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
     case MSIM_WL_PN_COUNTER: case MSIM_WL_G_COUNTER: ok = c->node_program == MSIM_NODE_PN_COUNTER; break;
     case MSIM_WL_UNIQUE_IDS: ok = c->node_program == MSIM_NODE_FLAKE_IDS || c->node_program == MSIM_NODE_TSO_IDS; break;
     case MSIM_WL_TXN_RW_REGISTER: ok = c->node_program == MSIM_NODE_TXN_RW_HAT; break;
+    case MSIM_WL_KAFKA: ok = c->node_program == MSIM_NODE_KAFKA; break;
     default: break;
   }
   if (!ok) { set_err(err, errlen, "node_program does not implement this workload"); return MSIM_E_INVALID; }
@@ -118,6 +121,15 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
     // txn_rw_register_hat.clj:85-90: with no other node the pending set of a txn is empty and replicate-step! sends to nil
     if (hat && (c->n_nodes < 2 || c->n_nodes > 8)) { set_err(err, errlen, "txn-rw-register: 2..8 nodes in this build"); return MSIM_E_UNSUPPORTED; }
   }
+  const bool kafka = c->workload == MSIM_WL_KAFKA;
+  if (kafka) {
+    if (c->key_count == 0) c->key_count = 4;
+    if (c->max_writes_per_key == 0) c->max_writes_per_key = 1024;
+    // the {key offset} maps of the protocol keep insertion order up to 8 entries (Clojure array-maps); message values and offsets
+    // travel in 11 bits of a history row
+    if (c->key_count > 8 || c->max_writes_per_key > 2046) { set_err(err, errlen, "kafka: key-count <= 8, max-writes-per-key <= 2046"); return MSIM_E_INVALID; }
+    if (c->concurrency != c->n_nodes || c->n_nodes > 30) { set_err(err, errlen, "kafka: one worker per node (concurrency == node-count <= 30) in this build"); return MSIM_E_UNSUPPORTED; }
+  }
   double expected = (double)c->rate_mhz * (double)c->time_limit_ms / 1e6;
   uint32_t ops_max = (uint32_t)(expected + expected / 8.0) + 64;
   uint32_t adds = (uint32_t)(ops_max / 2 + 4.0 * std::sqrt((double)ops_max)) + 32;
@@ -129,19 +141,25 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
   if (pn && c->n_nodes > 127) { set_err(err, errlen, "pn-counter: at most 127 nodes in this build"); return MSIM_E_UNSUPPORTED; }
   // pn-counter: a node's state is 2 x n_nodes counters (one G-counter for increments, one for decrements): max_values / 32 words
   if (pn) c->max_values = 64 * c->n_nodes;
-  const bool no_sets = c->workload == MSIM_WL_UNIQUE_IDS || c->workload == MSIM_WL_ECHO || c->workload == MSIM_WL_LIN_KV || txn || pn;
+  if (kafka) c->max_values = 32;   // (keys: at most 8)
+  const bool no_sets = kafka || c->workload == MSIM_WL_UNIQUE_IDS || c->workload == MSIM_WL_ECHO || c->workload == MSIM_WL_LIN_KV || txn || pn;
   // txn-list-append: max_values = distinct keys ever used (a key is retired after max_writes_per_key appends)
   if (txn && c->max_values == 0) c->max_values = c->key_count + (ops_max * c->max_txn_length) / c->max_writes_per_key + 32;
   if (txn && c->max_values > 32767) { set_err(err, errlen, "txn-list-append: more than 32767 keys"); return MSIM_E_INVALID; }
   if (c->max_values == 0) c->max_values = no_sets ? 32 : ((adds + 31) / 32) * 32;
   if (c->max_values % 32) c->max_values = ((c->max_values + 31) / 32) * 32;
-  if (c->max_rows == 0) c->max_rows = 2 * (ops_max + c->concurrency) + 2 * nem_ops + 16;
+  // kafka: the final generator adds an :assign and up to (messages per key / 32 + 2) polls per worker
+  const uint32_t kf_final_ops = kafka ? c->concurrency * (3 + (ops_max / 2 + 31) / 32 + c->max_writes_per_key / 32) : 0;
+  if (c->max_rows == 0) c->max_rows = 2 * (ops_max + c->concurrency + kf_final_ops) + 2 * nem_ops + 16;
   if (c->max_payload_words == 0) {
     uint32_t w = c->max_values / 32;
     uint64_t words = no_sets ? 16 : (uint64_t)(adds + c->concurrency) * w;
     // a transaction: <= L header words at :invoke, <= L x (1 + ceil((writes-per-key + L) / 4)) at completion
     if (txn) words = (uint64_t)(ops_max + c->concurrency) * c->max_txn_length * (2 + (c->max_writes_per_key + c->max_txn_length + 3) / 4) + 64;  // worst case: all reads of full lists
     if (hat) words = (uint64_t)(ops_max + c->concurrency) * c->max_txn_length * 2 + 64;  // one word per micro-op at :invoke and at completion
+    // kafka: a poll asks with <= 8 words and brings <= 8 x (1 + 16) back, the list_committed_offsets reply 8; every message is polled by
+    // every worker in the final phase (two per word + headers)
+    if (kafka) words = (uint64_t)(ops_max + c->concurrency) * 80 + (uint64_t)c->concurrency * (ops_max / 2 + 8ull * c->max_writes_per_key / 32 * 2 + 64) + (uint64_t)kf_final_ops * 24 + 64;
     words += (uint64_t)nem_ops * c->n_nodes * MSIM_MASK_WORDS + 16;
     if (words > 0xFFFFFFu) { set_err(err, errlen, "payload area above 2^24 words per instance"); return MSIM_E_INVALID; }
     c->max_payload_words = (uint32_t)words;
@@ -162,7 +180,7 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
     if (c->node_program == MSIM_NODE_BCAST_ACK_RETRY && c->nemesis_mask) depth += (deg < 4 ? deg : 4) * adds;
     if (c->node_program == MSIM_NODE_G_SET || c->node_program == MSIM_NODE_PN_COUNTER) depth = 16 + 2 * deg;  // one replicate_full per peer per 5 s tick (g_set.rb:33-38)
     if (c->node_program == MSIM_NODE_RAFT) depth = 24 + 1024;   // heartbeats / re-sent append_entries pile up behind a sleeping recv!
-    if (txn) depth = 16 + 4 * c->n_nodes;                       // the service sees <= 2 requests per transaction in flight
+    if (txn || kafka) depth = 16 + 4 * c->n_nodes;              // the service sees <= 2 requests per transaction in flight
     if (c->node_program == MSIM_NODE_TXN_MULTI_KEY) depth = 16 + 16 * c->n_nodes;   // lww-kv: up to max-txn-length thunk reads / writes per transaction
     if (hat) depth = 16 + 4 * c->n_nodes + (uint32_t)(20.0 * c->n_nodes * lat_s);  // a replicate + n-1 acks per peer per 100 ms tick
     if (c->node_program == MSIM_NODE_LIN_KV_PROXY || c->node_program == MSIM_NODE_TSO_IDS) depth = 16 + 2 * c->concurrency;   // the service sees every worker's request at once

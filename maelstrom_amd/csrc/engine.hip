@@ -743,6 +743,7 @@ __global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
 #include "sim_kernel_txn.inc"
 #include "sim_kernel_mk.inc"
 #include "sim_kernel_hat.inc"
+#include "sim_kernel_kafka.inc"
 #include "sim_kernel_svc.inc"
 
 // =====================================================================================================
@@ -870,6 +871,7 @@ static uint64_t proto_scratch_words(const msim_config &c) {
   if (c.node_program == MSIM_NODE_TXN_SINGLE_KEY) w = (uint64_t)c.max_values * (c.max_writes_per_key + 1);  // elements + counts per key
   if (c.node_program == MSIM_NODE_TXN_MULTI_KEY)   // elements, counts, map position, entry version, thunk counts, thunk versions + ids, the nodes' caches, the replica bytes
     w = (uint64_t)c.max_values * (c.max_writes_per_key + 4 + 2 * (c.max_writes_per_key + 1)) + (uint64_t)c.n_nodes * mk_ccap(c) + (uint64_t)c.n_nodes * mk_tcap(c) / 4;
+  if (c.node_program == MSIM_NODE_KAFKA) w = (uint64_t)KF_KEYS * (2 * (c.max_writes_per_key + 1) + 1);   // the logs + the committed-offset lists of the keys
   if (c.node_program == MSIM_NODE_TXN_RW_HAT) {  // registers per node + txn table + pending masks (bytes) + replicate lists
     const uint64_t G = c.max_rows / 2;
     w = (uint64_t)c.n_nodes * c.max_values + 2 * G + ((uint64_t)c.n_nodes * G + 3) / 4 + c.replication_words;
@@ -888,7 +890,7 @@ static uint64_t proto_scratch_words(const msim_config &c) {
   return (w + 3) & ~3ull;  // keep the spill area 16-byte aligned
 }
 static uint64_t scratch_words(const msim_config &c) {
-  const uint64_t queues = c.n_nodes + (c.node_program == MSIM_NODE_TXN_SINGLE_KEY || c.node_program == MSIM_NODE_LIN_KV_PROXY || c.node_program == MSIM_NODE_TSO_IDS ? 1 : c.node_program == MSIM_NODE_TXN_MULTI_KEY ? 2 : 0);  // + the services
+  const uint64_t queues = c.n_nodes + (c.node_program == MSIM_NODE_KAFKA || c.node_program == MSIM_NODE_TXN_SINGLE_KEY || c.node_program == MSIM_NODE_LIN_KV_PROXY || c.node_program == MSIM_NODE_TSO_IDS ? 1 : c.node_program == MSIM_NODE_TXN_MULTI_KEY ? 2 : 0);  // + the services
   uint64_t w = proto_scratch_words(c) + queues * c.spill_capacity * 4;
   if (msim_raft4_eligible(c)) w += msim_raft4_extra_scratch_words(c);   // raft4.hip keeps fewer envelopes in LDS
   if (msim_txn8_eligible(c)) w += msim_txn8_extra_scratch_words(c);     // txn8.hip likewise
@@ -964,16 +966,17 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   const bool wide = c.n_nodes > 32;
   size_t off = (wide ? WIDE_STAGE_ROWS : STAGE_ROWS) * 16;
   const bool is_txn = c.node_program == MSIM_NODE_TXN_SINGLE_KEY, is_px = c.node_program == MSIM_NODE_LIN_KV_PROXY || c.node_program == MSIM_NODE_TSO_IDS;
-  const bool is_hat = c.node_program == MSIM_NODE_TXN_RW_HAT, is_mk = c.node_program == MSIM_NODE_TXN_MULTI_KEY;
+  const bool is_hat = c.node_program == MSIM_NODE_TXN_RW_HAT, is_mk = c.node_program == MSIM_NODE_TXN_MULTI_KEY, is_kf = c.node_program == MSIM_NODE_KAFKA;
   kp.mk_tcap = is_mk ? mk_tcap(c) : 0; kp.mk_ccap = is_mk ? mk_ccap(c) : 0;
   kp.off_inbox = (u32)off;
-  off += is_mk ? ((size_t)(kp.N + 2) * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16 : is_hat ? ((size_t)kp.N * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16 : is_px ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.CS * R_CLIENT_CAP) * 16 : is_txn ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16
+  off += is_mk ? ((size_t)(kp.N + 2) * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16 : is_hat ? ((size_t)kp.N * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16 : is_px ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.CS * R_CLIENT_CAP) * 16 : (is_txn || is_kf) ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16
                 : ((size_t)kp.N * kp.cap_node + (size_t)kp.CS * (is_raft ? R_CLIENT_CAP : CLIENT_INBOX_CAP)) * 16;
   kp.off_seen = (u32)off;
   off += is_mk ? ((size_t)kp.N * MK_SLOTS * MKW + (size_t)kp.N * MK_KEYS * 3 + 36) * 4   // transactions in flight, a round's messages per node, the generator's key pool
        : is_hat ? 36 * 4   // the generator's key pool
        : is_px ? (size_t)kp.N * PX_SLOTS * 8 + 34 * 256 + 64 * 4   // callbacks per node + service states + seq-kv indices
        : is_txn ? (size_t)kp.N * TXN_SLOTS * 16 + 36 * 4   // transactions in flight per node + the generator's key pool
+       : is_kf ? ((size_t)kp.N * KF_SLOTS * KSW + 2 * (size_t)kp.N * KF_KEYS + 36 + 2 * KF_KEYS) * 4   // request handlers, offset caches, client offsets, key pool, lin-kv lengths
        : is_raft ? (size_t)kp.N * 256 + (size_t)kp.N * kp.N * 3 * 4   // KV state + next/match index + append_entries refs
        : wide ? 0   // the sets of a wide cluster live in HBM scratch
                  : (size_t)kp.N * kp.W * 4;
@@ -1046,6 +1049,12 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
       void (*fn)(const KParams) = c.nemesis_mask ? (rnd ? mk_kernel<true, true> : mk_kernel<true, false>) : (rnd ? mk_kernel<false, true> : mk_kernel<false, false>);
       e = lds > 64 * 1024 ? hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) : hipSuccess;   // (above ~17 nodes)
       if (e == hipSuccess) { hipLaunchKernelGGL(fn, dim3(n), dim3(64), lds, st, kp); e = hipGetLastError(); }
+    } break;
+    case MSIM_NODE_KAFKA: {
+      const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
+      if (c.nemesis_mask) { if (rnd) hipLaunchKernelGGL((kafka_kernel<true, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((kafka_kernel<true, false>), dim3(n), dim3(64), lds, st, kp); }
+      else { if (rnd) hipLaunchKernelGGL((kafka_kernel<false, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((kafka_kernel<false, false>), dim3(n), dim3(64), lds, st, kp); }
+      e = hipGetLastError();
     } break;
     case MSIM_NODE_TXN_RW_HAT: {
       const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;

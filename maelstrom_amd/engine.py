@@ -23,13 +23,13 @@ CHECK_DT = np.dtype([("valid", "<u4"), ("attempt_count", "<u4"), ("stable_count"
 
 WORKLOADS = {"echo": A.WL_ECHO, "broadcast": A.WL_BROADCAST, "g-set": A.WL_G_SET, "lin-kv": A.WL_LIN_KV,
              "txn-list-append": A.WL_TXN_LIST_APPEND, "pn-counter": A.WL_PN_COUNTER, "g-counter": A.WL_G_COUNTER, "unique-ids": A.WL_UNIQUE_IDS,
-             "txn-rw-register": A.WL_TXN_RW_REGISTER}
+             "txn-rw-register": A.WL_TXN_RW_REGISTER, "kafka": A.WL_KAFKA}
 NODE_PROGRAMS = {"echo": A.NODE_ECHO, "broadcast-ff": A.NODE_BCAST_FF, "broadcast-ff-echoback": A.NODE_BCAST_FF_ECHOBACK,
                  "broadcast-ack-retry": A.NODE_BCAST_ACK_RETRY, "broadcast-rpc-all": A.NODE_BCAST_RPC_ALL,
                  "g-set": A.NODE_G_SET, "raft": A.NODE_RAFT, "single-key-txn": A.NODE_TXN_SINGLE_KEY,
                  "pn-counter": A.NODE_PN_COUNTER, "flake-ids": A.NODE_FLAKE_IDS, "lin-kv-proxy": A.NODE_LIN_KV_PROXY,
                  "txn-rw-register-hat": A.NODE_TXN_RW_HAT,
-                 "multi-key-txn": A.NODE_TXN_MULTI_KEY, "tso-ids": A.NODE_TSO_IDS}
+                 "multi-key-txn": A.NODE_TXN_MULTI_KEY, "tso-ids": A.NODE_TSO_IDS, "kafka": A.NODE_KAFKA}
 SERVICES = {"lin-kv": A.SVC_LIN_KV, "seq-kv": A.SVC_SEQ_KV, "lww-kv": A.SVC_LWW_KV}
 CONSISTENCY_MODELS = {"strict-serializable": A.CM_STRICT_SERIALIZABLE, "serializable": A.CM_SERIALIZABLE,
                       "snapshot-isolation": A.CM_SNAPSHOT_ISOLATION, "read-committed": A.CM_READ_COMMITTED,
@@ -40,7 +40,7 @@ LATENCY_DISTS = {"constant": A.LAT_CONSTANT, "uniform": A.LAT_UNIFORM, "exponent
 TYPE_KW = {A.T_INVOKE: ":invoke", A.T_OK: ":ok", A.T_FAIL: ":fail", A.T_INFO: ":info"}
 F_KW = {A.F_ECHO: ":echo", A.F_BROADCAST: ":broadcast", A.F_READ: ":read", A.F_ADD: ":add",
         A.F_START_PARTITION: ":start-partition", A.F_STOP_PARTITION: ":stop-partition", A.F_WRITE: ":write", A.F_CAS: ":cas",
-        A.F_TXN: ":txn", A.F_GENERATE: ":generate"}
+        A.F_TXN: ":txn", A.F_GENERATE: ":generate", A.F_SEND: ":send", A.F_POLL: ":poll", A.F_ASSIGN: ":assign", A.F_CRASH: ":crash"}
 ERR_KW = {A.ERR_NET_TIMEOUT: ":net-timeout", A.ERR_TEMPORARILY_UNAVAILABLE: [":temporarily-unavailable", "not a leader"],
           A.ERR_KEY_DOES_NOT_EXIST: [":key-does-not-exist", "not found"], A.ERR_PRECONDITION_FAILED: [":precondition-failed", "cas mismatch"],
           A.ERR_TXN_CONFLICT: [":txn-conflict", "root altered"]}
@@ -306,6 +306,20 @@ def encode_rw_txn(txn):
     return [(1 if f == ":w" else 0) | (k << 1) | ((0xFF if v is None else v) << 16) for f, k, v in txn]
 
 
+def decode_poll(words):
+    """The poll_ok block of a kafka :poll -> {key [[offset msg] ...]} (include/maelsim.h msim_op)."""
+    out, i, words = {}, 0, [int(w) for w in words]
+    while i < len(words):
+        h = words[i]; i += 1
+        key, n, o = h & 7, (h >> 8) & 0xFF, h >> 16
+        msgs = []
+        for e in range(n):
+            msgs.append([o + e, (words[i + e // 2] >> (16 * (e % 2))) & 0xFFFF])
+        i += (n + 1) // 2
+        out[str(key)] = msgs
+    return out
+
+
 def decode_txn(words):
     """Payload words of one transaction -> [[f k v] ...] (txn_list_append.clj:27-39; encoding: include/maelsim.h msim_op)."""
     out, i, words = [], 0, [int(w) for w in words]
@@ -425,6 +439,20 @@ def decode_history(rows, payload, n_nodes, workload=A.WL_BROADCAST, node_program
             op["value"] = value if typ == A.T_OK else None
         elif f == A.F_GENERATE:   # flake id [time count node-id], flake_ids.clj:30-31
             op["value"] = [value >> 20, (value >> 5) & 0x7FFF, f"n{value & 31}"] if typ == A.T_OK else None
+        elif f == A.F_SEND:   # [[:send k msg]] / [[:send k [offset msg]]], workload/kafka.clj:188-190
+            k, msg, off = value & 63, (value >> 6) & 0x7FF, value >> 17
+            op["value"] = [[":send", str(k), msg if off == 0x7FF else [off, msg]]]
+        elif f == A.F_POLL:   # [[:poll]] / [[:poll {k [[offset msg] ...]}]], :171-186 (keys are strings, :247-283)
+            op["value"] = [[":poll", decode_poll(payload[value:value + ln])]] if typ == A.T_OK else [[":poll"]]
+            if typ != A.T_OK and ln:
+                op["offsets"] = {str(int(w) & 7): int(w) >> 8 for w in payload[value:value + ln]}   # engine abstraction: what the client asked with
+        elif f == A.F_ASSIGN:
+            ws = [int(w) for w in payload[value:value + ln]]
+            op["value"] = [str(w & 7) for w in ws]
+            if ws and ws[0] >> 31:
+                op["seek-to-beginning?"] = True
+        elif f == A.F_CRASH:
+            op["value"] = None
         elif f == A.F_TXN:
             op["value"] = (decode_rw_txn if workload == A.WL_TXN_RW_REGISTER else decode_txn)(payload[value:value + ln])
         elif workload in (A.WL_PN_COUNTER, A.WL_G_COUNTER) and f in (A.F_ADD, A.F_READ):  # pn_counter.clj:22-58: signed delta / counter value

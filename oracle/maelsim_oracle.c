@@ -75,7 +75,7 @@ enum { S_GEN = 1, S_GEN2 = 2, S_GEN3 = 3, S_LATENCY = 4, S_LOSS = 5, S_NODE = 11
        S_NEM_STAGGER = 7, S_NEM_SPEC = 8, S_NEM_SHUFFLE = 9, S_NEM_PICK = 10 };
 
 enum { PH_INIT, PH_INIT_WAIT, PH_TOPO, PH_TOPO_WAIT, PH_MAIN_START, PH_MAIN, PH_DRAIN, PH_NEM_FINAL,
-       PH_SLEEP, PH_FINAL, PH_FINAL_WAIT, PH_DONE };
+       PH_SLEEP, PH_FINAL, PH_FINAL_WAIT, PH_DONE, PH_KF_FINAL /* kafka: final polls */ };
 
 enum { K_NONE = 0, K_INIT, K_TOPO, K_OP };
 
@@ -94,6 +94,7 @@ typedef struct {
   struct svc_s *svc;  /* proxy node + key-value services (svc_nodes.inc) */
   struct hat_s *hat;  /* txn-rw-register highly-available-transactions node (hat_nodes.inc) */
   struct mk_s *mk;    /* txn-list-append over thunks in lww-kv and a root map in lin-kv (mk_nodes.inc) */
+  struct kafka_s *kafka; /* kafka workload: node, lin-kv contents, clients' offsets, generator (kafka_nodes.inc) */
   u32 *rtrace; u32 n_rtrace, cap_rtrace; /* test hook: what every Raft node did in every round (oracle_raft_schedule) */
   u64 key;
   u32 adj[MAXN][MW];
@@ -183,7 +184,7 @@ static void inbox_push(sim_t *s, u32 ep, qent q) {
   inbox_t *b = &s->inbox[ep];
   if (b->n == b->cap) { b->cap = b->cap ? b->cap * 2 : 8; b->v = (qent *)realloc(b->v, b->cap * sizeof(qent)); }
   b->v[b->n++] = q;
-  u32 lim = is_client(s, ep) ? (reusable_clients(s) && (s->cfg.workload != MSIM_WL_UNIQUE_IDS || s->cfg.node_program == MSIM_NODE_TSO_IDS) ? 32u : 2u) /* Reusable clients collect late replies */
+  u32 lim = is_client(s, ep) ? (reusable_clients(s) && (s->cfg.workload != MSIM_WL_UNIQUE_IDS || s->cfg.node_program == MSIM_NODE_TSO_IDS) ? 32u : s->cfg.workload == MSIM_WL_KAFKA ? 8u : 2u) /* Reusable clients collect late replies */
                              : s->cfg.inbox_capacity + s->cfg.spill_capacity; /* engine capacities: overflow is flagged, never silent */
   if (b->n > lim) s->meta.flags |= MSIM_FLAG_INBOX_OVERFLOW;
 }
@@ -381,6 +382,7 @@ static void node_timer(sim_t *s, u32 node) {
 #include "mk_nodes.inc"
 #include "svc_nodes.inc"
 #include "hat_nodes.inc"
+#include "kafka_nodes.inc"
 
 static void node_handle(sim_t *s, u32 node, const qent *q) {
   if (s->cfg.node_program == MSIM_NODE_RAFT) { raft_handle(s, node, q); return; }
@@ -389,6 +391,7 @@ static void node_handle(sim_t *s, u32 node, const qent *q) {
   if (s->cfg.node_program == MSIM_NODE_LIN_KV_PROXY) { px_node_handle(s, node, q); return; }
   if (s->cfg.node_program == MSIM_NODE_TSO_IDS) { tso_node_handle(s, node, q); return; }
   if (s->cfg.node_program == MSIM_NODE_TXN_RW_HAT) { hat_node_handle(s, node, q); return; }
+  if (s->cfg.node_program == MSIM_NODE_KAFKA) { kf_node_handle(s, node, q); return; }
   switch (q->type) {
     case M_INIT: /* node.rb init handler -> init_ok; g-set starts its periodic task (node.rb:129-138) */
       if (s->cfg.node_program == MSIM_NODE_G_SET || s->cfg.node_program == MSIM_NODE_PN_COUNTER) s->timer_next[node] = s->T;
@@ -440,6 +443,7 @@ static void client_complete(sim_t *s, u32 slot, u32 type, u32 err, u32 value, u3
     if (!reusable_clients(s)) { /* Reusable clients (lin_kv.clj:74-76) are not re-opened */
       c->next_msg_id = 0;
       s->inbox[s->N + slot].n = 0;
+      if (s->kafka) kf_client_reopen(s, slot);
     }
   }
 }
@@ -447,6 +451,7 @@ static void client_complete(sim_t *s, u32 slot, u32 type, u32 err, u32 value, u3
 static void client_deliver(sim_t *s, u32 slot, const qent *q) {
   struct cl *c = &s->cl[slot];
   if (!c->busy || q->b != c->want) return; /* stale reply, client.clj:105-107 */
+  if (s->kafka && c->kind == K_OP) { kf_client_deliver(s, slot, q); return; }
   switch (q->type) {
     case M_READ_OK:
       if (s->cfg.workload == MSIM_WL_LIN_KV) client_complete(s, slot, MSIM_T_OK, 0, (c->value & 0xFFu) | ((q->a & 0xFFu) << 8) | 0xFF0000u, 0); /* [k v], lin_kv.clj:56-61 */
@@ -465,6 +470,7 @@ static void client_deliver(sim_t *s, u32 slot, const qent *q) {
 
 static void client_timeout(sim_t *s, u32 slot) { /* client.clj:96-103 + :158-162 */
   struct cl *c = &s->cl[slot];
+  if (s->kafka && c->kind == K_OP) { kf_client_timeout(s, slot); return; }
   u32 type = idempotent(s, c->f) ? MSIM_T_FAIL : MSIM_T_INFO;
   u32 v = c->f == MSIM_F_READ && s->cfg.workload != MSIM_WL_LIN_KV ? MSIM_NO_VALUE : c->value;
   if (c->f == MSIM_F_TXN) client_complete(s, slot, type, MSIM_ERR_NET_TIMEOUT, v & 0xFFFFFFu, v >> 24);
@@ -477,6 +483,11 @@ static void client_invoke(sim_t *s, u32 slot) {
   u32 ep = s->N + slot, dest, type, a = 0;
   if (c->kind == K_INIT) { dest = slot; type = M_INIT; c->next_msg_id = 0; }
   else if (c->kind == K_TOPO) { dest = slot; type = M_TOPOLOGY; c->next_msg_id = 0; }
+  else if (s->kafka) { /* one or two RPCs per operation, or none (kafka_nodes.inc) */
+    if (s->kafka->cl[slot].stage != 2) { c->f = c->m_f; c->value = c->m_value; }
+    dest = c->process % s->N;
+    if (!kf_client_invoke(s, slot, &type, &a)) return;
+  }
   else {
     c->f = c->m_f; c->value = c->m_value;
     dest = c->process % s->N; /* worker -> node: nodes[process mod n] [upstream] */
@@ -506,7 +517,7 @@ static u32 stagger_us(const sim_t *s, u32 stream, u32 k, u64 period_us) { /* uni
 }
 static int any_busy(const sim_t *s, u32 n) { for (u32 i = 0; i < n; i++) if (s->cl[i].busy) return 1; return 0; }
 static int counter_workload(const sim_t *s) { return s->cfg.workload == MSIM_WL_PN_COUNTER || s->cfg.workload == MSIM_WL_G_COUNTER; }
-static int has_final(const sim_t *s) { return s->cfg.workload == MSIM_WL_BROADCAST || s->cfg.workload == MSIM_WL_G_SET || counter_workload(s); }
+static int has_final(const sim_t *s) { return s->cfg.workload == MSIM_WL_BROADCAST || s->cfg.workload == MSIM_WL_G_SET || counter_workload(s) || s->cfg.workload == MSIM_WL_KAFKA; }
 static int nem_on(const sim_t *s) { return (s->cfg.nemesis_mask & MSIM_NEMESIS_PARTITION) != 0; }
 static int gen_live(const sim_t *s) { return s->cfg.rate_mhz > 0 && s->gen_next < s->cutoff; }
 static int nem_live(const sim_t *s) { return nem_on(s) && s->nem_next < s->cutoff; }
@@ -532,6 +543,9 @@ static void sched_resolve(sim_t *s) {
         if (s->phase == PH_SLEEP) s->sleep_until = s->T + s->cfg.quiesce_ms * 1000u;
         continue;
       case PH_FINAL_WAIT: if (any_busy(s, s->C)) return; s->phase = PH_DONE; continue;
+      case PH_KF_FINAL: /* every worker has polled until nothing came (or the 10 s of workload/kafka.clj:305-306 are over) */
+        for (u32 i = 0; i < s->C; i++) if (s->cl[i].busy || (!s->kafka->cl[i].done && s->T < s->kafka->final_deadline)) return;
+        s->phase = PH_DONE; continue;
       default: return;
     }
   }
@@ -543,6 +557,9 @@ static u32 sched_due(const sim_t *s) {
   switch (s->phase) {
     case PH_INIT: case PH_TOPO: case PH_NEM_FINAL: case PH_FINAL: return T;
     case PH_SLEEP: return s->sleep_until;
+    case PH_KF_FINAL:
+      if (T < s->kafka->final_deadline) for (u32 i = 0; i < s->C; i++) if (!s->cl[i].busy && !s->kafka->cl[i].done) return T;
+      return INF;
     case PH_MAIN:
       if (nem_live(s)) d = s->nem_next > T ? s->nem_next : T;
       if (gen_live(s)) { int fr = 0; for (u32 i = 0; i < s->C; i++) fr |= !s->cl[i].busy;
@@ -607,6 +624,9 @@ static void sched_act(sim_t *s) {
             else if (scale32((u32)h2, 3) == 0) { c->m_f = MSIM_F_WRITE; c->m_value = key | (v1 << 8) | 0xFF0000u; }
             else { c->m_f = MSIM_F_CAS; c->m_value = key | (v1 << 8) | (v2 << 16); }
           }
+          else if (s->kafka) {
+            if (!kf_generate(s, k, c)) { c->mark = 0; s->phase = PH_DONE; return; }
+          }
           else if (txn_workload(s)) {
             u32 ref = txn_generate(s, k);
             if (ref == INF) { c->mark = 0; s->phase = PH_DONE; return; }
@@ -637,9 +657,18 @@ static void sched_act(sim_t *s) {
       s->phase = PH_SLEEP; s->sleep_until = T + s->cfg.quiesce_ms * 1000u; break;
     case PH_SLEEP: if (T >= s->sleep_until) s->phase = PH_FINAL; else break; /* fallthrough */
     case PH_FINAL: /* (gen/clients (gen/each-thread {:f :read [:final? true]})), broadcast.clj:240, g_set.clj:61 */
+      if (s->kafka) { /* [upstream] the final generator of jepsen.tests.kafka, clipped to 10 s (workload/kafka.clj:305-306) */
+        for (u32 i = 0; i < s->C; i++) { struct cl *c = &s->cl[i]; c->mark = 1; c->kind = K_OP; c->m_final = 0; s->kafka->cl[i].fin = 1;
+          if (!kf_final_assign(s, c)) { c->mark = 0; s->phase = PH_DONE; return; } }
+        s->kafka->final_deadline = T + 10000000u; s->phase = PH_KF_FINAL; break;
+      }
       for (u32 i = 0; i < s->C; i++) { struct cl *c = &s->cl[i]; c->mark = 1; c->kind = K_OP; c->m_f = MSIM_F_READ; c->m_value = MSIM_NO_VALUE;
         c->m_final = s->cfg.workload == MSIM_WL_BROADCAST || s->cfg.workload == MSIM_WL_PN_COUNTER || s->cfg.workload == MSIM_WL_G_COUNTER; } /* pn_counter.clj:137 */
       s->phase = PH_FINAL_WAIT; break;
+    case PH_KF_FINAL:
+      for (u32 i = 0; i < s->C; i++) { struct cl *c = &s->cl[i];
+        if (!c->busy && !s->kafka->cl[i].done && T < s->kafka->final_deadline) { c->mark = 1; c->kind = K_OP; c->m_final = 0; c->m_f = MSIM_F_POLL; c->m_value = MSIM_NO_VALUE; } }
+      break;
     default: break;
   }
 }
@@ -701,6 +730,7 @@ static void run_instance(sim_t *s) {
     for (u32 e = 0; e < E; e++) if (s->has_committed[e] && s->deliver_at[e] < tn) tn = s->deliver_at[e];
     for (u32 n = 0; n < N; n++) { u32 t = s->raft ? raft_next_time(s, n) : node_timer_time(s, n); if (t < tn) tn = t; }
     for (u32 c = 0; c < s->CS; c++) if (s->cl[c].busy && s->cl[c].timeout_at < tt) tt = s->cl[c].timeout_at;
+    for (u32 c = 0; c < s->CS; c++) if (s->cl[c].mark) tn = s->T; /* a client between the two RPCs of one operation (kafka poll -> commit_offsets) sends the second at once */
     if (tn == INF && tt == INF) { s->meta.flags |= MSIM_FLAG_ROUND_LIMIT; break; } /* stuck */
     int timeout_round = tt < tn;
     u32 T = timeout_round ? tt : tn;
@@ -716,7 +746,9 @@ static void run_instance(sim_t *s) {
     if (sched_due(s) <= T) sched_act(s);
     if (s->phase == PH_DONE) break;
     /* R2: marked clients invoke (slot order); their requests are committed and idle receivers poll */
+    if (s->kafka) s->defer_rows = 1; /* an operation that needs no RPC (:crash, :assign with :seek-to-beginning?) completes here: its row follows the round's invocations */
     for (u32 c = 0; c < s->CS; c++) if (s->cl[c].mark) client_invoke(s, c);
+    s->defer_rows = 0;
     commit_sends(s);
     for (u32 e = 0; e < E; e++) poll_endpoint(s, e);
     /* R3: one input per node (node order): a due timer, else the due committed message */
@@ -739,7 +771,7 @@ static void run_instance(sim_t *s) {
         qent q = s->committed[e]; s->has_committed[e] = 0;
         s->st.all_recv++; s->st.servers_recv++;
         jlog(s, 1, q.id, q.type, q.a, q.b, q.src, e);
-        if (s->mk) mk_svc_handle(s, e, &q); else if (s->cfg.node_program == MSIM_NODE_TSO_IDS) tso_svc_handle(s, &q); else if (s->svc) px_svc_handle(s, &q); else svc_handle(s, &q);
+        if (s->kafka) kf_svc_handle(s, &q); else if (s->mk) mk_svc_handle(s, e, &q); else if (s->cfg.node_program == MSIM_NODE_TSO_IDS) tso_svc_handle(s, &q); else if (s->svc) px_svc_handle(s, &q); else svc_handle(s, &q);
       }
     commit_sends(s);
     for (u32 e = 0; e < E; e++) poll_endpoint(s, e);
@@ -777,7 +809,7 @@ static sim_t *sim_new(const msim_config *cfg, uint64_t instance, msim_op *rows, 
   sim_t *s = (sim_t *)calloc(1, sizeof(sim_t));
   s->cfg = *cfg;
   s->N = cfg->n_nodes; s->C = cfg->concurrency; s->CS = s->C > s->N ? s->C : s->N;
-  s->S = cfg->node_program == MSIM_NODE_TXN_SINGLE_KEY || cfg->node_program == MSIM_NODE_LIN_KV_PROXY || cfg->node_program == MSIM_NODE_TSO_IDS ? 1 : cfg->node_program == MSIM_NODE_TXN_MULTI_KEY ? 2 : 0; /* lin-kv (+ lww-kv) */
+  s->S = cfg->node_program == MSIM_NODE_KAFKA || cfg->node_program == MSIM_NODE_TXN_SINGLE_KEY || cfg->node_program == MSIM_NODE_LIN_KV_PROXY || cfg->node_program == MSIM_NODE_TSO_IDS ? 1 : cfg->node_program == MSIM_NODE_TXN_MULTI_KEY ? 2 : 0; /* lin-kv (+ lww-kv) */
   s->E = s->N + s->CS + s->S;
   if (s->E > 255) { free(s); return NULL; }
   s->W = (cfg->max_values + 31) / 32;
@@ -811,6 +843,7 @@ static sim_t *sim_new(const msim_config *cfg, uint64_t instance, msim_op *rows, 
     v->client_idx = (u32 *)calloc(s->E, 4);
     memset(v->kv, 0xFF, 256); memset(v->ring, 0xFF, sizeof v->ring); memset(v->rep, 0xFF, sizeof v->rep);
     s->svc = v;
+  } else if (cfg->node_program == MSIM_NODE_KAFKA) { s->kafka = kf_new(s);
   } else if (s->S || cfg->node_program == MSIM_NODE_TXN_RW_HAT) { /* (the multi-key node too: generator state + the elements' versions) */
     txn_t *t = (txn_t *)calloc(1, sizeof(txn_t)); /* the rw-register workload only uses the generator state */
     t->slots = (tslot *)calloc((size_t)s->N * TXN_SLOTS, sizeof(tslot));
@@ -842,6 +875,7 @@ static void sim_free(sim_t *s) {
   if (s->svc) { free(s->svc->cb); free(s->svc->client_idx); free(s->svc); }
   if (s->hat) hat_free(s->hat);
   mk_free(s->mk, s->N);
+  kf_free(s->kafka);
   if (s->txn) { free(s->txn->slots); free(s->txn->kv); free(s->txn->kv_n); free(s->txn); }
   free(s->snap); free(s->inbox); free(s->committed); free(s->has_committed); free(s->deliver_at); free(s->seen);
   free(s->unacked); free(s->node_msg_id); free(s->nbr_known); free(s->tasks); free(s->key_reg); free(s->timer_next); free(s->tick); free(s->flake);

@@ -1,0 +1,33 @@
+"""kafka workload (workload/kafka.clj over demo/clojure/kafka.clj): the HIP engine against the CPU oracle, bit for bit."""
+import numpy as np
+import pytest
+
+from maelstrom_amd import _abi as A
+from maelstrom_amd import engine as E
+from test_parity_gpu import _compare
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    dict(node_count=3, rate=50, time_limit=5, latency=5, seed=3),
+    dict(node_count=5, rate=100, time_limit=6, latency=0, seed=4),
+    dict(node_count=5, rate=100, time_limit=6, latency=20, latency_dist="exponential", seed=5),
+    dict(node_count=4, rate=60, time_limit=8, latency=10, latency_dist="uniform", p_loss=0.05, seed=6),
+    dict(node_count=5, rate=80, time_limit=10, latency=5, nemesis=["partition"], nemesis_interval=3, seed=7),
+    dict(node_count=2, rate=200, time_limit=4, latency=2, key_count=2, max_writes_per_key=40, seed=8),   # keys retire, chunks fill
+    dict(node_count=5, rate=100, time_limit=5, latency=150, seed=9),                                    # slow lin-kv: client timeouts
+    dict(node_count=3, rate=30, time_limit=4, latency=3, journal=True, seed=10),
+]
+
+
+@pytest.mark.parametrize("kw", SHAPES)
+def test_kafka_parity(lib, kw):
+    kw = dict(kw)
+    journal = kw.pop("journal", False)
+    cfg = E.test_config("kafka", **kw)
+    if journal:
+        cfg.journal_capacity = 60000
+    ora = _compare(cfg, 0, 6)
+    ops = E.decode_history(*ora.history(0), cfg.n_nodes, A.WL_KAFKA)
+    fs = {op["f"] for op in ops}
+    assert {":send", ":poll", ":assign"} <= fs
