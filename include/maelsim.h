@@ -319,6 +319,15 @@ int msim_check_pn_batch(int device, const msim_op *rows, const uint32_t *n_rows,
 int msim_check_set_full_batch(int device, uint32_t workload, uint32_t concurrency, const msim_op *rows, const uint32_t *n_rows, uint32_t max_rows,
                               const uint32_t *payload, uint32_t max_payload_words, uint32_t max_values, uint32_t n_histories, msim_check_result *out);
 
+/* kafka: the checker behind msim_check for MSIM_WL_KAFKA on ONE history given on the host (csrc/kafka_check.cpp): the anomalies
+ * workload/kafka.clj:21-70 describes ([upstream] jepsen.tests.kafka's checker is not vendored: parity unpinned).  out->error_count =
+ * MSIM_KAFKA_* bits, valid = 1 iff none (2 = :unknown: nothing acknowledged, nothing polled), attempt_count / stable_count = sends invoked
+ * / acknowledged, lost_count = lost writes, never_read_count = unobserved writes (reported, not an error), duplicated_count. */
+enum { MSIM_KAFKA_LOST_WRITE = 1u, MSIM_KAFKA_NONMONOTONIC_POLL = 2u, MSIM_KAFKA_NONMONOTONIC_SEND = 4u, MSIM_KAFKA_POLL_SKIP = 8u,
+       MSIM_KAFKA_INT_NONMONOTONIC_POLL = 16u, MSIM_KAFKA_INT_POLL_SKIP = 32u, MSIM_KAFKA_INCONSISTENT_OFFSETS = 64u,
+       MSIM_KAFKA_DUPLICATE = 128u, MSIM_KAFKA_ABORTED_READ = 256u, MSIM_KAFKA_MALFORMED = 512u /* a row that does not decode */ };
+int msim_check_kafka_rows(const msim_op *rows, uint32_t n_rows, const uint32_t *payload, uint32_t n_words, msim_check_result *out);
+
 /* unique-ids: checks `n_histories` histories given on the host — history i in the slab rows + i * max_rows, n_rows[i] rows used —
  * with the device checker of msim_check ([upstream] jepsen.checker/unique-ids); out[i] is what msim_check_unique_rows gives. */
 int msim_check_unique_batch(int device, const msim_op *rows, const uint32_t *n_rows, uint32_t max_rows, uint32_t n_histories, msim_check_result *out);

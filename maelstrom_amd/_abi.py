@@ -31,13 +31,15 @@ FLAG_ROWS_OVERFLOW, FLAG_PAYLOAD_OVERFLOW, FLAG_INBOX_OVERFLOW, FLAG_VALUES_OVER
 MSG_TYPES = ["", "init", "init_ok", "topology", "topology_ok", "echo", "echo_ok", "broadcast", "broadcast_ok", "read", "read_ok",
              "add", "add_ok", "replicate", "write", "write_ok", "cas", "cas_ok", "error", "request_vote", "request_vote_res",
              "append_entries", "append_entries_res", "txn", "txn_ok", "generate", "generate_ok", "replicate_ack", "ts", "ts_ok"]
+KAFKA_ANOMALIES = {1: "lost-write", 2: "nonmonotonic-poll", 4: "nonmonotonic-send", 8: "poll-skip", 16: "int-nonmonotonic-poll", 32: "int-poll-skip",
+                   64: "inconsistent-offsets", 128: "duplicate", 256: "aborted-read", 512: "malformed"}
 ANOMALIES = {1: "G0", 2: "G1a", 4: "G1b", 8: "G1c", 16: "G-single", 32: "G2", 64: "internal", 128: "duplicate-elements",
              256: "incompatible-order", 512: "realtime", 1024: "dirty-update", 2048: "cyclic-versions"}
 MASK_WORDS = 4
 
 EXPORTS = [
     "msim_abi_version", "msim_device_count", "msim_config_defaults", "msim_config_finalize", "msim_create",
-    "msim_run", "msim_run_async", "msim_check", "msim_check_host_rechecks", "msim_set_dev_flags", "msim_check_lin_kv_batch", "msim_check_txn_batch", "msim_check_unique_batch", "msim_check_pn_batch", "msim_check_set_full_batch", "msim_check_rw_batch", "msim_check_lin_kv_rows", "msim_check_txn_rows", "msim_check_rw_rows", "msim_proscribed_anomalies", "msim_violated_anomalies", "msim_check_pn_rows", "msim_check_unique_rows", "msim_history_edn_rows", "msim_fetch", "msim_fetch_begin", "msim_history", "msim_net_stats_get", "msim_journal", "msim_meta",
+    "msim_run", "msim_run_async", "msim_check", "msim_check_host_rechecks", "msim_set_dev_flags", "msim_check_lin_kv_batch", "msim_check_txn_batch", "msim_check_unique_batch", "msim_check_pn_batch", "msim_check_set_full_batch", "msim_check_rw_batch", "msim_check_kafka_rows", "msim_check_lin_kv_rows", "msim_check_txn_rows", "msim_check_rw_rows", "msim_proscribed_anomalies", "msim_violated_anomalies", "msim_check_pn_rows", "msim_check_unique_rows", "msim_history_edn_rows", "msim_fetch", "msim_fetch_begin", "msim_history", "msim_net_stats_get", "msim_journal", "msim_meta",
     "msim_check_results", "msim_device_buffers_get", "msim_last_kernel_ms", "msim_get_config",
     "msim_selftest_wave", "msim_last_error", "msim_destroy",
     "msim_comm_unique_id", "msim_comm_init", "msim_gather", "msim_journal_fressian_rows",
@@ -150,6 +152,8 @@ def load():
     lib.msim_check_set_full_batch.restype = C.c_int
     lib.msim_check_rw_batch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
     lib.msim_check_rw_batch.restype = C.c_int
+    lib.msim_check_kafka_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, P(CheckResult)]
+    lib.msim_check_kafka_rows.restype = C.c_int
     lib.msim_history_edn_rows.argtypes = [P(Config), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_char_p, C.c_size_t, P(C.c_size_t)]
     lib.msim_history_edn_rows.restype = C.c_int
     lib.msim_history.argtypes = [C.c_void_p, C.c_uint32, P(P(Op)), P(C.c_uint32), P(P(C.c_uint32)), P(C.c_uint32)]

@@ -49,7 +49,7 @@ void txn(std::string &o, const uint32_t *w, uint32_t n, bool rw) {
 }
 
 const char *const TYPES[] = {":invoke", ":ok", ":fail", ":info"};
-const char *const FS[] = {":echo", ":broadcast", ":read", ":add", ":start-partition", ":stop-partition", ":write", ":cas", ":txn", ":generate"};
+const char *const FS[] = {":echo", ":broadcast", ":read", ":add", ":start-partition", ":stop-partition", ":write", ":cas", ":txn", ":generate", ":send", ":poll", ":assign", ":crash"};
 const char *const SPECS[] = {":one", ":majority", ":majorities-ring", ":minority-third"};
 
 }  // namespace
@@ -79,6 +79,41 @@ extern "C" int msim_history_edn_rows(const msim_config *cfg, const msim_op *rows
     } else if (f == MSIM_F_GENERATE) {
       if (typ == MSIM_T_OK) { o += '['; num(o, v >> 20); o += ' '; num(o, (v >> 5) & 0x7FFF); o += " \"n"; num(o, v & 31); o += "\"]"; }
       else o += "nil";
+    } else if (f == MSIM_F_SEND) {   // [[:send "k" msg]] / [[:send "k" [offset msg]]] (workload/kafka.clj:188-190; keys are strings, :247-283)
+      o += "[[:send \""; num(o, v & 63u); o += "\" ";
+      if ((v >> 17) == 0x7FFu) num(o, (v >> 6) & 0x7FFu); else { o += '['; num(o, v >> 17); o += ' '; num(o, (v >> 6) & 0x7FFu); o += ']'; }
+      o += "]]";
+    } else if (f == MSIM_F_POLL) {   // [[:poll]] / [[:poll {"k" [[offset msg] ...]}]] (:171-186); a key's runs are joined
+      if (typ != MSIM_T_OK) o += "[[:poll]]";
+      else {
+        o += "[[:poll {";
+        bool firstk = true;
+        for (uint32_t k = 0; k < 8; k++) {
+          bool has = false;
+          for (uint32_t i = 0; i < ln;) { const uint32_t h = payload[v + i]; if ((h & 7u) == k) has = true; i += 1 + (((h >> 8) & 0xFFu) + 1) / 2; }
+          if (!has) continue;
+          if (!firstk) o += ", ";
+          firstk = false;
+          o += '"'; num(o, k); o += "\" [";
+          bool firstp = true;
+          for (uint32_t i = 0; i < ln;) {
+            const uint32_t h = payload[v + i], cnt = (h >> 8) & 0xFFu, o0 = h >> 16;
+            if ((h & 7u) == k) for (uint32_t e = 0; e < cnt && i + 1 + e / 2 < ln; e++) {
+              if (!firstp) o += ' ';
+              firstp = false;
+              o += '['; num(o, o0 + e); o += ' '; num(o, (payload[v + i + 1 + e / 2] >> (16 * (e & 1))) & 0xFFFFu); o += ']';
+            }
+            i += 1 + (cnt + 1) / 2;
+          }
+          o += ']';
+        }
+        o += "}]]";
+      }
+    } else if (f == MSIM_F_ASSIGN) {   // ["k" ...] (:207-220)
+      o += '[';
+      for (uint32_t i = 0; i < ln; i++) { if (i) o += ' '; o += '"'; num(o, payload[v + i] & 7u); o += '"'; }
+      o += ']';
+    } else if (f == MSIM_F_CRASH) { o += "nil";
     } else if (f == MSIM_F_TXN) txn(o, payload + v, ln, wl == MSIM_WL_TXN_RW_REGISTER);
     else if (counter && (f == MSIM_F_ADD || f == MSIM_F_READ)) {
       if (f == MSIM_F_ADD || typ == MSIM_T_OK) num(o, (int32_t)v); else o += "nil";
@@ -122,6 +157,7 @@ extern "C" int msim_history_edn_rows(const msim_config *cfg, const msim_op *rows
       default: break;
     }
     if (fin) o += ", :final? true";
+    if (f == MSIM_F_ASSIGN && ln && (payload[v] >> 31)) o += ", :seek-to-beginning? true";
     o += "}\n";
   }
   if (needed) *needed = o.size() + 1;

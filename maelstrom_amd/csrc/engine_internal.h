@@ -98,6 +98,8 @@ int msim_check_txn_host(msim_ctx *ctx);
 int msim_check_txn_device(msim_ctx *ctx);
 // rw_check_dev.hip (device: proves a rw-register history free of what the consistency model proscribes, else hands it to the host)
 int msim_check_rw_device(msim_ctx *ctx);
+// kafka_check.cpp (host)
+int msim_check_kafka_host(msim_ctx *ctx);
 // unique_check_dev.hip, pn_check_dev.hip
 int msim_check_unique_device(msim_ctx *ctx);
 int msim_check_pn_device(msim_ctx *ctx);

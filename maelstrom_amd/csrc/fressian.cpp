@@ -100,13 +100,14 @@ std::string endpoint(uint32_t e, uint32_t n_nodes, uint32_t slots, const msim_co
 
 const char *const MSG_TYPES[] = {"", "init", "init_ok", "topology", "topology_ok", "echo", "echo_ok", "broadcast", "broadcast_ok", "read", "read_ok",
                                  "add", "add_ok", "replicate", "write", "write_ok", "cas", "cas_ok", "error", "request_vote", "request_vote_res",
-                                 "append_entries", "append_entries_res", "txn", "txn_ok", "generate", "generate_ok", "replicate_ack", "ts", "ts_ok"};
+                                 "append_entries", "append_entries_res", "txn", "txn_ok", "generate", "generate_ok", "replicate_ack", "ts", "ts_ok",
+                                 "send", "send_ok", "poll", "poll_ok", "list_committed_offsets", "list_committed_offsets_ok", "commit_offsets", "commit_offsets_ok"};
 
 bool is_reply(uint32_t t) {
   switch (t) {
     case MSIM_M_INIT_OK: case MSIM_M_TOPOLOGY_OK: case MSIM_M_ECHO_OK: case MSIM_M_BROADCAST_OK: case MSIM_M_READ_OK: case MSIM_M_ADD_OK:
     case MSIM_M_WRITE_OK: case MSIM_M_CAS_OK: case MSIM_M_ERROR: case MSIM_M_REQUEST_VOTE_RES: case MSIM_M_APPEND_ENTRIES_RES: case MSIM_M_TXN_OK:
-    case MSIM_M_GENERATE_OK: case MSIM_M_TS_OK: return true;
+    case MSIM_M_GENERATE_OK: case MSIM_M_TS_OK: case MSIM_M_SEND_OK: case MSIM_M_POLL_OK: case MSIM_M_LIST_COMMITTED_OFFSETS_OK: case MSIM_M_COMMIT_OFFSETS_OK: return true;
     default: return false;
   }
 }

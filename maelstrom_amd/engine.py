@@ -316,8 +316,58 @@ def decode_poll(words):
         for e in range(n):
             msgs.append([o + e, (words[i + e // 2] >> (16 * (e % 2))) & 0xFFFF])
         i += (n + 1) // 2
-        out[str(key)] = msgs
+        out.setdefault(str(key), []).extend(msgs)   # (a key's pairs that do not continue a run are a block of their own)
     return out
+
+
+def encode_kafka_history(ops):
+    """Jepsen-shaped kafka ops ({type, process, f, value[, time]}; values as decode_history gives them) -> (rows, payload) in the engine's
+    binary layout, so that externally produced histories can be fed to msim_check_kafka_rows."""
+    tkw = {v: k for k, v in TYPE_KW.items()}
+    fkw = {":send": A.F_SEND, ":poll": A.F_POLL, ":assign": A.F_ASSIGN, ":crash": A.F_CRASH}
+    rows = np.zeros(len(ops), dtype=OP_DT)
+    pay = []
+    for i, op in enumerate(ops):
+        typ, f, process = tkw[op["type"]], fkw[op["f"]], A.PROCESS_NEMESIS if op["process"] == ":nemesis" else int(op["process"])
+        value, ln = A.NO_VALUE, 0
+        if f == A.F_SEND:
+            _, k, v = op["value"][0]
+            msg, off = (v[1], v[0]) if isinstance(v, (list, tuple)) else (v, 0x7FF)
+            value = int(k) | (msg << 6) | (off << 17)
+        elif f == A.F_POLL and typ == A.T_OK and len(op["value"][0]) > 1:
+            value = len(pay)
+            for k, pairs in op["value"][0][1].items():
+                runs = []
+                for o, m in pairs:   # runs of consecutive offsets
+                    if runs and runs[-1][0] + len(runs[-1][1]) == o:
+                        runs[-1][1].append(m)
+                    else:
+                        runs.append((o, [m]))
+                for o, ms in runs or [(0, [])]:
+                    pay.append(int(k) | (len(ms) << 8) | (o << 16))
+                    for e in range(0, len(ms), 2):
+                        pay.append(ms[e] | ((ms[e + 1] << 16) if e + 1 < len(ms) else 0))
+            ln = len(pay) - value
+            if ln == 0:
+                value = A.NO_VALUE
+        elif f == A.F_ASSIGN:
+            value, ln = len(pay), len(op["value"])
+            pay.extend(int(k) | (0x80000000 if op.get("seek-to-beginning?") else 0) for k in op["value"])
+        rows[i] = (int(op.get("time", i * 1000)) | (ln << 48), typ | (f << 2) | (process << 12), value)
+    return rows, np.asarray(pay if pay else [0], dtype=np.uint32)
+
+
+def check_kafka_history(rows, payload):
+    """The kafka checker (msim_check_kafka_rows) on one history -> dict."""
+    lib = A.load()
+    res = A.CheckResult()
+    rows = np.ascontiguousarray(rows); payload = np.ascontiguousarray(payload, dtype=np.uint32)
+    rc = lib.msim_check_kafka_rows(rows.ctypes.data_as(C.c_void_p), len(rows), payload.ctypes.data_as(C.c_void_p), len(payload), C.byref(res))
+    if rc:
+        raise EngineError(f"msim_check_kafka_rows: {rc}")
+    return {"valid?": {1: True, 0: False, 2: "unknown"}[res.valid], "anomalies": sorted(n for b, n in A.KAFKA_ANOMALIES.items() if res.error_count & b),
+            "send-count": res.attempt_count, "acked-count": res.stable_count, "lost-count": res.lost_count, "unobserved-count": res.never_read_count,
+            "duplicate-count": res.duplicated_count, "ok-count": res.ok_count, "fail-count": res.fail_count, "info-count": res.info_count}
 
 
 def decode_txn(words):
@@ -642,12 +692,12 @@ def history_edn(ops):
         if isinstance(v, str):
             return v if v.startswith(":") else '"' + v + '"'
         if isinstance(v, dict):
-            return "{" + ", ".join(f"{edn(k if str(k).startswith(':') else ':' + str(k)) if not str(k).startswith('n') else edn(str(k))} {edn(x)}" for k, x in v.items()) + "}"
+            return "{" + ", ".join(f"{edn(k if str(k).startswith(':') else ':' + str(k)) if not (str(k).startswith('n') or str(k).isdigit()) else edn(str(k))} {edn(x)}" for k, x in v.items()) + "}"
         if isinstance(v, (list, tuple)):
             return "[" + " ".join(edn(x) for x in v) + "]"
         return str(v)
     lines = []
     for op in ops:
-        keys = ["type", "f", "value", "time", "process", "index"] + [k for k in ("error", "final?") if k in op]
+        keys = ["type", "f", "value", "time", "process", "index"] + [k for k in ("error", "final?", "seek-to-beginning?") if k in op]
         lines.append("{" + ", ".join(f":{k} {edn(op[k])}" for k in keys) + "}")
     return "\n".join(lines) + "\n"
