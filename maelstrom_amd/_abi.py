@@ -30,7 +30,8 @@ NO_VALUE = 0xFFFFFFFF
 FLAG_ROWS_OVERFLOW, FLAG_PAYLOAD_OVERFLOW, FLAG_INBOX_OVERFLOW, FLAG_VALUES_OVERFLOW, FLAG_ROUND_LIMIT, FLAG_JOURNAL_OVERFLOW, FLAG_ARENA_OVERRUN = 1, 2, 4, 8, 16, 32, 64
 MSG_TYPES = ["", "init", "init_ok", "topology", "topology_ok", "echo", "echo_ok", "broadcast", "broadcast_ok", "read", "read_ok",
              "add", "add_ok", "replicate", "write", "write_ok", "cas", "cas_ok", "error", "request_vote", "request_vote_res",
-             "append_entries", "append_entries_res", "txn", "txn_ok", "generate", "generate_ok", "replicate_ack", "ts", "ts_ok"]
+             "append_entries", "append_entries_res", "txn", "txn_ok", "generate", "generate_ok", "replicate_ack", "ts", "ts_ok",
+             "send", "send_ok", "poll", "poll_ok", "list_committed_offsets", "list_committed_offsets_ok", "commit_offsets", "commit_offsets_ok"]
 KAFKA_ANOMALIES = {1: "lost-write", 2: "nonmonotonic-poll", 4: "nonmonotonic-send", 8: "poll-skip", 16: "int-nonmonotonic-poll", 32: "int-poll-skip",
                    64: "inconsistent-offsets", 128: "duplicate", 256: "aborted-read", 512: "malformed"}
 ANOMALIES = {1: "G0", 2: "G1a", 4: "G1b", 8: "G1c", 16: "G-single", 32: "G2", 64: "internal", 128: "duplicate-elements",

@@ -226,3 +226,95 @@ def test_net_journal_of_a_kafka_run_is_writable_as_fressian():
     assert len(events) == len(ev)
     types = {str(e["message"]["body"]["type"]) for e in events}
     assert {"send", "poll", "commit_offsets", "cas", "read"} <= types, types
+
+
+# ---- the oracle's node and lin-kv against an independent transliteration of demo/clojure/kafka.clj + service.clj with real values ----
+def _replay_through_model(cfg, inst):
+    """Runs the oracle with the journal on, then replays its network schedule (what was sent, what was delivered and when,
+    journal.clj:220-239) through tests/kafka_ref.py: every message a node or the service emits must be the one the oracle emitted."""
+    import collections
+    import kafka_ref
+    o = O.run(cfg, inst, 1)
+    assert o.meta[0]["flags"] == 0 and o.meta[0]["n_events"] <= cfg.journal_capacity
+    pay = o.history(0)[1]
+    N = cfg.n_nodes
+    SVC = 2 * N
+    T = A.MSG_TYPES
+    nodes = [kafka_ref.KafkaNode() for _ in range(N)]
+    svc = kafka_ref.LinKV()
+    out = collections.defaultdict(collections.deque)
+    content, versions, n_checked = {}, {}, collections.Counter()
+
+    def block(a):
+        return [int(w) for w in pay[a & 0xFFFFFF:(a & 0xFFFFFF) + (a >> 24)]]
+
+    for ev in o.events(0):
+        msg, a, route = int(ev["msg"]), int(ev["a"]), int(ev["route"])
+        mid, recv, typ = msg >> 8, (msg >> 7) & 1, T[msg & 0x7F]
+        src, dest, b = route & 0xFF, (route >> 8) & 0xFF, route >> 16
+        if not recv:
+            if N <= src < SVC:    # a workload client's request: its real body, from the oracle's encoding
+                if typ == "send":
+                    body = {"type": "send", "key": str(a & 7), "msg": a >> 6}
+                elif typ == "poll":
+                    body = {"type": "poll", "offsets": {str(w & 7): w >> 8 for w in block(a)}}
+                elif typ == "list_committed_offsets":
+                    body = {"type": typ, "keys": [str(w & 7) for w in block(a)]}
+                elif typ == "commit_offsets":
+                    body = {"type": typ, "offsets": {k: v[-1][0] for k, v in E.decode_poll(block(a)).items() if v}}
+                else:
+                    body = {"type": "init"}
+                content[mid] = dict(body, msg_id=b)
+                continue
+            assert out[src], f"endpoint {src} sent {typ} (message {mid}), the model had nothing to send"
+            to, body = out[src].popleft()
+            to = {"lin-kv": SVC}.get(to, to)
+            assert (body["type"], to) == (typ, dest), (mid, src, body, typ, dest)
+            assert (body.get("msg_id", body.get("in_reply_to")) & 0xFFFF) == b, (mid, body, b)
+            n_checked[typ] += 1
+            if src < N and dest == SVC:
+                if typ == "read":
+                    assert body["key"] == ("offsets" if a >> 31 else f"log-{a & 7}-{a >> 8}"), (mid, body, hex(a))
+                elif a >> 31:
+                    assert body["key"] == "offsets"
+                else:
+                    assert body["key"] == f"log-{a & 7}-{(a >> 3) & 63}" and len(body["from"]) == (a >> 9) & 31 and body["to"] == body["from"] + [a >> 14], (mid, body, hex(a))
+            elif src < N:
+                if typ == "send_ok":
+                    assert body["offset"] == a
+                elif typ == "poll_ok":
+                    assert list(E.decode_poll(block(a)).items()) == list(body["msgs"].items()), (mid, body, E.decode_poll(block(a)))
+                elif typ == "list_committed_offsets_ok":
+                    assert {str(w & 7): (w >> 8) & 0x7FFFFF for w in block(a) if w >> 31} == body["offsets"], (mid, body)
+                elif typ == "error":
+                    assert body["code"] == a
+            else:   # the service's replies
+                if typ == "error":
+                    assert body["code"] == a
+                elif typ == "read_ok" and isinstance(body["value"], list):
+                    assert len(body["value"]) == a
+                elif typ == "read_ok":       # the offsets map travels as its version: one version, one value
+                    assert versions.setdefault(a, body["value"]) == body["value"], (mid, a, versions[a], body["value"])
+            content[mid] = body
+        elif dest < N:
+            for to, body in nodes[dest].handle(src, content[mid]):
+                out[dest].append((to, body))
+        elif dest == SVC:
+            req = content[mid]
+            out[SVC].append((src, dict(svc.handle(req), in_reply_to=req["msg_id"])))
+    assert not any(out.values()), {k: len(v) for k, v in out.items()}
+    assert len(set(map(repr, versions.values()))) == len(versions)     # different versions, different maps
+    return n_checked
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(latency=0, rate=100.0), dict(node_count=4, latency=25, latency_dist="exponential", p_loss=0.1),
+                                dict(nemesis=("partition",), nemesis_interval=1.5, latency=10), dict(node_count=2, key_count=2, max_writes_per_key=50, rate=200.0, latency=3)])
+def test_oracle_node_and_service_equal_transliterated_reference(kw):
+    cfg = _cfg(**kw)
+    cfg.journal_capacity = 400000
+    for inst in range(3):
+        n = _replay_through_model(cfg, inst)
+        if kw.get("p_loss"):    # a lost lin-kv message leaves its request waiting for ever (no RPC timeout in node.clj:121-129): few operations complete
+            assert n["send_ok"] + n["poll_ok"] > 6 and n["cas"] > 3 and n["read"] > 15, n
+        else:
+            assert n["send_ok"] > 10 and n["poll_ok"] > 5 and n["cas"] > 10 and n["commit_offsets_ok"] > 0, n
