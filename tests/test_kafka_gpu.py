@@ -31,3 +31,18 @@ def test_kafka_parity(lib, kw):
     ops = E.decode_history(*ora.history(0), cfg.n_nodes, A.WL_KAFKA)
     fs = {op["f"] for op in ops}
     assert {":send", ":poll", ":assign"} <= fs
+
+
+def test_kafka_engine_check(lib):
+    """msim_check for kafka (csrc/kafka_check.cpp on the host cores) over the histories of a run: all valid, as the one-history entry says"""
+    cfg = E.test_config("kafka", node_count=4, rate=100, time_limit=6, latency=5, nemesis=["partition"], nemesis_interval=2, seed=12)
+    with E.Engine(cfg) as eng:
+        eng.run(0, 64)
+        eng.check()
+        eng.fetch()
+        res = eng.check_results().copy()
+        assert (res["valid"] == 1).all() and (res["error_count"] == 0).all() and (res["stable_count"] > 20).all()
+        for i in (0, 17, 63):
+            rows, pay = eng.raw_history(i)
+            one = E.check_kafka_history(rows.copy(), pay.copy())
+            assert one["valid?"] is True and one["acked-count"] == int(res[i]["stable_count"]) and one["unobserved-count"] == int(res[i]["never_read_count"])

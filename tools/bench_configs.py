@@ -35,6 +35,7 @@ CONFIGS = {
     "broadcast n=100 grid lat0": (dict(workload="broadcast", node_count=100, rate=100, time_limit=20), 2048),
     "broadcast n=100 grid lat100 exponential": (dict(workload="broadcast", node_count=100, rate=100, time_limit=20, latency=100, latency_dist="exponential"), 2048),
     # the reference's own demo invocation for this workload (core.clj:115-121): 2 nodes, rate 100, partitions, read-committed
+    "kafka n=5 rate100 20s lat5 + partitions": (dict(workload="kafka", node_count=5, rate=100, time_limit=20, latency=5, nemesis=["partition"], nemesis_interval=10), 16384),
     "txn-rw-register hat n=2 rate100 30s + partitions": (dict(workload="txn-rw-register", node_count=2, rate=100, time_limit=30,
                                                                nemesis=["partition"], nemesis_interval=10), 16384),
     "txn-rw-register hat n=5 rate100 30s lat5 + partitions": (dict(workload="txn-rw-register", node_count=5, rate=100, time_limit=30, latency=5,
