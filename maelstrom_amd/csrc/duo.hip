@@ -186,6 +186,10 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
   // when the scheduler next acts (INF: it only waits), and whether every round has to be a GENERAL one until it says otherwise;
   // both change in GENERAL rounds only
   u32 sched_at = real ? 0u : INF, force_general = alive;
+  // The generator's draws (one 64-bit draw per generated op, stream S_GEN, counter gen_k) are computed 32 at a time: lane i of a cluster
+  // holds draw dc_base + i, the scheduler fetches the one it needs with two ds_bpermute (mix64's three 64-bit multiplications cost a
+  // round of the scheduler a quarter of its cycles when every lane computed the same draw)
+  u32 dc_base = 0; u64 dc = draw64(key, S_GEN, (u64)i);
 
   // Two LDS reads are kept one round ahead of their use, so that a round's dependent chain holds one LDS round trip
   // (the ds_bpermute exchange) instead of three:
@@ -505,8 +509,12 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
       const u32 free_mask = all_nodes & ~hb(busy != 0, hi);
       const bool gen = act && phase == PH_MAIN && rate > 0 && gen_next < cutoff && gen_next <= T && free_mask != 0;
       // one 64-bit draw per generated op: high word -> stagger, low word -> worker pick / gen/mix
-      const u64 h = draw64(key, S_GEN, gen_k);
-      const u32 r_hi = (u32)(h >> 32), r_lo = (u32)h;
+      {
+        const bool dc_refill = gen_k - dc_base >= 32u;   // (uniform within a cluster)
+        if (__ballot(dc_refill)) { const u64 dc_new = draw64(key, S_GEN, (u64)gen_k + i); dc = dc_refill ? dc_new : dc; dc_base = dc_refill ? gen_k : dc_base; }
+      }
+      const u32 dc_at = hbase4 + ((gen_k - dc_base) << 2);
+      const u32 r_hi = bperm(dc_at, (u32)(dc >> 32)), r_lo = bperm(dc_at, (u32)dc);
       const u32 pick = scale32(r_lo, __popc(free_mask));
       const bool sel = gen && is_node && busy == 0 && (u32)__popc(free_mask & lt) == pick;
       const bool is_rd = (r_lo & 1u) != 0;
@@ -538,7 +546,9 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
         if (inv && have_creq != 0) my_flags |= MSIM_FLAG_INBOX_OVERFLOW;   // cannot happen without client timeouts
         have_creq = inv ? 1u : have_creq; creq = inv ? e : creq; creq_t = inv ? T : creq_t;
       }
-      DUO_POLL();
+      // LAT0 / RND: nobody has to poll here — an idle node took its request directly (only the set word of its new envelope is
+      // missing), every other node holds an envelope already; constant latency > 0: the request waits beside the FIFO, recv! chooses
+      if (LAT0 || RND) DUO_SW_PREFETCH(); else DUO_POLL();
     }
 
     P3_MARK(2)   // [2] = R2 invoke + poll
@@ -570,6 +580,12 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
       }
       const u32 okm = hb(rd && ok, hi);
       u32 m = okm;
+      if (!__ballot((okm & (okm - 1u)) != 0)) {   // the usual round: at most one reader per cluster — lane w copies word w of its set
+        const u32 r1 = okm ? (u32)__builtin_ctz(okm) : 0u;
+        for (u32 w = i; __ballot(okm != 0 && w < words); w += 32)
+          if (okm != 0 && w < words) g_pay[n_payload + w] = seen[r1 * Wp + w];
+        m = 0;
+      }
       while (__ballot(m != 0)) {
         const bool on = m != 0;
         const u32 r = on ? (u32)__builtin_ctz(m) : 0u;
@@ -636,17 +652,24 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
       }
       if (phase == PH_DONE) alive = 0;
       if (alive != 0 && rounds > round_limit) { flags |= MSIM_FLAG_ROUND_LIMIT; alive = 0; }
+      const bool gen_live = rate > 0 && gen_next < cutoff;
+      u32 sa = INF;
+      if (phase == PH_MAIN) {
+        if (gen_live && (all_nodes & ~hbusy) != 0) sa = gen_next;
+        if (rate == 0) sa = min(sa, cutoff);
+      } else if (phase == PH_INIT || phase == PH_TOPO || phase == PH_FINAL) sa = T;
+      else if (phase == PH_SLEEP) sa = sleep_until;
+      sched_at = alive != 0 ? sa : INF;
+      force_general = (alive != 0 && !((phase == PH_MAIN && gen_live) || phase == PH_SLEEP)) ? 1u : 0u;
+    } else {
+      // every live cluster of the wavefront is in the main phase with its generator running (nearly every GENERAL round): the
+      // scheduler acts again when the generator's next op is due and a worker is free, plain gossip rounds may run meanwhile
+      sched_at = (alive != 0 && (all_nodes & ~hbusy) != 0) ? gen_next : INF;
+      force_general = 0;
     }
-    const bool gen_live = rate > 0 && gen_next < cutoff;
-    u32 sa = INF;
-    if (phase == PH_MAIN) {
-      if (gen_live && (all_nodes & ~hbusy) != 0) sa = gen_next;
-      if (rate == 0) sa = min(sa, cutoff);
-    } else if (phase == PH_INIT || phase == PH_TOPO || phase == PH_FINAL) sa = T;
-    else if (phase == PH_SLEEP) sa = sleep_until;
-    sched_at = alive != 0 ? sa : INF;
-    force_general = (alive != 0 && !((phase == PH_MAIN && gen_live) || phase == PH_SLEEP)) ? 1u : 0u;
-    if (alive == 0) { deliver_at = INF; in_n = 0; sp_n = 0; have_creq = 0; bag_used = 0; }   // a finished cluster takes no further part
+    if (__ballot(alive == 0)) {
+      if (alive == 0) { deliver_at = INF; in_n = 0; sp_n = 0; have_creq = 0; bag_used = 0; }   // a finished cluster takes no further part
+    }
     P3_MARK(7)   // [7] = the scheduler's view
     }
 #ifdef DUO_PROF

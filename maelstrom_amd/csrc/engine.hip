@@ -832,22 +832,35 @@ extern "C" int msim_create(const msim_config *cfg, int device, msim_ctx **out, c
   return MSIM_OK;
 }
 
-// sim_kernel_wide<NET_RANDOM, BCAST, NEM> for this configuration
-template <bool NR, int BC, bool NM>
+// sim_kernel_wide<NET_RANDOM, BCAST, NEM, SETL> for this configuration
+template <bool NR, int BC, bool NM, bool SL>
 static hipError_t launch_wide_one(const KParams &kp, uint32_t n, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sim_kernel_wide<NR, BC, NM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sim_kernel_wide<NR, BC, NM, SL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((sim_kernel_wide<NR, BC, NM>), dim3(n), dim3(64), lds, st, kp);
+  hipLaunchKernelGGL((sim_kernel_wide<NR, BC, NM, SL>), dim3(n), dim3(64), lds, st, kp);
   return hipGetLastError();
+}
+template <int BC, bool SL>
+static hipError_t launch_wide2(const KParams &kp, uint32_t n, size_t lds, hipStream_t st) {
+  const msim_config &c = kp.cfg;
+  const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0, nem = c.nemesis_mask != 0;
+  if (nem) return rnd ? launch_wide_one<true, BC, true, SL>(kp, n, lds, st) : launch_wide_one<false, BC, true, SL>(kp, n, lds, st);
+  return rnd ? launch_wide_one<true, BC, false, SL>(kp, n, lds, st) : launch_wide_one<false, BC, false, SL>(kp, n, lds, st);
+}
+// Which wide clusters keep their nodes' sets in LDS (SETL): g-set and fire-and-forget broadcast, when sets + client inboxes + the LDS
+// part of the queues leave a CU at least four clusters (40 KiB each); MSIM_DEV_FLAGS bit 14 keeps the sets in HBM scratch.
+static bool wide_sets_in_lds(const msim_config &c, uint32_t dev_flags) {
+  if (c.n_nodes <= 32 || (dev_flags & 0x4000u)) return false;
+  if (c.node_program != MSIM_NODE_G_SET && c.node_program != MSIM_NODE_BCAST_FF && c.node_program != MSIM_NODE_BCAST_FF_ECHOBACK) return false;
+  const size_t bytes = ((size_t)c.n_nodes * c.inbox_capacity + (size_t)c.n_nodes * CLIENT_INBOX_CAP) * 16 + (size_t)c.n_nodes * (c.max_values / 32) * 4 + (c.nemesis_mask ? 512 : 0) + 16;
+  return bytes <= 40 * 1024;
 }
 template <int BC>
 static hipError_t launch_wide(msim_ctx *, const KParams &kp, uint32_t n, size_t lds, hipStream_t st) {
-  const msim_config &c = kp.cfg;
-  const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0, nem = c.nemesis_mask != 0;
-  if (nem) return rnd ? launch_wide_one<true, BC, true>(kp, n, lds, st) : launch_wide_one<false, BC, true>(kp, n, lds, st);
-  return rnd ? launch_wide_one<true, BC, false>(kp, n, lds, st) : launch_wide_one<false, BC, false>(kp, n, lds, st);
+  if constexpr (BC <= 1) { if (wide_sets_in_lds(kp.cfg, kp.dev_flags)) return launch_wide2<BC, true>(kp, n, lds, st); }
+  return launch_wide2<BC, false>(kp, n, lds, st);
 }
 
 // multi-key transactional node: thunk ids a node may hand out (every attempt of a transaction writes its keys again: x4 for the
@@ -964,7 +977,8 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   kp.raft_log_cap = is_raft ? raft_log_cap(c) : 0;
   kp.dev_flags = msim_dev_flags(ctx);
   const bool wide = c.n_nodes > 32;
-  size_t off = (wide ? WIDE_STAGE_ROWS : STAGE_ROWS) * 16;
+  const bool wide_setl = wide_sets_in_lds(c, kp.dev_flags);   // (no row staging in that layout)
+  size_t off = wide_setl ? 0 : (wide ? WIDE_STAGE_ROWS : STAGE_ROWS) * 16;
   const bool is_txn = c.node_program == MSIM_NODE_TXN_SINGLE_KEY, is_px = c.node_program == MSIM_NODE_LIN_KV_PROXY || c.node_program == MSIM_NODE_TSO_IDS;
   const bool is_hat = c.node_program == MSIM_NODE_TXN_RW_HAT, is_mk = c.node_program == MSIM_NODE_TXN_MULTI_KEY, is_kf = c.node_program == MSIM_NODE_KAFKA;
   kp.mk_tcap = is_mk ? mk_tcap(c) : 0; kp.mk_ccap = is_mk ? mk_ccap(c) : 0;
@@ -978,7 +992,7 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
        : is_txn ? (size_t)kp.N * TXN_SLOTS * 16 + 36 * 4   // transactions in flight per node + the generator's key pool
        : is_kf ? ((size_t)kp.N * KF_SLOTS * KSW + 2 * (size_t)kp.N * KF_KEYS + 36 + 2 * KF_KEYS) * 4   // request handlers, offset caches, client offsets, key pool, lin-kv lengths
        : is_raft ? (size_t)kp.N * 256 + (size_t)kp.N * kp.N * 3 * 4   // KV state + next/match index + append_entries refs
-       : wide ? 0   // the sets of a wide cluster live in HBM scratch
+       : wide ? (wide_setl ? (size_t)kp.N * kp.W * 4 : 0)   // the sets of a wide cluster live in HBM scratch unless they fit LDS (wide_sets_in_lds)
                  : (size_t)kp.N * kp.W * 4;
   off = (off + 15) & ~(size_t)15;
   kp.off_misc = (u32)off; if (c.nemesis_mask) off += (wide ? 128 : 64) * 4;  // shuffle scratch, only the partition nemesis needs it

@@ -79,7 +79,7 @@ static inline unsigned msim_host_threads() {
 // (read once per process).  0x100 round limit x20, 0x200 one cluster per wavefront, 0x400 fail instead of falling back to it,
 // 0x800 checkers on the host cores, 0x1000 time the checkers' passes on stderr.
 static inline uint32_t msim_dev_flags(const msim_ctx *ctx) {
-  static const uint32_t env = []() { const char *e = std::getenv("MSIM_DEV_FLAGS"); return e ? (uint32_t)std::atoi(e) : 0u; }();
+  static const uint32_t env = []() { const char *e = std::getenv("MSIM_DEV_FLAGS"); return e ? (uint32_t)std::strtoul(e, nullptr, 0) : 0u; }();   // (decimal, 0x.. or 0..)
   return env | (ctx ? ctx->dev_flags : 0u);
 }
 

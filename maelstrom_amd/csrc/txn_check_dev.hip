@@ -360,8 +360,8 @@ __global__ void __launch_bounds__(64) txn_check_kernel(const TParams p) {
 // ---- the same analysis with its tables in LDS (round 3) ---------------------------------------------------------------------------------
 // txn_check_kernel above keeps the writer table, in-degrees, CSR and ready queue of a history in an HBM workspace (0.6 MB per history):
 // every edge costs three L2 atomics whose lines are evicted before they are touched again — 20.6 GB of HBM traffic per 8192 histories for
-// 1.35 GB of history bytes, 0.80 of the wave cycles waiting (profiles/r02_cfg5_counters.json).  Here one wavefront still takes one
-// history, but
+// 1.35 GB of history bytes, 0.80 of the wave cycles waiting (profiles/r02_cfg5_counters.json).  Here a workgroup takes one history
+// (see the kernel's header for how its wavefronts share the work), and
 //   * what is hit at random lives in LDS as 16-bit entries: the writer table (key, element) -> transaction | type << 13 | "the writer's
 //     last append to the key" << 15 (so G1a / G1b / the edge passes never read another transaction's words), the longest read per key,
 //     in-degrees and CSR offsets (two per word, updated by one 32-bit LDS atomic on the right half), the adjacency of the DEPENDENCY edges,
@@ -377,9 +377,22 @@ __device__ __forceinline__ u32 h16_add(u32 *w, u32 i, u32 d) { const u32 sh = (i
 __device__ __forceinline__ u32 h16_sub(u32 *w, u32 i) { const u32 sh = (i & 1u) * 16u; return (atomicSub(&w[i >> 1], 1u << sh) >> sh) & 0xFFFFu; }
 __device__ __forceinline__ u32 h16_get(const u32 *w, u32 i) { return (w[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu; }
 
-__global__ void __launch_bounds__(64) txn_check_lds_kernel(const TParams p) {
+// A workgroup of 1 .. 8 wavefronts takes one history (blockDim.x = 64 x wavefronts, TParams.lds_bytes of LDS per workgroup): the passes
+// whose unit of work is a transaction or a key (B, C, D, E, the realtime ranges) stride over all threads, so that many more of the
+// dependent payload loads they consist of are in flight per history; the passes that are serial by nature (pairing the rows, the suffix
+// minimum, the CSR prefix sums, Kahn's queue) stay on wavefront 0 while the others wait at the next barrier.  smem[0 .. 64) is the
+// workgroup's header: [0] verdict so far (0 go on, 1 tables do not fit -> txn_check_kernel, 2 not provably clean -> host), [1] n,
+// [2..4] ok / fail / info counts, [5] max key, [6] max element, [7] edges, [8] dependency edges.
+__device__ __forceinline__ void t_wave_fence() {   // orders the LDS / workspace traffic of ONE wavefront across its lanes (no s_barrier)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ void __launch_bounds__(512) txn_check_lds_kernel(const TParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const u32 lane = threadIdx.x, hist = p.list ? p.list[p.first + blockIdx.x] : p.first + blockIdx.x;
+  const u32 tid = threadIdx.x, NT = blockDim.x, lane = tid & 63u, wave = tid >> 6;
+  const u32 hist = p.list ? p.list[p.first + blockIdx.x] : p.first + blockIdx.x;
   const u64 lt = (1ull << lane) - 1ull;
   const uint4 *const r = reinterpret_cast<const uint4 *>(p.rows) + (p.row_off ? p.row_off[hist] : (u64)hist * p.max_rows);
   const u32 *const pay = p.payload + (p.pay_off ? p.pay_off[hist] : (u64)hist * p.max_pay);
@@ -392,24 +405,32 @@ __global__ void __launch_bounds__(64) txn_check_lds_kernel(const TParams p) {
   u32 *const t_first = t_lt + NM;            // transactions invoked before this one's completion row (= index of the first one after it)
   u32 *const sm = t_first + NM;              // [NM + 1] suffix minimum of the :ok completions ...
   u32 *const smf = sm + NM + 1;              // [NM + 1] ... and t_first of the transaction that attains it
+  u32 *const hdr = reinterpret_cast<u32 *>(smem);
+  unsigned char *const tab = smem + 64;
 
   msim_check_result res;
   res.valid = NEEDS_HOST; res.attempt_count = 0; res.stable_count = 0; res.lost_count = 0; res.never_read_count = 0; res.stale_count = 0;
   res.duplicated_count = 0; res.error_count = 0;
   for (int i = 0; i < 5; i++) res.stable_latency_ms[i] = 0;
   res.op_count = 0; res.ok_count = 0; res.fail_count = 0; res.info_count = 0;
-#define TO_HOST() do { if (lane == 0) p.out[hist] = res; return; } while (0)
-#define TO_HBM() do { res.valid = NEEDS_HBM; if (lane == 0) p.out[hist] = res; return; } while (0)
-  if (n_words >= (1u << 24)) TO_HOST();
+  // every thread of the workgroup sees the same verdict behind a barrier and leaves with it
+#define VERDICT(v_) atomicMax(&hdr[0], (u32)(v_))
+#define LEAVE_IF_DECIDED() do { __syncthreads(); const u32 vd_ = hdr[0]; if (vd_) { if (tid == 0) { res.valid = vd_ == 1u ? NEEDS_HBM : NEEDS_HOST; p.out[hist] = res; } return; } } while (0)
+  if (tid < 16) hdr[tid] = 0;
+  __syncthreads();
+  if (n_words >= (1u << 24)) { if (tid == 0) p.out[hist] = res; return; }
 
-  // ---- A: transactions; completions paired process by process ------------------------------------------------------------------------------
-  u32 n = 0, c_ok = 0, c_fail = 0, c_info = 0;
-  {
+  // ---- A: transactions; completions paired process by process (wavefront 0; the next block of rows is in flight while one is paired) ---------
+  if (wave == 0) {
+    u32 n = 0, c_ok = 0, c_fail = 0, c_info = 0;
     bool o_used = false; u32 o_proc = 0, o_txn = 0, o_len = 0; u32 bad = 0;   // lane = one open call (o_len: words of its request); bad: 1 host, 2 HBM kernel
+    uint4 row_next = make_uint4(0, 0, 0, 0);
+    if (lane < n_rows) row_next = r[lane];
     for (u32 base = 0; base < n_rows && !bad; base += 64) {
       const u32 idx = base + lane;
-      uint4 row = make_uint4(0, 0, 0, 0);
-      if (idx < n_rows) row = r[idx];
+      const uint4 row = row_next;
+      row_next = make_uint4(0, 0, 0, 0);
+      if (idx + 64u < n_rows) row_next = r[idx + 64u];
       const u32 type = row.z & 3u, f = (row.z >> 2) & 31u, proc = row.z >> 12, len = row.y >> 16, woff = row.w;
       const bool is = idx < n_rows && proc != MSIM_PROCESS_NEMESIS && f == MSIM_F_TXN;
       if (__ballot(is && (u64)woff + len > n_words)) { bad = 1; break; }
@@ -458,37 +479,46 @@ __global__ void __launch_bounds__(64) txn_check_lds_kernel(const TParams p) {
       c_fail += (u32)__popcll(__ballot(matched && type == MSIM_T_FAIL));
       c_info += (u32)__popcll(__ballot(matched && type == MSIM_T_INFO));
       n += (u32)__popcll(im);
+      t_wave_fence();   // (a later block's completion may rewrite t_off / t_lt of a transaction this block's invocation wrote)
     }
-    if (bad == 2) TO_HBM();
-    if (bad) TO_HOST();
+    if (lane == 0) { hdr[0] = bad == 2 ? 1u : bad ? 2u : 0u; hdr[1] = n; hdr[2] = c_ok; hdr[3] = c_fail; hdr[4] = c_info; }
   }
-  __syncthreads();
+  LEAVE_IF_DECIDED();
+  const u32 n = hdr[1], c_ok = hdr[2], c_fail = hdr[3], c_info = hdr[4];
   res.op_count = n; res.attempt_count = n; res.ok_count = c_ok; res.stable_count = c_ok; res.fail_count = c_fail; res.info_count = c_info;
 
   // ---- B: ranges; the LDS tables laid out and cleared ----------------------------------------------------------------------------------------
-  u32 max_key = 0, max_val = 0; bool bad = false;
-  for (u32 t = lane; t < n; t += 64) {
-    const u32 *w = pay + t_off[t]; const u32 wn = t_lt[t] & 0xFFFFu;
-    for (u32 i = 0; i < wn;) { const Mop m = next_mop(w, wn, i); bad |= m.bad; max_key = max(max_key, m.key); if (m.f) max_val = max(max_val, m.val); }
+  bool bad = false;
+  {
+    u32 max_key = 0, max_val = 0;
+    for (u32 t = tid; t < n; t += NT) {
+      const u32 *w = pay + t_off[t]; const u32 wn = t_lt[t] & 0xFFFFu;
+      for (u32 i = 0; i < wn;) { const Mop m = next_mop(w, wn, i); bad |= m.bad; max_key = max(max_key, m.key); if (m.f) max_val = max(max_val, m.val); }
+    }
+    max_key = t_max(max_key); max_val = t_max(max_val);
+    if (lane == 0) { atomicMax(&hdr[5], max_key); atomicMax(&hdr[6], max_val); }
+    if (bad) VERDICT(2);
   }
-  max_key = t_max(max_key); max_val = t_max(max_val);
+  LEAVE_IF_DECIDED();
+  const u32 max_key = hdr[5], max_val = hdr[6];
   const u32 stride = max_val + 1u, K = max_key + 1u;
-  if (__ballot(bad)) TO_HOST();
-  if (max_key >= KMAX || (u64)K * stride > WMAX) TO_HBM();
-  // LDS (bytes): in-degrees [n] and CSR offsets [n + 1] as halves of words | R1 = writer [K x stride] u16 + longest [K] u32, later the
-  // ready queue [n] u16 + realtime ranges [n] 2 x u16 | adjacency of the dependency edges, u16, whatever is left
+  // LDS (bytes, behind the header): in-degrees [n] and CSR offsets [n + 1] as halves of words | R1 = writer [K x stride] u16 + longest [K] u32,
+  // later the ready queue [n] u16 + realtime ranges [n] 2 x u16 | adjacency of the dependency edges, u16, whatever is left
   const u32 hw = (n + 2u) >> 1;                                   // words for n + 1 halves
   const u32 r1_a = ((K * stride + 1u) >> 1) + K, r1_b = ((n + 1u) >> 1) + n;
   const u32 r1_words = max(r1_a, r1_b);
-  if ((u64)(2u * hw + r1_words) * 4u + 64u > p.lds_bytes) TO_HBM();
-  u32 *const l_indeg = reinterpret_cast<u32 *>(smem), *const l_off = l_indeg + hw, *const l_r1 = l_off + hw;
+  if (max_key >= KMAX || (u64)K * stride > WMAX || (u64)(2u * hw + r1_words) * 4u + 128u > p.lds_bytes) {   // (the same for every thread)
+    if (tid == 0) { res.valid = NEEDS_HBM; p.out[hist] = res; }
+    return;
+  }
+  u32 *const l_indeg = reinterpret_cast<u32 *>(tab), *const l_off = l_indeg + hw, *const l_r1 = l_off + hw;
   unsigned short *const l_writer = reinterpret_cast<unsigned short *>(l_r1);
   u32 *const l_longest = l_r1 + ((K * stride + 1u) >> 1);
   unsigned short *const l_adj = reinterpret_cast<unsigned short *>(l_r1 + r1_words);
-  const u32 adj_cap = (p.lds_bytes - (2u * hw + r1_words) * 4u) / 2u;
-  for (u32 i = lane; i < 2u * hw; i += 64) l_indeg[i] = 0;        // (indeg and off are adjacent)
-  for (u32 i = lane; i < ((K * stride + 1u) >> 1); i += 64) l_r1[i] = 0xFFFFFFFFu;
-  for (u32 k = lane; k < K; k += 64) l_longest[k] = 0;
+  const u32 adj_cap = (p.lds_bytes - 64u - (2u * hw + r1_words) * 4u) / 2u;
+  for (u32 i = tid; i < 2u * hw; i += NT) l_indeg[i] = 0;        // (indeg and off are adjacent)
+  for (u32 i = tid; i < ((K * stride + 1u) >> 1); i += NT) l_r1[i] = 0xFFFFFFFFu;
+  for (u32 k = tid; k < K; k += NT) l_longest[k] = 0;
   __syncthreads();
 #define WENT(k_, el_) ((el_) < stride ? (u32)l_writer[(k_) * stride + (el_)] : 0xFFFFu)   // 0xFFFF: nobody wrote it
 #define W_TXN(e_) ((e_) & 0x1FFFu)
@@ -497,7 +527,7 @@ __global__ void __launch_bounds__(64) txn_check_lds_kernel(const TParams p) {
 
   // ---- C: writers (every transaction, whatever became of it); a second writer of a (key, element) finds the slot taken over ------------------
   for (int pass = 0; pass < 2; pass++) {
-    for (u32 t = lane; t < n; t += 64) {
+    for (u32 t = tid; t < n; t += NT) {
       const u32 *w = pay + t_off[t]; const u32 wn = t_lt[t] & 0xFFFFu, ty = (t_lt[t] >> 16) & 3u;
       for (u32 i = 0; i < wn;) {
         const Mop m = next_mop(w, wn, i);
@@ -511,10 +541,11 @@ __global__ void __launch_bounds__(64) txn_check_lds_kernel(const TParams p) {
     }
     __syncthreads();
   }
-  if (__ballot(bad)) TO_HOST();
+  if (bad) VERDICT(2);
+  LEAVE_IF_DECIDED();
 
   // ---- D: the reads of :ok transactions ----------------------------------------------------------------------------------------------------------
-  for (u32 t = lane; t < n; t += 64) {
+  for (u32 t = tid; t < n; t += NT) {
     if ((t_lt[t] >> 16) != MSIM_T_OK) continue;
     const u32 *w = pay + t_off[t]; const u32 wn = t_lt[t] & 0xFFFFu;
     u32 k = 0;
@@ -545,11 +576,10 @@ __global__ void __launch_bounds__(64) txn_check_lds_kernel(const TParams p) {
       atomicMax(&l_longest[m.key], ((m.len + 1u) << 24) | (u32)(m.list - pay));
     }
   }
-  __syncthreads();
-  if (__ballot(bad)) TO_HOST();
+  if (bad) VERDICT(2);
 
-  // realtime order in closed form (see txn_check_kernel)
-  {
+  // realtime order in closed form (see txn_check_kernel): wavefront 0, beside the other wavefronts' share of pass D
+  if (wave == 0) {
     u64 carry = ~0ull;
     for (int b = (int)((n + 63u) / 64u) - 1; b >= 0; b--) {
       const u32 t = (u32)b * 64u + lane;
@@ -565,15 +595,15 @@ __global__ void __launch_bounds__(64) txn_check_lds_kernel(const TParams p) {
     }
     if (lane == 0) { sm[n] = NONE; smf[n] = n; }
   }
-  __syncthreads();
+  LEAVE_IF_DECIDED();
 
   // ---- E: edges: pass 0 counts degrees, pass 1 fills the CSR of the dependency edges (realtime successors stay a range) -----------------------------
-  u32 n_edges = 0, n_dep = 0;
+  u32 n_edges = 0;
   for (int pass = 0; pass < 2; pass++) {
     u32 my_edges = 0, my_dep = 0;
 #define ADD(a_, b_) do { const u32 ea = (a_), eb = (b_); if (ea != eb) { if (pass == 0) { h16_add(l_off, ea, 1u); h16_add(l_indeg, eb, 1u); my_edges++; my_dep++; } \
                                                                          else l_adj[h16_add(l_off, ea, 1u)] = (unsigned short)eb; } } while (0)
-    for (u32 key = lane; key < K; key += 64) {   // ww along each key's version order (lane = key)
+    for (u32 key = tid; key < K; key += NT) {   // ww along each key's version order (thread = key)
       const u32 L = l_longest[key];
       if (L == 0) continue;
       const u32 len = (L >> 24) - 1u; const u32 *ord = pay + (L & 0xFFFFFFu);
@@ -585,7 +615,7 @@ __global__ void __launch_bounds__(64) txn_check_lds_kernel(const TParams p) {
         if (!fa && !fb) ADD(W_TXN(a), W_TXN(b));
       }
     }
-    for (u32 t = lane; t < n; t += 64) {   // wr / rw per read of an :ok transaction; its realtime successors
+    for (u32 t = tid; t < n; t += NT) {   // wr / rw per read of an :ok transaction; its realtime successors
       if ((t_lt[t] >> 16) != MSIM_T_OK) continue;
       const u32 *w = pay + t_off[t]; const u32 wn = t_lt[t] & 0xFFFFu;
       for (u32 i = 0; i < wn;) {
@@ -611,26 +641,34 @@ __global__ void __launch_bounds__(64) txn_check_lds_kernel(const TParams p) {
       }
     }
 #undef ADD
-    __syncthreads();
-    if (__ballot(bad)) TO_HOST();
+    if (bad) VERDICT(2);
     if (pass == 0) {
-      n_edges = t_sum(my_edges); n_dep = t_sum(my_dep);
-      if (n_edges > p.emax) TO_HOST();
-      if (n_dep > adj_cap || n_dep > 65535u || n_edges > 65535u) TO_HBM();
-      // out-degrees -> CSR offsets (exclusive prefix sums, 64 at a time); pass 1 advances off[a] to the END of a's entries
-      u32 carry = 0;
-      for (u32 base = 0; base <= n; base += 64) {
-        const u32 t = base + lane;
-        const u32 d = t < n ? h16_get(l_off, t) : 0u;
-        const u32 ex = t_excl_scan(d, lane);
-        const u32 tot = t_sum(d);
-        __syncthreads();
-        // two lanes share a word: the even one writes both halves
-        const u32 mine = carry + ex, next = (u32)__shfl_down((int)mine, 1);
-        if (t <= n && !(t & 1u)) l_off[t >> 1] = mine | ((lane < 63u && t + 1u <= n ? next : 0u) << 16);
-        carry += tot;
-        __syncthreads();
+      my_edges = t_sum(my_edges); my_dep = t_sum(my_dep);
+      if (lane == 0) { atomicAdd(&hdr[7], my_edges); atomicAdd(&hdr[8], my_dep); }
+    }
+    LEAVE_IF_DECIDED();
+    if (pass == 0) {
+      n_edges = hdr[7];
+      const u32 n_dep = hdr[8];
+      if (n_edges > p.emax) { if (tid == 0) p.out[hist] = res; return; }   // (NEEDS_HOST; the same for every thread)
+      if (n_dep > adj_cap || n_dep > 65535u || n_edges > 65535u) { if (tid == 0) { res.valid = NEEDS_HBM; p.out[hist] = res; } return; }
+      // out-degrees -> CSR offsets (exclusive prefix sums, 64 at a time, wavefront 0); pass 1 advances off[a] to the END of a's entries
+      if (wave == 0) {
+        u32 carry = 0;
+        for (u32 base = 0; base <= n; base += 64) {
+          const u32 t = base + lane;
+          const u32 d = t < n ? h16_get(l_off, t) : 0u;
+          const u32 ex = t_excl_scan(d, lane);
+          const u32 tot = t_sum(d);
+          t_wave_fence();
+          // two lanes share a word: the even one writes both halves
+          const u32 mine = carry + ex, next = (u32)__shfl_down((int)mine, 1);
+          if (t <= n && !(t & 1u)) l_off[t >> 1] = mine | ((lane < 63u && t + 1u <= n ? next : 0u) << 16);
+          carry += tot;
+          t_wave_fence();
+        }
       }
+      __syncthreads();
     }
   }
 #undef WENT
@@ -641,12 +679,13 @@ __global__ void __launch_bounds__(64) txn_check_lds_kernel(const TParams p) {
   // ---- F: acyclic?  Kahn's algorithm, 64 ready transactions per step; queue and realtime ranges where the writer table was --------------------------
   unsigned short *const l_queue = reinterpret_cast<unsigned short *>(l_r1);
   u32 *const l_rt = l_r1 + ((n + 1u) >> 1);   // first | last << 16
-  for (u32 t = lane; t < n; t += 64) {
+  for (u32 t = tid; t < n; t += NT) {
     u32 first = 0, last = 0;
     if ((t_lt[t] >> 16) == MSIM_T_OK) { first = t_first[t]; last = sm[first] == NONE ? n : smf[first]; }
     l_rt[t] = first | (last << 16);
   }
   __syncthreads();
+  if (wave != 0) return;   // the queue is one wavefront's work (a ready set is about as wide as the clients' concurrency)
   u32 tail = 0;
   for (u32 base = 0; base < n; base += 64) {
     const u32 t = base + lane;
@@ -655,7 +694,7 @@ __global__ void __launch_bounds__(64) txn_check_lds_kernel(const TParams p) {
     if (z) l_queue[tail + (u32)__popcll(zm & lt)] = (unsigned short)t;
     tail += (u32)__popcll(zm);
   }
-  __syncthreads();
+  t_wave_fence();
   u32 head = 0;
   while (head < tail) {
     const u32 cnt = min(64u, tail - head);
@@ -672,25 +711,25 @@ __global__ void __launch_bounds__(64) txn_check_lds_kernel(const TParams p) {
       tail += (u32)__popcll(pm);
     }
     head += cnt;
-    __syncthreads();
+    t_wave_fence();
   }
-  if (tail != n) TO_HOST();   // a cycle: the host finds and classifies it
-
   if (lane == 0) {
-    res.lost_count = n_edges;   // edges of the dependency graph
-    res.valid = flags ? 0u : (c_ok == 0 ? 2u : 1u);
+    if (tail == n) {   // (else a cycle: the host finds and classifies it — res.valid is still NEEDS_HOST)
+      res.lost_count = n_edges;   // edges of the dependency graph
+      res.valid = flags ? 0u : (c_ok == 0 ? 2u : 1u);
+    }
     p.out[hist] = res;
   }
-#undef TO_HOST
-#undef TO_HBM
+#undef VERDICT
+#undef LEAVE_IF_DECIDED
 }
 
 // words of workspace per history: the tables of txn_check_kernel / the per-transaction words of txn_check_lds_kernel
 uint64_t ws_words_for(u32 nmax, u32 emax) { return (uint64_t)nmax * 11 + 4 + KMAX + WMAX + emax; }
 uint64_t ws_words_lds(u32 nmax) { return (uint64_t)nmax * 6 + 8; }
 
-// LDS of a wavefront of txn_check_lds_kernel: what a history of `nmax` transactions over `keys` keys with elements below `stride`
-// needs with 4.5 dependency edges per transaction, at most 78 KiB (two wavefronts per CU)
+// LDS of a workgroup of txn_check_lds_kernel: what a history of `nmax` transactions over `keys` keys with elements below `stride`
+// needs with 4.5 dependency edges per transaction, at most 78 KiB (two workgroups per CU)
 u32 lds_bytes_for(u32 nmax, u32 keys, u32 stride) {
   const uint64_t hw = (nmax + 2u) / 2, r1 = std::max<uint64_t>(((uint64_t)keys * stride + 1) / 2 + keys, (nmax + 1u) / 2 + nmax);
   const uint64_t need = (2 * hw + r1) * 4 + (uint64_t)nmax * 9 + 256;
@@ -709,12 +748,13 @@ int grow_ws(msim_ctx *ctx, void **ws_buf, size_t *ws_cap, size_t need) {
 int txn_dev_run(msim_ctx *ctx, TParams tp, u32 n, u32 cm, const std::vector<msim_inst_meta> *hmeta, msim_check_result *h_out, hipStream_t st, u32 *n_host,
                 void **ws_buf, size_t *ws_cap) {
   const bool trace = (msim_dev_flags(ctx) & 0x1000u) != 0;   // developer: time the passes
-  // Which kernel takes the first pass.  Measured on cfg5 (32768 histories, profiles/r03b_cfg5_txn_check_*): tables in LDS = 22 GB of HBM
-  // traffic, 270 ms; tables in HBM = 82 GB, 131 ms.  78 KiB of LDS per history leave a CU two wavefronts where the HBM-table kernel
-  // keeps 64 in flight, and what both kernels spend their time on — dependent payload loads, a lane per transaction — is latency that
-  // only wavefronts in flight hide.  Until the LDS kernel's streaming passes are split off the faster one is the
-  // default; MSIM_DEV_FLAGS bit 13 (0x2000) selects the LDS kernel.
-  const bool hbm_only = (msim_dev_flags(ctx) & 0x2000u) == 0;
+  // Which kernel takes the first pass: the one with its tables in LDS, a workgroup of several wavefronts per history (round 3: one
+  // wavefront per history and 78 KiB of LDS left a CU two wavefronts to hide the dependent payload loads of the streaming passes with —
+  // 270 ms per 32768 histories of cfg5 against 131 ms for the HBM-table kernel, which keeps 64 in flight; with the streaming passes
+  // spread over the wavefronts of a workgroup the LDS kernel has as many loads in flight and a quarter of the HBM traffic).
+  // MSIM_DEV_FLAGS bit 13 (0x2000) keeps every history on the HBM-table kernel; MSIM_TXN_WG = threads per history (64 .. 512).
+  const bool hbm_only = (msim_dev_flags(ctx) & 0x2000u) != 0;
+  static const u32 wg_threads = []() { const char *e = std::getenv("MSIM_TXN_WG"); u32 v = e ? (u32)std::atoi(e) : 512u; v = (v / 64u) * 64u; return v < 64u ? 64u : v > 512u ? 512u : v; }();
   const auto t0 = std::chrono::steady_clock::now();
   auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
   const uint64_t budget = 6ull << 30;   // as many histories per launch as a few GB of workspace hold (every one of them has its own slice)
@@ -729,13 +769,13 @@ int txn_dev_run(msim_ctx *ctx, TParams tp, u32 n, u32 cm, const std::vector<msim
     if (tp.lds_bytes > 64 * 1024) MSIM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(txn_check_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tp.lds_bytes));
     for (u32 first = 0; first < n; first += chunk) {
       tp.first = first;
-      hipLaunchKernelGGL(txn_check_lds_kernel, dim3(std::min(chunk, n - first)), dim3(64), tp.lds_bytes, st, tp);
+      hipLaunchKernelGGL(txn_check_lds_kernel, dim3(std::min(chunk, n - first)), dim3(wg_threads), tp.lds_bytes, st, tp);
       MSIM_HIP_TRY(ctx, hipGetLastError());
     }
     MSIM_HIP_TRY(ctx, hipMemcpyAsync(h_out, tp.out, (size_t)n * sizeof(msim_check_result), hipMemcpyDeviceToHost, st));
     MSIM_HIP_TRY(ctx, hipStreamSynchronize(st));
     for (u32 i = 0; i < n; i++) if (h_out[i].valid == NEEDS_HBM) big.push_back(i);
-    if (trace) std::fprintf(stderr, "[txn-check] LDS pass (%u B per wavefront): %.2f ms, %zu of %u histories do not fit\n", tp.lds_bytes, ms(), big.size(), n);
+    if (trace) std::fprintf(stderr, "[txn-check] LDS pass (%u B per workgroup): %.2f ms, %zu of %u histories do not fit\n", tp.lds_bytes, ms(), big.size(), n);
   } else { big.resize(n); for (u32 i = 0; i < n; i++) big[i] = i; }
   if (!big.empty()) {
     // pass 2: the histories whose tables do not fit LDS, tables in an HBM workspace
