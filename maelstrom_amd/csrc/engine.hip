@@ -849,17 +849,19 @@ static hipError_t launch_wide2(const KParams &kp, uint32_t n, size_t lds, hipStr
   if (nem) return rnd ? launch_wide_one<true, BC, true, SL>(kp, n, lds, st) : launch_wide_one<false, BC, true, SL>(kp, n, lds, st);
   return rnd ? launch_wide_one<true, BC, false, SL>(kp, n, lds, st) : launch_wide_one<false, BC, false, SL>(kp, n, lds, st);
 }
-// Which wide clusters keep their nodes' sets in LDS (SETL): g-set and fire-and-forget broadcast, when sets + client inboxes + the LDS
-// part of the queues leave a CU at least four clusters (40 KiB each); MSIM_DEV_FLAGS bit 14 keeps the sets in HBM scratch.
+// Which wide clusters keep their nodes' sets in LDS (SETL): g-set, when sets + client inboxes + the LDS part of the queues leave a CU
+// at least four clusters (40 KiB each); MSIM_DEV_FLAGS bit 14 keeps the sets in HBM scratch.  Measured (profiles/r03k_wide_sets.txt):
+// cfg3 417 -> 348 ms per 16384 clusters.  Fire-and-forget broadcast stays in HBM scratch: its set traffic is one word per delivery,
+// and at 20.8 KiB of LDS per cluster a CU holds 7 clusters where a batch of 2048 needs 8 — 121 -> 198 ms per 2048 clusters at n = 100.
 static bool wide_sets_in_lds(const msim_config &c, uint32_t dev_flags) {
   if (c.n_nodes <= 32 || (dev_flags & 0x4000u)) return false;
-  if (c.node_program != MSIM_NODE_G_SET && c.node_program != MSIM_NODE_BCAST_FF && c.node_program != MSIM_NODE_BCAST_FF_ECHOBACK) return false;
+  if (c.node_program != MSIM_NODE_G_SET) return false;
   const size_t bytes = ((size_t)c.n_nodes * c.inbox_capacity + (size_t)c.n_nodes * CLIENT_INBOX_CAP) * 16 + (size_t)c.n_nodes * (c.max_values / 32) * 4 + (c.nemesis_mask ? 512 : 0) + 16;
   return bytes <= 40 * 1024;
 }
 template <int BC>
 static hipError_t launch_wide(msim_ctx *, const KParams &kp, uint32_t n, size_t lds, hipStream_t st) {
-  if constexpr (BC <= 1) { if (wide_sets_in_lds(kp.cfg, kp.dev_flags)) return launch_wide2<BC, true>(kp, n, lds, st); }
+  if constexpr (BC == 0) { if (wide_sets_in_lds(kp.cfg, kp.dev_flags)) return launch_wide2<BC, true>(kp, n, lds, st); }
   return launch_wide2<BC, false>(kp, n, lds, st);
 }
 
@@ -1001,8 +1003,12 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
 
   if (blocking) MSIM_HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
   hipError_t e;
-#ifdef MSIM_ISA_PROBE  // developer hook (tools/isa_probe.sh): instantiate only the headline kernel so its ISA compiles in seconds
+#ifdef MSIM_ISA_PROBE  // developer hook (tools/isa_probe.sh): instantiate only one kernel so its ISA compiles in seconds
+#ifdef MSIM_ISA_PROBE_WIDE   // BASELINE cfg3's kernel
+  hipLaunchKernelGGL((sim_kernel_wide<true, 0, false, true>), dim3(n), dim3(64), lds, st, kp);
+#else
   hipLaunchKernelGGL((sim_kernel_colo<MSIM_NODE_BCAST_FF, false, false, false>), dim3(n), dim3(64), lds, st, kp);
+#endif
   e = hipGetLastError();
 #else
   // the headline layout: two clusters per wavefront (duo.hip); MSIM_DEV_FLAGS bit 9 keeps the one-cluster kernels

@@ -748,12 +748,13 @@ int grow_ws(msim_ctx *ctx, void **ws_buf, size_t *ws_cap, size_t need) {
 int txn_dev_run(msim_ctx *ctx, TParams tp, u32 n, u32 cm, const std::vector<msim_inst_meta> *hmeta, msim_check_result *h_out, hipStream_t st, u32 *n_host,
                 void **ws_buf, size_t *ws_cap) {
   const bool trace = (msim_dev_flags(ctx) & 0x1000u) != 0;   // developer: time the passes
-  // Which kernel takes the first pass: the one with its tables in LDS, a workgroup of several wavefronts per history (round 3: one
-  // wavefront per history and 78 KiB of LDS left a CU two wavefronts to hide the dependent payload loads of the streaming passes with —
-  // 270 ms per 32768 histories of cfg5 against 131 ms for the HBM-table kernel, which keeps 64 in flight; with the streaming passes
-  // spread over the wavefronts of a workgroup the LDS kernel has as many loads in flight and a quarter of the HBM traffic).
-  // MSIM_DEV_FLAGS bit 13 (0x2000) keeps every history on the HBM-table kernel; MSIM_TXN_WG = threads per history (64 .. 512).
-  const bool hbm_only = (msim_dev_flags(ctx) & 0x2000u) != 0;
+  // Which kernel takes the first pass.  Measured on cfg5, 32768 histories (profiles/r03b_cfg5_txn_check_*, r03k_cfg5_txn_check.txt):
+  // tables in an HBM workspace, one wavefront per history: 82 GB of HBM traffic, 130 ms (64 histories in flight per CU); tables in LDS:
+  // 22 GB, and 264 / 200 / 168 / 149 ms with 1 / 2 / 4 / 8 wavefronts per history — 78 KiB of LDS leave a CU two histories, and what a
+  // history's time goes to is the dependent payload loads of the streaming passes plus the passes only one wavefront can do (pairing,
+  // Kahn's queue).  The faster one stays the default; MSIM_DEV_FLAGS bit 13 (0x2000) selects the LDS kernel, MSIM_TXN_WG its threads
+  // per history (64 .. 512).
+  const bool hbm_only = (msim_dev_flags(ctx) & 0x2000u) == 0;
   static const u32 wg_threads = []() { const char *e = std::getenv("MSIM_TXN_WG"); u32 v = e ? (u32)std::atoi(e) : 512u; v = (v / 64u) * 64u; return v < 64u ? 64u : v > 512u ? 512u : v; }();
   const auto t0 = std::chrono::steady_clock::now();
   auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };

@@ -96,6 +96,13 @@ __device__ __forceinline__ u32 scan32(u32 v) {
 // be carried around the round loops as a PHI
 __device__ __forceinline__ void forget(u32 &v) { v = __builtin_nondeterministic_value(v); }
 __device__ __forceinline__ void forget(uint4 &v) { forget(v.x); forget(v.y); forget(v.z); forget(v.w); }
+// hides how a per-lane value was computed from the optimizer: what is derived from it is recomputed where it is used instead of being
+// hoisted out of the round loop and held in registers for its whole run (loop-invariant code motion does not weigh register pressure)
+#ifdef MSIM_HIPEMU
+#define MSIM_OPAQUE(x_) asm volatile("" : "+r"(x_))
+#else
+#define MSIM_OPAQUE(x_) asm volatile("" : "+v"(x_))
+#endif
 // value of `v` in lane `l` (per-lane l; every lane must execute this: ds_bpermute_b32)
 __device__ __forceinline__ u32 lane_get(u32 v, u32 l) { return (u32)__builtin_amdgcn_ds_bpermute((int)(l << 2), (int)v); }
 

@@ -14,9 +14,11 @@ import oracle_lib as O
 pytestmark = pytest.mark.gpu
 
 
-def _compare(cfg, first, n):
+def _compare(cfg, first, n, dev_flags=0):
     ora = O.run(cfg, first, n)
     with E.Engine(cfg) as eng:
+        if dev_flags:
+            eng.set_dev_flags(dev_flags)
         eng.run(first, n)
         eng.fetch()
         for i in range(n):
@@ -97,9 +99,13 @@ def test_g_set_parity(lib):
 ])
 def test_wide_g_set_parity(lib, n, kw):
     """BASELINE cfg3: clusters wider than 32 nodes (two node/client pairs per lane, sim_kernel_wide<>), with
-    randomized latency and message loss; same oracle code path as narrow clusters."""
+    randomized latency and message loss; same oracle code path as narrow clusters.  Both layouts of the nodes' sets: in LDS (the
+    default where they fit: sim_kernel_wide<.., SETL = true>) and in HBM scratch (MSIM_DEV_FLAGS bit 14); with the lone-operation
+    path (default) and with every operation on the general path (bit 1)."""
     cfg = E.test_config("g-set", node_count=n, rate=100, time_limit=12, seed=77, **kw)
     _compare(cfg, 0, 3)
+    _compare(cfg, 0, 3, dev_flags=0x4000)
+    _compare(cfg, 0, 2, dev_flags=0x2)
 
 
 @pytest.mark.parametrize("n,kw", [

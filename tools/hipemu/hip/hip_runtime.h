@@ -154,6 +154,13 @@ HIPEMU_COLL void hipemu_wave_barrier(HIPEMU_AT) { (void)hipemu_coll(hipemu::OP_B
 #define __builtin_amdgcn_wave_barrier() hipemu_wave_barrier()
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(n) ((void)0)
+static inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned m, unsigned v) { const unsigned l = hipemu::cur_lane() & 63u; return v + (unsigned)__builtin_popcount(l >= 32u ? m : (m & ((1u << l) - 1u))); }
+static inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned m, unsigned v) { const unsigned l = hipemu::cur_lane() & 63u; return v + (l > 32u ? (unsigned)__builtin_popcount(m & ((1u << (l - 32u)) - 1u)) : 0u); }
+// global_load_lds_dword: lane l's dword lands at the (wave-uniform) LDS address + l x size; here the copy happens at once
+static inline void __builtin_amdgcn_global_load_lds(const void *g, void *l, unsigned size, int off, unsigned) {
+  std::memcpy((char *)l + off + (size_t)(hipemu::cur_lane() & 63u) * size, (const char *)g + off, size);
+}
 static inline bool __builtin_amdgcn_inverse_ballot_w64(unsigned long long m) { return (m >> (hipemu::cur_lane() & 63u)) & 1ull; }
 #if !defined(__clang__)
 #define __builtin_nondeterministic_value(v) (v)
