@@ -44,7 +44,7 @@ def cfg4_config(E, seed):
 CONFIGS = {
     # name: (config builder, instances over the whole job or None = --instances per GPU, description, dominant kernel)
     "cfg2": (headline_config, None, "broadcast n=25 x %d instances/GPU (grid, rate 100/s, time-limit 20 s + 10 s quiesce + final reads, latency 0, fire-and-forget gossip)",
-             "sim_kernel_duo<LAT0, DEG4> (duo.hip: two clusters per wavefront)", "sim_kernel_duo", "r02_headline_counters.json"),
+             "sim_kernel_duo<LAT0, DEG4> (duo.hip: two clusters per wavefront)", "sim_kernel_duo", "r03q_headline_counters.json"),
     "cfg4": (cfg4_config, 65536, "lin-kv over 5-node Raft x %d instances/GPU (65536 over the job; concurrency 10, rate 30/s, time-limit 60 s, latency 0), histories gathered to rank 0 over RCCL",
              "raft4_kernel<> (raft4.hip: four clusters per wavefront)", "raft4_kernel", "r02_cfg4_raft_counters.json"),
 }
@@ -341,7 +341,7 @@ def main():
                         "wave_cycles_per_launch": c.get("SQ_WAVE_CYCLES"),
                         "frac_of_wave_cycles": kd.get("derived"),
                         "profiled_kernel_ms": kd.get("avg_ms"),
-                        "batch_sweep": "profiles/r03a_headline_batch_sweep.jsonl (4096 / 8192 / 16384 instances: 9.8 / 22.0 / 39.1 ms, 2.2e10 msgs/s at saturation)" if args.config == "cfg2" else None,
+                        "batch_sweep": "profiles/r03q_headline_batch_sweep.jsonl + r03q_bench.json (4096 / 8192 / 16384 instances: 8.9 / 20.1 / 35.7 ms of simulation, 2.6e10 msgs/s incl. the checker at 16384)" if args.config == "cfg2" else None,
                     }
             except Exception:
                 pass
