@@ -885,7 +885,8 @@ static uint64_t proto_scratch_words(const msim_config &c) {
   if (c.node_program == MSIM_NODE_BCAST_ACK_RETRY) w = (uint64_t)c.n_nodes * c.max_values * 3;
   if (c.node_program == MSIM_NODE_TXN_SINGLE_KEY) w = (uint64_t)c.max_values * (c.max_writes_per_key + 1);  // elements + counts per key
   if (c.node_program == MSIM_NODE_TXN_MULTI_KEY)   // elements, counts, map position, entry version, thunk counts, thunk versions + ids, the nodes' caches, the replica bytes
-    w = (uint64_t)c.max_values * (c.max_writes_per_key + 4 + 2 * (c.max_writes_per_key + 1)) + (uint64_t)c.n_nodes * mk_ccap(c) + (uint64_t)c.n_nodes * mk_tcap(c) / 4;
+    w = (uint64_t)c.max_values * (c.max_writes_per_key + 4 + 2 * (c.max_writes_per_key + 1)) + (uint64_t)c.n_nodes * mk_ccap(c) + (uint64_t)c.n_nodes * mk_tcap(c) / 4 + 4 +
+        (uint64_t)c.n_nodes * (MK_SLOTS - MK_SL) * mk_slot_words(8);   // + the transaction slots that are not in LDS
   if (c.node_program == MSIM_NODE_KAFKA) w = (uint64_t)KF_KEYS * (2 * (c.max_writes_per_key + 1) + 1);   // the logs + the committed-offset lists of the keys
   if (c.node_program == MSIM_NODE_TXN_RW_HAT) {  // registers per node + txn table + pending masks (bytes) + replicate lists
     const uint64_t G = c.max_rows / 2;
@@ -909,6 +910,7 @@ static uint64_t scratch_words(const msim_config &c) {
   uint64_t w = proto_scratch_words(c) + queues * c.spill_capacity * 4;
   if (msim_raft4_eligible(c)) w += msim_raft4_extra_scratch_words(c);   // raft4.hip keeps fewer envelopes in LDS
   if (msim_txn8_eligible(c)) w += msim_txn8_extra_scratch_words(c);     // txn8.hip likewise
+  if (msim_mk8_eligible(c)) w += msim_mk8_extra_scratch_words(c);       // mk8.hip likewise
   return w;
 }
 
@@ -988,7 +990,7 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   off += is_mk ? ((size_t)(kp.N + 2) * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16 : is_hat ? ((size_t)kp.N * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16 : is_px ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.CS * R_CLIENT_CAP) * 16 : (is_txn || is_kf) ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16
                 : ((size_t)kp.N * kp.cap_node + (size_t)kp.CS * (is_raft ? R_CLIENT_CAP : CLIENT_INBOX_CAP)) * 16;
   kp.off_seen = (u32)off;
-  off += is_mk ? ((size_t)kp.N * MK_SLOTS * MKW + (size_t)kp.N * MK_KEYS * 3 + 36) * 4   // transactions in flight, a round's messages per node, the generator's key pool
+  off += is_mk ? ((size_t)kp.N * MK_SL * mk_slot_words(mk_keys_for(c)) + (size_t)kp.N * mk_keys_for(c) * 3 + 36) * 4   // transactions in flight (the first MK_SL per node), a round's messages per node, the generator's key pool
        : is_hat ? 36 * 4   // the generator's key pool
        : is_px ? (size_t)kp.N * PX_SLOTS * 8 + 34 * 256 + 64 * 4   // callbacks per node + service states + seq-kv indices
        : is_txn ? (size_t)kp.N * TXN_SLOTS * 16 + 36 * 4   // transactions in flight per node + the generator's key pool
@@ -1021,6 +1023,8 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   if (msim_raft4_eligible(c) && !(kp.dev_flags & 0x200u)) e = msim_launch_raft4(kp, n, st);
   // txn-list-append: eight clusters per wavefront (txn8.hip) when a cluster fits an 8-lane group
   if (msim_txn8_eligible(c) && !(kp.dev_flags & 0x200u)) e = msim_launch_txn8(kp, n, st);
+  // the canonical txn-list-append node: eight clusters per wavefront (mk8.hip) when a cluster fits an 8-lane group
+  if (msim_mk8_eligible(c) && !(kp.dev_flags & 0x200u)) e = msim_launch_mk8(kp, n, st);
   if (e == MSIM_LAYOUT_DOES_NOT_FIT && (kp.dev_flags & 0x400u) && is_raft) { ctx->err = "MSIM_DEV_FLAGS bit 10: the four-clusters-per-wavefront Raft layout was required but does not apply"; return MSIM_E_UNSUPPORTED; }
   if (e == MSIM_LAYOUT_DOES_NOT_FIT) switch (c.node_program) {   // not eligible, or the cluster state does not fit the duo layout
     case MSIM_NODE_ECHO: e = launch<MSIM_NODE_ECHO>(kp, n, lds, st); break;
@@ -1066,7 +1070,9 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
     } break;
     case MSIM_NODE_TXN_MULTI_KEY: {
       const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
-      void (*fn)(const KParams) = c.nemesis_mask ? (rnd ? mk_kernel<true, true> : mk_kernel<true, false>) : (rnd ? mk_kernel<false, true> : mk_kernel<false, false>);
+      void (*fn)(const KParams);
+      if (mk_keys_for(c) == 4u) fn = c.nemesis_mask ? (rnd ? mk_kernel<true, true, 4> : mk_kernel<true, false, 4>) : (rnd ? mk_kernel<false, true, 4> : mk_kernel<false, false, 4>);
+      else fn = c.nemesis_mask ? (rnd ? mk_kernel<true, true, 8> : mk_kernel<true, false, 8>) : (rnd ? mk_kernel<false, true, 8> : mk_kernel<false, false, 8>);
       e = lds > 64 * 1024 ? hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) : hipSuccess;   // (above ~17 nodes)
       if (e == hipSuccess) { hipLaunchKernelGGL(fn, dim3(n), dim3(64), lds, st, kp); e = hipGetLastError(); }
     } break;
