@@ -118,7 +118,12 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
   u32 *const gen = reinterpret_cast<u32 *>(smem + tp.off_gen) + grp * 36;                       // active[16], next_val[16], next_key
   u32 *const misc = reinterpret_cast<u32 *>(smem + tp.off_misc) + grp * GS;
   // slot si of node nd: LDS for the first M8_SL, HBM scratch beyond (a generic pointer: flat loads / stores reach both)
-  auto slot_of = [&](u32 nd, u32 si) -> u32 * { return si < M8_SL ? slots_g + (nd * M8_SL + si) * MKW : xslots + ((size_t)nd * (M8_SLOTS - M8_SL) + (si - M8_SL)) * MKW; };
+  // (Every handler runs on one or the other through a lambda inlined at both call sites, so that the LDS slots — the ones in use nearly
+  //  always — are read and written with ds_ instructions: through a generic pointer they cost flat accesses, which wait for every global
+  //  load in flight as well.)
+  auto lds_slot = [&](u32 nd, u32 si) -> u32 * { return slots_g + (nd * M8_SL + si) * MKW; };
+  auto hbm_slot = [&](u32 nd, u32 si) -> u32 * { return xslots + ((size_t)nd * (M8_SLOTS - M8_SL) + (si - M8_SL)) * MKW; };
+#define M8_ON_SLOT(nd_, si_, f_) ((si_) < M8_SL ? f_(lds_slot((nd_), (si_)), (si_)) : f_(hbm_slot((nd_), (si_)), (si_)))
   const u32 my_node = is_node ? l : 0u;
   u32 *const my_cache = g_cache + (size_t)my_node * CC;
 
@@ -152,13 +157,13 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
   u32 loss_on = 0, next_id = 0, n_rows = 0, n_payload = 0, flags = 0, rounds = 0;
   bool alive = real;
 
-  auto q_push = [&](const uint4 m) {
+  auto q_push = [&](const uint4 m) __attribute__((always_inline)) {
     if (in_n < RQ) { my_q[in_n * 64u] = m; in_n++; return; }
     if (sp_n < my_spill_cap) { my_spill[sp_n++] = m; return; }
     my_flags |= MSIM_FLAG_INBOX_OVERFLOW;
   };
   // an envelope for THIS lane's node/service arrives (net.clj:189-221)
-  auto arrive = [&](u32 id, u32 type, u32 a, u32 b, u32 src) {
+  auto arrive = [&](u32 id, u32 type, u32 a, u32 b, u32 src) __attribute__((always_inline)) {
     u32 lat = 0;
     if (src < N || src >= LIN) {  // neither end is a client
       if (!NET_RANDOM || lat_dist == MSIM_LAT_CONSTANT) lat = lat_mean;
@@ -171,13 +176,13 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
     if (m.x < pm.x || (m.x == pm.x && m.y < pm.y)) { const uint4 t = m; m = pm; pm = t; }
     q_push(m);
   };
-  auto try_commit = [&](const uint4 e) {
+  auto try_commit = [&](const uint4 e) __attribute__((always_inline)) {
     const u32 src = e.w >> 24;
     if (NEM && src < N && ((part >> src) & 1)) return;  // partitioned (node <-> node only; never happens in this program)
     cm = e;
     deliver_at = e.x <= T ? T : T + ((e.x - T) / 1000u) * 1000u;  // (Thread/sleep (long dt)) net.clj:236-238
   };
-  auto poll = [&]() {
+  auto poll = [&]() __attribute__((always_inline)) {
     if (have_pm) {
       have_pm = false;
       if (alive && deliver_at == INF && (in_n | sp_n) == 0) try_commit(pm);
@@ -208,7 +213,7 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
   };
   // elements of `k` visible at version `from`: versions only grow along a key's row, so the answer is a count — the row is read with
   // independent loads (one round trip) instead of one dependent load per element
-  auto visible = [&](u32 k, u32 from) -> u32 {
+  auto visible = [&](u32 k, u32 from) __attribute__((always_inline)) -> u32 {
     if (from == V_NIL) return 0u;
     const u32 cnt = g_kvn[k];
     u32 n = 0;
@@ -224,8 +229,18 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
     return n;
   };
 
+#ifdef M8_PROF   // developer build (tools/mk8_prof.sh): cycle counters of the round's sections -> the meta of the wavefront's first three clusters
+  u64 pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; u32 wave_rounds = 0;
+  u64 tprev = __builtin_readcyclecounter();
+#define M8_MARK(i) { const u64 now_ = __builtin_readcyclecounter(); pacc[i] += now_ - tprev; tprev = now_; }
+#else
+#define M8_MARK(i)
+#endif
   for (;;) {
     if (!__ballot(alive)) break;
+#ifdef M8_PROF
+    wave_rounds++;
+#endif
     const u32 busy_mask = GB(busy);
 
     // ---- time-free phase transitions ----
@@ -276,7 +291,7 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
     bool cmp_row = false; u32 cmp_packed = 0, cmp_value = 0, cmp_len = 0;
     u32 nem_rows = 0, nem_f = 0, nem_v1 = 0, nem_v2 = 0, nem_len2 = 0;
 
-    auto complete = [&](u32 type, u32 err, u32 ref) {
+    auto complete = [&](u32 type, u32 err, u32 ref) __attribute__((always_inline)) {
       busy = false;
       if (kind != K_OP) { if (type != MSIM_T_OK) my_flags |= MSIM_FLAG_ROUND_LIMIT; return; }
       cmp_row = true; cmp_packed = type | (MSIM_F_TXN << 2) | (err << 7) | (process << 12);
@@ -284,7 +299,7 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
       if (type == MSIM_T_INFO) process += N;  // crashed process; the Reusable client itself lives on
     };
     // the client's recv! consumes one envelope (client.clj:94-107)
-    auto client_deliver = [&](u32 qtype, u32 qa, u32 qb) {
+    auto client_deliver = [&](u32 qtype, u32 qa, u32 qb) __attribute__((always_inline)) {
       s_recv_cl++;
       if (busy && qb == want) {
         if (qtype == M_TXN_OK) complete(MSIM_T_OK, 0, qa);
@@ -298,6 +313,7 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
       if (busy && timeout_at <= T) complete(MSIM_T_INFO, MSIM_ERR_NET_TIMEOUT, c_value);
     }
     bool normal = alive && !timeout_round;   // this cluster runs R1-R4 in this wave-round
+    M8_MARK(0)
     if (__ballot(normal)) {
       // ---- R1: scheduler ----
       const bool act = normal && due <= T;
@@ -403,6 +419,7 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
         }
       }
 
+      M8_MARK(1)
       // ---- R2: marked clients invoke; the request goes to this lane's own node ----
       if (__ballot(mark && normal)) {
         const bool inv = mark && normal;
@@ -425,25 +442,25 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
         poll();
       }
 
+      M8_MARK(2)
       // ---- R3: one input per node, then one for each service (endpoint order: lin-kv, lww-kv) ----
       bool rep = false, svc_rep = false;   // node -> own client, service -> node
       u32 n_out = 0, o_dest = 0;           // node -> service: n_out messages in mout[l][..], all to the same service
       u32 o_type = 0, o_a = 0, o_b = 0, o_to = 0, need_words = 0, done_slot = 0;
       u32 *const my_out = mout_g + l * (KEYS * 3u);
-      auto out_msg = [&](u32 dest, u32 type, u32 a, u32 b) { o_dest = dest; my_out[n_out * 3u] = type; my_out[n_out * 3u + 1u] = a; my_out[n_out * 3u + 2u] = b; n_out++; };
+      auto out_msg = [&](u32 dest, u32 type, u32 a, u32 b) __attribute__((always_inline)) { o_dest = dest; my_out[n_out * 3u] = type; my_out[n_out * 3u + 1u] = a; my_out[n_out * 3u + 2u] = b; n_out++; };
       // the node's thunk cache: open addressing over CC slots of tid + 1 (multi_key_txn.js:17,80-106)
-      auto cached = [&](u32 tid) -> bool {
+      auto cached = [&](u32 tid) __attribute__((always_inline)) -> bool {
         for (u32 h = (tid * 0x9E3779B1u) & (CC - 1u);; h = (h + 1u) & (CC - 1u)) { const u32 v = my_cache[h]; if (v == 0u) return false; if (v == tid + 1u) return true; }
       };
-      auto cache_add = [&](u32 tid) {
-        if (cached(tid)) return;
-        if ((cache_n + 1u) * 2u > CC) { my_flags |= MSIM_FLAG_ARENA_OVERRUN; return; }   // engine capacity
+      auto cache_add = [&](u32 tid) __attribute__((always_inline)) {   // (one probe sequence: it ends at the thunk or at the free slot it goes to)
         u32 h = (tid * 0x9E3779B1u) & (CC - 1u);
-        while (my_cache[h] != 0u) h = (h + 1u) & (CC - 1u);
+        for (;;) { const u32 v = my_cache[h]; if (v == tid + 1u) return; if (v == 0u) break; h = (h + 1u) & (CC - 1u); }
+        if ((cache_n + 1u) * 2u > CC) { my_flags |= MSIM_FLAG_ARENA_OVERRUN; return; }   // engine capacity
         my_cache[h] = tid + 1u; cache_n++;
       };
       // the thunk the root of version v names for `k` (MK_NONE: the map does not have the key)
-      auto thunk_of = [&](u32 k, u32 v) -> u32 {
+      auto thunk_of = [&](u32 k, u32 v) __attribute__((always_inline)) -> u32 {
         const u32 first = g_first[k], cnt = g_updn[k];   // (never entered: MK_NONE > any version)
         if (first > v) return MK_NONE;
         if (mw1 <= 17u) {   // the versions of the key's thunks grow along the row: count those <= v with independent loads, then one more for the id
@@ -459,13 +476,13 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
         for (u32 i = 0; i < cnt && g_upd_v[k * mw1 + i] <= v; i++) t = g_upd_t[k * mw1 + i];
         return t;
       };
-      auto send_cas = [&](u32 *sl, u32 si) {   // casRoot, :120-137
+      auto send_cas = [&](u32 *sl, u32 si) __attribute__((always_inline)) {   // casRoot, :120-137
         const u32 rid = ++node_msgid;
         sl[SK_HDR] = 1u | (3u << 8); sl[SK_RPC] = rid;
         out_msg(D_LIN, M_CAS, sl[SK_RV] | (si << 16), rid);
       };
       // writeThunks (:160-177): state2's keys in insertion order — the thunks read, then the keys the transaction creates
-      auto begin_writes = [&](u32 *sl, u32 si) {
+      auto begin_writes = [&](u32 *sl, u32 si) __attribute__((always_inline)) {
         const u32 nk = sl[SK_NK], ns = sl[SK_NSTATE];
         u32 ord[KEYS], n = 0, in_state = 0;
         for (u32 i = 0; i < ns; i++) { const u32 j = sl[SK_SORD + i]; ord[n++] = j; in_state |= 1u << j; }
@@ -486,20 +503,64 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
         sl[SK_WROUT] = wr_out;
         if (wr_out == 0) send_cas(sl, si);
       };
-      auto thunk_ready = [&](u32 *sl, u32 j) { const u32 ns = sl[SK_NSTATE]; sl[SK_SORD + ns] = j; sl[SK_NSTATE] = ns + 1u; sl[SK_RDRPC + j] = 0; };
+      auto thunk_ready = [&](u32 *sl, u32 j) __attribute__((always_inline)) { const u32 ns = sl[SK_NSTATE]; sl[SK_SORD + ns] = j; sl[SK_NSTATE] = ns + 1u; sl[SK_RDRPC + j] = 0; };
       // transact (:213-236) from the node's cached root; getState (:141-156) walks the root's keys in map order
-      auto start_attempt = [&](u32 *sl, u32 si) {
+      // The loads of all of the transaction's keys go out together, stage by stage (map entry + thunk count + position; the last four thunk
+      // versions of each — the cached root is recent, the thunk it names is nearly always among them —; the thunk ids; the first probe of
+      // the cache): five round trips where a key at a time paid five each.
+      auto start_attempt = [&](u32 *sl, u32 si) __attribute__((always_inline)) {
         const u32 nk = sl[SK_NK], rv = root_v;
         sl[SK_RV] = rv; sl[SK_HDR] = 1u | (1u << 8); sl[SK_NSTATE] = 0;
-        u32 posn[KEYS], tids[KEYS], rd_out = 0;
-        for (u32 j = 0; j < nk; j++) { sl[SK_RDRPC + j] = 0; const u32 k = sl[SK_KEY + j]; tids[j] = thunk_of(k, rv); posn[j] = tids[j] == MK_NONE ? MK_NONE : g_pos[k]; }
+        u32 kk[KEYS], first[KEYS], cnt[KEYS], posn[KEYS], tids[KEYS], nle[KEYS], rd_out = 0;
+#pragma unroll
+        for (u32 j = 0; j < KEYS; j++) kk[j] = j < nk ? sl[SK_KEY + j] : 0u;
+#pragma unroll
+        for (u32 j = 0; j < KEYS; j++) {
+          first[j] = MK_NONE; cnt[j] = 0; posn[j] = MK_NONE;
+          if (j < nk) { sl[SK_RDRPC + j] = 0; first[j] = g_first[kk[j]]; cnt[j] = g_updn[kk[j]]; posn[j] = g_pos[kk[j]]; }
+        }
+        u32 l4[KEYS][4];
+#pragma unroll
+        for (u32 j = 0; j < KEYS; j++)
+#pragma unroll
+          for (u32 t = 0; t < 4u; t++) {
+            const u32 idx = (cnt[j] >= 4u ? cnt[j] - 4u : 0u) + t;
+            l4[j][t] = 0xFFFFFFFFu;
+            if (j < nk && first[j] <= rv && idx < cnt[j]) l4[j][t] = g_upd_v[kk[j] * mw1 + idx];
+          }
+#pragma unroll
+        for (u32 j = 0; j < KEYS; j++) {
+          nle[j] = 0;
+          if (j < nk && first[j] <= rv) {   // (never entered: MK_NONE > any version)
+            const u32 base = cnt[j] >= 4u ? cnt[j] - 4u : 0u;
+            if (base != 0u && l4[j][0] > rv) { u32 n = 0; while (n < base && g_upd_v[kk[j] * mw1 + n] <= rv) n++; nle[j] = n; }   // an old root: walk the row
+            else {
+              u32 n = base;
+#pragma unroll
+              for (u32 t = 0; t < 4u; t++) n += (base + t < cnt[j] && l4[j][t] <= rv) ? 1u : 0u;
+              nle[j] = n;
+            }
+          }
+        }
+#pragma unroll
+        for (u32 j = 0; j < KEYS; j++) { tids[j] = MK_NONE; if (nle[j]) tids[j] = g_upd_t[kk[j] * mw1 + nle[j] - 1u]; if (tids[j] == MK_NONE) posn[j] = MK_NONE; }
+        u32 pr[KEYS];   // first probe of the thunk cache, all keys at once
+#pragma unroll
+        for (u32 j = 0; j < KEYS; j++) { pr[j] = 0; if (tids[j] != MK_NONE) pr[j] = my_cache[(tids[j] * 0x9E3779B1u) & (CC - 1u)]; }
+        bool have[KEYS];
+#pragma unroll
+        for (u32 j = 0; j < KEYS; j++) have[j] = tids[j] != MK_NONE && (pr[j] == tids[j] + 1u || (pr[j] != 0u && cached(tids[j])));
         for (u32 done = 0;;) {   // ascending position in the root map
           u32 best = MK_NONE, bj = 0;
-          for (u32 j = 0; j < nk; j++) if (!((done >> j) & 1u) && posn[j] < best) { best = posn[j]; bj = j; }
+#pragma unroll
+          for (u32 j = 0; j < KEYS; j++) if (j < nk && !((done >> j) & 1u) && posn[j] < best) { best = posn[j]; bj = j; }
           if (best == MK_NONE) break;
           done |= 1u << bj;
-          if (cached(tids[bj])) thunk_ready(sl, bj);
-          else { const u32 rid = ++node_msgid; sl[SK_RDTID + bj] = tids[bj]; sl[SK_RDRPC + bj] = rid; rd_out++; out_msg(D_LWW, M_READ, tids[bj], rid); }
+          bool hv = false; u32 tb = 0;
+#pragma unroll
+          for (u32 j = 0; j < KEYS; j++) if (j == bj) { hv = have[j]; tb = tids[j]; }
+          if (hv) thunk_ready(sl, bj);
+          else { const u32 rid = ++node_msgid; sl[SK_RDTID + bj] = tb; sl[SK_RDRPC + bj] = rid; rd_out++; out_msg(D_LWW, M_READ, tb, rid); }
         }
         sl[SK_RDOUT] = rd_out;
         if (rd_out == 0) begin_writes(sl, si);
@@ -513,32 +574,36 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
           switch (qtype) {
             case M_INIT: rep = true; o_type = M_INIT_OK; o_b = qb; break;
             case M_TXN: {
-              u32 si = 0; while (si < M8_SLOTS && (slot_of(my_node, si)[SK_HDR] & 0xFFu)) si++;
+              u32 si = 0;
+              while (si < M8_SL && (lds_slot(my_node, si)[SK_HDR] & 0xFFu)) si++;
+              if (si == M8_SL) while (si < M8_SLOTS && (hbm_slot(my_node, si)[SK_HDR] & 0xFFu)) si++;
               if (si == M8_SLOTS) { my_flags |= MSIM_FLAG_ARENA_OVERRUN; break; }   // engine capacity; the reference has no bound
-              u32 *const sl = slot_of(my_node, si);
-              for (u32 i = 0; i < MKW; i++) sl[i] = 0;
-              sl[SK_HDR] = 1u; sl[SK_CMSG] = qb; sl[SK_REF] = qa;
-              const u32 off0 = qa & 0xFFFFFFu, n = qa >> 24;
-              u32 wv[KEYS];   // the micro-ops (at most KEYS: --max-txn-length), one round trip
+              auto on_txn = [&](u32 *sl, u32 si_) __attribute__((always_inline)) -> bool {
+                for (u32 i = 0; i < MKW; i++) sl[i] = 0;
+                sl[SK_HDR] = 1u; sl[SK_CMSG] = qb; sl[SK_REF] = qa;
+                const u32 off0 = qa & 0xFFFFFFu, n = qa >> 24;
+                u32 wv[KEYS];   // the micro-ops (at most KEYS: --max-txn-length), one round trip
 #pragma unroll
-              for (u32 i = 0; i < KEYS; i++) wv[i] = i < n ? g_pay[off0 + i] : 0u;
-              u32 nk = 0;
+                for (u32 i = 0; i < KEYS; i++) wv[i] = i < n ? g_pay[off0 + i] : 0u;
+                u32 nk = 0;
 #pragma unroll
-              for (u32 i = 0; i < KEYS; i++) if (i < n) {   // readSet / writeSet (:180-197)
-                const u32 w = wv[i], k = (w >> 1) & 0x7FFFu;
-                u32 j = 0; while (j < nk && sl[SK_KEY + j] != k) j++;
-                if (j == nk) { sl[SK_KEY + j] = k; nk++; }
-                if ((w & 1u) && !sl[SK_WR + j]) { sl[SK_WR + j] = 1u; sl[SK_FA + j] = i; }
-              }
-              sl[SK_NK] = nk;
-              start_attempt(sl, si);
+                for (u32 i = 0; i < KEYS; i++) if (i < n) {   // readSet / writeSet (:180-197)
+                  const u32 w = wv[i], k = (w >> 1) & 0x7FFFu;
+                  u32 j = 0; while (j < nk && sl[SK_KEY + j] != k) j++;
+                  if (j == nk) { sl[SK_KEY + j] = k; nk++; }
+                  if ((w & 1u) && !sl[SK_WR + j]) { sl[SK_WR + j] = 1u; sl[SK_FA + j] = i; }
+                }
+                sl[SK_NK] = nk;
+                start_attempt(sl, si_);
+                return true;
+              };
+              (void)M8_ON_SLOT(my_node, si, on_txn);
             } break;
             case M_READ_OK: case M_WRITE_OK: case M_CAS_OK: case M_ERROR: {
-              bool found = false;
-              for (u32 si = 0; si < M8_SLOTS && !found; si++) {
-                u32 *const sl = slot_of(my_node, si);
+              auto on_reply = [&](u32 *sl, u32 si_) __attribute__((always_inline)) -> bool {
+                bool found = false;
                 const u32 hdr = sl[SK_HDR];
-                if (!(hdr & 0xFFu)) continue;
+                if (!(hdr & 0xFFu)) return false;
                 const u32 stage_ = (hdr >> 8) & 0xFFu, nk = sl[SK_NK];
                 if (stage_ == 1u) {
                   for (u32 j = 0; j < nk; j++) if (qb && sl[SK_RDRPC + j] == qb) {
@@ -549,15 +614,17 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
                       if (cached(tid)) { thunk_ready(sl, j); sl[SK_RDOUT]--; }
                       else { const u32 rid = ++node_msgid; sl[SK_RDRPC + j] = rid; out_msg(D_LWW, M_READ, tid, rid); }
                     }
-                    if (sl[SK_RDOUT] == 0) begin_writes(sl, si);
+                    if (sl[SK_RDOUT] == 0) begin_writes(sl, si_);
                     break;
                   }
                 } else if (stage_ == 2u) {
                   for (u32 j = 0; j < nk; j++) if (qb && sl[SK_WR + j] && sl[SK_WRRPC + j] == qb) {
                     found = true;
                     sl[SK_WRRPC + j] = 0;
-                    if (thunk_of(sl[SK_KEY + j], sl[SK_RV]) == MK_NONE) { const u32 nn = sl[SK_NNEW]; sl[SK_NORD + nn] = j; sl[SK_NNEW] = nn + 1u; }
-                    if (--sl[SK_WROUT] == 0) send_cas(sl, si);
+                    // "the root of version rv has no thunk for the key" == the key entered the map later (or never): a key's first thunk is
+                    // committed by the cas that enters it, so g_first[k] is also the version of its first thunk — one load, not the row
+                    if (g_first[sl[SK_KEY + j]] > sl[SK_RV]) { const u32 nn = sl[SK_NNEW]; sl[SK_NORD + nn] = j; sl[SK_NNEW] = nn + 1u; }
+                    if (--sl[SK_WROUT] == 0) send_cas(sl, si_);
                     break;
                   }
                 } else if (sl[SK_RPC] == qb) {
@@ -567,17 +634,41 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
                       u32 writes = 0; for (u32 j = 0; j < nk; j++) writes |= sl[SK_WR + j];
                       const u32 rv = sl[SK_RV];
                       root_v = rv + (writes ? 1u : 0u);
-                      rep = true; o_type = M_TXN_OK; o_b = sl[SK_CMSG]; done_slot = si;
+                      rep = true; o_type = M_TXN_OK; o_b = sl[SK_CMSG]; done_slot = si_;
                       const u32 ref = sl[SK_REF], off0 = ref & 0xFFFFFFu, n = ref >> 24;
                       u32 wv[KEYS];
 #pragma unroll
                       for (u32 j = 0; j < KEYS; j++) wv[j] = j < n ? g_pay[off0 + j] : 0u;
+                      // how many elements each read sees at version rv: the counts of all read keys in one round trip, the last four
+                      // versions of each row in a second (rv is recent: what it does not see is at the row's end)
+                      u32 vcnt[KEYS], vl4[KEYS][4], vis[KEYS];
+#pragma unroll
+                      for (u32 j = 0; j < KEYS; j++) { vcnt[j] = 0; if (j < n && !(wv[j] & 1u) && rv != V_NIL) vcnt[j] = g_kvn[(wv[j] >> 1) & 0x7FFFu]; }
+#pragma unroll
+                      for (u32 j = 0; j < KEYS; j++)
+#pragma unroll
+                        for (u32 t = 0; t < 4u; t++) {
+                          const u32 idx = (vcnt[j] >= 4u ? vcnt[j] - 4u : 0u) + t;
+                          vl4[j][t] = 0xFFFFFFFFu;
+                          if (idx < vcnt[j]) vl4[j][t] = g_kv[((wv[j] >> 1) & 0x7FFFu) * mw + idx];
+                        }
+#pragma unroll
+                      for (u32 j = 0; j < KEYS; j++) {
+                        const u32 base = vcnt[j] >= 4u ? vcnt[j] - 4u : 0u;
+                        if (base != 0u && (vl4[j][0] >> 8) > rv) vis[j] = visible((wv[j] >> 1) & 0x7FFFu, rv);
+                        else {
+                          u32 c = base;
+#pragma unroll
+                          for (u32 t = 0; t < 4u; t++) c += (base + t < vcnt[j] && (vl4[j][t] >> 8) <= rv) ? 1u : 0u;
+                          vis[j] = c;
+                        }
+                      }
 #pragma unroll
                       for (u32 j = 0; j < KEYS; j++) if (j < n) {
                         const u32 w = wv[j], k = (w >> 1) & 0x7FFFu;
                         need_words++;
                         if (!(w & 1u)) {
-                          u32 len = visible(k, rv);
+                          u32 len = vis[j];
 #pragma unroll
                           for (u32 e = 0; e < KEYS; e++) if (e < j) { const u32 we = wv[e]; if ((we & 1u) && ((we >> 1) & 0x7FFFu) == k) len++; }
                           need_words += (len + 3u) / 4u;
@@ -586,10 +677,14 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
                     } else { const u32 rid = ++node_msgid; sl[SK_HDR] = 1u | (4u << 8); sl[SK_RPC] = rid; out_msg(D_LIN, M_READ, 0, rid); }   // :230-234
                   } else {   // getRoot (:112-116)
                     root_v = qtype == M_READ_OK ? qa : 0u;
-                    start_attempt(sl, si);
+                    start_attempt(sl, si_);
                   }
                 }
-              }
+                return found;
+              };
+              bool found = false;
+              for (u32 si = 0; si < M8_SL && !found; si++) found = on_reply(lds_slot(my_node, si), si);
+              for (u32 si = M8_SL; si < M8_SLOTS && !found; si++) found = on_reply(hbm_slot(my_node, si), si);
             } break;   // no handler under that id: ignored (node.js:152-156)
             default: break;
           }
@@ -601,7 +696,7 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
             const u32 from = qa & 0xFFFFu, si = qa >> 16;
             if (root_exists && cur_v != from) { o_type = M_ERROR; o_a = 22; }
             else {
-              const u32 *const sl = slot_of(qsrc, si);
+              auto on_cas = [&](u32 *sl, u32) __attribute__((always_inline)) -> bool {
               const u32 nk = sl[SK_NK], ref = sl[SK_REF], off0 = ref & 0xFFFFFFu, n = ref >> 24;
               u32 writes = 0; for (u32 j = 0; j < nk; j++) writes |= sl[SK_WR + j];
               root_exists = 1u;
@@ -609,14 +704,30 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
                 const u32 v = ++cur_v;
                 const u32 nn = sl[SK_NNEW];
                 for (u32 i = 0; i < nn; i++) { const u32 k = sl[SK_KEY + sl[SK_NORD + i]]; g_pos[k] = n_order++; g_first[k] = v; }
-                for (u32 j = 0; j < nk; j++) if (sl[SK_WR + j]) { const u32 k = sl[SK_KEY + j], c = g_updn[k]; g_upd_v[k * mw1 + c] = v; g_upd_t[k * mw1 + c] = sl[SK_WRTID + j]; g_updn[k] = c + 1u; }
+                // the thunk counts of the written keys and the element counts of the appended ones: every read-modify-write of the cas in
+                // one round trip behind the micro-ops' (a key is read once: a transaction's later appends to it continue from the first's count)
                 u32 wv[KEYS];
 #pragma unroll
                 for (u32 i = 0; i < KEYS; i++) wv[i] = i < n ? g_pay[off0 + i] : 0u;
+                u32 kj[KEYS], cu[KEYS], ca[KEYS];
 #pragma unroll
-                for (u32 i = 0; i < KEYS; i++) if (i < n) { const u32 w = wv[i];
-                  if (w & 1u) { const u32 k = (w >> 1) & 0x7FFFu, c = g_kvn[k]; g_kv[k * mw + c] = ((w >> 16) & 0xFFu) | (v << 8); g_kvn[k] = c + 1u; } }
+                for (u32 j = 0; j < KEYS; j++) { kj[j] = 0; cu[j] = 0; if (j < nk && sl[SK_WR + j]) { kj[j] = sl[SK_KEY + j]; cu[j] = g_updn[kj[j]]; } }
+#pragma unroll
+                for (u32 i = 0; i < KEYS; i++) { ca[i] = 0; if (i < n && (wv[i] & 1u)) ca[i] = g_kvn[(wv[i] >> 1) & 0x7FFFu]; }
+#pragma unroll
+                for (u32 j = 0; j < KEYS; j++) if (j < nk && sl[SK_WR + j]) { const u32 k = kj[j], c = cu[j]; g_upd_v[k * mw1 + c] = v; g_upd_t[k * mw1 + c] = sl[SK_WRTID + j]; g_updn[k] = c + 1u; }
+#pragma unroll
+                for (u32 i = 0; i < KEYS; i++) if (i < n && (wv[i] & 1u)) {
+                  const u32 w = wv[i], k = (w >> 1) & 0x7FFFu;
+                  u32 c = ca[i];
+#pragma unroll
+                  for (u32 e = 0; e < KEYS; e++) if (e < i && (wv[e] & 1u) && ((wv[e] >> 1) & 0x7FFFu) == k) c++;
+                  g_kv[k * mw + c] = ((w >> 16) & 0xFFu) | (v << 8); g_kvn[k] = c + 1u;
+                }
               }
+                return true;
+              };
+              (void)M8_ON_SLOT(qsrc, si, on_cas);
               o_type = M_CAS_OK; o_a = 0;
             }
           }
@@ -631,16 +742,19 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
         }
       }
 
+      M8_MARK(3)
       // completed transactions: payload words allocated in node order, each node writes its own
       if (__ballot(need_words != 0)) {
         u32 excl = 0, total = 0;
         for (u32 s = 0; s < N; s++) { const u32 v = GGET(need_words, s); excl += s < l ? v : 0u; total += v; }
         if (total) {
-          if (n_payload + total > max_pay) { flags |= MSIM_FLAG_PAYLOAD_OVERFLOW; if (need_words) { o_a = 0; slot_of(my_node, done_slot)[SK_HDR] = 0; } }
+          if (n_payload + total > max_pay) { flags |= MSIM_FLAG_PAYLOAD_OVERFLOW; if (need_words) { o_a = 0; if (done_slot < M8_SL) lds_slot(my_node, done_slot)[SK_HDR] = 0; else hbm_slot(my_node, done_slot)[SK_HDR] = 0; } }
           else {
             if (need_words) {
-              const u32 *const sl = slot_of(my_node, done_slot);
-              const u32 ref = sl[SK_REF], off0 = ref & 0xFFFFFFu, n = ref >> 24, from = sl[SK_RV];
+              u32 ref, from;
+              if (done_slot < M8_SL) { u32 *const sl = lds_slot(my_node, done_slot); ref = sl[SK_REF]; from = sl[SK_RV]; sl[SK_HDR] = 0; }
+              else { u32 *const sl = hbm_slot(my_node, done_slot); ref = sl[SK_REF]; from = sl[SK_RV]; sl[SK_HDR] = 0; }
+              const u32 off0 = ref & 0xFFFFFFu, n = ref >> 24;
               u32 pp = n_payload + excl;
               o_a = pp | (need_words << 24);
               u32 wv[KEYS];
@@ -671,13 +785,13 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
                 if (e & 3) g_pay[pp++] = acc;
                 g_pay[hdr] = (k << 1) | ((e ? e : 0xFFu) << 16);  // a key without elements reads nil
               }
-              slot_of(my_node, done_slot)[SK_HDR] = 0;
             }
             n_payload += total;
           }
         }
       }
 
+      M8_MARK(4)
       // COMMIT: ids in lane order (nodes, lin-kv, lww-kv); a node's messages in the order it emitted them
       bool c_arr = false; u32 ca_y = 0, ca_a = 0, ca_b = 0;
       {
@@ -718,6 +832,7 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
         poll();
       }
 
+      M8_MARK(5)
       // ---- R4: the clients' recv! loops (client.clj:94-107) ----
       if (__ballot(c_arr || (busy && (cin_n | csp_n) != 0))) {
         for (;;) {
@@ -753,6 +868,7 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
       }
     }
 
+    M8_MARK(6)
     // ---- history rows: nemesis rows, invocations (lane order), completions (lane order) ----
     {
       const u32 imask = GB(inv_row), cmask = GB(cmp_row);
@@ -776,6 +892,7 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
         n_rows = new_n;
       }
     }
+    M8_MARK(7)
   }
 
   // ---- epilogue ----
@@ -790,6 +907,11 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
     p.stats[inst] = st;
     msim_inst_meta m; m.n_rows = n_rows; m.n_payload_words = n_payload; m.flags = flags; m.n_rounds = rounds;
     m.n_events = 0; m.reserved[0] = 0; m.reserved[1] = 0; m.reserved[2] = 0;
+#ifdef M8_PROF
+    if (grp == 0) { m.n_events = (u32)(pacc[0] >> 6); m.reserved[0] = (u32)(pacc[1] >> 6); m.reserved[1] = (u32)(pacc[2] >> 6); m.reserved[2] = (u32)(pacc[3] >> 6); }
+    if (grp == 1) { m.n_events = (u32)(pacc[4] >> 6); m.reserved[0] = (u32)(pacc[5] >> 6); m.reserved[1] = (u32)(pacc[6] >> 6); m.reserved[2] = (u32)(pacc[7] >> 6); }
+    if (grp == 2) { m.n_events = wave_rounds; }
+#endif
     p.meta[inst] = m;
   }
 }
