@@ -216,10 +216,24 @@ def test_general_layout_parity_when_concurrency_differs_from_nodes(lib, conc):
     dict(node_count=5, rate=100, time_limit=6, latency=5, p_loss=0.05, journal_capacity=400000),
 ])
 def test_multi_key_txn_parity(lib, kw):
-    """The canonical txn-list-append node (thunks in lww-kv, root map in lin-kv): mk_kernel<> against oracle/mk_nodes.inc, which the
-    reference's own multi_key_txn.js pins on the process bridge (tests/test_process_bridge.py)."""
+    """The canonical txn-list-append node (thunks in lww-kv, root map in lin-kv) against oracle/mk_nodes.inc, which the reference's own
+    multi_key_txn.js pins on the process bridge (tests/test_process_bridge.py).  Both layouts: eight clusters per wavefront (mk8_kernel<>,
+    csrc/mk8.hip: what the engine picks for <= 6 nodes, --max-txn-length <= 4, journal off) and one cluster per wavefront (mk_kernel<>:
+    every other shape, and every shape under MSIM_DEV_FLAGS bit 9)."""
     cfg = E.test_config("txn-list-append", bin="multi-key-txn", seed=91, **kw)
-    _compare(cfg, 0, 4)
+    _compare(cfg, 0, 11)               # (11 clusters: a full group of eight and a partial one)
+    _compare(cfg, 0, 4, dev_flags=0x200)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(node_count=5, rate=100, time_limit=20, latency=100, latency_dist="exponential", p_loss=0.1, nemesis=["partition"], nemesis_interval=4),   # timeouts: several transactions in flight per node (the slots in HBM scratch), deep service queues
+    dict(node_count=6, rate=300, time_limit=6, latency=20, latency_dist="uniform", key_count=2),                                                   # the widest group: 6 nodes + 2 services; contended keys
+    dict(node_count=1, rate=50, time_limit=5, latency=1),
+])
+def test_multi_key_txn_packed_layout_parity(lib, kw):
+    """Shapes that stress what is specific to mk8_kernel<>: transaction slots beyond the LDS one, spilled queues, a full 8-lane group."""
+    cfg = E.test_config("txn-list-append", bin="multi-key-txn", seed=17, **kw)
+    _compare(cfg, 0, 16)
 
 
 def test_deep_queues_spill_to_hbm(lib):
