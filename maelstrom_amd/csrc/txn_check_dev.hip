@@ -416,6 +416,12 @@ __global__ void __launch_bounds__(512) txn_check_lds_kernel(const TParams p) {
   // every thread of the workgroup sees the same verdict behind a barrier and leaves with it
 #define VERDICT(v_) atomicMax(&hdr[0], (u32)(v_))
 #define LEAVE_IF_DECIDED() do { __syncthreads(); const u32 vd_ = hdr[0]; if (vd_) { if (tid == 0) { res.valid = vd_ == 1u ? NEEDS_HBM : NEEDS_HOST; p.out[hist] = res; } return; } } while (0)
+#ifdef TC_PROF   // developer build: cycles per phase (as wavefront 0 sees them: the barriers close a phase for the whole workgroup)
+  u64 tl_prev = __builtin_readcyclecounter(); u32 tl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define TL_MARK(i_) { const u64 now_ = __builtin_readcyclecounter(); tl[i_] += (u32)((now_ - tl_prev) >> 6); tl_prev = now_; }
+#else
+#define TL_MARK(i_)
+#endif
   if (tid < 16) hdr[tid] = 0;
   __syncthreads();
   if (n_words >= (1u << 24)) { if (tid == 0) p.out[hist] = res; return; }
@@ -484,6 +490,7 @@ __global__ void __launch_bounds__(512) txn_check_lds_kernel(const TParams p) {
     if (lane == 0) { hdr[0] = bad == 2 ? 1u : bad ? 2u : 0u; hdr[1] = n; hdr[2] = c_ok; hdr[3] = c_fail; hdr[4] = c_info; }
   }
   LEAVE_IF_DECIDED();
+  TL_MARK(0)
   const u32 n = hdr[1], c_ok = hdr[2], c_fail = hdr[3], c_info = hdr[4];
   res.op_count = n; res.attempt_count = n; res.ok_count = c_ok; res.stable_count = c_ok; res.fail_count = c_fail; res.info_count = c_info;
 
@@ -520,6 +527,7 @@ __global__ void __launch_bounds__(512) txn_check_lds_kernel(const TParams p) {
   for (u32 i = tid; i < ((K * stride + 1u) >> 1); i += NT) l_r1[i] = 0xFFFFFFFFu;
   for (u32 k = tid; k < K; k += NT) l_longest[k] = 0;
   __syncthreads();
+  TL_MARK(1)
 #define WENT(k_, el_) ((el_) < stride ? (u32)l_writer[(k_) * stride + (el_)] : 0xFFFFu)   // 0xFFFF: nobody wrote it
 #define W_TXN(e_) ((e_) & 0x1FFFu)
 #define W_TYPE(e_) (((e_) >> 13) & 3u)
@@ -543,6 +551,7 @@ __global__ void __launch_bounds__(512) txn_check_lds_kernel(const TParams p) {
   }
   if (bad) VERDICT(2);
   LEAVE_IF_DECIDED();
+  TL_MARK(2)
 
   // ---- D: the reads of :ok transactions ----------------------------------------------------------------------------------------------------------
   for (u32 t = tid; t < n; t += NT) {
@@ -578,6 +587,7 @@ __global__ void __launch_bounds__(512) txn_check_lds_kernel(const TParams p) {
   }
   if (bad) VERDICT(2);
 
+  TL_MARK(3)
   // realtime order in closed form (see txn_check_kernel): wavefront 0, beside the other wavefronts' share of pass D
   if (wave == 0) {
     u64 carry = ~0ull;
@@ -596,6 +606,7 @@ __global__ void __launch_bounds__(512) txn_check_lds_kernel(const TParams p) {
     if (lane == 0) { sm[n] = NONE; smf[n] = n; }
   }
   LEAVE_IF_DECIDED();
+  TL_MARK(4)
 
   // ---- E: edges: pass 0 counts degrees, pass 1 fills the CSR of the dependency edges (realtime successors stay a range) -----------------------------
   u32 n_edges = 0;
@@ -676,6 +687,7 @@ __global__ void __launch_bounds__(512) txn_check_lds_kernel(const TParams p) {
 #undef W_TYPE
 #undef W_FIN
 
+  TL_MARK(5)
   // ---- F: acyclic?  Kahn's algorithm, 64 ready transactions per step; queue and realtime ranges where the writer table was --------------------------
   unsigned short *const l_queue = reinterpret_cast<unsigned short *>(l_r1);
   u32 *const l_rt = l_r1 + ((n + 1u) >> 1);   // first | last << 16
@@ -695,15 +707,21 @@ __global__ void __launch_bounds__(512) txn_check_lds_kernel(const TParams p) {
     tail += (u32)__popcll(zm);
   }
   t_wave_fence();
+  // A step takes up to 64 ready transactions; the graph is deep and narrow (the realtime order: a ready set is about as wide as the
+  // clients' concurrency), so the wavefront's lanes are split among the ready ones — G lanes each, a power of two — and a transaction's
+  // successors are taken G at a time: a step is one or two turns of the loop below instead of one per successor (78 % of a history's
+  // cycles before: profiles/r03w_txn_check_phases.txt).
   u32 head = 0;
   while (head < tail) {
     const u32 cnt = min(64u, tail - head);
-    const bool on = lane < cnt;
-    const u32 v = on ? (u32)l_queue[head + lane] : 0u;
+    const u32 gsh = cnt <= 1u ? 6u : 6u - (32u - (u32)__clz(cnt - 1u));   // log2 of the lanes per ready transaction: 64 >> ceil(log2(cnt))
+    const u32 ti = lane >> gsh, sub = lane & ((1u << gsh) - 1u), G = 1u << gsh;
+    const bool on = ti < cnt;
+    const u32 v = on ? (u32)l_queue[head + ti] : 0u;
     const u32 a1 = on ? h16_get(l_off, v) : 0u, a0 = on ? (v ? h16_get(l_off, v - 1u) : 0u) : 0u;   // (after pass 1 off[v] is the end of v's entries)
     const u32 rt = on ? l_rt[v] : 0u, r0 = rt & 0xFFFFu, r1 = rt >> 16;
     const u32 deg = (a1 - a0) + (r1 - r0);
-    for (u32 k = 0; __ballot(k < deg); k++) {
+    for (u32 k = sub; __ballot(k < deg); k += G) {
       bool push = false; u32 wv = 0;
       if (k < deg) { wv = k < a1 - a0 ? (u32)l_adj[a0 + k] : r0 + (k - (a1 - a0)); push = h16_sub(l_indeg, wv) == 1u; }
       const u64 pm = __ballot(push);
@@ -718,6 +736,11 @@ __global__ void __launch_bounds__(512) txn_check_lds_kernel(const TParams p) {
       res.lost_count = n_edges;   // edges of the dependency graph
       res.valid = flags ? 0u : (c_ok == 0 ? 2u : 1u);
     }
+#ifdef TC_PROF
+    TL_MARK(6)
+    for (int i = 0; i < 5; i++) res.stable_latency_ms[i] = tl[i];
+    res.never_read_count = tl[5]; res.duplicated_count = tl[6];
+#endif
     p.out[hist] = res;
   }
 #undef VERDICT
@@ -748,13 +771,14 @@ int grow_ws(msim_ctx *ctx, void **ws_buf, size_t *ws_cap, size_t need) {
 int txn_dev_run(msim_ctx *ctx, TParams tp, u32 n, u32 cm, const std::vector<msim_inst_meta> *hmeta, msim_check_result *h_out, hipStream_t st, u32 *n_host,
                 void **ws_buf, size_t *ws_cap) {
   const bool trace = (msim_dev_flags(ctx) & 0x1000u) != 0;   // developer: time the passes
-  // Which kernel takes the first pass.  Measured on cfg5, 32768 histories (profiles/r03b_cfg5_txn_check_*, r03k_cfg5_txn_check.txt):
-  // tables in an HBM workspace, one wavefront per history: 82 GB of HBM traffic, 130 ms (64 histories in flight per CU); tables in LDS:
-  // 22 GB, and 264 / 200 / 168 / 149 ms with 1 / 2 / 4 / 8 wavefronts per history — 78 KiB of LDS leave a CU two histories, and what a
-  // history's time goes to is the dependent payload loads of the streaming passes plus the passes only one wavefront can do (pairing,
-  // Kahn's queue).  The faster one stays the default; MSIM_DEV_FLAGS bit 13 (0x2000) selects the LDS kernel, MSIM_TXN_WG its threads
-  // per history (64 .. 512).
-  const bool hbm_only = (msim_dev_flags(ctx) & 0x2000u) == 0;
+  // Which kernel takes the first pass: the one with its tables in LDS, a workgroup of eight wavefronts per history.  Measured on cfg5,
+  // 32768 histories (profiles/r03b_cfg5_txn_check_*, r03k_cfg5_txn_check.txt, r03x_txn_check.txt): tables in an HBM workspace, one
+  // wavefront per history: 82 GB of HBM traffic, 130 ms (64 histories in flight per CU); tables in LDS (78 KiB: two histories per CU),
+  // 22 GB: 264 ms with one wavefront per history; 149 ms with the streaming passes spread over eight; 75 ms once Kahn's steps — 78 % of
+  // what was left: a ready set as wide as the clients' concurrency, one turn of a loop per successor — split the wavefront's lanes among
+  // the ready transactions.  MSIM_DEV_FLAGS bit 13 (0x2000) keeps every history on the HBM-table kernel (which stays the second pass
+  // for histories whose tables do not fit); MSIM_TXN_WG = threads per history (64 .. 512).
+  const bool hbm_only = (msim_dev_flags(ctx) & 0x2000u) != 0;
   static const u32 wg_threads = []() { const char *e = std::getenv("MSIM_TXN_WG"); u32 v = e ? (u32)std::atoi(e) : 512u; v = (v / 64u) * 64u; return v < 64u ? 64u : v > 512u ? 512u : v; }();
   const auto t0 = std::chrono::steady_clock::now();
   auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };

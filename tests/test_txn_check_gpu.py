@@ -35,7 +35,7 @@ def _same(dev, host, ctx):
     dict(node_count=3, rate=200, time_limit=15, latency=20, latency_dist="exponential", p_loss=0.05),            # timeouts: :info transactions
     dict(node_count=5, rate=60, time_limit=20, latency=10, key_count=3, max_txn_length=6, nemesis=["partition"], nemesis_interval=4),
 ])
-@pytest.mark.parametrize("flags", [0, 0x2000])   # the HBM-table kernel (default) / the LDS kernel, a workgroup per history
+@pytest.mark.parametrize("flags", [0, 0x2000])   # the LDS kernel, a workgroup per history (default) / the HBM-table kernel
 def test_device_pass_equals_host_analysis_on_engine_histories(lib, kw, flags):
     cfg = E.test_config("txn-list-append", seed=23, **kw)
     n = 64
