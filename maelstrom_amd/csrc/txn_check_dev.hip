@@ -389,7 +389,7 @@ __device__ __forceinline__ void t_wave_fence() {   // orders the LDS / workspace
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__global__ void __launch_bounds__(512) txn_check_lds_kernel(const TParams p) {
+__global__ void __launch_bounds__(1024) txn_check_lds_kernel(const TParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const u32 tid = threadIdx.x, NT = blockDim.x, lane = tid & 63u, wave = tid >> 6;
   const u32 hist = p.list ? p.list[p.first + blockIdx.x] : p.first + blockIdx.x;
@@ -771,15 +771,15 @@ int grow_ws(msim_ctx *ctx, void **ws_buf, size_t *ws_cap, size_t need) {
 int txn_dev_run(msim_ctx *ctx, TParams tp, u32 n, u32 cm, const std::vector<msim_inst_meta> *hmeta, msim_check_result *h_out, hipStream_t st, u32 *n_host,
                 void **ws_buf, size_t *ws_cap) {
   const bool trace = (msim_dev_flags(ctx) & 0x1000u) != 0;   // developer: time the passes
-  // Which kernel takes the first pass: the one with its tables in LDS, a workgroup of eight wavefronts per history.  Measured on cfg5,
+  // Which kernel takes the first pass: the one with its tables in LDS, a workgroup of sixteen wavefronts per history.  Measured on cfg5,
   // 32768 histories (profiles/r03b_cfg5_txn_check_*, r03k_cfg5_txn_check.txt, r03x_txn_check.txt): tables in an HBM workspace, one
   // wavefront per history: 82 GB of HBM traffic, 130 ms (64 histories in flight per CU); tables in LDS (78 KiB: two histories per CU),
   // 22 GB: 264 ms with one wavefront per history; 149 ms with the streaming passes spread over eight; 75 ms once Kahn's steps — 78 % of
   // what was left: a ready set as wide as the clients' concurrency, one turn of a loop per successor — split the wavefront's lanes among
   // the ready transactions.  MSIM_DEV_FLAGS bit 13 (0x2000) keeps every history on the HBM-table kernel (which stays the second pass
-  // for histories whose tables do not fit); MSIM_TXN_WG = threads per history (64 .. 512).
+  // for histories whose tables do not fit); MSIM_TXN_WG = threads per history (64 .. 1024, the default: 66 ms; 512: 75 ms).
   const bool hbm_only = (msim_dev_flags(ctx) & 0x2000u) != 0;
-  static const u32 wg_threads = []() { const char *e = std::getenv("MSIM_TXN_WG"); u32 v = e ? (u32)std::atoi(e) : 512u; v = (v / 64u) * 64u; return v < 64u ? 64u : v > 512u ? 512u : v; }();
+  static const u32 wg_threads = []() { const char *e = std::getenv("MSIM_TXN_WG"); u32 v = e ? (u32)std::atoi(e) : 1024u; v = (v / 64u) * 64u; return v < 64u ? 64u : v > 1024u ? 1024u : v; }();
   const auto t0 = std::chrono::steady_clock::now();
   auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
   const uint64_t budget = 6ull << 30;   // as many histories per launch as a few GB of workspace hold (every one of them has its own slice)
