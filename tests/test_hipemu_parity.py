@@ -1,0 +1,51 @@
+"""The kernel SOURCES on the host wavefront emulator (tools/hipemu: fibers per lane, cross-lane operations as rendezvous) against the
+oracle — bit for bit, on a machine without a GPU.  Test infrastructure on both sides: the emulator library is built from
+maelstrom_amd/csrc by tools/hipemu/build_emu.py with the host compiler and loaded through MSIM_LIB in a child process; the product
+library (hipcc, gfx950) is not involved and still refuses to run without a device.  One small case per kernel layout the round touched:
+the two-clusters-per-wavefront broadcast kernel (constant and random latency), the wide kernel with the nodes' sets in LDS and its
+lone-operation path, eight clusters per wavefront for both txn-list-append nodes, the list-append check's workgroup-per-history kernel."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "tools", "hipemu", "_build", "libmaelsim_emu.so")
+
+CASES = [
+    "duo25", "duo25exp",
+    "{'workload':'g-set','node_count':40,'rate':40,'time_limit':6,'latency':50,'latency_dist':'exponential','p_loss':0.05,'n':2}",
+    "{'workload':'broadcast','node_count':36,'rate':20,'time_limit':3,'latency':10,'topology':'tree3','n':1}",
+    "{'workload':'txn-list-append','bin':'multi-key-txn','node_count':5,'rate':60,'time_limit':5,'latency':5,'nemesis':['partition'],'nemesis_interval':2,'n':9}",
+    "{'workload':'txn-list-append','node_count':5,'rate':60,'time_limit':5,'latency':5,'nemesis':['partition'],'nemesis_interval':2,'n':9}",
+]
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    if shutil.which(os.environ.get("HIPEMU_CXX", "g++")) is None:
+        pytest.skip("no host C++ compiler for the emulator build")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "hipemu", "build_emu.py")], cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert os.path.exists(EMU)
+    return EMU
+
+
+@pytest.mark.timeout(1800)
+def test_kernel_sources_on_the_emulator_equal_the_oracle(emu_lib):
+    env = dict(os.environ, MSIM_LIB=emu_lib, HIPEMU_DIVERGENT="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "emu_compare.py")] + CASES, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count(": OK") == len(CASES), r.stdout
+
+
+@pytest.mark.timeout(1800)
+def test_list_append_check_kernels_on_the_emulator_equal_the_host_analysis(emu_lib):
+    """tests/test_txn_check_gpu.py's hand-made anomalies and corrupted histories through the emulated device pass (both kernels)."""
+    for flags in ("0", "0x2000"):
+        env = dict(os.environ, MSIM_LIB=emu_lib, HIPEMU_DIVERGENT="1", MSIM_DEV_FLAGS=flags, MSIM_TXN_WG="256")
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", os.path.join(ROOT, "tests", "test_txn_check_gpu.py"), "-k", "hand_made"],
+                           cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
