@@ -41,6 +41,13 @@ __constant__ u32 duo_log2_q24[257];
 
 enum { DK_PLAIN = 0, DK_BCAST = 1, DK_READ = 2, DK_READ_FINAL = 3, DK_INIT = 4, DK_TOPO = 5 };  // kind of an envelope (bits 24-26)
 constexpr u32 DUO_STAGE_ROWS = 128u;
+// History rows go from their lanes to HBM unstaged (two 16-byte rows per operation; the L2 merges them into lines: WRITE_SIZE stays at the
+// algorithmic bytes): 9.00 -> 8.90 ms per 4096 clusters against staging 64 rows in LDS (-DDUO_STAGED_ROWS keeps that variant for A/B runs).
+#ifdef DUO_STAGED_ROWS
+constexpr bool DUO_DIRECT = false;
+#else
+constexpr bool DUO_DIRECT = true;
+#endif
 
 struct DuoParams {
   KParams k;
@@ -612,7 +619,7 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
       if (ovf) { flags |= MSIM_FLAG_ROWS_OVERFLOW; alive = 0; }
       const u64 tns = (u64)T * 1000ull;
       const u32 tlo = (u32)tns, thi = (u32)(tns >> 32);
-      if (RND) {   // the bags of the random-latency layout take the LDS a staging area would need: rows go straight to HBM
+      if (RND || DUO_DIRECT) {   // the bags of the random-latency layout take the LDS a staging area would need: rows go straight to HBM
         if (inv_row != 0 && !ovf) reinterpret_cast<uint4 *>(g_rows)[n_rows + __popc(imask & lt)] = make_uint4(tlo, thi, inv_packed, inv_value);
         if (cmp_row != 0 && !ovf) reinterpret_cast<uint4 *>(g_rows)[n_rows + ni + __popc(cmask & lt)] = make_uint4(tlo, thi | (cmp_len << 16), cmp_packed, cmp_value);
       } else {
@@ -620,7 +627,7 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
         if (cmp_row != 0 && !ovf) stage[(n_rows + ni + __popc(cmask & lt)) % DUO_STAGE_ROWS] = make_uint4(tlo, thi | (cmp_len << 16), cmp_packed, cmp_value);
       }
       const u32 new_n = ovf ? n_rows : n_rows + nr;
-      const bool flush = !RND && (new_n >> 6) != (n_rows >> 6);   // a 64-row block completed (at most one per round: nr <= 64)
+      const bool flush = !RND && !DUO_DIRECT && (new_n >> 6) != (n_rows >> 6);   // a 64-row block completed (at most one per round: nr <= 64)
       if (__ballot(flush)) {
         wave_lds_fence();
         if (flush) {
@@ -685,8 +692,8 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
   __syncthreads();
   {
     const u32 g0 = (n_rows >> 6) * 64u + i;
-    if (!RND && real && g0 < n_rows) reinterpret_cast<uint4 *>(g_rows)[g0] = stage[g0 % DUO_STAGE_ROWS];
-    if (!RND && real && g0 + 32u < n_rows) reinterpret_cast<uint4 *>(g_rows)[g0 + 32u] = stage[(g0 + 32u) % DUO_STAGE_ROWS];
+    if (!RND && !DUO_DIRECT && real && g0 < n_rows) reinterpret_cast<uint4 *>(g_rows)[g0] = stage[g0 % DUO_STAGE_ROWS];
+    if (!RND && !DUO_DIRECT && real && g0 + 32u < n_rows) reinterpret_cast<uint4 *>(g_rows)[g0 + 32u] = stage[(g0 + 32u) % DUO_STAGE_ROWS];
   }
   const u32 sc_cl = wave_incl_scan(n_cl), sc_arr = wave_incl_scan(n_arr), sc_rsv = wave_incl_scan(n_rsv);
   const u32 lo_cl = rdlane(sc_cl, 31), lo_arr = rdlane(sc_arr, 31), lo_rsv = rdlane(sc_rsv, 31);
