@@ -777,7 +777,8 @@ hipError_t msim_launch_duo(const KParams &kp, uint32_t n, hipStream_t st) {
   // wavefronts on a CU (20 KiB each: BASELINE's 4096 clusters are 2048 wavefronts on 256 CUs — a ninth would run alone in a second
   // pass), at least 8 entries per node; what does not fit goes to the HBM spill area.
   const size_t seen_bytes = (((size_t)kp.N * (kp.W | 1u) + 32) * 4 + 15) & ~(size_t)15;   // odd stride between the nodes' sets
-  const size_t fixed = seen_bytes + (rnd ? 0 : DUO_STAGE_ROWS * 16);
+  const size_t stage_bytes = (rnd || DUO_DIRECT) ? 0 : DUO_STAGE_ROWS * 16;   // (rows are staged only in the -DDUO_STAGED_ROWS build)
+  const size_t fixed = seen_bytes + stage_bytes;
   const size_t per_entry = rnd ? 0 : (size_t)32 * (lat0 ? 4 : 8);   // (RND: bags of a fixed 16 entries)
   const size_t budget = (20 * 1024 - (rnd ? 257 * 4 + 16 : 0)) / 2;
   uint32_t R = rnd ? 16 : 8;
@@ -788,7 +789,7 @@ hipError_t msim_launch_duo(const KParams &kp, uint32_t n, hipStream_t st) {
   // the spill area is spill_capacity x 16 bytes per node: 8-byte ring entries (constant latency) or 12-byte bag entries (RND)
   if ((size_t)dp.S * (rnd ? 12 : 8) > (size_t)c.spill_capacity * 16) return MSIM_LAYOUT_DOES_NOT_FIT;
   if (rnd) MSIM_UPLOAD_ONCE(duo_log2_q24, msim_log2_q24, sizeof(msim_log2_q24));   // (1 KiB, once per device)
-  size_t off = rnd ? 0 : DUO_STAGE_ROWS * 16;
+  size_t off = stage_bytes;
   dp.off_ring = (u32)off; off += rnd ? (size_t)(kp.N + 1) * 16 * 8 : (size_t)32 * R * (lat0 ? 4 : 8);
   dp.off_seq = (u32)off; if (rnd) off += (((size_t)(kp.N + 1) * 16 * 2) + 15) & ~(size_t)15;
   dp.R = R;
