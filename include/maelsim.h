@@ -327,6 +327,13 @@ enum { MSIM_KAFKA_LOST_WRITE = 1u, MSIM_KAFKA_NONMONOTONIC_POLL = 2u, MSIM_KAFKA
        MSIM_KAFKA_INT_NONMONOTONIC_POLL = 16u, MSIM_KAFKA_INT_POLL_SKIP = 32u, MSIM_KAFKA_INCONSISTENT_OFFSETS = 64u,
        MSIM_KAFKA_DUPLICATE = 128u, MSIM_KAFKA_ABORTED_READ = 256u, MSIM_KAFKA_MALFORMED = 512u /* a row that does not decode */ };
 int msim_check_kafka_rows(const msim_op *rows, uint32_t n_rows, const uint32_t *payload, uint32_t n_words, msim_check_result *out);
+/* kafka: `n_histories` histories given on the host (rows / payload words of history i at row_offsets[i] / payload_offsets[i]) as msim_check
+ * does for the histories of a run: the device proves a history free of every anomaly above (csrc/kafka_check_dev.hip: the tables of the
+ * checker in LDS, one workgroup per history), msim_check_kafka_rows' checker classifies the others; `concurrency` = the test's worker
+ * threads (process mod concurrency is the worker); *n_host (may be null) = how many went to the host.  out[i] = what
+ * msim_check_kafka_rows gives for history i. */
+int msim_check_kafka_batch(int device, const msim_op *rows, const uint64_t *row_offsets, const uint32_t *payload, const uint64_t *payload_offsets,
+                           uint32_t n_histories, uint32_t concurrency, msim_check_result *out, uint32_t *n_host);
 
 /* unique-ids: checks `n_histories` histories given on the host — history i in the slab rows + i * max_rows, n_rows[i] rows used —
  * with the device checker of msim_check ([upstream] jepsen.checker/unique-ids); out[i] is what msim_check_unique_rows gives. */

@@ -40,7 +40,7 @@ MASK_WORDS = 4
 
 EXPORTS = [
     "msim_abi_version", "msim_device_count", "msim_config_defaults", "msim_config_finalize", "msim_create",
-    "msim_run", "msim_run_async", "msim_check", "msim_check_host_rechecks", "msim_set_dev_flags", "msim_check_lin_kv_batch", "msim_check_txn_batch", "msim_check_unique_batch", "msim_check_pn_batch", "msim_check_set_full_batch", "msim_check_rw_batch", "msim_check_kafka_rows", "msim_check_lin_kv_rows", "msim_check_txn_rows", "msim_check_rw_rows", "msim_proscribed_anomalies", "msim_violated_anomalies", "msim_check_pn_rows", "msim_check_unique_rows", "msim_history_edn_rows", "msim_fetch", "msim_fetch_begin", "msim_history", "msim_net_stats_get", "msim_journal", "msim_meta",
+    "msim_run", "msim_run_async", "msim_check", "msim_check_host_rechecks", "msim_set_dev_flags", "msim_check_lin_kv_batch", "msim_check_txn_batch", "msim_check_unique_batch", "msim_check_pn_batch", "msim_check_set_full_batch", "msim_check_rw_batch", "msim_check_kafka_rows", "msim_check_kafka_batch", "msim_check_lin_kv_rows", "msim_check_txn_rows", "msim_check_rw_rows", "msim_proscribed_anomalies", "msim_violated_anomalies", "msim_check_pn_rows", "msim_check_unique_rows", "msim_history_edn_rows", "msim_fetch", "msim_fetch_begin", "msim_history", "msim_net_stats_get", "msim_journal", "msim_meta",
     "msim_check_results", "msim_device_buffers_get", "msim_last_kernel_ms", "msim_get_config",
     "msim_selftest_wave", "msim_last_error", "msim_destroy",
     "msim_comm_unique_id", "msim_comm_init", "msim_gather", "msim_journal_fressian_rows",
@@ -153,6 +153,8 @@ def load():
     lib.msim_check_set_full_batch.restype = C.c_int
     lib.msim_check_rw_batch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
     lib.msim_check_rw_batch.restype = C.c_int
+    lib.msim_check_kafka_batch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    lib.msim_check_kafka_batch.restype = C.c_int
     lib.msim_check_kafka_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, P(CheckResult)]
     lib.msim_check_kafka_rows.restype = C.c_int
     lib.msim_history_edn_rows.argtypes = [P(Config), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_char_p, C.c_size_t, P(C.c_size_t)]

@@ -1127,7 +1127,10 @@ extern "C" int msim_check(msim_ctx *ctx) {
     return (msim_dev_flags(ctx) & 0x800u) ?   // bit 11: keep the check on the host cores
            msim_check_txn_host(ctx) : msim_check_rw_device(ctx);
   }
-  if (ctx->cfg.workload == MSIM_WL_KAFKA) return msim_check_kafka_host(ctx);
+  if (ctx->cfg.workload == MSIM_WL_KAFKA) {
+    return (msim_dev_flags(ctx) & 0x800u) ?   // bit 11: keep the check on the host cores
+           msim_check_kafka_host(ctx) : msim_check_kafka_device(ctx);
+  }
   if (ctx->cfg.workload == MSIM_WL_PN_COUNTER || ctx->cfg.workload == MSIM_WL_G_COUNTER) {
     return (msim_dev_flags(ctx) & 0x800u) ?   // bit 11: keep the check on the host cores
            msim_check_pn_host(ctx) : msim_check_pn_device(ctx);

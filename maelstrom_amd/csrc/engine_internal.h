@@ -100,6 +100,8 @@ int msim_check_txn_device(msim_ctx *ctx);
 int msim_check_rw_device(msim_ctx *ctx);
 // kafka_check.cpp (host)
 int msim_check_kafka_host(msim_ctx *ctx);
+// kafka_check_dev.hip (device pass + host checker for what it cannot prove clean)
+int msim_check_kafka_device(msim_ctx *ctx);
 // unique_check_dev.hip, pn_check_dev.hip
 int msim_check_unique_device(msim_ctx *ctx);
 int msim_check_pn_device(msim_ctx *ctx);

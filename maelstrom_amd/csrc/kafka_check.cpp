@@ -165,6 +165,12 @@ void check_kafka(const msim_op *rows, uint32_t n_rows, const uint32_t *payload, 
 
 }  // namespace
 
+// one history on the calling thread (kafka_check_dev.hip: what the device pass could not prove clean)
+void msim_kafka_check_instance_host(const msim_op *rows, uint32_t n_rows, const uint32_t *payload, uint32_t n_words, uint32_t flags, msim_check_result *out) {
+  std::vector<Tables> t(1);
+  check_kafka(rows, n_rows, payload, n_words, flags, out, t[0]);
+}
+
 extern "C" int msim_check_kafka_rows(const msim_op *rows, uint32_t n_rows, const uint32_t *payload, uint32_t n_words, msim_check_result *out) {
   if ((!rows && n_rows) || !out || (!payload && n_words)) return MSIM_E_INVALID;
   std::vector<Tables> t(1);

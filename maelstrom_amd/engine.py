@@ -648,6 +648,28 @@ def check_rw_batch(histories, consistency_model="read-committed", device=0):
     return out, n_host.value
 
 
+
+def check_kafka_batch(histories, concurrency, device=0):
+    """kafka: several histories, each (rows, payload), through the device pass behind Engine.check() (csrc/kafka_check_dev.hip) with the
+    host checker for what it cannot prove clean (msim_check_kafka_batch); `concurrency` = the worker threads of the test.  Returns
+    (CHECK_DT records, how many histories went to the host)."""
+    rs = [np.ascontiguousarray(h[0]) for h in histories]
+    ps = [np.ascontiguousarray(h[1], dtype=np.uint32) for h in histories]
+    ro = np.zeros(len(rs) + 1, dtype=np.uint64); ro[1:] = np.cumsum([len(x) for x in rs])
+    po = np.zeros(len(ps) + 1, dtype=np.uint64); po[1:] = np.cumsum([len(x) for x in ps])
+    rows = np.concatenate(rs) if rs else np.zeros(0, dtype=OP_DT)
+    pay = np.concatenate(ps) if ps else np.zeros(0, dtype=np.uint32)
+    if len(pay) == 0:
+        pay = np.zeros(1, dtype=np.uint32)
+    out = np.zeros(len(rs), dtype=CHECK_DT)
+    n_host = C.c_uint32()
+    rc = A.load().msim_check_kafka_batch(device, rows.ctypes.data, ro.ctypes.data, pay.ctypes.data, po.ctypes.data, len(rs), concurrency,
+                                         out.ctypes.data, C.byref(n_host))
+    if rc:
+        raise EngineError(f"msim_check_kafka_batch: {rc}")
+    return out, n_host.value
+
+
 def journal_fressian(cfg, events, payload):
     """One instance's net journal as the bytes of a net-journal/<stripe>.fressian file (msim_journal_fressian_rows, csrc/fressian.cpp):
     what maelstrom.net.journal writes (journal.clj:55-141) and maelstrom.net.checker / net.viz read."""

@@ -3,7 +3,7 @@ oracle — bit for bit, on a machine without a GPU.  Test infrastructure on both
 maelstrom_amd/csrc by tools/hipemu/build_emu.py with the host compiler and loaded through MSIM_LIB in a child process; the product
 library (hipcc, gfx950) is not involved and still refuses to run without a device.  One small case per kernel layout the round touched:
 the two-clusters-per-wavefront broadcast kernel (constant and random latency), the wide kernel with the nodes' sets in LDS and its
-lone-operation path, eight clusters per wavefront for both txn-list-append nodes, the list-append check's workgroup-per-history kernel."""
+lone-operation path, eight clusters per wavefront for both txn-list-append nodes, the list-append check's workgroup-per-history kernel, the kafka checker's device pass."""
 import os
 import shutil
 import subprocess
@@ -49,3 +49,13 @@ def test_list_append_check_kernels_on_the_emulator_equal_the_host_analysis(emu_l
         r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", os.path.join(ROOT, "tests", "test_txn_check_gpu.py"), "-k", "hand_made"],
                            cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.timeout(1800)
+def test_kafka_check_kernel_on_the_emulator_equals_the_host_checker(emu_lib):
+    """tests/test_kafka_check_gpu.py (clean oracle histories, the anomalies by hand, corrupted histories, the engine's check) through the
+    emulated device pass of csrc/kafka_check_dev.hip."""
+    env = dict(os.environ, MSIM_LIB=emu_lib, HIPEMU_DIVERGENT="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", os.path.join(ROOT, "tests", "test_kafka_check_gpu.py")],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
