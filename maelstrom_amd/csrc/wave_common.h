@@ -172,6 +172,10 @@ hipError_t msim_launch_raft4(const KParams &kp, uint32_t n, hipStream_t st);
 bool msim_txn8_eligible(const msim_config &c);
 uint64_t msim_txn8_extra_scratch_words(const msim_config &c);
 hipError_t msim_launch_txn8(const KParams &kp, uint32_t n, hipStream_t st);
+// hat8.hip: sixteen / eight txn-rw-register clusters per wavefront (the highly-available-transactions node, clusters of <= 4 / 8 lanes)
+bool msim_hat8_eligible(const msim_config &c);
+uint64_t msim_hat8_extra_scratch_words(const msim_config &c);
+hipError_t msim_launch_hat8(const KParams &kp, uint32_t n, hipStream_t st);
 // mk8.hip: eight clusters of the multi-key transactional node per wavefront (n <= 6 nodes + lin-kv + lww-kv in an 8-lane group)
 bool msim_mk8_eligible(const msim_config &c);
 uint64_t msim_mk8_extra_scratch_words(const msim_config &c);

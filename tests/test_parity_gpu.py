@@ -316,12 +316,38 @@ def test_txn_list_append_journal_parity(lib):
     dict(key_count=3, max_txn_length=8, max_writes_per_key=40, rate=300),
 ])
 def test_txn_rw_register_parity(lib, kw):
-    """workload/txn_rw_register.clj over demo/clojure/txn_rw_register_hat.clj (hat_kernel<>)."""
+    """workload/txn_rw_register.clj over demo/clojure/txn_rw_register_hat.clj.  Both layouts: eight clusters per wavefront (hat8_kernel<>,
+    csrc/hat8.hip: what the engine picks for batches of 8192 clusters and more with --max-txn-length <= 4 and the journal off — asked for
+    here with MSIM_DEV_FLAGS bit 10 —, also in its 4-lane groups, bit 15) and one cluster per wavefront (hat_kernel<>: everything else)."""
     base = dict(node_count=2, rate=100, time_limit=8, seed=101)
     base.update(kw)
     cfg = E.test_config("txn-rw-register", **base)
-    ora = _compare(cfg, 0, 6)
+    ora = _compare(cfg, 0, 11, dev_flags=0x400)   # (11 clusters: a full wavefront of eight and a partial one)
     assert (ora.stats["servers_send"] > 0).all()   # replicate / replicate_ack traffic did flow
+    if cfg.n_nodes <= 4:
+        _compare(cfg, 0, 19, dev_flags=0x8400)
+    _compare(cfg, 0, 4)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(node_count=4, rate=200, time_limit=8, latency=150, latency_dist="exponential", p_loss=0.1, nemesis=["partition"], nemesis_interval=3),   # a full 4-lane group; timeouts, spilled queues, stale replies
+    dict(node_count=8, rate=300, time_limit=6, latency=5, latency_dist="uniform", nemesis=["partition"], nemesis_interval=2),                      # a full 8-lane group; relays; long lists behind the partitions
+    dict(node_count=2, rate=400, time_limit=10, latency=2, nemesis=["partition"], nemesis_interval=5, key_count=2),                                 # hundreds of unreplicated txns per tick
+    dict(node_count=3, rate=100, time_limit=5, latency=20, inbox_capacity=2),                                                                      # every queue spills
+])
+def test_txn_rw_register_packed_layout_parity(lib, kw):
+    """Shapes that stress what is specific to hat8_kernel<>: both group sizes filled, queues beyond the LDS slots, the tick's list built
+    by the lanes of a group."""
+    cfg = E.test_config("txn-rw-register", seed=23, **kw)
+    _compare(cfg, 0, 17, dev_flags=0x400)
+    if cfg.n_nodes <= 4:
+        _compare(cfg, 0, 17, dev_flags=0x8400)
+
+
+def test_txn_rw_register_large_batch_takes_the_packed_layout(lib):
+    """8192 clusters and more run eight per wavefront without being asked to (msim_launch_hat8): every one of 8200 identical to the oracle."""
+    cfg = E.test_config("txn-rw-register", node_count=2, rate=100, time_limit=2, nemesis=["partition"], nemesis_interval=1, seed=29)
+    _compare(cfg, 0, 8200)
 
 
 @pytest.mark.parametrize("kw", [
