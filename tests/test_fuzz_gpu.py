@@ -118,6 +118,36 @@ def test_random_rw_register_options_engine_equals_oracle(lib, case):
         E.Engine(cfg).close()
     except E.EngineError as e:
         pytest.skip(str(e))
+    first = rng.randrange(1 << 20)
+    _compare(cfg, first, N_INST)
+    _compare(cfg, first, N_INST, dev_flags=0x400)       # eight clusters per wavefront where csrc/hat8.hip applies (else the same kernel again)
+    if cfg.n_nodes <= 4:
+        _compare(cfg, first, N_INST, dev_flags=0x8400)  # its 4-lane groups
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("MSIM_FUZZ_CASES", "16"))))
+def test_random_kafka_options_engine_equals_oracle(lib, case):
+    """The same sweep for the kafka workload (logs in lin-kv chunks, committed offsets: csrc/sim_kernel_kafka.inc against oracle/kafka_nodes.inc)."""
+    rng = random.Random(0xCAFCA + case)
+    n = rng.choice([1, 2, 3, 5, 7])
+    kw = dict(node_count=n, rate=rng.choice([20, 60, 150, 400]), time_limit=rng.choice([3, 6, 10]), seed=rng.randrange(1 << 40),
+              key_count=rng.choice([1, 2, 4, 8]), max_writes_per_key=rng.choice([8, 40, 200, 1024]))
+    # a test has at most 8 keys (DESIGN.md §2.4b): a key retires after max-writes-per-key sends, so keep retirements below 8 - key-count
+    sends = kw["rate"] * kw["time_limit"]
+    kw["max_writes_per_key"] = min(2046, max(kw["max_writes_per_key"], sends // max(1, 8 - kw["key_count"]) + 8 if kw["key_count"] < 8 else sends + 8))
+    lat = rng.choice([0, 1, 5, 20, 120])
+    kw.update(latency=lat, latency_dist=rng.choice(["constant", "uniform", "exponential"]) if lat else "constant")
+    if rng.random() < 0.25:
+        kw["p_loss"] = rng.choice([0.02, 0.1])
+    if rng.random() < 0.4 and n >= 3:
+        kw.update(nemesis=["partition"], nemesis_interval=rng.choice([1, 3]))
+    if rng.random() < 0.2:
+        kw["journal_capacity"] = 1000000
+    try:
+        cfg = E.test_config("kafka", **kw)
+        E.Engine(cfg).close()
+    except E.EngineError as e:
+        pytest.skip(str(e))
     _compare(cfg, rng.randrange(1 << 20), N_INST)
 
 
