@@ -197,6 +197,10 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
   // holds draw dc_base + i, the scheduler fetches the one it needs with two ds_bpermute (mix64's three 64-bit multiplications cost a
   // round of the scheduler a quarter of its cycles when every lane computed the same draw)
   u32 dc_base = 0; u64 dc = draw64(key, S_GEN, (u64)i);
+  // RND: the same for the messages' latency draws (stream S_LATENCY, counter = message id, net.clj:178-187): a gossip round sends 1.3
+  // messages on average, and every lane of the wavefront computed a draw (mix64, the logarithm) for them — a third of the round's vector
+  // instructions.  Lane i of a cluster holds the latency (ms) of message id lc_base + i; DUO_RND_IDS keeps the block under the round's ids.
+  u32 lc_base = 0xFFFFFFC0u, lc = 0; bool lc_all = false;   // (no block yet: the first round with a send draws one)
 
   // Two LDS reads are kept one round ahead of their use, so that a round's dependent chain holds one LDS round trip
   // (the ds_bpermute exchange) instead of three:
@@ -345,12 +349,14 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
   // z = (x & 0x803F0000) ^ (0x80000000 | me << 16) is > 0 exactly then (negative: not sending; 0: sending, skipping me).
   // RND: the message's id = the sender's first id of the round + the rank of this node in the sender's fan-out (ascending
   // destination, net.clj:197); its latency is drawn from the id (net.clj:178-187: uniform int in [0, 2 mean) or floor(mean * -ln u))
+#define DUO_LAT_MS(r_) (lat_uniform ? scale32((r_), 2u * lat_mean) : (u32)(((u64)lat_mean * duo_neg_ln_q16((r_), log2_tab)) >> 16))
 #define DUO_RND_DEADLINE(x_, base_, fanadj_, dl_) do {                                                                    \
     const u32 rd_src = ((x_) >> 16) & 63u;                                                                                \
     const u32 rd_fan = dp.echoback ? (fanadj_) : ((fanadj_) & ~(rd_src < 32u ? (1u << rd_src) : 0u));                      \
     const u32 rd_id = (base_) + __popc(rd_fan & lt);                                                                      \
-    const u32 rd_r = draw32(key, S_LATENCY, rd_id);                                                                       \
-    const u32 rd_ms = lat_uniform ? scale32(rd_r, 2u * lat_mean) : (u32)(((u64)lat_mean * duo_neg_ln_q16(rd_r, log2_tab)) >> 16); \
+    u32 rd_ms;                                                                                                            \
+    if (lc_all) rd_ms = bperm(hbase4 + (((rd_id - lc_base) & 31u) << 2), lc);   /* the usual round: the draw is in the cluster's block */ \
+    else rd_ms = DUO_LAT_MS(draw32(key, S_LATENCY, rd_id));                                                               \
     dl_ = T + rd_ms * 1000u;                                                                                              \
   } while (0)
 #define DUO_ARRIVALS(pub_) do {                                                                                           \
@@ -427,7 +433,13 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
     const u32 id_incl = scan32(id_cnt);                                                                                   \
     pbase = next_id + id_incl - id_cnt;                                                                                   \
     const u32 id_lo = rdlane(id_incl, 31), id_up = rdlane(id_incl, 63);                                                   \
+    const u32 id_first = next_id;                                                                                         \
     next_id += hi ? id_up : id_lo;                                                                                        \
+    /* the latencies of the round's ids come from the cluster's block of 32 (lane i holds the one of id lc_base + i): a block that \
+       does not reach the round's last id is drawn again from the round's first id on; a round of more than 32 sends draws its own */ \
+    const bool id_rf = next_id - lc_base > 32u;                                                                           \
+    if (__ballot(id_rf)) { const u32 id_nl = DUO_LAT_MS(draw32(key, S_LATENCY, id_first + i)); lc = id_rf ? id_nl : lc; lc_base = id_rf ? id_first : lc_base; } \
+    lc_all = !__ballot(next_id - lc_base > 32u);                                                                          \
   } while (0)
 
 #ifdef DUO_PROF   // developer build (tools/duo_prof.sh): wave-round counts and cycles of the two round bodies -> meta
