@@ -9,7 +9,9 @@
 // NEEDS_HOST and the host checker classifies it (kafka_dev_run below): never approximated.
 //
 // Layout.  The tables of kafka_check.cpp (the key's log as observed, where each message was seen, polled / acknowledged / failed
-// flags) live in LDS, `T` entries per key (the configuration bounds offsets and messages by max-writes-per-key):
+// flags) live in LDS, `T` entries per key (the configuration bounds offsets and messages by max-writes-per-key; a first pass over
+// the launch's histories finds the highest one they name, kafka_bound_kernel: the bench shape needs 288 of the 1056 its configuration
+// allows, 27 KB of LDS per history instead of 77):
 //   pass 1  the workgroup's threads stride over the rows: every :ok send and every pair of every :ok poll is one observation — a
 //           compare-and-swap on the log entry and one on the message's home, an atomic OR for the flags, an atomic max for the
 //           highest polled offset of the key;
@@ -227,10 +229,53 @@ __global__ void __launch_bounds__(256) kafka_check_kernel(const KCParams p) {
 #undef GETBIT
 }
 
+// The highest offset / message value any :ok send or poll of the launch names: sizes the tables (most tests use a fraction of what
+// max-writes-per-key allows, and the LDS a history's tables take decides how many histories a CU works on at once).
+__global__ void __launch_bounds__(256) kafka_bound_kernel(const KCParams p, u32 *bound) {
+  const u32 tid = threadIdx.x, hist = blockIdx.x;
+  const uint4 *const r = reinterpret_cast<const uint4 *>(p.rows) + (p.row_off ? p.row_off[hist] : (u64)hist * p.max_rows);
+  const u32 *const pay = p.payload + (p.pay_off ? p.pay_off[hist] : (u64)hist * p.max_pay);
+  const u32 n = p.meta ? p.meta[hist].n_rows : (u32)(p.row_off[hist + 1] - p.row_off[hist]);
+  const u32 n_words = p.meta ? p.meta[hist].n_payload_words : (u32)(p.pay_off[hist + 1] - p.pay_off[hist]);
+  u32 hi = 0;
+  for (u32 idx = tid; idx < n; idx += NT) {
+    const uint4 row = r[idx];
+    const u32 type = row.z & 3u, f = (row.z >> 2) & 31u;
+    if ((row.z >> 12) == MSIM_PROCESS_NEMESIS || type == MSIM_T_INVOKE) continue;
+    if (f == MSIM_F_SEND) { hi = max(hi, (row.w >> 6) & 0x7FFu); if (type == MSIM_T_OK && (row.w >> 17) != 0x7FFu) hi = max(hi, row.w >> 17); }
+    else if (f == MSIM_F_POLL && type == MSIM_T_OK) {
+      const u32 len = row.y >> 16;
+      if (len == 0 || (u64)row.w + len > n_words) continue;
+      const u32 *const w = pay + row.w;
+      for (u32 q = 0; q < len;) {
+        const u32 h = w[q++], cnt = (h >> 8) & 0xFFu, o0 = h >> 16;
+        if (q + (cnt + 1) / 2 > len) break;
+        if (cnt) hi = max(hi, o0 + cnt - 1u);
+        for (u32 e = 0; e < cnt; e++) hi = max(hi, (w[q + e / 2] >> (16 * (e & 1))) & 0xFFFFu);
+        q += (cnt + 1) / 2;
+      }
+    }
+  }
+  for (int o = 32; o; o >>= 1) hi = max(hi, (u32)__shfl_xor((int)hi, o));
+  if ((tid & 63u) == 0 && hi) atomicMax(bound, hi);
+}
+
 int kafka_dev_run(msim_ctx *ctx, KCParams kp, u32 n, const std::vector<msim_inst_meta> *hmeta, msim_check_result *h_out, hipStream_t st, u32 *n_host) {
   const bool trace = (msim_dev_flags(ctx) & 0x1000u) != 0;   // developer: time the passes
   const auto t0 = std::chrono::steady_clock::now();
   auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+  {   // tables no larger than the launch's histories need (kp.T: what the configuration / the checker's own bound allows)
+    u32 *d_bound = nullptr, h_bound = 0;
+    MSIM_HIP_TRY(ctx, hipMalloc(&d_bound, 4));
+    hipError_t e = hipMemsetAsync(d_bound, 0, 4, st);
+    if (e == hipSuccess) { hipLaunchKernelGGL(kafka_bound_kernel, dim3(n), dim3(NT), 0, st, kp, d_bound); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_bound, d_bound, 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d_bound);
+    MSIM_HIP_TRY(ctx, e);
+    const u32 t = ((h_bound + 1u + 31u) & ~31u);
+    if (t < kp.T) kp.T = t < 32u ? 32u : t;
+  }
   const size_t lds = kafka_lds_bytes(kp.T);
   if (lds > 64 * 1024) MSIM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&kafka_check_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kafka_check_kernel, dim3(n), dim3(NT), lds, st, kp);

@@ -225,18 +225,21 @@ def test_unique_ids_device_checker_equals_host(lib):
     fields = ("valid", "attempt_count", "duplicated_count", "op_count", "ok_count", "fail_count", "info_count")
     cfg = E.test_config("unique-ids", node_count=3, rate=500, time_limit=6, latency=5, nemesis=["partition"], nemesis_interval=2, seed=12)
     n = 12
-    with E.Engine(cfg) as eng:
-        eng.run(0, n)
-        eng.check()
-        res = eng.check_results()
-        eng.fetch()
-        hs = [eng.raw_history(i)[0].copy() for i in range(n)]
-    for i in range(n):
-        h = host(hs[i])
-        for f in fields:
-            assert int(res[i][f]) == int(getattr(h, f)), (i, f)
-        assert [int(x) for x in res[i]["stable_latency_ms"][:2]] == [int(h.stable_latency_ms[0]), int(h.stable_latency_ms[1])]
-    assert (res["valid"] == 1).all() and (res["ok_count"] > 100).all()
+    for flags in (0, 0x2000):   # the table of a history in LDS (a workgroup per history; the default where it fits) / in HBM workspace
+        with E.Engine(cfg) as eng:
+            if flags:
+                eng.set_dev_flags(flags)
+            eng.run(0, n)
+            eng.check()
+            res = eng.check_results().copy()
+            eng.fetch()
+            hs = [eng.raw_history(i)[0].copy() for i in range(n)]
+        for i in range(n):
+            h = host(hs[i])
+            for f in fields:
+                assert int(res[i][f]) == int(getattr(h, f)), (i, f)
+            assert [int(x) for x in res[i]["stable_latency_ms"][:2]] == [int(h.stable_latency_ms[0]), int(h.stable_latency_ms[1])]
+        assert (res["valid"] == 1).all() and (res["ok_count"] > 100).all()
     rng = np.random.default_rng(2)
     bad = []
     for k, rows in enumerate(hs):
