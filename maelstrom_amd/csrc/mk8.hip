@@ -28,10 +28,16 @@ namespace {
 __constant__ u32 m8_log2_q24[257];
 
 constexpr u32 GS = 8u;            // lanes per cluster
-constexpr u32 RQ = 8u;            // LDS envelopes per node / service queue (the services take every RPC of the cluster: a scan of spilled envelopes is a round trip per batch)
+#ifndef M8_RQ
+#define M8_RQ 8u
+#endif
+#ifndef M8_SL_N
+#define M8_SL_N 1u
+#endif
+constexpr u32 RQ = M8_RQ;            // LDS envelopes per node / service queue (the services take every RPC of the cluster: a scan of spilled envelopes is a round trip per batch)
 constexpr u32 CQ = 1u;            // LDS envelopes per client inbox
 constexpr u32 M8_SLOTS = 8u;      // transactions in flight per node (the oracle's limit) ...
-constexpr u32 M8_SL = 1u;         // ... of which in LDS (a second one only while a client has timed out; the HBM slots lie where mk_kernel<> keeps its own)
+constexpr u32 M8_SL = M8_SL_N;         // ... of which in LDS (a second one only while a client has timed out; the HBM slots lie where mk_kernel<> keeps its own)
 constexpr u32 M8_CLIENT_CAP = 32u;
 constexpr u32 KEYS = 4u;          // distinct keys per transaction (--max-txn-length <= 4)
 constexpr u32 MKW = 10u + 9u * KEYS;
