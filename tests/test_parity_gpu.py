@@ -50,6 +50,28 @@ def test_wave_primitives_selftest(lib):
 def test_echo_parity(lib):
     cfg = E.test_config("echo", node_count=3, rate=5, time_limit=10, seed=1)
     _compare(cfg, 0, 8)
+    _compare(cfg, 0, 11, dev_flags=0x400)   # eight clusters per wavefront (csrc/uid8.hip; large batches take it unasked)
+
+
+@pytest.mark.parametrize("wl,kw", [
+    ("echo", dict(node_count=5, rate=400, time_limit=4, latency=3, p_loss=0.1)),                                                  # lost requests / replies: timeouts, fresh clients, stale replies
+    ("echo", dict(node_count=8, rate=1000, time_limit=3, latency=0)),                                                             # a full 8-lane group
+    ("echo", dict(node_count=1, rate=100, time_limit=3, latency=1, latency_dist="uniform", p_loss=0.3)),
+    ("unique-ids", dict(node_count=3, rate=1000, time_limit=5, latency=5, nemesis=["partition"], nemesis_interval=2)),            # the reference's demo shape (core.clj:122-126)
+    ("unique-ids", dict(node_count=7, rate=600, time_limit=4, latency=30, latency_dist="exponential", p_loss=0.05)),             # Reusable clients across timeouts
+    ("unique-ids", dict(node_count=2, rate=300, time_limit=4, latency=1, inbox_capacity=1, p_loss=0.2)),
+])
+def test_client_only_programs_packed_layout_parity(lib, wl, kw):
+    """echo and unique-ids (flake ids) — programs whose nodes talk to their clients only — eight clusters per wavefront (uid8_kernel<>,
+    csrc/uid8.hip) against the oracle, 17 clusters (two full wavefronts and a partial one)."""
+    cfg = E.test_config(wl, seed=37, **kw)
+    _compare(cfg, 0, 17, dev_flags=0x400)
+
+
+def test_unique_ids_large_batch_takes_the_packed_layout(lib):
+    """8192 clusters and more run eight per wavefront without being asked to (msim_launch_uid8): every one of 8200 identical to the oracle."""
+    cfg = E.test_config("unique-ids", node_count=3, rate=200, time_limit=2, latency=5, nemesis=["partition"], nemesis_interval=1, seed=43)
+    _compare(cfg, 0, 8200)
 
 
 @pytest.mark.parametrize("topology", ["grid", "line", "total", "tree4"])
@@ -378,6 +400,8 @@ def test_g_counter_parity(lib):
 def test_unique_ids_parity(lib, kw):
     cfg = E.test_config("unique-ids", node_count=3, rate=200, time_limit=5, seed=81, **kw)
     _compare(cfg, 0, 6)
+    if cfg.concurrency == cfg.n_nodes:
+        _compare(cfg, 0, 9, dev_flags=0x400)   # eight clusters per wavefront (csrc/uid8.hip)
     with E.Engine(cfg) as eng:
         eng.run(0, 6)
         eng.check()
