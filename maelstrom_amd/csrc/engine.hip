@@ -913,6 +913,7 @@ static uint64_t scratch_words(const msim_config &c) {
   if (msim_mk8_eligible(c)) w += msim_mk8_extra_scratch_words(c);       // mk8.hip likewise
   if (msim_hat8_eligible(c)) w += msim_hat8_extra_scratch_words(c);     // hat8.hip likewise
   if (msim_uid8_eligible(c)) w += msim_uid8_extra_scratch_words(c);     // uid8.hip likewise
+  if (msim_crdt8_eligible(c)) w += msim_crdt8_extra_scratch_words(c);   // crdt8.hip likewise
   return w;
 }
 
@@ -1031,6 +1032,8 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   if (msim_hat8_eligible(c) && !(kp.dev_flags & 0x200u)) e = msim_launch_hat8(kp, n, st);
   // echo / unique-ids (flake ids): eight clusters per wavefront (uid8.hip) for large batches of small clusters
   if (msim_uid8_eligible(c) && !(kp.dev_flags & 0x200u)) e = msim_launch_uid8(kp, n, st);
+  // g-set / pn-counter / g-counter: eight clusters per wavefront (crdt8.hip) for large batches of small clusters
+  if (msim_crdt8_eligible(c) && !(kp.dev_flags & 0x200u)) e = msim_launch_crdt8(kp, n, st);
   if (e == MSIM_LAYOUT_DOES_NOT_FIT && (kp.dev_flags & 0x400u) && is_raft) { ctx->err = "MSIM_DEV_FLAGS bit 10: the four-clusters-per-wavefront Raft layout was required but does not apply"; return MSIM_E_UNSUPPORTED; }
   if (e == MSIM_LAYOUT_DOES_NOT_FIT) switch (c.node_program) {   // not eligible, or the cluster state does not fit the duo layout
     case MSIM_NODE_ECHO: e = launch<MSIM_NODE_ECHO>(kp, n, lds, st); break;

@@ -22,6 +22,8 @@
 // it kept the other fifteen clusters of the wavefront waiting (first build: 127 ms per 16384 clusters against hat_kernel<>'s 84).
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+
 #include "wave_common.h"
 #include "log2_table.h"
 
@@ -752,6 +754,7 @@ hipError_t msim_launch_hat8(const KParams &kp, uint32_t n, hipStream_t st) {
   hp.off_misc = (u32)off; off += 64 * 4;
   hp.round_limit = (kp.dev_flags & 0x100u) ? 4000000u : ROUND_LIMIT;
   const size_t lds = off;
+  if (kp.dev_flags & 0x1000u) std::fprintf(stderr, "[hat8] %u clusters, several per wavefront, %zu B of LDS per wavefront\n", n, lds);   // developer trace bit
   const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
   if (rnd) MSIM_UPLOAD_ONCE(h8_log2_q24, msim_log2_q24, sizeof(msim_log2_q24));   // (1 KiB, once per device)
   // 8-lane groups for every cluster size: 4-lane groups halve the wavefronts again, and a wavefront's run is a chain of dependent round

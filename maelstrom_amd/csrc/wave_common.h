@@ -180,6 +180,10 @@ hipError_t msim_launch_hat8(const KParams &kp, uint32_t n, hipStream_t st);
 bool msim_uid8_eligible(const msim_config &c);
 uint64_t msim_uid8_extra_scratch_words(const msim_config &c);
 hipError_t msim_launch_uid8(const KParams &kp, uint32_t n, hipStream_t st);
+// crdt8.hip: eight g-set / pn-counter / g-counter clusters per wavefront (clusters of <= 8 lanes, states of <= 64 words)
+bool msim_crdt8_eligible(const msim_config &c);
+uint64_t msim_crdt8_extra_scratch_words(const msim_config &c);
+hipError_t msim_launch_crdt8(const KParams &kp, uint32_t n, hipStream_t st);
 // mk8.hip: eight clusters of the multi-key transactional node per wavefront (n <= 6 nodes + lin-kv + lww-kv in an 8-lane group)
 bool msim_mk8_eligible(const msim_config &c);
 uint64_t msim_mk8_extra_scratch_words(const msim_config &c);

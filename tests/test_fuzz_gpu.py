@@ -55,8 +55,8 @@ def test_random_options_engine_equals_oracle(lib, case):
     except E.EngineError as e:   # e.g. more endpoints than one wavefront has lanes
         pytest.skip(str(e))
     _compare(cfg, first, N_INST)
-    if wl in ("echo", "unique-ids") and cfg.n_nodes <= 8 and cfg.concurrency == cfg.n_nodes and not cfg.journal_capacity:
-        _compare(cfg, first, N_INST, dev_flags=0x400)   # eight clusters per wavefront (csrc/uid8.hip)
+    if wl != "broadcast" and cfg.n_nodes <= 8 and cfg.concurrency == cfg.n_nodes and not cfg.journal_capacity:
+        _compare(cfg, first, N_INST, dev_flags=0x400)   # eight clusters per wavefront (csrc/uid8.hip, csrc/crdt8.hip)
 
 
 def _random_kv_case(rng):

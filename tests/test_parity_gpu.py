@@ -68,6 +68,26 @@ def test_client_only_programs_packed_layout_parity(lib, wl, kw):
     _compare(cfg, 0, 17, dev_flags=0x400)
 
 
+@pytest.mark.parametrize("wl,kw", [
+    ("g-set", dict(node_count=5, rate=200, time_limit=12, latency=20, latency_dist="exponential", p_loss=0.1, nemesis=["partition"], nemesis_interval=3)),   # lost replicates, timeouts, the heal before the final reads
+    ("g-set", dict(node_count=8, rate=400, time_limit=7, latency=5)),                                                                                     # a full 8-lane group; several readers per round
+    ("g-set", dict(node_count=3, rate=100, time_limit=6, latency=300, inbox_capacity=2)),                                                                 # replicates older than the next tick; spilled queues
+    ("pn-counter", dict(node_count=5, rate=100, time_limit=12, latency=100, latency_dist="uniform", nemesis=["partition"], nemesis_interval=4)),
+    ("g-counter", dict(node_count=7, rate=150, time_limit=11, latency=30, latency_dist="exponential", p_loss=0.05)),
+    ("pn-counter", dict(node_count=1, rate=50, time_limit=6)),
+])
+def test_crdt_programs_packed_layout_parity(lib, wl, kw):
+    """g-set, pn-counter and g-counter eight clusters per wavefront (crdt8_kernel<>, csrc/crdt8.hip) against the oracle, 17 clusters."""
+    cfg = E.test_config(wl, seed=53, **kw)
+    _compare(cfg, 0, 17, dev_flags=0x400)
+
+
+def test_pn_counter_large_batch_takes_the_packed_layout(lib):
+    """4096 clusters and more run eight per wavefront without being asked to (msim_launch_crdt8): every one of 4100 identical to the oracle."""
+    cfg = E.test_config("pn-counter", node_count=5, rate=50, time_limit=6, latency=10, seed=59)
+    _compare(cfg, 0, 4100)
+
+
 def test_unique_ids_large_batch_takes_the_packed_layout(lib):
     """8192 clusters and more run eight per wavefront without being asked to (msim_launch_uid8): every one of 8200 identical to the oracle."""
     cfg = E.test_config("unique-ids", node_count=3, rate=200, time_limit=2, latency=5, nemesis=["partition"], nemesis_interval=1, seed=43)
@@ -107,6 +127,7 @@ def test_broadcast_loss_parity(lib):
 def test_g_set_parity(lib):
     cfg = E.test_config("g-set", node_count=5, rate=10, time_limit=10, seed=9)
     _compare(cfg, 0, 8)
+    _compare(cfg, 0, 11, dev_flags=0x400)   # eight clusters per wavefront (csrc/crdt8.hip; large batches take it unasked)
     cfg = E.test_config("g-set", node_count=25, rate=100, time_limit=10, latency=100, latency_dist="exponential", seed=9)
     _compare(cfg, 0, 4)
 
@@ -387,6 +408,8 @@ def test_pn_counter_parity(lib, kw):
     base.update(kw)
     cfg = E.test_config("pn-counter", **base)
     _compare(cfg, 0, 6)
+    if cfg.concurrency == cfg.n_nodes and cfg.n_nodes <= 8 and not cfg.journal_capacity:
+        _compare(cfg, 0, 9, dev_flags=0x400)   # eight clusters per wavefront (csrc/crdt8.hip)
 
 
 def test_g_counter_parity(lib):
