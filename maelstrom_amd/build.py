@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 OUT = os.path.join(HERE, "libmaelsim.so")
-SOURCES = ["config.cpp", "engine.hip", "duo.hip", "raft4.hip", "txn8.hip", "mk8.hip", "hat8.hip", "uid8.hip", "crdt8.hip", "checker.hip", "lin_check.cpp", "lin_check_dev.hip", "txn_check.cpp", "txn_check_dev.hip", "rw_check_dev.hip", "pn_check.cpp", "kafka_check.cpp", "kafka_check_dev.hip", "pn_check_dev.hip", "unique_check_dev.hip", "edn.cpp",
+SOURCES = ["config.cpp", "engine.hip", "duo.hip", "raft4.hip", "txn8.hip", "mk8.hip", "hat8.hip", "uid8.hip", "crdt8.hip", "bcast8.hip", "checker.hip", "lin_check.cpp", "lin_check_dev.hip", "txn_check.cpp", "txn_check_dev.hip", "rw_check_dev.hip", "pn_check.cpp", "kafka_check.cpp", "kafka_check_dev.hip", "pn_check_dev.hip", "unique_check_dev.hip", "edn.cpp",
            "fressian.cpp", "gather.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 LINK_LIBS = ["-ldl"]

@@ -914,6 +914,7 @@ static uint64_t scratch_words(const msim_config &c) {
   if (msim_hat8_eligible(c)) w += msim_hat8_extra_scratch_words(c);     // hat8.hip likewise
   if (msim_uid8_eligible(c)) w += msim_uid8_extra_scratch_words(c);     // uid8.hip likewise
   if (msim_crdt8_eligible(c)) w += msim_crdt8_extra_scratch_words(c);   // crdt8.hip likewise
+  if (msim_bcast8_eligible(c)) w += msim_bcast8_extra_scratch_words(c); // bcast8.hip likewise
   return w;
 }
 
@@ -1018,10 +1019,12 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
 #else
   // the headline layout: two clusters per wavefront (duo.hip); MSIM_DEV_FLAGS bit 9 keeps the one-cluster kernels
   e = MSIM_LAYOUT_DOES_NOT_FIT;
-  if (msim_duo_eligible(c) && !(kp.dev_flags & 0x200u)) {
+  if (msim_duo_eligible(c) && !(kp.dev_flags & 0x200u) && !((kp.dev_flags & 0x8000u) && msim_bcast8_eligible(c))) {   // (bit 15: small clusters eight per wavefront instead)
     e = msim_launch_duo(kp, n, st);
     if (e == MSIM_LAYOUT_DOES_NOT_FIT && (kp.dev_flags & 0x400u)) { ctx->err = "MSIM_DEV_FLAGS bit 10: the two-clusters-per-wavefront layout was required but this cluster state does not fit it"; return MSIM_E_UNSUPPORTED; }
   }
+  // the broadcast programs at the tutorial's cluster sizes: eight clusters per wavefront (bcast8.hip) where the headline layout does not apply
+  if (e == MSIM_LAYOUT_DOES_NOT_FIT && msim_bcast8_eligible(c) && !(kp.dev_flags & 0x200u)) e = msim_launch_bcast8(kp, n, st);
   // Raft: four clusters per wavefront (raft4.hip) when a cluster fits a 16-lane group
   if (msim_raft4_eligible(c) && !(kp.dev_flags & 0x200u)) e = msim_launch_raft4(kp, n, st);
   // txn-list-append: eight clusters per wavefront (txn8.hip) when a cluster fits an 8-lane group

@@ -184,6 +184,10 @@ hipError_t msim_launch_uid8(const KParams &kp, uint32_t n, hipStream_t st);
 bool msim_crdt8_eligible(const msim_config &c);
 uint64_t msim_crdt8_extra_scratch_words(const msim_config &c);
 hipError_t msim_launch_crdt8(const KParams &kp, uint32_t n, hipStream_t st);
+// bcast8.hip: eight broadcast clusters per wavefront (the four broadcast programs, clusters of <= 8 lanes, sets of <= 64 words)
+bool msim_bcast8_eligible(const msim_config &c);
+uint64_t msim_bcast8_extra_scratch_words(const msim_config &c);
+hipError_t msim_launch_bcast8(const KParams &kp, uint32_t n, hipStream_t st);
 // mk8.hip: eight clusters of the multi-key transactional node per wavefront (n <= 6 nodes + lin-kv + lww-kv in an 8-lane group)
 bool msim_mk8_eligible(const msim_config &c);
 uint64_t msim_mk8_extra_scratch_words(const msim_config &c);

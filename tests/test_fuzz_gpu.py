@@ -55,8 +55,9 @@ def test_random_options_engine_equals_oracle(lib, case):
     except E.EngineError as e:   # e.g. more endpoints than one wavefront has lanes
         pytest.skip(str(e))
     _compare(cfg, first, N_INST)
-    if wl != "broadcast" and cfg.n_nodes <= 8 and cfg.concurrency == cfg.n_nodes and not cfg.journal_capacity:
-        _compare(cfg, first, N_INST, dev_flags=0x400)   # eight clusters per wavefront (csrc/uid8.hip, csrc/crdt8.hip)
+    if cfg.n_nodes <= 8 and cfg.concurrency == cfg.n_nodes and not cfg.journal_capacity:
+        # eight clusters per wavefront (csrc/uid8.hip, csrc/crdt8.hip, csrc/bcast8.hip — bit 15: also where the headline layout applies)
+        _compare(cfg, first, N_INST, dev_flags=0x8400 if wl == "broadcast" else 0x400)
 
 
 def _random_kv_case(rng):

@@ -82,6 +82,27 @@ def test_crdt_programs_packed_layout_parity(lib, wl, kw):
     _compare(cfg, 0, 17, dev_flags=0x400)
 
 
+@pytest.mark.parametrize("bin,kw", [
+    ("broadcast-ff", dict(node_count=5, rate=100, time_limit=8, latency=10, nemesis=["partition"], nemesis_interval=2)),                                       # what duo.hip does not take: partitions
+    ("broadcast-ff", dict(node_count=8, rate=200, time_limit=5, latency=20, latency_dist="exponential", p_loss=0.1, topology="tree2")),                        # loss: client timeouts, :fail reads
+    ("broadcast-ff-echoback", dict(node_count=6, rate=100, time_limit=5, latency=5, topology="line")),                                                          # (healthy network: taken from duo.hip with bit 15)
+    ("broadcast-ack-retry", dict(node_count=5, rate=60, time_limit=10, latency=10, nemesis=["partition"], nemesis_interval=2, p_loss=0.1)),                    # retries pile up behind the partitions
+    ("broadcast-ack-retry", dict(node_count=3, rate=100, time_limit=5, latency=200, latency_dist="uniform", inbox_capacity=2)),                                # retries before the first ack; spilled queues
+    ("broadcast-rpc-all", dict(node_count=8, rate=60, time_limit=5, latency=20, latency_dist="exponential", topology="total")),                                # a full 8-lane group, 7 acks per value and node
+    ("broadcast-rpc-all", dict(node_count=1, rate=50, time_limit=4)),
+])
+def test_broadcast_programs_packed_layout_parity(lib, bin, kw):
+    """The four broadcast programs eight clusters per wavefront (bcast8_kernel<>, csrc/bcast8.hip) against the oracle, 17 clusters."""
+    cfg = E.test_config("broadcast", bin=bin, seed=61, **kw)
+    _compare(cfg, 0, 17, dev_flags=0x8400)
+
+
+def test_broadcast_ack_retry_large_batch_takes_the_packed_layout(lib):
+    """12288 clusters and more run eight per wavefront without being asked to (msim_launch_bcast8): every one of 12300 identical to the oracle."""
+    cfg = E.test_config("broadcast", bin="broadcast-ack-retry", node_count=5, rate=20, time_limit=4, latency=10, nemesis=["partition"], nemesis_interval=2, seed=67)
+    _compare(cfg, 0, 12300)
+
+
 def test_pn_counter_large_batch_takes_the_packed_layout(lib):
     """4096 clusters and more run eight per wavefront without being asked to (msim_launch_crdt8): every one of 4100 identical to the oracle."""
     cfg = E.test_config("pn-counter", node_count=5, rate=50, time_limit=6, latency=10, seed=59)
