@@ -24,12 +24,9 @@
 
 #include <cstdio>
 
-#include "wave_common.h"
-#include "log2_table.h"
+#include "group8.h"
 
 namespace {
-
-__constant__ u32 b8_log2_q24[257];
 
 constexpr u32 GS = 8u;            // lanes per cluster
 constexpr u32 RQ = 4u;            // LDS envelopes per node queue
@@ -45,25 +42,6 @@ struct B8Params {
   u32 round_limit;
 };
 
-__device__ __forceinline__ u32 b8_neg_ln_q16(u32 r) {
-  if (r == 0xFFFFFFFFu) return 0;
-  const u32 v = r + 1;
-  const u32 e = 31 - __clz(v);
-  const u32 m = v << (31 - e);
-  const u32 idx = (m >> 23) & 0xFF;
-  const u32 f = (m >> 7) & 0xFFFF;
-  const u32 l0 = b8_log2_q24[idx], l1 = b8_log2_q24[idx + 1];
-  const u32 lg = (e << 24) + l0 + (u32)(((u64)(l1 - l0) * f) >> 16);
-  const u32 d = (32u << 24) - lg;
-  return (u32)(((u64)d * 2977044472ull) >> 40);
-}
-// min over the 8 lanes of the caller's group, in every lane of it
-__device__ __forceinline__ u32 grp_min(u32 v) {
-  v = min(v, dpp_mov<0xB1, 0xF, 0xF, false>(v, v));   // quad_perm [1,0,3,2]
-  v = min(v, dpp_mov<0x4E, 0xF, 0xF, false>(v, v));   // quad_perm [2,3,0,1]
-  v = min(v, dpp_mov<0x141, 0xF, 0xF, false>(v, v));  // row_half_mirror
-  return v;
-}
 
 template <int PROG, bool NEM, bool NET_RANDOM>
 __global__ void __launch_bounds__(64) bcast8_kernel(const B8Params up) {
@@ -122,58 +100,7 @@ __global__ void __launch_bounds__(64) bcast8_kernel(const B8Params up) {
   u32 loss_on = 0, next_id = 0, n_rows = 0, n_payload = 0, flags = 0, rounds = 0;
   bool alive = real;
 
-  auto q_push = [&](const uint4 m) {
-    if (in_n < RQ) { my_q[in_n * 64u] = m; in_n++; return; }
-    if (sp_n < my_spill_cap) { my_spill[sp_n++] = m; return; }
-    my_flags |= MSIM_FLAG_INBOX_OVERFLOW;
-  };
-  // an envelope for THIS lane's node arrives (net.clj:189-221)
-  auto arrive = [&](u32 id, u32 type, u32 a, u32 b, u32 src) {
-    u32 lat = 0;
-    if (src < N) {  // neither end is a client
-      if (!NET_RANDOM || lat_dist == MSIM_LAT_CONSTANT) lat = lat_mean;
-      else if (lat_dist == MSIM_LAT_UNIFORM) lat = scale32(draw32(key, S_LATENCY, id), 2 * lat_mean);
-      else lat = (u32)(((u64)lat_mean * b8_neg_ln_q16(draw32(key, S_LATENCY, id))) >> 16);
-    }
-    if (NET_RANDOM && loss_on && p_loss && draw32(key, S_LOSS, id) < p_loss) return;
-    uint4 m = make_uint4(T + lat * 1000u, (id << 8) | type, a, b | (src << 24));
-    if (!have_pm) { pm = m; have_pm = true; return; }
-    if (m.x < pm.x || (m.x == pm.x && m.y < pm.y)) { const uint4 t = m; m = pm; pm = t; }
-    q_push(m);
-  };
-  auto try_commit = [&](const uint4 e) {
-    const u32 src = e.w >> 24;
-    if (NEM && src < N && ((part >> src) & 1)) return;  // partitioned: dropped at take time, no :recv (net.clj:232-234)
-    cm = e;
-    deliver_at = e.x <= T ? T : T + ((e.x - T) / 1000u) * 1000u;  // (Thread/sleep (long dt)) net.clj:236-238
-  };
-  auto poll = [&]() {
-    if (have_pm) {
-      have_pm = false;
-      if (alive && deliver_at == INF && (in_n | sp_n) == 0) try_commit(pm);
-      else q_push(pm);
-    }
-    while (alive && is_node && deliver_at == INF && (in_n | sp_n) != 0) {
-      u32 best = 0; bool in_spill = false;
-      uint2 bk = make_uint2(INF, INF);
-      for (u32 i = 0; i < in_n; i++) {
-        const uint2 kk = *reinterpret_cast<const uint2 *>(&my_q[i * 64u]);
-        if (kk.x < bk.x || (kk.x == bk.x && kk.y < bk.y)) { bk = kk; best = i; }
-      }
-      for (u32 i0 = 0; i0 < sp_n; i0 += 8) {   // deep queues only: 8 independent loads per trip
-        uint2 kq[8];
-#pragma unroll
-        for (u32 t = 0; t < 8; t++) kq[t] = *reinterpret_cast<const uint2 *>(&my_spill[min(i0 + t, sp_n - 1)]);
-#pragma unroll
-        for (u32 t = 0; t < 8; t++) if (i0 + t < sp_n && (kq[t].x < bk.x || (kq[t].x == bk.x && kq[t].y < bk.y))) { bk = kq[t]; best = i0 + t; in_spill = true; }
-      }
-      uint4 e;
-      if (in_spill) { e = my_spill[best]; sp_n--; if (best != sp_n) my_spill[best] = my_spill[sp_n]; }
-      else { e = my_q[best * 64u]; in_n--; if (best != in_n) my_q[best * 64u] = my_q[in_n * 64u]; }
-      try_commit(e);
-    }
-  };
-
+  #include "group8_net.inc"
   for (;;) {
     if (!__ballot(alive)) break;
     const u32 busy_mask = GB(busy);
@@ -220,7 +147,7 @@ __global__ void __launch_bounds__(64) bcast8_kernel(const B8Params up) {
       if (__ballot(jump)) {
         u32 k = min(deliver_at, retry_time); k = k == INF ? INF : k * 2;
         if (busy) k = min(k, timeout_at * 2 + 1);
-        u32 km = grp_min(k);
+        u32 km = g8_min<8>(k);
         if (due != INF) km = min(km, due * 2);
         if (jump) {
           if (km == INF) { flags |= MSIM_FLAG_ROUND_LIMIT; alive = false; }
@@ -267,62 +194,7 @@ __global__ void __launch_bounds__(64) bcast8_kernel(const B8Params up) {
           phase = PH_FINAL_WAIT;
         }
       }
-      if (NEM) {
-        const bool nem_act = act && phase == PH_MAIN && nem_live && nem_next <= T;
-        if (__ballot(nem_act)) {   // flip-flop start/stop (nemesis.clj:10-16 + [upstream] partition package)
-          const u32 j = nem_j;
-          const u32 spec = scale32(draw32(key, S_NEM_SPEC, j), 4);
-          const bool start = nem_act && (j & 1) == 0;
-          if (nem_act) { nem_j++; nem_rows = 2; }
-          if (__ballot(start)) {
-            misc[l] = l;
-            wave_lds_fence();
-            if (start && l == 0 && spec != MSIM_SPEC_ONE) {
-              for (u32 i = N - 1; i >= 1; i--) {
-                const u32 kk = scale32(draw32(key, S_NEM_SHUFFLE, ((u64)j << 16) | i), i + 1);
-                const u32 t = misc[i]; misc[i] = misc[kk]; misc[kk] = t;
-              }
-            }
-            wave_lds_fence();
-            u32 my_part = 0;
-            if (start && is_node) {
-              if (spec == MSIM_SPEC_ONE) {
-                const u32 loner = scale32(draw32(key, S_NEM_PICK, j), N);
-                my_part = l == loner ? (all_nodes & ~(1u << loner)) : (1u << loner);
-              } else if (spec == MSIM_SPEC_MAJORITY || spec == MSIM_SPEC_MINORITY_THIRD) {
-                const u32 cnt = spec == MSIM_SPEC_MAJORITY ? N / 2 : (N - 1) / 3;
-                u32 comp = 0;
-                for (u32 i = 0; i < cnt; i++) comp |= 1u << misc[i];
-                my_part = ((comp >> l) & 1) ? (all_nodes & ~comp) : comp;
-              } else {
-                const u32 m = N / 2 + 1;
-                u32 pos = 0;
-                for (u32 i = 0; i < N; i++) if (misc[i] == l) pos = i;
-                const u32 i0 = (pos + N - (m / 2) % N) % N;
-                u32 vis = 0;
-                for (u32 kk = 0; kk < m; kk++) vis |= 1u << misc[(i0 + kk) % N];
-                my_part = all_nodes & ~vis;
-              }
-            }
-            if (start) {
-              part |= my_part;
-              const u32 words = N * MSIM_MASK_WORDS;
-              u32 off = 0;
-              if (n_payload + words > max_pay) flags |= MSIM_FLAG_PAYLOAD_OVERFLOW;
-              else {
-                off = n_payload; n_payload += words;
-                if (is_node) { g_pay[off + l * 4] = part; g_pay[off + l * 4 + 1] = 0; g_pay[off + l * 4 + 2] = 0; g_pay[off + l * 4 + 3] = 0; }
-              }
-              nem_f = MSIM_F_START_PARTITION; nem_v1 = spec; nem_v2 = off; nem_len2 = words;
-            }
-          }
-          if (nem_act && (j & 1) != 0) {
-            part = 0;
-            nem_f = MSIM_F_STOP_PARTITION; nem_v1 = MSIM_NO_VALUE; nem_v2 = MSIM_NO_VALUE; nem_len2 = 0;
-          }
-          if (nem_act) nem_next = T + __umulhi(draw32(key, S_NEM_STAGGER, j), p.nem_period2_us);
-        }
-      }
+      #include "group8_nemesis.inc"
       {
         const bool gen_on = act && phase == PH_MAIN && gen_live && gen_next <= T && free_mask != 0;
         if (__ballot(gen_on)) {
@@ -468,41 +340,7 @@ __global__ void __launch_bounds__(64) bcast8_kernel(const B8Params up) {
         poll();
       }
 
-      // ---- R4: the clients' recv! loops (client.clj:94-107) ----
-      if (__ballot(c_arr || (busy && (cin_n | csp_n) != 0))) {
-        for (;;) {
-          const bool stale = normal && busy && (cin_n | csp_n) != 0;
-          const bool fresh = normal && !stale && busy && c_arr;
-          if (!__ballot(stale || fresh)) break;
-          if (stale) {
-            u32 best = 0; bool in_spill = false;
-            uint2 bk = make_uint2(INF, INF);
-            for (u32 i = 0; i < cin_n; i++) {
-              const uint2 kk = *reinterpret_cast<const uint2 *>(&my_cq[i * 64u]);
-              if (kk.x < bk.x || (kk.x == bk.x && kk.y < bk.y)) { bk = kk; best = i; }
-            }
-            for (u32 i = 0; i < csp_n; i++) {
-              const uint2 kk = *reinterpret_cast<const uint2 *>(&my_cspill[i]);
-              if (kk.x < bk.x || (kk.x == bk.x && kk.y < bk.y)) { bk = kk; best = i; in_spill = true; }
-            }
-            uint4 e;
-            if (in_spill) { e = my_cspill[best]; csp_n--; if (best != csp_n) my_cspill[best] = my_cspill[csp_n]; }
-            else { e = my_cq[best * 64u]; cin_n--; if (best != cin_n) my_cq[best * 64u] = my_cq[cin_n * 64u]; }
-            client_deliver(e.y & 0xFFu, e.z, e.w & 0xFFFFFFu);
-          } else if (fresh) {
-            c_arr = false;
-            client_deliver(ca_y & 0xFFu, ca_a, ca_b);
-          }
-        }
-        if (c_arr && normal) {  // nobody is in recv!: the envelope waits for the next RPC (and is skipped there as stale)
-          const uint4 e = make_uint4(T, ca_y, ca_a, ca_b | (l << 24));
-          if (cin_n < CQ) { my_cq[cin_n * 64u] = e; cin_n++; }
-          else if (csp_n < up.client_spill) my_cspill[csp_n++] = e;
-          else my_flags |= MSIM_FLAG_INBOX_OVERFLOW;
-        }
-      }
-    }
-
+      #include "group8_clients.inc"
     // ---- history rows: nemesis rows, invocations (lane order), completions (lane order) ----
     {
       const u32 imask = GB(inv_row), cmask = GB(cmp_row);
@@ -584,7 +422,7 @@ hipError_t msim_launch_bcast8(const KParams &kp, uint32_t n, hipStream_t st) {
   const size_t lds = off;
   if (kp.dev_flags & 0x1000u) std::fprintf(stderr, "[bcast8] %u clusters, eight per wavefront, %zu B of LDS per wavefront\n", n, lds);   // developer trace bit
   const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
-  if (rnd) MSIM_UPLOAD_ONCE(b8_log2_q24, msim_log2_q24, sizeof(msim_log2_q24));   // (1 KiB, once per device)
+  if (rnd) MSIM_UPLOAD_ONCE(g8_log2_q24, msim_log2_q24, sizeof(msim_log2_q24));   // (1 KiB, once per device)
   const bool nem = c.nemesis_mask != 0;
   switch (c.node_program) {
     case MSIM_NODE_BCAST_FF: return b8_launch<MSIM_NODE_BCAST_FF>(up, n, lds, nem, rnd, st);

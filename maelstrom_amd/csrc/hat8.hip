@@ -24,12 +24,9 @@
 
 #include <cstdio>
 
-#include "wave_common.h"
-#include "log2_table.h"
+#include "group8.h"
 
 namespace {
-
-__constant__ u32 h8_log2_q24[257];
 
 constexpr u32 RQ = 4u;            // LDS envelopes per node queue
 constexpr u32 CQ = 1u;            // LDS envelopes per client inbox
@@ -49,38 +46,18 @@ struct H8Params {
   u32 round_limit;
 };
 
-__device__ __forceinline__ u32 h8_neg_ln_q16(u32 r) {
-  if (r == 0xFFFFFFFFu) return 0;
-  const u32 v = r + 1;
-  const u32 e = 31 - __clz(v);
-  const u32 m = v << (31 - e);
-  const u32 idx = (m >> 23) & 0xFF;
-  const u32 f = (m >> 7) & 0xFFFF;
-  const u32 l0 = h8_log2_q24[idx], l1 = h8_log2_q24[idx + 1];
-  const u32 lg = (e << 24) + l0 + (u32)(((u64)(l1 - l0) * f) >> 16);
-  const u32 d = (32u << 24) - lg;
-  return (u32)(((u64)d * 2977044472ull) >> 40);
-}
-// min over the GS lanes of the caller's group, in every lane of it
-template <int GS>
-__device__ __forceinline__ u32 grp_min(u32 v) {
-  v = min(v, dpp_mov<0xB1, 0xF, 0xF, false>(v, v));   // quad_perm [1,0,3,2]
-  v = min(v, dpp_mov<0x4E, 0xF, 0xF, false>(v, v));   // quad_perm [2,3,0,1]
-  if (GS == 8) v = min(v, dpp_mov<0x141, 0xF, 0xF, false>(v, v));  // row_half_mirror
-  return v;
-}
 
 template <int GS, bool NEM, bool NET_RANDOM>
-__global__ void __launch_bounds__(64) hat8_kernel(const H8Params hp) {
+__global__ void __launch_bounds__(64) hat8_kernel(const H8Params up) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr u32 GM = (1u << GS) - 1u, NG = 64u / GS;
-  const KParams &p = hp.k;
+  const KParams &p = up.k;
   const u32 lane = threadIdx.x, l = lane & (GS - 1u), grp = lane / GS, gbase = lane & ~(u32)(GS - 1);
   const u32 N = p.N;
   const bool is_node = l < N;
   const u32 inst_raw = blockIdx.x * NG + grp;
-  const bool real = inst_raw < hp.n_inst;
-  const u32 inst = real ? inst_raw : hp.n_inst - 1u;
+  const bool real = inst_raw < up.n_inst;
+  const u32 inst = real ? inst_raw : up.n_inst - 1u;
   const u64 key = mix64(p.cfg.seed + 0x9E3779B97F4A7C15ull * (p.first_instance + inst + 1));
   const u32 lt = (1u << l) - 1u;
   const u32 all_nodes = (1u << N) - 1u;
@@ -88,7 +65,7 @@ __global__ void __launch_bounds__(64) hat8_kernel(const H8Params hp) {
   const u32 p_loss = p.cfg.p_loss_q32, lat_mean = p.cfg.latency_mean_ms, lat_dist = p.cfg.latency_dist;
   const u32 rate = p.cfg.rate_mhz, mw = p.cfg.max_writes_per_key;
   const u32 K = p.cfg.max_values, G = max_rows / 2, area_cap = p.cfg.replication_words;
-  const u32 round_limit = hp.round_limit;
+  const u32 round_limit = up.round_limit;
 
   msim_op *const g_rows = p.rows + (size_t)inst * max_rows;
   u32 *const g_pay = p.payload + (size_t)inst * max_pay;
@@ -99,14 +76,14 @@ __global__ void __launch_bounds__(64) hat8_kernel(const H8Params hp) {
   unsigned char *const g_pend = pend_all + (size_t)(is_node ? l : 0u) * G;
   u32 *const g_area = g_tab + 2 * (size_t)G + ((size_t)N * G + 3) / 4;              // replicate lists
   const u32 qlane = is_node ? l : 0u;
-  uint4 *const my_spill = reinterpret_cast<uint4 *>(g_scr + p.spill_off) + (size_t)qlane * hp.node_spill;
-  uint4 *const my_cspill = reinterpret_cast<uint4 *>(g_scr + hp.client_spill_off) + (size_t)qlane * hp.client_spill;
-  const u32 my_spill_cap = is_node ? hp.node_spill : 0u;
+  uint4 *const my_spill = reinterpret_cast<uint4 *>(g_scr + p.spill_off) + (size_t)qlane * up.node_spill;
+  uint4 *const my_cspill = reinterpret_cast<uint4 *>(g_scr + up.client_spill_off) + (size_t)qlane * up.client_spill;
+  const u32 my_spill_cap = is_node ? up.node_spill : 0u;
 
   uint4 *const my_q = reinterpret_cast<uint4 *>(smem) + lane;                                   // node queue: slot s at my_q[s * 64]
-  uint4 *const my_cq = reinterpret_cast<uint4 *>(smem + hp.off_cq) + lane;                      // client inbox
-  u32 *const gen = reinterpret_cast<u32 *>(smem + hp.off_gen) + grp * 36;                       // active[16], next_val[16], next_key
-  u32 *const misc = reinterpret_cast<u32 *>(smem + hp.off_misc) + grp * GS;
+  uint4 *const my_cq = reinterpret_cast<uint4 *>(smem + up.off_cq) + lane;                      // client inbox
+  u32 *const gen = reinterpret_cast<u32 *>(smem + up.off_gen) + grp * 36;                       // active[16], next_val[16], next_key
+  u32 *const misc = reinterpret_cast<u32 *>(smem + up.off_misc) + grp * GS;
 
   for (u32 i = l; i < 16; i += GS) { gen[i] = i; gen[16 + i] = 1; }
   if (l == 0) gen[32] = p.cfg.key_count;
@@ -134,58 +111,7 @@ __global__ void __launch_bounds__(64) hat8_kernel(const H8Params hp) {
   u32 n_txn = 0, n_area = 0;
   bool alive = real;
 
-  auto q_push = [&](const uint4 m) {
-    if (in_n < RQ) { my_q[in_n * 64u] = m; in_n++; return; }
-    if (sp_n < my_spill_cap) { my_spill[sp_n++] = m; return; }
-    my_flags |= MSIM_FLAG_INBOX_OVERFLOW;
-  };
-  // an envelope for THIS lane's node arrives (net.clj:189-221)
-  auto arrive = [&](u32 id, u32 type, u32 a, u32 b, u32 src) {
-    u32 lat = 0;
-    if (src < N) {  // neither end is a client
-      if (!NET_RANDOM || lat_dist == MSIM_LAT_CONSTANT) lat = lat_mean;
-      else if (lat_dist == MSIM_LAT_UNIFORM) lat = scale32(draw32(key, S_LATENCY, id), 2 * lat_mean);
-      else lat = (u32)(((u64)lat_mean * h8_neg_ln_q16(draw32(key, S_LATENCY, id))) >> 16);
-    }
-    if (NET_RANDOM && loss_on && p_loss && draw32(key, S_LOSS, id) < p_loss) return;
-    uint4 m = make_uint4(T + lat * 1000u, (id << 8) | type, a, b | (src << 24));
-    if (!have_pm) { pm = m; have_pm = true; return; }
-    if (m.x < pm.x || (m.x == pm.x && m.y < pm.y)) { const uint4 t = m; m = pm; pm = t; }
-    q_push(m);
-  };
-  auto try_commit = [&](const uint4 e) {
-    const u32 src = e.w >> 24;
-    if (NEM && src < N && ((part >> src) & 1)) return;  // partitioned: dropped at take time, no :recv (net.clj:232-234)
-    cm = e;
-    deliver_at = e.x <= T ? T : T + ((e.x - T) / 1000u) * 1000u;  // (Thread/sleep (long dt)) net.clj:236-238
-  };
-  auto poll = [&]() {
-    if (have_pm) {
-      have_pm = false;
-      if (alive && deliver_at == INF && (in_n | sp_n) == 0) try_commit(pm);
-      else q_push(pm);
-    }
-    while (alive && is_node && deliver_at == INF && (in_n | sp_n) != 0) {
-      u32 best = 0; bool in_spill = false;
-      uint2 bk = make_uint2(INF, INF);
-      for (u32 i = 0; i < in_n; i++) {
-        const uint2 kk = *reinterpret_cast<const uint2 *>(&my_q[i * 64u]);
-        if (kk.x < bk.x || (kk.x == bk.x && kk.y < bk.y)) { bk = kk; best = i; }
-      }
-      for (u32 i0 = 0; i0 < sp_n; i0 += 8) {   // deep queues only: 8 independent loads per trip
-        uint2 kq[8];
-#pragma unroll
-        for (u32 t = 0; t < 8; t++) kq[t] = *reinterpret_cast<const uint2 *>(&my_spill[min(i0 + t, sp_n - 1)]);
-#pragma unroll
-        for (u32 t = 0; t < 8; t++) if (i0 + t < sp_n && (kq[t].x < bk.x || (kq[t].x == bk.x && kq[t].y < bk.y))) { bk = kq[t]; best = i0 + t; in_spill = true; }
-      }
-      uint4 e;
-      if (in_spill) { e = my_spill[best]; sp_n--; if (best != sp_n) my_spill[best] = my_spill[sp_n]; }
-      else { e = my_q[best * 64u]; in_n--; if (best != in_n) my_q[best * 64u] = my_q[in_n * 64u]; }
-      try_commit(e);
-    }
-  };
-
+  #include "group8_net.inc"
   for (;;) {
     if (!__ballot(alive)) break;
     const u32 busy_mask = GB(busy);
@@ -225,7 +151,7 @@ __global__ void __launch_bounds__(64) hat8_kernel(const H8Params hp) {
       if (__ballot(jump)) {
         u32 k = min(deliver_at, timer_next); k = k == INF ? INF : k * 2;
         if (busy) k = min(k, timeout_at * 2 + 1);
-        u32 km = grp_min<GS>(k);
+        u32 km = g8_min<GS>(k);
         if (due != INF) km = min(km, due * 2);
         if (jump) {
           if (km == INF) { flags |= MSIM_FLAG_ROUND_LIMIT; alive = false; }
@@ -264,62 +190,7 @@ __global__ void __launch_bounds__(64) hat8_kernel(const H8Params hp) {
       if (__ballot(act && phase == PH_INIT)) {
         if (act && phase == PH_INIT) { if (is_node) { mark = true; kind = K_INIT; } phase = PH_INIT_WAIT; }
       }
-      if (NEM) {
-        const bool nem_act = act && phase == PH_MAIN && nem_live && nem_next <= T;
-        if (__ballot(nem_act)) {   // flip-flop start/stop (nemesis.clj:10-16 + [upstream] partition package)
-          const u32 j = nem_j;
-          const u32 spec = scale32(draw32(key, S_NEM_SPEC, j), 4);
-          const bool start = nem_act && (j & 1) == 0;
-          if (nem_act) { nem_j++; nem_rows = 2; }
-          if (__ballot(start)) {
-            misc[l] = l;
-            wave_lds_fence();
-            if (start && l == 0 && spec != MSIM_SPEC_ONE) {
-              for (u32 i = N - 1; i >= 1; i--) {
-                const u32 kk = scale32(draw32(key, S_NEM_SHUFFLE, ((u64)j << 16) | i), i + 1);
-                const u32 t = misc[i]; misc[i] = misc[kk]; misc[kk] = t;
-              }
-            }
-            wave_lds_fence();
-            u32 my_part = 0;
-            if (start && is_node) {
-              if (spec == MSIM_SPEC_ONE) {
-                const u32 loner = scale32(draw32(key, S_NEM_PICK, j), N);
-                my_part = l == loner ? (all_nodes & ~(1u << loner)) : (1u << loner);
-              } else if (spec == MSIM_SPEC_MAJORITY || spec == MSIM_SPEC_MINORITY_THIRD) {
-                const u32 cnt = spec == MSIM_SPEC_MAJORITY ? N / 2 : (N - 1) / 3;
-                u32 comp = 0;
-                for (u32 i = 0; i < cnt; i++) comp |= 1u << misc[i];
-                my_part = ((comp >> l) & 1) ? (all_nodes & ~comp) : comp;
-              } else {
-                const u32 m = N / 2 + 1;
-                u32 pos = 0;
-                for (u32 i = 0; i < N; i++) if (misc[i] == l) pos = i;
-                const u32 i0 = (pos + N - (m / 2) % N) % N;
-                u32 vis = 0;
-                for (u32 kk = 0; kk < m; kk++) vis |= 1u << misc[(i0 + kk) % N];
-                my_part = all_nodes & ~vis;
-              }
-            }
-            if (start) {
-              part |= my_part;
-              const u32 words = N * MSIM_MASK_WORDS;
-              u32 off = 0;
-              if (n_payload + words > max_pay) flags |= MSIM_FLAG_PAYLOAD_OVERFLOW;
-              else {
-                off = n_payload; n_payload += words;
-                if (is_node) { g_pay[off + l * 4] = part; g_pay[off + l * 4 + 1] = 0; g_pay[off + l * 4 + 2] = 0; g_pay[off + l * 4 + 3] = 0; }
-              }
-              nem_f = MSIM_F_START_PARTITION; nem_v1 = spec; nem_v2 = off; nem_len2 = words;
-            }
-          }
-          if (nem_act && (j & 1) != 0) {
-            part = 0;
-            nem_f = MSIM_F_STOP_PARTITION; nem_v1 = MSIM_NO_VALUE; nem_v2 = MSIM_NO_VALUE; nem_len2 = 0;
-          }
-          if (nem_act) nem_next = T + __umulhi(draw32(key, S_NEM_STAGGER, j), p.nem_period2_us);
-        }
-      }
+      #include "group8_nemesis.inc"
       {
         const bool gen_on = act && phase == PH_MAIN && gen_live && gen_next <= T && free_mask != 0;
         if (__ballot(gen_on)) {
@@ -636,41 +507,7 @@ __global__ void __launch_bounds__(64) hat8_kernel(const H8Params hp) {
         poll();
       }
 
-      // ---- R4: the clients' recv! loops (client.clj:94-107) ----
-      if (__ballot(c_arr || (busy && (cin_n | csp_n) != 0))) {
-        for (;;) {
-          const bool stale = normal && busy && (cin_n | csp_n) != 0;
-          const bool fresh = normal && !stale && busy && c_arr;
-          if (!__ballot(stale || fresh)) break;
-          if (stale) {
-            u32 best = 0; bool in_spill = false;
-            uint2 bk = make_uint2(INF, INF);
-            for (u32 i = 0; i < cin_n; i++) {
-              const uint2 kk = *reinterpret_cast<const uint2 *>(&my_cq[i * 64u]);
-              if (kk.x < bk.x || (kk.x == bk.x && kk.y < bk.y)) { bk = kk; best = i; }
-            }
-            for (u32 i = 0; i < csp_n; i++) {
-              const uint2 kk = *reinterpret_cast<const uint2 *>(&my_cspill[i]);
-              if (kk.x < bk.x || (kk.x == bk.x && kk.y < bk.y)) { bk = kk; best = i; in_spill = true; }
-            }
-            uint4 e;
-            if (in_spill) { e = my_cspill[best]; csp_n--; if (best != csp_n) my_cspill[best] = my_cspill[csp_n]; }
-            else { e = my_cq[best * 64u]; cin_n--; if (best != cin_n) my_cq[best * 64u] = my_cq[cin_n * 64u]; }
-            client_deliver(e.y & 0xFFu, e.z, e.w & 0xFFFFFFu);
-          } else if (fresh) {
-            c_arr = false;
-            client_deliver(ca_y & 0xFFu, ca_a, ca_b);
-          }
-        }
-        if (c_arr && normal) {  // nobody is in recv!: the envelope waits for the next RPC (and is skipped there as stale)
-          const uint4 e = make_uint4(T, ca_y, ca_a, ca_b | (l << 24));
-          if (cin_n < CQ) { my_cq[cin_n * 64u] = e; cin_n++; }
-          else if (csp_n < hp.client_spill) my_cspill[csp_n++] = e;
-          else my_flags |= MSIM_FLAG_INBOX_OVERFLOW;
-        }
-      }
-    }
-
+      #include "group8_clients.inc"
     // ---- history rows: nemesis rows, invocations (lane order), completions (lane order) ----
     {
       const u32 imask = GB(inv_row), cmask = GB(cmp_row);
@@ -712,10 +549,10 @@ __global__ void __launch_bounds__(64) hat8_kernel(const H8Params hp) {
 }
 
 template <int GS>
-hipError_t h8_launch(const H8Params &hp, uint32_t n, size_t lds, bool nem, bool rnd, hipStream_t st) {
+hipError_t h8_launch(const H8Params &up, uint32_t n, size_t lds, bool nem, bool rnd, hipStream_t st) {
   const dim3 grid((n + 64 / GS - 1) / (64 / GS)), block(64);
-  if (nem) { if (rnd) hipLaunchKernelGGL((hat8_kernel<GS, true, true>), grid, block, lds, st, hp); else hipLaunchKernelGGL((hat8_kernel<GS, true, false>), grid, block, lds, st, hp); }
-  else { if (rnd) hipLaunchKernelGGL((hat8_kernel<GS, false, true>), grid, block, lds, st, hp); else hipLaunchKernelGGL((hat8_kernel<GS, false, false>), grid, block, lds, st, hp); }
+  if (nem) { if (rnd) hipLaunchKernelGGL((hat8_kernel<GS, true, true>), grid, block, lds, st, up); else hipLaunchKernelGGL((hat8_kernel<GS, true, false>), grid, block, lds, st, up); }
+  else { if (rnd) hipLaunchKernelGGL((hat8_kernel<GS, false, true>), grid, block, lds, st, up); else hipLaunchKernelGGL((hat8_kernel<GS, false, false>), grid, block, lds, st, up); }
   return hipGetLastError();
 }
 
@@ -741,25 +578,25 @@ hipError_t msim_launch_hat8(const KParams &kp, uint32_t n, hipStream_t st) {
   // against 44.9 ms; 16384: 44.5 / 85.7), 3 nodes between 8192 and 16384 (63 / 53, 75 / 103), 5 nodes near 16384 (112 / 128; 8192:
   // 97 / 68).  MSIM_DEV_FLAGS bit 10 asks for this layout whatever the batch.
   if (n < 8192u * ((c.n_nodes + 1u) / 2u) && !(kp.dev_flags & 0x400u)) return MSIM_LAYOUT_DOES_NOT_FIT;
-  H8Params hp;
-  hp.k = kp; hp.n_inst = n;
+  H8Params up;
+  up.k = kp; up.n_inst = n;
   const uint32_t cap_tot = c.inbox_capacity + c.spill_capacity;
-  hp.node_spill = cap_tot > RQ ? cap_tot - RQ : 0;
-  hp.client_spill = H8_CLIENT_CAP - CQ;
-  hp.client_spill_off = kp.spill_off + (uint64_t)kp.N * hp.node_spill * 4;
+  up.node_spill = cap_tot > RQ ? cap_tot - RQ : 0;
+  up.client_spill = H8_CLIENT_CAP - CQ;
+  up.client_spill_off = kp.spill_off + (uint64_t)kp.N * up.node_spill * 4;
   size_t off = (size_t)RQ * 64 * 16;
-  hp.off_cq = (u32)off; off += (size_t)CQ * 64 * 16;
-  hp.off_gen = (u32)off; off += (size_t)16 * 36 * 4;
+  up.off_cq = (u32)off; off += (size_t)CQ * 64 * 16;
+  up.off_gen = (u32)off; off += (size_t)16 * 36 * 4;
   off = (off + 15) & ~(size_t)15;
-  hp.off_misc = (u32)off; off += 64 * 4;
-  hp.round_limit = (kp.dev_flags & 0x100u) ? 4000000u : ROUND_LIMIT;
+  up.off_misc = (u32)off; off += 64 * 4;
+  up.round_limit = (kp.dev_flags & 0x100u) ? 4000000u : ROUND_LIMIT;
   const size_t lds = off;
   if (kp.dev_flags & 0x1000u) std::fprintf(stderr, "[hat8] %u clusters, several per wavefront, %zu B of LDS per wavefront\n", n, lds);   // developer trace bit
   const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
-  if (rnd) MSIM_UPLOAD_ONCE(h8_log2_q24, msim_log2_q24, sizeof(msim_log2_q24));   // (1 KiB, once per device)
+  if (rnd) MSIM_UPLOAD_ONCE(g8_log2_q24, msim_log2_q24, sizeof(msim_log2_q24));   // (1 KiB, once per device)
   // 8-lane groups for every cluster size: 4-lane groups halve the wavefronts again, and a wavefront's run is a chain of dependent round
   // trips that only other wavefronts hide (16384 clusters of 2 nodes: 58 ms in 4-lane groups, 45 ms in 8-lane groups, 84 ms one per
   // wavefront; at 65536 clusters 139 / 143 / 317 ms).  MSIM_DEV_FLAGS bit 15 selects the 4-lane groups.
   const bool gs4 = c.n_nodes <= 4 && (kp.dev_flags & 0x8000u);
-  return gs4 ? h8_launch<4>(hp, n, lds, c.nemesis_mask != 0, rnd, st) : h8_launch<8>(hp, n, lds, c.nemesis_mask != 0, rnd, st);
+  return gs4 ? h8_launch<4>(up, n, lds, c.nemesis_mask != 0, rnd, st) : h8_launch<8>(up, n, lds, c.nemesis_mask != 0, rnd, st);
 }
