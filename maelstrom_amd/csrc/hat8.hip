@@ -11,7 +11,7 @@
 // ballot, another lane's value comes by `ds_bpermute` within the group, the time reduction is two or three DPP steps (txn8.hip's scheme).
 //
 // Scope (engine.hip picks this kernel when all of it holds, else hat_kernel<> runs): net journal off, max-txn-length <= 4 (the default),
-// at least 8192 clusters per two nodes of a cluster in the launch (msim_launch_hat8 says why).
+// at least 3200 clusters per node of a cluster in the launch (msim_launch_hat8 says why).
 //
 // LDS of a wavefront (slot-major: slot s of lane e at [s * 64 + e]): node queues (RQ envelopes, the rest spills to HBM: inbox_capacity +
 // spill_capacity in all, the oracle's limit), client inboxes (CQ envelopes + HBM spill: 32 in all), per cluster the generator's key
@@ -577,7 +577,7 @@ hipError_t msim_launch_hat8(const KParams &kp, uint32_t n, hipStream_t st) {
   // it.  Measured crossovers (profiles/r03ae_hat8.txt; both kernels with the wavefront-wide list passes): 2 nodes 8192 clusters (37.8
   // against 44.9 ms; 16384: 44.5 / 85.7), 3 nodes between 8192 and 16384 (63 / 53, 75 / 103), 5 nodes near 16384 (112 / 128; 8192:
   // 97 / 68).  MSIM_DEV_FLAGS bit 10 asks for this layout whatever the batch.
-  if (n < 8192u * ((c.n_nodes + 1u) / 2u) && !(kp.dev_flags & 0x400u)) return MSIM_LAYOUT_DOES_NOT_FIT;
+  if (n < 3200u * c.n_nodes && !(kp.dev_flags & 0x400u)) return MSIM_LAYOUT_DOES_NOT_FIT;   // (6400 / 9600 / 16000 clusters of 2 / 3 / 5 nodes)
   H8Params up;
   up.k = kp; up.n_inst = n;
   const uint32_t cap_tot = c.inbox_capacity + c.spill_capacity;
