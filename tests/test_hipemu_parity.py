@@ -3,7 +3,7 @@ oracle — bit for bit, on a machine without a GPU.  Test infrastructure on both
 maelstrom_amd/csrc by tools/hipemu/build_emu.py with the host compiler and loaded through MSIM_LIB in a child process; the product
 library (hipcc, gfx950) is not involved and still refuses to run without a device.  One small case per kernel layout the round touched:
 the two-clusters-per-wavefront broadcast kernel (constant and random latency), the wide kernel with the nodes' sets in LDS and its
-lone-operation path, eight clusters per wavefront for both txn-list-append nodes for txn-rw-register, echo / unique-ids, g-set / the counters and the broadcast programs, the list-append check's workgroup-per-history kernel, the kafka checker's device pass."""
+lone-operation path, eight clusters per wavefront for both txn-list-append nodes for txn-rw-register, echo / unique-ids, g-set / the counters the broadcast programs and kafka (one cluster per wavefront; its committed-offset lookup), the list-append check's workgroup-per-history kernel, the kafka checker's device pass."""
 import os
 import shutil
 import subprocess
@@ -29,6 +29,7 @@ CASES = [
     "{'workload':'pn-counter','node_count':5,'rate':100,'time_limit':12,'latency':50,'latency_dist':'exponential','p_loss':0.1,'flags':0x400,'n':9}",
     "{'workload':'broadcast','bin':'broadcast-ack-retry','node_count':5,'rate':60,'time_limit':8,'latency':10,'nemesis':['partition'],'nemesis_interval':2,'p_loss':0.1,'flags':0x400,'n':9}",
     "{'workload':'broadcast','node_count':5,'rate':100,'time_limit':5,'latency':5,'topology':'line','flags':0x8400,'n':9}",
+    "{'workload':'kafka','node_count':5,'rate':150,'time_limit':6,'latency':20,'latency_dist':'exponential','nemesis':['partition'],'nemesis_interval':2,'n':4}",
 ]
 
 
