@@ -51,6 +51,7 @@ struct RParams {
   u32 *ws;                       // workspace, ws_words per history of this launch
   uint64_t ws_words;
   u32 max_rows, max_pay, nmax, emax, first, cm, proscribed;
+  u32 kmax, wmax;                // keys / writer-table entries the workspace of a history holds (<= KMAX / WMAX: what the configuration can name)
 };
 
 __device__ __forceinline__ u32 r_rl(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
@@ -85,10 +86,10 @@ __global__ void __launch_bounds__(64) rw_check_kernel(const RParams p) {
   u32 *const sm = t_first + NM, *const smf = sm + NM + 1;
   u32 *const indeg = smf + NM + 1, *const off = indeg + NM;   // off [NM + 1]
   u32 *const cur = off + NM + 1, *const queue = cur + NM;
-  u32 *const vseen = queue + NM;             // [KMAX][2] versions of the key that exist (bit v; bit 0 = nil)
-  u32 *const writer = vseen + 2 * KMAX;      // [WMAX]
-  u32 *const vsucc = writer + WMAX;          // [WMAX][2] successors of (key, version) in the key's version order
-  u32 *const adj = vsucc + 2 * WMAX;         // [emax]
+  u32 *const vseen = queue + NM;             // [kmax][2] versions of the key that exist (bit v; bit 0 = nil)
+  u32 *const writer = vseen + 2 * p.kmax;    // [wmax]
+  u32 *const vsucc = writer + p.wmax;        // [wmax][2] successors of (key, version) in the key's version order
+  u32 *const adj = vsucc + 2 * p.wmax;       // [emax]
 
   msim_check_result res;
   res.valid = NEEDS_HOST; res.attempt_count = 0; res.stable_count = 0; res.lost_count = 0; res.never_read_count = 0; res.stale_count = 0;
@@ -155,7 +156,7 @@ __global__ void __launch_bounds__(64) rw_check_kernel(const RParams p) {
   }
   max_key = r_max(max_key); max_val = r_max(max_val);
   const u32 stride = max_val + 1u;
-  if (max_val >= 64u || max_key >= KMAX || (u64)(max_key + 1u) * stride > WMAX) TO_HOST();   // (check_rw answers :unknown for values >= 64)
+  if (max_val >= 64u || max_key >= p.kmax || (u64)(max_key + 1u) * stride > p.wmax) TO_HOST();   // (check_rw answers :unknown for values >= 64)
   for (u32 k = lane; k <= max_key; k += 64) { vseen[2 * k] = 0; vseen[2 * k + 1] = 0; }
   for (u32 k = lane; k < (max_key + 1u) * stride; k += 64) { writer[k] = NONE; vsucc[2 * k] = 0; vsucc[2 * k + 1] = 0; }
   for (u32 t = lane; t <= n; t += 64) { off[t] = 0; if (t < n) { indeg[t] = 0; cur[t] = 0; } }
@@ -358,14 +359,16 @@ __global__ void __launch_bounds__(64) rw_check_kernel(const RParams p) {
 #undef SETBIT
 }
 
-uint64_t rw_ws_words(u32 nmax, u32 emax) { return (uint64_t)nmax * 11 + 4 + 2 * KMAX + 3 * (uint64_t)WMAX + emax; }
+uint64_t rw_ws_words(u32 nmax, u32 emax, u32 kmax, u32 wmax) { return (uint64_t)nmax * 11 + 4 + 2 * (uint64_t)kmax + 3 * (uint64_t)wmax + emax; }
 
 int rw_dev_run(msim_ctx *ctx, RParams rp, u32 n, const std::vector<msim_inst_meta> *hmeta, msim_check_result *h_out, hipStream_t st, u32 *n_host,
                void **ws_buf, size_t *ws_cap) {
   const bool trace = (msim_dev_flags(ctx) & 0x1000u) != 0;   // developer: time the passes
   const auto t0 = std::chrono::steady_clock::now();
   auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
-  rp.ws_words = rw_ws_words(rp.nmax, rp.emax);
+  if (rp.kmax == 0 || rp.kmax > KMAX) rp.kmax = KMAX;
+  if (rp.wmax == 0 || rp.wmax > WMAX) rp.wmax = WMAX;
+  rp.ws_words = rw_ws_words(rp.nmax, rp.emax, rp.kmax, rp.wmax);
   const uint64_t budget = 6ull << 30;   // as many histories per launch as a few GB of workspace hold
   const u32 chunk = (u32)std::min<uint64_t>(n, std::max<uint64_t>(1, budget / (rp.ws_words * 4)));
   const size_t need = (size_t)chunk * rp.ws_words * 4;
@@ -436,6 +439,10 @@ int msim_check_rw_device(msim_ctx *ctx) {
   rp.max_rows = ctx->cfg.max_rows; rp.max_pay = ctx->cfg.max_payload_words;
   rp.nmax = ctx->cfg.max_rows / 2 + 1; rp.emax = rp.nmax * 16;
   rp.cm = ctx->cfg.consistency_model; rp.proscribed = msim_proscribed_anomalies(rp.cm);
+  // a run names keys below max_values and values up to max-writes-per-key (<= 63): tables of that size instead of the 4096 x 16 a caller's
+  // histories may need — 1 MB of workspace per history was four launches of 4096 for the demo shape, each waiting for its slowest history
+  rp.kmax = ctx->cfg.max_values ? ctx->cfg.max_values : 1u;
+  rp.wmax = (u32)std::min<uint64_t>(WMAX, (uint64_t)rp.kmax * (ctx->cfg.max_writes_per_key + 2u));
   u32 redone = 0;
   int rc = rw_dev_run(ctx, rp, n, &hm, ctx->h_check, ctx->stream, &redone, &ctx->d_check_scratch, &ctx->cap_check_scratch);
   if (rc != MSIM_OK) return rc;
