@@ -17,6 +17,11 @@
 //   * history rows are staged in LDS and appended to HBM 64 rows (1 KiB) at a time, one 16-B store per
 //     lane; read results (bitmaps) are copied LDS->HBM by the whole wave, 256 B per instruction.
 //   No MFMA: this is integer/indexing work.  No CUDA/hipify/Triton layers.
+//
+// This file holds the one-cluster-per-wavefront kernels (and the wide layout) and msim_run's choice of a kernel.  Denser layouts live in
+// their own translation units and are taken where a configuration and the batch fit them (DESIGN.md §4.1b has the table): duo.hip (two
+// broadcast clusters per wavefront, the headline), raft4.hip (four), txn8.hip / mk8.hip / hat8.hip / uid8.hip / crdt8.hip / bcast8.hip
+// (eight: the transactional programs, echo / unique-ids, the CRDTs, the broadcast programs at tutorial sizes).
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 
@@ -1031,7 +1036,7 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   if (msim_txn8_eligible(c) && !(kp.dev_flags & 0x200u)) e = msim_launch_txn8(kp, n, st);
   // the canonical txn-list-append node: eight clusters per wavefront (mk8.hip) when a cluster fits an 8-lane group
   if (msim_mk8_eligible(c) && !(kp.dev_flags & 0x200u)) e = msim_launch_mk8(kp, n, st);
-  // txn-rw-register over the highly-available-transactions node: sixteen / eight clusters per wavefront (hat8.hip)
+  // txn-rw-register over the highly-available-transactions node: eight clusters per wavefront (hat8.hip)
   if (msim_hat8_eligible(c) && !(kp.dev_flags & 0x200u)) e = msim_launch_hat8(kp, n, st);
   // echo / unique-ids (flake ids): eight clusters per wavefront (uid8.hip) for large batches of small clusters
   if (msim_uid8_eligible(c) && !(kp.dev_flags & 0x200u)) e = msim_launch_uid8(kp, n, st);
