@@ -299,8 +299,10 @@ def main():
             # the checkers behind histories_per_sec restate [upstream] Jepsen / Knossos / Elle from their published descriptions: no JVM
             # here to pin them against.  Reference-held vectors: pn_counter_test.clj (the counter checker) and the
             # anomalies doc/05-datomic prints (the list-append checker, tests/test_elle_reference_vectors.py); set-full (this line's
-            # checker) and the linearizability search have none in the reference tree
-            "checker_parity": "unpinned for set-full / linearizability; partial (doc vectors) for list-append; pinned (pn_counter_test.clj) for the counters",
+            # checker) and the linearizability search are held to the runs of the real checkers the tutorial prints — closing reads with
+            # the stable / stale / lost elements of doc/03-broadcast/01-broadcast.md:388-430 and 02-performance.md:282-301, the
+            # linearizable run and the write-2-read-4 pair of doc/06-raft/01-key-value.md:131-195 (tests/test_checker_reference_vectors.py)
+            "checker_parity": "partial (doc vectors) for set-full, linearizability and list-append; pinned (pn_counter_test.clj) for the counters",
             "histories_checked": n * k * world, "histories_valid": valid_all, "instances_flagged": flagged_all,
             "msgs_per_instance": msgs_all / (n * k * world),
             "kernel_ms": {"sim": sim_avg, "check": chk_avg},

@@ -69,8 +69,9 @@ enum {
   MSIM_NODE_TXN_RW_HAT = 11,    /* demo/clojure/txn_rw_register_hat.clj:1-190: highly available transactions — every node applies a
                                    txn locally at a Lamport timestamp (last write wins per key), then replicates it to the
                                    others every 100 ms until they acknowledge (the demo of core.clj:115-121)                */
-  MSIM_NODE_TXN_MULTI_KEY = 12, /* demo/js/multi_key_txn.js:1-246 == demo/clojure/multi_key_txn.clj (the JS / Clojure form of
-                                   demo/ruby/datomic_list_append.rb, the workload's demo at core.clj:113-114): thunks in lww-kv, the root
+  MSIM_NODE_TXN_MULTI_KEY = 12, /* demo/js/multi_key_txn.js:1-246 == demo/clojure/multi_key_txn.clj (same architecture as the workload's demo at
+                                   core.clj:113-114, demo/ruby/datomic_list_append.rb, but a different program — that one keeps a persistent
+                                   hash tree of lazily loaded nodes and is NOT built): thunks in lww-kv, the root
                                    map in lin-kv, retry when the root cas is lost (oracle/mk_nodes.inc, pinned by the real program on
                                    the process bridge; csrc/sim_kernel_mk.inc).  One worker per node, at most 30 nodes               */
   MSIM_NODE_KAFKA = 14,         /* demo/clojure/kafka.clj:1-172: logs in 32-message chunks under lin-kv keys (read + cas per send), committed

@@ -8,6 +8,7 @@ built separately by oracle/Makefile (see __graft_entry__.build)."""
 import concurrent.futures as cf
 import hashlib
 import os
+import re
 import subprocess
 import sys
 
@@ -15,7 +16,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 OUT = os.path.join(HERE, "libmaelsim.so")
-SOURCES = ["config.cpp", "engine.hip", "duo.hip", "raft4.hip", "txn8.hip", "mk8.hip", "hat8.hip", "uid8.hip", "crdt8.hip", "bcast8.hip", "checker.hip", "lin_check.cpp", "lin_check_dev.hip", "txn_check.cpp", "txn_check_dev.hip", "rw_check_dev.hip", "pn_check.cpp", "kafka_check.cpp", "kafka_check_dev.hip", "pn_check_dev.hip", "unique_check_dev.hip", "edn.cpp",
+SOURCES = ["config.cpp", "engine.hip",
+           # the one-cluster-per-wavefront kernels (csrc/sim_kernels.h), one unit per family or part of one
+           "k_general_a.hip", "k_general_b.hip", "k_general_c.hip", "k_wide_gset.hip", "k_wide_bcast.hip", "k_wide_ack.hip", "k_wide_pn.hip",
+           "k_raft.hip", "k_svc.hip", "k_txn.hip", "k_mk.hip", "k_kafka.hip", "k_hat.hip",
+           "duo.hip", "raft4.hip", "txn8.hip", "mk8.hip", "hat8.hip", "uid8.hip", "crdt8.hip", "bcast8.hip", "checker.hip", "lin_check.cpp", "lin_check_dev.hip", "txn_check.cpp", "txn_check_dev.hip", "rw_check_dev.hip", "pn_check.cpp", "kafka_check.cpp", "kafka_check_dev.hip", "pn_check_dev.hip", "unique_check_dev.hip", "edn.cpp",
            "fressian.cpp", "gather.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 LINK_LIBS = ["-ldl"]
@@ -23,14 +28,26 @@ LINK_LIBS = ["-ldl"]
 STAMP = OUT + ".stamp"
 
 
+_INC = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
+
+
+def _deps(path, seen=None):
+    """The files `path` includes with #include "..." (recursively), resolved like the compiler does: relative to the including file."""
+    seen = set() if seen is None else seen
+    with open(path, errors="ignore") as f:
+        txt = f.read()
+    for inc in _INC.findall(txt):
+        q = os.path.normpath(os.path.join(os.path.dirname(path), inc))
+        if q not in seen and os.path.exists(q):
+            seen.add(q)
+            _deps(q, seen)
+    return seen
+
+
 def _headers_digest():
-    h = hashlib.sha256(" ".join(FLAGS).encode())
-    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))) + [os.path.join(HERE, "..", "include", "maelsim.h")]
-    for d in deps:
-        h.update(os.path.basename(d).encode())
-        with open(d, "rb") as f:
-            h.update(f.read())
-    return h.hexdigest()
+    """Flags only: every source hashes the headers IT includes (_src_digest), so that a change to one kernel's .inc rebuilds the units
+    that include it and nothing else."""
+    return hashlib.sha256(" ".join(FLAGS).encode()).hexdigest()
 
 
 def _sources():
@@ -39,8 +56,11 @@ def _sources():
 
 def _src_digest(src, hd):
     h = hashlib.sha256(hd.encode())
-    with open(os.path.join(CSRC, src), "rb") as f:
-        h.update(f.read())
+    path = os.path.join(CSRC, src)
+    for d in [path] + sorted(_deps(path)):
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
     return h.hexdigest()
 
 

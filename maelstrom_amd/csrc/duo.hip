@@ -442,7 +442,7 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
     lc_all = !__ballot(next_id - lc_base > 32u);                                                                          \
   } while (0)
 
-#ifdef DUO_PROF   // developer build (tools/duo_prof.sh): wave-round counts and cycles of the two round bodies -> meta
+#ifdef DUO_PROF   // developer build (tools/variant_lib.sh prof duo.hip -DDUO_PROF): wave-round counts and cycles of the two round bodies -> meta
   u64 pf_t0 = __builtin_readcyclecounter(), pf_gen = 0; u32 pf_ngen = 0, pf_nwave = 0;
 #endif
 #if defined(DUO_PROF2) || defined(DUO_PROF3)  // developer builds: cycles of the sections of the gossip round (PROF2) or of the GENERAL round (PROF3)

@@ -18,7 +18,8 @@
 //     lane; read results (bitmaps) are copied LDS->HBM by the whole wave, 256 B per instruction.
 //   No MFMA: this is integer/indexing work.  No CUDA/hipify/Triton layers.
 //
-// This file holds the one-cluster-per-wavefront kernels (and the wide layout) and msim_run's choice of a kernel.  Denser layouts live in
+// This file holds the host runtime and msim_run's choice of a kernel.  The one-cluster-per-wavefront kernels (sim_kernel*.inc, collected by
+// sim_kernels.h) are instantiated by the k_*.hip units; denser layouts live in
 // their own translation units and are taken where a configuration and the batch fit them (DESIGN.md §4.1b has the table): duo.hip (two
 // broadcast clusters per wavefront, the headline), raft4.hip (four), txn8.hip / mk8.hip / hat8.hip / uid8.hip / crdt8.hip / bcast8.hip
 // (eight: the transactional programs, echo / unique-ids, the CRDTs, the broadcast programs at tutorial sizes).
@@ -30,57 +31,8 @@
 #include <new>
 #include <vector>
 
-#include "engine_internal.h"
-#include "wave_common.h"
-#include "log2_table.h"
 
-
-__constant__ u32 d_log2_q24[257];
-
-
-// -ln(u), u = (r+1)/2^32, Q16, integer only
-__device__ __forceinline__ u32 neg_ln_q16(u32 r) {
-  if (r == 0xFFFFFFFFu) return 0;
-  const u32 v = r + 1;
-  const u32 e = 31 - __clz(v);
-  const u32 m = v << (31 - e);
-  const u32 idx = (m >> 23) & 0xFF;
-  const u32 f = (m >> 7) & 0xFFFF;
-  const u32 l0 = d_log2_q24[idx], l1 = d_log2_q24[idx + 1];
-  const u32 lg = (e << 24) + l0 + (u32)(((u64)(l1 - l0) * f) >> 16);
-  const u32 d = (32u << 24) - lg;
-  return (u32)(((u64)d * 2977044472ull) >> 40);
-}
-
-// min (deadline, id) over the n envelopes of an HBM spill area.  The scan is latency-bound — with one dependent load per
-// step every queued envelope costs an L2/HBM round trip — so 8 independent loads are in flight per step.
-__device__ __forceinline__ void spill_min(const uint4 *q, u32 n, u64 &bk, u32 &best, bool &hit) {
-  for (u32 i0 = 0; i0 < n; i0 += 8) {
-    uint2 k[8];
-#pragma unroll
-    for (u32 t = 0; t < 8; t++) k[t] = *reinterpret_cast<const uint2 *>(&q[min(i0 + t, n - 1)]);
-#pragma unroll
-    for (u32 t = 0; t < 8; t++) {
-      const u64 kk = ((u64)k[t].x << 32) | k[t].y;
-      if (i0 + t < n && kk < bk) { bk = kk; best = i0 + t; hit = true; }
-    }
-  }
-}
-
-// merges a W-word replicate snapshot (HBM scratch) into a node's state (LDS): `or` for sets, element-wise max for counters.
-// Both merges are idempotent, so the tail of the last batch re-reads word W-1 instead of branching, and B independent loads
-// are in flight per step (one dependent load per word made every replicate delivery cost W HBM round trips).
-template <bool IS_MAX, int B = 16>
-__device__ __forceinline__ void merge_snapshot(u32 *mine, const u32 *snap, u32 W) {
-  for (u32 w0 = 0; w0 < W; w0 += B) {
-    u32 v[B];
-#pragma unroll
-    for (u32 t = 0; t < B; t++) v[t] = snap[min(w0 + t, W - 1)];
-#pragma unroll
-    for (u32 t = 0; t < B; t++) { const u32 i = min(w0 + t, W - 1); mine[i] = IS_MAX ? max(mine[i], v[t]) : (mine[i] | v[t]); }
-  }
-}
-
+#include "sim_kernels.h"   // the layout constants of the kernels; this unit instantiates none of them (the k_*.hip units do)
 
 // Reference (shuffle) versions, used only by the self-test to validate the DPP encodings on hardware.
 __device__ u32 wave_min_ref(u32 v) { for (int o = 32; o; o >>= 1) v = min(v, (u32)__shfl_xor((int)v, o)); return v; }
@@ -101,655 +53,6 @@ __global__ void wave_selftest_kernel(const u32 *in, u32 *out) {
   out[blockIdx.x * 64 + lane] = bad;
 }
 
-
-// =====================================================================================================
-// The simulation kernel: one wavefront = one cluster.  PROG = node program (MSIM_NODE_*), NEM = the
-// partition nemesis is compiled in, NET_RANDOM = latency is drawn per message and/or messages can be lost
-// (false: constant latency, no loss — no per-message RNG in the hot path).  Follows DESIGN.md §2 step by step; the CPU oracle implements the
-// same text independently.
-//
-// One round:
-//   R0 pick the time: stay at T while anything is due, else jump to the next event (DPP min)
-//   R1 scheduler (generator interpreter, nemesis) — wave-uniform, scalar
-//   R2 marked clients invoke -> COMMIT -> idle receivers poll
-//   R3 one input per node (timer or due message) -> COMMIT -> idle receivers poll
-//   R4 clients run their recv! loop -> completion rows
-// so an RPC to an idle node completes inside one round, and a gossip hop costs one round.
-// =====================================================================================================
-template <int PROG, bool NEM, bool NET_RANDOM>
-__global__ void __launch_bounds__(64, 4) sim_kernel(const KParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint4 *const stage = reinterpret_cast<uint4 *>(smem);
-  uint4 *const inbox = reinterpret_cast<uint4 *>(smem + p.off_inbox);
-  u32 *const seen = reinterpret_cast<u32 *>(smem + p.off_seen);
-  u32 *const misc = reinterpret_cast<u32 *>(smem + p.off_misc);
-
-  constexpr bool IS_BCAST = PROG >= MSIM_NODE_BCAST_FF && PROG <= MSIM_NODE_BCAST_RPC_ALL;
-  constexpr bool IS_RPC = PROG == MSIM_NODE_BCAST_ACK_RETRY || PROG == MSIM_NODE_BCAST_RPC_ALL;
-  constexpr bool IS_ACK = PROG == MSIM_NODE_BCAST_ACK_RETRY;
-  constexpr bool IS_PN = PROG == MSIM_NODE_PN_COUNTER;    // pn_counter.rb: same replication skeleton as g-set, counters instead of a set
-  constexpr bool IS_GSET = PROG == MSIM_NODE_G_SET || IS_PN;  // "CRDT with a 5 s replicate timer"
-  constexpr bool IS_ECHO = PROG == MSIM_NODE_ECHO;
-  constexpr bool IS_FLAKE = PROG == MSIM_NODE_FLAKE_IDS;  // flake_ids.clj: unique-ids workload, Reusable clients (unique_ids.clj:59-61)
-  constexpr bool HAS_FINAL = IS_BCAST || IS_GSET;
-  constexpr bool FINAL_FLAG = IS_BCAST || IS_PN;  // :final? true on the last reads (broadcast.clj:240, pn_counter.clj:137)
-  constexpr bool HAS_TIMERS = IS_ACK || IS_GSET;
-  constexpr bool REP_FIRST = IS_ACK;  // the ack variant replies before it gossips
-  constexpr u32 FAN_TYPE = IS_GSET ? M_REPLICATE : M_BROADCAST;
-  // fan-outs of these programs only ever go to topology neighbours
-  constexpr bool TOPO_BOUND = PROG == MSIM_NODE_BCAST_FF || PROG == MSIM_NODE_BCAST_FF_ECHOBACK || IS_ACK;
-  // programs whose server<->server traffic is plain gossip (no msg_id, no reply): eligible for the cascade loop
-  constexpr bool FAST_OK = PROG == MSIM_NODE_BCAST_FF || PROG == MSIM_NODE_BCAST_FF_ECHOBACK;
-
-  const u32 lane = threadIdx.x;
-  const u32 inst = blockIdx.x;
-  const u32 N = p.N, C = p.C, CS = p.CS, W = p.W;
-  const bool is_node = lane < N;
-  const bool is_client = lane >= N && lane < N + CS;
-  const u32 slot = lane - N;
-  const bool is_worker = is_client && slot < C;
-  const u64 key = mix64(p.cfg.seed + 0x9E3779B97F4A7C15ull * (p.first_instance + inst + 1));
-  const u64 lt_mask = (1ull << lane) - 1;
-  const u32 lt32 = lane < 32 ? ((1u << lane) - 1) : 0xFFFFFFFFu;
-  const u64 worker_mask = ((C >= 64 ? ~0ull : ((1ull << C) - 1)) << N);
-  const u32 all_nodes = N >= 32 ? 0xFFFFFFFFu : ((1u << N) - 1);
-  const u32 max_values = p.cfg.max_values, max_rows = p.cfg.max_rows, max_pay = p.cfg.max_payload_words;
-  const u32 p_loss = p.cfg.p_loss_q32, lat_mean = p.cfg.latency_mean_ms, lat_dist = p.cfg.latency_dist;
-  const u32 rate = p.cfg.rate_mhz;
-
-  msim_op *const g_rows = p.rows + (size_t)inst * max_rows;
-  u32 *const g_pay = p.payload + (size_t)inst * max_pay;
-  u32 *const g_scr = p.scratch + (size_t)inst * p.scratch_words;
-  // ack/retry scratch: unacked[N][V], fifo[N][V][2]; g-set scratch: snapshots[tick][N][W]
-  u32 *const g_unacked = g_scr + (size_t)lane * max_values;
-  u32 *const g_fifo = g_scr + (size_t)N * max_values + (size_t)lane * max_values * 2;
-
-  const u32 jcap = p.cfg.journal_capacity;  // net journal (journal.clj:53,220-239); 0 = off
-  uint4 *const g_ev = p.journal + (size_t)inst * jcap;
-  const u32 my_cap = is_node ? p.cap_node : CLIENT_INBOX_CAP;
-  const u32 my_spill_cap = is_node ? p.spill_cap : 0u;
-  uint4 *const my_inbox = inbox + (is_node ? lane * p.cap_node : (is_client ? N * p.cap_node + slot * CLIENT_INBOX_CAP : 0));
-  uint4 *const my_spill = reinterpret_cast<uint4 *>(g_scr + p.spill_off) + (size_t)(is_node ? lane : 0) * p.spill_cap;  // HBM spill behind the LDS queue
-  u32 *const my_seen = seen + (is_node ? lane : 0) * W;
-
-  for (u32 i = lane; i < N * W; i += 64) seen[i] = 0;
-  if (IS_ACK) { if (is_node) for (u32 v = 0; v < max_values; v++) g_unacked[v] = 0; }
-  __syncthreads();
-
-  const u32 adj = is_node ? topo_adj(p.cfg.topology, N, lane) : 0;
-  // which lanes can ever address a fan-out to this node
-  const u32 cand_all = is_node ? (TOPO_BOUND ? adj : (all_nodes & ~(1u << lane))) : 0u;
-  const u32 c_mod_n = C % N;
-
-  // ---- per-lane endpoint state ----
-  bool has_c = false; u32 deliver_at = 0; uint4 cm = make_uint4(0, 0, 0, 0);  // the envelope recv! is sleeping on
-  bool have_pm = false; uint4 pm = make_uint4(0, 0, 0, 0);                    // smallest arrival of this commit
-  u32 in_n = 0, sp_n = 0;                                                     // queued envelopes in LDS / in the HBM spill
-  u32 node_msgid = 0, timer_next = INF, tick = 0, part = 0;
-  u32 flake_time = 0, flake_count = 0;  // flake_ids.clj:10-14
-  u32 fifo_head = 0, fifo_tail = 0, retry_time = INF;
-  bool busy = false, mark = false; u32 kind = K_NONE;
-  u32 want = 0, timeout_at = 0, next_msg_id = 0, c_f = 0, c_value = 0, process = slot, c_final = 0;
-  u32 dest_node = is_client ? slot % N : 0;  // nodes[process mod n] [upstream], kept incrementally
-  u32 m_f = 0, m_value = 0, m_final = 0;
-  u32 s_send_cl = 0, s_send_sv = 0, s_recv_cl = 0, s_recv_sv = 0, my_flags = 0;
-  // ---- wave-uniform state ----
-  u32 T = 0, phase = PH_INIT, cutoff = 0, gen_next = 0, gen_k = 0, next_value = 0, nem_next = 0, nem_j = 0;
-  u32 sleep_until = 0, loss_on = 0, next_id = 0, n_rows = 0, n_payload = 0, flags = 0, rounds = 0;
-  u32 n_ev = 0, ev_base = 0, id_base = 0;  // journal cursor; :send events of a COMMIT sit at ev_base + (id - id_base)
-
-  // one journal event (event :id = idx); y = (message id << 8) | body type
-  auto jwrite = [&](u32 idx, u32 recv, u32 y, u32 a, u32 b, u32 src, u32 dest) {
-    if (idx < jcap) g_ev[idx] = make_uint4(T, (y & ~0x80u) | (recv << 7), a, src | (dest << 8) | ((b & 0xFFFFu) << 16));
-    else my_flags |= MSIM_FLAG_JOURNAL_OVERFLOW;
-  };
-  // queue an envelope in this lane's LDS inbox
-  auto lds_push = [&](const uint4 m) {
-    if (in_n < my_cap) { my_inbox[in_n++] = m; return; }
-    if (sp_n < my_spill_cap) { my_spill[sp_n++] = m; return; }
-    my_flags |= MSIM_FLAG_INBOX_OVERFLOW;
-  };
-  // a message addressed to this lane arrives (net.clj:189-221: latency, loss, enqueue)
-  auto arrive = [&](u32 id, u32 type, u32 a, u32 b, u32 src) {
-    u32 lat = 0;
-    if (src < N && is_node) {  // latency only between servers (net.clj:178-187)
-      if (!NET_RANDOM || lat_dist == MSIM_LAT_CONSTANT) lat = lat_mean;
-      else if (lat_dist == MSIM_LAT_UNIFORM) lat = scale32(draw32(key, S_LATENCY, id), 2 * lat_mean);
-      else lat = (u32)(((u64)lat_mean * neg_ln_q16(draw32(key, S_LATENCY, id))) >> 16);
-    }
-    if (jcap) jwrite(ev_base + (id - id_base), 0, (id << 8) | type, a, b, src, lane);  // journal :send precedes the loss decision (net.clj:208)
-    if (NET_RANDOM && loss_on && p_loss && draw32(key, S_LOSS, id) < p_loss) return;  // net.clj:214
-    uint4 m = make_uint4(T + lat * 1000u, (id << 8) | type, a, b | (src << 24));
-    if (!have_pm) { pm = m; have_pm = true; return; }
-    if (m.x < pm.x || (m.x == pm.x && m.y < pm.y)) { const uint4 t = m; m = pm; pm = t; }
-    lds_push(m);
-  };
-  // commit an envelope to this receiver: partition check at poll time (net.clj:234), sleep floor(dt) ms (:236-238)
-  auto try_commit = [&](const uint4 e) {
-    const u32 src = e.w >> 24;
-    if (NEM && is_node && src < N && ((part >> src) & 1)) return;  // dropped, no :recv
-    cm = e; has_c = true;
-    deliver_at = e.x <= T ? T : T + ((e.x - T) / 1000u) * 1000u;
-  };
-  // idle receivers poll (net.clj:223-247): min (deadline, id) over queued + just-arrived envelopes
-  auto poll = [&]() {
-    const bool elig = is_node || busy;  // clients only poll inside recv! (client.clj:94-95)
-    if (have_pm) {
-      have_pm = false;
-      if (elig && !has_c && (in_n | sp_n) == 0) try_commit(pm);  // common case: nothing queued, no LDS traffic
-      else lds_push(pm);
-    }
-    while (elig && !has_c && (in_n | sp_n) != 0) {
-      u32 best = 0; bool in_spill = false;
-      u64 bk = ~0ull;
-      for (u32 i = 0; i < in_n; i++) {
-        const uint2 kk = *reinterpret_cast<const uint2 *>(&my_inbox[i]);
-        const u64 k2 = ((u64)kk.x << 32) | kk.y;
-        if (k2 < bk) { bk = k2; best = i; }
-      }
-      spill_min(my_spill, sp_n, bk, best, in_spill);  // deep queues only (long head-of-line sleeps)
-      uint4 e;
-      if (in_spill) { e = my_spill[best]; sp_n--; if (best != sp_n) my_spill[best] = my_spill[sp_n]; }
-      else { e = my_inbox[best]; in_n--; if (best != in_n) my_inbox[best] = my_inbox[in_n]; }
-      try_commit(e);
-    }
-  };
-  // COMMIT of the nodes' fan-outs, receiver side: every node pulls from the lanes that may address it.
-  // ids = next_id + id_off(sender) + rank of the receiver inside the sender's fan mask (net.clj:197).
-  auto commit_fan = [&](u32 fan_mask, u32 fan_a, u32 fan_b0, u32 id_off) {
-    const u32 send = (u32)__ballot(fan_mask != 0);
-    u32 cand = cand_all & send;
-    while (__ballot(cand != 0)) {
-      const bool has = cand != 0;
-      const u32 s = has ? (u32)__builtin_ctz(cand) : 0u;
-      cand &= cand - 1;
-      const u32 fs = lane_get(fan_mask, s);
-      const u32 as = lane_get(fan_a, s);
-      const u32 os = lane_get(id_off, s);
-      u32 bs = 0;
-      if (IS_RPC) bs = lane_get(fan_b0, s);
-      if (has && ((fs >> lane) & 1)) {
-        const u32 rank = __popc(fs & lt32);
-        arrive(next_id + os + rank, FAN_TYPE, as, IS_RPC ? bs + rank : 0u, s);
-      }
-    }
-  };
-
-  for (;;) {
-    const u64 busy_mask = __ballot(busy);  // only client lanes are ever busy
-
-    // ---- time-free phase transitions (oracle: sched_resolve) ----
-    if (!(phase == PH_MAIN && ((rate > 0 && gen_next < cutoff) || (NEM && nem_next < cutoff)))) {
-      for (bool again = true; again;) {
-        again = false;
-        switch (phase) {
-          case PH_INIT_WAIT: if (!busy_mask) { phase = IS_BCAST ? PH_TOPO : PH_MAIN_START; again = true; } break;
-          case PH_TOPO_WAIT: if (!busy_mask) { phase = PH_MAIN_START; again = true; } break;
-          case PH_MAIN_START:
-            cutoff = T + p.cfg.time_limit_ms * 1000u; gen_next = T; nem_next = T;
-            next_msg_id = 0; loss_on = 1; phase = PH_MAIN; again = true; break;
-          case PH_MAIN: {
-            const bool gl = rate > 0 && gen_next < cutoff, nl = NEM && nem_next < cutoff;
-            if (gl || nl) break;
-            if (rate == 0 && T < cutoff) break;
-            phase = PH_DRAIN; again = true;
-          } break;
-          case PH_DRAIN:
-            if (busy_mask & worker_mask) break;
-            phase = (NEM && HAS_FINAL) ? PH_NEM_FINAL : HAS_FINAL ? PH_SLEEP : PH_DONE;
-            if (phase == PH_SLEEP) sleep_until = T + p.cfg.quiesce_ms * 1000u;
-            again = true; break;
-          case PH_FINAL_WAIT: if (!(busy_mask & worker_mask)) { phase = PH_DONE; again = true; } break;
-          default: break;
-        }
-      }
-      if (phase == PH_DONE) break;
-    }
-    if (++rounds > ROUND_LIMIT) { flags |= MSIM_FLAG_ROUND_LIMIT; break; }
-
-    // ---- R0: time ----
-    const bool gen_live = rate > 0 && gen_next < cutoff;
-    const bool nem_live = NEM && nem_next < cutoff;
-    const u64 free_mask = worker_mask & ~busy_mask;
-    u32 due = INF;
-    switch (phase) {
-      case PH_INIT: case PH_TOPO: case PH_NEM_FINAL: case PH_FINAL: due = T; break;
-      case PH_SLEEP: due = sleep_until; break;
-      case PH_MAIN:
-        if (nem_live) due = max(nem_next, T);
-        if (gen_live && free_mask) due = min(due, max(gen_next, T));
-        if (rate == 0 && !nem_live) due = min(due, cutoff);
-        break;
-      default: break;
-    }
-    u32 my_t = has_c ? deliver_at : INF;  // this lane's next "normal" event
-    if (HAS_TIMERS && is_node) my_t = min(my_t, min(timer_next, retry_time));
-    bool timeout_round = false;
-    if (due > T && !__ballot(my_t <= T)) {  // nothing due now: jump to the next event
-      u32 k = my_t == INF ? INF : my_t * 2;
-      if (busy) k = min(k, timeout_at * 2 + 1);
-      u32 km = wave_min(k);
-      if (due != INF) km = min(km, due * 2);
-      if (km == INF) { flags |= MSIM_FLAG_ROUND_LIMIT; break; }  // stuck
-      timeout_round = (km & 1) != 0;
-      T = max(T, km >> 1);
-    }
-
-    bool inv_row = false; u32 inv_packed = 0, inv_value = 0;               // invoke row of this round
-    bool cmp_row = false; u32 cmp_packed = 0, cmp_value = 0, cmp_len = 0;  // completion row of this round
-    u32 nem_rows = 0, nem_f = 0, nem_v1 = 0, nem_v2 = 0, nem_len2 = 0;
-
-    // completion of a client op (oracle: client_complete)
-    auto complete = [&](u32 type, u32 err, u32 value, u32 len) {
-      busy = false;
-      if (kind != K_OP) { if (type != MSIM_T_OK) my_flags |= MSIM_FLAG_ROUND_LIMIT; return; }
-      cmp_row = true; cmp_packed = type | (c_f << 2) | (err << 7) | (c_final << 11) | (process << 12);
-      cmp_value = value; cmp_len = len;
-      if (type == MSIM_T_INFO) {  // crashed process: new process id, fresh client [upstream interpreter]
-        process += C; dest_node += c_mod_n; if (dest_node >= N) dest_node -= N;
-        if (!IS_FLAKE) { next_msg_id = 0; in_n = 0; }  // Reusable clients (unique_ids.clj:59-61) are not re-opened
-      }
-    };
-
-    if (timeout_round) {
-      if (busy && timeout_at <= T) {  // client.clj:96-103 + :158-162
-        const bool idem = IS_BCAST && c_f == MSIM_F_READ;
-        complete(idem ? MSIM_T_FAIL : MSIM_T_INFO, MSIM_ERR_NET_TIMEOUT, c_f == MSIM_F_READ ? MSIM_NO_VALUE : c_value, 0);
-      }
-    } else {
-      // ---- R1: scheduler (generator interpreter, nemesis) — wave-uniform ----
-      if (due <= T) {
-        switch (phase) {
-          case PH_INIT: if (is_client && slot < N) { mark = true; kind = K_INIT; } phase = PH_INIT_WAIT; break;
-          case PH_TOPO: if (is_client && slot < N) { mark = true; kind = K_TOPO; } phase = PH_TOPO_WAIT; break;
-          case PH_MAIN: {
-            if (NEM && nem_live && nem_next <= T) {
-              const u32 j = nem_j++;
-              nem_rows = 2;
-              if ((j & 1) == 0) {  // :start-partition (jepsen.nemesis.combined partition-package, restated)
-                const u32 spec = scale32(draw32(key, S_NEM_SPEC, j), 4);
-                // shuffle (Fisher-Yates) in LDS by lane 0; every node lane then derives its own grudge row
-                if (lane < N) misc[lane] = lane;
-                __syncthreads();
-                if (lane == 0 && spec != MSIM_SPEC_ONE) {
-                  for (u32 i = N - 1; i >= 1; i--) {
-                    const u32 kk = scale32(draw32(key, S_NEM_SHUFFLE, ((u64)j << 16) | i), i + 1);
-                    const u32 t = misc[i]; misc[i] = misc[kk]; misc[kk] = t;
-                  }
-                }
-                __syncthreads();
-                u32 my_part = 0;
-                if (is_node) {
-                  if (spec == MSIM_SPEC_ONE) {
-                    const u32 loner = scale32(draw32(key, S_NEM_PICK, j), N);
-                    my_part = lane == loner ? (all_nodes & ~(1u << loner)) : (1u << loner);
-                  } else if (spec == MSIM_SPEC_MAJORITY || spec == MSIM_SPEC_MINORITY_THIRD) {
-                    const u32 cnt = spec == MSIM_SPEC_MAJORITY ? N / 2 : (N - 1) / 3;
-                    u32 comp = 0;
-                    for (u32 i = 0; i < cnt; i++) comp |= 1u << misc[i];
-                    my_part = ((comp >> lane) & 1) ? (all_nodes & ~comp) : comp;
-                  } else {  // majorities-ring
-                    const u32 m = N / 2 + 1;
-                    u32 pos = 0;
-                    for (u32 i = 0; i < N; i++) if (misc[i] == lane) pos = i;
-                    const u32 i0 = (pos + N - (m / 2) % N) % N;
-                    u32 vis = 0;
-                    for (u32 kk = 0; kk < m; kk++) vis |= 1u << misc[(i0 + kk) % N];
-                    my_part = all_nodes & ~vis;
-                  }
-                }
-                part |= my_part;
-                const u32 words = N * MSIM_MASK_WORDS;
-                u32 off = 0;
-                if (n_payload + words > max_pay) flags |= MSIM_FLAG_PAYLOAD_OVERFLOW;
-                else {
-                  off = n_payload; n_payload += words;
-                  if (is_node) { g_pay[off + lane * 4] = part; g_pay[off + lane * 4 + 1] = 0; g_pay[off + lane * 4 + 2] = 0; g_pay[off + lane * 4 + 3] = 0; }
-                }
-                nem_f = MSIM_F_START_PARTITION; nem_v1 = spec; nem_v2 = off; nem_len2 = words;
-              } else {  // :stop-partition -> heal! (net.clj:112-113)
-                part = 0;
-                nem_f = MSIM_F_STOP_PARTITION; nem_v1 = MSIM_NO_VALUE; nem_v2 = MSIM_NO_VALUE; nem_len2 = 0;
-              }
-              nem_next = T + __umulhi(draw32(key, S_NEM_STAGGER, j), p.nem_period2_us);
-            }
-            if (gen_live && gen_next <= T && free_mask) {
-              // one 64-bit draw per generated op: high word -> stagger, low word -> pick / mix / echo payload
-              const u32 nfree = __popcll(free_mask);
-              const u32 kk = gen_k++;
-              const u64 h = draw64(key, S_GEN, kk);
-              const u32 r_hi = (u32)(h >> 32), r_lo = (u32)h;
-              const u32 pick = scale32(r_lo, nfree);
-              const bool sel = is_worker && !busy && (u32)__popcll(free_mask & lt_mask) == pick;
-              u32 f, val = MSIM_NO_VALUE;
-              bool ok = true;
-              if (IS_ECHO) { f = MSIM_F_ECHO; val = (r_lo >> 4) & 127; }
-              else if (IS_FLAKE) f = MSIM_F_GENERATE;  // (gen/repeat {:f :generate}), unique_ids.clj:72
-              else if (IS_PN && p.cfg.workload == MSIM_WL_G_COUNTER) {
-                // g_counter.clj:37-41: (gen/filter ...) skips negative adds and takes the mix's next op at once
-                u32 rr = r_lo, a = 0;
-                int d = (int)((((rr >> 4) & 0xFFFFu) * 10u) >> 16) - 5;
-                while (!(rr & 1) && d < 0 && a < 15) { a++; rr = (u32)draw64(key, S_GEN2, (u64)kk * 16 + a); d = (int)((((rr >> 4) & 0xFFFFu) * 10u) >> 16) - 5; }
-                if ((rr & 1) || d < 0) f = MSIM_F_READ; else { f = MSIM_F_ADD; val = (u32)d; }
-              }
-              else if (r_lo & 1) f = MSIM_F_READ;
-              else {
-                f = IS_BCAST ? MSIM_F_BROADCAST : MSIM_F_ADD;
-                if (IS_PN) val = (u32)((int)((((r_lo >> 4) & 0xFFFFu) * 10u) >> 16) - 5);  // (- (rand-int 10) 5), pn_counter.clj:134-135
-                else if (next_value >= max_values) { flags |= MSIM_FLAG_VALUES_OVERFLOW; ok = false; }
-                else val = next_value++;
-              }
-              if (!ok) { phase = PH_DONE; break; }
-              if (sel) { mark = true; kind = K_OP; m_f = f; m_value = val; m_final = 0; }
-              gen_next = T + __umulhi(r_hi, p.gen_period2_us);
-            }
-          } break;
-          case PH_NEM_FINAL:
-            part = 0; nem_rows = 2; nem_f = MSIM_F_STOP_PARTITION; nem_v1 = MSIM_NO_VALUE; nem_v2 = MSIM_NO_VALUE;
-            phase = PH_SLEEP; sleep_until = T + p.cfg.quiesce_ms * 1000u; break;
-          case PH_SLEEP:
-            if (T < sleep_until) break;
-            phase = PH_FINAL;
-            [[fallthrough]];
-          case PH_FINAL:
-            if (is_worker) { mark = true; kind = K_OP; m_f = MSIM_F_READ; m_value = MSIM_NO_VALUE; m_final = FINAL_FLAG ? 1 : 0; }
-            phase = PH_FINAL_WAIT; break;
-          default: break;
-        }
-        if (phase == PH_DONE) break;
-      }
-
-      // ---- R2: marked clients invoke; COMMIT (ids in slot order); idle receivers poll ----
-      u64 inv_mask = __ballot(mark);
-      if (inv_mask) {
-        u32 rq_dest = 0, rq_type = 0, rq_a = 0;
-        if (mark) {  // oracle: client_invoke
-          mark = false; busy = true;
-          if (kind == K_INIT) { rq_dest = slot; rq_type = M_INIT; next_msg_id = 0; }
-          else if (kind == K_TOPO) { rq_dest = slot; rq_type = M_TOPOLOGY; next_msg_id = 0; }
-          else {
-            c_f = m_f; c_value = m_value; c_final = m_final;
-            rq_dest = dest_node;
-            inv_row = true; inv_packed = MSIM_T_INVOKE | (c_f << 2) | (c_final << 11) | (process << 12); inv_value = c_value;
-            rq_type = c_f == MSIM_F_ECHO ? M_ECHO : c_f == MSIM_F_BROADCAST ? M_BROADCAST : c_f == MSIM_F_ADD ? M_ADD : c_f == MSIM_F_GENERATE ? M_GENERATE : M_READ;
-            rq_a = (c_f == MSIM_F_READ || c_f == MSIM_F_GENERATE) ? 0u : c_value;
-          }
-          want = ++next_msg_id;
-          timeout_at = T + (kind == K_OP ? p.cfg.client_timeout_ms : 10000u) * 1000u;
-          s_send_cl++;
-        }
-        const u32 rq_pack = rq_dest | (rq_type << 8);
-        ev_base = n_ev; id_base = next_id; n_ev += (u32)__popcll(inv_mask);
-        while (inv_mask) {
-          const u32 s = (u32)__builtin_ctzll(inv_mask); inv_mask &= inv_mask - 1;
-          const u32 pk = rdlane(rq_pack, s);
-          const u32 a = rdlane(rq_a, s), b = rdlane(want, s);
-          if (lane == (pk & 0xFF)) arrive(next_id, pk >> 8, a, b, s);
-          next_id++;
-        }
-        poll();
-      }
-
-      // ---- R3: one input per node: a due timer, else the due committed envelope ----
-      u32 fan_mask = 0, fan_a = 0, fan_b0 = 0;
-      bool rep = false; u32 rep_dest = 0, rep_type = 0, rep_a = 0, rep_b = 0;
-      bool rd = false;
-      u64 jd_mask = 0;  // nodes delivering an envelope this round (their :recv events come first, node order)
-      if (jcap) jd_mask = __ballot(is_node && !(IS_GSET && timer_next <= T) && !(IS_ACK && retry_time <= T) && has_c && deliver_at <= T);
-      if (is_node) {
-        if (IS_GSET && timer_next <= T) {  // g_set.rb:33-38
-          timer_next = T + 5000000u;
-          u32 *snap = g_scr + ((size_t)tick * N + lane) * W;
-          for (u32 w = 0; w < W; w++) snap[w] = my_seen[w];
-          fan_mask = all_nodes & ~(1u << lane); fan_a = tick; tick++;
-        } else if (IS_ACK && retry_time <= T) {  // gossip thread wakes (02-performance.md:421-438)
-          const u32 slot_i = (fifo_head % max_values) * 2;
-          const u32 v = g_fifo[slot_i];
-          fifo_head++;
-          const u32 un = g_unacked[v];
-          if (un) {
-            fan_mask = un; fan_a = v; fan_b0 = node_msgid + 1; node_msgid += __popc(un);
-            const u32 ts = (fifo_tail % max_values) * 2;
-            g_fifo[ts] = v; g_fifo[ts + 1] = T + 1000000u; fifo_tail++;
-          }
-          retry_time = fifo_head < fifo_tail ? g_fifo[(fifo_head % max_values) * 2 + 1] : INF;
-        } else if (has_c && deliver_at <= T) {
-          const uint4 q = cm; has_c = false;
-          const u32 qsrc = q.w >> 24, qb = q.w & 0xFFFFFFu, qtype = q.y & 0xFFu, qa = q.z;
-          if (qsrc >= N) s_recv_cl++; else s_recv_sv++;  // journal :recv (net.clj:244)
-          if (jcap) jwrite(n_ev + (u32)__popcll(jd_mask & lt_mask), 1, q.y, qa, qb, qsrc, lane);
-          switch (qtype) {
-            case M_INIT:
-              if (IS_GSET) timer_next = T;
-              rep = true; rep_dest = qsrc; rep_type = M_INIT_OK; rep_b = qb; break;
-            case M_TOPOLOGY: rep = true; rep_dest = qsrc; rep_type = M_TOPOLOGY_OK; rep_b = qb; break;
-            case M_ECHO: rep = true; rep_dest = qsrc; rep_type = M_ECHO_OK; rep_a = qa; rep_b = qb; break;
-            case M_GENERATE: {  // flake_ids.clj:16-31: [max(now in s, last time), counter within that second, node]
-              u32 t = T / 1000000u;
-              if (t < flake_time) t = flake_time;
-              flake_count = t == flake_time ? flake_count + 1 : 0u; flake_time = t;
-              rep = true; rep_dest = qsrc; rep_type = M_GENERATE_OK; rep_a = (t << 20) | ((flake_count & 0x7FFFu) << 5) | lane; rep_b = qb;
-            } break;
-            case M_READ:
-              rep = true; rep_dest = qsrc; rep_type = M_READ_OK; rep_b = qb;
-              if (IS_PN) { u32 v = 0; for (u32 i = 0; i < N; i++) v += my_seen[i] - my_seen[N + i]; rep_a = v; }  // increments - decrements
-              else rd = true;
-              break;
-            case M_ADD:
-              if (IS_PN) { const int d = (int)qa; if (d >= 0) my_seen[lane] += (u32)d; else my_seen[N + lane] += (u32)(-d); }  // own slot of inc / dec
-              else my_seen[qa >> 5] |= 1u << (qa & 31);
-              rep = true; rep_dest = qsrc; rep_type = M_ADD_OK; rep_a = qa; rep_b = qb; break;
-            case M_REPLICATE: {
-              const u32 *snap = g_scr + ((size_t)qa * N + qsrc) * W;
-              if (IS_PN) merge_snapshot<true>(my_seen, snap, W);  // element-wise max
-              else merge_snapshot<false>(my_seen, snap, W);
-            } break;
-            case M_BROADCAST: {
-              const u32 v = qa, bitm = 1u << (v & 31);
-              const u32 wv = my_seen[v >> 5];
-              if (!(wv & bitm)) {
-                my_seen[v >> 5] = wv | bitm;
-                u32 tg = PROG == MSIM_NODE_BCAST_RPC_ALL ? (all_nodes & ~(1u << lane)) : adj;
-                if (PROG != MSIM_NODE_BCAST_FF_ECHOBACK && qsrc < N) tg &= ~(1u << qsrc);
-                fan_mask = tg; fan_a = v;
-                if (IS_RPC) { fan_b0 = node_msgid + 1; node_msgid += __popc(tg); }
-                if (IS_ACK && tg) {
-                  g_unacked[v] = tg;
-                  const u32 ts = (fifo_tail % max_values) * 2;
-                  g_fifo[ts] = v; g_fifo[ts + 1] = T + 1000000u;
-                  if (fifo_head == fifo_tail) retry_time = T + 1000000u;
-                  fifo_tail++;
-                }
-              }
-              if (qb != 0) { rep = true; rep_dest = qsrc; rep_type = M_BROADCAST_OK; rep_a = v; rep_b = qb; }
-            } break;
-            case M_BROADCAST_OK: if (IS_ACK) g_unacked[qa] &= ~(1u << qsrc); break;
-            default: break;
-          }
-        }
-      }
-
-      n_ev += (u32)__popcll(jd_mask);
-      // read results: the whole wave copies the node's set LDS -> HBM payload (256 B per instruction)
-      {
-        u64 rdmask = __ballot(rd);
-        if (rdmask) {
-          __syncthreads();
-          const u32 words = (next_value + 31) >> 5;
-          while (rdmask) {
-            const u32 r = (u32)__builtin_ctzll(rdmask); rdmask &= rdmask - 1;
-            u32 off = 0;
-            if (n_payload + words > max_pay) flags |= MSIM_FLAG_PAYLOAD_OVERFLOW;
-            else {
-              off = n_payload; n_payload += words;
-              for (u32 w = lane; w < words; w += 64) g_pay[off + w] = seen[r * W + w];
-            }
-            if (lane == r) rep_a = off | (words << 24);
-          }
-        }
-      }
-
-      // COMMIT node sends (net.clj:189-221): ids in node order, then emission order
-      {
-        const u32 fan_cnt = __popc(fan_mask);
-        const u32 cnt = fan_cnt + (rep ? 1u : 0u);
-        if (__ballot(cnt != 0)) {
-          const u32 incl = scan32(cnt);  // senders are node lanes (< 32)
-          ev_base = n_ev; id_base = next_id; n_ev += rdlane(incl, 31);
-          if (is_node) { s_send_sv += fan_cnt; if (rep) { if (rep_dest >= N) s_send_cl++; else s_send_sv++; } }
-          if (__ballot(fan_mask != 0)) commit_fan(fan_mask, fan_a, fan_b0, incl - cnt + ((REP_FIRST && rep) ? 1u : 0u));
-          u64 reps = __ballot(rep);
-          if (reps) {
-            const u32 rep_pack = rep_dest | (rep_type << 8);
-            const u32 rep_off = incl - cnt + (REP_FIRST ? 0u : fan_cnt);
-            while (reps) {
-              const u32 s = (u32)__builtin_ctzll(reps); reps &= reps - 1;
-              const u32 pk = rdlane(rep_pack, s), o = rdlane(rep_off, s);
-              const u32 r_a = rdlane(rep_a, s), r_b = rdlane(rep_b, s);
-              if (lane == (pk & 0xFF)) arrive(next_id + o, pk >> 8, r_a, r_b, s);
-            }
-          }
-          next_id += rdlane(incl, 31);
-        }
-        poll();  // every round: a node that just went idle may still have queued envelopes
-      }
-
-      // ---- R4: clients run their recv! loops (client.clj:94-107); envelope k of every client before envelope k+1 ----
-      for (;;) {
-        const bool dl = is_client && has_c && deliver_at <= T;
-        const u64 dm = __ballot(dl);
-        if (!dm) break;
-        if (dl) {
-          const uint4 q = cm; has_c = false;
-          s_recv_cl++;
-          const u32 qb = q.w & 0xFFFFFFu, qtype = q.y & 0xFFu, qa = q.z;
-          if (jcap) jwrite(n_ev + (u32)__popcll(dm & lt_mask), 1, q.y, qa, qb, q.w >> 24, lane);
-          if (busy && qb == want) {  // else: stale reply, keep polling (client.clj:105-107)
-            if (qtype == M_READ_OK) { if (IS_PN) complete(MSIM_T_OK, 0, qa, 0); else complete(MSIM_T_OK, 0, qa & 0xFFFFFFu, qa >> 24); }
-            else if (qtype == M_ECHO_OK || qtype == M_GENERATE_OK) complete(MSIM_T_OK, 0, qa, 0);
-            else complete(MSIM_T_OK, 0, c_value, 0);
-          }
-          poll();
-        }
-        n_ev += (u32)__popcll(dm);
-      }
-    }
-
-    // ---- history rows: canonical order = nemesis rows, invokes (slot order), completions (slot order) ----
-    {
-      const u64 imask = __ballot(inv_row), cmask = __ballot(cmp_row);
-      const u32 ni = (u32)__popcll(imask);
-      const u32 nr = nem_rows + ni + (u32)__popcll(cmask);
-      if (nr) {
-        if (n_rows + nr > max_rows) { flags |= MSIM_FLAG_ROWS_OVERFLOW; break; }
-        const u32 tlo = (u32)((u64)T * 1000ull), thi = (u32)(((u64)T * 1000ull) >> 32);
-        if (NEM && nem_rows && lane == 0) {
-          const u32 pk = MSIM_T_INFO | (nem_f << 2) | (MSIM_PROCESS_NEMESIS << 12);
-          stage[n_rows % STAGE_ROWS] = make_uint4(tlo, thi, pk, nem_v1);
-          stage[(n_rows + 1) % STAGE_ROWS] = make_uint4(tlo, thi | (nem_len2 << 16), pk, nem_v2);
-        }
-        if (inv_row) stage[(n_rows + nem_rows + (u32)__popcll(imask & lt_mask)) % STAGE_ROWS] = make_uint4(tlo, thi, inv_packed, inv_value);
-        if (cmp_row) stage[(n_rows + nem_rows + ni + (u32)__popcll(cmask & lt_mask)) % STAGE_ROWS] = make_uint4(tlo, thi | (cmp_len << 16), cmp_packed, cmp_value);
-        const u32 new_n = n_rows + nr;
-        if ((new_n >> 6) != (n_rows >> 6)) {  // a 64-row block completed: coalesced 1 KiB append to HBM
-          __syncthreads();
-          for (u32 blk = n_rows >> 6; blk < (new_n >> 6); blk++) {
-            const u32 gi = blk * 64 + lane;
-            if (gi < max_rows) reinterpret_cast<uint4 *>(g_rows)[gi] = stage[gi % STAGE_ROWS];
-          }
-          __syncthreads();
-        }
-        n_rows = new_n;
-      }
-    }
-
-    // ---- cascade loop: while the scheduler is quiet at T and only plain gossip is due, every round is
-    //      R3 + COMMIT + poll (no scheduler, no clients, no rows).  Same rounds the loop above would run. ----
-    if (FAST_OK && !timeout_round) {
-      const u64 bm = __ballot(busy);
-      bool quiet = false;
-      u32 d2 = INF;  // when the scheduler next wants to act (the clients' busy set cannot change inside this loop)
-      if (phase == PH_MAIN) {
-        const bool gl = rate > 0 && gen_next < cutoff, nl = NEM && nem_next < cutoff;
-        if (gl || nl) {
-          if (nl) d2 = max(nem_next, T);
-          if (gl && (worker_mask & ~bm)) d2 = min(d2, max(gen_next, T));
-          quiet = d2 > T;
-        }
-      } else if (phase == PH_SLEEP) { d2 = sleep_until; quiet = d2 > T; }
-      while (quiet) {
-        bool due_now = has_c && deliver_at <= T;  // only node lanes hold an envelope across rounds
-        if (!__ballot(due_now)) {
-          // R0 inside the loop: jump to the next delivery if it precedes the scheduler and every client timeout
-          u32 k = has_c ? deliver_at * 2 : INF;
-          if (busy) k = min(k, timeout_at * 2 + 1);
-          const u32 km = wave_min(k);
-          if (km == INF || (km & 1) || (km >> 1) >= d2) break;
-          T = km >> 1;
-          due_now = has_c && deliver_at <= T;
-        }
-        const bool plain = (cm.y & 0xFFu) == M_BROADCAST && (cm.w & 0xFFFFFFu) == 0;
-        if (__ballot(due_now && !plain)) break;
-        if (++rounds > ROUND_LIMIT) { flags |= MSIM_FLAG_ROUND_LIMIT; phase = PH_DONE; break; }
-        const u32 v = cm.z;
-        u32 fan = 0;
-        if (jcap) {
-          const u64 dmj = __ballot(due_now);
-          if (due_now) jwrite(n_ev + (u32)__popcll(dmj & lt_mask), 1, cm.y, v, 0, cm.w >> 24, lane);
-          n_ev += (u32)__popcll(dmj);
-        }
-        if (due_now) {
-          has_c = false; s_recv_sv++;
-          const u32 wv = my_seen[v >> 5], bitm = 1u << (v & 31);
-          if (!(wv & bitm)) {
-            my_seen[v >> 5] = wv | bitm;
-            fan = PROG == MSIM_NODE_BCAST_FF_ECHOBACK ? adj : (adj & ~(1u << (cm.w >> 24)));
-          }
-        }
-        if (__ballot(fan != 0)) {
-          const u32 cnt = __popc(fan);
-          const u32 incl = scan32(cnt);
-          s_send_sv += cnt;
-          ev_base = n_ev; id_base = next_id; n_ev += rdlane(incl, 31);
-          commit_fan(fan, v, 0, incl - cnt);
-          next_id += rdlane(incl, 31);
-        }
-        poll();
-      }
-      if (phase == PH_DONE) break;
-    }
-  }
-
-  // ---- epilogue: flush the partial row block, reduce counters, write stats + meta ----
-  __syncthreads();
-  {
-    const u32 blk = n_rows >> 6;
-    const u32 gi = blk * 64 + lane;
-    if (gi < n_rows) reinterpret_cast<uint4 *>(g_rows)[gi] = stage[gi % STAGE_ROWS];
-  }
-  const u32 t_send_cl = wave_sum(s_send_cl), t_send_sv = wave_sum(s_send_sv);
-  const u32 t_recv_cl = wave_sum(s_recv_cl), t_recv_sv = wave_sum(s_recv_sv);
-  for (u32 b = 1; b <= MSIM_FLAG_JOURNAL_OVERFLOW; b <<= 1) if (__ballot((my_flags & b) != 0)) flags |= b;
-  if (lane == 0) {
-    msim_net_stats st;
-    st.all_send = (u64)t_send_cl + t_send_sv; st.all_recv = (u64)t_recv_cl + t_recv_sv;
-    st.clients_send = t_send_cl; st.clients_recv = t_recv_cl;
-    st.servers_send = t_send_sv; st.servers_recv = t_recv_sv;
-    p.stats[inst] = st;
-    msim_inst_meta m; m.n_rows = n_rows; m.n_payload_words = n_payload; m.flags = flags; m.n_rounds = rounds;
-    m.n_events = jcap ? n_ev : 0; m.reserved[0] = 0; m.reserved[1] = 0; m.reserved[2] = 0;
-    p.meta[inst] = m;
-  }
-}
-
-#include "sim_kernel_colo.inc"
-#include "sim_kernel_raft.inc"
-#include "sim_kernel_wide.inc"
-#include "sim_kernel_txn.inc"
-#include "sim_kernel_mk.inc"
-#include "sim_kernel_hat.inc"
-#include "sim_kernel_kafka.inc"
-#include "sim_kernel_svc.inc"
 
 // =====================================================================================================
 // Host runtime
@@ -831,43 +134,9 @@ extern "C" int msim_create(const msim_config *cfg, int device, msim_ctx **out, c
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev2);
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev3);
-  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(d_log2_q24), msim_log2_q24, sizeof(msim_log2_q24));
   if (e != hipSuccess) { set_err(err, errlen, hipGetErrorString(e)); delete ctx; return MSIM_E_HIP; }
   *out = ctx;
   return MSIM_OK;
-}
-
-// sim_kernel_wide<NET_RANDOM, BCAST, NEM, SETL> for this configuration
-template <bool NR, int BC, bool NM, bool SL>
-static hipError_t launch_wide_one(const KParams &kp, uint32_t n, size_t lds, hipStream_t st) {
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sim_kernel_wide<NR, BC, NM, SL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-  }
-  hipLaunchKernelGGL((sim_kernel_wide<NR, BC, NM, SL>), dim3(n), dim3(64), lds, st, kp);
-  return hipGetLastError();
-}
-template <int BC, bool SL>
-static hipError_t launch_wide2(const KParams &kp, uint32_t n, size_t lds, hipStream_t st) {
-  const msim_config &c = kp.cfg;
-  const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0, nem = c.nemesis_mask != 0;
-  if (nem) return rnd ? launch_wide_one<true, BC, true, SL>(kp, n, lds, st) : launch_wide_one<false, BC, true, SL>(kp, n, lds, st);
-  return rnd ? launch_wide_one<true, BC, false, SL>(kp, n, lds, st) : launch_wide_one<false, BC, false, SL>(kp, n, lds, st);
-}
-// Which wide clusters keep their nodes' sets in LDS (SETL): g-set, when sets + client inboxes + the LDS part of the queues leave a CU
-// at least four clusters (40 KiB each); MSIM_DEV_FLAGS bit 14 keeps the sets in HBM scratch.  Measured (profiles/r03k_wide_sets.txt):
-// cfg3 417 -> 348 ms per 16384 clusters.  Fire-and-forget broadcast stays in HBM scratch: its set traffic is one word per delivery,
-// and at 20.8 KiB of LDS per cluster a CU holds 7 clusters where a batch of 2048 needs 8 — 121 -> 198 ms per 2048 clusters at n = 100.
-static bool wide_sets_in_lds(const msim_config &c, uint32_t dev_flags) {
-  if (c.n_nodes <= 32 || (dev_flags & 0x4000u)) return false;
-  if (c.node_program != MSIM_NODE_G_SET) return false;
-  const size_t bytes = ((size_t)c.n_nodes * c.inbox_capacity + (size_t)c.n_nodes * CLIENT_INBOX_CAP) * 16 + (size_t)c.n_nodes * (c.max_values / 32) * 4 + (c.nemesis_mask ? 512 : 0) + 16;
-  return bytes <= 40 * 1024;
-}
-template <int BC>
-static hipError_t launch_wide(msim_ctx *, const KParams &kp, uint32_t n, size_t lds, hipStream_t st) {
-  if constexpr (BC == 0) { if (wide_sets_in_lds(kp.cfg, kp.dev_flags)) return launch_wide2<BC, true>(kp, n, lds, st); }
-  return launch_wide2<BC, false>(kp, n, lds, st);
 }
 
 // multi-key transactional node: thunk ids a node may hand out (every attempt of a transaction writes its keys again: x4 for the
@@ -939,33 +208,6 @@ static int ensure_buffers(msim_ctx *ctx, uint32_t n) {
   return MSIM_OK;
 }
 
-template <int PROG, bool NEM, bool NET_RANDOM>
-static hipError_t launch3(const KParams &kp, uint32_t n, size_t lds, hipStream_t st) {
-  // colocated layout when every worker is pinned to "its" node (concurrency == n_nodes, the default 1n)
-  const bool colo = kp.C == kp.N;
-  // FIFO queues (constant latency only) when deep queues are expected: the scan-based poll is cheaper for shallow ones
-  constexpr bool CAN_FIFO = !NET_RANDOM && PROG != MSIM_NODE_BCAST_ACK_RETRY && PROG != MSIM_NODE_BCAST_RPC_ALL;
-  static const char *force = std::getenv("MSIM_QUEUE");  // developer knob: "fifo" / "scan" override the choice below
-  const bool fifo = CAN_FIFO && colo && (force && force[0] == 'f' ? true : force && force[0] == 's' ? false : kp.spill_cap >= 64);
-  const void *fn = !colo ? reinterpret_cast<const void *>(&sim_kernel<PROG, NEM, NET_RANDOM>)
-                 : fifo ? reinterpret_cast<const void *>(&sim_kernel_colo<PROG, NEM, NET_RANDOM, CAN_FIFO>)
-                        : reinterpret_cast<const void *>(&sim_kernel_colo<PROG, NEM, NET_RANDOM, false>);
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-  }
-  if (!colo) hipLaunchKernelGGL((sim_kernel<PROG, NEM, NET_RANDOM>), dim3(n), dim3(64), lds, st, kp);
-  else if (fifo) hipLaunchKernelGGL((sim_kernel_colo<PROG, NEM, NET_RANDOM, CAN_FIFO>), dim3(n), dim3(64), lds, st, kp);
-  else hipLaunchKernelGGL((sim_kernel_colo<PROG, NEM, NET_RANDOM, false>), dim3(n), dim3(64), lds, st, kp);
-  return hipGetLastError();
-}
-template <int PROG>
-static hipError_t launch(const KParams &kp, uint32_t n, size_t lds, hipStream_t st) {
-  const bool rnd = kp.cfg.latency_dist != MSIM_LAT_CONSTANT || kp.cfg.p_loss_q32 != 0;
-  if (kp.cfg.nemesis_mask) return rnd ? launch3<PROG, true, true>(kp, n, lds, st) : launch3<PROG, true, false>(kp, n, lds, st);
-  return rnd ? launch3<PROG, false, true>(kp, n, lds, st) : launch3<PROG, false, false>(kp, n, lds, st);
-}
-
 static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, bool blocking) {
   if (!ctx) return MSIM_E_INVALID;
   if (n == 0) { ctx->err = "n_instances must be > 0"; return MSIM_E_INVALID; }
@@ -1014,14 +256,6 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
 
   if (blocking) MSIM_HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
   hipError_t e;
-#ifdef MSIM_ISA_PROBE  // developer hook (tools/isa_probe.sh): instantiate only one kernel so its ISA compiles in seconds
-#ifdef MSIM_ISA_PROBE_WIDE   // BASELINE cfg3's kernel
-  hipLaunchKernelGGL((sim_kernel_wide<true, 0, false, true>), dim3(n), dim3(64), lds, st, kp);
-#else
-  hipLaunchKernelGGL((sim_kernel_colo<MSIM_NODE_BCAST_FF, false, false, false>), dim3(n), dim3(64), lds, st, kp);
-#endif
-  e = hipGetLastError();
-#else
   // the headline layout: two clusters per wavefront (duo.hip); MSIM_DEV_FLAGS bit 9 keeps the one-cluster kernels
   e = MSIM_LAYOUT_DOES_NOT_FIT;
   if (msim_duo_eligible(c) && !(kp.dev_flags & 0x200u) && !((kp.dev_flags & 0x8000u) && msim_bcast8_eligible(c))) {   // (bit 15: small clusters eight per wavefront instead)
@@ -1043,71 +277,20 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   // g-set / pn-counter / g-counter: eight clusters per wavefront (crdt8.hip) for large batches of small clusters
   if (msim_crdt8_eligible(c) && !(kp.dev_flags & 0x200u)) e = msim_launch_crdt8(kp, n, st);
   if (e == MSIM_LAYOUT_DOES_NOT_FIT && (kp.dev_flags & 0x400u) && is_raft) { ctx->err = "MSIM_DEV_FLAGS bit 10: the four-clusters-per-wavefront Raft layout was required but does not apply"; return MSIM_E_UNSUPPORTED; }
-  if (e == MSIM_LAYOUT_DOES_NOT_FIT) switch (c.node_program) {   // not eligible, or the cluster state does not fit the duo layout
-    case MSIM_NODE_ECHO: e = launch<MSIM_NODE_ECHO>(kp, n, lds, st); break;
-    case MSIM_NODE_BCAST_FF:
-    case MSIM_NODE_BCAST_FF_ECHOBACK:
-      if (wide) {
-        e = launch_wide<1>(ctx, kp, n, lds, st);
-      } else if (c.node_program == MSIM_NODE_BCAST_FF) e = launch<MSIM_NODE_BCAST_FF>(kp, n, lds, st);
-      else e = launch<MSIM_NODE_BCAST_FF_ECHOBACK>(kp, n, lds, st);
-      break;
-    case MSIM_NODE_BCAST_ACK_RETRY: e = wide ? launch_wide<2>(ctx, kp, n, lds, st) : launch<MSIM_NODE_BCAST_ACK_RETRY>(kp, n, lds, st); break;
-    case MSIM_NODE_BCAST_RPC_ALL: e = wide ? launch_wide<3>(ctx, kp, n, lds, st) : launch<MSIM_NODE_BCAST_RPC_ALL>(kp, n, lds, st); break;
-    case MSIM_NODE_G_SET:
-      if (wide) {
-        e = launch_wide<0>(ctx, kp, n, lds, st);
-      } else e = launch<MSIM_NODE_G_SET>(kp, n, lds, st);
-      break;
-    case MSIM_NODE_PN_COUNTER: e = wide ? launch_wide<4>(ctx, kp, n, lds, st) : launch<MSIM_NODE_PN_COUNTER>(kp, n, lds, st); break;
-    case MSIM_NODE_FLAKE_IDS: e = launch<MSIM_NODE_FLAKE_IDS>(kp, n, lds, st); break;
-    case MSIM_NODE_RAFT: {
-      const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
-      if (c.nemesis_mask) { if (rnd) hipLaunchKernelGGL((raft_kernel<true, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((raft_kernel<true, false>), dim3(n), dim3(64), lds, st, kp); }
-      else { if (rnd) hipLaunchKernelGGL((raft_kernel<false, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((raft_kernel<false, false>), dim3(n), dim3(64), lds, st, kp); }
-      e = hipGetLastError();
-    } break;
-    case MSIM_NODE_LIN_KV_PROXY: {
-      const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
-      if (c.nemesis_mask) { if (rnd) hipLaunchKernelGGL((svc_kernel<true, true, false>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((svc_kernel<true, false, false>), dim3(n), dim3(64), lds, st, kp); }
-      else { if (rnd) hipLaunchKernelGGL((svc_kernel<false, true, false>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((svc_kernel<false, false, false>), dim3(n), dim3(64), lds, st, kp); }
-      e = hipGetLastError();
-    } break;
-    case MSIM_NODE_TSO_IDS: {   // unique-ids over the lin-tso service: the proxy's layout with the timestamp oracle on the service lane
-      const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
-      if (c.nemesis_mask) { if (rnd) hipLaunchKernelGGL((svc_kernel<true, true, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((svc_kernel<true, false, true>), dim3(n), dim3(64), lds, st, kp); }
-      else { if (rnd) hipLaunchKernelGGL((svc_kernel<false, true, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((svc_kernel<false, false, true>), dim3(n), dim3(64), lds, st, kp); }
-      e = hipGetLastError();
-    } break;
-    case MSIM_NODE_TXN_SINGLE_KEY: {
-      const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
-      if (c.nemesis_mask) { if (rnd) hipLaunchKernelGGL((txn_kernel<true, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((txn_kernel<true, false>), dim3(n), dim3(64), lds, st, kp); }
-      else { if (rnd) hipLaunchKernelGGL((txn_kernel<false, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((txn_kernel<false, false>), dim3(n), dim3(64), lds, st, kp); }
-      e = hipGetLastError();
-    } break;
-    case MSIM_NODE_TXN_MULTI_KEY: {
-      const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
-      void (*fn)(const KParams);
-      if (mk_keys_for(c) == 4u) fn = c.nemesis_mask ? (rnd ? mk_kernel<true, true, 4> : mk_kernel<true, false, 4>) : (rnd ? mk_kernel<false, true, 4> : mk_kernel<false, false, 4>);
-      else fn = c.nemesis_mask ? (rnd ? mk_kernel<true, true, 8> : mk_kernel<true, false, 8>) : (rnd ? mk_kernel<false, true, 8> : mk_kernel<false, false, 8>);
-      e = lds > 64 * 1024 ? hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) : hipSuccess;   // (above ~17 nodes)
-      if (e == hipSuccess) { hipLaunchKernelGGL(fn, dim3(n), dim3(64), lds, st, kp); e = hipGetLastError(); }
-    } break;
-    case MSIM_NODE_KAFKA: {
-      const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
-      if (c.nemesis_mask) { if (rnd) hipLaunchKernelGGL((kafka_kernel<true, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((kafka_kernel<true, false>), dim3(n), dim3(64), lds, st, kp); }
-      else { if (rnd) hipLaunchKernelGGL((kafka_kernel<false, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((kafka_kernel<false, false>), dim3(n), dim3(64), lds, st, kp); }
-      e = hipGetLastError();
-    } break;
-    case MSIM_NODE_TXN_RW_HAT: {
-      const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
-      if (c.nemesis_mask) { if (rnd) hipLaunchKernelGGL((hat_kernel<true, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((hat_kernel<true, false>), dim3(n), dim3(64), lds, st, kp); }
-      else { if (rnd) hipLaunchKernelGGL((hat_kernel<false, true>), dim3(n), dim3(64), lds, st, kp); else hipLaunchKernelGGL((hat_kernel<false, false>), dim3(n), dim3(64), lds, st, kp); }
-      e = hipGetLastError();
-    } break;
+  if (e == MSIM_LAYOUT_DOES_NOT_FIT) switch (c.node_program) {   // not eligible, or the cluster state does not fit the dense layout: one cluster per wavefront (k_*.hip)
+    case MSIM_NODE_ECHO: case MSIM_NODE_FLAKE_IDS: e = msim_launch_general_a(kp, n, lds, st); break;
+    case MSIM_NODE_G_SET: e = wide ? msim_launch_wide_gset(kp, n, lds, st) : msim_launch_general_a(kp, n, lds, st); break;
+    case MSIM_NODE_PN_COUNTER: e = wide ? msim_launch_wide_pn(kp, n, lds, st) : msim_launch_general_a(kp, n, lds, st); break;
+    case MSIM_NODE_BCAST_FF: case MSIM_NODE_BCAST_FF_ECHOBACK: e = wide ? msim_launch_wide_bcast(kp, n, lds, st) : msim_launch_general_b(kp, n, lds, st); break;
+    case MSIM_NODE_BCAST_ACK_RETRY: case MSIM_NODE_BCAST_RPC_ALL: e = wide ? msim_launch_wide_ack(kp, n, lds, st) : msim_launch_general_c(kp, n, lds, st); break;
+    case MSIM_NODE_RAFT: e = msim_launch_raft1(kp, n, lds, st); break;
+    case MSIM_NODE_LIN_KV_PROXY: case MSIM_NODE_TSO_IDS: e = msim_launch_svc1(kp, n, lds, st); break;   // (lin-tso ids: the proxy's layout with the timestamp oracle on the service lane)
+    case MSIM_NODE_TXN_SINGLE_KEY: e = msim_launch_txn1(kp, n, lds, st); break;
+    case MSIM_NODE_TXN_MULTI_KEY: e = msim_launch_mk1(kp, n, lds, st); break;
+    case MSIM_NODE_KAFKA: e = msim_launch_kafka1(kp, n, lds, st); break;
+    case MSIM_NODE_TXN_RW_HAT: e = msim_launch_hat1(kp, n, lds, st); break;
     default: ctx->err = "node program not built into this engine"; return MSIM_E_UNSUPPORTED;
   }
-#endif
   if (e != hipSuccess) { ctx->err = std::string("kernel launch: ") + hipGetErrorString(e); return MSIM_E_HIP; }
   ctx->n_inst = n; ctx->first_instance = first;
   ctx->fetched = false; ctx->fetch_pending = false; ctx->checked = false; ctx->check_fetched = false; ctx->ran = true;
@@ -1366,7 +549,7 @@ extern "C" int msim_set_dev_flags(msim_ctx *ctx, uint32_t flags) {
   return MSIM_OK;
 }
 
-extern "C" uint32_t msim_check_host_rechecks(const msim_ctx *ctx) { return ctx && ctx->checked && (ctx->cfg.workload == MSIM_WL_LIN_KV || ctx->cfg.workload == MSIM_WL_TXN_LIST_APPEND || ctx->cfg.workload == MSIM_WL_TXN_RW_REGISTER || ctx->cfg.workload == MSIM_WL_PN_COUNTER || ctx->cfg.workload == MSIM_WL_G_COUNTER) ? ctx->lin_host_rechecks : 0u; }
+extern "C" uint32_t msim_check_host_rechecks(const msim_ctx *ctx) { return ctx && ctx->checked && (ctx->cfg.workload == MSIM_WL_LIN_KV || ctx->cfg.workload == MSIM_WL_TXN_LIST_APPEND || ctx->cfg.workload == MSIM_WL_TXN_RW_REGISTER || ctx->cfg.workload == MSIM_WL_PN_COUNTER || ctx->cfg.workload == MSIM_WL_G_COUNTER || ctx->cfg.workload == MSIM_WL_KAFKA) ? ctx->lin_host_rechecks : 0u; }
 
 extern "C" int msim_check_results(msim_ctx *ctx, const msim_check_result **results, uint32_t *n) {
   if (!ctx) return MSIM_E_INVALID;

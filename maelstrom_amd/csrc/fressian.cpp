@@ -193,7 +193,7 @@ extern "C" int msim_journal_fressian_rows(const msim_config *cfg, const msim_eve
           if ((uint64_t)off + words > n_words) return MSIM_E_RANGE;
           w.keyword(wl == MSIM_WL_BROADCAST ? "messages" : "value", true);
           int_list_from_bitmap(w, payload + off, words);
-        } else if (wl == MSIM_WL_TXN_LIST_APPEND) { w.keyword("elided", true); w.raw(0xF5); kv_int("a", e.a); }   // a root version / a thunk id
+        } else if (wl == MSIM_WL_TXN_LIST_APPEND || wl == MSIM_WL_KAFKA) { w.keyword("elided", true); w.raw(0xF5); kv_int("a", e.a); }   // a root version / a thunk id; kafka: a chunk's element count / the offsets map's version (engine-internal, never a real body)
         else kv_int("value", wl == MSIM_WL_PN_COUNTER || wl == MSIM_WL_G_COUNTER ? (int64_t)(int32_t)e.a : (int64_t)e.a);
         break;
       case MSIM_M_ERROR: kv_int("code", e.a); break;
@@ -205,7 +205,7 @@ extern "C" int msim_journal_fressian_rows(const msim_config *cfg, const msim_eve
         break;
       case MSIM_M_INIT_OK: case MSIM_M_TOPOLOGY_OK: case MSIM_M_BROADCAST_OK: case MSIM_M_ADD_OK: case MSIM_M_READ: case MSIM_M_GENERATE:
         if (type == MSIM_M_READ && wl == MSIM_WL_LIN_KV) kv_int("key", e.a & 0xFF);
-        else if (type == MSIM_M_READ && wl == MSIM_WL_TXN_LIST_APPEND) { w.keyword("elided", true); w.raw(0xF5); kv_int("a", e.a); }   // the root / a thunk, by id
+        else if (type == MSIM_M_READ && (wl == MSIM_WL_TXN_LIST_APPEND || wl == MSIM_WL_KAFKA)) { w.keyword("elided", true); w.raw(0xF5); kv_int("a", e.a); }   // the root / a thunk / a kafka chunk or the offsets map, by id
         break;
       case MSIM_M_TXN: case MSIM_M_TXN_OK: {   // [[f k v] ...] (doc/workloads.md txn-list-append / txn-rw-register); micro-ops in the payload area
         const uint32_t off = e.a & 0xFFFFFFu, nw = e.a >> 24;

@@ -355,10 +355,11 @@ int msim_check_kafka_device(msim_ctx *ctx) {
 extern "C" int msim_check_kafka_batch(int device, const msim_op *rows, const uint64_t *row_offsets, const uint32_t *payload, const uint64_t *payload_offsets,
                                       uint32_t n_histories, uint32_t concurrency, msim_check_result *out, uint32_t *n_host) {
   if (!rows || !row_offsets || !payload_offsets || !out || n_histories == 0 || concurrency == 0 || concurrency > CMAX) return MSIM_E_INVALID;
+  const uint64_t tr = row_offsets[n_histories], tw = payload_offsets[n_histories];
+  if (tw != 0 && !payload) return MSIM_E_INVALID;   // (as msim_check_kafka_rows: payload words announced, none given)
   if (hipSetDevice(device) != hipSuccess) return MSIM_E_HIP;
   msim_ctx tmp_ctx; msim_ctx *ctx = &tmp_ctx;   // only for error text
   tmp_ctx.device = device;
-  const uint64_t tr = row_offsets[n_histories], tw = payload_offsets[n_histories];
   for (u32 i = 0; i < n_histories; i++) if (row_offsets[i + 1] - row_offsets[i] > 0x7FFFFFFFull || payload_offsets[i + 1] - payload_offsets[i] > 0x7FFFFFFFull) return MSIM_E_RANGE;
   msim_op *d_rows = nullptr; u32 *d_pay = nullptr; uint64_t *d_ro = nullptr, *d_po = nullptr; msim_check_result *d_out = nullptr;
   int rc = MSIM_E_HIP;

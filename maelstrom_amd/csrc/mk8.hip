@@ -1,5 +1,6 @@
-// mk8.hip — EIGHT clusters of the canonical txn-list-append node per wavefront (BASELINE configs[4] over the node
-// the reference itself runs for the workload, core.clj:113-114 -> demo/ruby/datomic_list_append.rb == demo/js/multi_key_txn.js).
+// mk8.hip — EIGHT clusters of the multi-key txn-list-append node per wavefront (BASELINE configs[4] over
+// demo/js/multi_key_txn.js — the flat key -> thunk form of the architecture of demo/ruby/datomic_list_append.rb, which core.clj:113-114 runs and
+// which is a different program (a persistent hash tree; not built).
 //
 // Same program and the same rounds as mk_kernel<> (sim_kernel_mk.inc; specification: oracle/mk_nodes.inc): node =
 // demo/js/multi_key_txn.js:1-246 (immutable thunks in lww-kv, one root map key -> thunk id in lin-kv; getState / applyTxn / writeThunks /
@@ -235,7 +236,7 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
     return n;
   };
 
-#ifdef M8_PROF   // developer build (tools/mk8_prof.sh): cycle counters of the round's sections -> the meta of the wavefront's first three clusters
+#ifdef M8_PROF   // developer build (tools/variant_lib.sh m8prof mk8.hip -DM8_PROF): cycle counters of the round's sections -> the meta of the wavefront's first three clusters
   u64 pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; u32 wave_rounds = 0;
   u64 tprev = __builtin_readcyclecounter();
 #define M8_MARK(i) { const u64 now_ = __builtin_readcyclecounter(); pacc[i] += now_ - tprev; tprev = now_; }

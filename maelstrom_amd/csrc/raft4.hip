@@ -818,7 +818,7 @@ __global__ void __launch_bounds__(64) raft4_kernel(const R4Params rp) {
     p.stats[inst] = st;
     msim_inst_meta m; m.n_rows = n_rows; m.n_payload_words = n_payload; m.flags = flags; m.n_rounds = rounds;
     m.n_events = 0; m.reserved[0] = 0; m.reserved[1] = 0; m.reserved[2] = 0;
-#ifdef R4_PROF   // developer build (tools/raft4_prof.sh): cycle counters of the round's sections, 4 per cluster of the wavefront
+#ifdef R4_PROF   // developer build (tools/variant_lib.sh r4prof raft4.hip -DR4_PROF): cycle counters of the round's sections, 4 per cluster of the wavefront
     {
       u32 v[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
       for (int i = 0; i < 9; i++) v[i] = (u32)(pacc[i] >> 6);

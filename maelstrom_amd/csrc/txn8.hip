@@ -683,7 +683,7 @@ __global__ void __launch_bounds__(64) txn8_kernel(const T8Params tp) {
     p.stats[inst] = st;
     msim_inst_meta m; m.n_rows = n_rows; m.n_payload_words = n_payload; m.flags = flags; m.n_rounds = rounds;
     m.n_events = 0; m.reserved[0] = 0; m.reserved[1] = 0; m.reserved[2] = 0;
-#ifdef T8_PROF   // developer build (tools/txn8_prof.sh): cycle counters of the round's sections in the meta of the wavefront's first three clusters
+#ifdef T8_PROF   // developer build (tools/variant_lib.sh t8prof txn8.hip -DT8_PROF): cycle counters of the round's sections in the meta of the wavefront's first three clusters
     if (grp == 0) { m.n_events = (u32)(pacc[0] >> 6); m.reserved[0] = (u32)(pacc[1] >> 6); m.reserved[1] = (u32)(pacc[2] >> 6); m.reserved[2] = (u32)(pacc[3] >> 6); }
     if (grp == 1) { m.n_events = (u32)(pacc[4] >> 6); m.reserved[0] = (u32)(pacc[5] >> 6); m.reserved[1] = (u32)(pacc[6] >> 6); m.reserved[2] = (u32)(pacc[7] >> 6); }
     if (grp == 2) { m.n_events = wave_rounds; }

@@ -107,13 +107,17 @@ __global__ void __launch_bounds__(256) unique_check_lds_kernel(const UParams p) 
     lo = min(lo, id); hi = max(hi, id); n_ids++;
     if (id == EMPTY) { n_empty_id++; continue; }   // (the one value the table cannot hold is counted apart)
     u32 h = (id * 0x9E3779B1u) >> 7;
-    for (;;) {
+    // (the host only takes this kernel when every row of the history could be an acknowledged id and the table still stays below a
+    //  load factor of 0.6; the probe count is bounded all the same: a full table must end in a verdict, not in a hung GPU)
+    u32 probes = 0;
+    for (; probes < LDS_SLOTS; probes++) {
       h &= LDS_SLOTS - 1u;
       const u32 old = atomicCAS(&tab[h], EMPTY, id);
       if (old == EMPTY) break;
       if (old == id) { atomicOr(&again[h >> 5], 1u << (h & 31u)); break; }
       h++;
     }
+    if (probes == LDS_SLOTS) atomicOr(&hdr[10], 1u);   // table full
   }
   atomicAdd(&hdr[0], c_inv); atomicAdd(&hdr[1], c_ok); atomicAdd(&hdr[2], c_fail); atomicAdd(&hdr[3], c_info); atomicAdd(&hdr[4], c_att);
   atomicAdd(&hdr[5], n_empty_id); atomicAdd(&hdr[6], n_ids); atomicMin(&hdr[8], lo); atomicMax(&hdr[9], hi);
@@ -126,8 +130,8 @@ __global__ void __launch_bounds__(256) unique_check_lds_kernel(const UParams p) 
     u32 d = hdr[7];
     if (hdr[5] >= 2) d++;
     msim_check_result o;
-    o.valid = flags ? 0u : (d == 0 ? 1u : 0u);
-    o.attempt_count = hdr[4]; o.stable_count = 0; o.lost_count = 0; o.never_read_count = 0; o.stale_count = 0; o.duplicated_count = d; o.error_count = 0;
+    o.valid = (flags || hdr[10]) ? 0u : (d == 0 ? 1u : 0u);
+    o.attempt_count = hdr[4]; o.stable_count = 0; o.lost_count = 0; o.never_read_count = 0; o.stale_count = 0; o.duplicated_count = d; o.error_count = hdr[10];
     for (int i = 0; i < 5; i++) o.stable_latency_ms[i] = 0;
     if (hdr[6]) { o.stable_latency_ms[0] = hdr[8]; o.stable_latency_ms[1] = hdr[9]; }   // :range
     o.op_count = hdr[0]; o.ok_count = hdr[1]; o.fail_count = hdr[2]; o.info_count = hdr[3];
@@ -137,9 +141,12 @@ __global__ void __launch_bounds__(256) unique_check_lds_kernel(const UParams p) 
 
 }  // namespace
 
-static int unique_dev_run(msim_ctx *ctx, UParams up, u32 n, void **ws, size_t *ws_cap, hipStream_t st) {
-  // at most max_rows / 2 ids are acknowledged: a load factor of 0.6 keeps the LDS table's probe sequences short
-  if ((uint64_t)(up.max_rows / 2) * 10 <= (uint64_t)LDS_SLOTS * 6 && !(msim_dev_flags(ctx) & 0x2000u)) {   // (MSIM_DEV_FLAGS bit 13: the HBM tables)
+// `paired`: the histories are the engine's own — every :ok row follows its :invoke row, so at most max_rows / 2 ids are acknowledged;
+// rows handed in by a caller (msim_check_unique_batch) may be ALL acknowledgements (a history filtered to its completions).
+static int unique_dev_run(msim_ctx *ctx, UParams up, u32 n, void **ws, size_t *ws_cap, hipStream_t st, bool paired) {
+  // a load factor of 0.6 keeps the LDS table's probe sequences short (and the table can never fill up)
+  const uint64_t max_ids = paired ? up.max_rows / 2 : up.max_rows;
+  if (max_ids * 10 <= (uint64_t)LDS_SLOTS * 6 && !(msim_dev_flags(ctx) & 0x2000u)) {   // (MSIM_DEV_FLAGS bit 13: the HBM tables)
     const size_t lds = ((size_t)LDS_SLOTS + LDS_SLOTS / 32 + 16) * 4;
     MSIM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&unique_check_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     up.first = 0;
@@ -147,7 +154,7 @@ static int unique_dev_run(msim_ctx *ctx, UParams up, u32 n, void **ws, size_t *w
     MSIM_HIP_TRY(ctx, hipGetLastError());
     return MSIM_OK;
   }
-  u32 slots = 64; while (slots < up.max_rows) slots <<= 1;   // >= 2 x (max_rows / 2) acknowledged ids
+  u32 slots = 64; while (slots < (paired ? up.max_rows : 2 * up.max_rows)) slots <<= 1;   // >= 2 x the ids a history can acknowledge
   up.table_slots = slots;
   const uint64_t budget = 4ull << 30;
   const u32 chunk = (u32)std::min<uint64_t>(n, std::max<uint64_t>(1, budget / ((uint64_t)slots * 8)));
@@ -173,7 +180,7 @@ int msim_check_unique_device(msim_ctx *ctx) {
   UParams up;
   up.rows = ctx->d_rows; up.meta = ctx->d_meta; up.out = ctx->d_check; up.max_rows = ctx->cfg.max_rows; up.ws = nullptr; up.table_slots = 0; up.first = 0;
   MSIM_HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
-  int rc = unique_dev_run(ctx, up, ctx->n_inst, &ctx->d_check_scratch, &ctx->cap_check_scratch, ctx->stream);
+  int rc = unique_dev_run(ctx, up, ctx->n_inst, &ctx->d_check_scratch, &ctx->cap_check_scratch, ctx->stream, true);
   if (rc != MSIM_OK) return rc;
   MSIM_HIP_TRY(ctx, hipEventRecord(ctx->ev3, ctx->stream));
   MSIM_HIP_TRY(ctx, hipEventSynchronize(ctx->ev3));
@@ -201,7 +208,7 @@ extern "C" int msim_check_unique_batch(int device, const msim_op *rows, const ui
     if (hipMemcpy(d_meta, hm.data(), (size_t)n_histories * sizeof(msim_inst_meta), hipMemcpyHostToDevice) != hipSuccess) break;
     UParams up;
     up.rows = d_rows; up.meta = d_meta; up.out = d_out; up.max_rows = max_rows; up.ws = nullptr; up.table_slots = 0; up.first = 0;
-    rc = unique_dev_run(ctx, up, n_histories, &ws, &ws_cap, nullptr);
+    rc = unique_dev_run(ctx, up, n_histories, &ws, &ws_cap, nullptr, false);
     if (rc != MSIM_OK) break;
     rc = hipMemcpy(out, d_out, (size_t)n_histories * sizeof(msim_check_result), hipMemcpyDeviceToHost) == hipSuccess ? MSIM_OK : MSIM_E_HIP;
   } while (false);

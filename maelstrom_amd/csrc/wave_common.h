@@ -161,6 +161,21 @@ static const hipError_t MSIM_LAYOUT_DOES_NOT_FIT = static_cast<hipError_t>(0x7F0
     }                                                                                                            \
   } while (0)
 
+// k_*.hip: the one-cluster-per-wavefront kernels (sim_kernels.h), one launcher per family / unit; MSIM_LAYOUT_DOES_NOT_FIT for a node
+// program the unit does not hold
+hipError_t msim_launch_general_a(const KParams &kp, uint32_t n, size_t lds, hipStream_t st);   // echo, flake ids, g-set, the counters
+hipError_t msim_launch_general_b(const KParams &kp, uint32_t n, size_t lds, hipStream_t st);   // fire-and-forget broadcast
+hipError_t msim_launch_general_c(const KParams &kp, uint32_t n, size_t lds, hipStream_t st);   // acknowledged gossip, rpc-to-all
+hipError_t msim_launch_wide_gset(const KParams &kp, uint32_t n, size_t lds, hipStream_t st);
+hipError_t msim_launch_wide_bcast(const KParams &kp, uint32_t n, size_t lds, hipStream_t st);
+hipError_t msim_launch_wide_ack(const KParams &kp, uint32_t n, size_t lds, hipStream_t st);
+hipError_t msim_launch_wide_pn(const KParams &kp, uint32_t n, size_t lds, hipStream_t st);
+hipError_t msim_launch_raft1(const KParams &kp, uint32_t n, size_t lds, hipStream_t st);
+hipError_t msim_launch_svc1(const KParams &kp, uint32_t n, size_t lds, hipStream_t st);
+hipError_t msim_launch_txn1(const KParams &kp, uint32_t n, size_t lds, hipStream_t st);
+hipError_t msim_launch_mk1(const KParams &kp, uint32_t n, size_t lds, hipStream_t st);
+hipError_t msim_launch_kafka1(const KParams &kp, uint32_t n, size_t lds, hipStream_t st);
+hipError_t msim_launch_hat1(const KParams &kp, uint32_t n, size_t lds, hipStream_t st);
 // duo.hip: two clusters per wavefront (fire-and-forget broadcast, constant latency, colocated clients)
 bool msim_duo_eligible(const msim_config &c);
 hipError_t msim_launch_duo(const KParams &kp, uint32_t n, hipStream_t st);

@@ -320,6 +320,13 @@ def decode_poll(words):
     return out
 
 
+def _kafka_range(i, key, msg, offset):
+    """The binary layout's fields (include/maelsim.h: keys 0..7, message values and offsets below 2047): out-of-range values are an
+    error, never masked — a masked key or a count that spills into the offset bits would be CHECKED as a different history."""
+    if not (0 <= int(key) < 8 and 0 <= int(msg) < 2047 and 0 <= int(offset) < 2047):
+        raise EngineError(f"kafka op {i}: key {key} / message {msg} / offset {offset} outside the binary layout (keys 0..7, messages and offsets below 2047)")
+
+
 def encode_kafka_history(ops):
     """Jepsen-shaped kafka ops ({type, process, f, value[, time]}; values as decode_history gives them) -> (rows, payload) in the engine's
     binary layout, so that externally produced histories can be fed to msim_check_kafka_rows."""
@@ -333,16 +340,20 @@ def encode_kafka_history(ops):
         if f == A.F_SEND:
             _, k, v = op["value"][0]
             msg, off = (v[1], v[0]) if isinstance(v, (list, tuple)) else (v, 0x7FF)
+            _kafka_range(i, k, msg, off if isinstance(v, (list, tuple)) else 0)
             value = int(k) | (msg << 6) | (off << 17)
         elif f == A.F_POLL and typ == A.T_OK and len(op["value"][0]) > 1:
             value = len(pay)
             for k, pairs in op["value"][0][1].items():
                 runs = []
-                for o, m in pairs:   # runs of consecutive offsets
-                    if runs and runs[-1][0] + len(runs[-1][1]) == o:
+                for o, m in pairs:   # runs of consecutive offsets, at most 255 messages each (the header's count has 8 bits)
+                    _kafka_range(i, k, m, o)
+                    if runs and runs[-1][0] + len(runs[-1][1]) == o and len(runs[-1][1]) < 255:
                         runs[-1][1].append(m)
                     else:
                         runs.append((o, [m]))
+                if not pairs:
+                    _kafka_range(i, k, 0, 0)
                 for o, ms in runs or [(0, [])]:
                     pay.append(int(k) | (len(ms) << 8) | (o << 16))
                     for e in range(0, len(ms), 2):
@@ -352,6 +363,8 @@ def encode_kafka_history(ops):
                 value = A.NO_VALUE
         elif f == A.F_ASSIGN:
             value, ln = len(pay), len(op["value"])
+            for k in op["value"]:
+                _kafka_range(i, k, 0, 0)
             pay.extend(int(k) | (0x80000000 if op.get("seek-to-beginning?") else 0) for k in op["value"])
         rows[i] = (int(op.get("time", i * 1000)) | (ln << 48), typ | (f << 2) | (process << 12), value)
     return rows, np.asarray(pay if pay else [0], dtype=np.uint32)
@@ -471,6 +484,62 @@ def encode_pn_history(ops):
         f = A.F_ADD if op["f"] == ":add" else A.F_READ
         rows["packed"][i] = tkw[op["type"]] | (f << 2) | ((1 if op.get("final?") else 0) << 11) | (int(op.get("process", 0)) << 12)
     return rows
+
+
+def encode_set_history(ops):
+    """Jepsen-shaped broadcast / g-set ops ({type, process, f, value[, time, final?]}: :broadcast / :add carry the element, a read's :ok
+    the list of elements) -> (rows, payload) in the engine's binary layout (include/maelsim.h msim_op: a read result is a bitmap in the
+    payload area), so that externally produced histories can be fed to msim_check_set_full_batch.  Inverse of decode_history."""
+    tkw = {v: k for k, v in TYPE_KW.items()}
+    fkw = {":broadcast": A.F_BROADCAST, ":add": A.F_ADD, ":read": A.F_READ}
+    rows = np.zeros(len(ops), dtype=OP_DT)
+    pay = []
+    for i, op in enumerate(ops):
+        typ, f, process = tkw[op["type"]], fkw[op["f"]], int(op["process"])
+        value, ln = A.NO_VALUE, 0
+        if f != A.F_READ:
+            value = int(op["value"])
+            if not 0 <= value < 65536:
+                raise EngineError(f"op {i}: element {value} outside the binary layout (0..65535)")
+        elif typ == A.T_OK:
+            els = [int(x) for x in op["value"]]
+            if len(set(els)) != len(els):
+                raise EngineError(f"op {i}: a read holding an element twice has no bitmap form")
+            ln = (max(els) // 32 + 1) if els else 0
+            value = len(pay)
+            words = [0] * ln
+            for x in els:
+                words[x // 32] |= 1 << (x % 32)
+            pay.extend(words)
+        rows[i] = (int(op.get("time", i * 1000)) | (ln << 48), typ | (f << 2) | ((1 if op.get("final?") else 0) << 11) | (process << 12), value)
+    return rows, np.asarray(pay if pay else [0], dtype=np.uint32)
+
+
+def encode_lin_kv_history(ops):
+    """Jepsen-shaped lin-kv ops ({type, process, f, value = [k v] / [k [v v']][, time]}; lin_kv.clj:53-67) -> rows for
+    msim_check_lin_kv_rows / msim_check_lin_kv_batch.  Keys and values below 255 (nil = 255 in the binary layout)."""
+    tkw = {v: k for k, v in TYPE_KW.items()}
+    fkw = {":read": A.F_READ, ":write": A.F_WRITE, ":cas": A.F_CAS}
+    rows = np.zeros(len(ops), dtype=OP_DT)
+    for i, op in enumerate(ops):
+        k, v = op["value"]
+        v1, v2 = (v if op["f"] == ":cas" else (v, None))
+        for x in (k, v1, v2):
+            if x is not None and not 0 <= int(x) < 255:
+                raise EngineError(f"op {i}: key / value {x} outside the binary layout (0..254)")
+        value = int(k) | ((0xFF if v1 is None else int(v1)) << 8) | ((0xFF if v2 is None else int(v2)) << 16)
+        rows[i] = (int(op.get("time", i * 1000)), tkw[op["type"]] | (fkw[op["f"]] << 2) | (int(op["process"]) << 12), value)
+    return rows
+
+
+def check_lin_kv_history(rows):
+    """The per-key linearizability check (msim_check_lin_kv_rows, host search) on one history -> dict."""
+    res = A.CheckResult()
+    rows = np.ascontiguousarray(rows)
+    rc = A.load().msim_check_lin_kv_rows(rows.ctypes.data_as(C.c_void_p), len(rows), C.byref(res))
+    if rc:
+        raise EngineError(f"msim_check_lin_kv_rows: {rc}")
+    return {"valid?": {1: True, 0: False, 2: "unknown"}[res.valid], "key-count": res.attempt_count, "invalid-keys": res.error_count}
 
 
 def decode_history(rows, payload, n_nodes, workload=A.WL_BROADCAST, node_program=None):

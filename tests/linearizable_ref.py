@@ -19,6 +19,12 @@ def _step(state, op):
 
 def check_key(ops):
     """ops: history of one key, in order (maps with type/f/process/value; read :ok carries the value read)."""
+    return check_key_configs(ops)[0]
+
+
+def check_key_configs(ops):
+    """-> (linearizable?, the register values of the configurations the search ends with: Knossos' :configs, e.g.
+    `#knossos.model.CASRegister{:value 3}` at doc/06-raft/01-key-value.md:145)."""
     # pair invokes with completions; drop failed ops entirely
     comp = {}
     open_by_proc = {}
@@ -69,8 +75,8 @@ def check_key(ops):
         pending.discard(i)
         configs = out
         if not configs:
-            return False
-    return True
+            return False, []
+    return True, sorted({st for st, _ in configs}, key=lambda x: (x is None, x))
 
 
 def check(history):

@@ -69,6 +69,19 @@ def test_engine_fails_loudly_without_a_gpu(lib):
         E.Engine(E.test_config("echo", node_count=3))
 
 
+def test_batch_checkers_validate_their_arguments_before_touching_a_device(lib):
+    """msim_check_kafka_batch: payload words announced but no payload given is MSIM_E_INVALID (like msim_check_kafka_rows), not a kernel
+    reading uninitialised memory."""
+    import numpy as np
+    rows = np.zeros(2, dtype=E.OP_DT)
+    ro = np.array([0, 2], dtype=np.uint64)
+    po = np.array([0, 5], dtype=np.uint64)
+    out = np.zeros(1, dtype=E.CHECK_DT)
+    nh = C.c_uint32(0)
+    rc = lib.msim_check_kafka_batch(0, rows.ctypes.data_as(C.c_void_p), ro.ctypes.data_as(C.c_void_p), None, po.ctypes.data_as(C.c_void_p), 1, 3, out.ctypes.data_as(C.c_void_p), C.byref(nh))
+    assert rc == A.E_INVALID
+
+
 def test_product_never_touches_the_oracle():
     """The oracle is test infrastructure: nothing under maelstrom_amd/ or include/ may import, include, load or link it."""
     bad = re.compile(r"^\s*(?:import|from)\s+\S*oracle|#\s*include\s+\S*oracle|oracle_lib|libmaelsim_oracle|oracle_run|CDLL\([^)]*oracle", re.M)

@@ -84,7 +84,7 @@ def test_cfg5_txn_list_append_shape(lib):
 
 
 def test_cfg5_multi_key_txn_shape(lib):
-    """cfg5 over the workload's canonical node (core.clj:113-114: datomic_list_append.rb == multi_key_txn.js)."""
+    """cfg5 over the multi-key node (multi_key_txn.js: same architecture as core.clj:113-114's datomic_list_append.rb, a different program)."""
     cfg = E.test_config("txn-list-append", bin="multi-key-txn", node_count=5, rate=100, time_limit=30, latency=5, nemesis=["partition"], nemesis_interval=10, seed=99)
     _compare_digests(cfg, 0, 64)
 

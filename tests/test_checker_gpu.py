@@ -258,6 +258,26 @@ def test_unique_ids_device_checker_equals_host(lib):
     assert int(dev[0]["valid"]) == 1 and (dev["valid"][1:n] == 0).all()
 
 
+def test_unique_ids_batch_of_completions_only_history_terminates(lib):
+    """A caller's history may be ALL acknowledgements (filtered to its completions): 36000 distinct :ok ids in 36000 rows are more than the
+    LDS table's 32768 slots — the batch entry sizes by the rows, not by rows / 2 (the LDS kernel's probe loop spun for ever
+    on a full table), and the verdict is the host checker's."""
+    import ctypes as C
+    from maelstrom_amd import _abi as A
+    for n_ids, dup in ((36000, False), (36000, True), (19000, False), (30000, True)):
+        rows = np.zeros(n_ids, dtype=E.OP_DT)
+        rows["time_len"] = np.arange(n_ids, dtype=np.uint64) * 1000
+        rows["packed"] = A.T_OK | (A.F_GENERATE << 2) | (1 << 12)
+        rows["value"] = (np.arange(n_ids, dtype=np.uint64) * 2654435761 % (1 << 31)).astype(np.uint32)
+        if dup:
+            rows["value"][n_ids - 1] = rows["value"][7]
+        dev = E.check_unique_batch([rows])[0]
+        res = A.CheckResult()
+        assert A.load().msim_check_unique_rows(rows.ctypes.data_as(C.c_void_p), len(rows), C.byref(res)) == 0
+        assert int(dev["valid"]) == int(res.valid) == (0 if dup else 1) and int(dev["duplicated_count"]) == int(res.duplicated_count) == (1 if dup else 0)
+        assert int(dev["ok_count"]) == n_ids and int(dev["error_count"]) == 0
+
+
 def test_pn_counter_device_checker_equals_host(lib):
     """The counter checker on the device (csrc/pn_check_dev.hip: a 4096-value bitmap of acceptable sums) against the host checker
     (csrc/pn_check.cpp) — on the reference's own vectors (pn_counter_test.clj:10-36, KAT-9), on engine histories with lost acks

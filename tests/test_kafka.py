@@ -170,6 +170,20 @@ def test_each_anomaly_by_hand():
     assert _check(_h(*_send(0, "1", 1, typ=":info"), *_poll(1, {"1": [[0, 1]]})))["anomalies"] == []   # an indeterminate send may have happened
 
 
+def test_encoder_splits_long_polls_and_refuses_what_the_layout_cannot_hold():
+    """A poll run longer than the header's 8-bit count is split into blocks (the format allows several per key); keys, messages and
+    offsets outside the layout raise instead of being masked into a different history."""
+    ops = _h(*(sum((_send(1, "3", m + 1, m) for m in range(300)), [])), *_poll(0, {"3": [[m, m + 1] for m in range(300)]}))
+    res = _check(ops)
+    assert res["valid?"] is True and res["anomalies"] == [] and res["lost-count"] == 0 and res["acked-count"] == 300
+    rows, pay = E.encode_kafka_history(ops)
+    assert E.decode_history(rows, pay, 1, KF)[-1]["value"][0][1]["3"] == [[m, m + 1] for m in range(300)]
+    for bad in (_send(0, "9", 1, 0), _send(0, "1", 2047, 0), _send(0, "1", 1, 2047), _poll(0, {"8": [[0, 1]]}), _poll(0, {"1": [[0, 70000]]}),
+                [{"type": ":invoke", "process": 0, "f": ":assign", "value": ["12"]}]):
+        with pytest.raises(E.EngineError):
+            E.encode_kafka_history(_h(*bad))
+
+
 def test_checker_agrees_with_restatement_on_corrupted_histories():
     cfg = _cfg(node_count=3, rate=80.0, time_limit=5.0)
     o = O.run(cfg, 0, 3)

@@ -29,7 +29,7 @@ CONFIGS = {
     "unique-ids n=3 rate1000 10s lat5 + partitions": (dict(workload="unique-ids", node_count=3, rate=1000, time_limit=10, latency=5, nemesis=["partition"], nemesis_interval=3), 16384),
     "cfg5 txn-list-append n=5 rate100 30s lat5 + partitions": (dict(workload="txn-list-append", node_count=5, rate=100, time_limit=30, latency=5,
                                                                      nemesis=["partition"], nemesis_interval=10), 32768),
-    # the canonical node of the workload (core.clj:113-114 -> datomic_list_append.rb == multi_key_txn.js): thunks in lww-kv, root map in lin-kv
+    # the multi-key node (multi_key_txn.js; same architecture as core.clj:113-114's datomic_list_append.rb, a different program): thunks in lww-kv, root map in lin-kv
     "cfg5-mk txn-list-append multi-key n=5 rate100 30s lat5 + partitions": (dict(workload="txn-list-append", bin="multi-key-txn", node_count=5, rate=100, time_limit=30, latency=5,
                                                                                   nemesis=["partition"], nemesis_interval=10), 32768),
     "broadcast n=100 grid lat0": (dict(workload="broadcast", node_count=100, rate=100, time_limit=20), 2048),

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer tool (GPU box): the headline shape with the DUO_PROF2 build (tools/duo_prof.sh p2 -UDUO_PROF -DDUO_PROF2): cycles of a
+"""Developer tool (GPU box): the headline shape with the DUO_PROF2 build (tools/variant_lib.sh p2 duo.hip -DDUO_PROF2): cycles of a
 wavefront by section of the gossip round.  Env: N, LAT, DIST, MSIM_LIB."""
 import os
 import sys

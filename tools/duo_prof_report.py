@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer tool (GPU box): runs the headline batch with the DUO_PROF build (tools/duo_prof.sh) and prints, per wavefront,
+"""Developer tool (GPU box): runs the headline batch with the DUO_PROF build (tools/variant_lib.sh prof duo.hip -DDUO_PROF) and prints, per wavefront,
 the number of wave-rounds, how many of them were GENERAL rounds, and the cycles spent in each kind."""
 import os
 import sys

@@ -1,16 +1,19 @@
 #!/bin/bash
-# Developer tool: compiles only the headline kernel (sim_kernel_colo<BCAST_FF, no nemesis, constant latency>) to ISA and
-# prints register use, spills and static instruction counts of its innermost loops (the cascade loop is VALU-issue bound,
-# DESIGN.md §4.4).  Usage: tools/isa_probe.sh [out.s]
+# Developer tool: compiles one translation unit to ISA and prints register use, spills and static instruction counts by loop depth of
+# one kernel of it (a regular expression over the mangled name).
+# Usage: tools/isa_probe.sh [unit.hip] [kernel regex] [out.s]      default: duo.hip, the headline instantiation sim_kernel_duo<true,true,false>
 set -e
-OUT=${1:-/tmp/isa_probe.s}
+UNIT=${1:-duo.hip}
+KERNEL=${2:-sim_kernel_duoILb1ELb1ELb0EE}
+OUT=${3:-/tmp/isa_probe.s}
 cd "$(dirname "$0")/.."
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -DMSIM_ISA_PROBE -S --cuda-device-only -o "$OUT" maelstrom_amd/csrc/engine.hip 2>/dev/null
-python3 - "$OUT" <<'PY'
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only -o "$OUT" maelstrom_amd/csrc/$UNIT 2>/dev/null
+python3 - "$OUT" "$KERNEL" <<'PY'
 import re, sys
 txt = open(sys.argv[1]).read()
-m = re.search(r"^_Z15sim_kernel_coloILi1ELb0ELb0ELb0EEv7KParams:(.*?)\.end_amdhsa_kernel", txt, re.S | re.M)
-body = m.group(1)
+m = re.search(r"^(_Z\S*%s\S*):(.*?)\.end_amdhsa_kernel" % sys.argv[2], txt, re.S | re.M)
+print(m.group(1))
+body = m.group(2)
 for k in ("NumVgprs", "NumSgprs", "ScratchSize", "Occupancy"):
     mm = re.search(r"; %s: (\d+)" % k, txt[m.start():])
     print(k, mm.group(1) if mm else "?")

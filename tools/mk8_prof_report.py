@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer tool (GPU box): BASELINE configs[4] over the canonical multi-key node with the M8_PROF build (tools/mk8_prof.sh): cycles a wavefront
+"""Developer tool (GPU box): BASELINE configs[4] over the multi-key node with the M8_PROF build (tools/variant_lib.sh m8prof mk8.hip -DM8_PROF): cycles a wavefront
 spends in each section of the round.  Env: N (instances)."""
 import os
 import sys

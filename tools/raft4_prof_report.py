@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer tool (GPU box): runs the Raft lin-kv batch (BASELINE configs[3]) with the R4_PROF build (tools/raft4_prof.sh) and
+"""Developer tool (GPU box): runs the Raft lin-kv batch (BASELINE configs[3]) with the R4_PROF build (tools/variant_lib.sh r4prof raft4.hip -DR4_PROF) and
 prints the cycles a wavefront spends in each section of the round.  Env: N (instances), PART=1 (partitions + 10 ms latency)."""
 import os
 import sys

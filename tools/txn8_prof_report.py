@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer tool (GPU box): BASELINE configs[4] (txn-list-append) with the T8_PROF build (tools/txn8_prof.sh): cycles a wavefront
+"""Developer tool (GPU box): BASELINE configs[4] (txn-list-append) with the T8_PROF build (tools/variant_lib.sh t8prof txn8.hip -DT8_PROF): cycles a wavefront
 spends in each section of the round.  Env: N (instances)."""
 import os
 import sys

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer tool (GPU box): BASELINE cfg3 (or WL=broadcast) with the WIDE_PROF build (tools/wide_prof.sh): cycles of a wavefront of
+"""Developer tool (GPU box): BASELINE cfg3 (or WL=broadcast) with the WIDE_PROF build (tools/variant_lib.sh wprof k_wide_gset.hip -DWIDE_PROF): cycles of a wavefront of
 sim_kernel_wide<> by section of the round.  Env: N (instances), WL, NODES, LAT, DIST, MSIM_LIB, MSIM_DEV_FLAGS."""
 import os
 import sys
