@@ -31,7 +31,7 @@ def _digest(path, extra):
 def _deps_digest():
     h = hashlib.sha256((CXX + " ".join(FLAGS)).encode())
     deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc")))
-    deps += [os.path.join(ROOT, "include", "maelsim.h"), os.path.join(HERE, "hip", "hip_runtime.h")]
+    deps += [os.path.join(ROOT, "include", "maelsim.h"), os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "rccl", "rccl.h")]
     for d in deps:
         with open(d, "rb") as f:
             h.update(f.read())
@@ -42,9 +42,10 @@ def build(force=False, only=None):
     from maelstrom_amd.build import SOURCES
     os.makedirs(OBJ, exist_ok=True)
     dd = _deps_digest()
-    jobs = [(os.path.join(CSRC, s), os.path.join(OBJ, s + ".o")) for s in SOURCES if os.path.exists(os.path.join(CSRC, s)) and s != "gather.cpp"]   # (RCCL: stubbed)
-    for s in ("hipemu.cpp", "emu_stubs.cpp"):
-        jobs.append((os.path.join(HERE, s), os.path.join(OBJ, s + ".o")))
+    # gather.cpp included: it compiles against tools/hipemu/rccl/rccl.h (types only) and binds librccl.so at run time like the product —
+    # tests put tools/hipemu/_build/librccl.so (rccl_stub.cpp: the same entry points between processes, over a socket) on the path
+    jobs = [(os.path.join(CSRC, s), os.path.join(OBJ, s + ".o")) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    jobs.append((os.path.join(HERE, "hipemu.cpp"), os.path.join(OBJ, "hipemu.cpp.o")))
 
     def one(job):
         src, obj = job
@@ -66,6 +67,14 @@ def build(force=False, only=None):
     cmd = [CXX, "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl", "-pthread"]
     print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    stub_src, stub_out = os.path.join(HERE, "rccl_stub.cpp"), os.path.join(OBJ, "librccl.so")
+    dg = _digest(stub_src, dd)
+    if force or not os.path.exists(stub_out) or not os.path.exists(stub_out + ".stamp") or open(stub_out + ".stamp").read() != dg:
+        cmd = [CXX] + FLAGS + ["-shared", "-o", stub_out, stub_src]
+        print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        with open(stub_out + ".stamp", "w") as f:
+            f.write(dg)
     return OUT
 
 
