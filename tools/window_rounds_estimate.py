@@ -37,12 +37,13 @@ def main():
     lib = O.load()
     cfg = E.test_config("broadcast", node_count=25, rate=100, time_limit=20, latency=lat, latency_dist=dist, seed=7, journal_capacity=400000)
     N = cfg.n_nodes
-    r = O.run(cfg, 0, 1)
+    INST = int(os.environ.get("INST", "0")); r = O.run(cfg, INST, 1)
     assert r.meta["flags"][0] == 0
     ev = r.events(0)
     per_node = [[] for _ in range(N)]   # delivery times per node (server envelopes and client requests)
     general = set()                     # times of rounds that need the scheduler / client machinery
-    sends_at = {}                       # (t, node) -> server sends of that delivery
+    sends_at = {}
+    lat_at = {}                       # (t, node) -> server sends of that delivery
     n_sends = 0
     first_id_at = {}
     for e in ev:
@@ -59,6 +60,7 @@ def main():
                 general.add(t)
             elif dest < N:
                 sends_at[(t, src)] = sends_at.get((t, src), 0) + 1
+                lat_at.setdefault((t, src), []).append(latency_ms(lib, cfg, INST, mid))
                 first_id_at.setdefault((t, src), mid)
             n_sends += 1
     general = sorted(general)
@@ -67,6 +69,7 @@ def main():
     rounds = handled_tot = gen_rounds = 0
     hist = {}
     over_k = 0
+    binds = {}
     next_id_guess = 0
     while True:
         t1 = [per_node[n][ptr[n]] if ptr[n] < len(per_node[n]) else None for n in range(N)]
@@ -86,7 +89,7 @@ def main():
                 # the ids the round's sends will take start at the id of the first send at or after Tm
                 cand = [first_id_at[k] for k in first_id_at if k[0] >= Tm]
                 nid = min(cand) if cand else 0
-                m = min(latency_ms(lib, cfg, 0, nid + j) for j in range(K))
+                m = min(latency_ms(lib, cfg, INST, nid + j) for j in range(K))
             H0 = min(G, Tm + max(m * 1000 - 999, 1))
             B = 1 << 62
             for n in range(N):
@@ -95,6 +98,17 @@ def main():
                 t2 = per_node[n][ptr[n] + 1] if ptr[n] + 1 < len(per_node[n]) else 1 << 62
                 B = min(B, max(t2, t1[n] + 1))
             H = min(H0, B)
+            bind = 'B' if B <= H0 else ('G' if G <= Tm + max(m * 1000 - 999, 1) else 'L')
+            binds[bind] = binds.get(bind, 0) + 1
+            if os.environ.get('NOB'): H = H0
+            if os.environ.get('ACT'):
+                Hc = min(G, B) if not os.environ.get('NOB') else G
+                cmin = 1 << 62
+                for n in range(N):
+                    if t1[n] is not None and t1[n] < Hc:
+                        for l in lat_at.get((t1[n], n), []):
+                            cmin = min(cmin, t1[n] + max(l * 1000 - 999, 1))
+                H = min(Hc, max(cmin, Tm + 1))
         h = 0
         s = 0
         for n in range(N):
@@ -109,6 +123,7 @@ def main():
         hist[h] = hist.get(h, 0) + 1
     print(f"latency {lat} ms {dist}: oracle rounds {int(r.meta['n_rounds'][0])}, deliveries {handled_tot}, window rounds {rounds} "
           f"(of them at scheduler / request times {gen_rounds}), deliveries per window round {handled_tot / rounds:.2f}, rounds with more than K={K} sends {over_k}")
+    print("  binding constraint:", binds)
     print("  handled-per-round histogram:", dict(sorted(hist.items())))
 
 
