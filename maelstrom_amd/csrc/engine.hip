@@ -170,7 +170,8 @@ static uint64_t proto_scratch_words(const msim_config &c) {
     const uint64_t total_ms = (uint64_t)c.time_limit_ms + c.quiesce_ms + 2ull * c.client_timeout_ms;
     const uint64_t ticks = total_ms / 5000 + 3;
     w = ticks * c.n_nodes * (c.max_values / 32);
-    if (c.n_nodes > 32) w = ((w + 3) & ~3ull) + (((uint64_t)c.n_nodes * (c.max_values / 32) + 3) & ~3ull);  // wide clusters: + the nodes' sets
+    // wide clusters: + the union of every tick's snapshots (wide_union_off: what a node that received all of a tick merges in one go) + the nodes' sets
+    if (c.n_nodes > 32) w = ((w + ticks * (c.max_values / 32) + 3) & ~3ull) + (((uint64_t)c.n_nodes * (c.max_values / 32) + 3) & ~3ull);
   }
   const bool bcast_ff = c.node_program == MSIM_NODE_BCAST_FF || c.node_program == MSIM_NODE_BCAST_FF_ECHOBACK;
   const bool bcast_rpc = c.node_program == MSIM_NODE_BCAST_ACK_RETRY || c.node_program == MSIM_NODE_BCAST_RPC_ALL;
@@ -233,13 +234,14 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   kp.dev_flags = msim_dev_flags(ctx);
   const bool wide = c.n_nodes > 32;
   const bool wide_setl = wide_sets_in_lds(c, kp.dev_flags);   // (no row staging in that layout)
-  size_t off = wide_setl ? 0 : (wide ? WIDE_STAGE_ROWS : STAGE_ROWS) * 16;
+  const bool wide_crdt = wide && (c.node_program == MSIM_NODE_G_SET || c.node_program == MSIM_NODE_PN_COUNTER);   // (rows unstaged: sim_kernel_wide.inc ROWS_DIRECT)
+  size_t off = (wide_setl || wide_crdt) ? 0 : (wide ? WIDE_STAGE_ROWS : STAGE_ROWS) * 16;
   const bool is_txn = c.node_program == MSIM_NODE_TXN_SINGLE_KEY, is_px = c.node_program == MSIM_NODE_LIN_KV_PROXY || c.node_program == MSIM_NODE_TSO_IDS;
   const bool is_hat = c.node_program == MSIM_NODE_TXN_RW_HAT, is_mk = c.node_program == MSIM_NODE_TXN_MULTI_KEY, is_kf = c.node_program == MSIM_NODE_KAFKA;
   kp.mk_tcap = is_mk ? mk_tcap(c) : 0; kp.mk_ccap = is_mk ? mk_ccap(c) : 0;
   kp.off_inbox = (u32)off;
   off += is_mk ? ((size_t)(kp.N + 2) * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16 : is_hat ? ((size_t)kp.N * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16 : is_px ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.CS * R_CLIENT_CAP) * 16 : (is_txn || is_kf) ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16
-                : ((size_t)kp.N * kp.cap_node + (size_t)kp.CS * (is_raft ? R_CLIENT_CAP : CLIENT_INBOX_CAP)) * 16;
+                : ((size_t)kp.N * kp.cap_node + (size_t)kp.CS * (is_raft ? R_CLIENT_CAP : CLIENT_INBOX_CAP)) * 16 + wide_client_bytes(c);   // (wide: + the pairs' client state)
   kp.off_seen = (u32)off;
   off += is_mk ? ((size_t)kp.N * MK_SL * mk_slot_words(mk_keys_for(c)) + (size_t)kp.N * mk_keys_for(c) * 3 + 36) * 4   // transactions in flight (the first MK_SL per node), a round's messages per node, the generator's key pool
        : is_hat ? 36 * 4   // the generator's key pool
@@ -247,7 +249,7 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
        : is_txn ? (size_t)kp.N * TXN_SLOTS * 16 + 36 * 4   // transactions in flight per node + the generator's key pool
        : is_kf ? ((size_t)kp.N * KF_SLOTS * KSW + 2 * (size_t)kp.N * KF_KEYS + 36 + 2 * KF_KEYS) * 4   // request handlers, offset caches, client offsets, key pool, lin-kv lengths
        : is_raft ? (size_t)kp.N * 256 + (size_t)kp.N * kp.N * 3 * 4   // KV state + next/match index + append_entries refs
-       : wide ? (wide_setl ? (size_t)kp.N * kp.W * 4 : 0)   // the sets of a wide cluster live in HBM scratch unless they fit LDS (wide_sets_in_lds)
+       : wide ? (wide_setl ? (size_t)kp.N * kp.W * 4 : 0) + wide_pending_bytes(c)   // the sets of a wide cluster live in HBM scratch unless they fit LDS (wide_sets_in_lds); + the CRDTs' delivered-but-unmerged replicates
                  : (size_t)kp.N * kp.W * 4;
   off = (off + 15) & ~(size_t)15;
   kp.off_misc = (u32)off; if (c.nemesis_mask) off += (wide ? 128 : 64) * 4;  // shuffle scratch, only the partition nemesis needs it

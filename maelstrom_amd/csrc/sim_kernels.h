@@ -63,6 +63,19 @@ __device__ __forceinline__ void merge_snapshot(u32 *mine, const u32 *snap, u32 W
 }
 
 
+// wide g-set / counters: replicate ticks a run can see (the snapshot slots and the per-tick unions in HBM scratch are indexed by tick)
+__host__ __device__ static inline uint32_t wide_crdt_ticks(const msim_config &c) {
+  return (uint32_t)(((uint64_t)c.time_limit_ms + c.quiesce_ms + 2ull * c.client_timeout_ms) / 5000 + 3);
+}
+// ... and the LDS a wide CRDT cluster keeps per node for the replicates it has received and not merged yet (sim_kernel_wide.inc: WPEND words)
+#define WPEND 6u
+// ... and for every wide cluster the client state that lives in LDS (sim_kernel_wide.inc CL(): WIDE_CLW words per pair + a dummy entry)
+#define WIDE_CLW 11u
+static inline size_t wide_client_bytes(const msim_config &c) { return c.n_nodes > 32 ? (((size_t)c.n_nodes + 1) * WIDE_CLW * 4 + 15) & ~(size_t)15 : 0; }
+static inline size_t wide_pending_bytes(const msim_config &c) {
+  return c.n_nodes > 32 && (c.node_program == MSIM_NODE_G_SET || c.node_program == MSIM_NODE_PN_COUNTER) ? (size_t)c.n_nodes * WPEND * 4 : 0;
+}
+
 #include "sim_kernel_general.inc"
 #include "sim_kernel_colo.inc"
 #include "sim_kernel_raft.inc"
@@ -73,14 +86,16 @@ __device__ __forceinline__ void merge_snapshot(u32 *mine, const u32 *snap, u32 W
 #include "sim_kernel_kafka.inc"
 #include "sim_kernel_svc.inc"
 
-// Which wide clusters keep their nodes' sets in LDS (SETL): g-set, when sets + client inboxes + the LDS part of the queues leave a CU
-// at least four clusters (40 KiB each); MSIM_DEV_FLAGS bit 14 keeps the sets in HBM scratch.  Measured (profiles/r03k_wide_sets.txt):
-// cfg3 417 -> 348 ms per 16384 clusters.  Fire-and-forget broadcast stays in HBM scratch: its set traffic is one word per delivery,
-// and at 20.8 KiB of LDS per cluster a CU holds 7 clusters where a batch of 2048 needs 8 — 121 -> 198 ms per 2048 clusters at n = 100.
+// Which wide clusters keep their nodes' sets in LDS (SETL) instead of HBM scratch.  Round 3 took the layout for g-set when sets + client
+// inboxes fit 40 KiB (a set union was a ds_or instead of an L2 atomic: cfg3 417 -> 348 ms per 16384 clusters).  Since replicate deliveries
+// are noted and merged when the node's state is next looked at (round 4, sim_kernel_wide.inc: a union per tick instead of N - 1 snapshots)
+// a set is rarely touched, and the 17.6 KiB of sets per cluster cost more in resident wavefronts than they save: cfg3 274 ms with the sets in
+// LDS, 207 ms in HBM scratch (5 % loss: 410 / 312 ms, 50 %: 283 / 215 ms; profiles/r04f_wide_sets.txt).  HBM scratch is the default now,
+// MSIM_DEV_FLAGS bit 14 asks for the LDS layout (both are parity-tested).
 static inline bool wide_sets_in_lds(const msim_config &c, uint32_t dev_flags) {
-  if (c.n_nodes <= 32 || (dev_flags & 0x4000u)) return false;
+  if (c.n_nodes <= 32 || !(dev_flags & 0x4000u)) return false;
   if (c.node_program != MSIM_NODE_G_SET) return false;
-  const size_t bytes = ((size_t)c.n_nodes * c.inbox_capacity + (size_t)c.n_nodes * CLIENT_INBOX_CAP) * 16 + (size_t)c.n_nodes * (c.max_values / 32) * 4 + (c.nemesis_mask ? 512 : 0) + 16;
+  const size_t bytes = ((size_t)c.n_nodes * c.inbox_capacity + (size_t)c.n_nodes * CLIENT_INBOX_CAP) * 16 + (size_t)c.n_nodes * (c.max_values / 32) * 4 + wide_pending_bytes(c) + wide_client_bytes(c) + (c.nemesis_mask ? 512 : 0) + 16;
   return bytes <= 40 * 1024;
 }
 

@@ -17,6 +17,9 @@ EMU = os.path.join(ROOT, "tools", "hipemu", "_build", "libmaelsim_emu.so")
 CASES = [
     "duo25", "duo25exp",
     "{'workload':'g-set','node_count':40,'rate':40,'time_limit':6,'latency':50,'latency_dist':'exponential','p_loss':0.05,'n':2}",
+    "{'workload':'g-set','node_count':40,'rate':40,'time_limit':11,'latency':50,'latency_dist':'exponential','n':2,'flags':0x4000}",   # whole ticks: the union merge; sets in LDS
+    "{'workload':'g-set','node_count':45,'rate':50,'time_limit':12,'latency':3000,'latency_dist':'exponential','n':1}",             # ticks overlap: a slot is flushed for another tick
+    "{'workload':'pn-counter','node_count':40,'rate':50,'time_limit':12,'latency':50,'p_loss':0.2,'n':1}",
     "{'workload':'broadcast','node_count':36,'rate':20,'time_limit':3,'latency':10,'topology':'tree3','n':1}",
     "{'workload':'txn-list-append','bin':'multi-key-txn','node_count':5,'rate':60,'time_limit':5,'latency':5,'nemesis':['partition'],'nemesis_interval':2,'n':9}",
     "{'workload':'txn-list-append','node_count':5,'rate':60,'time_limit':5,'latency':5,'nemesis':['partition'],'nemesis_interval':2,'n':9}",

@@ -163,13 +163,14 @@ def test_g_set_parity(lib):
 ])
 def test_wide_g_set_parity(lib, n, kw):
     """BASELINE cfg3: clusters wider than 32 nodes (two node/client pairs per lane, sim_kernel_wide<>), with
-    randomized latency and message loss; same oracle code path as narrow clusters.  Both layouts of the nodes' sets: in LDS (the
-    default where they fit: sim_kernel_wide<.., SETL = true>) and in HBM scratch (MSIM_DEV_FLAGS bit 14); with the lone-operation
-    path (default) and with every operation on the general path (bit 1)."""
+    randomized latency and message loss; same oracle code path as narrow clusters.  Both layouts of the nodes' sets: in HBM scratch
+    (the default since replicate deliveries are merged lazily) and in LDS (MSIM_DEV_FLAGS bit 14: sim_kernel_wide<.., SETL = true>);
+    with the lone-operation path (default) and with every operation on the general path (bit 1), in either layout."""
     cfg = E.test_config("g-set", node_count=n, rate=100, time_limit=12, seed=77, **kw)
     _compare(cfg, 0, 3)
     _compare(cfg, 0, 3, dev_flags=0x4000)
     _compare(cfg, 0, 2, dev_flags=0x2)
+    _compare(cfg, 0, 2, dev_flags=0x4002)
 
 
 @pytest.mark.parametrize("n,kw", [

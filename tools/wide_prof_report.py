@@ -25,7 +25,7 @@ with E.Engine(cfg) as eng:
         st, m = eng.net_stats_raw(i), eng.meta(i)
         a.append([st.all_send, st.all_recv, st.clients_send, st.clients_recv, st.servers_send, st.servers_recv, m.reserved[0] * 64, m.reserved[1] * 64, m.reserved[2] * 64, m.n_events * 64, m.n_rounds])
 a = np.array(a, dtype=np.float64)
-names = ["phase checks + R0 (time)", "quiet-round test", "quiet: deliveries merged", "quiet: polls", "general: scheduler .. arrivals", "general: sort passes", "general: polls", "rows", "lone-operation path + its test", "general: R4 (clients)"]
+names = ["phase checks + R0 (time)", "quiet-round test", "quiet: deliveries noted", "quiet: polls", "general: scheduler .. arrivals", "general: sort passes", "general: polls", "rows", "lone-operation path + its test", "general: R4 (clients)"]
 NS = len(names)
 tot = a[:, :NS].sum(axis=1).mean()
 print(f"{kw['workload']} n={kw['node_count']} latency {kw['latency']} ms {kw['latency_dist']}, {n} instances: sim kernel {sim_ms:.2f} ms, cycles per wavefront {tot:.3e}, rounds {a[:, NS].mean():.0f} ({tot / a[:, NS].mean():.0f} cycles per round)")
