@@ -25,6 +25,7 @@
 #include <cstdio>
 
 #include "group8.h"
+#include "layout_thresholds.h"
 
 namespace {
 
@@ -406,7 +407,7 @@ uint64_t msim_bcast8_extra_scratch_words(const msim_config &c) { return (uint64_
 
 hipError_t msim_launch_bcast8(const KParams &kp, uint32_t n, hipStream_t st) {
   const msim_config &c = kp.cfg;
-  if (n < 12288u && !(kp.dev_flags & 0x400u)) return MSIM_LAYOUT_DOES_NOT_FIT;   // (see the header)
+  if (n < MSIM_BCAST8_MIN_CLUSTERS && !(kp.dev_flags & 0x400u)) return MSIM_LAYOUT_DOES_NOT_FIT;   // (see the header)
   B8Params up;
   up.k = kp; up.n_inst = n;
   const uint32_t cap_tot = c.inbox_capacity + c.spill_capacity;

@@ -25,6 +25,7 @@
 #include <cstdio>
 
 #include "group8.h"
+#include "layout_thresholds.h"
 
 namespace {
 
@@ -577,7 +578,7 @@ hipError_t msim_launch_hat8(const KParams &kp, uint32_t n, hipStream_t st) {
   // it.  Measured crossovers (profiles/r03ae_hat8.txt; both kernels with the wavefront-wide list passes): 2 nodes 8192 clusters (37.8
   // against 44.9 ms; 16384: 44.5 / 85.7), 3 nodes between 8192 and 16384 (63 / 53, 75 / 103), 5 nodes near 16384 (112 / 128; 8192:
   // 97 / 68).  MSIM_DEV_FLAGS bit 10 asks for this layout whatever the batch.
-  if (n < 3200u * c.n_nodes && !(kp.dev_flags & 0x400u)) return MSIM_LAYOUT_DOES_NOT_FIT;   // (6400 / 9600 / 16000 clusters of 2 / 3 / 5 nodes)
+  if (n < MSIM_HAT8_MIN_CLUSTERS_PER_NODE * c.n_nodes && !(kp.dev_flags & 0x400u)) return MSIM_LAYOUT_DOES_NOT_FIT;   // (6400 / 9600 / 16000 clusters of 2 / 3 / 5 nodes)
   H8Params up;
   up.k = kp; up.n_inst = n;
   const uint32_t cap_tot = c.inbox_capacity + c.spill_capacity;

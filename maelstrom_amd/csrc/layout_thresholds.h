@@ -1,0 +1,18 @@
+// layout_thresholds.h — the launch sizes from which the eight-clusters-per-wavefront layouts are taken instead of one cluster per
+// wavefront (msim_launch_*8 return MSIM_LAYOUT_DOES_NOT_FIT below them and msim_run falls back; MSIM_DEV_FLAGS bit 10 forces the
+// packed layout whatever the launch).  The packed kernels are latency-bound — a wavefront's run takes a fixed time whatever the batch —
+// so they win from the batch size on where the one-cluster kernels have filled the chip.  Each number is a crossover MEASURED on one
+// MI355X (256 CUs); on another part they are the first thing to re-measure.
+//
+//   constant                     value   crossover measured                                                      profile
+//   MSIM_UID8_MIN_CLUSTERS        4096   unique-ids 3 nodes: 18.9 ms packed against 38.8 ms at 4096 clusters      profiles/r03am_uid8.txt
+//   MSIM_CRDT8_MIN_CLUSTERS       4096   pn-counter 5 nodes: 7.0 against 30.4 ms at 16384; even at 4096           profiles/r03an_crdt8.txt
+//   MSIM_BCAST8_MIN_CLUSTERS     12288   broadcast 5 nodes: 23.7 against 14.8 ms at 4096 (loses), 26.8 / 47.6 at 16384   profiles/r03ar_bcast8.txt
+//   MSIM_HAT8_MIN_CLUSTERS_PER_NODE 3200 txn-rw-register: 2 nodes even near 6400, 3 nodes 8192..16384, 5 nodes near 16384   profiles/r03ae_hat8.txt
+#ifndef MSIM_LAYOUT_THRESHOLDS_H
+#define MSIM_LAYOUT_THRESHOLDS_H
+#define MSIM_UID8_MIN_CLUSTERS 4096u
+#define MSIM_CRDT8_MIN_CLUSTERS 4096u
+#define MSIM_BCAST8_MIN_CLUSTERS 12288u
+#define MSIM_HAT8_MIN_CLUSTERS_PER_NODE 3200u
+#endif
