@@ -187,6 +187,7 @@ static uint64_t scratch_words(const msim_config &c) {
   if (msim_txn8_eligible(c)) w += msim_txn8_extra_scratch_words(c);     // txn8.hip likewise
   if (msim_mk8_eligible(c)) w += msim_mk8_extra_scratch_words(c);       // mk8.hip likewise
   if (msim_hat8_eligible(c)) w += msim_hat8_extra_scratch_words(c);     // hat8.hip likewise
+  if (msim_kafka8_eligible(c)) w += msim_kafka8_extra_scratch_words(c); // kafka8.hip likewise
   if (msim_uid8_eligible(c)) w += msim_uid8_extra_scratch_words(c);     // uid8.hip likewise
   if (msim_crdt8_eligible(c)) w += msim_crdt8_extra_scratch_words(c);   // crdt8.hip likewise
   if (msim_bcast8_eligible(c)) w += msim_bcast8_extra_scratch_words(c); // bcast8.hip likewise
@@ -274,6 +275,8 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   if (msim_mk8_eligible(c) && !(kp.dev_flags & 0x200u)) e = msim_launch_mk8(kp, n, st);
   // txn-rw-register over the highly-available-transactions node: eight clusters per wavefront (hat8.hip)
   if (msim_hat8_eligible(c) && !(kp.dev_flags & 0x200u)) e = msim_launch_hat8(kp, n, st);
+  // kafka: eight clusters per wavefront (kafka8.hip) for large batches
+  if (msim_kafka8_eligible(c) && !(kp.dev_flags & 0x200u)) e = msim_launch_kafka8(kp, n, st);
   // echo / unique-ids (flake ids): eight clusters per wavefront (uid8.hip) for large batches of small clusters
   if (msim_uid8_eligible(c) && !(kp.dev_flags & 0x200u)) e = msim_launch_uid8(kp, n, st);
   // g-set / pn-counter / g-counter: eight clusters per wavefront (crdt8.hip) for large batches of small clusters

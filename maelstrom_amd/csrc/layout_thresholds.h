@@ -15,4 +15,5 @@
 #define MSIM_CRDT8_MIN_CLUSTERS 4096u
 #define MSIM_BCAST8_MIN_CLUSTERS 12288u
 #define MSIM_HAT8_MIN_CLUSTERS_PER_NODE 3200u
+#define MSIM_KAFKA8_MIN_CLUSTERS 4096u
 #endif

@@ -191,6 +191,10 @@ hipError_t msim_launch_txn8(const KParams &kp, uint32_t n, hipStream_t st);
 bool msim_hat8_eligible(const msim_config &c);
 uint64_t msim_hat8_extra_scratch_words(const msim_config &c);
 hipError_t msim_launch_hat8(const KParams &kp, uint32_t n, hipStream_t st);
+// kafka8.hip: eight kafka clusters per wavefront (the kafka node over lin-kv, clusters of <= 8 lanes)
+bool msim_kafka8_eligible(const msim_config &c);
+uint64_t msim_kafka8_extra_scratch_words(const msim_config &c);
+hipError_t msim_launch_kafka8(const KParams &kp, uint32_t n, hipStream_t st);
 // uid8.hip: eight echo / unique-ids clusters per wavefront (programs whose nodes talk to their clients only, clusters of <= 8 lanes)
 bool msim_uid8_eligible(const msim_config &c);
 uint64_t msim_uid8_extra_scratch_words(const msim_config &c);

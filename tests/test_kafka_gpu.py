@@ -17,6 +17,7 @@ SHAPES = [
     dict(node_count=2, rate=200, time_limit=4, latency=2, key_count=2, max_writes_per_key=40, seed=8),   # keys retire, chunks fill
     dict(node_count=5, rate=100, time_limit=5, latency=150, seed=9),                                    # slow lin-kv: client timeouts
     dict(node_count=3, rate=30, time_limit=4, latency=3, journal=True, seed=10),
+    dict(node_count=7, rate=150, time_limit=8, latency=30, latency_dist="exponential", p_loss=0.02, nemesis=["partition"], nemesis_interval=2, seed=19),
 ]
 
 
@@ -28,6 +29,8 @@ def test_kafka_parity(lib, kw):
     if journal:
         cfg.journal_capacity = 60000
     ora = _compare(cfg, 0, 6)
+    if not journal:
+        _compare(cfg, 0, 11, dev_flags=0x400)   # eight clusters per wavefront (csrc/kafka8.hip; large batches take it unasked)
     ops = E.decode_history(*ora.history(0), cfg.n_nodes, A.WL_KAFKA)
     fs = {op["f"] for op in ops}
     assert {":send", ":poll", ":assign"} <= fs
