@@ -101,6 +101,7 @@ int check_key(const msim_op *rows, const std::vector<uint32_t> &idx) {
   std::unordered_map<uint32_t, uint32_t> slot_of;
   std::vector<uint32_t> op_in_slot(64, 0);
   uint64_t pending = 0, info_bits = 0;   // info_bits: pending ops that will never return (:info, or no completion)
+  uint64_t twins_below[64];              // per never-returning op: the never-returning ops in LOWER slots that are the same operation
   // Dominance: for equal (register value, linearized returning ops), a configuration that has linearized FEWER
   // never-returning ops can still do everything the other can (it may apply them later, or never).  Only the
   // minimal ones are kept — without this, k indeterminate writes cost 2^k configurations.
@@ -126,7 +127,15 @@ int check_key(const msim_op *rows, const std::vector<uint32_t> &idx) {
       if (pending == ~0ull) return 2;
       const uint32_t s = (uint32_t)__builtin_ctzll(~pending);
       pending |= 1ull << s; slot_of[ev.id] = s; op_in_slot[s] = ev.id;
-      if (!eff[ev.id].ok) info_bits |= 1ull << s;
+      if (!eff[ev.id].ok) {
+        const Op &o = eff[ev.id];
+        twins_below[s] = 0;
+        for (uint64_t m = info_bits; m && !o.skip; m &= m - 1) {
+          const uint32_t j = (uint32_t)__builtin_ctzll(m); const Op &t = eff[op_in_slot[j]];
+          if (t.f == o.f && t.v1 == o.v1 && t.v2 == o.v2 && !t.skip) { if (j < s) twins_below[s] |= 1ull << j; else twins_below[j] |= 1ull << s; }
+        }
+        info_bits |= 1ull << s;
+      }
       continue;
     }
     const uint32_t s = slot_of[ev.id];
@@ -144,6 +153,10 @@ int check_key(const msim_op *rows, const std::vector<uint32_t> &idx) {
         const uint32_t j = (uint32_t)__builtin_ctzll(cand); cand &= cand - 1;
         const Op &o = eff[op_in_slot[j]];
         if (o.skip) continue;
+        // Symmetry: never-returning calls that are the same operation are interchangeable from now on (none of them constrains
+        // anything later), so of those not yet linearized only the one in the lowest slot is tried — exact, and it keeps k
+        // identical timed-out writes from costing 2^k configurations that dominance cannot compare.
+        if (((info_bits >> j) & 1) && (twins_below[j] & ~c.lin)) continue;
         uint32_t nv;
         if (!step(c.val, o, &nv)) continue;
         const Cfg c2{c.lin | (1ull << j), nv};

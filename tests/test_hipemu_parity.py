@@ -79,10 +79,11 @@ def test_kafka_check_kernel_on_the_emulator_equals_the_host_checker(emu_lib):
 @pytest.mark.timeout(1800)
 def test_device_checkers_on_the_emulator_equal_the_host_checkers(emu_lib):
     """The unique-ids check (a history's id table in LDS / in HBM workspace, tests/test_checker_gpu.py), the rw-register analysis
-    (tests/test_rw_check_gpu.py) and the reference-held set-full / linearizability vectors (tests/test_checker_reference_vectors.py)
+    (tests/test_rw_check_gpu.py), the wide keys of the lin-kv search (tests/test_lin_check_gpu.py) and the reference-held set-full / linearizability vectors (tests/test_checker_reference_vectors.py)
     through the emulated device kernels."""
     env = dict(os.environ, MSIM_LIB=emu_lib, HIPEMU_DIVERGENT="1")
     for args in ([os.path.join(ROOT, "tests", "test_checker_gpu.py"), "-k", "unique"], [os.path.join(ROOT, "tests", "test_rw_check_gpu.py")],
+                 [os.path.join(ROOT, "tests", "test_lin_check_gpu.py")],   # the linearizability search beyond 64 configurations: LDS pools, the host for the rest
                  [os.path.join(ROOT, "tests", "test_checker_reference_vectors.py")]):   # set-full / linearizability against the runs the reference docs print
         r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
         assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
