@@ -2,20 +2,26 @@
 //
 // The reference's lin-kv checker is `independent/checker` over Knossos' `checker/linearizable` with a CAS-register model
 // (workload/lin_kv.clj:84, [upstream] jepsen.tests.linearizable-register).  lin_check.cpp restates it on the host as just-in-time
-// linearization with dominance pruning; this file is the same search laid out for a wavefront, one wavefront per history:
+// linearization with dominance pruning (and the symmetry of identical never-returning calls); this file is the same search on the device:
 //
 //   * a CONFIGURATION (register value, set of pending calls already linearized) lives in the registers of one lane — at most 64
 //     at a time; a PENDING CALL (process, f, values, will-it-return) lives in the registers of the lane that carries its bit;
-//   * "is this configuration dominated / does it dominate" is one compare per lane and a ballot; a new configuration goes to the
-//     first free lane; the worklist is a 64-bit mask; what a step needs from another lane comes with v_readlane;
+//   * when a call returns, the frontier is expanded a call at a time for all its configurations at once; "is this successor
+//     dominated / does it dominate" is one compare per lane and a ballot; a new configuration goes to the first free lane;
 //   * pass 0 streams the rows once (64 rows = 1 KiB per load), pairs every invocation with its completion (the call's outcome
 //     decides how the search treats it from the start: a :fail never happened, an :ok read must see its value, everything else
-//     stays pending forever) and notes the row range of each key; pass 1 walks the ranges key by key.
+//     stays pending forever) and notes the row range of each key; then the keys are walked one by one;
+//   * a closure that needs more than 64 configurations (many calls open at once: a partition that leaves a dozen writes and cas
+//     indeterminate) moves to a POOL — a hash table over (value, linearized returning calls) whose chains are what dominance
+//     compares, filled by every thread with compare-and-swap pushes — and the survivors come back to the registers as soon as 64
+//     lanes hold them again.  Pass 1 (one wavefront per history, 14 per CU) has pools of 2048 configurations in an HBM workspace;
+//     what outgrows those runs again in pass 2 (a workgroup of 1024 per history, the pool in LDS: 14 784 configurations), and a
+//     closure that outgrows that too moves on to an HBM slot of 262 144.
 //
-// The search is exact, so its verdict is the host's.  A history that needs more than 64 configurations at a time (many calls
-// open at once: a partition that keeps every client waiting) is marked and runs again with eight configurations per lane; what
-// exceeds that too (or 64 pending calls in the pairing table, more rows than the LDS table covers, a runaway search) goes to the
-// host search of lin_check.cpp (lin_check_dev_run below) — never silently approximated.
+// The search is exact, so its verdict is the host's.  What exceeds all of that (or 64 pending calls in the pairing table, 23 on one
+// key while a pool is in use, more rows than the LDS table covers) goes to the host search of lin_check.cpp — never silently
+// approximated.  BASELINE configs[3] with partitions: 8192 histories, 3147 use a pool, 73 reach pass 2, 2 the large HBM slots, none
+// the host: 66 ms where the registers-then-host version of round 3 took 127 (profiles/r04v_lin_check.txt).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -25,6 +31,7 @@
 #include <cstdlib>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "engine_internal.h"
@@ -52,13 +59,25 @@ __device__ __forceinline__ u32 l_wave_sum(u32 v) {
   return v;
 }
 
+// The outcome table of a history (LDS): per row 16 bits of value (bytes 1 and 2 of the completion's value word) and 2 bits of state
+// (0 = no completion, else the completion's type), 2.125 bytes per row — pass 1 keeps 14 histories per CU resident with it.
+struct Outcome { unsigned short *val; u32 *state; };
+__host__ __device__ __forceinline__ size_t outcome_bytes(u32 rows) { return (((size_t)rows * 2 + 3) & ~(size_t)3) + (size_t)((rows + 15) / 16) * 4; }
+__device__ __forceinline__ Outcome outcome_at(u32 *base, u32 rows) { Outcome o; o.state = base; o.val = reinterpret_cast<unsigned short *>(base + (rows + 15) / 16); return o; }
+// bit 31 = has a completion, bits 0-1 its type, bits 8-23 its value bytes 1 and 2
+__device__ __forceinline__ u32 outcome_get(const Outcome &o, u32 row) {
+  const u32 st = (o.state[row >> 4] >> ((row & 15u) * 2u)) & 3u;
+  return st ? (0x80000000u | st | ((u32)o.val[row] << 8)) : 0u;
+}
+
 // ---- pass 0: counts, key ranges, invocation -> completion (one wavefront) ------------------------------------------------------------
-// outcome word of an invocation row: bit 31 = has a completion, bits 0-1 its type, bits 8-23 its value bytes 1 and 2.
 // Returns false when more than 64 calls are open at once (the pairing table is the wavefront).
-__device__ bool pair_rows(const uint4 *r, u32 n, u32 *key_lo, u32 *key_hi, u32 *outcome, u32 lane, u32 &c_inv, u32 &c_ok, u32 &c_fail, u32 &c_info) {
+__device__ bool pair_rows(const uint4 *r, u32 n, u32 *key_lo, u32 *key_hi, const Outcome outcome, u32 lane, u32 &c_inv, u32 &c_ok, u32 &c_fail, u32 &c_info) {
   bool o_used = false; u32 o_proc = 0, o_key = 0, o_row = 0;   // lane = one open call
   c_inv = 0; c_ok = 0; c_fail = 0; c_info = 0;
   bool fits = true;
+  for (u32 i = lane; i < (n + 15) / 16; i += 64) outcome.state[i] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   for (u32 base = 0; base < n && fits; base += 64) {
     const u32 idx = base + lane;
     uint4 row = make_uint4(0, 0, 0, 0);
@@ -68,7 +87,6 @@ __device__ bool pair_rows(const uint4 *r, u32 n, u32 *key_lo, u32 *key_hi, u32 *
     if (live) { c_inv += type == MSIM_T_INVOKE; c_ok += type == MSIM_T_OK; c_fail += type == MSIM_T_FAIL; c_info += type == MSIM_T_INFO; }
     const bool reg = live && (f == MSIM_F_READ || f == MSIM_F_WRITE || f == MSIM_F_CAS);
     if (reg) { atomicMin(&key_lo[row.w & 0xFFu], idx); atomicMax(&key_hi[row.w & 0xFFu], idx); }
-    if (reg && type == MSIM_T_INVOKE) outcome[idx] = 0;
     u64 m = __ballot(reg);
     while (m) {
       const u32 j = (u32)__builtin_ctzll(m); m &= m - 1;
@@ -87,7 +105,7 @@ __device__ bool pair_rows(const uint4 *r, u32 n, u32 *key_lo, u32 *key_hi, u32 *
       } else if (hit) {
         const u32 s = (u32)__builtin_ctzll(hit);
         const u32 irow = rl(o_row, s);
-        if (lane == s) { o_used = false; outcome[irow] = 0x80000000u | jt | (w & 0xFFFF00u); }
+        if (lane == s) { o_used = false; outcome.val[irow] = (unsigned short)(w >> 8); outcome.state[irow >> 4] |= jt << ((irow & 15u) * 2u); }   // (a completion's type is 1..3)
       }
     }
   }
@@ -97,17 +115,214 @@ __device__ bool pair_rows(const uint4 *r, u32 n, u32 *key_lo, u32 *key_hi, u32 *
 
 enum { KEY_OK = 0, KEY_BAD = 1, KEY_UNKNOWN = 2, KEY_TOO_WIDE = 3 };   // what the search of one key returns
 
-// ---- one key, the configurations in registers (one wavefront) ---------------------------------------------------------------------
-// configurations: lane i holds (c_lin[b], c_val[b]) while bit i of alive[b] is set; pending calls: lane s holds slot s
-template <int CPL>   // configurations per lane: 64 * CPL at a time
-__device__ int search_key_regs(const uint4 *r, u32 n, u32 k, u32 lo, u32 hi, const u32 *outcome, u32 lane) {
-  u64 c_lin[CPL]; u32 c_val[CPL]; u64 alive[CPL], expanded[CPL];
-#pragma unroll
-  for (int b = 0; b < CPL; b++) { c_lin[b] = 0; c_val[b] = 0xFFu; alive[b] = 0; expanded[b] = 0; }
-  alive[0] = 1ull;
+// ---- the configurations of one key in registers (one wavefront) ------------------------------------------------------------------
+// lane i holds configuration i (c_lin, c_val) while bit i of `alive` is set; pending calls: lane s holds slot s (s_proc, s_op =
+// f | v1 << 8 | v2 << 16 | skip << 31, s_ok, s_tw = for a never-returning call the never-returning calls in lower slots that are the
+// same operation — the symmetry of lin_check.cpp: of identical ones only the lowest unused is tried).
+struct RegSet { u64 c_lin; u32 c_val; u64 alive; };
+
+// Every surviving configuration must have linearized the call with bit `bit` when it returns: close the set under linearizing
+// pending calls, then keep what contains the bit.  The frontier is expanded a call at a time, all its configurations at once: one
+// lane-parallel step decides which configurations may linearize call q next, and only those LEGAL successors are admitted one
+// after the other (two ballots each: is it dominated, what does it dominate).  Returns KEY_OK (S = the survivors, the bit
+// stripped), KEY_BAD (none) or KEY_TOO_WIDE (more than 64 at once: S = what was reached so far, ov_* = the one that did not fit).
+__device__ int close_regs(RegSet &S, u64 pending, u64 info_bits, u32 s_op, u64 s_tw, u64 bit, u32 lane, u64 &ov_lin, u32 &ov_val) {
+  u64 expanded = 0;
+  u32 admitted = 0;
+  for (;;) {
+    const u64 front = S.alive & ~expanded;
+    if (!front) break;
+    expanded |= front;
+    bool mine = ((front >> lane) & 1ull) && !(S.c_lin & bit);
+    if (!__ballot(mine)) continue;
+    u64 calls = pending;
+    while (calls) {
+      const u32 q = (u32)__builtin_ctzll(calls); calls &= calls - 1;
+      const u32 op = rl(s_op, q);
+      if (op >> 31) continue;                                             // an unfinished read constrains nothing
+      u64 tw = 0;
+      if ((info_bits >> q) & 1ull) tw = ((u64)rl((u32)(s_tw >> 32), q) << 32) | rl((u32)s_tw, q);
+      const u32 of = op & 0xFFu, v1 = (op >> 8) & 0xFFu, v2 = (op >> 16) & 0xFFu;
+      bool legal = mine && ((S.alive >> lane) & 1ull) && !((S.c_lin >> q) & 1ull) && !(tw & ~S.c_lin);
+      u32 nv = S.c_val;
+      if (of == MSIM_F_READ) legal = legal && S.c_val == v1;              // only :ok reads are stepped; they must see the current value
+      else if (of == MSIM_F_WRITE) nv = v1;
+      else { legal = legal && S.c_val == v1; nv = v2; }                   // cas [v v']
+      u64 m = __ballot(legal);
+      while (m) {
+        const u32 j = (u32)__builtin_ctzll(m); m &= m - 1;
+        const u64 lin2 = (((u64)rl((u32)(S.c_lin >> 32), j) << 32) | rl((u32)S.c_lin, j)) | (1ull << q);
+        const u32 nv2 = rl(nv, j);
+        // Dominance: for equal (value, linearized returning calls), a configuration that has linearized FEWER never-returning
+        // calls can still do everything the other can.  Keep only the minimal ones.
+        const u64 ib2 = lin2 & info_bits, key2 = lin2 & ~info_bits;
+        const bool same = ((S.alive >> lane) & 1ull) && S.c_val == nv2 && (S.c_lin & ~info_bits) == key2;
+        const u64 my_ib = S.c_lin & info_bits;
+        if (__ballot(same && (my_ib & ib2) == my_ib)) continue;           // an existing subset dominates the new one (or is it)
+        const u64 kill = __ballot(same && (my_ib & ib2) == ib2);          // the new one dominates these: their successors are dominated by its
+        S.alive &= ~kill; m &= ~kill;
+        if (++admitted > EXPLORE_LIMIT) { ov_lin = lin2; ov_val = nv2; return KEY_TOO_WIDE; }
+        if (S.alive == ~0ull) { ov_lin = lin2; ov_val = nv2; return KEY_TOO_WIDE; }
+        const u32 fl = (u32)__builtin_ctzll(~S.alive);
+        if (lane == fl) { S.c_lin = lin2; S.c_val = nv2; mine = false; }  // (a new configuration: the next round expands it)
+        S.alive |= 1ull << fl; expanded &= ~(1ull << fl); m &= ~(1ull << fl);
+      }
+    }
+  }
+  S.alive = __ballot(((S.alive >> lane) & 1ull) && (S.c_lin & bit));       // the others could not linearize the call in time
+  S.c_lin &= ~bit;
+  return S.alive ? KEY_OK : KEY_BAD;
+}
+
+// ---- the configurations in an LDS table (one workgroup) ----------------------------------------------------------------------------
+// For the moments a key's search outgrows the registers (a partition that leaves a dozen writes and cas indeterminate: thousands of
+// configurations while one call returns).  A configuration is one word — value << 24 | DEAD | linearized calls (23 slots) — in a pool
+// that is also the work list (entries are expanded in the order they were admitted, a workgroup's worth at a time); the pool is
+// chained into a hash table over (value, linearized RETURNING calls), so that what dominance has to compare — the sets of linearized
+// never-returning calls of one such group — is one chain.  Every thread admits its own candidates: walk the chain (dominated: drop;
+// dominating: mark the old entry DEAD), then push with a compare-and-swap on the chain's head; a push that loses the race walks what
+// arrived meanwhile and tries again.  Two candidates admitted in the same instant may both survive although one dominates the other
+// — that costs work, never the verdict: the search stays exact, dominance is only what keeps it small.
+// The pool's arrays are in LDS (pass 2, until a closure outgrows them) or in a slot of an HBM workspace (pass 1, which keeps 14
+// histories per CU resident and needs a pool for one closure in a hundred; pass 2 after a closure has outgrown the LDS one): the
+// pointers are generic, what the threads hand each other through them is read with agent-scope loads (past the vector L1 when it
+// is HBM) and published behind an agent-scope release.  ctr / ops / tws are always LDS.
+struct Pool { u32 *cfg, *next, *heads, *outb; u32 *ctr, *ops, *tws; u32 cap, n_heads, out_cap; };
+constexpr u32 P_NIL = 0xFFFFFFFFu;   // end of a chain
+constexpr u32 P_DEAD = 1u << 23, P_LIN = 0x7FFFFFu;
+// P.ctr: 0 entries in the pool, 1 survivors, 2 overflow, 3 command of the first wavefront to the others, 4 (trace) why a key was too wide,
+//        5 pending calls, 6 never-returning calls, 7 the returning call's bit, 8-13 (trace) counters, 15 the workspace slot claimed
+enum { CMD_CLOSE = 1, CMD_DONE = 2 };
+__device__ __forceinline__ u32 pool_ld(const u32 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void pool_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
+__host__ __device__ __forceinline__ size_t pool_words(u32 cap, u32 n_heads, u32 out_cap) { return (size_t)cap * 2 + n_heads + out_cap; }
+__device__ __forceinline__ void pool_place(Pool &P, u32 *base) { P.cfg = base; P.next = base + P.cap; P.heads = P.next + P.cap; P.outb = P.heads + P.n_heads; }
+__device__ __forceinline__ void pool_admit(const Pool &P, u32 c2, u32 info_bits) {
+  const u32 val = c2 >> 24, lin = c2 & P_LIN, key2 = lin & ~info_bits, ib = lin & info_bits;
+  u32 h = (val * 0x9E3779B1u) ^ (key2 * 0x85EBCA6Bu); h ^= h >> 15;
+  u32 *const head = &P.heads[h & (P.n_heads - 1u)];
+  u32 mine = P_NIL, stop = P_NIL;
+  for (;;) {
+    const u32 first = pool_ld(head);
+    for (u32 e = first; e != stop; e = pool_ld(&P.next[e])) {
+      const u32 w = pool_ld(&P.cfg[e]);
+      if ((w & P_DEAD) || (w >> 24) != val || (w & P_LIN & ~info_bits) != key2) continue;
+      const u32 eib = w & info_bits;
+      if ((eib & ib) == eib) { if (mine != P_NIL) atomicOr(&P.cfg[mine], P_DEAD); return; }   // an existing subset dominates the new one (or is it)
+      if ((eib & ib) == ib) atomicOr(&P.cfg[e], P_DEAD);                                       // the new one dominates this one
+    }
+    if (mine == P_NIL) {
+      mine = atomicAdd(&P.ctr[0], 1u);
+      if (mine >= P.cap) { P.ctr[2] = 1u; return; }
+      P.cfg[mine] = c2;
+    }
+    P.next[mine] = first;
+    pool_release();   // the entry before the head that publishes it
+    if (atomicCAS(head, first, mine) == first) return;
+    stop = first;   // (what lies below was compared already)
+  }
+}
+
+// The closure for one returning call, by every thread of the workgroup: the pool holds the configurations to start from, P.ctr[5..7]
+// the calls, P.ops / P.tws their operations.  Returns KEY_OK with the survivors (bit stripped) in P.outb[0 .. n_out) — and, when they
+// are more than 64, also back in the pool for the next call —, KEY_BAD or KEY_TOO_WIDE (the pool / P.outb overflowed).
+__device__ int pool_close(const Pool &P, u32 &n_out) {
+  const u32 tid = threadIdx.x, T = blockDim.x;
+  const u32 pending = P.ctr[5], info_bits = P.ctr[6], bit = P.ctr[7];
+  u32 wptr = 0;
+  for (;;) {
+    __syncthreads();
+    const u32 pn = P.ctr[0], ovf = P.ctr[2];
+    __syncthreads();
+    if (ovf) return KEY_TOO_WIDE;
+    if (wptr >= pn) break;
+    // a small level spreads the calls of a configuration over G threads (the latency of a level is the longest chain of admits one
+    // thread makes); a large one gives every thread its own configuration
+    const u32 span = pn - wptr;
+    u32 G = 1; while (G < 16u && span * (G * 2u) <= T) G *= 2u;
+    const u32 i = wptr + tid / G, sub = tid & (G - 1u);
+    if (i < pn) {
+      const u32 c = pool_ld(&P.cfg[i]);
+      if (!(c & P_DEAD) && !(c & bit)) {
+        const u32 lin_i = c & P_LIN, val_i = c >> 24;
+        u32 cand = pending & ~lin_i, nth = 0;
+        while (cand) {
+          const u32 q = (u32)__builtin_ctz(cand); cand &= cand - 1;
+          if ((nth++ & (G - 1u)) != sub) continue;
+          const u32 op = P.ops[q];
+          if (op >> 31) continue;
+          if (((info_bits >> q) & 1u) && (P.tws[q] & ~lin_i)) continue;
+          const u32 of = op & 0xFFu, v1 = (op >> 8) & 0xFFu, v2 = (op >> 16) & 0xFFu;
+          u32 nv = val_i;
+          if (of == MSIM_F_READ) { if (val_i != v1) continue; }
+          else if (of == MSIM_F_WRITE) nv = v1;
+          else { if (val_i != v1) continue; nv = v2; }
+          pool_admit(P, lin_i | (1u << q) | (nv << 24), info_bits);
+        }
+      }
+    }
+    wptr = min(pn, wptr + T / G);
+  }
+  // the survivors are the configurations that linearized the call.  Without its bit their groups stay apart (all of them had it),
+  // so they are still minimal and distinct.
+  const u32 pn = P.ctr[0];
+  for (u32 i = tid; i < pn; i += T) {
+    const u32 c = pool_ld(&P.cfg[i]);
+    if (!(c & P_DEAD) && (c & bit)) { const u32 o = atomicAdd(&P.ctr[1], 1u); if (o < P.out_cap) P.outb[o] = c & ~bit; else P.ctr[2] = 1u; }
+  }
+  pool_release();
+  __syncthreads();
+  n_out = P.ctr[1];
+  const u32 ovf = P.ctr[2];
+  __syncthreads();
+  if (ovf) return KEY_TOO_WIDE;
+  if (!n_out) return KEY_BAD;
+  if (n_out > 64u) {   // they stay in the pool: rebuilt under their new keys
+    for (u32 i = tid; i < P.n_heads; i += T) P.heads[i] = P_NIL;
+    if (tid == 0) { P.ctr[0] = 0; P.ctr[1] = 0; }
+    pool_release();
+    __syncthreads();
+    for (u32 i = tid; i < n_out; i += T) pool_admit(P, pool_ld(&P.outb[i]), info_bits);
+    __syncthreads();
+  }
+  return KEY_OK;
+}
+
+// pool_close with a way out when the pool overflows: what it holds — configurations reached so far, a sound start for the same closure —
+// moves to a slot of the workgroup-sized HBM workspace `g` (claimed here, kept for the rest of the history) and the closure runs again.
+struct Grow { u32 *ws; u32 *claim; u32 n_slots, cap, n_heads, out_cap; };   // ws == nullptr: no such workspace (pass 1)
+__device__ int pool_close_grow(Pool &P, u32 &n_out, const Grow &g) {
+  int st = pool_close(P, n_out);
+  if (st != KEY_TOO_WIDE || g.ws == nullptr || P.cap >= g.cap) return st;
+  const u32 tid = threadIdx.x, T = blockDim.x;
+  if (tid == 0) { const u32 slot = atomicAdd(g.claim, 1u); P.ctr[15] = slot < g.n_slots ? slot : P_NIL; }
+  __syncthreads();
+  const u32 slot = P.ctr[15], old_n = min(P.ctr[0], P.cap), info_bits = P.ctr[6];
+  __syncthreads();
+  if (slot == P_NIL) return KEY_TOO_WIDE;
+  Pool B = P;
+  B.cap = g.cap; B.n_heads = g.n_heads; B.out_cap = g.out_cap;
+  pool_place(B, g.ws + (size_t)slot * pool_words(g.cap, g.n_heads, g.out_cap));
+  for (u32 i = tid; i < B.n_heads; i += T) B.heads[i] = P_NIL;
+  if (tid == 0) { P.ctr[0] = 0; P.ctr[1] = 0; P.ctr[2] = 0; }
+  pool_release();
+  __syncthreads();
+  for (u32 i = tid; i < old_n; i += T) { const u32 c = pool_ld(&P.cfg[i]); if (!(c & P_DEAD)) pool_admit(B, c, info_bits); }
+  P = B;
+  return pool_close(P, n_out);   // (begins with a barrier)
+}
+
+// ---- one key -----------------------------------------------------------------------------------------------------------------------
+// Walks the rows of key k (one wavefront: every cross-lane step below is the wavefront's) with the configurations in its registers.
+// A closure that outgrows them moves to the pool P — `acquire` provides it at the first need, false = there is none: KEY_TOO_WIDE —
+// where the whole workgroup finishes it (pass 1: the wavefront alone; pass 2: it is the FIRST of a workgroup whose other wavefronts
+// wait in pool_workers()), and the survivors come back to the registers as soon as 64 lanes hold them again.
+template <class Acquire>
+__device__ int search_key(const uint4 *r, u32 n, u32 k, u32 lo, u32 hi, const Outcome outcome, u32 lane, Pool &P, Acquire acquire, const Grow &grow) {
+  RegSet S; S.c_lin = 0; S.c_val = 0xFFu; S.alive = 1ull;
+  bool in_pool = false;                               // the configurations are in the pool (more than 64 survived the last call)
   u64 pending = 0, info_bits = 0;
-  u32 s_proc = 0, s_op = 0; bool s_ok = false;       // s_op = f | v1 << 8 | v2 << 16 | skip << 31
-  u64 s_tw = 0;                                      // never-returning call: the never-returning calls in lower slots that are the same operation
+  u32 s_proc = 0, s_op = 0; bool s_ok = false; u64 s_tw = 0;
   for (u32 base = lo & ~63u; base <= hi; base += 64) {
     const u32 idx = base + lane;
     uint4 row = make_uint4(0, 0, 0, 0);
@@ -120,7 +335,7 @@ __device__ int search_key_regs(const uint4 *r, u32 n, u32 k, u32 lo, u32 hi, con
       const u32 z = rl(row.z, j), w = rl(row.w, j);
       const u32 jt = z & 3u, jf = (z >> 2) & 31u, jp = z >> 12;
       if (jt == MSIM_T_INVOKE) {
-        const u32 oc = outcome[base + j];
+        const u32 oc = outcome_get(outcome, base + j);
         const bool done = (oc >> 31) != 0;
         const u32 ct = oc & 3u;
         if (done && ct == MSIM_T_FAIL) continue;                       // never happened
@@ -129,8 +344,9 @@ __device__ int search_key_regs(const uint4 *r, u32 n, u32 k, u32 lo, u32 hi, con
         const u32 skip = (!ok && jf == MSIM_F_READ) ? 1u : 0u;         // an unfinished read constrains nothing
         if (pending == ~0ull) return KEY_UNKNOWN;
         const u32 s = (u32)__builtin_ctzll(~pending);
+        if (in_pool && s >= 23u) { if (lane == 0) P.ctr[4] = 1u; return KEY_TOO_WIDE; }   // (a pool word has 23 slots; the host search has 64)
         const u32 opw = jf | vv | (skip << 31);
-        if (!ok && !skip) {   // the symmetry of lin_check.cpp: identical never-returning calls, lowest slot first
+        if (!ok && !skip) {
           const u64 same = __ballot(((info_bits >> lane) & 1ull) && s_op == opw);
           if (lane == s) s_tw = same & ((1ull << s) - 1ull);
           else if (((same >> lane) & 1ull) && lane > s) s_tw |= 1ull << s;
@@ -145,215 +361,55 @@ __device__ int search_key_regs(const uint4 *r, u32 n, u32 k, u32 lo, u32 hi, con
       if (!sm) continue;
       const u32 s = (u32)__builtin_ctzll(sm);
       const u64 bit = 1ull << s;
-      // every surviving configuration must linearize call s now: close the set under linearizing pending calls first
-#pragma unroll
-      for (int b = 0; b < CPL; b++) expanded[b] = 0;
-      u32 explored = 0;
-      for (;;) {
-        u64 lin_i = 0; u32 val_i = 0; bool found = false;
-#pragma unroll
-        for (int b = 0; b < CPL; b++) {
-          const u64 todo = alive[b] & ~expanded[b];
-          if (!found && todo) {
-            const u32 i = (u32)__builtin_ctzll(todo);
-            expanded[b] |= 1ull << i;
-            lin_i = ((u64)rl((u32)(c_lin[b] >> 32), i) << 32) | rl((u32)c_lin[b], i);
-            val_i = rl(c_val[b], i);
-            found = true;
+      int st = KEY_TOO_WIDE;
+      u64 ov_lin = 0; u32 ov_val = 0;
+      const bool prof = P.ctr[8] != 0;   // (developer trace: ctr[9..13] = register closures, their time, pool closures, their time, entries they admitted)
+      const u64 tq0 = prof ? wall_clock64() : 0;
+      if (!in_pool) st = close_regs(S, pending, info_bits, s_op, s_tw, bit, lane, ov_lin, ov_val);
+      if (prof && lane == 0) { P.ctr[9]++; P.ctr[10] += (u32)(wall_clock64() - tq0); }
+      if (st == KEY_TOO_WIDE) {
+        if (!in_pool && !acquire()) return KEY_TOO_WIDE;   // (pass 1: no workspace slot left)
+        if (pending >> 23) { if (lane == 0) P.ctr[4] = 1u; return KEY_TOO_WIDE; }
+        if (lane < 32u) { P.ops[lane] = s_op; P.tws[lane] = (u32)s_tw; }
+        if (lane == 0) { P.ctr[5] = (u32)pending; P.ctr[6] = (u32)info_bits; P.ctr[7] = (u32)bit; }
+        if (!in_pool) {   // what the registers hold (and the one that did not fit) goes to the pool; the closure starts over there
+          for (u32 i = lane; i < P.n_heads; i += 64) P.heads[i] = P_NIL;
+          if (lane == 0) { P.ctr[0] = 0; P.ctr[1] = 0; P.ctr[2] = 0; }
+          pool_release();
+          __builtin_amdgcn_wave_barrier();
+          if ((S.alive >> lane) & 1ull) pool_admit(P, (u32)S.c_lin | (S.c_val << 24), (u32)info_bits);
+          if (lane == 0) pool_admit(P, (u32)ov_lin | (ov_val << 24), (u32)info_bits);
+        }
+        if (lane == 0) P.ctr[3] = CMD_CLOSE;
+        __syncthreads();   // (the command barrier: the other wavefronts join)
+        u32 n_out = 0;
+        const u64 tq1 = prof ? wall_clock64() : 0;
+        st = pool_close_grow(P, n_out, grow);
+        if (prof && lane == 0) { P.ctr[11]++; P.ctr[12] += (u32)(wall_clock64() - tq1); P.ctr[13] += P.ctr[0]; }
+        if (st == KEY_TOO_WIDE) return KEY_TOO_WIDE;
+        if (st == KEY_OK) {
+          in_pool = n_out > 64u;
+          if (!in_pool) {
+            const u32 c = lane < n_out ? pool_ld(&P.outb[lane]) : 0u;
+            S.c_lin = c & P_LIN; S.c_val = c >> 24; S.alive = n_out == 64u ? ~0ull : (1ull << n_out) - 1ull;
           }
         }
-        if (!found) break;
-        if (lin_i & bit) continue;
-        if (++explored > EXPLORE_LIMIT) return KEY_TOO_WIDE;
-        u64 cand = pending & ~lin_i;
-        while (cand) {
-          const u32 q = (u32)__builtin_ctzll(cand); cand &= cand - 1;
-          const u32 op = rl(s_op, q);
-          if (op >> 31) continue;
-          if ((info_bits >> q) & 1ull) { const u64 tw = ((u64)rl((u32)(s_tw >> 32), q) << 32) | rl((u32)s_tw, q); if (tw & ~lin_i) continue; }
-          const u32 of = op & 0xFFu, v1 = (op >> 8) & 0xFFu, v2 = (op >> 16) & 0xFFu;
-          u32 nv = val_i;
-          if (of == MSIM_F_READ) { if (val_i != v1) continue; }          // only :ok reads are stepped; they must see the current value
-          else if (of == MSIM_F_WRITE) nv = v1;
-          else { if (val_i != v1) continue; nv = v2; }                   // cas [v v']
-          const u64 lin2 = lin_i | (1ull << q);
-          // Dominance: for equal (value, linearized returning calls), a configuration that has linearized FEWER never-returning
-          // calls can still do everything the other can.  Keep only the minimal ones.
-          const u64 ib2 = lin2 & info_bits, key2 = lin2 & ~info_bits;
-          u64 killm[CPL]; bool dominated = false;
-#pragma unroll
-          for (int b = 0; b < CPL; b++) {
-            killm[b] = 0;
-            if (alive[b]) {   // (uniform: banks fill in order, the empty ones cost nothing)
-              const bool same = ((alive[b] >> lane) & 1ull) && c_val[b] == nv && (c_lin[b] & ~info_bits) == key2;
-              const u64 my_ib = c_lin[b] & info_bits;
-              dominated |= __ballot(same && (my_ib & ib2) == my_ib) != 0;   // an existing subset dominates the new one
-              killm[b] = __ballot(same && (my_ib & ib2) == ib2);            // the new one dominates these
-            }
-          }
-          if (dominated) continue;
-          bool placed = false;
-#pragma unroll
-          for (int b = 0; b < CPL; b++) {
-            alive[b] &= ~killm[b];
-            if (!placed && alive[b] != ~0ull) {
-              const u32 fl = (u32)__builtin_ctzll(~alive[b]);
-              if (lane == fl) { c_lin[b] = lin2; c_val[b] = nv; }
-              alive[b] |= 1ull << fl; expanded[b] &= ~(1ull << fl);
-              placed = true;
-            }
-          }
-          if (!placed) return KEY_TOO_WIDE;
-        }
-      }
-      u64 any = 0;
-#pragma unroll
-      for (int b = 0; b < CPL; b++) if (alive[b]) {
-        alive[b] = __ballot(((alive[b] >> lane) & 1ull) && (c_lin[b] & bit));   // the others could not linearize the call in time
-        c_lin[b] &= ~bit;
-        any |= alive[b];
       }
       pending &= ~bit;
-      if (!any) return KEY_BAD;
+      if (st == KEY_BAD) return KEY_BAD;
     }
   }
   return KEY_OK;
 }
 
-// ---- one key, the configurations in an LDS table (one workgroup) --------------------------------------------------------------------
-// For the keys whose search outgrows the registers (a partition that leaves a dozen writes and cas indeterminate: thousands of
-// configurations while one call returns).  A configuration is one word — value << 24 | DEAD | linearized calls (23 slots) — in a pool
-// that is also the work list (entries are expanded in the order they were admitted, a workgroup's worth at a time); the pool is
-// chained into a hash table over (value, linearized RETURNING calls), so that what dominance has to compare — the sets of linearized
-// never-returning calls of one such group — is one chain.  Every thread admits its own candidates: walk the chain (dominated: drop;
-// dominating: mark the old entry DEAD), then push with a compare-and-swap on the chain's head; a push that loses the race walks what
-// arrived meanwhile and tries again.  Two candidates admitted in the same instant may both survive although one dominates the other
-// — that costs work, never the verdict: the search stays exact, dominance is only what keeps it small.
-struct LdsPool { u32 *cfg; unsigned short *next; u32 *heads; u32 *outb; u32 *ctr; u32 *ops; u32 *tws; u32 cap, n_heads, out_cap; };
-constexpr u32 P_NIL = 0xFFFFu, P_DEAD = 1u << 23, P_LIN = 0x7FFFFFu, P_SLOTS = 23u;
-
-__device__ int search_key_lds(const uint4 *r, u32 n, u32 k, u32 lo, u32 hi, const u32 *outcome, const LdsPool P) {
-  const u32 tid = threadIdx.x, lane = tid & 63u, T = blockDim.x;
-  u32 pending = 0, info_bits = 0;                    // uniform over the workgroup: every wavefront walks the same rows
-  u32 s_proc = 0, s_op = 0, s_tw = 0; bool s_ok = false;   // lane s of EVERY wavefront holds slot s; P.ops / P.tws mirror them for the divergent reads
-  auto admit = [&](u32 c2) {
-    const u32 val = c2 >> 24, lin = c2 & P_LIN, key2 = lin & ~info_bits, ib = lin & info_bits;
-    u32 h = (val * 0x9E3779B1u) ^ (key2 * 0x85EBCA6Bu); h ^= h >> 15;
-    u32 *const head = &P.heads[h & (P.n_heads - 1u)];
-    u32 mine = P_NIL, stop = P_NIL;
-    for (;;) {
-      const u32 first = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      for (u32 e = first; e != stop; e = P.next[e]) {
-        const u32 w = __hip_atomic_load(&P.cfg[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if ((w & P_DEAD) || (w >> 24) != val || (w & P_LIN & ~info_bits) != key2) continue;
-        const u32 eib = w & info_bits;
-        if ((eib & ib) == eib) { if (mine != P_NIL) atomicOr(&P.cfg[mine], P_DEAD); return; }   // an existing subset dominates the new one (or is it)
-        if ((eib & ib) == ib) atomicOr(&P.cfg[e], P_DEAD);                                       // the new one dominates this one
-      }
-      if (mine == P_NIL) {
-        mine = atomicAdd(&P.ctr[0], 1u);
-        if (mine >= P.cap) { P.ctr[2] = 1u; return; }
-        P.cfg[mine] = c2;
-      }
-      P.next[mine] = (unsigned short)first;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the entry before the head that publishes it
-      if (atomicCAS(head, first, mine) == first) return;
-      stop = first;   // (what lies below was compared already)
-    }
-  };
-  auto clear = [&]() { for (u32 i = tid; i < P.n_heads; i += T) P.heads[i] = P_NIL; if (tid == 0) { P.ctr[0] = 0; P.ctr[1] = 0; P.ctr[2] = 0; } };
-  __syncthreads();
-  clear();
-  __syncthreads();
-  if (tid == 0) admit(0xFFu << 24);
-  for (u32 base = lo & ~63u; base <= hi; base += 64) {
-    const u32 idx = base + lane;
-    uint4 row = make_uint4(0, 0, 0, 0);
-    if (idx < n) row = r[idx];
-    const u32 f0 = (row.z >> 2) & 31u;
-    const bool reg = idx < n && (row.z >> 12) != MSIM_PROCESS_NEMESIS && (f0 == MSIM_F_READ || f0 == MSIM_F_WRITE || f0 == MSIM_F_CAS) && (row.w & 0xFFu) == k;
-    u64 m = __ballot(reg);
-    while (m) {
-      const u32 j = (u32)__builtin_ctzll(m); m &= m - 1;
-      const u32 z = rl(row.z, j), w = rl(row.w, j);
-      const u32 jt = z & 3u, jf = (z >> 2) & 31u, jp = z >> 12;
-      if (jt == MSIM_T_INVOKE) {
-        const u32 oc = outcome[base + j];
-        const bool done = (oc >> 31) != 0;
-        const u32 ct = oc & 3u;
-        if (done && ct == MSIM_T_FAIL) continue;
-        const bool ok = done && ct == MSIM_T_OK;
-        const u32 vv = ok ? (oc & 0xFFFF00u) : (w & 0xFFFF00u);
-        const u32 skip = (!ok && jf == MSIM_F_READ) ? 1u : 0u;
-        if ((pending & P_LIN) == P_LIN) return KEY_TOO_WIDE;   // (the host search has 64 slots)
-        const u32 s = (u32)__builtin_ctz(~pending);
-        const u32 opw = jf | vv | (skip << 31);
-        if (!ok && !skip) {
-          const u32 same = (u32)__ballot(lane < 32u && ((info_bits >> lane) & 1u) && s_op == opw);
-          if (lane == s) s_tw = same & ((1u << s) - 1u);
-          else if (lane < 32u && ((same >> lane) & 1u) && lane > s) s_tw |= 1u << s;
-        } else if (lane == s) s_tw = 0;
-        pending |= 1u << s;
-        if (!ok) info_bits |= 1u << s;
-        if (lane == s) { s_proc = jp; s_op = opw; s_ok = ok; }
-        if (lane < 32u) { P.ops[lane] = s_op; P.tws[lane] = s_tw; }   // (every wavefront writes the same words; read after the next barrier)
-        continue;
-      }
-      if (jt != MSIM_T_OK) continue;
-      const u32 sm = (u32)__ballot(lane < 32u && ((pending >> lane) & 1u) && s_ok && s_proc == jp);
-      if (!sm) continue;
-      const u32 s = (u32)__builtin_ctz(sm);
-      const u32 bit = 1u << s;
-      // close the set under linearizing pending calls: the pool is the work list
-      u32 wptr = 0;
-      for (;;) {
-        __syncthreads();
-        const u32 pn = P.ctr[0], ovf = P.ctr[2];
-        __syncthreads();
-        if (ovf) return KEY_TOO_WIDE;
-        if (wptr >= pn) break;
-        const u32 i = wptr + tid;
-        if (i < pn) {
-          const u32 c = P.cfg[i];
-          if (!(c & P_DEAD) && !(c & bit)) {
-            const u32 lin_i = c & P_LIN, val_i = c >> 24;
-            u32 cand = pending & ~lin_i;
-            while (cand) {
-              const u32 q = (u32)__builtin_ctz(cand); cand &= cand - 1;
-              const u32 op = P.ops[q];
-              if (op >> 31) continue;
-              if (((info_bits >> q) & 1u) && (P.tws[q] & ~lin_i)) continue;
-              const u32 of = op & 0xFFu, v1 = (op >> 8) & 0xFFu, v2 = (op >> 16) & 0xFFu;
-              u32 nv = val_i;
-              if (of == MSIM_F_READ) { if (val_i != v1) continue; }
-              else if (of == MSIM_F_WRITE) nv = v1;
-              else { if (val_i != v1) continue; nv = v2; }
-              admit(lin_i | (1u << q) | (nv << 24));
-            }
-          }
-        }
-        wptr = min(pn, wptr + T);
-      }
-      // the survivors are the configurations that linearized the call; without its bit they are compared anew
-      {
-        const u32 pn = P.ctr[0];
-        for (u32 i = tid; i < pn; i += T) {
-          const u32 c = P.cfg[i];
-          if (!(c & P_DEAD) && (c & bit)) { const u32 o = atomicAdd(&P.ctr[1], 1u); if (o < P.out_cap) P.outb[o] = c & ~bit; else P.ctr[2] = 1u; }
-        }
-        __syncthreads();
-        const u32 no = P.ctr[1], ovf = P.ctr[2];
-        __syncthreads();
-        if (ovf) return KEY_TOO_WIDE;
-        pending &= ~bit;
-        if (!no) return KEY_BAD;
-        clear();
-        __syncthreads();
-        for (u32 i = tid; i < no; i += T) admit(P.outb[i]);
-      }
-    }
+// the other wavefronts of the workgroup: wait for the first one's closures
+__device__ void pool_workers(Pool &P, const Grow &grow) {
+  for (;;) {
+    __syncthreads();
+    if (P.ctr[3] == CMD_DONE) return;
+    u32 n_out;
+    (void)pool_close_grow(P, n_out, grow);
   }
-  return KEY_OK;
 }
 
 // A history that awaits a wider search says where to go on in its result record: lost_count = the key to resume at (RESUME_NONE: the
@@ -367,12 +423,13 @@ __device__ void clear_result(msim_check_result &res) {
   res.op_count = 0; res.ok_count = 0; res.fail_count = 0; res.info_count = 0;
 }
 
-// pass 1: one wavefront per history, 64 configurations
-__global__ void __launch_bounds__(64) lin_check_kernel(const LParams p) {
+// pass 1: one wavefront per history; the configurations in its registers, the closures that outgrow them in a slot of the HBM workspace
+struct HParams { u32 *pool; u32 *claim; u32 n_slots, cap, n_heads, out_cap, trace; };   // slot = cfg[cap] next[cap] heads[n_heads] outb[out_cap] words
+__global__ void __launch_bounds__(64) lin_check_kernel(const LParams p, const HParams hp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32 *const key_lo = reinterpret_cast<u32 *>(smem);          // [256] first row of the key
   u32 *const key_hi = key_lo + 256;                           // [256] last row of the key
-  u32 *const outcome = key_hi + 256;                          // [table_rows]
+  const Outcome outcome = outcome_at(key_hi + 256, p.table_rows);   // [table_rows]
   const u32 lane = threadIdx.x, inst = p.list ? p.list[blockIdx.x] : blockIdx.x;
   const uint4 *const r = reinterpret_cast<const uint4 *>(p.rows) + (p.off ? p.off[inst] : (u64)inst * p.stride);
   const u32 n = p.meta ? p.meta[inst].n_rows : (u32)(p.off[inst + 1] - p.off[inst]);
@@ -381,15 +438,30 @@ __global__ void __launch_bounds__(64) lin_check_kernel(const LParams p) {
   msim_check_result res;
   clear_result(res);
   if (n > p.table_rows) { if (lane == 0) { res.valid = NEEDS_HOST; res.lost_count = RESUME_NONE; p.out[inst] = res; } return; }
+  Pool P;
+  P.cap = hp.cap; P.n_heads = hp.n_heads; P.out_cap = hp.out_cap; P.cfg = nullptr; P.next = nullptr; P.heads = nullptr; P.outb = nullptr;
+  P.ctr = key_hi + 256 + outcome_bytes(p.table_rows) / 4; P.ops = P.ctr + 16; P.tws = P.ops + 32;
   for (u32 i = lane; i < 256; i += 64) { key_lo[i] = 0xFFFFFFFFu; key_hi[i] = 0; }
+  if (lane < 16) P.ctr[lane] = lane == 8 ? hp.trace : 0u;
+  const u64 t_start = hp.trace ? wall_clock64() : 0;
   __syncthreads();
   const bool paired = pair_rows(r, n, key_lo, key_hi, outcome, lane, res.op_count, res.ok_count, res.fail_count, res.info_count);
   __syncthreads();
+  auto acquire = [&]() -> bool {   // the first closure of this history that needs the pool claims a slot of the workspace (kept to the end)
+    if (P.cfg) return true;
+    u32 slot = 0;
+    if (lane == 0) slot = atomicAdd(hp.claim, 1u);
+    slot = (u32)__builtin_amdgcn_readfirstlane((int)slot);
+    if (slot >= hp.n_slots) return false;
+    pool_place(P, hp.pool + (size_t)slot * pool_words(hp.cap, hp.n_heads, hp.out_cap));
+    return true;
+  };
+  Grow no_grow; no_grow.ws = nullptr; no_grow.claim = nullptr; no_grow.n_slots = 0; no_grow.cap = 0; no_grow.n_heads = 0; no_grow.out_cap = 0;
   u32 n_keys = 0, n_bad = 0, n_unknown = 0, resume = paired ? 256u : RESUME_NONE;
   for (u32 k = 0; k < 256 && paired; k++) {
     const u32 lo = key_lo[k], hi = key_hi[k];
     if (lo == 0xFFFFFFFFu) continue;
-    const int st = search_key_regs<1>(r, n, k, lo, hi, outcome, lane);
+    const int st = search_key(r, n, k, lo, hi, outcome, lane, P, acquire, no_grow);
     if (st == KEY_TOO_WIDE) { resume = k; break; }
     n_keys++; n_bad += st == KEY_BAD; n_unknown += st == KEY_UNKNOWN;
   }
@@ -398,79 +470,96 @@ __global__ void __launch_bounds__(64) lin_check_kernel(const LParams p) {
     res.error_count = n_bad;       // keys whose history is not linearizable
     if (resume != 256u) { res.valid = NEEDS_HOST; res.lost_count = resume; res.stale_count = n_unknown; }
     else res.valid = flags ? 0u : n_bad ? 0u : n_unknown ? 2u : 1u;
+    if (hp.trace) { res.never_read_count = (u32)((wall_clock64() - t_start) / 100u); res.stable_latency_ms[3] = P.ctr[11]; res.stable_latency_ms[4] = P.ctr[12] / 100u; res.stable_count = P.ctr[13]; }   // (developer trace only)
     p.out[inst] = res;
   }
 }
 
-// passes 2 and 3: one workgroup per history that pass 1 left open, from the key it stopped at; the registers of the first wavefront
-// first, the LDS table (pool of `cap` configurations) for the keys that outgrow them
-struct WParams { u32 cap, n_heads, out_cap; };
-__global__ void __launch_bounds__(256) lin_check_wg_kernel(const LParams p, const WParams wp) {
+// pass 2: one workgroup per history still open, from the key it stopped at: the first wavefront walks the keys with the configurations
+// in its registers, the whole workgroup closes the calls that outgrow them in the pool — in LDS (`cap` configurations = what 160 KiB
+// hold); the handful of closures that outgrow that too move to a slot of the HBM workspace `grow`
+struct WParams { u32 cap, n_heads, out_cap, trace; Grow grow; };
+__global__ void __launch_bounds__(1024) lin_check_wg_kernel(const LParams p, const WParams wp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32 *const key_lo = reinterpret_cast<u32 *>(smem);
   u32 *const key_hi = key_lo + 256;
-  u32 *const outcome = key_hi + 256;
-  LdsPool P;
+  const Outcome outcome = outcome_at(key_hi + 256, p.table_rows);
+  Pool P;
   P.cap = wp.cap; P.n_heads = wp.n_heads; P.out_cap = wp.out_cap;
-  P.cfg = outcome + p.table_rows; P.heads = P.cfg + wp.cap; P.outb = P.heads + wp.n_heads; P.ctr = P.outb + wp.out_cap; P.ops = P.ctr + 8; P.tws = P.ops + 32;
-  P.next = reinterpret_cast<unsigned short *>(P.tws + 32);
+  P.ctr = key_hi + 256 + outcome_bytes(p.table_rows) / 4; P.ops = P.ctr + 16; P.tws = P.ops + 32;
+  pool_place(P, P.tws + 32);
   const u32 tid = threadIdx.x, lane = tid & 63u, inst = p.list[blockIdx.x];
   msim_check_result res = p.out[inst];
   if (res.valid != NEEDS_HOST || res.lost_count == RESUME_NONE) return;   // decided by an earlier pass / not the device's
   const u32 k0 = res.lost_count;
+  const u64 t_start = wp.trace ? wall_clock64() : 0;
   const uint4 *const r = reinterpret_cast<const uint4 *>(p.rows) + (p.off ? p.off[inst] : (u64)inst * p.stride);
   const u32 n = p.meta ? p.meta[inst].n_rows : (u32)(p.off[inst + 1] - p.off[inst]);
   const u32 flags = p.meta ? p.meta[inst].flags : 0u;
   for (u32 i = tid; i < 256; i += blockDim.x) { key_lo[i] = 0xFFFFFFFFu; key_hi[i] = 0; }
+  if (tid < 16) P.ctr[tid] = 0;
   __syncthreads();
-  if (tid < 64) { u32 a, b, c, d; (void)pair_rows(r, n, key_lo, key_hi, outcome, lane, a, b, c, d); }   // (pass 1 paired them: it fits)
+  if (tid == 0) P.ctr[8] = wp.trace;
   __syncthreads();
+  if (tid >= 64) { pool_workers(P, wp.grow); return; }
+  const u64 t_p0 = wp.trace ? wall_clock64() : 0;
+  { u32 a, b, c, d; (void)pair_rows(r, n, key_lo, key_hi, outcome, lane, a, b, c, d); }   // (pass 1 paired them: it fits)
+  const u32 t_pair = wp.trace ? (u32)(wall_clock64() - t_p0) : 0;
   u32 n_keys = res.attempt_count, n_bad = res.error_count, n_unknown = res.stale_count, resume = 256u;
   for (u32 k = k0; k < 256; k++) {
     const u32 lo = key_lo[k], hi = key_hi[k];
     if (lo == 0xFFFFFFFFu) continue;
-    int st = KEY_TOO_WIDE;
-    if (k != k0) {   // (the key pass 1 stopped at is known not to fit the registers)
-      if (tid < 64) { st = search_key_regs<1>(r, n, k, lo, hi, outcome, lane); if (tid == 0) P.ctr[3] = (u32)st; }
-      __syncthreads();
-      st = (int)P.ctr[3];
-      __syncthreads();
-    }
-    if (st == KEY_TOO_WIDE) st = search_key_lds(r, n, k, lo, hi, outcome, P);
+    const int st = search_key(r, n, k, lo, hi, outcome, lane, P, []() { return true; }, wp.grow);
     if (st == KEY_TOO_WIDE) { resume = k; break; }
     n_keys++; n_bad += st == KEY_BAD; n_unknown += st == KEY_UNKNOWN;
   }
+  if (lane == 0) P.ctr[3] = CMD_DONE;
+  __syncthreads();   // (the command barrier: the other wavefronts leave)
   if (tid == 0) {
     res.attempt_count = n_keys; res.error_count = n_bad;
-    if (resume != 256u) { res.valid = NEEDS_HOST; res.lost_count = resume; res.stale_count = n_unknown; }
+    if (resume != 256u) { res.valid = NEEDS_HOST; res.lost_count = resume; res.stale_count = n_unknown; res.duplicated_count = P.ctr[4]; }   // (developer trace: 1 = more than 23 calls pending, 0 = the pool)
     else { res.valid = flags ? 0u : n_bad ? 0u : n_unknown ? 2u : 1u; res.lost_count = 0; res.stale_count = 0; }
+    if (wp.trace) { res.never_read_count = (u32)((wall_clock64() - t_start) / 100u);   // developer trace only: microseconds this workgroup took (100 MHz counter)
+      res.stable_latency_ms[0] = t_pair / 100u; res.stable_latency_ms[1] = P.ctr[9]; res.stable_latency_ms[2] = P.ctr[10] / 100u; res.stable_latency_ms[3] = P.ctr[11]; res.stable_latency_ms[4] = P.ctr[12] / 100u; res.stable_count = P.ctr[13]; }
     p.out[inst] = res;
   }
 }
 
-// launches the search over `n` histories: pass 1 (a wavefront each, 64 configurations in registers), then for what it left open
-// passes 2 and 3 (a workgroup each, the LDS table: a small pool at several workgroups per CU, then the largest that fits), and the
-// host search (all host threads, overlapped with passes 2 and 3) for what exceeds even that
+// launches the search over `n` histories: pass 1 (a wavefront each: 64 configurations in registers, the closures beyond that in a
+// slot of an HBM workspace), then for what it left open pass 2 (a workgroup of 1024 each, the pool in LDS: the largest that fits) and
+// the host search (all host threads) for what exceeds even that
 int lin_check_dev_run(msim_ctx *ctx, const LParams &lp0, u32 n, u32 max_rows_any, msim_check_result *h_out, hipStream_t st, u32 *n_host) {
   LParams lp = lp0;
   const bool trace = (msim_dev_flags(ctx) & 0x1000u) != 0;   // developer: time the passes
+  const bool tiny = (msim_dev_flags(ctx) & 0x2000u) != 0;    // developer / tests: pools small enough that every level is reached, the host search included
   const auto t0 = std::chrono::steady_clock::now();
   auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
-  const u32 table_cap = (60u * 1024u - 2048u) / 4u;
+  const u32 table_cap = 24u * 1024u;   // rows (51 KiB of LDS)
   lp.table_rows = max_rows_any < table_cap ? max_rows_any : table_cap;
   lp.list = nullptr;
-  const size_t lds = 2048 + (size_t)lp.table_rows * 4;
-  hipLaunchKernelGGL(lin_check_kernel, dim3(n), dim3(64), lds, st, lp);
+  const size_t lds = 2048 + outcome_bytes(lp.table_rows);
+  const size_t fixed = lds + (16 + 32 + 32) * 4;   // + the pools' counters and the calls' operations
+  HParams hp;
+  hp.cap = tiny ? 66 : 2048; hp.n_heads = tiny ? 32 : 512; hp.out_cap = tiny ? 66 : 1024;
+  hp.n_slots = n < 4096u ? n : 4096u;   // (a history claims one when a closure first outgrows the registers; without one it waits for pass 2)
+  hp.pool = nullptr; hp.claim = nullptr; hp.trace = trace ? 1u : 0u;
+  const size_t ws_bytes = (size_t)hp.n_slots * pool_words(hp.cap, hp.n_heads, hp.out_cap) * 4 + 256;
+  MSIM_HIP_TRY(ctx, hipMalloc(&hp.pool, ws_bytes));
+  hp.claim = hp.pool + (ws_bytes - 256) / 4;
+  struct Ws { u32 *p; ~Ws() { if (p) (void)hipFree(p); } } ws_guard{hp.pool};
+  MSIM_HIP_TRY(ctx, hipMemsetAsync(hp.claim, 0, 4, st));
+  hipLaunchKernelGGL(lin_check_kernel, dim3(n), dim3(64), fixed, st, lp, hp);
   MSIM_HIP_TRY(ctx, hipGetLastError());
   MSIM_HIP_TRY(ctx, hipMemcpyAsync(h_out, lp.out, (size_t)n * sizeof(msim_check_result), hipMemcpyDeviceToHost, st));
   MSIM_HIP_TRY(ctx, hipStreamSynchronize(st));
   std::vector<u32> todo;
   for (u32 i = 0; i < n; i++) if (h_out[i].valid == NEEDS_HOST) todo.push_back(i);
-  if (trace) std::fprintf(stderr, "[lin-check] pass 1 (64 configurations): %.2f ms, %zu of %u histories marked\n", ms(), todo.size(), n);
+  if (trace) { u32 claimed = 0; (void)hipMemcpy(&claimed, hp.claim, 4, hipMemcpyDeviceToHost);
+    { std::vector<u32> us, pc, ad, pt; for (u32 i = 0; i < n; i++) { us.push_back(h_out[i].never_read_count); pc.push_back(h_out[i].stable_latency_ms[3]); pt.push_back(h_out[i].stable_latency_ms[4]); ad.push_back(h_out[i].stable_count); }
+      auto q = [&](std::vector<u32> &v, const char *nm) { std::sort(v.begin(), v.end()); std::fprintf(stderr, "[lin-check]   pass 1 %s per history: median %u, 90%% %u, 95%% %u, 97%% %u, 99%% %u, max %u\n", nm, v[v.size() / 2], v[v.size() * 9 / 10], v[v.size() * 95 / 100], v[v.size() * 97 / 100], v[v.size() * 99 / 100], v.back()); };
+      q(us, "microseconds"); q(pc, "pool closures"); q(pt, "microseconds in pool closures"); q(ad, "pool entries admitted"); }
+    std::fprintf(stderr, "[lin-check] pass 1 (registers + HBM pools of %u configurations, %zu MB of workspace): %.2f ms, %u histories claimed a pool, %zu of %u still open\n", hp.cap, ws_bytes >> 20, ms(), claimed, todo.size(), n); }
   if (!todo.empty()) {
-    // While the device works through the marked histories, the host cores already search them — those with the most indeterminate
-    // calls first: they are the likeliest to exceed the device's pools too — so that what the device leaves over is mostly done
-    // by the time it is known.  Whichever side finishes a history first, the result is the same (both searches are exact).
     std::vector<msim_inst_meta> hm;
     std::vector<uint64_t> ho;
     if (lp.meta) { hm.resize(n); MSIM_HIP_TRY(ctx, hipMemcpy(hm.data(), lp.meta, (size_t)n * sizeof(msim_inst_meta), hipMemcpyDeviceToHost)); }
@@ -481,7 +570,6 @@ int lin_check_dev_run(msim_ctx *ctx, const LParams &lp0, u32 n, u32 max_rows_any
     std::stable_sort(order.begin(), order.end(), [&](u32 x, u32 y) { return h_out[x].info_count > h_out[y].info_count; });
     std::vector<char> host_done(todo.size(), 0);
     std::atomic<size_t> next{0};
-    std::atomic<bool> device_done{false};
     std::atomic<int> copy_err{0};
     std::vector<char> wanted;                       // after the device passes: which histories the host still has to do
     auto host_one = [&](size_t k) {
@@ -493,49 +581,57 @@ int lin_check_dev_run(msim_ctx *ctx, const LParams &lp0, u32 n, u32 max_rows_any
       msim_lin_check_instance_host(rows.data(), nr, lp.meta ? hm[i].flags : 0u, &hh[k]);
       host_done[k] = 1;
     };
-    // (the speculative host search only pays where the device may leave something over: it is started for the histories the device
-    // cannot take at all, and otherwise after the passes)
-    u32 *d_list = nullptr;
+    u32 *d_list = nullptr, *ws2 = nullptr;
     hipError_t e = hipMalloc(&d_list, todo.size() * 4);
     if (e == hipSuccess) e = hipMemcpyAsync(d_list, todo.data(), todo.size() * 4, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
       lp.list = d_list;
-      // pass 2: a pool of 2048 configurations; pass 3: what 160 KiB of LDS hold beside the pairing table
-      const size_t fixed = lds + (8 + 32 + 32) * 4;
-      for (int pass = 2; pass <= 3 && e == hipSuccess; pass++) {
-        WParams wp;
-        const bool tiny = (msim_dev_flags(ctx) & 0x2000u) != 0;   // developer / tests: pools small enough that every level is reached, the host search included
-        if (pass == 2) { wp.cap = tiny ? 128 : 2048; wp.n_heads = tiny ? 64 : 1024; wp.out_cap = tiny ? 128 : 1024; }
-        else if (tiny) { wp.cap = 512; wp.n_heads = 256; wp.out_cap = 256; }
-        else {
-          wp.n_heads = 4096; wp.out_cap = 4096;
-          const size_t room = 160u * 1024u - fixed - (size_t)(wp.n_heads + wp.out_cap) * 4 - 256;
-          wp.cap = (u32)std::min<size_t>(room / 6, 0xFFF0u) & ~63u;
-        }
-        const size_t l2 = fixed + (size_t)(wp.cap + wp.n_heads + wp.out_cap) * 4 + (size_t)wp.cap * 2;
-        if (l2 > 64 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lin_check_wg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
-        if (e != hipSuccess) break;
-        hipLaunchKernelGGL(lin_check_wg_kernel, dim3((u32)todo.size()), dim3(256), l2, st, lp, wp);
+      // pass 2: what 160 KiB of LDS hold beside the pairing table
+      WParams wp;
+      wp.trace = trace ? 1u : 0u;
+      if (tiny) { wp.cap = 72; wp.n_heads = 64; wp.out_cap = 72; }
+      else {
+        wp.n_heads = 4096; wp.out_cap = 4096;
+        const size_t room = 160u * 1024u - fixed - (size_t)(wp.n_heads + wp.out_cap) * 4 - 256;
+        wp.cap = (u32)(room / 8) & ~63u;
+      }
+      const size_t l2 = fixed + pool_words(wp.cap, wp.n_heads, wp.out_cap) * 4;
+      // the workspace of the closures that outgrow the LDS pool: a quarter of a million configurations each, for up to 64 histories
+      Grow &g = wp.grow;
+      g.cap = tiny ? 80u : 262144u; g.n_heads = tiny ? 64u : 65536u; g.out_cap = tiny ? 80u : 65536u;
+      g.n_slots = (u32)std::min<size_t>(todo.size(), tiny ? 2 : 64);
+      g.ws = nullptr; g.claim = nullptr;
+      e = hipMalloc(&ws2, (size_t)g.n_slots * pool_words(g.cap, g.n_heads, g.out_cap) * 4 + 256);
+      if (e == hipSuccess) { g.ws = ws2; g.claim = ws2 + (size_t)g.n_slots * pool_words(g.cap, g.n_heads, g.out_cap); e = hipMemsetAsync(g.claim, 0, 4, st); }
+      if (e == hipSuccess && l2 > 64 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lin_check_wg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL(lin_check_wg_kernel, dim3((u32)todo.size()), dim3(1024), l2, st, lp, wp);
         e = hipGetLastError();
-        if (trace && e == hipSuccess) {
-          (void)hipMemcpyAsync(h2.data(), lp.out, (size_t)n * sizeof(msim_check_result), hipMemcpyDeviceToHost, st);
-          (void)hipStreamSynchronize(st);
-          size_t left = 0; for (u32 i : todo) left += h2[i].valid == NEEDS_HOST;
-          std::fprintf(stderr, "[lin-check] pass %d (pool of %u configurations, %zu B of LDS) done at %.2f ms, %zu histories still open\n", pass, wp.cap, l2, ms(), left);
-        }
+      }
+      if (trace && e == hipSuccess) {
+        (void)hipMemcpyAsync(h2.data(), lp.out, (size_t)n * sizeof(msim_check_result), hipMemcpyDeviceToHost, st);
+        (void)hipStreamSynchronize(st);
+        size_t left = 0; std::vector<u32> us;
+        double a[6] = {0, 0, 0, 0, 0, 0};
+        for (u32 i : todo) { left += h2[i].valid == NEEDS_HOST; us.push_back(h2[i].never_read_count); for (int q = 0; q < 5; q++) a[q] += h2[i].stable_latency_ms[q]; a[5] += h2[i].stable_count; }
+        std::sort(us.begin(), us.end());
+        u32 grown = 0; (void)hipMemcpy(&grown, g.claim, 4, hipMemcpyDeviceToHost);
+        std::fprintf(stderr, "[lin-check] pass 2 (pool of %u configurations, %zu B of LDS; %u histories moved on to an HBM pool of %u) done at %.2f ms, %zu histories still open\n", wp.cap, l2, grown, g.cap, ms(), left);
+        std::fprintf(stderr, "[lin-check]   sums: pairing %.0f us; %.0f register closures %.0f us; %.0f pool closures %.0f us, %.0f entries admitted\n", a[0], a[1], a[2], a[3], a[4], a[5]);
+        std::fprintf(stderr, "[lin-check]   microseconds per workgroup: median %u, 90%% %u, max %u\n", us[us.size() / 2], us[us.size() * 9 / 10], us.back());
       }
     }
     if (e == hipSuccess) e = hipMemcpyAsync(h2.data(), lp.out, (size_t)n * sizeof(msim_check_result), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (ws2) (void)hipFree(ws2);
     wanted.assign(order.size(), 0);
     if (e == hipSuccess) for (size_t k = 0; k < order.size(); k++) wanted[k] = h2[order[k]].valid == NEEDS_HOST;
     else std::fill(wanted.begin(), wanted.end(), 1);   // (the host can still do everything)
-    device_done = true;
     const double t_dev = ms();
     if (d_list) (void)hipFree(d_list);
     u32 n_host_needed = 0;
     for (size_t k = 0; k < order.size(); k++) n_host_needed += wanted[k] != 0;
-    if (n_host_needed) {
+    if (n_host_needed) {   // what even the HBM pools could not hold (or found no slot): the host search, all host threads
       unsigned nt = msim_host_threads();
       if (nt > n_host_needed) nt = n_host_needed;
       std::vector<std::thread> th;
@@ -558,7 +654,8 @@ int lin_check_dev_run(msim_ctx *ctx, const LParams &lp0, u32 n, u32 max_rows_any
       else h_out[i] = h2[i];
     }
     if (copy_err) { ctx->err = "lin-kv check: copying a history to the host failed"; return MSIM_E_HIP; }
-    if (trace) std::fprintf(stderr, "[lin-check] device passes done at %.2f ms, %u histories needed the host search\n", t_dev, n_host_needed);
+    if (trace) { u32 slots = 0; for (size_t k = 0; k < order.size(); k++) if (wanted[k] && h2[order[k]].duplicated_count == 1u) slots++;
+      std::fprintf(stderr, "[lin-check] device passes done at %.2f ms, %u histories needed the host search (%u of them: more than 23 calls pending on a key)\n", t_dev, n_host_needed, slots); }
     todo.resize(n_host_needed);
   }
   if (trace) std::fprintf(stderr, "[lin-check] done at %.2f ms\n", ms());
