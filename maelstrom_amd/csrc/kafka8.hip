@@ -197,8 +197,18 @@ __global__ void __launch_bounds__(64) kafka8_kernel(const K8Params up) {
     return a ? 1u + (u[a - 1u] & 0xFFFFu) : 0u;
   };
 
+  const u64 pc = rate ? (u64)N * 65536ull * 1000ull / (30ull * (u64)rate) : ~0ull;   // a :crash every 30 s per worker on average ([upstream] jepsen.tests.kafka), as a 16-bit threshold
+#ifdef K8_PROF   // developer build (tools/variant_lib.sh k8prof kafka8.hip -DK8_PROF; tools/kafka8_prof_report.py): cycles of a wavefront by section of the round
+  u64 kp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kp_t = __builtin_readcyclecounter(); u32 kp_rounds = 0;
+#define K8_MARK(i_) { const u64 kp_n = __builtin_readcyclecounter(); kp[i_] += kp_n - kp_t; kp_t = kp_n; }
+#else
+#define K8_MARK(i_)
+#endif
   for (;;) {
     if (!__ballot(alive)) break;
+#ifdef K8_PROF
+    kp_rounds++;
+#endif
     const u32 busy_mask = GB(busy);
     const u32 pend_mask = GB(mark);   // clients between the two RPCs of a poll
 
@@ -326,6 +336,7 @@ __global__ void __launch_bounds__(64) kafka8_kernel(const K8Params up) {
         else abort_op(c_f == MSIM_F_ASSIGN ? MSIM_T_FAIL : MSIM_T_INFO, MSIM_ERR_NET_TIMEOUT);   // (c/with-errors op #{:assign} ..), :205
       }
     }
+    K8_MARK(0)   // [0] = phase checks, R0 (time), timeouts
     bool normal = alive && !timeout_round;   // this cluster runs R1-R4 in this wave-round
     if (__ballot(normal)) {
       // ---- R1: scheduler ----
@@ -345,7 +356,6 @@ __global__ void __launch_bounds__(64) kafka8_kernel(const K8Params up) {
           const bool sel = gen_on && is_node && !busy && (u32)__popc(free_mask & lt) == pick;
           // one operation ([upstream] jepsen.tests.kafka, oracle/kafka_nodes.inc kf_generate): every lane of the cluster computes it, lane 0 owns the key pool
           const u64 h2 = draw64(key, S_GEN2, kk);
-          const u64 pc = (u64)N * 65536ull * 1000ull / (30ull * (u64)rate);
           u32 f = 0, val = MSIM_NO_VALUE, bad = 0;
           u32 npay = 0;   // payload words the operation takes (an :assign's keys)
           const bool is_crash = ((h2 >> 48) & 0xFFFFu) < pc;
@@ -419,6 +429,7 @@ __global__ void __launch_bounds__(64) kafka8_kernel(const K8Params up) {
         }
       }
 
+      K8_MARK(1)   // [1] = R1 scheduler / generator
       // ---- R2: marked clients invoke (or send the second RPC of a poll); the request goes to this lane's own node ----
       if (__ballot(mark && normal)) {
         const bool inv = mark && normal;
@@ -471,6 +482,7 @@ __global__ void __launch_bounds__(64) kafka8_kernel(const K8Params up) {
         poll();
       }
 
+      K8_MARK(2)   // [2] = R2 invocations
       // ---- R3: one input per node, then one for the service (endpoint order) ----
       bool to_svc = false, rep = false, svc_rep = false;   // node -> service, node -> own client, service -> node
       u32 o_type = 0, o_a = 0, o_b = 0, o_dest = 0, need_words = 0, done_slot = 0;
@@ -598,6 +610,7 @@ __global__ void __launch_bounds__(64) kafka8_kernel(const K8Params up) {
           if (fits) n_payload += total;
         }
       }
+      K8_MARK(3)   // [3] = R3 nodes (+ reply payloads)
       wave_lds_fence();   // the service reads the handlers' tables (LDS) after the nodes have written them
       // the lin-kv service (service.clj:31-61 over the chunk keys and "offsets"): one request per round, after the nodes
       if (__ballot(svc_due)) {
@@ -642,6 +655,7 @@ __global__ void __launch_bounds__(64) kafka8_kernel(const K8Params up) {
       }
       wave_lds_fence();
 
+      K8_MARK(4)   // [4] = R3 service
       // COMMIT: ids in lane order (nodes, then the service)
       bool c_arr = false; u32 ca_y = 0, ca_a = 0, ca_b = 0;
       {
@@ -674,7 +688,9 @@ __global__ void __launch_bounds__(64) kafka8_kernel(const K8Params up) {
         poll();
       }
 
+      K8_MARK(5)   // [5] = COMMIT + polls
       #include "group8_clients.inc"
+    K8_MARK(6)   // [6] = R4 clients
     // ---- history rows: nemesis rows, invocations (lane order), completions (lane order) ----
     {
       const u32 imask = GB(inv_row), cmask = GB(cmp_row);
@@ -697,6 +713,7 @@ __global__ void __launch_bounds__(64) kafka8_kernel(const K8Params up) {
         n_rows = wr ? n_rows + nr : n_rows;
       }
     }
+    K8_MARK(7)   // [7] = rows
   }
 
   // ---- epilogue ----
@@ -711,6 +728,10 @@ __global__ void __launch_bounds__(64) kafka8_kernel(const K8Params up) {
     p.stats[inst] = st;
     msim_inst_meta m; m.n_rows = n_rows; m.n_payload_words = n_payload; m.flags = flags; m.n_rounds = rounds;
     m.n_events = 0; m.reserved[0] = 0; m.reserved[1] = 0; m.reserved[2] = 0;
+#ifdef K8_PROF
+    if (grp == 0) { st.all_send = kp[0]; st.all_recv = kp[1]; st.clients_send = kp[2]; st.clients_recv = kp[3]; st.servers_send = kp[4]; st.servers_recv = kp[5]; p.stats[inst] = st;
+                    m.reserved[0] = (u32)(kp[6] >> 6); m.reserved[1] = (u32)(kp[7] >> 6); m.n_events = kp_rounds; }
+#endif
     p.meta[inst] = m;
   }
 }
