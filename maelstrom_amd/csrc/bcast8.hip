@@ -92,6 +92,7 @@ __global__ void __launch_bounds__(64) bcast8_kernel(const B8Params up) {
   bool have_pm = false; uint4 pm = make_uint4(0, 0, 0, 0);
   u32 in_n = 0, sp_n = 0, part = 0;
   u32 node_msgid = 0, fifo_head = 0, fifo_tail = 0, retry_time = INF;
+  u32 fifo_hi = 0, fifo_ti = 0;   // (fifo_head / fifo_tail modulo max_values, kept by compare-and-wrap: a division by a run-time value is forty instructions in the round loop)
   // ---- client state ----
   bool busy = false, mark = false; u32 kind = K_NONE;
   u32 timeout_at = 0, next_msg_id = 0, c_f = 0, c_value = 0, c_final = 0, process = l, m_f = 0, m_value = 0, m_final = 0, cin_n = 0, csp_n = 0;
@@ -244,15 +245,15 @@ __global__ void __launch_bounds__(64) bcast8_kernel(const B8Params up) {
       const bool retry_now = IS_ACK && normal && is_node && retry_time <= T;
       const bool msg = normal && is_node && !retry_now && deliver_at <= T;
       if (retry_now) {
-        const u32 v = g_fifo[(fifo_head % max_values) * 2];
-        fifo_head++;
+        const u32 v = g_fifo[fifo_hi * 2];
+        fifo_head++; fifo_hi = fifo_hi + 1 == max_values ? 0u : fifo_hi + 1;
         const u32 un = g_unacked[v];
         if (un) {
           dmask = un; fan_a = v; fan_b0 = node_msgid + 1; node_msgid += __popc(un);
-          const u32 ts = (fifo_tail % max_values) * 2;
-          g_fifo[ts] = v; g_fifo[ts + 1] = T + 1000000u; fifo_tail++;
+          const u32 ts = fifo_ti * 2;
+          g_fifo[ts] = v; g_fifo[ts + 1] = T + 1000000u; fifo_tail++; fifo_ti = fifo_ti + 1 == max_values ? 0u : fifo_ti + 1;
         }
-        retry_time = fifo_head < fifo_tail ? g_fifo[(fifo_head % max_values) * 2 + 1] : INF;
+        retry_time = fifo_head < fifo_tail ? g_fifo[fifo_hi * 2 + 1] : INF;
       } else if (msg) {
         const uint4 q = cm; deliver_at = INF;
         const u32 qsrc = q.w >> 24, qb = q.w & 0xFFFFFFu, qtype = q.y & 0xFFu, qa = q.z;
@@ -272,10 +273,10 @@ __global__ void __launch_bounds__(64) bcast8_kernel(const B8Params up) {
               if (IS_RPC) { fan_b0 = node_msgid + 1; node_msgid += __popc(tg); }
               if (IS_ACK && tg) {
                 g_unacked[v] = tg;
-                const u32 ts = (fifo_tail % max_values) * 2;
+                const u32 ts = fifo_ti * 2;
                 g_fifo[ts] = v; g_fifo[ts + 1] = T + 1000000u;
                 if (fifo_head == fifo_tail) retry_time = T + 1000000u;
-                fifo_tail++;
+                fifo_tail++; fifo_ti = fifo_ti + 1 == max_values ? 0u : fifo_ti + 1;
               }
             }
             if (qb != 0) { rep = true; rep_dest = qsrc; rep_type = M_BROADCAST_OK; rep_a = v; rep_b = qb; }
