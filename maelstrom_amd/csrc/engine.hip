@@ -257,6 +257,19 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   const size_t lds = off;
   if (lds > 160 * 1024) { ctx->err = "cluster state exceeds the 160 KiB LDS of a CU (lower inbox_capacity / max_values)"; return MSIM_E_INVALID; }
 
+  // developer check for reads of memory no kernel of this launch wrote: MSIM_POISON=<byte> fills every device buffer of the context
+  // with that byte before each launch (HBM comes back from hipMalloc with whatever its last owner left there); results must not depend on it
+  static const int poison = []() { const char *p = std::getenv("MSIM_POISON"); return p ? (int)(std::strtoul(p, nullptr, 0) & 0xFFu) : -1; }();
+  if (poison >= 0) {
+    MSIM_HIP_TRY(ctx, hipMemsetAsync(ctx->d_rows, poison, (size_t)ctx->cap_inst * c.max_rows * sizeof(msim_op), st));
+    MSIM_HIP_TRY(ctx, hipMemsetAsync(ctx->d_payload, poison, (size_t)ctx->cap_inst * c.max_payload_words * 4, st));
+    MSIM_HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, poison, (size_t)ctx->cap_inst * sizeof(msim_net_stats), st));
+    MSIM_HIP_TRY(ctx, hipMemsetAsync(ctx->d_meta, poison, (size_t)ctx->cap_inst * sizeof(msim_inst_meta), st));
+    MSIM_HIP_TRY(ctx, hipMemsetAsync(ctx->d_scratch, poison, (size_t)ctx->cap_inst * ctx->scratch_words_per_inst * 4, st));
+    MSIM_HIP_TRY(ctx, hipMemsetAsync(ctx->d_check, poison, (size_t)ctx->cap_inst * sizeof(msim_check_result), st));
+    if (ctx->d_journal) MSIM_HIP_TRY(ctx, hipMemsetAsync(ctx->d_journal, poison, (size_t)ctx->cap_inst * c.journal_capacity * sizeof(msim_event), st));
+    if (ctx->d_check_scratch) MSIM_HIP_TRY(ctx, hipMemsetAsync(ctx->d_check_scratch, poison, ctx->cap_check_scratch, st));
+  }
   if (blocking) MSIM_HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
   hipError_t e;
   // the headline layout: two clusters per wavefront (duo.hip); MSIM_DEV_FLAGS bit 9 keeps the one-cluster kernels

@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Results must not depend on what hipMalloc hands back: every config below is run with its device buffers pre-filled with
+0x00, 0xFF and 0xA5 before each launch (MSIM_POISON, csrc/engine.hip run_impl) and once unpoisoned; the digests of everything the
+run returns (rows, payload, net stats, meta, checker results, the journal where it is on) have to agree.  A kernel that reads
+HBM nothing in its own launch wrote shows up as a differing digest, a fault or a hang (each run is a subprocess under a timeout).
+
+    python tools/poison_sweep.py [name-substring ...]        # one JSON line per (config, batch); exit 1 on any difference
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+# (name, test_config keywords, batch sizes — small ones take the one-cluster kernels, large ones the packed layouts
+# of csrc/layout_thresholds.h)
+CASES = [
+    ("headline broadcast n=25", dict(workload="broadcast", node_count=25, rate=100, time_limit=20, inbox_capacity=6), [64, 4096]),
+    ("broadcast n=25 lat100 exponential", dict(workload="broadcast", node_count=25, rate=100, time_limit=20, latency=100, latency_dist="exponential"), [64, 1024]),
+    ("broadcast n=25 journal", dict(workload="broadcast", node_count=25, rate=20, time_limit=5, journal_capacity=40000), [33]),
+    ("broadcast n=5 + partitions", dict(workload="broadcast", node_count=5, rate=50, time_limit=10, latency=10, nemesis=["partition"], nemesis_interval=3), [64, 12288]),
+    ("ack-retry n=25 + partitions", dict(workload="broadcast", bin="broadcast-ack-retry", node_count=25, rate=50, time_limit=10, latency=10, nemesis=["partition"], nemesis_interval=5), [96]),
+    ("ack-retry n=5 + partitions", dict(workload="broadcast", bin="broadcast-ack-retry", node_count=5, rate=50, time_limit=10, latency=10, nemesis=["partition"], nemesis_interval=3), [64, 12288]),
+    ("echo n=3", dict(workload="echo", node_count=3, rate=5, time_limit=10), [64, 4096]),
+    ("unique-ids n=3 + partitions", dict(workload="unique-ids", node_count=3, rate=200, time_limit=5, latency=5, nemesis=["partition"], nemesis_interval=2), [64, 4096]),
+    ("g-set n=5 + partitions", dict(workload="g-set", node_count=5, rate=50, time_limit=12, latency=10, nemesis=["partition"], nemesis_interval=4), [64, 4096]),
+    ("pn-counter n=5", dict(workload="pn-counter", node_count=5, rate=50, time_limit=12, latency=100, latency_dist="exponential"), [64, 4096]),
+    ("g-set n=100 exp p_loss 0.05", dict(workload="g-set", node_count=100, rate=100, time_limit=12, latency=100, latency_dist="exponential", p_loss=0.05), [40]),
+    ("broadcast n=100 exp", dict(workload="broadcast", node_count=100, rate=50, time_limit=6, latency=100, latency_dist="exponential"), [24]),
+    ("broadcast n=60 + partitions", dict(workload="broadcast", node_count=60, rate=50, time_limit=8, latency=10, nemesis=["partition"], nemesis_interval=3), [24]),
+    ("ack-retry n=40", dict(workload="broadcast", bin="broadcast-ack-retry", node_count=40, rate=30, time_limit=6, latency=10), [16]),
+    ("lin-kv raft", dict(workload="lin-kv", bin="raft", node_count=5, rate=30, time_limit=20), [40, 1024]),
+    ("lin-kv raft + partitions", dict(workload="lin-kv", bin="raft", node_count=5, rate=30, time_limit=20, latency=10, nemesis=["partition"], nemesis_interval=5), [40, 1024]),
+    ("lin-kv proxy", dict(workload="lin-kv", bin="lin-kv-proxy", node_count=3, rate=30, time_limit=10, latency=5), [40]),
+    ("txn-list-append + partitions", dict(workload="txn-list-append", node_count=5, rate=100, time_limit=10, latency=5, nemesis=["partition"], nemesis_interval=4), [40, 4096]),
+    ("txn-list-append multi-key + partitions", dict(workload="txn-list-append", bin="multi-key-txn", node_count=5, rate=100, time_limit=10, latency=5, nemesis=["partition"], nemesis_interval=4), [40, 4096]),
+    ("txn-list-append datomic + partitions", dict(workload="txn-list-append", bin="datomic", node_count=5, rate=100, time_limit=10, latency=5, nemesis=["partition"], nemesis_interval=4), [40, 4096]),
+    ("kafka + partitions", dict(workload="kafka", node_count=5, rate=100, time_limit=8, latency=5, nemesis=["partition"], nemesis_interval=3), [40, 16384]),
+    ("txn-rw-register n=2 + partitions", dict(workload="txn-rw-register", node_count=2, rate=100, time_limit=10, nemesis=["partition"], nemesis_interval=4), [40, 16384]),
+    ("txn-rw-register n=5 + partitions", dict(workload="txn-rw-register", node_count=5, rate=100, time_limit=10, latency=5, nemesis=["partition"], nemesis_interval=4), [40, 4096]),
+]
+
+
+def child(kw, n):
+    from maelstrom_amd import engine as E
+    import numpy as np
+    cfg = E.test_config(seed=777, **kw)
+    h = hashlib.sha256()
+    with E.Engine(cfg) as eng:
+        for first in (0, n + 5):   # a second launch over the first one's leftovers, too
+            eng.run(first, n)
+            eng.check()
+            eng.fetch()
+            for i in range(n):
+                rows, pay = eng.raw_history(i)
+                h.update(rows.tobytes()); h.update(pay.tobytes())
+                st = eng.net_stats_raw(i)
+                h.update(bytes(st))
+                h.update(bytes(eng.meta(i)))
+                if cfg.journal_capacity:
+                    h.update(eng.raw_journal(i).tobytes())
+            res = eng.check_results()
+            h.update(np.ascontiguousarray(res).tobytes())
+    print("DIGEST " + h.hexdigest(), flush=True)
+
+
+def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--child":
+        kw, n = json.loads(sys.argv[2]), int(sys.argv[3])
+        child(kw, n)
+        return
+    pick = sys.argv[1:]
+    bad = 0
+    for name, kw, batches in CASES:
+        if pick and not any(p in name for p in pick):
+            continue
+        for n in batches:
+            out = {}
+            for poison in (None, "0x00", "0xFF", "0xA5"):
+                env = dict(os.environ)
+                env.pop("MSIM_POISON", None)
+                if poison:
+                    env["MSIM_POISON"] = poison
+                try:
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", json.dumps(kw), str(n)], env=env, capture_output=True, text=True, timeout=300)
+                    d = [ln[7:] for ln in r.stdout.splitlines() if ln.startswith("DIGEST ")]
+                    out[poison or "none"] = d[0][:16] if d else f"rc={r.returncode} {r.stderr.strip().splitlines()[-1][:160] if r.stderr.strip() else ''}"
+                except subprocess.TimeoutExpired:
+                    out[poison or "none"] = "timeout"
+            ok = len(set(out.values())) == 1 and not any(v.startswith(("rc=", "timeout")) for v in out.values())
+            bad += 0 if ok else 1
+            print(json.dumps({"config": name, "instances": n, "ok": ok, "digests": out}), flush=True)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
