@@ -77,6 +77,12 @@ enum {
   MSIM_NODE_KAFKA = 14,         /* demo/clojure/kafka.clj:1-172: logs in 32-message chunks under lin-kv keys (read + cas per send), committed
                                    offsets under one lin-kv key; brings the `lin-kv` service endpoint with it.  One worker per node, at most
                                    8 keys per test (oracle/kafka_nodes.inc, csrc/sim_kernel_kafka.inc; parity unpinned: babashka only)      */
+  MSIM_NODE_TXN_DATOMIC = 15,   /* demo/ruby/datomic_list_append.rb:47-424, the node core.clj:113-114 runs for this workload: the database is a
+                                   persistent hash tree (128 hash values, branch factor 8, CRC32 of the key) of immutable nodes in lww-kv under
+                                   fresh pointers, the root pointer in lin-kv; a transaction takes the node's lock, reads the root pointer, loads the
+                                   tree nodes on its keys' paths lazily (a cache of what the node has loaded), copies the paths it appends to, writes
+                                   the new nodes children first and cas-es the root; a lost cas answers error 30 (oracle/dt_nodes.inc — parity
+                                   unpinned: there is no Ruby here; csrc/sim_kernel_dt.inc).  One worker per node, at most 8 nodes          */
   MSIM_NODE_TSO_IDS = 13        /* unique-ids over the `lin-tso` timestamp oracle (service.clj:116-132,290-296; doc/services.md): every
                                    `generate` becomes a {type "ts"} RPC to lin-tso, the timestamp is the id.  The reference ships the
                                    service but no demo that uses it; this node (tools/harness_tso_node.py is its process form) is what

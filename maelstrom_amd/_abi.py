@@ -15,7 +15,7 @@ ABI_VERSION = 1
 # enums (include/maelsim.h)
 OK, E_INVALID, E_NO_DEVICE, E_HIP, E_NOMEM, E_RANGE, E_UNSUPPORTED, E_OVERFLOW = 0, -1, -2, -3, -4, -5, -6, -7
 WL_ECHO, WL_BROADCAST, WL_G_SET, WL_LIN_KV, WL_TXN_LIST_APPEND, WL_PN_COUNTER, WL_G_COUNTER, WL_UNIQUE_IDS, WL_TXN_RW_REGISTER, WL_KAFKA = range(10)
-NODE_ECHO, NODE_BCAST_FF, NODE_BCAST_FF_ECHOBACK, NODE_BCAST_ACK_RETRY, NODE_BCAST_RPC_ALL, NODE_G_SET, NODE_RAFT, NODE_TXN_SINGLE_KEY, NODE_PN_COUNTER, NODE_FLAKE_IDS, NODE_LIN_KV_PROXY, NODE_TXN_RW_HAT, NODE_TXN_MULTI_KEY, NODE_TSO_IDS, NODE_KAFKA = range(15)
+NODE_ECHO, NODE_BCAST_FF, NODE_BCAST_FF_ECHOBACK, NODE_BCAST_ACK_RETRY, NODE_BCAST_RPC_ALL, NODE_G_SET, NODE_RAFT, NODE_TXN_SINGLE_KEY, NODE_PN_COUNTER, NODE_FLAKE_IDS, NODE_LIN_KV_PROXY, NODE_TXN_RW_HAT, NODE_TXN_MULTI_KEY, NODE_TSO_IDS, NODE_KAFKA, NODE_TXN_DATOMIC = range(16)
 SVC_LIN_KV, SVC_SEQ_KV, SVC_LWW_KV = range(3)
 CM_STRICT_SERIALIZABLE, CM_SERIALIZABLE, CM_SNAPSHOT_ISOLATION, CM_READ_COMMITTED, CM_READ_UNCOMMITTED = range(5)
 LAT_CONSTANT, LAT_UNIFORM, LAT_EXPONENTIAL = range(3)

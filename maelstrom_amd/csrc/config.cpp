@@ -97,7 +97,7 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
     case MSIM_WL_BROADCAST: ok = c->node_program >= MSIM_NODE_BCAST_FF && c->node_program <= MSIM_NODE_BCAST_RPC_ALL; break;
     case MSIM_WL_G_SET: ok = c->node_program == MSIM_NODE_G_SET; break;
     case MSIM_WL_LIN_KV: ok = c->node_program == MSIM_NODE_RAFT || c->node_program == MSIM_NODE_LIN_KV_PROXY; break;
-    case MSIM_WL_TXN_LIST_APPEND: ok = c->node_program == MSIM_NODE_TXN_SINGLE_KEY || c->node_program == MSIM_NODE_TXN_MULTI_KEY; break;
+    case MSIM_WL_TXN_LIST_APPEND: ok = c->node_program == MSIM_NODE_TXN_SINGLE_KEY || c->node_program == MSIM_NODE_TXN_MULTI_KEY || c->node_program == MSIM_NODE_TXN_DATOMIC; break;
     case MSIM_WL_PN_COUNTER: case MSIM_WL_G_COUNTER: ok = c->node_program == MSIM_NODE_PN_COUNTER; break;
     case MSIM_WL_UNIQUE_IDS: ok = c->node_program == MSIM_NODE_FLAKE_IDS || c->node_program == MSIM_NODE_TSO_IDS; break;
     case MSIM_WL_TXN_RW_REGISTER: ok = c->node_program == MSIM_NODE_TXN_RW_HAT; break;
@@ -182,6 +182,7 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
     if (c->node_program == MSIM_NODE_RAFT) depth = 24 + 1024;   // heartbeats / re-sent append_entries pile up behind a sleeping recv!
     if (txn || kafka) depth = 16 + 4 * c->n_nodes;              // the service sees <= 2 requests per transaction in flight
     if (c->node_program == MSIM_NODE_TXN_MULTI_KEY) depth = 16 + 16 * c->n_nodes;   // lww-kv: up to max-txn-length thunk reads / writes per transaction
+    if (c->node_program == MSIM_NODE_TXN_DATOMIC) depth = 16 + 64 * c->n_nodes;     // lww-kv: every node may have the new tree nodes of a transaction in flight (DT_MAXW)
     if (hat) depth = 16 + 4 * c->n_nodes + (uint32_t)(20.0 * c->n_nodes * lat_s);  // a replicate + n-1 acks per peer per 100 ms tick
     if (c->node_program == MSIM_NODE_LIN_KV_PROXY || c->node_program == MSIM_NODE_TSO_IDS) depth = 16 + 2 * c->concurrency;   // the service sees every worker's request at once
     // wide clusters: 100+ queues would take a fifth of the LDS budget of a cluster; their queues live in the HBM spill area

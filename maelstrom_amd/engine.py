@@ -29,7 +29,7 @@ NODE_PROGRAMS = {"echo": A.NODE_ECHO, "broadcast-ff": A.NODE_BCAST_FF, "broadcas
                  "g-set": A.NODE_G_SET, "raft": A.NODE_RAFT, "single-key-txn": A.NODE_TXN_SINGLE_KEY,
                  "pn-counter": A.NODE_PN_COUNTER, "flake-ids": A.NODE_FLAKE_IDS, "lin-kv-proxy": A.NODE_LIN_KV_PROXY,
                  "txn-rw-register-hat": A.NODE_TXN_RW_HAT,
-                 "multi-key-txn": A.NODE_TXN_MULTI_KEY, "tso-ids": A.NODE_TSO_IDS, "kafka": A.NODE_KAFKA}
+                 "multi-key-txn": A.NODE_TXN_MULTI_KEY, "datomic": A.NODE_TXN_DATOMIC, "tso-ids": A.NODE_TSO_IDS, "kafka": A.NODE_KAFKA}
 SERVICES = {"lin-kv": A.SVC_LIN_KV, "seq-kv": A.SVC_SEQ_KV, "lww-kv": A.SVC_LWW_KV}
 CONSISTENCY_MODELS = {"strict-serializable": A.CM_STRICT_SERIALIZABLE, "serializable": A.CM_SERIALIZABLE,
                       "snapshot-isolation": A.CM_SNAPSHOT_ISOLATION, "read-committed": A.CM_READ_COMMITTED,

@@ -94,6 +94,7 @@ typedef struct {
   struct svc_s *svc;  /* proxy node + key-value services (svc_nodes.inc) */
   struct hat_s *hat;  /* txn-rw-register highly-available-transactions node (hat_nodes.inc) */
   struct mk_s *mk;    /* txn-list-append over thunks in lww-kv and a root map in lin-kv (mk_nodes.inc) */
+  struct dt_s *dt;    /* txn-list-append over a persistent hash tree in lww-kv and a root pointer in lin-kv (dt_nodes.inc) */
   struct kafka_s *kafka; /* kafka workload: node, lin-kv contents, clients' offsets, generator (kafka_nodes.inc) */
   u32 *rtrace; u32 n_rtrace, cap_rtrace; /* test hook: what every Raft node did in every round (oracle_raft_schedule) */
   u64 key;
@@ -380,6 +381,7 @@ static void node_timer(sim_t *s, u32 node) {
 #include "raft_nodes.inc"
 #include "txn_nodes.inc"
 #include "mk_nodes.inc"
+#include "dt_nodes.inc"
 #include "svc_nodes.inc"
 #include "hat_nodes.inc"
 #include "kafka_nodes.inc"
@@ -388,6 +390,7 @@ static void node_handle(sim_t *s, u32 node, const qent *q) {
   if (s->cfg.node_program == MSIM_NODE_RAFT) { raft_handle(s, node, q); return; }
   if (s->cfg.node_program == MSIM_NODE_TXN_SINGLE_KEY) { txn_node_handle(s, node, q); return; }
   if (s->cfg.node_program == MSIM_NODE_TXN_MULTI_KEY) { mk_node_handle(s, node, q); return; }
+  if (s->cfg.node_program == MSIM_NODE_TXN_DATOMIC) { dt_node_handle(s, node, q); return; }
   if (s->cfg.node_program == MSIM_NODE_LIN_KV_PROXY) { px_node_handle(s, node, q); return; }
   if (s->cfg.node_program == MSIM_NODE_TSO_IDS) { tso_node_handle(s, node, q); return; }
   if (s->cfg.node_program == MSIM_NODE_TXN_RW_HAT) { hat_node_handle(s, node, q); return; }
@@ -771,7 +774,7 @@ static void run_instance(sim_t *s) {
         qent q = s->committed[e]; s->has_committed[e] = 0;
         s->st.all_recv++; s->st.servers_recv++;
         jlog(s, 1, q.id, q.type, q.a, q.b, q.src, e);
-        if (s->kafka) kf_svc_handle(s, &q); else if (s->mk) mk_svc_handle(s, e, &q); else if (s->cfg.node_program == MSIM_NODE_TSO_IDS) tso_svc_handle(s, &q); else if (s->svc) px_svc_handle(s, &q); else svc_handle(s, &q);
+        if (s->kafka) kf_svc_handle(s, &q); else if (s->mk) mk_svc_handle(s, e, &q); else if (s->dt) dt_svc_handle(s, e, &q); else if (s->cfg.node_program == MSIM_NODE_TSO_IDS) tso_svc_handle(s, &q); else if (s->svc) px_svc_handle(s, &q); else svc_handle(s, &q);
       }
     commit_sends(s);
     for (u32 e = 0; e < E; e++) poll_endpoint(s, e);
@@ -809,7 +812,7 @@ static sim_t *sim_new(const msim_config *cfg, uint64_t instance, msim_op *rows, 
   sim_t *s = (sim_t *)calloc(1, sizeof(sim_t));
   s->cfg = *cfg;
   s->N = cfg->n_nodes; s->C = cfg->concurrency; s->CS = s->C > s->N ? s->C : s->N;
-  s->S = cfg->node_program == MSIM_NODE_KAFKA || cfg->node_program == MSIM_NODE_TXN_SINGLE_KEY || cfg->node_program == MSIM_NODE_LIN_KV_PROXY || cfg->node_program == MSIM_NODE_TSO_IDS ? 1 : cfg->node_program == MSIM_NODE_TXN_MULTI_KEY ? 2 : 0; /* lin-kv (+ lww-kv) */
+  s->S = cfg->node_program == MSIM_NODE_KAFKA || cfg->node_program == MSIM_NODE_TXN_SINGLE_KEY || cfg->node_program == MSIM_NODE_LIN_KV_PROXY || cfg->node_program == MSIM_NODE_TSO_IDS ? 1 : cfg->node_program == MSIM_NODE_TXN_MULTI_KEY || cfg->node_program == MSIM_NODE_TXN_DATOMIC ? 2 : 0; /* lin-kv (+ lww-kv) */
   s->E = s->N + s->CS + s->S;
   if (s->E > 255) { free(s); return NULL; }
   s->W = (cfg->max_values + 31) / 32;
@@ -856,6 +859,7 @@ static sim_t *sim_new(const msim_config *cfg, uint64_t instance, msim_op *rows, 
   }
   if (cfg->node_program == MSIM_NODE_TXN_RW_HAT) s->hat = hat_new(s);
   if (cfg->node_program == MSIM_NODE_TXN_MULTI_KEY) s->mk = mk_new(s);
+  if (cfg->node_program == MSIM_NODE_TXN_DATOMIC) s->dt = dt_new(s);
   for (u32 i = 0; i < s->CS; i++) s->cl[i].process = i;
   s->rows = rows; s->payload = payload;
   s->phase = PH_INIT;
@@ -875,6 +879,7 @@ static void sim_free(sim_t *s) {
   if (s->svc) { free(s->svc->cb); free(s->svc->client_idx); free(s->svc); }
   if (s->hat) hat_free(s->hat);
   mk_free(s->mk, s->N);
+  dt_free(s->dt, s->N);
   kf_free(s->kafka);
   if (s->txn) { free(s->txn->slots); free(s->txn->kv); free(s->txn->kv_n); free(s->txn); }
   free(s->snap); free(s->inbox); free(s->committed); free(s->has_committed); free(s->deliver_at); free(s->seen);
@@ -1060,6 +1065,8 @@ int oracle_run(const msim_config *cfg, uint64_t first, uint32_t n, msim_op *rows
   return 0;
 }
 
+/* Exposed so tests can pin the datomic node's key hash against zlib. */
+uint32_t oracle_dt_hash(uint32_t key) { return dt_hash(key); }
 /* Exposed so tests can pin the integer samplers directly. */
 uint32_t oracle_neg_ln_q16(uint32_t r) { return neg_ln_q16(r); }
 uint32_t oracle_draw32(uint64_t seed, uint64_t instance, uint32_t stream, uint64_t ctr) {

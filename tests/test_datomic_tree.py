@@ -1,0 +1,190 @@
+"""txn-list-append over the Datomic-style node (demo/ruby/datomic_list_append.rb; oracle/dt_nodes.inc).  PARITY UNPINNED against the
+reference: no Ruby here.  What is checked instead:
+  * the hash is Ruby's (Zlib.crc32 of the decimal string, mod 128) — against Python's zlib;
+  * a replay: the oracle's net journal of whole runs is fed, receive by receive, to tests/datomic_ref.py (the Ruby classes in Python
+    with materialised tree nodes, maps and lists, real lin-kv / lww-kv services), which must send exactly the messages the journal
+    holds next — destination, type, msg_id / in_reply_to, pointers, error codes, completed transactions;
+  * the tree's invariants over those runs (splits at the ninth key, chains in two-wide ranges, lazily loaded paths);
+  * every history passes the list-append checker as strict-serializable; message counts follow the protocol's arithmetic."""
+import ctypes as C
+import zlib
+
+import numpy as np
+import pytest
+
+from maelstrom_amd import _abi as A
+from maelstrom_amd import engine as E
+import datomic_ref as R
+import oracle_lib as O
+
+
+def _cfg(**kw):
+    base = dict(workload="txn-list-append", bin="datomic", node_count=3, rate=60, time_limit=6, latency=3, seed=11, journal_capacity=200000)
+    base.update(kw)
+    return E.test_config(**base)
+
+
+def _word(ptr):
+    if ptr == "empty":
+        return 0
+    node, n = ptr[1:].split("-")
+    return (int(node) << 20) | int(n)
+
+
+def test_hash_is_rubys_crc32_of_the_decimal_string():
+    lib = O.load()
+    lib.oracle_dt_hash.argtypes = [C.c_uint32]
+    lib.oracle_dt_hash.restype = C.c_uint32
+    for k in list(range(0, 1200)) + [32766, 32767]:
+        assert lib.oracle_dt_hash(k) == zlib.crc32(str(k).encode()) % 128 == R.tree_hash(k)
+
+
+def replay(cfg, instance):
+    """Feeds the oracle's journal to the reference classes; returns statistics of the run."""
+    lib = O.load()
+    ora = O.run(cfg, instance, 1)
+    assert int(ora.meta[0]["flags"]) == 0
+    rows, pay = ora.history(0)
+    ev = ora.events(0)
+    N = cfg.n_nodes
+    LIN, LWW = 2 * N, 2 * N + 1
+    names = [f"n{i}" for i in range(N)] + [f"c{i}" for i in range(N)] + ["lin-kv", "lww-kv"]
+    idx = {n: i for i, n in enumerate(names)}
+    outq = {i: [] for i in range(len(names))}
+    ctr = [0]
+
+    def rand_int(n):
+        v = lib.oracle_draw32(cfg.seed, instance, 12, ctr[0])
+        ctr[0] += 1
+        return (v * n) >> 32
+
+    nodes = [R.DatomicListAppendNode((lambda i: lambda dest, body: outq[i].append((dest, body)))(i)) for i in range(N)]
+    lin, lww = R.LinKV(), R.LwwKV(rand_int)
+    inflight, stats = {}, {"loads": 0, "load_retries": 0, "writes": 0, "cas_ok": 0, "cas_lost": 0, "max_depth": 0, "splits": 0, "txn_ok": 0}
+
+    def check_a(src, dest, body, a, req_key):
+        t = body["type"]
+        if src < N and dest == LIN:
+            return a == (0 if t == "read" else _word(body["value"] if t == "write" else body["to"]))
+        if src < N and dest == LWW:
+            return a == _word(body["key"])
+        if src == LIN:
+            return a == (_word(body["value"]) if t == "read_ok" else body["code"] if t == "error" else 0)
+        if src == LWW:
+            return a == (body["code"] if t == "error" else _word(req_key))
+        if t == "txn_ok":
+            got = E.decode_txn(pay[(a & 0xFFFFFF):(a & 0xFFFFFF) + (a >> 24)])
+            want = [[":append" if f == "append" else ":r", k, v] for f, k, v in body["txn"]]
+            return got == want
+        return a == (body["code"] if t == "error" else 0)
+
+    for i in range(len(ev)):
+        msg, route, a = int(ev["msg"][i]), int(ev["route"][i]), int(ev["a"][i])
+        mid, typ, recv = msg >> 8, A.MSG_TYPES[msg & 0x7F], bool(msg & 0x80)
+        src, dest, b = route & 0xFF, (route >> 8) & 0xFF, route >> 16
+        if not recv:
+            if N <= src < 2 * N:   # a client's request: the journal says what it is
+                if typ == "init":
+                    body = {"type": "init", "node_id": names[dest], "node_ids": names[:N], "msg_id": b}
+                else:
+                    txn = [["append" if f == ":append" else "r", k, v] for f, k, v in E.decode_txn(pay[(a & 0xFFFFFF):(a & 0xFFFFFF) + (a >> 24)])]
+                    body = {"type": "txn", "txn": txn, "msg_id": b}
+                inflight[mid] = {"src": names[src], "dest": names[dest], "body": body}
+                continue
+            assert outq[src], f"event {i}: the journal has {names[src]} send {typ} to {names[dest]}; the reference program sent nothing"
+            d, body = outq[src].pop(0)
+            assert idx[d] == dest and body["type"] == typ, (i, names[src], d, body, names[dest], typ)
+            assert (body.get("msg_id") or body.get("in_reply_to") or 0) & 0xFFFF == b, (i, body, b)
+            assert check_a(src, dest, body, a, body.pop("_key", None)), (i, names[src], names[dest], body, hex(a))
+            inflight[mid] = {"src": names[src], "dest": d, "body": body}
+            if src < N and dest == LWW:
+                stats["writes" if typ == "write" else "loads"] += 1
+            continue
+        m = inflight.pop(mid)
+        assert idx[m["dest"]] == dest
+        if dest < N:
+            nodes[dest].handle(m)
+        elif dest == LIN or dest == LWW:
+            rep = (lin if dest == LIN else lww).handle(m["body"])
+            rep = {**rep, "in_reply_to": m["body"]["msg_id"], "_key": m["body"].get("key")}
+            outq[dest].append((m["src"], rep))
+            if dest == LWW and m["body"]["type"] == "read" and rep["type"] == "error":
+                stats["load_retries"] += 1
+            if dest == LIN and m["body"]["type"] == "cas":
+                stats["cas_ok" if rep["type"] == "cas_ok" else "cas_lost"] += 1
+        else:
+            stats["txn_ok"] += m["body"]["type"] == "txn_ok"
+    assert not any(outq.values()), {names[k]: v[:2] for k, v in outq.items() if v}
+    assert not inflight
+
+    # the committed tree, walked in the store: every leaf holds the keys of its range, a full leaf was split
+    store = {}
+    for r in lww.replicas:
+        store.update(r)
+
+    def walk(ptr, depth):
+        nd = store[ptr]
+        stats["max_depth"] = max(stats["max_depth"], depth)
+        lo, hi = nd["range"]
+        if nd["type"] == "leaf":
+            for k, _ in nd["pairs"]:
+                assert lo <= R.tree_hash(k) < hi
+            return {k: v for k, v in nd["pairs"]}
+        stats["splits"] += 1
+        assert len(nd["branches"]) == R.BRANCH_FACTOR and nd["branches"][-1][0] == hi
+        out = {}
+        for _, child in nd["branches"]:
+            out.update(walk(child, depth + 1))
+        return out
+    final = walk(lin.m["root"], 1)
+    # ... and holds, key by key, what the history's acknowledged appends say (the order of a key's list = commit order)
+    h = E.decode_history(rows, pay, N, cfg.workload)
+    acked = {}
+    for op in h:
+        if op["type"] == ":ok" and op["process"] != ":nemesis":
+            for f, k, v in op["value"]:
+                if f == ":append":
+                    acked.setdefault(k, set()).add(v)
+    for k, vs in acked.items():
+        assert vs <= set(final.get(k, [])), (k, vs, final.get(k))
+    stats["keys"] = len(final)
+    stats["history"] = (rows, pay)
+    stats["stats"] = ora.stats[0]
+    return stats
+
+
+@pytest.mark.parametrize("kw,instance", [
+    (dict(), 0), (dict(), 1),
+    (dict(node_count=1, rate=40), 2),
+    (dict(node_count=5, rate=100, time_limit=8, latency=5, nemesis=["partition"], nemesis_interval=3), 3),
+    (dict(node_count=2, rate=100, time_limit=10, latency=2, latency_dist="exponential"), 4),
+    (dict(node_count=3, rate=150, time_limit=10, latency=0, key_count=16, max_writes_per_key=2), 5),   # many keys: deep trees, chains
+])
+def test_replay_against_the_reference_classes(kw, instance):
+    cfg = _cfg(**kw)
+    st = replay(cfg, instance)
+    rows, pay = st["history"]
+    res = E.check_txn_history(rows, pay)
+    assert res["valid?"] is True and res["info-count"] == 0, res
+    assert st["txn_ok"] == res["ok-count"] and st["cas_lost"] == res["fail-count"]
+    assert st["loads"] > 0 and st["writes"] >= st["cas_ok"] + 1
+
+
+def test_many_keys_grow_branches_and_chains():
+    st = replay(_cfg(node_count=3, rate=150, time_limit=10, latency=0, key_count=16, max_writes_per_key=2), 5)
+    assert st["keys"] > 128 and st["max_depth"] >= 4 and st["splits"] > 9, {k: v for k, v in st.items() if k not in ("history", "stats")}
+
+
+def test_message_arithmetic_single_node():
+    """One node, nothing lost, nothing contended: every transaction costs a root read; a transaction that appends also costs its new tree
+    nodes' writes, one cas and — at the next transaction — the loads of what it wrote (each repeated while lww-kv draws the other replica)."""
+    cfg = _cfg(node_count=1, rate=40, time_limit=8, latency=2)
+    st = replay(cfg, 7)
+    rows, pay = st["history"]
+    h = [op for op in E.decode_history(rows, pay, 1, cfg.workload) if op["type"] == ":invoke"]
+    n_txn, n_app = len(h), sum(1 for op in h if any(f == ":append" for f, _, _ in op["value"]))
+    assert st["cas_lost"] == 0 and st["cas_ok"] == n_app
+    s = st["stats"]
+    # requests: init + txns from the client; 2 init writes; per txn a root read; loads (+ retries); writes; a cas per appending txn — and as many replies
+    assert int(s["clients_send"]) == 2 * (1 + n_txn)
+    assert int(s["servers_send"]) == 2 * (2 + n_txn + st["loads"] + st["writes"] - 1 + n_app)
