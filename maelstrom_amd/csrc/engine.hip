@@ -106,8 +106,8 @@ extern "C" int msim_create(const msim_config *cfg, int device, msim_ctx **out, c
   msim_config c = *cfg;
   int rc = msim_config_finalize(&c, err, errlen);
   if (rc != MSIM_OK) return rc;
-  if (c.node_program == MSIM_NODE_TXN_MULTI_KEY && (c.concurrency != c.n_nodes || c.n_nodes > 30)) {
-    set_err(err, errlen, "multi_key_txn: one worker per node and at most 30 nodes (two service lanes) in this build");
+  if ((c.node_program == MSIM_NODE_TXN_MULTI_KEY || c.node_program == MSIM_NODE_TXN_DATOMIC) && (c.concurrency != c.n_nodes || c.n_nodes > 30)) {
+    set_err(err, errlen, "multi_key_txn / datomic: one worker per node and at most 30 nodes (two service lanes) in this build");
     return MSIM_E_UNSUPPORTED;
   }
   const uint32_t slots = c.concurrency > c.n_nodes ? c.concurrency : c.n_nodes;
@@ -161,6 +161,7 @@ static uint64_t proto_scratch_words(const msim_config &c) {
   if (c.node_program == MSIM_NODE_TXN_MULTI_KEY)   // elements, counts, map position, entry version, thunk counts, thunk versions + ids, the nodes' caches, the replica bytes
     w = (uint64_t)c.max_values * (c.max_writes_per_key + 4 + 2 * (c.max_writes_per_key + 1)) + (uint64_t)c.n_nodes * mk_ccap(c) + (uint64_t)c.n_nodes * mk_tcap(c) / 4 + 4 +
         (uint64_t)c.n_nodes * (MK_SLOTS - MK_SL) * mk_slot_words(8);   // + the transaction slots that are not in LDS
+  if (c.node_program == MSIM_NODE_TXN_DATOMIC) w = dt_scratch_words(c);   // elements, counts, first versions, key hashes, the tree nodes, the nodes' caches, a round's write lists
   if (c.node_program == MSIM_NODE_KAFKA) w = (uint64_t)KF_KEYS * (2 * (c.max_writes_per_key + 1) + 1);   // the logs + the committed-offset lists of the keys
   if (c.node_program == MSIM_NODE_TXN_RW_HAT) {  // registers per node + txn table + pending masks (bytes) + replicate lists
     const uint64_t G = c.max_rows / 2;
@@ -181,7 +182,7 @@ static uint64_t proto_scratch_words(const msim_config &c) {
   return (w + 3) & ~3ull;  // keep the spill area 16-byte aligned
 }
 static uint64_t scratch_words(const msim_config &c) {
-  const uint64_t queues = c.n_nodes + (c.node_program == MSIM_NODE_KAFKA || c.node_program == MSIM_NODE_TXN_SINGLE_KEY || c.node_program == MSIM_NODE_LIN_KV_PROXY || c.node_program == MSIM_NODE_TSO_IDS ? 1 : c.node_program == MSIM_NODE_TXN_MULTI_KEY ? 2 : 0);  // + the services
+  const uint64_t queues = c.n_nodes + (c.node_program == MSIM_NODE_KAFKA || c.node_program == MSIM_NODE_TXN_SINGLE_KEY || c.node_program == MSIM_NODE_LIN_KV_PROXY || c.node_program == MSIM_NODE_TSO_IDS ? 1 : c.node_program == MSIM_NODE_TXN_MULTI_KEY || c.node_program == MSIM_NODE_TXN_DATOMIC ? 2 : 0);  // + the services
   uint64_t w = proto_scratch_words(c) + queues * c.spill_capacity * 4;
   if (msim_raft4_eligible(c)) w += msim_raft4_extra_scratch_words(c);   // raft4.hip keeps fewer envelopes in LDS
   if (msim_txn8_eligible(c)) w += msim_txn8_extra_scratch_words(c);     // txn8.hip likewise
@@ -238,13 +239,14 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   const bool wide_crdt = wide && (c.node_program == MSIM_NODE_G_SET || c.node_program == MSIM_NODE_PN_COUNTER);   // (rows unstaged: sim_kernel_wide.inc ROWS_DIRECT)
   size_t off = (wide_setl || wide_crdt) ? 0 : (wide ? WIDE_STAGE_ROWS : STAGE_ROWS) * 16;
   const bool is_txn = c.node_program == MSIM_NODE_TXN_SINGLE_KEY, is_px = c.node_program == MSIM_NODE_LIN_KV_PROXY || c.node_program == MSIM_NODE_TSO_IDS;
-  const bool is_hat = c.node_program == MSIM_NODE_TXN_RW_HAT, is_mk = c.node_program == MSIM_NODE_TXN_MULTI_KEY, is_kf = c.node_program == MSIM_NODE_KAFKA;
-  kp.mk_tcap = is_mk ? mk_tcap(c) : 0; kp.mk_ccap = is_mk ? mk_ccap(c) : 0;
+  const bool is_hat = c.node_program == MSIM_NODE_TXN_RW_HAT, is_mk = c.node_program == MSIM_NODE_TXN_MULTI_KEY, is_kf = c.node_program == MSIM_NODE_KAFKA, is_dt = c.node_program == MSIM_NODE_TXN_DATOMIC;
+  kp.mk_tcap = is_mk ? mk_tcap(c) : is_dt ? dt_tcap(c) : 0; kp.mk_ccap = is_mk ? mk_ccap(c) : 0;
   kp.off_inbox = (u32)off;
-  off += is_mk ? ((size_t)(kp.N + 2) * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16 : is_hat ? ((size_t)kp.N * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16 : is_px ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.CS * R_CLIENT_CAP) * 16 : (is_txn || is_kf) ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16
+  off += (is_mk || is_dt) ? ((size_t)(kp.N + 2) * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16 : is_hat ? ((size_t)kp.N * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16 : is_px ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.CS * R_CLIENT_CAP) * 16 : (is_txn || is_kf) ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16
                 : ((size_t)kp.N * kp.cap_node + (size_t)kp.CS * (is_raft ? R_CLIENT_CAP : CLIENT_INBOX_CAP)) * 16 + wide_client_bytes(c);   // (wide: + the pairs' client state)
   kp.off_seen = (u32)off;
   off += is_mk ? ((size_t)kp.N * MK_SL * mk_slot_words(mk_keys_for(c)) + (size_t)kp.N * mk_keys_for(c) * 3 + 36) * 4   // transactions in flight (the first MK_SL per node), a round's messages per node, the generator's key pool
+       : is_dt ? ((size_t)kp.N * DC_WORDS + 36) * 4   // the nodes' transactions (lock holder, waiting queue, save stack), the generator's key pool
        : is_hat ? 36 * 4   // the generator's key pool
        : is_px ? (size_t)kp.N * PX_SLOTS * 8 + 34 * 256 + 64 * 4   // callbacks per node + service states + seq-kv indices
        : is_txn ? (size_t)kp.N * TXN_SLOTS * 16 + 36 * 4   // transactions in flight per node + the generator's key pool
@@ -305,6 +307,7 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
     case MSIM_NODE_LIN_KV_PROXY: case MSIM_NODE_TSO_IDS: e = msim_launch_svc1(kp, n, lds, st); break;   // (lin-tso ids: the proxy's layout with the timestamp oracle on the service lane)
     case MSIM_NODE_TXN_SINGLE_KEY: e = msim_launch_txn1(kp, n, lds, st); break;
     case MSIM_NODE_TXN_MULTI_KEY: e = msim_launch_mk1(kp, n, lds, st); break;
+    case MSIM_NODE_TXN_DATOMIC: e = msim_launch_dt1(kp, n, lds, st); break;
     case MSIM_NODE_KAFKA: e = msim_launch_kafka1(kp, n, lds, st); break;
     case MSIM_NODE_TXN_RW_HAT: e = msim_launch_hat1(kp, n, lds, st); break;
     default: ctx->err = "node program not built into this engine"; return MSIM_E_UNSUPPORTED;

@@ -91,7 +91,7 @@ std::string endpoint(uint32_t e, uint32_t n_nodes, uint32_t slots, const msim_co
   else {
     const char *name = "lin-kv";
     if (cfg->node_program == MSIM_NODE_LIN_KV_PROXY) name = cfg->proxy_service == MSIM_SVC_SEQ_KV ? "seq-kv" : cfg->proxy_service == MSIM_SVC_LWW_KV ? "lww-kv" : "lin-kv";
-    else if (cfg->node_program == MSIM_NODE_TXN_MULTI_KEY && e == n_nodes + slots + 1) name = "lww-kv";
+    else if ((cfg->node_program == MSIM_NODE_TXN_MULTI_KEY || cfg->node_program == MSIM_NODE_TXN_DATOMIC) && e == n_nodes + slots + 1) name = "lww-kv";
     else if (cfg->node_program == MSIM_NODE_TSO_IDS) name = "lin-tso";
     std::snprintf(b, sizeof b, "%s", name);
   }

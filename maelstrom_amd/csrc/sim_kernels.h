@@ -1,5 +1,5 @@
 // sim_kernels.h - the one-cluster-per-wavefront simulation kernels (templates) and what they share, for the translation units that
-// instantiate them (k_general_*.hip, k_wide_*.hip, k_raft.hip, k_svc.hip, k_txn.hip, k_mk.hip, k_kafka.hip, k_hat.hip) and for engine.hip,
+// instantiate them (k_general_*.hip, k_wide_*.hip, k_raft.hip, k_svc.hip, k_txn.hip, k_mk.hip, k_dt.hip, k_kafka.hip, k_hat.hip) and for engine.hip,
 // which needs their LDS / scratch layout constants.  A template nobody instantiates costs a parse: every unit includes all of them (the
 // families share message enums and constants in include order) and compiles only its own.
 #ifndef MSIM_SIM_KERNELS_H
@@ -82,6 +82,7 @@ static inline size_t wide_pending_bytes(const msim_config &c) {
 #include "sim_kernel_wide.inc"
 #include "sim_kernel_txn.inc"
 #include "sim_kernel_mk.inc"
+#include "sim_kernel_dt.inc"
 #include "sim_kernel_hat.inc"
 #include "sim_kernel_kafka.inc"
 #include "sim_kernel_svc.inc"

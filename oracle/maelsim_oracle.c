@@ -726,6 +726,7 @@ static void run_instance(sim_t *s) {
     sched_resolve(s);
     if (s->phase == PH_DONE) break;
     if (++s->rounds > 50000000u) { s->meta.flags |= MSIM_FLAG_ROUND_LIMIT; break; }
+    if (s->dt && (s->meta.flags & MSIM_FLAG_ARENA_OVERRUN)) break; /* an engine capacity was exceeded: what follows would not be the program's behaviour */
 
     /* R0: next event time.  Deliveries, node timers and the scheduler are "normal" events; client
      * timeouts only fire in a round where nothing else is due. */

@@ -89,6 +89,12 @@ def test_cfg5_multi_key_txn_shape(lib):
     _compare_digests(cfg, 0, 64)
 
 
+def test_cfg5_datomic_shape(lib):
+    """cfg5 over the node core.clj:113-114 runs (demo/ruby/datomic_list_append.rb)."""
+    cfg = E.test_config("txn-list-append", bin="datomic", node_count=5, rate=100, time_limit=30, latency=5, nemesis=["partition"], nemesis_interval=10, seed=99)
+    _compare_digests(cfg, 0, 64)
+
+
 @pytest.mark.parametrize("kw", [
     dict(node_count=25, topology="line", latency=10),
     dict(node_count=25, topology="tree4", latency=0),

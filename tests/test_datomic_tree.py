@@ -188,3 +188,29 @@ def test_message_arithmetic_single_node():
     # requests: init + txns from the client; 2 init writes; per txn a root read; loads (+ retries); writes; a cas per appending txn — and as many replies
     assert int(s["clients_send"]) == 2 * (1 + n_txn)
     assert int(s["servers_send"]) == 2 * (2 + n_txn + st["loads"] + st["writes"] - 1 + n_app)
+
+
+@pytest.mark.parametrize("kw", [dict(latency=2), dict(latency=20, latency_dist="exponential", rate=100, node_count=5),
+                                dict(latency=5, nemesis=["partition"], nemesis_interval=2, node_count=5), dict(node_count=3, rate=200, latency=1, key_count=2),
+                                dict(latency=10, p_loss=0.02, node_count=5, time_limit=20)])
+def test_histories_are_strict_serializable_whatever_the_schedule(kw):
+    """A transaction only completes through a root cas against the exact pointer it read (or changes nothing): the list-append analysis finds
+    nothing; a lost cas is REPORTED (error 30 => :fail with :txn-conflict, datomic_list_append.rb:385), never retried; a lost message leaves
+    the node's lock taken (Promise#await's 5 s are not modelled), so its clients time out (:info) from then on."""
+    base = dict(journal_capacity=0)
+    base.update(kw)
+    cfg = _cfg(**base)
+    r = O.run(cfg, 0, 4)
+    for i in range(4):
+        assert r.meta["flags"][i] == 0
+        rows, pay = r.history(i)
+        ops = [o for o in E.decode_history(rows, pay, cfg.n_nodes, A.WL_TXN_LIST_APPEND) if o["process"] != ":nemesis"]
+        done = [o for o in ops if o["type"] != ":invoke"]
+        assert len(done) > 20
+        for o in done:
+            if o["type"] == ":fail":
+                assert o["error"][0] == ":txn-conflict"
+        if not cfg.p_loss_q32:
+            assert not any(o["type"] == ":info" for o in done)
+        res = E.check_txn_history(rows, pay)
+        assert res["valid?"] is True and res["anomalies"] == [], res

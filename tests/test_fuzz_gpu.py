@@ -87,6 +87,9 @@ def _random_kv_case(rng):
     if kind == "mk":
         kw["bin"] = "multi-key-txn"
         kw["node_count"] = rng.choice([1, 2, 3, 5, 6, 7, 12])
+    if kind == "dt":
+        kw["bin"] = "datomic"
+        kw["node_count"] = rng.choice([1, 2, 3, 5, 6, 7, 12])
     return "txn-list-append", kw
 
 
@@ -95,6 +98,23 @@ def test_random_multi_key_txn_options_engine_equals_oracle(lib, case):
     """The same sweep for the canonical txn-list-append node (multi_key_txn: thunks in lww-kv, the root map in lin-kv)."""
     rng = random.Random(0xD47A + case)
     os.environ["MSIM_FUZZ_KIND"] = "mk"
+    try:
+        wl, kw = _random_kv_case(rng)
+    finally:
+        del os.environ["MSIM_FUZZ_KIND"]
+    try:
+        cfg = E.test_config(wl, **kw)
+        E.Engine(cfg).close()
+    except E.EngineError as e:
+        pytest.skip(str(e))
+    _compare(cfg, rng.randrange(1 << 20), N_INST)
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("MSIM_FUZZ_CASES", "24"))))
+def test_random_datomic_txn_options_engine_equals_oracle(lib, case):
+    """The same sweep for the Datomic-style transactor node (datomic_list_append.rb: the hash tree in lww-kv, the root pointer in lin-kv)."""
+    rng = random.Random(0xDA70 + case)
+    os.environ["MSIM_FUZZ_KIND"] = "dt"
     try:
         wl, kw = _random_kv_case(rng)
     finally:

@@ -3,7 +3,7 @@ oracle — bit for bit, on a machine without a GPU.  Test infrastructure on both
 maelstrom_amd/csrc by tools/hipemu/build_emu.py with the host compiler and loaded through MSIM_LIB in a child process; the product
 library (hipcc, gfx950) is not involved and still refuses to run without a device.  One small case per kernel layout the round touched:
 the two-clusters-per-wavefront broadcast kernel (constant and random latency), the wide kernel with the nodes' sets in LDS and its
-lone-operation path, eight clusters per wavefront for both txn-list-append nodes for txn-rw-register, echo / unique-ids, g-set / the counters the broadcast programs and kafka (one cluster per wavefront; its committed-offset lookup), the list-append check's workgroup-per-history kernel, the kafka checker's device pass."""
+lone-operation path, eight clusters per wavefront for two txn-list-append nodes, the Datomic-style one (one cluster per wavefront), for txn-rw-register, echo / unique-ids, g-set / the counters the broadcast programs and kafka (one cluster per wavefront; its committed-offset lookup), the list-append check's workgroup-per-history kernel, the kafka checker's device pass."""
 import os
 import shutil
 import subprocess
@@ -23,6 +23,8 @@ CASES = [
     "{'workload':'broadcast','node_count':36,'rate':20,'time_limit':3,'latency':10,'topology':'tree3','n':1}",
     "{'workload':'txn-list-append','bin':'multi-key-txn','node_count':5,'rate':60,'time_limit':5,'latency':5,'nemesis':['partition'],'nemesis_interval':2,'n':9}",
     "{'workload':'txn-list-append','node_count':5,'rate':60,'time_limit':5,'latency':5,'nemesis':['partition'],'nemesis_interval':2,'n':9}",
+    "{'workload':'txn-list-append','bin':'datomic','node_count':5,'rate':60,'time_limit':5,'latency':5,'nemesis':['partition'],'nemesis_interval':2,'n':3,'journal_capacity':100000}",
+    "{'workload':'txn-list-append','bin':'datomic','node_count':3,'rate':150,'time_limit':6,'latency':0,'key_count':16,'max_writes_per_key':2,'n':2}",   # ~600 keys: splits at every level, chains
     "{'workload':'txn-rw-register','node_count':2,'rate':100,'time_limit':8,'nemesis':['partition'],'nemesis_interval':2,'flags':0x400,'n':11}",
     "{'workload':'txn-rw-register','node_count':4,'rate':200,'time_limit':6,'latency':20,'latency_dist':'exponential','p_loss':0.05,'flags':0x8400,'n':19}",
     "{'workload':'txn-rw-register','node_count':5,'rate':200,'time_limit':8,'latency':5,'nemesis':['partition'],'nemesis_interval':3,'flags':0x400,'n':9}",

@@ -301,6 +301,25 @@ def test_multi_key_txn_packed_layout_parity(lib, kw):
     _compare(cfg, 0, 16)
 
 
+@pytest.mark.parametrize("kw", [
+    dict(node_count=2, rate=20, time_limit=2, latency=2, key_count=3),
+    dict(node_count=3, rate=50, time_limit=4, latency=5),
+    dict(node_count=5, rate=100, time_limit=8, latency=10, latency_dist="exponential", nemesis=["partition"], nemesis_interval=2),
+    dict(node_count=3, rate=200, time_limit=3, latency=3, latency_dist="uniform", key_count=2, max_txn_length=8, max_writes_per_key=32),
+    dict(node_count=7, rate=100, time_limit=4, latency=0),
+    dict(node_count=5, rate=100, time_limit=6, latency=5, p_loss=0.05, journal_capacity=400000),                 # a lost message: the node's lock stays taken, its clients time out, the waiting queue fills
+    dict(node_count=3, rate=150, time_limit=10, latency=0, key_count=16, max_writes_per_key=2),                 # ~1000 keys: splits at every level, chains in the two-wide ranges
+    dict(node_count=1, rate=50, time_limit=5, latency=1),
+    dict(node_count=12, rate=200, time_limit=5, latency=20, latency_dist="exponential"),
+])
+def test_datomic_txn_parity(lib, kw):
+    """The node core.clj:113-114 runs for txn-list-append (demo/ruby/datomic_list_append.rb: a persistent hash tree in lww-kv, the root pointer
+    in lin-kv, lazily loaded paths, a lock per node) — dt_kernel<> (csrc/sim_kernel_dt.inc) against oracle/dt_nodes.inc, which
+    tests/test_datomic_tree.py holds to the Ruby classes written out in Python.  Parity with the reference itself is unpinned (no Ruby)."""
+    cfg = E.test_config("txn-list-append", bin="datomic", seed=91, **kw)
+    _compare(cfg, 0, 11)
+
+
 def test_deep_queues_spill_to_hbm(lib):
     """Exponential latency => long head-of-line sleeps => queues far deeper than the LDS part: the HBM spill area
     behind each node's queue keeps the result bit-identical (and unflagged)."""
