@@ -9,12 +9,12 @@
 //   MSIM_CRDT8_MIN_CLUSTERS       4096   pn-counter 5 nodes: 7.0 against 30.4 ms at 16384; even at 4096           profiles/r03an_crdt8.txt
 //   MSIM_BCAST8_MIN_CLUSTERS     12288   broadcast 5 nodes: 23.7 against 14.8 ms at 4096 (loses), 26.8 / 47.6 at 16384   profiles/r03ar_bcast8.txt
 //   MSIM_HAT8_MIN_CLUSTERS_PER_NODE 3200 txn-rw-register: 2 nodes even near 6400, 3 nodes 8192..16384, 5 nodes near 16384   profiles/r03ae_hat8.txt
-//   MSIM_KAFKA8_MIN_CLUSTERS      4096   kafka 5 nodes: 101.5 against 177.9 ms at 16384 (crossover not swept: the uid8 / crdt8 one assumed)   profiles/r04n_kafka8.txt
+//   MSIM_KAFKA8_MIN_CLUSTERS      8192   kafka 1 / 3 / 5 / 7 nodes: packed 30 / 73 / 88 / 93 ms against 21 / 50 / 61 / 63 at 4096 (loses), 31 / 77 / 92 / 97 against 34 / 80 / 94 / 97 at 8192 (even), 34 / 83 / 99 / 105 against 65 / 151 / 177 / 184 at 16384   profiles/r05_kafka8_threshold_sweep.jsonl
 #ifndef MSIM_LAYOUT_THRESHOLDS_H
 #define MSIM_LAYOUT_THRESHOLDS_H
 #define MSIM_UID8_MIN_CLUSTERS 4096u
 #define MSIM_CRDT8_MIN_CLUSTERS 4096u
 #define MSIM_BCAST8_MIN_CLUSTERS 12288u
 #define MSIM_HAT8_MIN_CLUSTERS_PER_NODE 3200u
-#define MSIM_KAFKA8_MIN_CLUSTERS 4096u
+#define MSIM_KAFKA8_MIN_CLUSTERS 8192u
 #endif

@@ -11,7 +11,9 @@ TAG=$1; UNIT=$2; shift 2
 python -m maelstrom_amd.build > /dev/null
 mkdir -p maelstrom_amd/build/variants
 OBJ=maelstrom_amd/build/variants/${UNIT}_$TAG.o
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -c -o $OBJ maelstrom_amd/csrc/$UNIT
+# the product's own flags for this unit (maelstrom_amd/build.py FLAGS + UNIT_FLAGS), so that a variant differs from the product by "$@" only
+FLAGS=$(python -c "from maelstrom_amd.build import FLAGS, UNIT_FLAGS; print(*FLAGS, *UNIT_FLAGS.get('$UNIT', []))")
+hipcc $FLAGS "$@" -c -o $OBJ maelstrom_amd/csrc/$UNIT
 OBJS=$(ls maelstrom_amd/build/*.o | grep -v "/$UNIT.o")
 hipcc --offload-arch=gfx950 -shared -fPIC -o maelstrom_amd/libmaelsim_$TAG.so $OBJS $OBJ -ldl
 echo built maelstrom_amd/libmaelsim_$TAG.so
