@@ -178,7 +178,9 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
     uint32_t depth = 32 + 2 * deg + (uint32_t)(per_s * lat_s * 6.0);  // x6: fan-in bursts (every neighbour forwards at once)
     // retrying gossip under partitions: at heal time every neighbour re-sends everything it could not deliver
     if (c->node_program == MSIM_NODE_BCAST_ACK_RETRY && c->nemesis_mask) depth += (deg < 4 ? deg : 4) * adds;
-    if (c->node_program == MSIM_NODE_G_SET || c->node_program == MSIM_NODE_PN_COUNTER) depth = 16 + 2 * deg;  // one replicate_full per peer per 5 s tick (g_set.rb:33-38)
+    // one replicate_full per peer per 5 s tick (g_set.rb:33-38): two ticks' worth, + one per 5 s a message can be under way (1 s exponential: 25 of 4096
+    // instances of cfg3's shape overflowed the two-tick queues, profiles/r05_cfg3_latency_sweep.jsonl)
+    if (c->node_program == MSIM_NODE_G_SET || c->node_program == MSIM_NODE_PN_COUNTER) depth = 16 + (2 + (uint32_t)(lat_s / 5.0)) * deg;
     if (c->node_program == MSIM_NODE_RAFT) depth = 24 + 1024;   // heartbeats / re-sent append_entries pile up behind a sleeping recv!
     if (txn || kafka) depth = 16 + 4 * c->n_nodes;              // the service sees <= 2 requests per transaction in flight
     if (c->node_program == MSIM_NODE_TXN_MULTI_KEY) depth = 16 + 16 * c->n_nodes;   // lww-kv: up to max-txn-length thunk reads / writes per transaction

@@ -1,0 +1,897 @@
+// dt8.hip — EIGHT clusters of the Datomic-style txn-list-append node per wavefront (BASELINE configs[4] over
+// demo/ruby/datomic_list_append.rb, the node core.clj:113-114 runs).
+//
+// Same program and the same rounds as dt_kernel<> (sim_kernel_dt.inc; specification: oracle/dt_nodes.inc — parity with the Ruby program
+// unpinned): a persistent hash tree of immutable nodes in lww-kv, the root pointer in lin-kv, a lock per node, lazily loaded paths, path
+// copies, save + cas.  What changes is the mapping, as in mk8.hip / txn8.hip: a cluster is n nodes (each with its client) + lin-kv + lww-kv
+// = n + 2 <= 8 endpoints, one lane each of an 8-lane group, and a wavefront carries eight clusters.  dt_kernel<> runs one cluster per
+// wavefront — 7 live lanes of 64 — and waits for dependent HBM loads (a walk down the tree per micro-op); here one instruction stream
+// serves eight clusters and eight walks are in flight.  What is uniform per CLUSTER lives in VGPRs (equal within a group), a "ballot" is
+// the group's 8 bits of the wave ballot, another lane's value comes by ds_bpermute within the group, the time reduction is three DPP steps.
+//
+// Scope (engine.hip picks this kernel when all of it holds, else dt_kernel<> runs): n_nodes <= 6, one worker per node, net journal off,
+// launches of at least MSIM_DT8_MIN_CLUSTERS clusters (csrc/layout_thresholds.h; MSIM_DEV_FLAGS bit 10 takes it whatever the launch).
+// Measured (profiles/r05_dt8_*): cfg5 x 32768 clusters 760 ms against 1042 ms one per wavefront; 224 registers, two wavefronts per SIMD —
+// tighter register budgets (168 / 128) and fewer LDS queue slots were measured and lose (spills in the handlers).
+//
+// LDS of a wavefront: node / service queues and client inboxes slot-major (slot s of lane e at [s * 64 + e]; RQ / CQ envelopes, the rest
+// spills to HBM), per cluster the nodes' transactions (lock holder + waiting queue: D8_CW words each; the save stack lives in HBM scratch),
+// the generator's key pool and the nemesis shuffle.  History rows go straight to HBM.  The per-instance scratch is dt_kernel<>'s.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+#include "wave_common.h"
+#include "log2_table.h"
+#include "layout_thresholds.h"
+
+namespace {
+
+__constant__ u32 m8_log2_q24[257];
+
+constexpr u32 GS = 8u;            // lanes per cluster
+#ifndef D8_RQ
+#define D8_RQ 8u
+#endif
+constexpr u32 RQ = D8_RQ;         // LDS envelopes per node / service queue
+constexpr u32 CQ = 1u;            // LDS envelopes per client inbox
+constexpr u32 M8_CLIENT_CAP = 32u;
+constexpr u32 V_NIL = 0xFFFFu;
+enum { M_WRITE = 14, M_WRITE_OK, M_CAS, M_CAS_OK, M_ERROR, M_TXN = 23, M_TXN_OK = 24 };
+enum { S_GEN3 = 3 };
+enum { D_LIN = 0, D_LWW = 1 };
+// what dt_kernel<> defines (sim_kernel_dt.inc): capacities, stages, the words of a node's transaction — here without the save stack
+constexpr u32 DT_WAITQ = 8u, DT_MAXDEPTH = 40u, DT_MAXW = 256u, DT_NONE = 0xFFFFFFFFu, DT_RW = 12u;
+enum { DS_IDLE = 0, DS_ROOT, DS_LOAD, DS_SAVE, DS_CAS, DS_INIT_LEAF, DS_INIT_ROOT };
+enum { DC_STAGE = 0, DC_CMSG, DC_REF, DC_RPC, DC_P1, DC_RV, DC_T, DC_TARGET, DC_PSTART, DC_WLO, DC_WN, DC_WOUT, DC_J, DC_NOWN, DC_OWN /* 8 */, DC_WQN = DC_OWN + 8, DC_WQ /* DT_WAITQ x {client msg, txn ref} */,
+       D8_CW = DC_WQ + 2 * DT_WAITQ };
+constexpr u32 D8_STK = 2u * (DT_MAXDEPTH + 1u);   // words of a node's save stack (HBM scratch, behind the clients' spill)
+
+struct M8Params {
+  KParams k;
+  u32 n_inst;
+  u32 off_cq, off_cur, off_gen, off_misc;               // LDS byte offsets (queues at 0)
+  u32 node_spill, client_spill;                          // HBM spill entries per node-or-service queue / client inbox
+  u64 client_spill_off, stack_off;                       // word offsets inside the per-instance scratch: the clients' spill area, the nodes' save stacks
+  u32 round_limit;
+};
+
+// Tree.hash (:60-64): Zlib.crc32(k.to_s) % RING_SIZE
+__device__ __forceinline__ u32 d8_hash(u32 k) {
+  u32 dig[5], n = 0;
+  do { dig[n++] = k % 10u; k /= 10u; } while (k);
+  u32 c = 0xFFFFFFFFu;
+  for (u32 i = n; i-- > 0;) {
+    c ^= 48u + dig[i];
+#pragma unroll
+    for (u32 b = 0; b < 8; b++) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+  }
+  return (~c) & 127u;
+}
+
+__device__ __forceinline__ u32 m8_neg_ln_q16(u32 r) {
+  if (r == 0xFFFFFFFFu) return 0;
+  const u32 v = r + 1;
+  const u32 e = 31 - __clz(v);
+  const u32 m = v << (31 - e);
+  const u32 idx = (m >> 23) & 0xFF;
+  const u32 f = (m >> 7) & 0xFFFF;
+  const u32 l0 = m8_log2_q24[idx], l1 = m8_log2_q24[idx + 1];
+  const u32 lg = (e << 24) + l0 + (u32)(((u64)(l1 - l0) * f) >> 16);
+  const u32 d = (32u << 24) - lg;
+  return (u32)(((u64)d * 2977044472ull) >> 40);
+}
+// min over the 8 lanes of the caller's group, in every lane of it
+__device__ __forceinline__ u32 m8_oct_min(u32 v) {
+  v = min(v, dpp_mov<0xB1, 0xF, 0xF, false>(v, v));   // quad_perm [1,0,3,2]
+  v = min(v, dpp_mov<0x4E, 0xF, 0xF, false>(v, v));   // quad_perm [2,3,0,1]
+  v = min(v, dpp_mov<0x141, 0xF, 0xF, false>(v, v));  // row_half_mirror
+  return v;
+}
+
+#ifdef D8_WAVES_PER_EU   // (developer A/B: a register budget for that many wavefronts per SIMD)
+#define D8_OCC __attribute__((amdgpu_waves_per_eu(D8_WAVES_PER_EU)))
+#else
+#define D8_OCC
+#endif
+template <bool NEM, bool NET_RANDOM>
+__global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const KParams &p = tp.k;
+  const u32 lane = threadIdx.x, l = lane & (GS - 1u), grp = lane >> 3, gbase = lane & 56u;
+  const u32 N = p.N;
+  const bool is_node = l < N, is_lin = l == N;
+  const u32 LIN = 2 * N;   // endpoint index of lin-kv (lane N of the group); lww-kv is LIN + 1 (lane N + 1)
+  const u32 inst_raw = blockIdx.x * 8u + grp;
+  const bool real = inst_raw < tp.n_inst;
+  const u32 inst = real ? inst_raw : tp.n_inst - 1u;
+  const u64 key = mix64(p.cfg.seed + 0x9E3779B97F4A7C15ull * (p.first_instance + inst + 1));
+  const u32 lt = (1u << l) - 1u;
+  const u32 all_nodes = (1u << N) - 1u;
+  const u32 max_rows = p.cfg.max_rows, max_pay = p.cfg.max_payload_words;
+  const u32 p_loss = p.cfg.p_loss_q32, lat_mean = p.cfg.latency_mean_ms, lat_dist = p.cfg.latency_dist;
+  const u32 rate = p.cfg.rate_mhz, mw = p.cfg.max_writes_per_key, mv = p.cfg.max_values;
+  const u32 TC = p.mk_tcap, CWD = TC / 32u;   // tree nodes a node may create; words of one owner's part of a cache bitmap
+  const u32 round_limit = tp.round_limit;
+
+  msim_op *const g_rows = p.rows + (size_t)inst * max_rows;
+  u32 *const g_pay = p.payload + (size_t)inst * max_pay;
+  u32 *const g_scr = p.scratch + (size_t)inst * p.scratch_words;
+  // the per-instance scratch of dt_kernel<> (sim_kernel_dt.inc), same layout
+  u32 *const g_kv = g_scr;                                           // [max_values][mw]: element | version << 8
+  u32 *const g_kvn = g_kv + (size_t)mv * mw;                         // [max_values]
+  u32 *const g_first = g_kvn + mv;                                   // [max_values] version at which the key entered the tree (DT_NONE: never)
+  unsigned char *const g_hash = reinterpret_cast<unsigned char *>(g_first + mv);   // [max_values] Tree.hash of the key
+  u32 *const g_rec = g_first + mv + (mv + 3u) / 4u;                  // [N][TC][DT_RW] tree nodes by pointer
+  u32 *const g_cache = g_rec + (size_t)N * TC * DT_RW;               // [N readers][N owners][TC / 32]
+  u32 *const g_wl = g_cache + (size_t)N * N * CWD;                   // [N][DT_MAXW] the pointers a node writes this round
+  const u32 qlane = l <= N + 1u ? l : 0u;
+  uint4 *const my_spill = reinterpret_cast<uint4 *>(g_scr + p.spill_off) + (size_t)qlane * tp.node_spill;
+  uint4 *const my_cspill = reinterpret_cast<uint4 *>(g_scr + tp.client_spill_off) + (size_t)(is_node ? l : 0u) * tp.client_spill;
+  const u32 my_spill_cap = l <= N + 1u ? tp.node_spill : 0u;
+  const u32 my_node = is_node ? l : 0u;
+  u32 *const my_stk = g_scr + tp.stack_off + (size_t)my_node * D8_STK;
+
+  uint4 *const my_q = reinterpret_cast<uint4 *>(smem) + lane;                                   // node / service queue: slot s at my_q[s * 64]
+  uint4 *const my_cq = reinterpret_cast<uint4 *>(smem + tp.off_cq) + lane;                      // client inbox
+  u32 *const curs_g = reinterpret_cast<u32 *>(smem + tp.off_cur) + grp * (N * D8_CW);           // [node of the group][D8_CW]
+  u32 *const gen = reinterpret_cast<u32 *>(smem + tp.off_gen) + grp * 36;                       // active[16], next_val[16], next_key
+  u32 *const misc = reinterpret_cast<u32 *>(smem + tp.off_misc) + grp * GS;
+  u32 *const cu = curs_g + my_node * D8_CW;
+  u32 *const my_cache = g_cache + (size_t)my_node * N * CWD;
+  u32 *const my_wl = g_wl + (size_t)my_node * DT_MAXW;
+
+  for (u32 i = lane; i < 8 * N * D8_CW; i += 64) reinterpret_cast<u32 *>(smem + tp.off_cur)[i] = 0;
+  for (u32 i = l; i < 16; i += GS) { gen[i] = i; gen[16 + i] = 1; }
+  if (l == 0) gen[32] = p.cfg.key_count;
+  if (real) {
+    for (u32 i = l; i < mv; i += GS) { g_kvn[i] = 0; g_first[i] = DT_NONE; g_hash[i] = (unsigned char)d8_hash(i); }
+    for (u32 i = l; i < N * N * CWD; i += GS) g_cache[i] = 0;
+  }
+  __syncthreads();
+
+  auto GB = [&](bool pred) -> u32 { return (u32)(__ballot(pred) >> gbase) & 0xFFu; };            // the cluster's slice of a ballot
+  auto GGET = [&](u32 v, u32 s) -> u32 { return (u32)__builtin_amdgcn_ds_bpermute((int)((gbase + s) << 2), (int)v); };   // v of lane s of my group
+
+  // ---- node / service state ----
+  u32 deliver_at = INF; uint4 cm = make_uint4(0, 0, 0, 0);
+  bool have_pm = false; uint4 pm = make_uint4(0, 0, 0, 0);
+  u32 in_n = 0, sp_n = 0, node_msgid = 0, part = 0;
+  u32 next_p = 0;                                      // node: @ptr (:332, :352-355)
+  u32 root = 0, root_exists = 0, cur_v = 0;            // lin-kv lane: the root pointer; versions so far
+  u32 svc_ctr = 0;                                     // lww-kv lane: rand-int draws so far
+  // ---- client state ----
+  bool busy = false, mark = false; u32 kind = K_NONE;
+  u32 want = 0, timeout_at = 0, next_msg_id = 0, c_value = 0, process = l, m_value = 0, cin_n = 0, csp_n = 0;
+  u32 s_send_cl = 0, s_send_sv = 0, s_recv_cl = 0, s_recv_sv = 0, my_flags = 0;
+  // ---- per-cluster state (uniform within a group) ----
+  u32 T = 0, phase = PH_INIT, cutoff = 0, gen_next = 0, gen_k = 0, nem_next = 0, nem_j = 0;
+  u32 loss_on = 0, next_id = 0, n_rows = 0, n_payload = 0, flags = 0, rounds = 0;
+  bool alive = real;
+
+  auto q_push = [&](const uint4 m) __attribute__((always_inline)) {
+    if (in_n < RQ) { my_q[in_n * 64u] = m; in_n++; return; }
+    if (sp_n < my_spill_cap) { my_spill[sp_n++] = m; return; }
+    my_flags |= MSIM_FLAG_INBOX_OVERFLOW;
+  };
+  // an envelope for THIS lane's node/service arrives (net.clj:189-221)
+  auto arrive = [&](u32 id, u32 type, u32 a, u32 b, u32 src) __attribute__((always_inline)) {
+    u32 lat = 0;
+    if (src < N || src >= LIN) {  // neither end is a client
+      if (!NET_RANDOM || lat_dist == MSIM_LAT_CONSTANT) lat = lat_mean;
+      else if (lat_dist == MSIM_LAT_UNIFORM) lat = scale32(draw32(key, S_LATENCY, id), 2 * lat_mean);
+      else lat = (u32)(((u64)lat_mean * m8_neg_ln_q16(draw32(key, S_LATENCY, id))) >> 16);
+    }
+    if (NET_RANDOM && loss_on && p_loss && draw32(key, S_LOSS, id) < p_loss) return;
+    uint4 m = make_uint4(T + lat * 1000u, (id << 8) | type, a, b | (src << 24));
+    if (!have_pm) { pm = m; have_pm = true; return; }
+    if (m.x < pm.x || (m.x == pm.x && m.y < pm.y)) { const uint4 t = m; m = pm; pm = t; }
+    q_push(m);
+  };
+  auto try_commit = [&](const uint4 e) __attribute__((always_inline)) {
+    const u32 src = e.w >> 24;
+    if (NEM && src < N && ((part >> src) & 1)) return;  // partitioned (node <-> node only; never happens in this program)
+    cm = e;
+    deliver_at = e.x <= T ? T : T + ((e.x - T) / 1000u) * 1000u;  // (Thread/sleep (long dt)) net.clj:236-238
+  };
+  auto poll = [&]() __attribute__((always_inline)) {
+    if (have_pm) {
+      have_pm = false;
+      if (alive && deliver_at == INF && (in_n | sp_n) == 0) try_commit(pm);
+      else q_push(pm);
+    }
+    while (alive && l <= N + 1u && deliver_at == INF && (in_n | sp_n) != 0) {
+      u32 best = 0; bool in_spill = false;
+      uint2 bk = make_uint2(INF, INF);
+      for (u32 i = 0; i < in_n; i++) {
+        const uint2 kk = *reinterpret_cast<const uint2 *>(&my_q[i * 64u]);
+        if (kk.x < bk.x || (kk.x == bk.x && kk.y < bk.y)) { bk = kk; best = i; }
+      }
+      for (u32 i0 = 0; i0 < sp_n; i0 += 8) {   // eight spilled keys per round trip
+        uint2 k8[8];
+#pragma unroll
+        for (u32 t = 0; t < 8; t++) k8[t] = *reinterpret_cast<const uint2 *>(&my_spill[min(i0 + t, sp_n - 1u)]);
+#pragma unroll
+        for (u32 t = 0; t < 8; t++) {
+          const uint2 kk = k8[t];
+          if (i0 + t < sp_n && (kk.x < bk.x || (kk.x == bk.x && kk.y < bk.y))) { bk = kk; best = i0 + t; in_spill = true; }
+        }
+      }
+      uint4 e;
+      if (in_spill) { e = my_spill[best]; sp_n--; if (best != sp_n) my_spill[best] = my_spill[sp_n]; }
+      else { e = my_q[best * 64u]; in_n--; if (best != in_n) my_q[best * 64u] = my_q[in_n * 64u]; }
+      try_commit(e);
+    }
+  };
+  // elements of `k` visible at version `from`: versions only grow along a key's row, so the answer is a count — the row is read with
+  // independent loads (one round trip) instead of one dependent load per element
+  auto visible = [&](u32 k, u32 from) __attribute__((always_inline)) -> u32 {
+    if (from == V_NIL) return 0u;
+    const u32 cnt = g_kvn[k];
+    u32 n = 0;
+    if (mw <= 16u) {
+      u32 row[16];
+#pragma unroll
+      for (u32 i = 0; i < 16u; i++) row[i] = i < cnt ? g_kv[k * mw + i] : 0xFFFFFFFFu;
+#pragma unroll
+      for (u32 i = 0; i < 16u; i++) n += (i < cnt && (row[i] >> 8) <= from) ? 1u : 0u;
+      return n;
+    }
+    while (n < cnt && (g_kv[k * mw + n] >> 8) <= from) n++;
+    return n;
+  };
+
+#define M8_MARK(i)
+  for (;;) {
+    if (!__ballot(alive)) break;
+    const u32 busy_mask = GB(busy);
+
+    // ---- time-free phase transitions ----
+    if (__ballot(alive && !(phase == PH_MAIN && ((rate > 0 && gen_next < cutoff) || (NEM && nem_next < cutoff))))) {
+      for (;;) {
+        bool ch = false;
+        if (alive) {
+          if (phase == PH_INIT_WAIT && !busy_mask) { phase = PH_MAIN_START; ch = true; }
+          if (phase == PH_MAIN_START) { cutoff = T + p.cfg.time_limit_ms * 1000u; gen_next = T; nem_next = T; next_msg_id = 0; loss_on = 1; phase = PH_MAIN; ch = true; }
+          if (phase == PH_MAIN && !((rate > 0 && gen_next < cutoff) || (NEM && nem_next < cutoff)) && !(rate == 0 && T < cutoff)) { phase = PH_DRAIN; ch = true; }
+          if (phase == PH_DRAIN && !busy_mask) { phase = PH_DONE; ch = true; }   // no final phase (txn_list_append.clj:142)
+        }
+        if (!__ballot(ch)) break;
+      }
+      if (phase == PH_DONE) alive = false;
+      if (!__ballot(alive)) break;
+    }
+    if (alive && ++rounds > round_limit) { flags |= MSIM_FLAG_ROUND_LIMIT; alive = false; }
+    if (GB((my_flags & MSIM_FLAG_ARENA_OVERRUN) != 0)) alive = false;   // an engine capacity was exceeded: what follows would not be the program's behaviour
+
+    // ---- R0: time ----
+    const bool gen_live = rate > 0 && gen_next < cutoff;
+    const bool nem_live = NEM && nem_next < cutoff;
+    const u32 free_mask = all_nodes & ~busy_mask;
+    u32 due = INF;
+    if (phase == PH_INIT) due = T;
+    else if (phase == PH_MAIN) {
+      if (nem_live) due = max(nem_next, T);
+      if (gen_live && free_mask) due = min(due, max(gen_next, T));
+      if (rate == 0 && !nem_live) due = min(due, cutoff);
+    }
+    bool timeout_round = false;
+    {
+      const bool none_due = GB(deliver_at <= T) == 0;
+      const bool jump = alive && due > T && none_due;
+      if (__ballot(jump)) {
+        u32 k = deliver_at == INF ? INF : deliver_at * 2;
+        if (busy) k = min(k, timeout_at * 2 + 1);
+        u32 km = m8_oct_min(k);
+        if (due != INF) km = min(km, due * 2);
+        if (jump) {
+          if (km == INF) { flags |= MSIM_FLAG_ROUND_LIMIT; alive = false; }
+          else { timeout_round = (km & 1) != 0; T = max(T, km >> 1); }
+        }
+      }
+    }
+
+    bool inv_row = false; u32 inv_packed = 0, inv_value = 0, inv_len = 0;
+    bool cmp_row = false; u32 cmp_packed = 0, cmp_value = 0, cmp_len = 0;
+    u32 nem_rows = 0, nem_f = 0, nem_v1 = 0, nem_v2 = 0, nem_len2 = 0;
+
+    auto complete = [&](u32 type, u32 err, u32 ref) __attribute__((always_inline)) {
+      busy = false;
+      if (kind != K_OP) { if (type != MSIM_T_OK) my_flags |= MSIM_FLAG_ROUND_LIMIT; return; }
+      cmp_row = true; cmp_packed = type | (MSIM_F_TXN << 2) | (err << 7) | (process << 12);
+      cmp_value = ref & 0xFFFFFFu; cmp_len = ref >> 24;
+      if (type == MSIM_T_INFO) process += N;  // crashed process; the Reusable client itself lives on
+    };
+    // the client's recv! consumes one envelope (client.clj:94-107)
+    auto client_deliver = [&](u32 qtype, u32 qa, u32 qb) __attribute__((always_inline)) {
+      s_recv_cl++;
+      if (busy && qb == want) {
+        if (qtype == M_TXN_OK) complete(MSIM_T_OK, 0, qa);
+        else if (qtype == M_ERROR)
+          complete(MSIM_T_FAIL, qa == 11 ? MSIM_ERR_TEMPORARILY_UNAVAILABLE : qa == 20 ? MSIM_ERR_KEY_DOES_NOT_EXIST : qa == 30 ? MSIM_ERR_TXN_CONFLICT : MSIM_ERR_PRECONDITION_FAILED, c_value);
+        else complete(MSIM_T_OK, 0, c_value);  // init_ok
+      }
+    };
+
+    if (alive && timeout_round) {
+      if (busy && timeout_at <= T) complete(MSIM_T_INFO, MSIM_ERR_NET_TIMEOUT, c_value);
+    }
+    bool normal = alive && !timeout_round;   // this cluster runs R1-R4 in this wave-round
+    M8_MARK(0)
+    if (__ballot(normal)) {
+      // ---- R1: scheduler ----
+      const bool act = normal && due <= T;
+      if (__ballot(act && phase == PH_INIT)) {
+        if (act && phase == PH_INIT) { if (is_node) { mark = true; kind = K_INIT; } phase = PH_INIT_WAIT; }
+      }
+      if (NEM) {
+        const bool nem_act = act && phase == PH_MAIN && nem_live && nem_next <= T;
+        if (__ballot(nem_act)) {   // flip-flop start/stop (nemesis.clj:10-16 + [upstream] partition package)
+          const u32 j = nem_j;
+          const u32 spec = scale32(draw32(key, S_NEM_SPEC, j), 4);
+          const bool start = nem_act && (j & 1) == 0;
+          if (nem_act) { nem_j++; nem_rows = 2; }
+          if (__ballot(start)) {
+            misc[l] = l;
+            wave_lds_fence();
+            if (start && l == 0 && spec != MSIM_SPEC_ONE) {
+              for (u32 i = N - 1; i >= 1; i--) {
+                const u32 kk = scale32(draw32(key, S_NEM_SHUFFLE, ((u64)j << 16) | i), i + 1);
+                const u32 t = misc[i]; misc[i] = misc[kk]; misc[kk] = t;
+              }
+            }
+            wave_lds_fence();
+            u32 my_part = 0;
+            if (start && is_node) {
+              if (spec == MSIM_SPEC_ONE) {
+                const u32 loner = scale32(draw32(key, S_NEM_PICK, j), N);
+                my_part = l == loner ? (all_nodes & ~(1u << loner)) : (1u << loner);
+              } else if (spec == MSIM_SPEC_MAJORITY || spec == MSIM_SPEC_MINORITY_THIRD) {
+                const u32 cnt = spec == MSIM_SPEC_MAJORITY ? N / 2 : (N - 1) / 3;
+                u32 comp = 0;
+                for (u32 i = 0; i < cnt; i++) comp |= 1u << misc[i];
+                my_part = ((comp >> l) & 1) ? (all_nodes & ~comp) : comp;
+              } else {
+                const u32 m = N / 2 + 1;
+                u32 pos = 0;
+                for (u32 i = 0; i < N; i++) if (misc[i] == l) pos = i;
+                const u32 i0 = (pos + N - (m / 2) % N) % N;
+                u32 vis = 0;
+                for (u32 kk = 0; kk < m; kk++) vis |= 1u << misc[(i0 + kk) % N];
+                my_part = all_nodes & ~vis;
+              }
+            }
+            if (start) {
+              part |= my_part;
+              const u32 words = N * MSIM_MASK_WORDS;
+              u32 off = 0;
+              if (n_payload + words > max_pay) flags |= MSIM_FLAG_PAYLOAD_OVERFLOW;
+              else {
+                off = n_payload; n_payload += words;
+                if (is_node) { g_pay[off + l * 4] = part; g_pay[off + l * 4 + 1] = 0; g_pay[off + l * 4 + 2] = 0; g_pay[off + l * 4 + 3] = 0; }
+              }
+              nem_f = MSIM_F_START_PARTITION; nem_v1 = spec; nem_v2 = off; nem_len2 = words;
+            }
+          }
+          if (nem_act && (j & 1) != 0) {
+            part = 0;
+            nem_f = MSIM_F_STOP_PARTITION; nem_v1 = MSIM_NO_VALUE; nem_v2 = MSIM_NO_VALUE; nem_len2 = 0;
+          }
+          if (nem_act) nem_next = T + __umulhi(draw32(key, S_NEM_STAGGER, j), p.nem_period2_us);
+        }
+      }
+      {
+        const bool gen_on = act && phase == PH_MAIN && gen_live && gen_next <= T && free_mask != 0;
+        if (__ballot(gen_on)) {
+          const u32 nfree = __popc(free_mask);
+          const u32 kk = gen_k;
+          const u64 h = draw64(key, S_GEN, kk);
+          const u32 r_hi = (u32)(h >> 32), r_lo = (u32)h;
+          const u32 pick = scale32(r_lo, nfree);
+          const bool sel = gen_on && is_node && !busy && (u32)__popc(free_mask & lt) == pick;
+          // the transaction ([upstream] elle list-append gen): lane 0 of the cluster writes the micro-ops and owns the key pool
+          const u32 n_mops = 1 + scale32((u32)(draw64(key, S_GEN2, kk) >> 32), p.cfg.max_txn_length);
+          u32 bad = 0;
+          if (gen_on && n_payload + n_mops > max_pay) bad = MSIM_FLAG_PAYLOAD_OVERFLOW;
+          else if (gen_on && l == 0) {
+            const u32 kc = p.cfg.key_count;
+            for (u32 j = 0; j < n_mops; j++) {
+              const u64 h3 = draw64(key, S_GEN3, (u64)kk * 8 + j);
+              const u32 x = scale32((u32)(h3 >> 32), (1u << kc) - 1) + 1;
+              const u32 ki = 31 - (u32)__clz((int)x);
+              const u32 k = gen[ki];
+              if (h3 & 1) {
+                const u32 v = gen[16 + ki];
+                gen[16 + ki] = v + 1;
+                g_pay[n_payload + j] = 1u | (k << 1) | (v << 16);
+                if (v + 1 > mw) {
+                  const u32 nk = gen[32];
+                  if (nk >= p.cfg.max_values) { bad = MSIM_FLAG_VALUES_OVERFLOW; break; }
+                  gen[ki] = nk; gen[32] = nk + 1; gen[16 + ki] = 1;
+                }
+              } else g_pay[n_payload + j] = (k << 1) | (0xFFu << 16);
+            }
+          }
+          bad = GGET(bad, 0);
+          if (gen_on && bad) { flags |= bad; phase = PH_DONE; alive = false; normal = false; }
+          else if (gen_on) {
+            if (sel) { mark = true; kind = K_OP; m_value = n_payload | (n_mops << 24); }
+            n_payload += n_mops;
+            gen_k++;
+            gen_next = T + __umulhi(r_hi, p.gen_period2_us);
+          }
+        }
+      }
+
+      M8_MARK(1)
+      // ---- R2: marked clients invoke; the request goes to this lane's own node ----
+      if (__ballot(mark && normal)) {
+        const bool inv = mark && normal;
+        const u32 inv_mask = GB(inv);
+        if (inv) {
+          mark = false; busy = true;
+          u32 rq_type, rq_a = 0;
+          if (kind == K_INIT) { rq_type = M_INIT; next_msg_id = 0; }
+          else {
+            c_value = m_value;
+            inv_row = true; inv_packed = MSIM_T_INVOKE | (MSIM_F_TXN << 2) | (process << 12); inv_value = c_value & 0xFFFFFFu; inv_len = c_value >> 24;
+            rq_type = M_TXN; rq_a = c_value;
+          }
+          want = ++next_msg_id;
+          timeout_at = T + (kind == K_OP ? p.cfg.client_timeout_ms : 10000u) * 1000u;
+          s_send_cl++;
+          arrive(next_id + __popc(inv_mask & lt), rq_type, rq_a, want, N + l);
+        }
+        next_id += __popc(inv_mask);
+        poll();
+      }
+
+      M8_MARK(2)
+      // ---- R3: one input per node, then one for each service (endpoint order: lin-kv, lww-kv) ----
+      bool rep = false, svc_rep = false;   // node -> own client, service -> node
+      u32 r_type = 0, r_a = 0, r_b = 0;    // the answer to the client
+      u32 n_out = 0, o_dest = 0;           // node -> service: n_out messages, all to the same service; one in registers (o1_*) or the writes of my_wl[]
+      u32 o1_type = 0, o1_a = 0, o1_b = 0, o_wlo = 0;
+      u32 o_type = 0, o_a = 0, o_b = 0, o_to = 0, need_words = 0, done_ref = 0, done_rv = 0;   // service -> node; the completed transaction's payload
+      auto rec_of = [&](u32 ptr) -> u32 * { return g_rec + ((size_t)(ptr >> 20) * TC + (ptr & 0xFFFFFu)) * DT_RW; };
+      auto is_new = [&](u32 ptr) -> bool { return (ptr >> 20) == l && (ptr & 0xFFFFFu) >= cu[DC_PSTART]; };
+      auto cached = [&](u32 ptr) -> bool { const u32 i = ptr & 0xFFFFFu; return (my_cache[(ptr >> 20) * CWD + (i >> 5)] >> (i & 31u)) & 1u; };
+      auto has_key = [&](u32 k) -> bool {   // the key is in the lineage of the working tree
+        if (g_first[k] <= cu[DC_RV]) return true;   // (DT_NONE is above every version)
+        const u32 no = cu[DC_NOWN];
+        for (u32 i = 0; i < no; i++) if (cu[DC_OWN + i] == k) return true;
+        return false;
+      };
+      auto br_index = [&](u32 w0, u32 h) -> u32 {   // branch_index (:231-247) with the split's bounds (:170-181)
+        const u32 lo = (w0 >> 8) & 0xFFu, hi = (w0 >> 16) & 0xFFu, bs = (hi - lo) / 8u;
+        for (u32 i = 0; i < 7u; i++) if (h < lo + (i + 1u) * bs) return i;
+        return 7u;
+      };
+      auto send1 = [&](u32 dest, u32 type, u32 a, u32 b) { o_dest = dest; n_out = 1; o1_type = type; o1_a = a; o1_b = b; };
+      auto start_txn = [&](u32 cmsg, u32 ref) {   // the lock is ours: current_tree (:358-365)
+        cu[DC_STAGE] = DS_ROOT; cu[DC_CMSG] = cmsg; cu[DC_REF] = ref; cu[DC_J] = 0; cu[DC_NOWN] = 0;
+        const u32 rid = ++node_msgid; cu[DC_RPC] = rid;
+        send1(D_LIN, M_READ, 0, rid);
+      };
+      auto unlock = [&]() {   // the next waiting transaction takes the lock (:348, :371)
+        cu[DC_STAGE] = DS_IDLE;
+        const u32 wqn = cu[DC_WQN];
+        if (wqn) {
+          const u32 cmsg = cu[DC_WQ], ref = cu[DC_WQ + 1];
+          for (u32 i = 1; i < wqn; i++) { cu[DC_WQ + 2 * (i - 1)] = cu[DC_WQ + 2 * i]; cu[DC_WQ + 2 * (i - 1) + 1] = cu[DC_WQ + 2 * i + 1]; }
+          cu[DC_WQN] = wqn - 1;
+          start_txn(cmsg, ref);
+        }
+      };
+      auto load = [&](u32 ptr) {   // Tree.load with a cache miss (:83-101)
+        const u32 rid = ++node_msgid;
+        cu[DC_STAGE] = DS_LOAD; cu[DC_TARGET] = ptr; cu[DC_RPC] = rid;
+        send1(D_LWW, M_READ, ptr, rid);
+      };
+      // walks to the key's leaf; the first tree node on the way that has to be fetched, DT_NONE if the path is in memory
+      auto descend = [&](u32 k) -> u32 {
+        const u32 h = g_hash[k];
+        u32 pt = cu[DC_T];
+        for (u32 d = 0; d < DT_MAXDEPTH; d++) {
+          const u32 *const r = rec_of(pt);
+          const u32 w0 = r[0];
+          if ((w0 & 1u) == 0u) return DT_NONE;
+          const u32 ch = r[4u + br_index(w0, h)];
+          if (!is_new(ch) && !cached(ch)) return ch;
+          pt = ch;
+        }
+        my_flags |= MSIM_FLAG_ARENA_OVERRUN;
+        return DT_NONE;
+      };
+      // assoc (:158-197, :256-268) along a path that is in memory.  New pointers go leaf first, then upwards: with n branches above a
+      // leaf level of L new nodes (1, or 8 leaves + their branch) the leaf level takes base+1 .. base+L, the branch at depth i
+      // base+L+(n-i) — known before the walk down that writes the copies.
+      auto assoc = [&](u32 k) {
+        const u32 h = g_hash[k];
+        u32 n = 0, pt = cu[DC_T];
+        for (; n + 1u < DT_MAXDEPTH; n++) { const u32 *const r = rec_of(pt); const u32 w0 = r[0]; if ((w0 & 1u) == 0u) break; pt = r[4u + br_index(w0, h)]; }
+        const u32 *const lf = rec_of(pt);
+        const u32 lw0 = lf[0], lcount = lf[1];
+        if (lw0 & 1u) { my_flags |= MSIM_FLAG_ARENA_OVERRUN; return; }
+        const bool has = has_key(k);
+        const u32 L = (has || lcount < 8u) ? 1u : 9u, base = next_p, ver = cu[DC_RV] + 1u;
+        if (base + L + n >= TC) { my_flags |= MSIM_FLAG_ARENA_OVERRUN; return; }   // engine capacity
+        const u32 lo = (lw0 >> 8) & 0xFFu, hi = (lw0 >> 16) & 0xFFu;
+        auto put = [&](u32 idx, u32 w0, u32 cnt) -> u32 * { u32 *const r = g_rec + ((size_t)l * TC + idx) * DT_RW; r[0] = w0; r[1] = cnt; r[2] = ver; r[3] = 0xFFu; return r; };
+        if (L == 1u) put(base + 1u, lw0, lcount + (has ? 0u : 1u));
+        else {   // eight leaves under a new branch: the lineage's keys of this range (and the new one) by sub-range
+          const u32 bs = (hi - lo) / 8u, nk = gen[32];
+          u64 c_lo = 0, c_hi = 0;   // 4 x 16-bit counters each
+          for (u32 q = 0; q < nk; q++) {
+            if (q != k && !has_key(q)) continue;
+            const u32 hq = g_hash[q];
+            if (hq < lo || hq >= hi) continue;
+            const u32 ci = bs ? min((hq - lo) / bs, 7u) : 7u;
+            if (ci < 4u) c_lo += 1ull << (16u * ci); else c_hi += 1ull << (16u * (ci - 4u));
+          }
+          u32 *const br = put(base + 9u, 1u | (lo << 8) | (hi << 16), 0u);
+          for (u32 i = 0; i < 8u; i++) {
+            const u32 b_lo = lo + i * bs, b_hi = i == 7u ? hi : b_lo + bs;
+            const u32 cnt = (u32)((i < 4u ? c_lo >> (16u * i) : c_hi >> (16u * (i - 4u))) & 0xFFFFu);
+            put(base + 1u + i, (b_lo << 8) | (b_hi << 16), cnt);
+            br[4u + i] = (l << 20) | (base + 1u + i);
+          }
+        }
+        pt = cu[DC_T];
+        for (u32 i = 0; i < n; i++) {   // a copy of every branch above, pointing at the new child
+          const u32 *const r = rec_of(pt);
+          const u32 w0 = r[0], ci = br_index(w0, h);
+          u32 ch[8];
+#pragma unroll
+          for (u32 c = 0; c < 8u; c++) ch[c] = r[4u + c];
+          u32 *const nr = put(base + L + (n - i), w0, 0u);
+          const u32 child_new = (l << 20) | (i + 1u == n ? base + L : base + L + (n - i - 1u));
+#pragma unroll
+          for (u32 c = 0; c < 8u; c++) nr[4u + c] = c == ci ? child_new : ch[c];
+          pt = ch[0];
+#pragma unroll
+          for (u32 c = 1; c < 8u; c++) pt = c == ci ? ch[c] : pt;
+        }
+        next_p = base + L + n;
+        cu[DC_T] = (l << 20) | next_p;
+        if (!has) { const u32 no = cu[DC_NOWN]; if (no < 8u) { cu[DC_OWN + no] = k; cu[DC_NOWN] = no + 1u; } }
+      };
+      // save! (:212-224, :291-320): the new tree nodes the final tree reaches, children before their parent
+      auto save = [&]() {
+        u32 *const stk = my_stk;   // (HBM scratch)
+        u32 sp = 1, wn = 0;
+        const u32 wlo = node_msgid + 1u;
+        stk[0] = cu[DC_T]; stk[1] = 0;
+        while (sp) {
+          const u32 pt = stk[2u * (sp - 1u)];
+          const u32 *const r = rec_of(pt);
+          bool pushed = false;
+          if (r[0] & 1u) {
+            u32 ci = stk[2u * (sp - 1u) + 1u];
+            while (ci < 8u) {
+              const u32 ch = r[4u + ci++];
+              if (is_new(ch)) {
+                if (sp > DT_MAXDEPTH) { my_flags |= MSIM_FLAG_ARENA_OVERRUN; break; }
+                stk[2u * (sp - 1u) + 1u] = ci; stk[2u * sp] = ch; stk[2u * sp + 1u] = 0; sp++; pushed = true; break;
+              }
+            }
+            if (!pushed) stk[2u * (sp - 1u) + 1u] = ci;
+          }
+          if (pushed) continue;
+          if (wn >= DT_MAXW) my_flags |= MSIM_FLAG_ARENA_OVERRUN; else my_wl[wn++] = pt;
+          sp--;
+        }
+        node_msgid += wn;
+        cu[DC_STAGE] = DS_SAVE; cu[DC_WLO] = wlo; cu[DC_WN] = wn; cu[DC_WOUT] = wn;
+        o_dest = D_LWW; n_out = wn; o_wlo = wlo;
+      };
+      auto reply_txn_ok = [&]() {   // the completed transaction: its reads see the version read + its own appends
+        rep = true; r_type = M_TXN_OK; r_b = cu[DC_CMSG];
+        done_ref = cu[DC_REF]; done_rv = cu[DC_RV];
+        const u32 off0 = done_ref & 0xFFFFFFu, n = done_ref >> 24;
+        for (u32 j = 0; j < n; j++) {
+          const u32 w = g_pay[off0 + j], k = (w >> 1) & 0x7FFFu;
+          need_words++;
+          if (!(w & 1u)) {
+            u32 len = visible(k, done_rv);
+            for (u32 e = 0; e < j; e++) { const u32 we = g_pay[off0 + e]; if ((we & 1u) && ((we >> 1) & 0x7FFFu) == k) len++; }
+            need_words += (len + 3u) / 4u;
+          }
+        }
+      };
+      // apply_txn (:391-415) from micro-op j on; stops at the first tree node that has to be fetched
+      auto apply = [&]() {
+        const u32 ref = cu[DC_REF], off0 = ref & 0xFFFFFFu, n = ref >> 24;
+        u32 j = cu[DC_J];
+        while (j < n) {
+          const u32 w = g_pay[off0 + j], k = (w >> 1) & 0x7FFFu;
+          const u32 miss = descend(k);   // t[k] — for an append too (:405)
+          if (miss != DT_NONE) { cu[DC_J] = j; load(miss); return; }
+          if (w & 1u) assoc(k);
+          j++;
+        }
+        cu[DC_J] = j;
+        if (cu[DC_T] == cu[DC_P1]) { reply_txn_ok(); unlock(); return; }   // nothing appended: no write, no cas
+        save();
+      };
+
+      const bool take = normal && l <= N + 1u && deliver_at <= T;
+      if (take) {
+        const uint4 q = cm; deliver_at = INF;
+        const u32 qsrc = q.w >> 24, qb = q.w & 0xFFFFFFu, qtype = q.y & 0xFFu, qa = q.z;
+        if (qsrc >= N && qsrc < LIN) s_recv_cl++; else s_recv_sv++;
+        if (is_node) {
+          const u32 st = cu[DC_STAGE];
+          switch (qtype) {
+            case M_INIT:
+              if (l != 0u) { rep = true; r_type = M_INIT_OK; r_b = qb; break; }
+              {   // the first node writes the initial state (:337-345): Tree.empty, then the root pointer
+                u32 *const r = g_rec;
+                r[0] = (128u << 16); r[1] = 0; r[2] = 0; r[3] = 0xFFu;
+                const u32 rid = ++node_msgid;
+                cu[DC_STAGE] = DS_INIT_LEAF; cu[DC_CMSG] = qb; cu[DC_RPC] = rid;
+                send1(D_LWW, M_WRITE, 0, rid);
+              } break;
+            case M_TXN:
+              if (st == DS_IDLE) start_txn(qb, qa);
+              else { const u32 wqn = cu[DC_WQN];
+                if (wqn == DT_WAITQ) my_flags |= MSIM_FLAG_ARENA_OVERRUN;
+                else { cu[DC_WQ + 2u * wqn] = qb; cu[DC_WQ + 2u * wqn + 1u] = qa; cu[DC_WQN] = wqn + 1u; } }
+              break;
+            case M_READ_OK: case M_WRITE_OK: case M_CAS_OK: case M_ERROR:
+              switch (st) {
+                case DS_INIT_LEAF:
+                  if (qb != cu[DC_RPC]) break;
+                  { const u32 rid = ++node_msgid; cu[DC_STAGE] = DS_INIT_ROOT; cu[DC_RPC] = rid; send1(D_LIN, M_WRITE, 0, rid); }
+                  break;
+                case DS_INIT_ROOT:
+                  if (qb != cu[DC_RPC]) break;
+                  cu[DC_STAGE] = DS_IDLE; rep = true; r_type = M_INIT_OK; r_b = cu[DC_CMSG];
+                  break;
+                case DS_ROOT:
+                  if (qb != cu[DC_RPC]) break;
+                  if (qtype != M_READ_OK) { rep = true; r_type = M_ERROR; r_a = 14; r_b = cu[DC_CMSG]; unlock(); break; }   // "Unsure how to handle" (:364)
+                  cu[DC_P1] = qa; cu[DC_T] = qa; cu[DC_RV] = rec_of(qa)[2]; cu[DC_PSTART] = next_p + 1u;
+                  if (cached(qa)) apply(); else load(qa);
+                  break;
+                case DS_LOAD:
+                  if (qb != cu[DC_RPC]) break;
+                  if (qtype == M_READ_OK) { const u32 t = cu[DC_TARGET], i = t & 0xFFFFFu; my_cache[(t >> 20) * CWD + (i >> 5)] |= 1u << (i & 31u); apply(); }
+                  else load(cu[DC_TARGET]);   // "Retrying read of tree node" (:97)
+                  break;
+                case DS_SAVE:
+                  if (qb < cu[DC_WLO] || qb >= cu[DC_WLO] + cu[DC_WN]) break;
+                  { const u32 left = cu[DC_WOUT] - 1u; cu[DC_WOUT] = left;
+                    if (left == 0u) { const u32 rid = ++node_msgid; cu[DC_STAGE] = DS_CAS; cu[DC_RPC] = rid; send1(D_LIN, M_CAS, cu[DC_T], rid); } }   // advance_root! (:376-388)
+                  break;
+                case DS_CAS:
+                  if (qb != cu[DC_RPC]) break;
+                  if (qtype == M_CAS_OK) reply_txn_ok();
+                  else { rep = true; r_type = M_ERROR; r_a = 30; r_b = cu[DC_CMSG]; }   // txn_conflict (:385)
+                  unlock();
+                  break;
+                default: break;   // "Ignoring reply ... with no callback" (node.rb:160-162)
+              }
+              break;
+            default: break;
+          }
+        } else if (is_lin) {   // lin-kv over the key "root" (service.clj:31-61)
+          svc_rep = true; o_to = qsrc; o_b = qb;
+          if (qtype == M_READ) {
+            if (!root_exists) { o_type = M_ERROR; o_a = 20; } else { o_type = M_READ_OK; o_a = root; }
+          } else if (qtype == M_WRITE) { root = qa; root_exists = 1u; o_type = M_WRITE_OK; o_a = 0; }
+          else {   // cas, no create_if_not_exists: the sender waits for this answer, its transaction is the one it holds
+            const u32 *const sc = curs_g + qsrc * D8_CW;
+            if (!root_exists) { o_type = M_ERROR; o_a = 20; }
+            else if (root != sc[DC_P1]) { o_type = M_ERROR; o_a = 22; }
+            else {
+              const u32 ref = sc[DC_REF], off0 = ref & 0xFFFFFFu, n = ref >> 24, v = ++cur_v;
+              root = qa;
+              for (u32 i = 0; i < n; i++) { const u32 w = g_pay[off0 + i];
+                if (w & 1u) { const u32 k = (w >> 1) & 0x7FFFu, c = g_kvn[k]; if (g_first[k] == DT_NONE) g_first[k] = v;
+                  g_kv[k * mw + c] = ((w >> 16) & 0xFFu) | (v << 8); g_kvn[k] = c + 1u; } }
+              o_type = M_CAS_OK; o_a = 0;
+            }
+          }
+        } else {   // lww-kv (service.clj:214-243 as written): merge-source, merge-dest, then the replica that serves the request
+          svc_rep = true; o_to = qsrc; o_b = qb;
+          svc_ctr += 2u;
+          const u32 r = scale32(draw32(key, 12u /* S_SVC */, svc_ctr++), 2);
+          u32 *const rp = rec_of(qa) + 3;
+          if (qtype == M_WRITE) { *rp = r; o_type = M_WRITE_OK; o_a = qa; }
+          else if (*rp == r) { o_type = M_READ_OK; o_a = qa; }
+          else { o_type = M_ERROR; o_a = 20; }
+        }
+      }
+
+      M8_MARK(3)
+      // completed transactions: payload words allocated in node order, each node writes its own
+      if (__ballot(need_words != 0)) {
+        u32 excl = 0, total = 0;
+        for (u32 s = 0; s < N; s++) { const u32 v = GGET(need_words, s); excl += s < l ? v : 0u; total += v; }
+        if (total) {
+          if (n_payload + total > max_pay) { flags |= MSIM_FLAG_PAYLOAD_OVERFLOW; if (need_words) r_a = 0; }
+          else {
+            if (need_words) {
+              const u32 off0 = done_ref & 0xFFFFFFu, n = done_ref >> 24;
+              u32 pp = n_payload + excl;
+              r_a = pp | (need_words << 24);
+              for (u32 j = 0; j < n; j++) {
+                const u32 w = g_pay[off0 + j], k = (w >> 1) & 0x7FFFu;
+                if (w & 1u) { g_pay[pp++] = w; continue; }
+                const u32 vis = visible(k, done_rv);
+                u32 e = 0, acc = 0;
+                const u32 hdr = pp++;
+                for (u32 i = 0; i < vis; i++) { acc |= (g_kv[k * mw + i] & 0xFFu) << (8 * (e & 3)); if ((++e & 3) == 0) { g_pay[pp++] = acc; acc = 0; } }
+                for (u32 i = 0; i < j; i++) { const u32 wi = g_pay[off0 + i];
+                  if ((wi & 1u) && ((wi >> 1) & 0x7FFFu) == k) { acc |= ((wi >> 16) & 0xFFu) << (8 * (e & 3)); if ((++e & 3) == 0) { g_pay[pp++] = acc; acc = 0; } } }
+                if (e & 3) g_pay[pp++] = acc;
+                g_pay[hdr] = (k << 1) | ((e ? e : 0xFFu) << 16);  // a key without elements reads nil
+              }
+            }
+            n_payload += total;
+          }
+        }
+      }
+
+      M8_MARK(4)
+      // COMMIT: ids in lane order (nodes, lin-kv, lww-kv); a node's messages in the order it emitted them: the answer to its client, then
+      // what the next step sends to a service
+      bool c_arr = false; u32 ca_y = 0, ca_a = 0, ca_b = 0;
+      {
+        const u32 rcnt = rep ? 1u : 0u;
+        const u32 cnt = is_node ? rcnt + n_out : (svc_rep ? 1u : 0u);
+        if (__ballot(cnt != 0)) {
+          u32 my_off = 0, total = 0;
+          for (u32 s = 0; s < N + 2u; s++) { const u32 v = GGET(cnt, s); my_off += s < l ? v : 0u; total += v; }
+          if (is_node) { s_send_cl += rcnt; s_send_sv += n_out; } else s_send_sv += cnt;
+          // node -> service: the service lane takes each node's run in node order
+          u32 ts = GB(is_node && n_out != 0);
+          while (__ballot(ts != 0)) {
+            const bool on = ts != 0;
+            const u32 s = on ? (u32)__builtin_ctz(ts) : 0u; ts &= ts - 1u;
+            const u32 dst = GGET(o_dest, s), kn = GGET(n_out, s), off = GGET(my_off, s) + GGET(rcnt, s);
+            const u32 t1 = GGET(o1_type, s), a1 = GGET(o1_a, s), b1 = GGET(o1_b, s), wlo = GGET(o_wlo, s);
+            if (on && l == N + dst) {
+              if (wlo == 0u) arrive(next_id + off, t1, a1, b1, s);
+              else { const u32 *const wl = g_wl + (size_t)s * DT_MAXW;
+                for (u32 k = 0; k < kn; k++) arrive(next_id + off + k, M_WRITE, wl[k], wlo + k, s); }
+            }
+          }
+          // service -> node (lin-kv, then lww-kv)
+          {
+            const u32 sv = GB(svc_rep);
+#pragma unroll
+            for (u32 q2 = 0; q2 < 2u; q2++) {
+              const u32 s = N + q2;
+              const u32 ty = GGET(o_type, s), a = GGET(o_a, s), b = GGET(o_b, s), d = GGET(o_to, s), off = GGET(my_off, s);
+              if (((sv >> s) & 1u) && l == d) arrive(next_id + off, ty, a, b, N + s);
+            }
+          }
+          // node -> its own client: no latency; lost like any other message (net.clj:214)
+          if (rep) {
+            const u32 id = next_id + my_off;
+            if (!(NET_RANDOM && loss_on && p_loss && draw32(key, S_LOSS, id) < p_loss)) { c_arr = true; ca_y = (id << 8) | r_type; ca_a = r_a; ca_b = r_b; }
+          }
+          next_id += total;
+        }
+        poll();
+      }
+
+      M8_MARK(5)
+      // ---- R4: the clients' recv! loops (client.clj:94-107) ----
+      if (__ballot(c_arr || (busy && (cin_n | csp_n) != 0))) {
+        for (;;) {
+          const bool stale = normal && busy && (cin_n | csp_n) != 0;
+          const bool fresh = normal && !stale && busy && c_arr;
+          if (!__ballot(stale || fresh)) break;
+          if (stale) {
+            u32 best = 0; bool in_spill = false;
+            uint2 bk = make_uint2(INF, INF);
+            for (u32 i = 0; i < cin_n; i++) {
+              const uint2 kk = *reinterpret_cast<const uint2 *>(&my_cq[i * 64u]);
+              if (kk.x < bk.x || (kk.x == bk.x && kk.y < bk.y)) { bk = kk; best = i; }
+            }
+            for (u32 i = 0; i < csp_n; i++) {
+              const uint2 kk = *reinterpret_cast<const uint2 *>(&my_cspill[i]);
+              if (kk.x < bk.x || (kk.x == bk.x && kk.y < bk.y)) { bk = kk; best = i; in_spill = true; }
+            }
+            uint4 e;
+            if (in_spill) { e = my_cspill[best]; csp_n--; if (best != csp_n) my_cspill[best] = my_cspill[csp_n]; }
+            else { e = my_cq[best * 64u]; cin_n--; if (best != cin_n) my_cq[best * 64u] = my_cq[cin_n * 64u]; }
+            client_deliver(e.y & 0xFFu, e.z, e.w & 0xFFFFFFu);
+          } else if (fresh) {
+            c_arr = false;
+            client_deliver(ca_y & 0xFFu, ca_a, ca_b);
+          }
+        }
+        if (c_arr && normal) {  // nobody is in recv!: the envelope waits for the next RPC (and is skipped there as stale)
+          const uint4 e = make_uint4(T, ca_y, ca_a, ca_b | (l << 24));
+          if (cin_n < CQ) { my_cq[cin_n * 64u] = e; cin_n++; }
+          else if (csp_n < tp.client_spill) my_cspill[csp_n++] = e;
+          else my_flags |= MSIM_FLAG_INBOX_OVERFLOW;
+        }
+      }
+    }
+
+    M8_MARK(6)
+    // ---- history rows: nemesis rows, invocations (lane order), completions (lane order) ----
+    {
+      const u32 imask = GB(inv_row), cmask = GB(cmp_row);
+      const u32 ni = __popc(imask);
+      const u32 nr = nem_rows + ni + __popc(cmask);
+      if (__ballot(alive && nr != 0)) {
+        const bool ovf = alive && nr != 0 && n_rows + nr > max_rows;
+        if (ovf) { flags |= MSIM_FLAG_ROWS_OVERFLOW; alive = false; }
+        const bool wr = alive && nr != 0;
+        const u64 tns = (u64)T * 1000ull;
+        const u32 tlo = (u32)tns, thi = (u32)(tns >> 32);
+        uint4 *const out = reinterpret_cast<uint4 *>(g_rows) + n_rows;   // (no staging: a few 16-byte rows per round; the L2 merges them into lines)
+        if (NEM && wr && nem_rows && l == 0) {
+          const u32 pk = MSIM_T_INFO | (nem_f << 2) | (MSIM_PROCESS_NEMESIS << 12);
+          out[0] = make_uint4(tlo, thi, pk, nem_v1);
+          out[1] = make_uint4(tlo, thi | (nem_len2 << 16), pk, nem_v2);
+        }
+        if (wr && inv_row) out[nem_rows + __popc(imask & lt)] = make_uint4(tlo, thi | (inv_len << 16), inv_packed, inv_value);
+        if (wr && cmp_row) out[nem_rows + ni + __popc(cmask & lt)] = make_uint4(tlo, thi | (cmp_len << 16), cmp_packed, cmp_value);
+        const u32 new_n = wr ? n_rows + nr : n_rows;
+        n_rows = new_n;
+      }
+    }
+    M8_MARK(7)
+  }
+
+  // ---- epilogue ----
+  u32 t_send_cl = 0, t_send_sv = 0, t_recv_cl = 0, t_recv_sv = 0;
+  for (u32 s = 0; s < GS; s++) { t_send_cl += GGET(s_send_cl, s); t_send_sv += GGET(s_send_sv, s); t_recv_cl += GGET(s_recv_cl, s); t_recv_sv += GGET(s_recv_sv, s); }
+  for (u32 b = 1; b <= MSIM_FLAG_ARENA_OVERRUN; b <<= 1) if (GB((my_flags & b) != 0)) flags |= b;
+  if (real && l == 0) {
+    msim_net_stats st;
+    st.all_send = (u64)t_send_cl + t_send_sv; st.all_recv = (u64)t_recv_cl + t_recv_sv;
+    st.clients_send = t_send_cl; st.clients_recv = t_recv_cl;
+    st.servers_send = t_send_sv; st.servers_recv = t_recv_sv;
+    p.stats[inst] = st;
+    msim_inst_meta m; m.n_rows = n_rows; m.n_payload_words = n_payload; m.flags = flags; m.n_rounds = rounds;
+    m.n_events = 0; m.reserved[0] = 0; m.reserved[1] = 0; m.reserved[2] = 0;
+    p.meta[inst] = m;
+  }
+}
+
+}  // namespace
+
+// Whether eight clusters per wavefront simulate this configuration (see the header of this file).
+bool msim_dt8_eligible(const msim_config &c) {
+  return c.node_program == MSIM_NODE_TXN_DATOMIC && c.journal_capacity == 0 && c.n_nodes >= 1 && c.n_nodes <= GS - 2u && c.concurrency == c.n_nodes;
+}
+
+// Extra per-instance scratch words behind the queues' spill area: what of the LDS queues of dt_kernel<> does not fit this kernel's RQ slots,
+// the clients' spill, the nodes' save stacks.
+uint64_t msim_dt8_extra_scratch_words(const msim_config &c) {
+  return ((uint64_t)(c.n_nodes + 2) * c.inbox_capacity + (uint64_t)c.n_nodes * M8_CLIENT_CAP) * 4 + (((uint64_t)c.n_nodes * D8_STK + 3) & ~3ull);   // (an instance's scratch stays a multiple of 16 bytes: the queues are read as uint4)
+}
+
+hipError_t msim_launch_dt8(const KParams &kp, uint32_t n, hipStream_t st) {
+  const msim_config &c = kp.cfg;
+  if (n < MSIM_DT8_MIN_CLUSTERS && !(kp.dev_flags & 0x400u)) return MSIM_LAYOUT_DOES_NOT_FIT;   // the kernel is latency-bound: below the measured crossover one cluster per wavefront is faster
+  M8Params tp;
+  tp.k = kp; tp.n_inst = n;
+  const uint32_t cap_tot = c.inbox_capacity + c.spill_capacity;
+  tp.node_spill = cap_tot > RQ ? cap_tot - RQ : 0;
+  tp.client_spill = M8_CLIENT_CAP - CQ;
+  tp.client_spill_off = kp.spill_off + (uint64_t)(kp.N + 2) * tp.node_spill * 4;
+  tp.stack_off = tp.client_spill_off + (uint64_t)kp.N * tp.client_spill * 4;
+  size_t off = (size_t)RQ * 64 * 16;
+  tp.off_cq = (u32)off; off += (size_t)CQ * 64 * 16;
+  tp.off_cur = (u32)off; off += (size_t)8 * kp.N * D8_CW * 4;
+  tp.off_gen = (u32)off; off += (size_t)8 * 36 * 4;
+  off = (off + 15) & ~(size_t)15;
+  tp.off_misc = (u32)off; off += 64 * 4;
+  tp.round_limit = (kp.dev_flags & 0x100u) ? 4000000u : ROUND_LIMIT;
+  const size_t lds = off;
+  const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
+  if (rnd) MSIM_UPLOAD_ONCE(m8_log2_q24, msim_log2_q24, sizeof(msim_log2_q24));   // (1 KiB, once per device)
+  const dim3 grid((n + 7) / 8), block(64);
+  if (kp.dev_flags & 0x1000u) std::fprintf(stderr, "[dt8] %u clusters, eight per wavefront, %zu B of LDS per wavefront\n", n, lds);   // developer trace bit
+  if (c.nemesis_mask) { if (rnd) hipLaunchKernelGGL((dt8_kernel<true, true>), grid, block, lds, st, tp); else hipLaunchKernelGGL((dt8_kernel<true, false>), grid, block, lds, st, tp); }
+  else { if (rnd) hipLaunchKernelGGL((dt8_kernel<false, true>), grid, block, lds, st, tp); else hipLaunchKernelGGL((dt8_kernel<false, false>), grid, block, lds, st, tp); }
+  return hipGetLastError();
+}

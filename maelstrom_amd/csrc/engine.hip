@@ -187,6 +187,7 @@ static uint64_t scratch_words(const msim_config &c) {
   if (msim_raft4_eligible(c)) w += msim_raft4_extra_scratch_words(c);   // raft4.hip keeps fewer envelopes in LDS
   if (msim_txn8_eligible(c)) w += msim_txn8_extra_scratch_words(c);     // txn8.hip likewise
   if (msim_mk8_eligible(c)) w += msim_mk8_extra_scratch_words(c);       // mk8.hip likewise
+  if (msim_dt8_eligible(c)) w += msim_dt8_extra_scratch_words(c);       // dt8.hip likewise (+ the nodes' save stacks)
   if (msim_hat8_eligible(c)) w += msim_hat8_extra_scratch_words(c);     // hat8.hip likewise
   if (msim_kafka8_eligible(c)) w += msim_kafka8_extra_scratch_words(c); // kafka8.hip likewise
   if (msim_uid8_eligible(c)) w += msim_uid8_extra_scratch_words(c);     // uid8.hip likewise
@@ -288,6 +289,8 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   if (msim_txn8_eligible(c) && !(kp.dev_flags & 0x200u)) e = msim_launch_txn8(kp, n, st);
   // the canonical txn-list-append node: eight clusters per wavefront (mk8.hip) when a cluster fits an 8-lane group
   if (msim_mk8_eligible(c) && !(kp.dev_flags & 0x200u)) e = msim_launch_mk8(kp, n, st);
+  // the Datomic-style txn-list-append node: eight clusters per wavefront (dt8.hip) when a cluster fits an 8-lane group
+  if (msim_dt8_eligible(c) && !(kp.dev_flags & 0x200u)) e = msim_launch_dt8(kp, n, st);
   // txn-rw-register over the highly-available-transactions node: eight clusters per wavefront (hat8.hip)
   if (msim_hat8_eligible(c) && !(kp.dev_flags & 0x200u)) e = msim_launch_hat8(kp, n, st);
   // kafka: eight clusters per wavefront (kafka8.hip) for large batches

@@ -212,5 +212,9 @@ hipError_t msim_launch_bcast8(const KParams &kp, uint32_t n, hipStream_t st);
 bool msim_mk8_eligible(const msim_config &c);
 uint64_t msim_mk8_extra_scratch_words(const msim_config &c);
 hipError_t msim_launch_mk8(const KParams &kp, uint32_t n, hipStream_t st);
+// dt8.hip: the Datomic-style txn-list-append node, eight clusters per wavefront
+bool msim_dt8_eligible(const msim_config &c);
+uint64_t msim_dt8_extra_scratch_words(const msim_config &c);
+hipError_t msim_launch_dt8(const KParams &kp, uint32_t n, hipStream_t st);
 
 #endif

@@ -93,6 +93,7 @@ def test_cfg5_datomic_shape(lib):
     """cfg5 over the node core.clj:113-114 runs (demo/ruby/datomic_list_append.rb)."""
     cfg = E.test_config("txn-list-append", bin="datomic", node_count=5, rate=100, time_limit=30, latency=5, nemesis=["partition"], nemesis_interval=10, seed=99)
     _compare_digests(cfg, 0, 64)
+    _compare_digests(cfg, 0, 64, batch=12288)   # the batch size from which eight clusters per wavefront are taken (csrc/dt8.hip)
 
 
 @pytest.mark.parametrize("kw", [

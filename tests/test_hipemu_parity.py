@@ -23,8 +23,11 @@ CASES = [
     "{'workload':'broadcast','node_count':36,'rate':20,'time_limit':3,'latency':10,'topology':'tree3','n':1}",
     "{'workload':'txn-list-append','bin':'multi-key-txn','node_count':5,'rate':60,'time_limit':5,'latency':5,'nemesis':['partition'],'nemesis_interval':2,'n':9}",
     "{'workload':'txn-list-append','node_count':5,'rate':60,'time_limit':5,'latency':5,'nemesis':['partition'],'nemesis_interval':2,'n':9}",
-    "{'workload':'txn-list-append','bin':'datomic','node_count':5,'rate':60,'time_limit':5,'latency':5,'nemesis':['partition'],'nemesis_interval':2,'n':3,'journal_capacity':100000}",
-    "{'workload':'txn-list-append','bin':'datomic','node_count':3,'rate':150,'time_limit':6,'latency':0,'key_count':16,'max_writes_per_key':2,'n':2}",   # ~600 keys: splits at every level, chains
+    "{'workload':'txn-list-append','bin':'datomic','node_count':5,'rate':60,'time_limit':5,'latency':5,'nemesis':['partition'],'nemesis_interval':2,'n':3,'journal_capacity':100000}",   # (journal on: one cluster per wavefront)
+    "{'workload':'txn-list-append','bin':'datomic','node_count':3,'rate':150,'time_limit':6,'latency':0,'key_count':16,'max_writes_per_key':2,'n':2}",   # ~600 keys: splits at every level, chains; one cluster per wavefront
+    "{'workload':'txn-list-append','bin':'datomic','node_count':3,'rate':150,'time_limit':6,'latency':0,'key_count':16,'max_writes_per_key':2,'n':3,'flags':0x400}",   # the same, eight per wavefront (dt8.hip)
+    "{'workload':'txn-list-append','bin':'datomic','node_count':5,'rate':60,'time_limit':5,'latency':5,'nemesis':['partition'],'nemesis_interval':2,'n':11,'flags':0x400}",
+    "{'workload':'txn-list-append','bin':'datomic','node_count':6,'rate':120,'time_limit':4,'latency':10,'latency_dist':'uniform','p_loss':0.02,'n':9,'flags':0x400}",
     "{'workload':'txn-rw-register','node_count':2,'rate':100,'time_limit':8,'nemesis':['partition'],'nemesis_interval':2,'flags':0x400,'n':11}",
     "{'workload':'txn-rw-register','node_count':4,'rate':200,'time_limit':6,'latency':20,'latency_dist':'exponential','p_loss':0.05,'flags':0x8400,'n':19}",
     "{'workload':'txn-rw-register','node_count':5,'rate':200,'time_limit':8,'latency':5,'nemesis':['partition'],'nemesis_interval':3,'flags':0x400,'n':9}",

@@ -38,6 +38,8 @@ CASES = [
     ("txn-list-append + partitions", dict(workload="txn-list-append", node_count=5, rate=100, time_limit=10, latency=5, nemesis=["partition"], nemesis_interval=4), [40, 4096]),
     ("txn-list-append multi-key + partitions", dict(workload="txn-list-append", bin="multi-key-txn", node_count=5, rate=100, time_limit=10, latency=5, nemesis=["partition"], nemesis_interval=4), [40, 4096]),
     ("txn-list-append datomic + partitions", dict(workload="txn-list-append", bin="datomic", node_count=5, rate=100, time_limit=10, latency=5, nemesis=["partition"], nemesis_interval=4), [40, 4096]),
+    ("txn-list-append datomic + partitions, eight per wavefront", dict(workload="txn-list-append", bin="datomic", node_count=5, rate=100, time_limit=10, latency=5, nemesis=["partition"], nemesis_interval=4, _flags=0x400), [40, 1024]),
+    ("txn-list-append datomic n=7 (one cluster per wavefront)", dict(workload="txn-list-append", bin="datomic", node_count=7, rate=100, time_limit=8, latency=5), [40, 1024]),
     ("kafka + partitions", dict(workload="kafka", node_count=5, rate=100, time_limit=8, latency=5, nemesis=["partition"], nemesis_interval=3), [40, 16384]),
     ("txn-rw-register n=2 + partitions", dict(workload="txn-rw-register", node_count=2, rate=100, time_limit=10, nemesis=["partition"], nemesis_interval=4), [40, 16384]),
     ("txn-rw-register n=5 + partitions", dict(workload="txn-rw-register", node_count=5, rate=100, time_limit=10, latency=5, nemesis=["partition"], nemesis_interval=4), [40, 4096]),
@@ -47,9 +49,12 @@ CASES = [
 def child(kw, n):
     from maelstrom_amd import engine as E
     import numpy as np
+    flags = kw.pop("_flags", 0)   # developer switches of the context (e.g. 0x400: the packed layout whatever the batch)
     cfg = E.test_config(seed=777, **kw)
     h = hashlib.sha256()
     with E.Engine(cfg) as eng:
+        if flags:
+            eng.set_dev_flags(flags)
         for first in (0, n + 5):   # a second launch over the first one's leftovers, too
             eng.run(first, n)
             eng.check()
