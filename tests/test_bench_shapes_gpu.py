@@ -96,6 +96,15 @@ def test_cfg5_datomic_shape(lib):
     _compare_digests(cfg, 0, 64, batch=12288)   # the batch size from which eight clusters per wavefront are taken (csrc/dt8.hip)
 
 
+def test_the_reference_demo_invocation_for_txn_list_append(lib):
+    """core.clj:113-114: `{:workload :txn-list-append :bin "demo/ruby/datomic_list_append.rb"}` with the defaults of core.clj:136-229 — five nodes,
+    one worker per node, rate 5, 60 s, latency 0."""
+    cfg = E.test_config("txn-list-append", bin="datomic", seed=99)
+    assert (cfg.n_nodes, cfg.concurrency, cfg.rate_mhz, cfg.time_limit_ms, cfg.latency_mean_ms) == (5, 5, 5000, 60000, 0)
+    ora = _compare_digests(cfg, 0, 32)
+    assert (ora.meta["n_rows"] > 400).all()
+
+
 @pytest.mark.parametrize("kw", [
     dict(node_count=25, topology="line", latency=10),
     dict(node_count=25, topology="tree4", latency=0),
