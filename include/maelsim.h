@@ -177,7 +177,8 @@ enum { MSIM_F_ECHO = 0, MSIM_F_BROADCAST = 1, MSIM_F_READ = 2, MSIM_F_ADD = 3,
 enum { MSIM_ERR_NONE = 0, MSIM_ERR_NET_TIMEOUT = 1 /* client.clj:158-162 */, MSIM_ERR_RPC = 2,
        /* RPC errors of resources/errors.edn, as :error [name text] (client.clj:163-172) */
        MSIM_ERR_TEMPORARILY_UNAVAILABLE = 3 /* code 11 */, MSIM_ERR_KEY_DOES_NOT_EXIST = 4 /* code 20 */,
-       MSIM_ERR_PRECONDITION_FAILED = 5 /* code 22 */, MSIM_ERR_TXN_CONFLICT = 6 /* code 30 */ };
+       MSIM_ERR_PRECONDITION_FAILED = 5 /* code 22 */, MSIM_ERR_TXN_CONFLICT = 6 /* code 30 */,
+       MSIM_ERR_TIMEOUT = 7 /* code 0: the NODE reports a timeout; not :definite? => :info */, MSIM_ERR_ABORT = 8 /* code 14 */ };
 enum { MSIM_SPEC_ONE = 0, MSIM_SPEC_MAJORITY = 1, MSIM_SPEC_MAJORITIES_RING = 2, MSIM_SPEC_MINORITY_THIRD = 3 };
 #define MSIM_PROCESS_NEMESIS 0xFFFFFu
 #define MSIM_NO_VALUE 0xFFFFFFFFu   /* :value nil */

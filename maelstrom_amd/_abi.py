@@ -23,7 +23,7 @@ TOPO_GRID, TOPO_LINE, TOPO_TOTAL, TOPO_TREE2, TOPO_TREE3, TOPO_TREE4 = range(6)
 NEMESIS_PARTITION = 1
 T_INVOKE, T_OK, T_FAIL, T_INFO = range(4)
 F_ECHO, F_BROADCAST, F_READ, F_ADD, F_START_PARTITION, F_STOP_PARTITION, F_WRITE, F_CAS, F_TXN, F_GENERATE, F_SEND, F_POLL, F_ASSIGN, F_CRASH = range(14)
-ERR_NONE, ERR_NET_TIMEOUT, ERR_RPC, ERR_TEMPORARILY_UNAVAILABLE, ERR_KEY_DOES_NOT_EXIST, ERR_PRECONDITION_FAILED, ERR_TXN_CONFLICT = range(7)
+ERR_NONE, ERR_NET_TIMEOUT, ERR_RPC, ERR_TEMPORARILY_UNAVAILABLE, ERR_KEY_DOES_NOT_EXIST, ERR_PRECONDITION_FAILED, ERR_TXN_CONFLICT, ERR_TIMEOUT, ERR_ABORT = range(9)
 SPEC_ONE, SPEC_MAJORITY, SPEC_MAJORITIES_RING, SPEC_MINORITY_THIRD = range(4)
 PROCESS_NEMESIS = 0xFFFFF
 NO_VALUE = 0xFFFFFFFF

@@ -40,7 +40,7 @@ enum { M_WRITE = 14, M_WRITE_OK, M_CAS, M_CAS_OK, M_ERROR, M_TXN = 23, M_TXN_OK 
 enum { S_GEN3 = 3 };
 enum { D_LIN = 0, D_LWW = 1 };
 // what dt_kernel<> defines (sim_kernel_dt.inc): capacities, stages, the words of a node's transaction — here without the save stack
-constexpr u32 DT_WAITQ = 8u, DT_MAXDEPTH = 40u, DT_MAXW = 256u, DT_NONE = 0xFFFFFFFFu, DT_RW = 12u;
+constexpr u32 DT_WAITQ = 8u, DT_MAXDEPTH = 40u, DT_MAXW = 256u, DT_NONE = 0xFFFFFFFFu, DT_RW = 12u, DT_AWAIT_US = 5000000u;
 enum { DS_IDLE = 0, DS_ROOT, DS_LOAD, DS_SAVE, DS_CAS, DS_INIT_LEAF, DS_INIT_ROOT };
 enum { DC_STAGE = 0, DC_CMSG, DC_REF, DC_RPC, DC_P1, DC_RV, DC_T, DC_TARGET, DC_PSTART, DC_WLO, DC_WN, DC_WOUT, DC_J, DC_NOWN, DC_OWN /* 8 */, DC_WQN = DC_OWN + 8, DC_WQ /* DT_WAITQ x {client msg, txn ref} */,
        D8_CW = DC_WQ + 2 * DT_WAITQ };
@@ -157,6 +157,7 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
   bool have_pm = false; uint4 pm = make_uint4(0, 0, 0, 0);
   u32 in_n = 0, sp_n = 0, node_msgid = 0, part = 0;
   u32 next_p = 0;                                      // node: @ptr (:332, :352-355)
+  u32 wait_until = INF;                                // node: when the lock holder's Promise#await gives up (promise.rb:5,17-30), INF: not waiting
   u32 root = 0, root_exists = 0, cur_v = 0;            // lin-kv lane: the root pointer; versions so far
   u32 svc_ctr = 0;                                     // lww-kv lane: rand-int draws so far
   // ---- client state ----
@@ -276,10 +277,11 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
     }
     bool timeout_round = false;
     {
-      const bool none_due = GB(deliver_at <= T) == 0;
+      const bool none_due = GB(deliver_at <= T || wait_until <= T) == 0;
       const bool jump = alive && due > T && none_due;
       if (__ballot(jump)) {
         u32 k = deliver_at == INF ? INF : deliver_at * 2;
+        if (wait_until != INF) k = min(k, wait_until * 2);   // (a node's timer is a normal event)
         if (busy) k = min(k, timeout_at * 2 + 1);
         u32 km = m8_oct_min(k);
         if (due != INF) km = min(km, due * 2);
@@ -307,7 +309,8 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
       if (busy && qb == want) {
         if (qtype == M_TXN_OK) complete(MSIM_T_OK, 0, qa);
         else if (qtype == M_ERROR)
-          complete(MSIM_T_FAIL, qa == 11 ? MSIM_ERR_TEMPORARILY_UNAVAILABLE : qa == 20 ? MSIM_ERR_KEY_DOES_NOT_EXIST : qa == 30 ? MSIM_ERR_TXN_CONFLICT : MSIM_ERR_PRECONDITION_FAILED, c_value);
+          if (qa == 0u) complete(MSIM_T_INFO, MSIM_ERR_TIMEOUT, c_value);   // code 0 :timeout is not :definite? (errors.edn:2-4)
+          else complete(MSIM_T_FAIL, qa == 11 ? MSIM_ERR_TEMPORARILY_UNAVAILABLE : qa == 20 ? MSIM_ERR_KEY_DOES_NOT_EXIST : qa == 30 ? MSIM_ERR_TXN_CONFLICT : qa == 14 ? MSIM_ERR_ABORT : MSIM_ERR_PRECONDITION_FAILED, c_value);
         else complete(MSIM_T_OK, 0, c_value);  // init_ok
       }
     };
@@ -471,9 +474,11 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
         cu[DC_STAGE] = DS_ROOT; cu[DC_CMSG] = cmsg; cu[DC_REF] = ref; cu[DC_J] = 0; cu[DC_NOWN] = 0;
         const u32 rid = ++node_msgid; cu[DC_RPC] = rid;
         send1(D_LIN, M_READ, 0, rid);
+        wait_until = T + DT_AWAIT_US;
       };
       auto unlock = [&]() {   // the next waiting transaction takes the lock (:348, :371)
         cu[DC_STAGE] = DS_IDLE;
+        wait_until = INF;
         const u32 wqn = cu[DC_WQN];
         if (wqn) {
           const u32 cmsg = cu[DC_WQ], ref = cu[DC_WQ + 1];
@@ -486,6 +491,7 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
         const u32 rid = ++node_msgid;
         cu[DC_STAGE] = DS_LOAD; cu[DC_TARGET] = ptr; cu[DC_RPC] = rid;
         send1(D_LWW, M_READ, ptr, rid);
+        wait_until = T + DT_AWAIT_US;
       };
       // walks to the key's leaf; the first tree node on the way that has to be fetched, DT_NONE if the path is in memory
       auto descend = [&](u32 k) -> u32 {
@@ -583,6 +589,7 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
         node_msgid += wn;
         cu[DC_STAGE] = DS_SAVE; cu[DC_WLO] = wlo; cu[DC_WN] = wn; cu[DC_WOUT] = wn;
         o_dest = D_LWW; n_out = wn; o_wlo = wlo;
+        wait_until = T + DT_AWAIT_US;   // `tree2.save!.await` (:366)
       };
       auto reply_txn_ok = [&]() {   // the completed transaction: its reads see the version read + its own appends
         rep = true; r_type = M_TXN_OK; r_b = cu[DC_CMSG];
@@ -614,7 +621,12 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
         save();
       };
 
-      const bool take = normal && l <= N + 1u && deliver_at <= T;
+      const bool await_over = normal && is_node && wait_until <= T;   // a node's due timer comes before its due message
+      const bool take = normal && !await_over && l <= N + 1u && deliver_at <= T;
+      if (await_over) {   // Promise#await gave up (promise.rb:24-29): RPCError.timeout => error 0 to the client (node.rb:172), the lock is free
+        rep = true; r_type = M_ERROR; r_a = 0; r_b = cu[DC_CMSG];
+        unlock();
+      }
       if (take) {
         const uint4 q = cm; deliver_at = INF;
         const u32 qsrc = q.w >> 24, qb = q.w & 0xFFFFFFu, qtype = q.y & 0xFFu, qa = q.z;
@@ -661,7 +673,7 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
                 case DS_SAVE:
                   if (qb < cu[DC_WLO] || qb >= cu[DC_WLO] + cu[DC_WN]) break;
                   { const u32 left = cu[DC_WOUT] - 1u; cu[DC_WOUT] = left;
-                    if (left == 0u) { const u32 rid = ++node_msgid; cu[DC_STAGE] = DS_CAS; cu[DC_RPC] = rid; send1(D_LIN, M_CAS, cu[DC_T], rid); } }   // advance_root! (:376-388)
+                    if (left == 0u) { const u32 rid = ++node_msgid; cu[DC_STAGE] = DS_CAS; cu[DC_RPC] = rid; send1(D_LIN, M_CAS, cu[DC_T], rid); wait_until = T + DT_AWAIT_US; } }   // advance_root! (:376-388)
                   break;
                 case DS_CAS:
                   if (qb != cu[DC_RPC]) break;

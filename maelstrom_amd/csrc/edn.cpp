@@ -154,6 +154,8 @@ extern "C" int msim_history_edn_rows(const msim_config *cfg, const msim_op *rows
       case MSIM_ERR_KEY_DOES_NOT_EXIST: o += ", :error [:key-does-not-exist \"not found\"]"; break;
       case MSIM_ERR_PRECONDITION_FAILED: o += ", :error [:precondition-failed \"cas mismatch\"]"; break;
       case MSIM_ERR_TXN_CONFLICT: o += ", :error [:txn-conflict \"root altered\"]"; break;
+      case MSIM_ERR_TIMEOUT: o += ", :error [:timeout \"promise timed out\"]"; break;
+      case MSIM_ERR_ABORT: o += ", :error [:abort \"aborted\"]"; break;
       default: break;
     }
     if (fin) o += ", :final? true";

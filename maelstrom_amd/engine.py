@@ -43,7 +43,7 @@ F_KW = {A.F_ECHO: ":echo", A.F_BROADCAST: ":broadcast", A.F_READ: ":read", A.F_A
         A.F_TXN: ":txn", A.F_GENERATE: ":generate", A.F_SEND: ":send", A.F_POLL: ":poll", A.F_ASSIGN: ":assign", A.F_CRASH: ":crash"}
 ERR_KW = {A.ERR_NET_TIMEOUT: ":net-timeout", A.ERR_TEMPORARILY_UNAVAILABLE: [":temporarily-unavailable", "not a leader"],
           A.ERR_KEY_DOES_NOT_EXIST: [":key-does-not-exist", "not found"], A.ERR_PRECONDITION_FAILED: [":precondition-failed", "cas mismatch"],
-          A.ERR_TXN_CONFLICT: [":txn-conflict", "root altered"]}
+          A.ERR_TXN_CONFLICT: [":txn-conflict", "root altered"], A.ERR_TIMEOUT: [":timeout", "promise timed out"], A.ERR_ABORT: [":abort", "aborted"]}
 SPEC_KW = {A.SPEC_ONE: ":one", A.SPEC_MAJORITY: ":majority", A.SPEC_MAJORITIES_RING: ":majorities-ring",
            A.SPEC_MINORITY_THIRD: ":minority-third"}
 

@@ -360,8 +360,10 @@ static void snap_put(sim_t *s, u32 tick, u32 node, const u32 *words) {
 }
 
 static void hat_tick(sim_t *s, u32 node);
+static void dt_timeout(sim_t *s, u32 node);
 static void node_timer(sim_t *s, u32 node) {
   if (s->hat) { hat_tick(s, node); return; }
+  if (s->dt) { dt_timeout(s, node); return; }
   if (s->timer_next[node] <= s->T) { /* g_set.rb:33-38: every 5 s, replicate_full to all other nodes */
     s->timer_next[node] = s->T + 5000000u;
     u32 tick = s->tick[node]++;           /* the message carries (sender, tick): a reference to the sender's set then */
@@ -464,8 +466,9 @@ static void client_deliver(sim_t *s, u32 slot, const qent *q) {
     case M_ECHO_OK: case M_GENERATE_OK: client_complete(s, slot, MSIM_T_OK, 0, q->a, 0); break;
     case M_TXN_OK: client_complete(s, slot, MSIM_T_OK, 0, q->a & 0xFFFFFFu, q->a >> 24); break; /* txn_list_append.clj:109-117 */
     case M_ERROR: { /* client.clj:125-138 throw-errors!; every code the raft node emits is :definite? => :fail (errors.edn) */
-      u32 err = q->a == 11 ? MSIM_ERR_TEMPORARILY_UNAVAILABLE : q->a == 20 ? MSIM_ERR_KEY_DOES_NOT_EXIST : q->a == 30 ? MSIM_ERR_TXN_CONFLICT : MSIM_ERR_PRECONDITION_FAILED;
-      if (txn_workload(s)) client_complete(s, slot, MSIM_T_FAIL, err, c->value & 0xFFFFFFu, c->value >> 24); /* :value stays the requested txn */
+      u32 err = q->a == 11 ? MSIM_ERR_TEMPORARILY_UNAVAILABLE : q->a == 20 ? MSIM_ERR_KEY_DOES_NOT_EXIST : q->a == 30 ? MSIM_ERR_TXN_CONFLICT : q->a == 14 ? MSIM_ERR_ABORT : MSIM_ERR_PRECONDITION_FAILED;
+      if (txn_workload(s) && q->a == 0) client_complete(s, slot, MSIM_T_INFO, MSIM_ERR_TIMEOUT, c->value & 0xFFFFFFu, c->value >> 24); /* code 0 :timeout is not :definite? (errors.edn:2-4) */
+      else if (txn_workload(s)) client_complete(s, slot, MSIM_T_FAIL, err, c->value & 0xFFFFFFu, c->value >> 24); /* :value stays the requested txn */
       else client_complete(s, slot, MSIM_T_FAIL, err, c->value, 0); } break;
     default: client_complete(s, slot, MSIM_T_OK, 0, c->value, 0); break;
   }

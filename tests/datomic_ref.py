@@ -169,8 +169,12 @@ class Branch(Tree):
 class DatomicListAppendNode:
     """:323-424 over the message loop of node.rb:147-183"""
 
-    def __init__(self, send):
+    AWAIT_US = 5_000_000          # Promise::TIMEOUT (promise.rb:5), in the replay's virtual microseconds
+
+    def __init__(self, send, clock=lambda: 0):
         self.send = send              # send(dest, body)
+        self.clock = clock            # now, in microseconds
+        self.waits = {}               # thread -> (deadline, token, step) while it sits in Promise#await
         self.node_id, self.node_ids = None, None
         self.next_msg_id, self.callbacks = 0, {}
         self.ptr, self.cache = 0, {}
@@ -196,9 +200,12 @@ class DatomicListAppendNode:
         self._thread(co, msg)
 
     def _thread(self, co, msg):
-        def step(value):
+        tokens = [0]
+
+        def step(value=None, exc=None):
+            self.waits.pop(id(co), None)
             try:
-                req = co.send(value)
+                req = co.throw(exc) if exc is not None else co.send(value)
             except StopIteration:
                 return
             except RPCError as e:
@@ -208,13 +215,22 @@ class DatomicListAppendNode:
                 self.reply(msg, {"type": "error", "code": e.code, "text": e.text})
                 self._unlock(co)
                 return
-            if req[0] == "sync_rpc":
-                self.rpc(req[1], req[2], step)
+            tokens[0] += 1
+            tok = tokens[0]
+
+            def resume(v):   # a late delivery finds its promise abandoned (the await has given up)
+                w = self.waits.get(id(co))
+                if w is not None and w[1] == tok:
+                    step(v)
+            if req[0] == "sync_rpc":       # node.rb:117-123: rpc! + Promise#await
+                self.waits[id(co)] = (self.clock() + self.AWAIT_US, tok, step)
+                self.rpc(req[1], req[2], resume)
             elif req[0] == "await":
                 if req[1].value is not Promise.WAITING:
                     step(req[1].value)
                 else:
-                    req[1].waiters.append(step)
+                    self.waits[id(co)] = (self.clock() + self.AWAIT_US, tok, step)
+                    req[1].waiters.append(resume)
             elif req[0] == "lock":
                 if self.lock_holder is None:
                     self.lock_holder = co
@@ -225,6 +241,15 @@ class DatomicListAppendNode:
                 self._unlock(co)
                 step(None)
         step(None)
+
+    def fire_due(self, now):
+        """Promise#await's timeout (promise.rb:17-30) for every thread whose wait began 5 s ago or more: RPCError.timeout"""
+        fired = False
+        for key, (deadline, _, step) in list(self.waits.items()):
+            if deadline <= now and key in self.waits:
+                fired = True
+                step(exc=RPCError(0, "promise timed out"))
+        return fired
 
     def _unlock(self, co):
         if self.lock_holder is co:

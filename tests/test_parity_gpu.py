@@ -307,8 +307,10 @@ def test_multi_key_txn_packed_layout_parity(lib, kw):
     dict(node_count=5, rate=100, time_limit=8, latency=10, latency_dist="exponential", nemesis=["partition"], nemesis_interval=2),
     dict(node_count=3, rate=200, time_limit=3, latency=3, latency_dist="uniform", key_count=2, max_txn_length=8, max_writes_per_key=32),
     dict(node_count=7, rate=100, time_limit=4, latency=0),
-    dict(node_count=5, rate=100, time_limit=6, latency=5, p_loss=0.05, journal_capacity=400000),                 # a lost message: the node's lock stays taken, its clients time out, the waiting queue fills
+    dict(node_count=5, rate=100, time_limit=6, latency=5, p_loss=0.05, journal_capacity=400000),                 # lost messages: clients time out, transactions queue behind the node's lock
     dict(node_count=3, rate=150, time_limit=10, latency=0, key_count=16, max_writes_per_key=2),                 # ~1000 keys: splits at every level, chains in the two-wide ranges
+    dict(node_count=5, rate=60, time_limit=20, latency=10, p_loss=0.02),                                        # long enough for Promise#await's 5 s: the lock holder gives up (error 0), the node recovers
+    dict(node_count=3, rate=80, time_limit=25, latency=30, latency_dist="exponential", p_loss=0.05),
     dict(node_count=1, rate=50, time_limit=5, latency=1),
     dict(node_count=12, rate=200, time_limit=5, latency=20, latency_dist="exponential"),
 ])
