@@ -71,7 +71,7 @@ enum {
                                    others every 100 ms until they acknowledge (the demo of core.clj:115-121)                */
   MSIM_NODE_TXN_MULTI_KEY = 12, /* demo/js/multi_key_txn.js:1-246 == demo/clojure/multi_key_txn.clj (same architecture as the workload's demo at
                                    core.clj:113-114, demo/ruby/datomic_list_append.rb, but a different program — that one keeps a persistent
-                                   hash tree of lazily loaded nodes and is NOT built): thunks in lww-kv, the root
+                                   hash tree of lazily loaded nodes: MSIM_NODE_TXN_DATOMIC): thunks in lww-kv, the root
                                    map in lin-kv, retry when the root cas is lost (oracle/mk_nodes.inc, pinned by the real program on
                                    the process bridge; csrc/sim_kernel_mk.inc).  One worker per node, at most 30 nodes               */
   MSIM_NODE_KAFKA = 14,         /* demo/clojure/kafka.clj:1-172: logs in 32-message chunks under lin-kv keys (read + cas per send), committed
@@ -82,7 +82,8 @@ enum {
                                    fresh pointers, the root pointer in lin-kv; a transaction takes the node's lock, reads the root pointer, loads the
                                    tree nodes on its keys' paths lazily (a cache of what the node has loaded), copies the paths it appends to, writes
                                    the new nodes children first and cas-es the root; a lost cas answers error 30 (oracle/dt_nodes.inc — parity
-                                   unpinned: there is no Ruby here; csrc/sim_kernel_dt.inc).  One worker per node, at most 8 nodes          */
+                                   unpinned: there is no Ruby here; csrc/sim_kernel_dt.inc, csrc/dt8.hip).  One worker per node, at most 30 nodes; every
+                                   blocking step of a transaction gives up after 5 s (promise.rb:5): error 0 => :info with MSIM_ERR_TIMEOUT   */
   MSIM_NODE_TSO_IDS = 13        /* unique-ids over the `lin-tso` timestamp oracle (service.clj:116-132,290-296; doc/services.md): every
                                    `generate` becomes a {type "ts"} RPC to lin-tso, the timestamp is the id.  The reference ships the
                                    service but no demo that uses it; this node (tools/harness_tso_node.py is its process form) is what

@@ -1,6 +1,6 @@
 // mk8.hip — EIGHT clusters of the multi-key txn-list-append node per wavefront (BASELINE configs[4] over
 // demo/js/multi_key_txn.js — the flat key -> thunk form of the architecture of demo/ruby/datomic_list_append.rb, which core.clj:113-114 runs and
-// which is a different program (a persistent hash tree; not built).
+// which is a different program (a persistent hash tree: dt8.hip / sim_kernel_dt.inc).
 //
 // Same program and the same rounds as mk_kernel<> (sim_kernel_mk.inc; specification: oracle/mk_nodes.inc): node =
 // demo/js/multi_key_txn.js:1-246 (immutable thunks in lww-kv, one root map key -> thunk id in lin-kv; getState / applyTxn / writeThunks /
