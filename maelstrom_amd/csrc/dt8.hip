@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
   const u32 max_rows = p.cfg.max_rows, max_pay = p.cfg.max_payload_words;
   const u32 p_loss = p.cfg.p_loss_q32, lat_mean = p.cfg.latency_mean_ms, lat_dist = p.cfg.latency_dist;
   const u32 rate = p.cfg.rate_mhz, mw = p.cfg.max_writes_per_key, mv = p.cfg.max_values;
-  const u32 TC = p.mk_tcap, CWD = TC / 32u;   // tree nodes a node may create; words of one owner's part of a cache bitmap
+  const u32 TC = p.mk_tcap;   // tree nodes a node may create
   const u32 round_limit = tp.round_limit;
 
   msim_op *const g_rows = p.rows + (size_t)inst * max_rows;
@@ -122,8 +122,7 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
   u32 *const g_first = g_kvn + mv;                                   // [max_values] version at which the key entered the tree (DT_NONE: never)
   unsigned char *const g_hash = reinterpret_cast<unsigned char *>(g_first + mv);   // [max_values] Tree.hash of the key
   u32 *const g_rec = g_first + mv + (mv + 3u) / 4u;                  // [N][TC][DT_RW] tree nodes by pointer
-  u32 *const g_cache = g_rec + (size_t)N * TC * DT_RW;               // [N readers][N owners][TC / 32]
-  u32 *const g_wl = g_cache + (size_t)N * N * CWD;                   // [N][DT_MAXW] the pointers a node writes this round
+  u32 *const g_wl = g_rec + (size_t)N * TC * DT_RW;                  // [N][DT_MAXW] the pointers a node writes this round
   const u32 qlane = l <= N + 1u ? l : 0u;
   uint4 *const my_spill = reinterpret_cast<uint4 *>(g_scr + p.spill_off) + (size_t)qlane * tp.node_spill;
   uint4 *const my_cspill = reinterpret_cast<uint4 *>(g_scr + tp.client_spill_off) + (size_t)(is_node ? l : 0u) * tp.client_spill;
@@ -137,7 +136,6 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
   u32 *const gen = reinterpret_cast<u32 *>(smem + tp.off_gen) + grp * 36;                       // active[16], next_val[16], next_key
   u32 *const misc = reinterpret_cast<u32 *>(smem + tp.off_misc) + grp * GS;
   u32 *const cu = curs_g + my_node * D8_CW;
-  u32 *const my_cache = g_cache + (size_t)my_node * N * CWD;
   u32 *const my_wl = g_wl + (size_t)my_node * DT_MAXW;
 
   for (u32 i = lane; i < 8 * N * D8_CW; i += 64) reinterpret_cast<u32 *>(smem + tp.off_cur)[i] = 0;
@@ -145,7 +143,6 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
   if (l == 0) gen[32] = p.cfg.key_count;
   if (real) {
     for (u32 i = l; i < mv; i += GS) { g_kvn[i] = 0; g_first[i] = DT_NONE; g_hash[i] = (unsigned char)d8_hash(i); }
-    for (u32 i = l; i < N * N * CWD; i += GS) g_cache[i] = 0;
   }
   __syncthreads();
 
@@ -241,9 +238,18 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
     return n;
   };
 
+#ifdef D8_PROF   // developer build (tools/variant_lib.sh d8prof dt8.hip -DD8_PROF; tools/dt8_prof_report.py): cycle counters of the round's sections -> the meta of the wavefront's first three clusters
+  u64 pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; u32 wave_rounds = 0;
+  u64 tprev = __builtin_readcyclecounter();
+#define M8_MARK(i) { const u64 now_ = __builtin_readcyclecounter(); pacc[i] += now_ - tprev; tprev = now_; }
+#else
 #define M8_MARK(i)
+#endif
   for (;;) {
     if (!__ballot(alive)) break;
+#ifdef D8_PROF
+    wave_rounds++;
+#endif
     const u32 busy_mask = GB(busy);
 
     // ---- time-free phase transitions ----
@@ -457,7 +463,6 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
       u32 o_type = 0, o_a = 0, o_b = 0, o_to = 0, need_words = 0, done_ref = 0, done_rv = 0;   // service -> node; the completed transaction's payload
       auto rec_of = [&](u32 ptr) -> u32 * { return g_rec + ((size_t)(ptr >> 20) * TC + (ptr & 0xFFFFFu)) * DT_RW; };
       auto is_new = [&](u32 ptr) -> bool { return (ptr >> 20) == l && (ptr & 0xFFFFFu) >= cu[DC_PSTART]; };
-      auto cached = [&](u32 ptr) -> bool { const u32 i = ptr & 0xFFFFFu; return (my_cache[(ptr >> 20) * CWD + (i >> 5)] >> (i & 31u)) & 1u; };
       auto has_key = [&](u32 k) -> bool {   // the key is in the lineage of the working tree
         if (g_first[k] <= cu[DC_RV]) return true;   // (DT_NONE is above every version)
         const u32 no = cu[DC_NOWN];
@@ -493,17 +498,23 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
         send1(D_LWW, M_READ, ptr, rid);
         wait_until = T + DT_AWAIT_US;
       };
-      // walks to the key's leaf; the first tree node on the way that has to be fetched, DT_NONE if the path is in memory
+      // walks to the key's leaf; the first tree node on the way that has to be fetched, DT_NONE if the path is in memory.  One round trip per
+      // level: a record's kind / range, its flags word (which nodes have loaded it) and its eight children are loaded together.
       auto descend = [&](u32 k) -> u32 {
         const u32 h = g_hash[k];
         u32 pt = cu[DC_T];
         for (u32 d = 0; d < DT_MAXDEPTH; d++) {
           const u32 *const r = rec_of(pt);
-          const u32 w0 = r[0];
+          const u32 w0 = r[0], w3 = __hip_atomic_load(r + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (word 3 is the one word of a record that changes after its creation, by L2 atomics: read past the L1)
+          u32 ch[8];
+#pragma unroll
+          for (u32 c = 0; c < 8u; c++) ch[c] = r[4u + c];
+          if (!is_new(pt) && !((w3 >> (2u + l)) & 1u)) return pt;   // neither created by this transaction nor loaded by this node
           if ((w0 & 1u) == 0u) return DT_NONE;
-          const u32 ch = r[4u + br_index(w0, h)];
-          if (!is_new(ch) && !cached(ch)) return ch;
-          pt = ch;
+          const u32 ci = br_index(w0, h);
+          pt = ch[0];
+#pragma unroll
+          for (u32 c = 1; c < 8u; c++) pt = c == ci ? ch[c] : pt;
         }
         my_flags |= MSIM_FLAG_ARENA_OVERRUN;
         return DT_NONE;
@@ -514,7 +525,18 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
       auto assoc = [&](u32 k) {
         const u32 h = g_hash[k];
         u32 n = 0, pt = cu[DC_T];
-        for (; n + 1u < DT_MAXDEPTH; n++) { const u32 *const r = rec_of(pt); const u32 w0 = r[0]; if ((w0 & 1u) == 0u) break; pt = r[4u + br_index(w0, h)]; }
+        for (; n + 1u < DT_MAXDEPTH; n++) {
+          const u32 *const r = rec_of(pt);
+          const u32 w0 = r[0];
+          u32 ch[8];
+#pragma unroll
+          for (u32 c = 0; c < 8u; c++) ch[c] = r[4u + c];
+          if ((w0 & 1u) == 0u) break;
+          const u32 ci = br_index(w0, h);
+          pt = ch[0];
+#pragma unroll
+          for (u32 c = 1; c < 8u; c++) pt = c == ci ? ch[c] : pt;
+        }
         const u32 *const lf = rec_of(pt);
         const u32 lw0 = lf[0], lcount = lf[1];
         if (lw0 & 1u) { my_flags |= MSIM_FLAG_ARENA_OVERRUN; return; }
@@ -522,7 +544,7 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
         const u32 L = (has || lcount < 8u) ? 1u : 9u, base = next_p, ver = cu[DC_RV] + 1u;
         if (base + L + n >= TC) { my_flags |= MSIM_FLAG_ARENA_OVERRUN; return; }   // engine capacity
         const u32 lo = (lw0 >> 8) & 0xFFu, hi = (lw0 >> 16) & 0xFFu;
-        auto put = [&](u32 idx, u32 w0, u32 cnt) -> u32 * { u32 *const r = g_rec + ((size_t)l * TC + idx) * DT_RW; r[0] = w0; r[1] = cnt; r[2] = ver; r[3] = 0xFFu; return r; };
+        auto put = [&](u32 idx, u32 w0, u32 cnt) -> u32 * { u32 *const r = g_rec + ((size_t)l * TC + idx) * DT_RW; r[0] = w0; r[1] = cnt; r[2] = ver; __hip_atomic_store(r + 3, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return r; };   // (word 3: lww-kv replica in bits 0-1, 3 = not written; bit 2 + i: node i has loaded it)
         if (L == 1u) put(base + 1u, lw0, lcount + (has ? 0u : 1u));
         else {   // eight leaves under a new branch: the lineage's keys of this range (and the new one) by sub-range
           const u32 bs = (hi - lo) / 8u, nk = gen[32];
@@ -561,28 +583,38 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
         cu[DC_T] = (l << 20) | next_p;
         if (!has) { const u32 no = cu[DC_NOWN]; if (no < 8u) { cu[DC_OWN + no] = k; cu[DC_NOWN] = no + 1u; } }
       };
-      // save! (:212-224, :291-320): the new tree nodes the final tree reaches, children before their parent
+      // save! (:212-224, :291-320): the new tree nodes the final tree reaches, children before their parent.  A stack entry is a tree node and
+      // the mask of its new children still to visit (a branch's eight children are loaded together: one round trip per visit).
       auto save = [&]() {
-        u32 *const stk = my_stk;   // (HBM scratch)
+        u32 *const stk = my_stk;
         u32 sp = 1, wn = 0;
         const u32 wlo = node_msgid + 1u;
-        stk[0] = cu[DC_T]; stk[1] = 0;
+        stk[0] = cu[DC_T]; stk[1] = 0x100u;   // (0x100: not looked at yet)
         while (sp) {
           const u32 pt = stk[2u * (sp - 1u)];
+          u32 mask = stk[2u * (sp - 1u) + 1u];
           const u32 *const r = rec_of(pt);
-          bool pushed = false;
-          if (r[0] & 1u) {
-            u32 ci = stk[2u * (sp - 1u) + 1u];
-            while (ci < 8u) {
-              const u32 ch = r[4u + ci++];
-              if (is_new(ch)) {
-                if (sp > DT_MAXDEPTH) { my_flags |= MSIM_FLAG_ARENA_OVERRUN; break; }
-                stk[2u * (sp - 1u) + 1u] = ci; stk[2u * sp] = ch; stk[2u * sp + 1u] = 0; sp++; pushed = true; break;
-              }
+          const u32 w0 = r[0];
+          u32 ch[8];
+#pragma unroll
+          for (u32 c = 0; c < 8u; c++) ch[c] = r[4u + c];
+          if (mask & 0x100u) {
+            mask = 0;
+            if (w0 & 1u) {
+#pragma unroll
+              for (u32 c = 0; c < 8u; c++) mask |= is_new(ch[c]) ? 1u << c : 0u;
             }
-            if (!pushed) stk[2u * (sp - 1u) + 1u] = ci;
           }
-          if (pushed) continue;
+          if (mask) {
+            const u32 ci = (u32)__builtin_ctz(mask);
+            u32 nxt = ch[0];
+#pragma unroll
+            for (u32 c = 1; c < 8u; c++) nxt = c == ci ? ch[c] : nxt;
+            stk[2u * (sp - 1u) + 1u] = mask & (mask - 1u);
+            if (sp > DT_MAXDEPTH) { my_flags |= MSIM_FLAG_ARENA_OVERRUN; stk[2u * (sp - 1u) + 1u] = 0; continue; }
+            stk[2u * sp] = nxt; stk[2u * sp + 1u] = 0x100u; sp++;
+            continue;
+          }
           if (wn >= DT_MAXW) my_flags |= MSIM_FLAG_ARENA_OVERRUN; else my_wl[wn++] = pt;
           sp--;
         }
@@ -638,7 +670,7 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
               if (l != 0u) { rep = true; r_type = M_INIT_OK; r_b = qb; break; }
               {   // the first node writes the initial state (:337-345): Tree.empty, then the root pointer
                 u32 *const r = g_rec;
-                r[0] = (128u << 16); r[1] = 0; r[2] = 0; r[3] = 0xFFu;
+                r[0] = (128u << 16); r[1] = 0; r[2] = 0; __hip_atomic_store(r + 3, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const u32 rid = ++node_msgid;
                 cu[DC_STAGE] = DS_INIT_LEAF; cu[DC_CMSG] = qb; cu[DC_RPC] = rid;
                 send1(D_LWW, M_WRITE, 0, rid);
@@ -662,12 +694,12 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
                 case DS_ROOT:
                   if (qb != cu[DC_RPC]) break;
                   if (qtype != M_READ_OK) { rep = true; r_type = M_ERROR; r_a = 14; r_b = cu[DC_CMSG]; unlock(); break; }   // "Unsure how to handle" (:364)
-                  cu[DC_P1] = qa; cu[DC_T] = qa; cu[DC_RV] = rec_of(qa)[2]; cu[DC_PSTART] = next_p + 1u;
-                  if (cached(qa)) apply(); else load(qa);
+                  cu[DC_P1] = qa; cu[DC_T] = qa; cu[DC_PSTART] = next_p + 1u;
+                  { const u32 *const rr = rec_of(qa); const u32 rv2 = rr[2], rw3 = __hip_atomic_load(rr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); cu[DC_RV] = rv2; if ((rw3 >> (2u + l)) & 1u) apply(); else load(qa); }
                   break;
                 case DS_LOAD:
                   if (qb != cu[DC_RPC]) break;
-                  if (qtype == M_READ_OK) { const u32 t = cu[DC_TARGET], i = t & 0xFFFFFu; my_cache[(t >> 20) * CWD + (i >> 5)] |= 1u << (i & 31u); apply(); }
+                  if (qtype == M_READ_OK) { atomicOr(rec_of(cu[DC_TARGET]) + 3, 1u << (2u + l)); apply(); }   // @@cache[ptr] = tree (:95)
                   else load(cu[DC_TARGET]);   // "Retrying read of tree node" (:97)
                   break;
                 case DS_SAVE:
@@ -708,9 +740,9 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
           svc_rep = true; o_to = qsrc; o_b = qb;
           svc_ctr += 2u;
           const u32 r = scale32(draw32(key, 12u /* S_SVC */, svc_ctr++), 2);
-          u32 *const rp = rec_of(qa) + 3;
-          if (qtype == M_WRITE) { *rp = r; o_type = M_WRITE_OK; o_a = qa; }
-          else if (*rp == r) { o_type = M_READ_OK; o_a = qa; }
+          u32 *const rp = rec_of(qa) + 3;   // (the replica bits; the nodes set their "loaded" bits in the same word: atomics)
+          if (qtype == M_WRITE) { atomicAnd(rp, ~3u); atomicOr(rp, r); o_type = M_WRITE_OK; o_a = qa; }
+          else if ((__hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 3u) == r) { o_type = M_READ_OK; o_a = qa; }
           else { o_type = M_ERROR; o_a = 20; }
         }
       }
@@ -864,6 +896,11 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
     p.stats[inst] = st;
     msim_inst_meta m; m.n_rows = n_rows; m.n_payload_words = n_payload; m.flags = flags; m.n_rounds = rounds;
     m.n_events = 0; m.reserved[0] = 0; m.reserved[1] = 0; m.reserved[2] = 0;
+#ifdef D8_PROF
+    if (grp == 0) { m.n_events = (u32)(pacc[0] >> 6); m.reserved[0] = (u32)(pacc[1] >> 6); m.reserved[1] = (u32)(pacc[2] >> 6); m.reserved[2] = (u32)(pacc[3] >> 6); }
+    if (grp == 1) { m.n_events = (u32)(pacc[4] >> 6); m.reserved[0] = (u32)(pacc[5] >> 6); m.reserved[1] = (u32)(pacc[6] >> 6); m.reserved[2] = (u32)(pacc[7] >> 6); }
+    if (grp == 2) { m.n_events = wave_rounds; }
+#endif
     p.meta[inst] = m;
   }
 }
