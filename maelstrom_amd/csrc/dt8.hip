@@ -458,6 +458,9 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
       // ---- R3: one input per node, then one for each service (endpoint order: lin-kv, lww-kv) ----
       bool rep = false, svc_rep = false;   // node -> own client, service -> node
       u32 r_type = 0, r_a = 0, r_b = 0;    // the answer to the client
+      // The heavy steps run ONCE per round, after the handlers have said who needs them: lanes that reach them from different states (a root
+      // read answered, a load answered, a cas answered, a timeout) would otherwise execute separate inlined copies one after the other.
+      bool do_apply = false, do_reply_ok = false, do_unlock = false;
       u32 n_out = 0, o_dest = 0;           // node -> service: n_out messages, all to the same service; one in registers (o1_*) or the writes of my_wl[]
       u32 o1_type = 0, o1_a = 0, o1_b = 0, o_wlo = 0;
       u32 o_type = 0, o_a = 0, o_b = 0, o_to = 0, need_words = 0, done_ref = 0, done_rv = 0;   // service -> node; the completed transaction's payload
@@ -649,7 +652,7 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
           j++;
         }
         cu[DC_J] = j;
-        if (cu[DC_T] == cu[DC_P1]) { reply_txn_ok(); unlock(); return; }   // nothing appended: no write, no cas
+        if (cu[DC_T] == cu[DC_P1]) { do_reply_ok = true; do_unlock = true; return; }   // nothing appended: no write, no cas
         save();
       };
 
@@ -657,7 +660,7 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
       const bool take = normal && !await_over && l <= N + 1u && deliver_at <= T;
       if (await_over) {   // Promise#await gave up (promise.rb:24-29): RPCError.timeout => error 0 to the client (node.rb:172), the lock is free
         rep = true; r_type = M_ERROR; r_a = 0; r_b = cu[DC_CMSG];
-        unlock();
+        do_unlock = true;
       }
       if (take) {
         const uint4 q = cm; deliver_at = INF;
@@ -693,13 +696,13 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
                   break;
                 case DS_ROOT:
                   if (qb != cu[DC_RPC]) break;
-                  if (qtype != M_READ_OK) { rep = true; r_type = M_ERROR; r_a = 14; r_b = cu[DC_CMSG]; unlock(); break; }   // "Unsure how to handle" (:364)
+                  if (qtype != M_READ_OK) { rep = true; r_type = M_ERROR; r_a = 14; r_b = cu[DC_CMSG]; do_unlock = true; break; }   // "Unsure how to handle" (:364)
                   cu[DC_P1] = qa; cu[DC_T] = qa; cu[DC_PSTART] = next_p + 1u;
-                  { const u32 *const rr = rec_of(qa); const u32 rv2 = rr[2], rw3 = __hip_atomic_load(rr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); cu[DC_RV] = rv2; if ((rw3 >> (2u + l)) & 1u) apply(); else load(qa); }
+                  { const u32 *const rr = rec_of(qa); const u32 rv2 = rr[2], rw3 = __hip_atomic_load(rr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); cu[DC_RV] = rv2; if ((rw3 >> (2u + l)) & 1u) do_apply = true; else load(qa); }
                   break;
                 case DS_LOAD:
                   if (qb != cu[DC_RPC]) break;
-                  if (qtype == M_READ_OK) { atomicOr(rec_of(cu[DC_TARGET]) + 3, 1u << (2u + l)); apply(); }   // @@cache[ptr] = tree (:95)
+                  if (qtype == M_READ_OK) { atomicOr(rec_of(cu[DC_TARGET]) + 3, 1u << (2u + l)); do_apply = true; }   // @@cache[ptr] = tree (:95)
                   else load(cu[DC_TARGET]);   // "Retrying read of tree node" (:97)
                   break;
                 case DS_SAVE:
@@ -709,9 +712,9 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
                   break;
                 case DS_CAS:
                   if (qb != cu[DC_RPC]) break;
-                  if (qtype == M_CAS_OK) reply_txn_ok();
+                  if (qtype == M_CAS_OK) do_reply_ok = true;
                   else { rep = true; r_type = M_ERROR; r_a = 30; r_b = cu[DC_CMSG]; }   // txn_conflict (:385)
-                  unlock();
+                  do_unlock = true;
                   break;
                 default: break;   // "Ignoring reply ... with no callback" (node.rb:160-162)
               }
@@ -747,6 +750,9 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
         }
       }
 
+      if (do_apply) apply();            // apply_txn from where it stopped: may ask for a load, start the save, or finish a read-only transaction
+      if (do_reply_ok) reply_txn_ok();
+      if (do_unlock) unlock();          // (after the answer: the next lock holder's root read follows it)
       M8_MARK(3)
       // completed transactions: payload words allocated in node order, each node writes its own
       if (__ballot(need_words != 0)) {
