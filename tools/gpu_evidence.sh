@@ -8,6 +8,7 @@ timeout 600 bash tools/profile_headline.sh ${TAG}_headline full > gpurun_out/${T
 timeout 600 bash tools/profile_config.sh ${TAG}_cfg3 "cfg3 g-set n=100 lat100 exponential" > gpurun_out/${TAG}_cfg3.log 2>&1
 timeout 600 bash tools/profile_config.sh ${TAG}_cfg4 "cfg4 lin-kv raft n=5 c=10 rate30 60s" > gpurun_out/${TAG}_cfg4.log 2>&1
 timeout 600 bash tools/profile_config.sh ${TAG}_cfg5 "cfg5 txn-list-append n=5 rate100 30s lat5 + partitions" > gpurun_out/${TAG}_cfg5.log 2>&1
+timeout 600 bash tools/profile_config.sh ${TAG}_cfg5dt "cfg5-datomic txn-list-append datomic n=5 rate100 30s lat5 + partitions" > gpurun_out/${TAG}_cfg5dt.log 2>&1
 cd $R
 timeout 900 python tools/bench_configs.py > gpurun_out/${TAG}_other_configs.jsonl 2> gpurun_out/${TAG}_other_configs.err
 timeout 1700 python -m pytest tests -m gpu -q --timeout 300 > gpurun_out/${TAG}_gpu_suite.txt 2>&1
