@@ -16,4 +16,6 @@ rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_write" -o w -- python $ROOT/tools/bench_
 DBS=$(find "$OUT" -name "*_results.db" | sort)
 python $ROOT/tools/rocpd_summary.py $DBS > "$OUT/summary.txt" 2>&1
 python $ROOT/tools/rocpd_summary.py --counters "$OUT/counters.json" $DBS
+# the raw rocprofv3 databases are tens of MiB per pass and gpurun merges at most 64 MiB back: the summaries are what is kept (KEEP_RAW=1 keeps everything)
+[ "${KEEP_RAW:-0}" = 1 ] || rm -rf "$OUT/trace" "$OUT"/pmc_*
 grep -v "compact\|__amd" "$OUT/summary.txt" | tail -60

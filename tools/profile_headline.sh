@@ -20,4 +20,6 @@ python $ROOT/tools/rocpd_summary.py $DBS > "$OUT/summary.txt" 2>&1
 python $ROOT/tools/rocpd_summary.py --counters "$OUT/counters.json" $DBS
 if [ "${2:-}" = "full" ]; then python $ROOT/tools/rocpd_summary.py --traffic "$OUT/traffic.json" $DBS; fi
 cp "$OUT"/trace/*kernel_stats.csv "$OUT/kernel_stats.csv" 2>/dev/null || find "$OUT/trace" -name "*stats*" | head
+# the raw rocprofv3 databases are tens of MiB per pass and gpurun merges at most 64 MiB back: the summaries are what is kept (KEEP_RAW=1 keeps everything)
+[ "${KEEP_RAW:-0}" = 1 ] || rm -rf "$OUT/trace" "$OUT"/pmc_*
 tail -40 "$OUT/summary.txt"
