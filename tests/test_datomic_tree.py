@@ -19,7 +19,7 @@ import oracle_lib as O
 
 
 def _cfg(**kw):
-    base = dict(workload="txn-list-append", bin="datomic", node_count=3, rate=60, time_limit=6, latency=3, seed=11, journal_capacity=200000)
+    base = dict(workload="txn-list-append", bin="datomic", node_count=3, rate=60, time_limit=6, latency=3, seed=11, journal_capacity=500000)
     base.update(kw)
     return E.test_config(**base)
 
@@ -225,3 +225,24 @@ def test_histories_are_strict_serializable_whatever_the_schedule(kw):
             assert not any(o["type"] == ":info" for o in done)
         res = E.check_txn_history(rows, pay)
         assert res["valid?"] is True and res["anomalies"] == [], res
+
+
+@pytest.mark.parametrize("case", range(32))
+def test_replay_random_options(case):
+    """The same replay over random option sets: cluster sizes, rates, latency distributions, loss, key pools from one key to many, transactions of
+    one to eight micro-ops, short-lived keys (deep trees), the partition nemesis."""
+    import random
+    rng = random.Random(0xDA70 + case)
+    kw = dict(node_count=rng.choice([1, 2, 3, 5, 7]), rate=rng.choice([20, 50, 100, 200]), time_limit=rng.choice([4, 8, 14]), seed=rng.randrange(1 << 30),
+              key_count=rng.choice([1, 3, 10, 16]), max_txn_length=rng.choice([1, 4, 8]), max_writes_per_key=rng.choice([2, 16, 40]))
+    lat = rng.choice([0, 1, 5, 20])
+    kw.update(latency=lat, latency_dist=rng.choice(["constant", "uniform", "exponential"]) if lat else "constant")
+    if rng.random() < 0.3:
+        kw["p_loss"] = rng.choice([0.02, 0.1])
+    if rng.random() < 0.3 and kw["node_count"] >= 3:
+        kw.update(nemesis=["partition"], nemesis_interval=rng.choice([1, 3]))
+    cfg = _cfg(**kw)
+    st = replay(cfg, rng.randrange(1 << 20))
+    rows, pay = st["history"]
+    res = E.check_txn_history(rows, pay)
+    assert res["valid?"] is True or (res["valid?"] == "unknown" and res["ok-count"] == 0), res   # (nothing acknowledged: elle says :unknown)
