@@ -19,7 +19,9 @@
 (def node-programs {"builtin:echo" 0 "builtin:broadcast-ff" 1 "builtin:broadcast-ff-echoback" 2
                     "builtin:broadcast-ack-retry" 3 "builtin:broadcast-rpc-all" 4 "builtin:g-set" 5
                     "builtin:raft" 6 "builtin:single-key-txn" 7 "builtin:pn-counter" 8 "builtin:flake-ids" 9 "builtin:lin-kv-proxy" 10
-                    "builtin:txn-rw-register-hat" 11})
+                    "builtin:txn-rw-register-hat" 11 "builtin:multi-key-txn" 12 "builtin:tso-ids" 13 "builtin:kafka" 14
+                    ; demo/ruby/datomic_list_append.rb, what core.clj:113-114 runs for txn-list-append (MSIM_NODE_TXN_DATOMIC)
+                    "builtin:datomic" 15})
 (def topologies {:grid 0 :line 1 :total 2 :tree 3 :tree2 3 :tree3 4 :tree4 5})
 (def latency-dists {:constant 0 :uniform 1 :exponential 2})
 (def services {"lin-kv" 0 "seq-kv" 1 "lww-kv" 2})
