@@ -184,7 +184,7 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
     if (c->node_program == MSIM_NODE_RAFT) depth = 24 + 1024;   // heartbeats / re-sent append_entries pile up behind a sleeping recv!
     if (txn || kafka) depth = 16 + 4 * c->n_nodes;              // the service sees <= 2 requests per transaction in flight
     if (c->node_program == MSIM_NODE_TXN_MULTI_KEY) depth = 16 + 16 * c->n_nodes;   // lww-kv: up to max-txn-length thunk reads / writes per transaction
-    if (c->node_program == MSIM_NODE_TXN_DATOMIC) depth = 16 + 96 * c->n_nodes;     // lww-kv: every node may have the new tree nodes of a transaction in flight (a path per append; DT_MAXW bounds one transaction)
+    if (c->node_program == MSIM_NODE_TXN_DATOMIC) depth = 16 + (c->n_nodes < 4 ? 304 : 96 * c->n_nodes);   // lww-kv: every node may have the new tree nodes of a transaction in flight (a path per append; one transaction writes at most DT_MAXW = 256)
     if (hat) depth = 16 + 4 * c->n_nodes + (uint32_t)(20.0 * c->n_nodes * lat_s);  // a replicate + n-1 acks per peer per 100 ms tick
     if (c->node_program == MSIM_NODE_LIN_KV_PROXY || c->node_program == MSIM_NODE_TSO_IDS) depth = 16 + 2 * c->concurrency;   // the service sees every worker's request at once
     // wide clusters: 100+ queues would take a fifth of the LDS budget of a cluster; their queues live in the HBM spill area
