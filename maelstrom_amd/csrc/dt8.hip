@@ -795,6 +795,7 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
           for (u32 s = 0; s < N + 2u; s++) { const u32 v = GGET(cnt, s); my_off += s < l ? v : 0u; total += v; }
           if (is_node) { s_send_cl += rcnt; s_send_sv += n_out; } else s_send_sv += cnt;
           // node -> service: the service lane takes each node's run in node order
+          wave_lds_fence();   // (the write lists of this round were stored by other lanes of this wavefront: keep the compiler from moving the loads up)
           u32 ts = GB(is_node && n_out != 0);
           while (__ballot(ts != 0)) {
             const bool on = ts != 0;
