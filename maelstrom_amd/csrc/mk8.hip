@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
   if (l == 0) gen[32] = p.cfg.key_count;
   if (real) {
     for (u32 i = l; i < mv; i += GS) { g_kvn[i] = 0; g_updn[i] = 0; g_first[i] = MK_NONE; g_pos[i] = MK_NONE; }
-    for (u32 i = l; i < N * CC; i += GS) g_cache[i] = 0;
+    for (u32 r = 0; r < N; r++) for (u32 i = l; i < N * (TC >> 5); i += GS) g_cache[(size_t)r * CC + i] = 0;   // (the bitmaps at the head of every node's area)
     for (u32 i = l; i < N * TC / 4u; i += GS) reinterpret_cast<u32 *>(g_rep)[i] = 0xFFFFFFFFu;
   }
   __syncthreads();
@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
   u32 deliver_at = INF; uint4 cm = make_uint4(0, 0, 0, 0);
   bool have_pm = false; uint4 pm = make_uint4(0, 0, 0, 0);
   u32 in_n = 0, sp_n = 0, node_msgid = 0, part = 0;
-  u32 root_v = 0, next_tid = 0, cache_n = 0;           // node: the cached root's version, thunk ids handed out, thunks cached
+  u32 root_v = 0, next_tid = 0;                        // node: the cached root's version, thunk ids handed out
   u32 root_exists = 0, cur_v = 0, n_order = 0;         // lin-kv lane: the root
   u32 svc_ctr = 0;                                     // lww-kv lane: rand-int draws so far
   // ---- client state ----
@@ -456,16 +456,10 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
       u32 o_type = 0, o_a = 0, o_b = 0, o_to = 0, need_words = 0, done_slot = 0;
       u32 *const my_out = mout_g + l * (KEYS * 3u);
       auto out_msg = [&](u32 dest, u32 type, u32 a, u32 b) __attribute__((always_inline)) { o_dest = dest; my_out[n_out * 3u] = type; my_out[n_out * 3u + 1u] = a; my_out[n_out * 3u + 2u] = b; n_out++; };
-      // the node's thunk cache: open addressing over CC slots of tid + 1 (multi_key_txn.js:17,80-106)
-      auto cached = [&](u32 tid) __attribute__((always_inline)) -> bool {
-        for (u32 h = (tid * 0x9E3779B1u) & (CC - 1u);; h = (h + 1u) & (CC - 1u)) { const u32 v = my_cache[h]; if (v == 0u) return false; if (v == tid + 1u) return true; }
-      };
-      auto cache_add = [&](u32 tid) __attribute__((always_inline)) {   // (one probe sequence: it ends at the thunk or at the free slot it goes to)
-        u32 h = (tid * 0x9E3779B1u) & (CC - 1u);
-        for (;;) { const u32 v = my_cache[h]; if (v == tid + 1u) return; if (v == 0u) break; h = (h + 1u) & (CC - 1u); }
-        if ((cache_n + 1u) * 2u > CC) { my_flags |= MSIM_FLAG_ARENA_OVERRUN; return; }   // engine capacity
-        my_cache[h] = tid + 1u; cache_n++;
-      };
+      // the node's thunk cache (multi_key_txn.js:17,80-106): one bit per thunk id <node>.<i>, [owner][i / 32] in the first N x TC / 32 words of the
+      // node's CC-word area (round 5: a probe of the open-addressing table it replaces was a dependent load into 256 KiB per node)
+      auto cached = [&](u32 tid) __attribute__((always_inline)) -> bool { const u32 i = tid & 0xFFFFFu; return (my_cache[(tid >> 20) * (TC >> 5) + (i >> 5)] >> (i & 31u)) & 1u; };
+      auto cache_add = [&](u32 tid) __attribute__((always_inline)) { const u32 i = tid & 0xFFFFFu; my_cache[(tid >> 20) * (TC >> 5) + (i >> 5)] |= 1u << (i & 31u); };
       // the thunk the root of version v names for `k` (MK_NONE: the map does not have the key)
       auto thunk_of = [&](u32 k, u32 v) __attribute__((always_inline)) -> u32 {
         const u32 first = g_first[k], cnt = g_updn[k];   // (never entered: MK_NONE > any version)
@@ -551,12 +545,12 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
         }
 #pragma unroll
         for (u32 j = 0; j < KEYS; j++) { tids[j] = MK_NONE; if (nle[j]) tids[j] = g_upd_t[kk[j] * mw1 + nle[j] - 1u]; if (tids[j] == MK_NONE) posn[j] = MK_NONE; }
-        u32 pr[KEYS];   // first probe of the thunk cache, all keys at once
+        u32 pr[KEYS];   // the thunk cache's word of every key, all keys at once
 #pragma unroll
-        for (u32 j = 0; j < KEYS; j++) { pr[j] = 0; if (tids[j] != MK_NONE) pr[j] = my_cache[(tids[j] * 0x9E3779B1u) & (CC - 1u)]; }
+        for (u32 j = 0; j < KEYS; j++) { pr[j] = 0; if (tids[j] != MK_NONE) pr[j] = my_cache[(tids[j] >> 20) * (TC >> 5) + ((tids[j] & 0xFFFFFu) >> 5)]; }
         bool have[KEYS];
 #pragma unroll
-        for (u32 j = 0; j < KEYS; j++) have[j] = tids[j] != MK_NONE && (pr[j] == tids[j] + 1u || (pr[j] != 0u && cached(tids[j])));
+        for (u32 j = 0; j < KEYS; j++) have[j] = tids[j] != MK_NONE && ((pr[j] >> (tids[j] & 31u)) & 1u);
         for (u32 done = 0;;) {   // ascending position in the root map
           u32 best = MK_NONE, bj = 0;
 #pragma unroll
