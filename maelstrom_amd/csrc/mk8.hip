@@ -454,6 +454,9 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
       bool rep = false, svc_rep = false;   // node -> own client, service -> node
       u32 n_out = 0, o_dest = 0;           // node -> service: n_out messages in mout[l][..], all to the same service
       u32 o_type = 0, o_a = 0, o_b = 0, o_to = 0, need_words = 0, done_slot = 0;
+      // The three heavy steps of a transaction run ONCE per round each, after the handlers have said which slot needs which (hact: 1 start an attempt,
+      // 2 write the thunks, 3 cas the root): lanes reaching them from different states would otherwise execute separate inlined copies one after the other.
+      u32 hact = 0, hact_si = 0;
       u32 *const my_out = mout_g + l * (KEYS * 3u);
       auto out_msg = [&](u32 dest, u32 type, u32 a, u32 b) __attribute__((always_inline)) { o_dest = dest; my_out[n_out * 3u] = type; my_out[n_out * 3u + 1u] = a; my_out[n_out * 3u + 2u] = b; n_out++; };
       // the node's thunk cache (multi_key_txn.js:17,80-106): one bit per thunk id <node>.<i>, [owner][i / 32] in the first N x TC / 32 words of the
@@ -502,7 +505,7 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
           out_msg(D_LWW, M_WRITE, tid, rid);
         }
         sl[SK_WROUT] = wr_out;
-        if (wr_out == 0) send_cas(sl, si);
+        hact = wr_out == 0 ? 3u : 0u; hact_si = si;
       };
       auto thunk_ready = [&](u32 *sl, u32 j) __attribute__((always_inline)) { const u32 ns = sl[SK_NSTATE]; sl[SK_SORD + ns] = j; sl[SK_NSTATE] = ns + 1u; sl[SK_RDRPC + j] = 0; };
       // transact (:213-236) from the node's cached root; getState (:141-156) walks the root's keys in map order
@@ -564,7 +567,7 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
           else { const u32 rid = ++node_msgid; sl[SK_RDTID + bj] = tb; sl[SK_RDRPC + bj] = rid; rd_out++; out_msg(D_LWW, M_READ, tb, rid); }
         }
         sl[SK_RDOUT] = rd_out;
-        if (rd_out == 0) begin_writes(sl, si);
+        hact = rd_out == 0 ? 2u : 0u; hact_si = si;
       };
       const bool take = normal && l <= N + 1u && deliver_at <= T;
       if (take) {
@@ -595,7 +598,7 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
                   if ((w & 1u) && !sl[SK_WR + j]) { sl[SK_WR + j] = 1u; sl[SK_FA + j] = i; }
                 }
                 sl[SK_NK] = nk;
-                start_attempt(sl, si_);
+                hact = 1u; hact_si = si_;
                 return true;
               };
               (void)M8_ON_SLOT(my_node, si, on_txn);
@@ -615,7 +618,7 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
                       if (cached(tid)) { thunk_ready(sl, j); sl[SK_RDOUT]--; }
                       else { const u32 rid = ++node_msgid; sl[SK_RDRPC + j] = rid; out_msg(D_LWW, M_READ, tid, rid); }
                     }
-                    if (sl[SK_RDOUT] == 0) begin_writes(sl, si_);
+                    if (sl[SK_RDOUT] == 0) { hact = 2u; hact_si = si_; }
                     break;
                   }
                 } else if (stage_ == 2u) {
@@ -625,7 +628,7 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
                     // "the root of version rv has no thunk for the key" == the key entered the map later (or never): a key's first thunk is
                     // committed by the cas that enters it, so g_first[k] is also the version of its first thunk — one load, not the row
                     if (g_first[sl[SK_KEY + j]] > sl[SK_RV]) { const u32 nn = sl[SK_NNEW]; sl[SK_NORD + nn] = j; sl[SK_NNEW] = nn + 1u; }
-                    if (--sl[SK_WROUT] == 0) send_cas(sl, si_);
+                    if (--sl[SK_WROUT] == 0) { hact = 3u; hact_si = si_; }
                     break;
                   }
                 } else if (sl[SK_RPC] == qb) {
@@ -678,7 +681,7 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
                     } else { const u32 rid = ++node_msgid; sl[SK_HDR] = 1u | (4u << 8); sl[SK_RPC] = rid; out_msg(D_LIN, M_READ, 0, rid); }   // :230-234
                   } else {   // getRoot (:112-116)
                     root_v = qtype == M_READ_OK ? qa : 0u;
-                    start_attempt(sl, si_);
+                    hact = 1u; hact_si = si_;
                   }
                 }
                 return found;
@@ -742,6 +745,10 @@ __global__ void __launch_bounds__(64) mk8_kernel(const M8Params tp) {
           else { o_type = M_ERROR; o_a = 20; }
         }
       }
+
+      if (hact == 1u) { if (hact_si < M8_SL) start_attempt(lds_slot(my_node, hact_si), hact_si); else start_attempt(hbm_slot(my_node, hact_si), hact_si); }   // (sets hact = 2 when nothing has to be read)
+      if (hact == 2u) { if (hact_si < M8_SL) begin_writes(lds_slot(my_node, hact_si), hact_si); else begin_writes(hbm_slot(my_node, hact_si), hact_si); }     // (sets hact = 3 when nothing has to be written)
+      if (hact == 3u) { if (hact_si < M8_SL) send_cas(lds_slot(my_node, hact_si), hact_si); else send_cas(hbm_slot(my_node, hact_si), hact_si); }
 
       M8_MARK(3)
       // completed transactions: payload words allocated in node order, each node writes its own
