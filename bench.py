@@ -102,10 +102,12 @@ def supervise(argv):
                 os.unlink(status)
             except OSError:
                 pass
-        if r.returncode == 0 and lines:
+        if lines:   # the line is out: the measurement is complete whatever happened to the process afterwards (a teardown that dies is noted, not repeated)
             out = json.loads(lines[-1])
-            if failures:
+            if failures or r.returncode != 0:
                 out["attempts"] = {"n": attempt + 1, "failed": failures}
+                if r.returncode != 0:
+                    out["attempts"]["exit_after_the_line"] = r.returncode
             print(json.dumps(out), flush=True)
             return 0
         leg = next((x["name"] for x in reversed(notes) if x.get("stage") == "leg"), None)
