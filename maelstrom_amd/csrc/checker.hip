@@ -364,9 +364,9 @@ int msim_check_launch(msim_ctx *ctx) {
   if (const char *why = check_limits(c.max_rows, c.max_values, c.concurrency)) { ctx->err = why; return MSIM_E_UNSUPPORTED; }
   const size_t rec_bytes = (size_t)ctx->n_inst * (c.max_rows / 2 + 1) * 3 * sizeof(u32);
   if (ctx->cap_check_scratch < rec_bytes) {
-    if (ctx->d_check_scratch) (void)hipFree(ctx->d_check_scratch);
+    if (ctx->d_check_scratch) (void)msim_dev_free(ctx->d_check_scratch);
     ctx->d_check_scratch = nullptr; ctx->cap_check_scratch = 0;
-    MSIM_HIP_TRY(ctx, hipMalloc(&ctx->d_check_scratch, rec_bytes));
+    MSIM_HIP_TRY(ctx, msim_dev_malloc(&ctx->d_check_scratch, rec_bytes));
     ctx->cap_check_scratch = rec_bytes;
   }
   cp.recs = static_cast<u32 *>(ctx->d_check_scratch);
@@ -396,11 +396,11 @@ extern "C" int msim_check_set_full_batch(int device, uint32_t workload, uint32_t
   const size_t pay_bytes = (size_t)n_histories * (max_payload_words ? max_payload_words : 1) * sizeof(u32);
   int rc = MSIM_E_HIP;
   do {
-    if (hipMalloc(&d_rows, (size_t)n_histories * max_rows * sizeof(msim_op)) != hipSuccess) break;
-    if (hipMalloc(&d_pay, pay_bytes) != hipSuccess) break;
-    if (hipMalloc(&d_meta, (size_t)n_histories * sizeof(msim_inst_meta)) != hipSuccess) break;
-    if (hipMalloc(&d_out, (size_t)n_histories * sizeof(msim_check_result)) != hipSuccess) break;
-    if (hipMalloc(&d_rec, (size_t)n_histories * (max_rows / 2 + 1) * 3 * sizeof(u32)) != hipSuccess) break;
+    if (msim_dev_malloc(&d_rows, (size_t)n_histories * max_rows * sizeof(msim_op)) != hipSuccess) break;
+    if (msim_dev_malloc(&d_pay, pay_bytes) != hipSuccess) break;
+    if (msim_dev_malloc(&d_meta, (size_t)n_histories * sizeof(msim_inst_meta)) != hipSuccess) break;
+    if (msim_dev_malloc(&d_out, (size_t)n_histories * sizeof(msim_check_result)) != hipSuccess) break;
+    if (msim_dev_malloc(&d_rec, (size_t)n_histories * (max_rows / 2 + 1) * 3 * sizeof(u32)) != hipSuccess) break;
     if (hipMemcpy(d_rows, rows, (size_t)n_histories * max_rows * sizeof(msim_op), hipMemcpyHostToDevice) != hipSuccess) break;
     if (max_payload_words && hipMemcpy(d_pay, payload, pay_bytes, hipMemcpyHostToDevice) != hipSuccess) break;
     if (hipMemcpy(d_meta, hm.data(), (size_t)n_histories * sizeof(msim_inst_meta), hipMemcpyHostToDevice) != hipSuccess) break;
@@ -410,7 +410,7 @@ extern "C" int msim_check_set_full_batch(int device, uint32_t workload, uint32_t
     if (hipMemcpy(out, d_out, (size_t)n_histories * sizeof(msim_check_result), hipMemcpyDeviceToHost) != hipSuccess) break;
     rc = MSIM_OK;
   } while (false);
-  for (void *q : {(void *)d_rows, (void *)d_pay, (void *)d_meta, (void *)d_out, (void *)d_rec}) if (q) (void)hipFree(q);
+  for (void *q : {(void *)d_rows, (void *)d_pay, (void *)d_meta, (void *)d_out, (void *)d_rec}) if (q) (void)msim_dev_free(q);
   return rc;
 }
 
@@ -452,13 +452,13 @@ extern "C" int msim_check_availability(msim_ctx *ctx, uint32_t mode, double avai
   MSIM_HIP_TRY(ctx, hipSetDevice(ctx->device));
   const size_t bytes = (size_t)ctx->n_inst * sizeof(uint2);
   uint2 *d = nullptr;
-  MSIM_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&d), bytes));
+  MSIM_HIP_TRY(ctx, msim_dev_malloc(reinterpret_cast<void **>(&d), bytes));
   hipLaunchKernelGGL(availability_kernel, dim3(ctx->n_inst), dim3(64), 0, ctx->stream, ctx->d_rows, ctx->d_meta, ctx->cfg.max_rows, d);
   std::vector<uint2> h(ctx->n_inst);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d, bytes, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d);
+  (void)msim_dev_free(d);
   if (e != hipSuccess) { ctx->err = std::string("msim_check_availability: ") + hipGetErrorString(e); return MSIM_E_HIP; }
   for (uint32_t i = 0; i < ctx->n_inst; i++) availability_verdict(h[i].x, h[i].y, mode, availability, &out[i]);
   return MSIM_OK;

@@ -66,29 +66,29 @@ extern "C" int msim_device_count(void) {
 }
 
 static void free_buffers(msim_ctx *c) {
-  if (c->d_rows) (void)hipFree(c->d_rows);
-  if (c->d_payload) (void)hipFree(c->d_payload);
-  if (c->d_stats) (void)hipFree(c->d_stats);
-  if (c->d_meta) (void)hipFree(c->d_meta);
-  if (c->d_scratch) (void)hipFree(c->d_scratch);
-  if (c->d_check) (void)hipFree(c->d_check);
-  if (c->d_journal) (void)hipFree(c->d_journal);
+  if (c->d_rows) (void)msim_dev_free(c->d_rows);
+  if (c->d_payload) (void)msim_dev_free(c->d_payload);
+  if (c->d_stats) (void)msim_dev_free(c->d_stats);
+  if (c->d_meta) (void)msim_dev_free(c->d_meta);
+  if (c->d_scratch) (void)msim_dev_free(c->d_scratch);
+  if (c->d_check) (void)msim_dev_free(c->d_check);
+  if (c->d_journal) (void)msim_dev_free(c->d_journal);
   if (c->h_rows) (void)hipHostFree(c->h_rows);
   if (c->h_payload) (void)hipHostFree(c->h_payload);
   if (c->h_stats) (void)hipHostFree(c->h_stats);
   if (c->h_meta) (void)hipHostFree(c->h_meta);
   if (c->h_check) (void)hipHostFree(c->h_check);
   if (c->h_journal) (void)hipHostFree(c->h_journal);
-  if (c->d_check_scratch) (void)hipFree(c->d_check_scratch);
+  if (c->d_check_scratch) (void)msim_dev_free(c->d_check_scratch);
   c->d_check_scratch = nullptr; c->cap_check_scratch = 0;
-  if (c->d_compact) (void)hipFree(c->d_compact);
-  if (c->d_off) (void)hipFree(c->d_off);
-  if (c->d_compact2) (void)hipFree(c->d_compact2);
-  if (c->d_off2) (void)hipFree(c->d_off2);
+  if (c->d_compact) (void)msim_dev_free(c->d_compact);
+  if (c->d_off) (void)msim_dev_free(c->d_off);
+  if (c->d_compact2) (void)msim_dev_free(c->d_compact2);
+  if (c->d_off2) (void)msim_dev_free(c->d_off2);
   c->d_compact2 = nullptr; c->d_off2 = nullptr; c->cap_compact2 = c->cap_off2 = 0;
-  if (c->d_grows) (void)hipFree(c->d_grows);
-  if (c->d_gpay) (void)hipFree(c->d_gpay);
-  if (c->d_goff) (void)hipFree(c->d_goff);
+  if (c->d_grows) (void)msim_dev_free(c->d_grows);
+  if (c->d_gpay) (void)msim_dev_free(c->d_gpay);
+  if (c->d_goff) (void)msim_dev_free(c->d_goff);
   c->d_grows = c->d_gpay = nullptr; c->d_goff = nullptr; c->cap_grows = c->cap_gpay = c->cap_goff = 0;
   c->d_compact = nullptr; c->d_off = nullptr;
   c->cap_compact = c->cap_off = c->cap_h_rows = c->cap_h_payload = c->cap_h_journal = c->cap_h_meta = 0;
@@ -201,13 +201,13 @@ static int ensure_buffers(msim_ctx *ctx, uint32_t n) {
   free_buffers(ctx);
   const msim_config &c = ctx->cfg;
   ctx->scratch_words_per_inst = scratch_words(c);
-  MSIM_HIP_TRY(ctx, hipMalloc(&ctx->d_rows, (size_t)n * c.max_rows * sizeof(msim_op)));
-  MSIM_HIP_TRY(ctx, hipMalloc(&ctx->d_payload, (size_t)n * c.max_payload_words * 4));
-  MSIM_HIP_TRY(ctx, hipMalloc(&ctx->d_stats, (size_t)n * sizeof(msim_net_stats)));
-  MSIM_HIP_TRY(ctx, hipMalloc(&ctx->d_meta, (size_t)n * sizeof(msim_inst_meta)));
-  MSIM_HIP_TRY(ctx, hipMalloc(&ctx->d_scratch, (size_t)n * ctx->scratch_words_per_inst * 4));
-  MSIM_HIP_TRY(ctx, hipMalloc(&ctx->d_check, (size_t)n * sizeof(msim_check_result)));
-  if (c.journal_capacity) MSIM_HIP_TRY(ctx, hipMalloc(&ctx->d_journal, (size_t)n * c.journal_capacity * sizeof(msim_event)));
+  MSIM_HIP_TRY(ctx, msim_dev_malloc(&ctx->d_rows, (size_t)n * c.max_rows * sizeof(msim_op)));
+  MSIM_HIP_TRY(ctx, msim_dev_malloc(&ctx->d_payload, (size_t)n * c.max_payload_words * 4));
+  MSIM_HIP_TRY(ctx, msim_dev_malloc(&ctx->d_stats, (size_t)n * sizeof(msim_net_stats)));
+  MSIM_HIP_TRY(ctx, msim_dev_malloc(&ctx->d_meta, (size_t)n * sizeof(msim_inst_meta)));
+  MSIM_HIP_TRY(ctx, msim_dev_malloc(&ctx->d_scratch, (size_t)n * ctx->scratch_words_per_inst * 4));
+  MSIM_HIP_TRY(ctx, msim_dev_malloc(&ctx->d_check, (size_t)n * sizeof(msim_check_result)));
+  if (c.journal_capacity) MSIM_HIP_TRY(ctx, msim_dev_malloc(&ctx->d_journal, (size_t)n * c.journal_capacity * sizeof(msim_event)));
   ctx->cap_inst = n;
   return MSIM_OK;
 }
@@ -216,6 +216,9 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   if (!ctx) return MSIM_E_INVALID;
   if (n == 0) { ctx->err = "n_instances must be > 0"; return MSIM_E_INVALID; }
   MSIM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // msim_fetch_begin has queued PCIe copies on the context's stream: they are over before this launch (which may sit on the caller's own
+  // stream, msim_run_async) drops the claim to them — the pinned mirrors they write may be regrown by the next fetch
+  if (ctx->fetch_pending) { MSIM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); ctx->fetch_pending = false; }
   int rc = ensure_buffers(ctx, n);
   if (rc != MSIM_OK) return rc;
   const msim_config &c = ctx->cfg;
@@ -407,15 +410,15 @@ static int fetch_compacted(msim_ctx *ctx, const void *d_src, uint64_t stride_uni
   const size_t unit = units16 ? 16 : 4, bytes = (size_t)total * unit;
   if (phase == 1) { MSIM_HIP_TRY(ctx, hipMemcpyAsync(h_dst, *d_compact, bytes, hipMemcpyDeviceToHost, ctx->stream)); return MSIM_OK; }
   if (*cap_compact < bytes) {
-    if (*d_compact) (void)hipFree(*d_compact);
+    if (*d_compact) (void)msim_dev_free(*d_compact);
     *d_compact = nullptr; *cap_compact = 0;
-    MSIM_HIP_TRY(ctx, hipMalloc(d_compact, bytes + bytes / 8));
+    MSIM_HIP_TRY(ctx, msim_dev_malloc(d_compact, bytes + bytes / 8));
     *cap_compact = bytes + bytes / 8;
   }
   if (*cap_off < (size_t)(n + 1) * 8) {
-    if (*d_off) (void)hipFree(*d_off);
+    if (*d_off) (void)msim_dev_free(*d_off);
     *d_off = nullptr; *cap_off = 0;
-    MSIM_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(d_off), (size_t)(n + 1) * 8));
+    MSIM_HIP_TRY(ctx, msim_dev_malloc(reinterpret_cast<void **>(d_off), (size_t)(n + 1) * 8));
     *cap_off = (size_t)(n + 1) * 8;
   }
   MSIM_HIP_TRY(ctx, hipMemcpyAsync(*d_off, h_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -432,9 +435,9 @@ static int fetch_compacted(msim_ctx *ctx, const void *d_src, uint64_t stride_uni
 template <typename T>
 static int grow_device(msim_ctx *ctx, T **buf, size_t *cap, size_t bytes) {
   if (*buf && *cap >= bytes) return MSIM_OK;
-  if (*buf) { (void)hipFree(*buf); *buf = nullptr; *cap = 0; }
+  if (*buf) { (void)msim_dev_free(*buf); *buf = nullptr; *cap = 0; }
   const size_t want = bytes + bytes / 8 + 256;
-  MSIM_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(buf), want));
+  MSIM_HIP_TRY(ctx, msim_dev_malloc(reinterpret_cast<void **>(buf), want));
   *cap = want;
   return MSIM_OK;
 }
@@ -642,12 +645,12 @@ extern "C" int msim_selftest_wave(int device) {
   u64 x = 12345;
   for (int i = 0; i < n; i++) { x = mix64(x + i); h[i] = (u32)x; if (i % 7 == 0) h[i] = 0xFFFFFFFFu; }
   int bad = 0;
-  if (hipMalloc(&d_in, n * 4) != hipSuccess || hipMalloc(&d_out, n * 4) != hipSuccess) { delete[] h; return MSIM_E_HIP; }
+  if (msim_dev_malloc(&d_in, n * 4) != hipSuccess || msim_dev_malloc(&d_out, n * 4) != hipSuccess) { delete[] h; return MSIM_E_HIP; }
   (void)hipMemcpy(d_in, h, n * 4, hipMemcpyHostToDevice);
   hipLaunchKernelGGL(wave_selftest_kernel, dim3(blocks), dim3(64), 0, 0, d_in, d_out);
   if (hipMemcpy(h, d_out, n * 4, hipMemcpyDeviceToHost) != hipSuccess) bad = MSIM_E_HIP;
   else for (int i = 0; i < n; i++) bad += h[i] != 0;
-  (void)hipFree(d_in); (void)hipFree(d_out);
+  (void)msim_dev_free(d_in); (void)msim_dev_free(d_out);
   delete[] h;
   return bad;
 }

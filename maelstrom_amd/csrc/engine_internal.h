@@ -110,6 +110,11 @@ int msim_check_pn_device(msim_ctx *ctx);
 int msim_check_pn_host(msim_ctx *ctx);
 int msim_check_unique_host(msim_ctx *ctx);
 
+// guard.cpp: the library's device allocator — hipMalloc / hipFree unless MSIM_GUARD asks for fenced slabs (developer's electric fence for HBM)
+hipError_t msim_dev_malloc_impl(void **out, size_t bytes);
+hipError_t msim_dev_free(void *ptr);
+template <typename T> static inline hipError_t msim_dev_malloc(T **out, size_t bytes) { return msim_dev_malloc_impl(reinterpret_cast<void **>(out), bytes); }
+
 #define MSIM_HIP_TRY(ctx, call)                                                        \
   do {                                                                                 \
     hipError_t e_ = (call);                                                            \

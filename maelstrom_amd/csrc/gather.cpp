@@ -57,9 +57,9 @@ Rccl &rccl() {
 template <typename T>
 int grow(msim_ctx *ctx, T **buf, size_t *cap, size_t bytes) {
   if (*buf && *cap >= bytes) return MSIM_OK;
-  if (*buf) { (void)hipFree(*buf); *buf = nullptr; *cap = 0; }
+  if (*buf) { (void)msim_dev_free(*buf); *buf = nullptr; *cap = 0; }
   const size_t want = bytes + bytes / 8 + 256;
-  MSIM_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(buf), want));
+  MSIM_HIP_TRY(ctx, msim_dev_malloc(reinterpret_cast<void **>(buf), want));
   *cap = want;
   return MSIM_OK;
 }
@@ -79,8 +79,8 @@ void msim_gather_layout(const uint64_t *sizes, int world, std::vector<uint64_t> 
 }
 
 void msim_gather_free(msim_ctx *ctx) {
-  for (int k = 0; k < 4; k++) { if (ctx->d_all[k]) (void)hipFree(ctx->d_all[k]); ctx->d_all[k] = nullptr; ctx->cap_all[k] = 0; }
-  if (ctx->d_sizes) { (void)hipFree(ctx->d_sizes); ctx->d_sizes = nullptr; }
+  for (int k = 0; k < 4; k++) { if (ctx->d_all[k]) (void)msim_dev_free(ctx->d_all[k]); ctx->d_all[k] = nullptr; ctx->cap_all[k] = 0; }
+  if (ctx->d_sizes) { (void)msim_dev_free(ctx->d_sizes); ctx->d_sizes = nullptr; }
   if (ctx->ev_g0) { (void)hipEventDestroy(ctx->ev_g0); (void)hipEventDestroy(ctx->ev_g1); ctx->ev_g0 = ctx->ev_g1 = nullptr; }
   if (ctx->comm && rccl().ok) (void)rccl().CommDestroy(static_cast<ncclComm_t>(ctx->comm));
   ctx->comm = nullptr;
@@ -102,7 +102,7 @@ extern "C" int msim_comm_init(msim_ctx *ctx, const unsigned char id[MSIM_COMM_ID
   if (!r.ok) { ctx->err = r.err; return MSIM_E_UNSUPPORTED; }
   MSIM_HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (ctx->comm) { (void)r.CommDestroy(static_cast<ncclComm_t>(ctx->comm)); ctx->comm = nullptr; }
-  if (ctx->d_sizes) { (void)hipFree(ctx->d_sizes); ctx->d_sizes = nullptr; }   // sized for the previous world
+  if (ctx->d_sizes) { (void)msim_dev_free(ctx->d_sizes); ctx->d_sizes = nullptr; }   // sized for the previous world
   ncclUniqueId u;
   std::memcpy(u.internal, id, MSIM_COMM_ID_BYTES);
   ncclComm_t comm = nullptr;
@@ -130,7 +130,7 @@ extern "C" int msim_gather(msim_ctx *ctx, int root, msim_gathered *out) {
   else {
     // (1) every rank learns every rank's four byte counts
     Rccl &r = rccl();
-    if (!ctx->d_sizes) MSIM_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_sizes), ((size_t)world + 1) * 4 * 8));
+    if (!ctx->d_sizes) MSIM_HIP_TRY(ctx, msim_dev_malloc(reinterpret_cast<void **>(&ctx->d_sizes), ((size_t)world + 1) * 4 * 8));
     uint64_t *d_mine = ctx->d_sizes + (size_t)world * 4;
     MSIM_HIP_TRY(ctx, hipMemcpyAsync(d_mine, mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream));
     MSIM_NCCL_TRY(ctx, r.AllGather(d_mine, ctx->d_sizes, 4, ncclUint64, static_cast<ncclComm_t>(ctx->comm), ctx->stream));

@@ -266,12 +266,12 @@ int kafka_dev_run(msim_ctx *ctx, KCParams kp, u32 n, const std::vector<msim_inst
   auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
   {   // tables no larger than the launch's histories need (kp.T: what the configuration / the checker's own bound allows)
     u32 *d_bound = nullptr, h_bound = 0;
-    MSIM_HIP_TRY(ctx, hipMalloc(&d_bound, 4));
+    MSIM_HIP_TRY(ctx, msim_dev_malloc(&d_bound, 4));
     hipError_t e = hipMemsetAsync(d_bound, 0, 4, st);
     if (e == hipSuccess) { hipLaunchKernelGGL(kafka_bound_kernel, dim3(n), dim3(NT), 0, st, kp, d_bound); e = hipGetLastError(); }
     if (e == hipSuccess) e = hipMemcpyAsync(&h_bound, d_bound, 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(d_bound);
+    (void)msim_dev_free(d_bound);
     MSIM_HIP_TRY(ctx, e);
     const u32 t = ((h_bound + 1u + 31u) & ~31u);
     if (t < kp.T) kp.T = t < 32u ? 32u : t;
@@ -364,10 +364,10 @@ extern "C" int msim_check_kafka_batch(int device, const msim_op *rows, const uin
   msim_op *d_rows = nullptr; u32 *d_pay = nullptr; uint64_t *d_ro = nullptr, *d_po = nullptr; msim_check_result *d_out = nullptr;
   int rc = MSIM_E_HIP;
   do {
-    if (hipMalloc(&d_rows, (size_t)(tr ? tr : 1) * sizeof(msim_op)) != hipSuccess) break;
-    if (hipMalloc(&d_pay, (size_t)(tw ? tw : 1) * 4) != hipSuccess) break;
-    if (hipMalloc(&d_ro, (size_t)(n_histories + 1) * 8) != hipSuccess || hipMalloc(&d_po, (size_t)(n_histories + 1) * 8) != hipSuccess) break;
-    if (hipMalloc(&d_out, (size_t)n_histories * sizeof(msim_check_result)) != hipSuccess) break;
+    if (msim_dev_malloc(&d_rows, (size_t)(tr ? tr : 1) * sizeof(msim_op)) != hipSuccess) break;
+    if (msim_dev_malloc(&d_pay, (size_t)(tw ? tw : 1) * 4) != hipSuccess) break;
+    if (msim_dev_malloc(&d_ro, (size_t)(n_histories + 1) * 8) != hipSuccess || msim_dev_malloc(&d_po, (size_t)(n_histories + 1) * 8) != hipSuccess) break;
+    if (msim_dev_malloc(&d_out, (size_t)n_histories * sizeof(msim_check_result)) != hipSuccess) break;
     if (tr && hipMemcpy(d_rows, rows, (size_t)tr * sizeof(msim_op), hipMemcpyHostToDevice) != hipSuccess) break;
     if (tw && payload && hipMemcpy(d_pay, payload, (size_t)tw * 4, hipMemcpyHostToDevice) != hipSuccess) break;
     if (hipMemcpy(d_ro, row_offsets, (size_t)(n_histories + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) break;
@@ -378,6 +378,6 @@ extern "C" int msim_check_kafka_batch(int device, const msim_op *rows, const uin
     kp.T = OFFS; kp.C = concurrency;
     rc = kafka_dev_run(ctx, kp, n_histories, nullptr, out, nullptr, n_host);
   } while (false);
-  for (void *q : {(void *)d_rows, (void *)d_pay, (void *)d_ro, (void *)d_po, (void *)d_out}) if (q) (void)hipFree(q);
+  for (void *q : {(void *)d_rows, (void *)d_pay, (void *)d_ro, (void *)d_po, (void *)d_out}) if (q) (void)msim_dev_free(q);
   return rc;
 }

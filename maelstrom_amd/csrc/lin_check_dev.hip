@@ -544,9 +544,9 @@ int lin_check_dev_run(msim_ctx *ctx, const LParams &lp0, u32 n, u32 max_rows_any
   hp.n_slots = n < 4096u ? n : 4096u;   // (a history claims one when a closure first outgrows the registers; without one it waits for pass 2)
   hp.pool = nullptr; hp.claim = nullptr; hp.trace = trace ? 1u : 0u;
   const size_t ws_bytes = (size_t)hp.n_slots * pool_words(hp.cap, hp.n_heads, hp.out_cap) * 4 + 256;
-  MSIM_HIP_TRY(ctx, hipMalloc(&hp.pool, ws_bytes));
+  MSIM_HIP_TRY(ctx, msim_dev_malloc(&hp.pool, ws_bytes));
   hp.claim = hp.pool + (ws_bytes - 256) / 4;
-  struct Ws { u32 *p; ~Ws() { if (p) (void)hipFree(p); } } ws_guard{hp.pool};
+  struct Ws { u32 *p; ~Ws() { if (p) (void)msim_dev_free(p); } } ws_guard{hp.pool};
   MSIM_HIP_TRY(ctx, hipMemsetAsync(hp.claim, 0, 4, st));
   hipLaunchKernelGGL(lin_check_kernel, dim3(n), dim3(64), fixed, st, lp, hp);
   MSIM_HIP_TRY(ctx, hipGetLastError());
@@ -582,7 +582,7 @@ int lin_check_dev_run(msim_ctx *ctx, const LParams &lp0, u32 n, u32 max_rows_any
       host_done[k] = 1;
     };
     u32 *d_list = nullptr, *ws2 = nullptr;
-    hipError_t e = hipMalloc(&d_list, todo.size() * 4);
+    hipError_t e = msim_dev_malloc(&d_list, todo.size() * 4);
     if (e == hipSuccess) e = hipMemcpyAsync(d_list, todo.data(), todo.size() * 4, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
       lp.list = d_list;
@@ -601,7 +601,7 @@ int lin_check_dev_run(msim_ctx *ctx, const LParams &lp0, u32 n, u32 max_rows_any
       g.cap = tiny ? 80u : 262144u; g.n_heads = tiny ? 64u : 65536u; g.out_cap = tiny ? 80u : 65536u;
       g.n_slots = (u32)std::min<size_t>(todo.size(), tiny ? 2 : 64);
       g.ws = nullptr; g.claim = nullptr;
-      e = hipMalloc(&ws2, (size_t)g.n_slots * pool_words(g.cap, g.n_heads, g.out_cap) * 4 + 256);
+      e = msim_dev_malloc(&ws2, (size_t)g.n_slots * pool_words(g.cap, g.n_heads, g.out_cap) * 4 + 256);
       if (e == hipSuccess) { g.ws = ws2; g.claim = ws2 + (size_t)g.n_slots * pool_words(g.cap, g.n_heads, g.out_cap); e = hipMemsetAsync(g.claim, 0, 4, st); }
       if (e == hipSuccess && l2 > 64 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lin_check_wg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
       if (e == hipSuccess) {
@@ -623,12 +623,12 @@ int lin_check_dev_run(msim_ctx *ctx, const LParams &lp0, u32 n, u32 max_rows_any
     }
     if (e == hipSuccess) e = hipMemcpyAsync(h2.data(), lp.out, (size_t)n * sizeof(msim_check_result), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (ws2) (void)hipFree(ws2);
+    if (ws2) (void)msim_dev_free(ws2);
     wanted.assign(order.size(), 0);
     if (e == hipSuccess) for (size_t k = 0; k < order.size(); k++) wanted[k] = h2[order[k]].valid == NEEDS_HOST;
     else std::fill(wanted.begin(), wanted.end(), 1);   // (the host can still do everything)
     const double t_dev = ms();
-    if (d_list) (void)hipFree(d_list);
+    if (d_list) (void)msim_dev_free(d_list);
     u32 n_host_needed = 0;
     for (size_t k = 0; k < order.size(); k++) n_host_needed += wanted[k] != 0;
     if (n_host_needed) {   // what even the HBM pools could not hold (or found no slot): the host search, all host threads
@@ -698,17 +698,17 @@ extern "C" int msim_check_lin_kv_batch(int device, const msim_op *rows, const ui
   msim_op *d_rows = nullptr; uint64_t *d_off = nullptr; msim_check_result *d_out = nullptr;
   int rc = MSIM_E_HIP;
   do {
-    if (hipMalloc(&d_rows, (size_t)(total ? total : 1) * sizeof(msim_op)) != hipSuccess) break;
-    if (hipMalloc(&d_off, (size_t)(n_histories + 1) * 8) != hipSuccess) break;
-    if (hipMalloc(&d_out, (size_t)n_histories * sizeof(msim_check_result)) != hipSuccess) break;
+    if (msim_dev_malloc(&d_rows, (size_t)(total ? total : 1) * sizeof(msim_op)) != hipSuccess) break;
+    if (msim_dev_malloc(&d_off, (size_t)(n_histories + 1) * 8) != hipSuccess) break;
+    if (msim_dev_malloc(&d_out, (size_t)n_histories * sizeof(msim_check_result)) != hipSuccess) break;
     if (total && hipMemcpy(d_rows, rows, (size_t)total * sizeof(msim_op), hipMemcpyHostToDevice) != hipSuccess) break;
     if (hipMemcpy(d_off, row_offsets, (size_t)(n_histories + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) break;
     LParams lp;
     lp.rows = d_rows; lp.meta = nullptr; lp.off = d_off; lp.out = d_out; lp.stride = 0; lp.table_rows = 0; lp.list = nullptr;
     rc = lin_check_dev_run(ctx, lp, n_histories, max_n, out, nullptr, nullptr);
   } while (false);
-  if (d_rows) (void)hipFree(d_rows);
-  if (d_off) (void)hipFree(d_off);
-  if (d_out) (void)hipFree(d_out);
+  if (d_rows) (void)msim_dev_free(d_rows);
+  if (d_off) (void)msim_dev_free(d_off);
+  if (d_out) (void)msim_dev_free(d_out);
   return rc;
 }

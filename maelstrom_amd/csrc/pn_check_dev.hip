@@ -172,13 +172,13 @@ extern "C" int msim_check_pn_batch(int device, const msim_op *rows, const uint32
   msim_op *d_rows = nullptr; msim_inst_meta *d_meta = nullptr; msim_check_result *d_out = nullptr;
   int rc = MSIM_E_HIP;
   do {
-    if (hipMalloc(&d_rows, (size_t)n_histories * max_rows * sizeof(msim_op)) != hipSuccess) break;
-    if (hipMalloc(&d_meta, (size_t)n_histories * sizeof(msim_inst_meta)) != hipSuccess) break;
-    if (hipMalloc(&d_out, (size_t)n_histories * sizeof(msim_check_result)) != hipSuccess) break;
+    if (msim_dev_malloc(&d_rows, (size_t)n_histories * max_rows * sizeof(msim_op)) != hipSuccess) break;
+    if (msim_dev_malloc(&d_meta, (size_t)n_histories * sizeof(msim_inst_meta)) != hipSuccess) break;
+    if (msim_dev_malloc(&d_out, (size_t)n_histories * sizeof(msim_check_result)) != hipSuccess) break;
     if (hipMemcpy(d_rows, rows, (size_t)n_histories * max_rows * sizeof(msim_op), hipMemcpyHostToDevice) != hipSuccess) break;
     if (hipMemcpy(d_meta, hm.data(), (size_t)n_histories * sizeof(msim_inst_meta), hipMemcpyHostToDevice) != hipSuccess) break;
     rc = pn_dev_run(ctx, d_rows, d_meta, d_out, max_rows, n_histories, out, nullptr, nullptr);
   } while (false);
-  for (void *q : {(void *)d_rows, (void *)d_meta, (void *)d_out}) if (q) (void)hipFree(q);
+  for (void *q : {(void *)d_rows, (void *)d_meta, (void *)d_out}) if (q) (void)msim_dev_free(q);
   return rc;
 }

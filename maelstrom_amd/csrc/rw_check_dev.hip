@@ -373,9 +373,9 @@ int rw_dev_run(msim_ctx *ctx, RParams rp, u32 n, const std::vector<msim_inst_met
   const u32 chunk = (u32)std::min<uint64_t>(n, std::max<uint64_t>(1, budget / (rp.ws_words * 4)));
   const size_t need = (size_t)chunk * rp.ws_words * 4;
   if (*ws_cap < need) {
-    if (*ws_buf) (void)hipFree(*ws_buf);
+    if (*ws_buf) (void)msim_dev_free(*ws_buf);
     *ws_buf = nullptr; *ws_cap = 0;
-    MSIM_HIP_TRY(ctx, hipMalloc(ws_buf, need));
+    MSIM_HIP_TRY(ctx, msim_dev_malloc(ws_buf, need));
     *ws_cap = need;
   }
   rp.ws = static_cast<u32 *>(*ws_buf);
@@ -466,10 +466,10 @@ extern "C" int msim_check_rw_batch(int device, const msim_op *rows, const uint64
   msim_op *d_rows = nullptr; u32 *d_pay = nullptr; uint64_t *d_ro = nullptr, *d_po = nullptr; msim_check_result *d_out = nullptr; void *ws = nullptr; size_t ws_cap = 0;
   int rc = MSIM_E_HIP;
   do {
-    if (hipMalloc(&d_rows, (size_t)(tr ? tr : 1) * sizeof(msim_op)) != hipSuccess) break;
-    if (hipMalloc(&d_pay, (size_t)(tw ? tw : 1) * 4) != hipSuccess) break;
-    if (hipMalloc(&d_ro, (size_t)(n_histories + 1) * 8) != hipSuccess || hipMalloc(&d_po, (size_t)(n_histories + 1) * 8) != hipSuccess) break;
-    if (hipMalloc(&d_out, (size_t)n_histories * sizeof(msim_check_result)) != hipSuccess) break;
+    if (msim_dev_malloc(&d_rows, (size_t)(tr ? tr : 1) * sizeof(msim_op)) != hipSuccess) break;
+    if (msim_dev_malloc(&d_pay, (size_t)(tw ? tw : 1) * 4) != hipSuccess) break;
+    if (msim_dev_malloc(&d_ro, (size_t)(n_histories + 1) * 8) != hipSuccess || msim_dev_malloc(&d_po, (size_t)(n_histories + 1) * 8) != hipSuccess) break;
+    if (msim_dev_malloc(&d_out, (size_t)n_histories * sizeof(msim_check_result)) != hipSuccess) break;
     if (tr && hipMemcpy(d_rows, rows, (size_t)tr * sizeof(msim_op), hipMemcpyHostToDevice) != hipSuccess) break;
     if (tw && hipMemcpy(d_pay, payload, (size_t)tw * 4, hipMemcpyHostToDevice) != hipSuccess) break;
     if (hipMemcpy(d_ro, row_offsets, (size_t)(n_histories + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) break;
@@ -480,6 +480,6 @@ extern "C" int msim_check_rw_batch(int device, const msim_op *rows, const uint64
     rp.nmax = max_r / 2 + 65; rp.emax = rp.nmax * 16; rp.cm = consistency_model; rp.proscribed = msim_proscribed_anomalies(consistency_model);
     rc = rw_dev_run(ctx, rp, n_histories, nullptr, out, nullptr, n_host, &ws, &ws_cap);
   } while (false);
-  for (void *q : {(void *)d_rows, (void *)d_pay, (void *)d_ro, (void *)d_po, (void *)d_out, ws}) if (q) (void)hipFree(q);
+  for (void *q : {(void *)d_rows, (void *)d_pay, (void *)d_ro, (void *)d_po, (void *)d_out, ws}) if (q) (void)msim_dev_free(q);
   return rc;
 }

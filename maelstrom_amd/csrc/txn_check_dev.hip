@@ -761,9 +761,9 @@ u32 lds_bytes_for(u32 nmax, u32 keys, u32 stride) {
 
 int grow_ws(msim_ctx *ctx, void **ws_buf, size_t *ws_cap, size_t need) {
   if (*ws_cap >= need) return MSIM_OK;
-  if (*ws_buf) (void)hipFree(*ws_buf);
+  if (*ws_buf) (void)msim_dev_free(*ws_buf);
   *ws_buf = nullptr; *ws_cap = 0;
-  MSIM_HIP_TRY(ctx, hipMalloc(ws_buf, need));
+  MSIM_HIP_TRY(ctx, msim_dev_malloc(ws_buf, need));
   *ws_cap = need;
   return MSIM_OK;
 }
@@ -805,7 +805,7 @@ int txn_dev_run(msim_ctx *ctx, TParams tp, u32 n, u32 cm, const std::vector<msim
   if (!big.empty()) {
     // pass 2: the histories whose tables do not fit LDS, tables in an HBM workspace
     u32 *d_list = nullptr;
-    MSIM_HIP_TRY(ctx, hipMalloc(&d_list, big.size() * 4));
+    MSIM_HIP_TRY(ctx, msim_dev_malloc(&d_list, big.size() * 4));
     MSIM_HIP_TRY(ctx, hipMemcpy(d_list, big.data(), big.size() * 4, hipMemcpyHostToDevice));
     tp.ws_words = ws_words_for(tp.nmax, tp.emax); tp.list = d_list;
     const u32 nb = (u32)big.size();
@@ -820,7 +820,7 @@ int txn_dev_run(msim_ctx *ctx, TParams tp, u32 n, u32 cm, const std::vector<msim
       }
     }
     if (rc == MSIM_OK && (hipMemcpyAsync(h_out, tp.out, (size_t)n * sizeof(msim_check_result), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) { rc = MSIM_E_HIP; ctx->err = "txn check: copy of the results"; }
-    (void)hipFree(d_list);
+    (void)msim_dev_free(d_list);
     if (rc != MSIM_OK) return rc;
     if (trace) std::fprintf(stderr, "[txn-check] HBM-table pass over %u histories: done at %.2f ms\n", nb, ms());
   }
@@ -900,10 +900,10 @@ extern "C" int msim_check_txn_batch(int device, const msim_op *rows, const uint6
   msim_op *d_rows = nullptr; u32 *d_pay = nullptr; uint64_t *d_ro = nullptr, *d_po = nullptr; msim_check_result *d_out = nullptr; void *ws = nullptr; size_t ws_cap = 0;
   int rc = MSIM_E_HIP;
   do {
-    if (hipMalloc(&d_rows, (size_t)(tr ? tr : 1) * sizeof(msim_op)) != hipSuccess) break;
-    if (hipMalloc(&d_pay, (size_t)(tw ? tw : 1) * 4) != hipSuccess) break;
-    if (hipMalloc(&d_ro, (size_t)(n_histories + 1) * 8) != hipSuccess || hipMalloc(&d_po, (size_t)(n_histories + 1) * 8) != hipSuccess) break;
-    if (hipMalloc(&d_out, (size_t)n_histories * sizeof(msim_check_result)) != hipSuccess) break;
+    if (msim_dev_malloc(&d_rows, (size_t)(tr ? tr : 1) * sizeof(msim_op)) != hipSuccess) break;
+    if (msim_dev_malloc(&d_pay, (size_t)(tw ? tw : 1) * 4) != hipSuccess) break;
+    if (msim_dev_malloc(&d_ro, (size_t)(n_histories + 1) * 8) != hipSuccess || msim_dev_malloc(&d_po, (size_t)(n_histories + 1) * 8) != hipSuccess) break;
+    if (msim_dev_malloc(&d_out, (size_t)n_histories * sizeof(msim_check_result)) != hipSuccess) break;
     if (tr && hipMemcpy(d_rows, rows, (size_t)tr * sizeof(msim_op), hipMemcpyHostToDevice) != hipSuccess) break;
     if (tw && hipMemcpy(d_pay, payload, (size_t)tw * 4, hipMemcpyHostToDevice) != hipSuccess) break;
     if (hipMemcpy(d_ro, row_offsets, (size_t)(n_histories + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) break;
@@ -914,6 +914,6 @@ extern "C" int msim_check_txn_batch(int device, const msim_op *rows, const uint6
     tp.lds_bytes = lds_bytes_for(tp.nmax, std::min<u32>(KMAX, tp.nmax * 2 + 16), 17);
     rc = txn_dev_run(ctx, tp, n_histories, MSIM_CM_STRICT_SERIALIZABLE, nullptr, out, nullptr, nullptr, &ws, &ws_cap);
   } while (false);
-  for (void *q : {(void *)d_rows, (void *)d_pay, (void *)d_ro, (void *)d_po, (void *)d_out, ws}) if (q) (void)hipFree(q);
+  for (void *q : {(void *)d_rows, (void *)d_pay, (void *)d_ro, (void *)d_po, (void *)d_out, ws}) if (q) (void)msim_dev_free(q);
   return rc;
 }

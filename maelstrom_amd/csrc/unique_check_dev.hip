@@ -160,9 +160,9 @@ static int unique_dev_run(msim_ctx *ctx, UParams up, u32 n, void **ws, size_t *w
   const u32 chunk = (u32)std::min<uint64_t>(n, std::max<uint64_t>(1, budget / ((uint64_t)slots * 8)));
   const size_t need = (size_t)chunk * slots * 8;
   if (*ws_cap < need) {
-    if (*ws) (void)hipFree(*ws);
+    if (*ws) (void)msim_dev_free(*ws);
     *ws = nullptr; *ws_cap = 0;
-    MSIM_HIP_TRY(ctx, hipMalloc(ws, need));
+    MSIM_HIP_TRY(ctx, msim_dev_malloc(ws, need));
     *ws_cap = need;
   }
   up.ws = static_cast<uint2 *>(*ws);
@@ -201,9 +201,9 @@ extern "C" int msim_check_unique_batch(int device, const msim_op *rows, const ui
   msim_op *d_rows = nullptr; msim_inst_meta *d_meta = nullptr; msim_check_result *d_out = nullptr; void *ws = nullptr; size_t ws_cap = 0;
   int rc = MSIM_E_HIP;
   do {
-    if (hipMalloc(&d_rows, (size_t)n_histories * max_rows * sizeof(msim_op)) != hipSuccess) break;
-    if (hipMalloc(&d_meta, (size_t)n_histories * sizeof(msim_inst_meta)) != hipSuccess) break;
-    if (hipMalloc(&d_out, (size_t)n_histories * sizeof(msim_check_result)) != hipSuccess) break;
+    if (msim_dev_malloc(&d_rows, (size_t)n_histories * max_rows * sizeof(msim_op)) != hipSuccess) break;
+    if (msim_dev_malloc(&d_meta, (size_t)n_histories * sizeof(msim_inst_meta)) != hipSuccess) break;
+    if (msim_dev_malloc(&d_out, (size_t)n_histories * sizeof(msim_check_result)) != hipSuccess) break;
     if (hipMemcpy(d_rows, rows, (size_t)n_histories * max_rows * sizeof(msim_op), hipMemcpyHostToDevice) != hipSuccess) break;
     if (hipMemcpy(d_meta, hm.data(), (size_t)n_histories * sizeof(msim_inst_meta), hipMemcpyHostToDevice) != hipSuccess) break;
     UParams up;
@@ -212,6 +212,6 @@ extern "C" int msim_check_unique_batch(int device, const msim_op *rows, const ui
     if (rc != MSIM_OK) break;
     rc = hipMemcpy(out, d_out, (size_t)n_histories * sizeof(msim_check_result), hipMemcpyDeviceToHost) == hipSuccess ? MSIM_OK : MSIM_E_HIP;
   } while (false);
-  for (void *q : {(void *)d_rows, (void *)d_meta, (void *)d_out, ws}) if (q) (void)hipFree(q);
+  for (void *q : {(void *)d_rows, (void *)d_meta, (void *)d_out, ws}) if (q) (void)msim_dev_free(q);
   return rc;
 }

@@ -18,3 +18,21 @@ def lib():
     from maelstrom_amd import build, _abi
     build.build(verbose=False)
     return _abi.load()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Under MSIM_GUARD (csrc/guard.cpp: fenced device slabs) the run ends with the count of bytes written outside any slab;
+    tools/guard_sweep.sh reads the line.  A damaged byte fails the session."""
+    if not os.environ.get("MSIM_GUARD"):
+        return
+    import ctypes as C
+    from maelstrom_amd import _abi
+    if _abi._lib is None:
+        return
+    lib = _abi._lib
+    lib.msim_guard_check.restype = C.c_ulonglong
+    n_allocs = C.c_ulonglong(0)
+    damaged = int(lib.msim_guard_check(C.byref(n_allocs)))
+    print(f"\n[msim guard] {damaged} damaged byte(s) around {n_allocs.value} slabs (MSIM_GUARD={os.environ['MSIM_GUARD']})")
+    if damaged:
+        session.exitstatus = 1

@@ -55,10 +55,12 @@ def emu_lib():
 
 @pytest.mark.timeout(1800)
 def test_kernel_sources_on_the_emulator_equal_the_oracle(emu_lib):
-    env = dict(os.environ, MSIM_LIB=emu_lib, HIPEMU_DIVERGENT="1")
+    # MSIM_GUARD=3: every device slab between two pattern-filled red zones (csrc/guard.cpp), verified when it is freed and at the end
+    env = dict(os.environ, MSIM_LIB=emu_lib, HIPEMU_DIVERGENT="1", MSIM_GUARD="3")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "emu_compare.py")] + CASES, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count(": OK") == len(CASES), r.stdout
+    assert "guard: 0 damaged byte(s)" in r.stdout, r.stdout[-2000:]
 
 
 @pytest.mark.timeout(1800)

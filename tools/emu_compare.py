@@ -78,6 +78,15 @@ def main():
         bad, n, to, te = compare(kw)
         print(f"{a}: {'OK' if not bad else 'MISMATCH'} ({n - bad}/{n} identical; oracle {to:.1f} s, engine {te:.1f} s)", flush=True)
         rc |= bad != 0
+    if os.environ.get("MSIM_GUARD"):   # fenced slabs (csrc/guard.cpp): bytes written outside a slab, over every case above
+        import ctypes as C
+        from maelstrom_amd import _abi
+        lib = _abi.load()
+        lib.msim_guard_check.restype = C.c_ulonglong
+        n_allocs = C.c_ulonglong(0)
+        damaged = int(lib.msim_guard_check(C.byref(n_allocs)))
+        print(f"guard: {damaged} damaged byte(s) around {n_allocs.value} slabs (MSIM_GUARD={os.environ['MSIM_GUARD']})", flush=True)
+        rc |= damaged != 0
     sys.exit(rc)
 
 
