@@ -40,7 +40,7 @@ enum { M_WRITE = 14, M_WRITE_OK, M_CAS, M_CAS_OK, M_ERROR, M_TXN = 23, M_TXN_OK 
 enum { S_GEN3 = 3 };
 enum { D_LIN = 0, D_LWW = 1 };
 // what dt_kernel<> defines (sim_kernel_dt.inc): capacities, stages, the words of a node's transaction — here without the save stack
-constexpr u32 DT_WAITQ = 8u, DT_MAXDEPTH = 40u, DT_MAXW = 256u, DT_NONE = 0xFFFFFFFFu, DT_RW = 12u, DT_AWAIT_US = 5000000u;
+constexpr u32 DT_WAITQ = 8u, DT_MAXDEPTH = 40u, DT_MAXW = 256u, DT_NONE = 0xFFFFFFFFu, DT_RW = 12u, DT_AWAIT_US = 5000000u, DT_CASQ = 4u;
 enum { DS_IDLE = 0, DS_ROOT, DS_LOAD, DS_SAVE, DS_CAS, DS_INIT_LEAF, DS_INIT_ROOT };
 enum { DC_STAGE = 0, DC_CMSG, DC_REF, DC_RPC, DC_P1, DC_RV, DC_T, DC_TARGET, DC_PSTART, DC_WLO, DC_WN, DC_WOUT, DC_J, DC_NOWN, DC_OWN /* 8 */, DC_WQN = DC_OWN + 8, DC_WQ /* DT_WAITQ x {client msg, txn ref} */,
        D8_CW = DC_WQ + 2 * DT_WAITQ };
@@ -123,6 +123,7 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
   unsigned char *const g_hash = reinterpret_cast<unsigned char *>(g_first + mv);   // [max_values] Tree.hash of the key
   u32 *const g_rec = g_first + mv + (mv + 3u) / 4u;                  // [N][TC][DT_RW] tree nodes by pointer
   u32 *const g_wl = g_rec + (size_t)N * TC * DT_RW;                  // [N][DT_MAXW] the pointers a node writes this round
+  u32 *const g_cas = g_wl + (size_t)N * DT_MAXW;                     // [N][DT_CASQ] x {msg_id, from, transaction}: what a node's cas requests carry beside `to`
   const u32 qlane = l <= N + 1u ? l : 0u;
   uint4 *const my_spill = reinterpret_cast<uint4 *>(g_scr + p.spill_off) + (size_t)qlane * tp.node_spill;
   uint4 *const my_cspill = reinterpret_cast<uint4 *>(g_scr + tp.client_spill_off) + (size_t)(is_node ? l : 0u) * tp.client_spill;
@@ -143,6 +144,7 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
   if (l == 0) gen[32] = p.cfg.key_count;
   if (real) {
     for (u32 i = l; i < mv; i += GS) { g_kvn[i] = 0; g_first[i] = DT_NONE; g_hash[i] = (unsigned char)d8_hash(i); }
+    for (u32 i = l; i < N * DT_CASQ * 3u; i += GS) g_cas[i] = 0;
   }
   __syncthreads();
 
@@ -155,6 +157,7 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
   u32 in_n = 0, sp_n = 0, node_msgid = 0, part = 0;
   u32 next_p = 0;                                      // node: @ptr (:332, :352-355)
   u32 wait_until = INF;                                // node: when the lock holder's Promise#await gives up (promise.rb:5,17-30), INF: not waiting
+  u32 casn = 0;                                        // node: cas requests so far
   u32 root = 0, root_exists = 0, cur_v = 0;            // lin-kv lane: the root pointer; versions so far
   u32 svc_ctr = 0;                                     // lww-kv lane: rand-int draws so far
   // ---- client state ----
@@ -708,7 +711,9 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
                 case DS_SAVE:
                   if (qb < cu[DC_WLO] || qb >= cu[DC_WLO] + cu[DC_WN]) break;
                   { const u32 left = cu[DC_WOUT] - 1u; cu[DC_WOUT] = left;
-                    if (left == 0u) { const u32 rid = ++node_msgid; cu[DC_STAGE] = DS_CAS; cu[DC_RPC] = rid; send1(D_LIN, M_CAS, cu[DC_T], rid); wait_until = T + DT_AWAIT_US; } }   // advance_root! (:376-388)
+                    if (left == 0u) { const u32 rid = ++node_msgid; cu[DC_STAGE] = DS_CAS; cu[DC_RPC] = rid;   // advance_root! (:376-388): cas root from the pointer read to the new one
+                      { u32 *const ce = g_cas + ((size_t)l * DT_CASQ + (casn++ % DT_CASQ)) * 3u; ce[0] = rid; ce[1] = cu[DC_P1]; ce[2] = cu[DC_REF]; }
+                      send1(D_LIN, M_CAS, cu[DC_T], rid); wait_until = T + DT_AWAIT_US; } }
                   break;
                 case DS_CAS:
                   if (qb != cu[DC_RPC]) break;
@@ -726,12 +731,17 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
           if (qtype == M_READ) {
             if (!root_exists) { o_type = M_ERROR; o_a = 20; } else { o_type = M_READ_OK; o_a = root; }
           } else if (qtype == M_WRITE) { root = qa; root_exists = 1u; o_type = M_WRITE_OK; o_a = 0; }
-          else {   // cas, no create_if_not_exists: the sender waits for this answer, its transaction is the one it holds
-            const u32 *const sc = curs_g + qsrc * D8_CW;
-            if (!root_exists) { o_type = M_ERROR; o_a = 20; }
-            else if (root != sc[DC_P1]) { o_type = M_ERROR; o_a = 22; }
+          else {   // cas, no create_if_not_exists.  The request is self-contained (:376-388): its `from` and its transaction come from the sender's
+            // table of cas requests under the msg_id, not from what the sender holds NOW (it may have given up on this cas and moved on)
+            u32 c_from = 0, c_ref = 0; bool c_hit = false;
+            { const u32 *const ce = g_cas + (size_t)qsrc * DT_CASQ * 3u;
+#pragma unroll
+              for (u32 i = 0; i < DT_CASQ; i++) { const u32 e0 = ce[3u * i], e1 = ce[3u * i + 1u], e2 = ce[3u * i + 2u]; if (e0 == qb) { c_hit = true; c_from = e1; c_ref = e2; } } }
+            if (!c_hit) { my_flags |= MSIM_FLAG_ARENA_OVERRUN; o_type = M_ERROR; o_a = 22; }   // engine capacity: DT_CASQ outstanding cas requests per node
+            else if (!root_exists) { o_type = M_ERROR; o_a = 20; }
+            else if (root != c_from) { o_type = M_ERROR; o_a = 22; }
             else {
-              const u32 ref = sc[DC_REF], off0 = ref & 0xFFFFFFu, n = ref >> 24, v = ++cur_v;
+              const u32 ref = c_ref, off0 = ref & 0xFFFFFFu, n = ref >> 24, v = ++cur_v;
               root = qa;
               for (u32 i = 0; i < n; i++) { const u32 w = g_pay[off0 + i];
                 if (w & 1u) { const u32 k = (w >> 1) & 0x7FFFu, c = g_kvn[k]; if (g_first[k] == DT_NONE) g_first[k] = v;

@@ -20,6 +20,26 @@ def lib():
     return _abi.load()
 
 
+_guard_seen = [0]
+
+
+@pytest.fixture(autouse=True)
+def _guard_after_every_test(request):
+    """Under MSIM_GUARD: the damaged-byte count after every test, so that a damaged zone names the test that ran over it."""
+    yield
+    if not os.environ.get("MSIM_GUARD"):
+        return
+    import ctypes as C
+    from maelstrom_amd import _abi
+    if _abi._lib is None:
+        return
+    _abi._lib.msim_guard_check.restype = C.c_ulonglong
+    damaged = int(_abi._lib.msim_guard_check(None))
+    if damaged != _guard_seen[0]:
+        print(f"\n[msim guard] {damaged - _guard_seen[0]} newly damaged byte(s) after {request.node.nodeid}", flush=True)
+        _guard_seen[0] = damaged
+
+
 def pytest_sessionfinish(session, exitstatus):
     """Under MSIM_GUARD (csrc/guard.cpp: fenced device slabs) the run ends with the count of bytes written outside any slab;
     tools/guard_sweep.sh reads the line.  A damaged byte fails the session."""

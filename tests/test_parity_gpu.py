@@ -323,6 +323,20 @@ def test_datomic_txn_parity(lib, kw):
     _compare(cfg, 0, 4)                     # one cluster per wavefront (dt_kernel<>)
 
 
+@pytest.mark.parametrize("kw,first", [
+    (dict(node_count=3, rate=20, time_limit=60, latency=1200, latency_dist="exponential", key_count=3), 4),   # instance 4: a cas served 5 s after it was sent, cas_ok
+    (dict(node_count=2, rate=15, time_limit=60, latency=1300, latency_dist="exponential"), 10),                # instances 14 and 18 likewise
+])
+def test_datomic_late_cas_parity(lib, kw, first):
+    """Latencies of seconds: a cas reaches lin-kv after its sender's Promise#await gave up and the sender holds the next transaction.  The request
+    is self-contained (datomic_list_append.rb:376-388: from / to travel in the message; here in the sender's table of cas requests under the msg_id),
+    so the service commits — or refuses — the transaction that SENT it, in the oracle (held to the reference classes on such runs by
+    tests/test_datomic_tree.py::test_a_cas_served_after_its_sender_gave_up_is_still_its_own) and in both kernels."""
+    cfg = E.test_config("txn-list-append", bin="datomic", seed=91, **kw)
+    _compare(cfg, first, 11, dev_flags=0x400)
+    _compare(cfg, first, 4)
+
+
 def test_deep_queues_spill_to_hbm(lib):
     """Exponential latency => long head-of-line sleeps => queues far deeper than the LDS part: the HBM spill area
     behind each node's queue keeps the result bit-identical (and unflagged)."""
