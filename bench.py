@@ -6,7 +6,8 @@
     way — or plainly as `python bench.py --gpus N`, which starts those N ranks itself; it refuses to run on fewer devices than N
     and never reports an n_gpus other than --gpus.)
 
-One "step" = one pass of the hot path over one batch: every rank simulates `--instances` (default 4096,
+One "step" = one pass of the hot path over one batch (steps are pipelined: `--in-flight` of them, default 3 for cfg2, are on the GPU
+together, each on its own engine context and HIP stream; all K start and end inside the timed region): every rank simulates `--instances` (default 4096,
 BASELINE.json configs[1]) independent broadcast test instances (25 nodes, grid topology, --rate 100,
 --time-limit 20 + 10 s quiesce + 25 final reads — the invocation of doc/03-broadcast/02-performance.md:87)
 to completion and runs the set-full checker over all emitted histories, everything resident in HBM.
@@ -75,9 +76,9 @@ def respawn_if_needed(args):
 
 def supervise(argv):
     """N = 1 outside a launcher: the measurement runs in a child process (`--worker`) and this process only forwards its one JSON line.
-    A GPU memory-access fault aborts the process it happens in (the round-4 driver run ended that way 2 s in, inside a secondary leg;
-    90 repeats of the same command on the same pool did not fault — tools/bench_flake_hunt.sh), and only a parent can still report
-    what had been measured by then.  The child notes its progress in a status file (MSIM_BENCH_STATUS): the headline once the timed
+    A GPU memory-access fault aborts the process it happens in (the round-4 driver run ended that way 2 s in — BENCH_r04.json holds no
+    stage marker, so where is not known; hundreds of repeats of the same command did not fault, and the hunt under fenced slabs is
+    tools/guard_sweep.sh / DESIGN.md §7), and only a parent can still report what had been measured by then.  The child notes its progress in a status file (MSIM_BENCH_STATUS): the headline once the timed
     region is over, then every secondary leg it enters.  If it dies, it is started again — without the leg it died in — at most
     twice; the line that is finally printed says so in `attempts`.  If no attempt gets through its legs, the headline of the last
     attempt that measured one is printed with the legs marked absent.  Nothing here touches the timed region."""
@@ -89,7 +90,11 @@ def supervise(argv):
         os.close(fd)
         env = dict(os.environ, MSIM_BENCH_STATUS=status)
         cmd = [sys.executable, os.path.abspath(__file__)] + list(argv) + ["--worker"] + skip
-        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+        try:   # a child hung in the timed region or in teardown (a GPU fault can hang as well as abort) must not hold the parent for ever
+            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, timeout=float(os.environ.get("MSIM_BENCH_CHILD_TIMEOUT", "900")))
+        except subprocess.TimeoutExpired as ex:   # (subprocess.run has killed the child by now)
+            r = subprocess.CompletedProcess(cmd, -9, stdout=ex.stdout or b"")
+            sys.stderr.write(f"[bench] attempt {attempt + 1}: the measuring process did not finish in {ex.timeout:.0f} s and was killed\n")
         lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
         notes = []
         try:
@@ -196,6 +201,7 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2", help="BASELINE.json config: cfg2 = the headline (broadcast n=25), cfg4 = lin-kv over Raft, 65536 instances over the job + RCCL history gather")
     ap.add_argument("--cpu-sample", type=float, default=10.0, help="seconds of CPU-oracle work for cpu_baseline (0 = skip)")
     ap.add_argument("--seed", type=int, default=2026)
+    ap.add_argument("--in-flight", type=int, default=0, help="steps in flight together, one engine context and HIP stream each (default: 3 for cfg2, 1 for cfg4)")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-fetch", action="store_true", help="skip the PCIe-inclusive leg (value_incl_fetch)")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)   # the measuring process under supervise()
@@ -254,30 +260,55 @@ def main():
 
     from maelstrom_amd import ensemble as EN
 
-    def step(k):
-        first = k * world * n + EN.shard(world * n, rank, world)[0]  # distinct instances for every (step, rank)
-        eng.run(first, n)     # simulate (blocking; kernel time from HIP events inside the library)
-        eng.check()           # the workload checker over the HBM-resident histories (cfg2: set-full; cfg4: per-key linearizability)
-        db = eng.device_buffers()
+    # Steps are pipelined: D engine contexts, each with its own HIP stream, hold the batches of steps k, k+1, .. k+D-1 in flight together.
+    # One launch of 4096 clusters is 2048 wavefronts — two per SIMD — and every one of them is a chain of dependent LDS round trips that
+    # nothing hides; with the next steps' wavefronts resident beside them the SIMDs have something to issue while a wavefront waits, and
+    # the tail of a launch (the slowest wavefront sets its duration) is filled by the head of the next (tools/cfg2_overlap.py:
+    # profiles/r06_cfg2_overlap.jsonl).  Every step is still one whole pass — simulate n instances, check every history — and all K of
+    # them start and end inside the timed region; --in-flight 1 is the one-batch-at-a-time run of the earlier rounds.
+    depth = max(1, min(args.in_flight or (3 if args.config == "cfg2" else 1), args.steps))
+    engs = [eng] + [E.Engine(cfg, device=local_rank) for _ in range(depth - 1)]
+    pending = [None] * depth      # per context: the step whose batch it holds
+    sim_ms, chk_ms = [], []
+
+    def retire(j):
+        e = engs[j]
+        e.check()             # waits for this context's simulation (same stream), then the workload checker over the HBM-resident histories (cfg2: set-full; cfg4: per-key linearizability)
+        db = e.device_buffers()
         stats = torch_view(db.stats, db.stats_bytes, torch.int64, dev).view(-1, 6)
         meta = torch_view(db.meta, db.meta_bytes, torch.int32, dev).view(-1, 8)
         chk = torch_view(db.check, db.check_bytes, torch.int32, dev).view(-1, 17)
         acc.add_(torch.stack([stats[:, 0].sum(), (chk[:, 0] == 1).sum(), (meta[:, 2] != 0).sum(),
                               meta[:, 0].sum(dtype=torch.int64), meta[:, 1].sum(dtype=torch.int64)]))
-        return eng.kernel_ms()
+        a, b = e.kernel_ms()  # this launch's duration from the HIP events on its own stream (other launches were in flight beside it)
+        sim_ms.append(a)
+        chk_ms.append(b)
+        pending[j] = None
+
+    def step(k):
+        j = k % depth
+        if pending[j] is not None:
+            retire(j)
+        first = k * world * n + EN.shard(world * n, rank, world)[0]  # distinct instances for every (step, rank)
+        engs[j].run_async(first, n)   # simulate, on the context's own stream
+        pending[j] = k
+
+    def drain():
+        for k, j in sorted((k, j) for j, k in enumerate(pending) if k is not None):
+            retire(j)
 
     for k in range(args.warmup):
         step(k)
+    drain()
     acc.zero_()
+    del sim_ms[:], chk_ms[:]
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
-    sim_ms, chk_ms = [], []
     t0 = time.perf_counter()
     for k in range(args.steps):
-        a, b = step(args.warmup + k)
-        sim_ms.append(a)
-        chk_ms.append(b)
+        step(args.warmup + k)
+    drain()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -328,7 +359,10 @@ def main():
         chk_avg = sum(chk_ms) / k
         # algorithmic bytes of one sim launch on this rank: 16 B/row + 4 B/payload word + 48 B stats
         b_alg = (16.0 * rows_tot + 4.0 * words_tot) / k + 48.0 * n
-        achieved = b_alg / (sim_avg * 1e-3) / 1e9
+        # `depth` launches of the kernel share the chip: a launch takes sim_avg from start to end while, on average, in_flight launches
+        # (= the launches' summed durations / the timed region) run beside each other — HBM sees in_flight launches' bytes per sim_avg
+        in_flight = min(float(depth), max(1.0, sum(sim_ms) * 1e-3 / elapsed)) if depth > 1 else 1.0
+        achieved = in_flight * b_alg / (sim_avg * 1e-3) / 1e9
         out = {
             "metric": "simulated_msgs_per_sec (histories/sec passing checker in histories_per_sec)",
             "value": msgs_all / elapsed,
@@ -351,10 +385,13 @@ def main():
             "checker_parity": "partial (doc vectors) for set-full, linearizability and list-append; pinned (pn_counter_test.clj) for the counters",
             "histories_checked": n * k * world, "histories_valid": valid_all, "instances_flagged": flagged_all,
             "msgs_per_instance": msgs_all / (n * k * world),
-            "kernel_ms": {"sim": sim_avg, "check": chk_avg},
+            "kernel_ms": {"sim": sim_avg, "check": chk_avg, "steps_in_flight": depth,
+                          "note": "per launch, HIP events on the launch's own stream; with steps_in_flight > 1 a launch shares the chip with the next steps' launches, so sim exceeds ms_per_step"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": kernel_text, "algorithmic_bytes_per_launch": b_alg},
+                         "kernel": kernel_text, "algorithmic_bytes_per_launch": b_alg,
+                         "launches_in_flight": in_flight, "achieved_per_launch": b_alg / (sim_avg * 1e-3) / 1e9,
+                         "how": "achieved = launches_in_flight x algorithmic_bytes_per_launch / the kernel's average launch duration (kernel_ms.sim); launches_in_flight = summed launch durations / timed region"},
         }
         # HBM bytes per launch and the instruction-issue picture from the PMC passes of the committed profile (counters cannot be
         # read inside this process): FETCH_SIZE x 2 + WRITE_SIZE, KiB -> bytes; SQ_* per launch (tools/profile_headline.sh ->
@@ -443,7 +480,8 @@ def main():
     if dist:
         dist.barrier()
         dist.destroy_process_group()
-    eng.close()
+    for e in engs:
+        e.close()
 
 
 def fetch_inclusive(E, cfg, torch, dev, local_rank, n, steps, first0, torch_view):

@@ -33,7 +33,10 @@ constexpr u32 GS = 8u;            // lanes per cluster
 #define D8_RQ 8u
 #endif
 constexpr u32 RQ = D8_RQ;         // LDS envelopes per node / service queue
-constexpr u32 CQ = 1u;            // LDS envelopes per client inbox
+#ifndef D8_CQ
+#define D8_CQ 1u
+#endif
+constexpr u32 CQ = D8_CQ;         // LDS envelopes per client inbox (0: the inbox lives in its HBM spill alone)
 constexpr u32 M8_CLIENT_CAP = 32u;
 constexpr u32 V_NIL = 0xFFFFu;
 enum { M_WRITE = 14, M_WRITE_OK, M_CAS, M_CAS_OK, M_ERROR, M_TXN = 23, M_TXN_OK = 24 };
@@ -42,16 +45,22 @@ enum { D_LIN = 0, D_LWW = 1 };
 // what dt_kernel<> defines (sim_kernel_dt.inc): capacities, stages, the words of a node's transaction — here without the save stack
 constexpr u32 DT_WAITQ = 8u, DT_MAXDEPTH = 40u, DT_MAXW = 256u, DT_NONE = 0xFFFFFFFFu, DT_RW = 12u, DT_AWAIT_US = 5000000u, DT_CASQ = 4u;
 enum { DS_IDLE = 0, DS_ROOT, DS_LOAD, DS_SAVE, DS_CAS, DS_INIT_LEAF, DS_INIT_ROOT };
-enum { DC_STAGE = 0, DC_CMSG, DC_REF, DC_RPC, DC_P1, DC_RV, DC_T, DC_TARGET, DC_PSTART, DC_WLO, DC_WN, DC_WOUT, DC_J, DC_NOWN, DC_OWN /* 8 */, DC_WQN = DC_OWN + 8, DC_WQ /* DT_WAITQ x {client msg, txn ref} */,
-       D8_CW = DC_WQ + 2 * DT_WAITQ };
-constexpr u32 D8_STK = 2u * (DT_MAXDEPTH + 1u);   // words of a node's save stack (HBM scratch, behind the clients' spill)
+// a node's transaction (the lock holder) in LDS.  DC_J packs the next micro-op, the appends applied so far and the new tree nodes they have
+// replaced again (j | appends << 8 | replaced << 16); DC_WQN the waiting transactions (count | ring head << 8; the ring itself is in HBM
+// scratch); DC_RC is the record of the working tree's ROOT — kind / range word + eight children — which every micro-op's walk starts from.
+enum { DC_STAGE = 0, DC_CMSG, DC_REF, DC_RPC, DC_P1, DC_RV, DC_T, DC_TARGET, DC_PSTART, DC_WLO, DC_WN, DC_WOUT, DC_J, DC_NOWN, DC_OWN /* 8 */, DC_WQN = DC_OWN + 8,
+       DC_RC /* 9 */, D8_CW = DC_RC + 9 };
+// a node's auxiliary words in HBM scratch (behind the clients' spill): the waiting ring (DT_WAITQ x {client msg, txn ref}), the walked path below
+// depth 2, and one position key per tree node the transaction has created (what save! sorts by)
+constexpr u32 D8_AUX_WQ = 0u, D8_AUX_PATH = 16u, D8_AUX_KEYS = 64u, D8_MAXNEW = 512u, D8_AUX = D8_AUX_KEYS + D8_MAXNEW + 4u;
+constexpr u32 D8_DEAD = 0xFFFFFFFFu;
 
 struct M8Params {
   KParams k;
   u32 n_inst;
   u32 off_cq, off_cur, off_gen, off_misc;               // LDS byte offsets (queues at 0)
   u32 node_spill, client_spill;                          // HBM spill entries per node-or-service queue / client inbox
-  u64 client_spill_off, stack_off;                       // word offsets inside the per-instance scratch: the clients' spill area, the nodes' save stacks
+  u64 client_spill_off, stack_off;                       // word offsets inside the per-instance scratch: the clients' spill area, the nodes' auxiliary words (D8_AUX each)
   u32 round_limit;
 };
 
@@ -129,7 +138,7 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
   uint4 *const my_cspill = reinterpret_cast<uint4 *>(g_scr + tp.client_spill_off) + (size_t)(is_node ? l : 0u) * tp.client_spill;
   const u32 my_spill_cap = l <= N + 1u ? tp.node_spill : 0u;
   const u32 my_node = is_node ? l : 0u;
-  u32 *const my_stk = g_scr + tp.stack_off + (size_t)my_node * D8_STK;
+  u32 *const aux = g_scr + tp.stack_off + (size_t)my_node * D8_AUX;
 
   uint4 *const my_q = reinterpret_cast<uint4 *>(smem) + lane;                                   // node / service queue: slot s at my_q[s * 64]
   uint4 *const my_cq = reinterpret_cast<uint4 *>(smem + tp.off_cq) + lane;                      // client inbox
@@ -468,17 +477,12 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
       u32 o1_type = 0, o1_a = 0, o1_b = 0, o_wlo = 0;
       u32 o_type = 0, o_a = 0, o_b = 0, o_to = 0, need_words = 0, done_ref = 0, done_rv = 0;   // service -> node; the completed transaction's payload
       auto rec_of = [&](u32 ptr) -> u32 * { return g_rec + ((size_t)(ptr >> 20) * TC + (ptr & 0xFFFFFu)) * DT_RW; };
-      auto is_new = [&](u32 ptr) -> bool { return (ptr >> 20) == l && (ptr & 0xFFFFFu) >= cu[DC_PSTART]; };
-      auto has_key = [&](u32 k) -> bool {   // the key is in the lineage of the working tree
-        if (g_first[k] <= cu[DC_RV]) return true;   // (DT_NONE is above every version)
-        const u32 no = cu[DC_NOWN];
-        for (u32 i = 0; i < no; i++) if (cu[DC_OWN + i] == k) return true;
-        return false;
-      };
       auto br_index = [&](u32 w0, u32 h) -> u32 {   // branch_index (:231-247) with the split's bounds (:170-181)
         const u32 lo = (w0 >> 8) & 0xFFu, hi = (w0 >> 16) & 0xFFu, bs = (hi - lo) / 8u;
-        for (u32 i = 0; i < 7u; i++) if (h < lo + (i + 1u) * bs) return i;
-        return 7u;
+        u32 r = 7u;
+#pragma unroll
+        for (u32 i = 7u; i-- > 0u;) r = h < lo + (i + 1u) * bs ? i : r;
+        return r;
       };
       auto send1 = [&](u32 dest, u32 type, u32 a, u32 b) { o_dest = dest; n_out = 1; o1_type = type; o1_a = a; o1_b = b; };
       auto start_txn = [&](u32 cmsg, u32 ref) {   // the lock is ours: current_tree (:358-365)
@@ -487,14 +491,13 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
         send1(D_LIN, M_READ, 0, rid);
         wait_until = T + DT_AWAIT_US;
       };
-      auto unlock = [&]() {   // the next waiting transaction takes the lock (:348, :371)
+      auto unlock = [&]() {   // the next waiting transaction takes the lock (:348, :371), in arrival order
         cu[DC_STAGE] = DS_IDLE;
         wait_until = INF;
-        const u32 wqn = cu[DC_WQN];
-        if (wqn) {
-          const u32 cmsg = cu[DC_WQ], ref = cu[DC_WQ + 1];
-          for (u32 i = 1; i < wqn; i++) { cu[DC_WQ + 2 * (i - 1)] = cu[DC_WQ + 2 * i]; cu[DC_WQ + 2 * (i - 1) + 1] = cu[DC_WQ + 2 * i + 1]; }
-          cu[DC_WQN] = wqn - 1;
+        const u32 wq = cu[DC_WQN], cnt = wq & 0xFFu, head = wq >> 8;
+        if (cnt) {
+          const u32 cmsg = aux[D8_AUX_WQ + 2u * head], ref = aux[D8_AUX_WQ + 2u * head + 1u];
+          cu[DC_WQN] = (cnt - 1u) | (((head + 1u) & (DT_WAITQ - 1u)) << 8);
           start_txn(cmsg, ref);
         }
       };
@@ -504,125 +507,39 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
         send1(D_LWW, M_READ, ptr, rid);
         wait_until = T + DT_AWAIT_US;
       };
-      // walks to the key's leaf; the first tree node on the way that has to be fetched, DT_NONE if the path is in memory.  One round trip per
-      // level: a record's kind / range, its flags word (which nodes have loaded it) and its eight children are loaded together.
-      auto descend = [&](u32 k) -> u32 {
-        const u32 h = g_hash[k];
-        u32 pt = cu[DC_T];
-        for (u32 d = 0; d < DT_MAXDEPTH; d++) {
-          const u32 *const r = rec_of(pt);
-          const u32 w0 = r[0], w3 = __hip_atomic_load(r + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (word 3 is the one word of a record that changes after its creation, by L2 atomics: read past the L1)
-          u32 ch[8];
-#pragma unroll
-          for (u32 c = 0; c < 8u; c++) ch[c] = r[4u + c];
-          if (!is_new(pt) && !((w3 >> (2u + l)) & 1u)) return pt;   // neither created by this transaction nor loaded by this node
-          if ((w0 & 1u) == 0u) return DT_NONE;
-          const u32 ci = br_index(w0, h);
-          pt = ch[0];
-#pragma unroll
-          for (u32 c = 1; c < 8u; c++) pt = c == ci ? ch[c] : pt;
-        }
-        my_flags |= MSIM_FLAG_ARENA_OVERRUN;
-        return DT_NONE;
+      // Where a tree node sits decides when save! writes it: children before their parent, siblings by child index (:291-320) — ascending
+      // in this key.  Positions are (c0, c1, then the chain): a 128-wide root splits into 16-wide ranges, those into 2-wide ones, and a
+      // 2-wide range can only hand everything to its LAST child (branch_index, :231-247), so below depth 2 a path is all sevens: the spine
+      // node at depth 2 + m gets 1023 - m (deeper first), its seven empty siblings 8 m + i (before every spine node).  An absent digit
+      // (the node IS the c0 / c1 subtree's root) is 8 / 1023: after everything below it.
+      auto poskey = [&](u32 d, u32 c0, u32 c1) -> u32 { return d == 0u ? ((8u << 14) | (8u << 10) | 1023u) : d == 1u ? ((c0 << 14) | (8u << 10) | 1023u) : ((c0 << 14) | (c1 << 10) | (1023u - (d - 2u))); };
+      auto childkey = [&](u32 n, u32 i, u32 c0, u32 c1) -> u32 {   // child i of the node at depth n of that path
+        if (n == 0u) return (i << 14) | (8u << 10) | 1023u;
+        if (n == 1u) return (c0 << 14) | (i << 10) | 1023u;
+        return (c0 << 14) | (c1 << 10) | (i == 7u ? 1023u - (n - 1u) : (n - 1u) * 8u + i);
       };
-      // assoc (:158-197, :256-268) along a path that is in memory.  New pointers go leaf first, then upwards: with n branches above a
-      // leaf level of L new nodes (1, or 8 leaves + their branch) the leaf level takes base+1 .. base+L, the branch at depth i
-      // base+L+(n-i) — known before the walk down that writes the copies.
-      auto assoc = [&](u32 k) {
-        const u32 h = g_hash[k];
-        u32 n = 0, pt = cu[DC_T];
-        for (; n + 1u < DT_MAXDEPTH; n++) {
-          const u32 *const r = rec_of(pt);
-          const u32 w0 = r[0];
-          u32 ch[8];
-#pragma unroll
-          for (u32 c = 0; c < 8u; c++) ch[c] = r[4u + c];
-          if ((w0 & 1u) == 0u) break;
-          const u32 ci = br_index(w0, h);
-          pt = ch[0];
-#pragma unroll
-          for (u32 c = 1; c < 8u; c++) pt = c == ci ? ch[c] : pt;
-        }
-        const u32 *const lf = rec_of(pt);
-        const u32 lw0 = lf[0], lcount = lf[1];
-        if (lw0 & 1u) { my_flags |= MSIM_FLAG_ARENA_OVERRUN; return; }
-        const bool has = has_key(k);
-        const u32 L = (has || lcount < 8u) ? 1u : 9u, base = next_p, ver = cu[DC_RV] + 1u;
-        if (base + L + n >= TC) { my_flags |= MSIM_FLAG_ARENA_OVERRUN; return; }   // engine capacity
-        const u32 lo = (lw0 >> 8) & 0xFFu, hi = (lw0 >> 16) & 0xFFu;
-        auto put = [&](u32 idx, u32 w0, u32 cnt) -> u32 * { u32 *const r = g_rec + ((size_t)l * TC + idx) * DT_RW; r[0] = w0; r[1] = cnt; r[2] = ver; __hip_atomic_store(r + 3, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return r; };   // (word 3: lww-kv replica in bits 0-1, 3 = not written; bit 2 + i: node i has loaded it)
-        if (L == 1u) put(base + 1u, lw0, lcount + (has ? 0u : 1u));
-        else {   // eight leaves under a new branch: the lineage's keys of this range (and the new one) by sub-range
-          const u32 bs = (hi - lo) / 8u, nk = gen[32];
-          u64 c_lo = 0, c_hi = 0;   // 4 x 16-bit counters each
-          for (u32 q = 0; q < nk; q++) {
-            if (q != k && !has_key(q)) continue;
-            const u32 hq = g_hash[q];
-            if (hq < lo || hq >= hi) continue;
-            const u32 ci = bs ? min((hq - lo) / bs, 7u) : 7u;
-            if (ci < 4u) c_lo += 1ull << (16u * ci); else c_hi += 1ull << (16u * (ci - 4u));
-          }
-          u32 *const br = put(base + 9u, 1u | (lo << 8) | (hi << 16), 0u);
-          for (u32 i = 0; i < 8u; i++) {
-            const u32 b_lo = lo + i * bs, b_hi = i == 7u ? hi : b_lo + bs;
-            const u32 cnt = (u32)((i < 4u ? c_lo >> (16u * i) : c_hi >> (16u * (i - 4u))) & 0xFFFFu);
-            put(base + 1u + i, (b_lo << 8) | (b_hi << 16), cnt);
-            br[4u + i] = (l << 20) | (base + 1u + i);
-          }
-        }
-        pt = cu[DC_T];
-        for (u32 i = 0; i < n; i++) {   // a copy of every branch above, pointing at the new child
-          const u32 *const r = rec_of(pt);
-          const u32 w0 = r[0], ci = br_index(w0, h);
-          u32 ch[8];
-#pragma unroll
-          for (u32 c = 0; c < 8u; c++) ch[c] = r[4u + c];
-          u32 *const nr = put(base + L + (n - i), w0, 0u);
-          const u32 child_new = (l << 20) | (i + 1u == n ? base + L : base + L + (n - i - 1u));
-#pragma unroll
-          for (u32 c = 0; c < 8u; c++) nr[4u + c] = c == ci ? child_new : ch[c];
-          pt = ch[0];
-#pragma unroll
-          for (u32 c = 1; c < 8u; c++) pt = c == ci ? ch[c] : pt;
-        }
-        next_p = base + L + n;
-        cu[DC_T] = (l << 20) | next_p;
-        if (!has) { const u32 no = cu[DC_NOWN]; if (no < 8u) { cu[DC_OWN + no] = k; cu[DC_NOWN] = no + 1u; } }
-      };
-      // save! (:212-224, :291-320): the new tree nodes the final tree reaches, children before their parent.  A stack entry is a tree node and
-      // the mask of its new children still to visit (a branch's eight children are loaded together: one round trip per visit).
-      auto save = [&]() {
-        u32 *const stk = my_stk;
-        u32 sp = 1, wn = 0;
-        const u32 wlo = node_msgid + 1u;
-        stk[0] = cu[DC_T]; stk[1] = 0x100u;   // (0x100: not looked at yet)
-        while (sp) {
-          const u32 pt = stk[2u * (sp - 1u)];
-          u32 mask = stk[2u * (sp - 1u) + 1u];
-          const u32 *const r = rec_of(pt);
-          const u32 w0 = r[0];
-          u32 ch[8];
-#pragma unroll
-          for (u32 c = 0; c < 8u; c++) ch[c] = r[4u + c];
-          if (mask & 0x100u) {
-            mask = 0;
-            if (w0 & 1u) {
-#pragma unroll
-              for (u32 c = 0; c < 8u; c++) mask |= is_new(ch[c]) ? 1u << c : 0u;
+      // save! (:212-224, :291-320): the new tree nodes the final tree reaches, children before their parent.  Nothing is walked: every node the
+      // transaction created left its position key in aux[], a node whose position a later copy took is marked dead there, and a live node's
+      // place in the write list is the number of live keys below its own.  One append alone: creation order IS that order (leaf level first, then upwards).
+      auto save = [&](u32 napp, u32 ndead) {
+        const u32 pstart = cu[DC_PSTART], M = next_p + 1u - pstart, wlo = node_msgid + 1u;
+        u32 wn = M - ndead;
+        if (wn > DT_MAXW) { my_flags |= MSIM_FLAG_ARENA_OVERRUN; wn = DT_MAXW; }
+        if (napp == 1u) {
+          for (u32 i = 0; i < wn; i++) my_wl[i] = (l << 20) | (pstart + i);
+        } else {
+          u32 *const nk = aux + D8_AUX_KEYS;
+          nk[M] = D8_DEAD; nk[M + 1u] = D8_DEAD; nk[M + 2u] = D8_DEAD;   // (the rank loop reads four keys at a time)
+          for (u32 i = 0; i < M; i++) {
+            const u32 ki = nk[i];
+            if (ki == D8_DEAD) continue;
+            u32 rank = 0;
+            for (u32 j4 = 0; j4 < M; j4 += 4u) {
+              const uint4 q = *reinterpret_cast<const uint4 *>(nk + j4);
+              rank += (q.x < ki ? 1u : 0u) + (q.y < ki ? 1u : 0u) + (q.z < ki ? 1u : 0u) + (q.w < ki ? 1u : 0u);
             }
+            if (rank < DT_MAXW) my_wl[rank] = (l << 20) | (pstart + i);
           }
-          if (mask) {
-            const u32 ci = (u32)__builtin_ctz(mask);
-            u32 nxt = ch[0];
-#pragma unroll
-            for (u32 c = 1; c < 8u; c++) nxt = c == ci ? ch[c] : nxt;
-            stk[2u * (sp - 1u) + 1u] = mask & (mask - 1u);
-            if (sp > DT_MAXDEPTH) { my_flags |= MSIM_FLAG_ARENA_OVERRUN; stk[2u * (sp - 1u) + 1u] = 0; continue; }
-            stk[2u * sp] = nxt; stk[2u * sp + 1u] = 0x100u; sp++;
-            continue;
-          }
-          if (wn >= DT_MAXW) my_flags |= MSIM_FLAG_ARENA_OVERRUN; else my_wl[wn++] = pt;
-          sp--;
         }
         node_msgid += wn;
         cu[DC_STAGE] = DS_SAVE; cu[DC_WLO] = wlo; cu[DC_WN] = wn; cu[DC_WOUT] = wn;
@@ -643,20 +560,148 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
           }
         }
       };
-      // apply_txn (:391-415) from micro-op j on; stops at the first tree node that has to be fetched
+      // apply_txn (:391-415) from micro-op j on; stops at the first tree node that has to be fetched.  ONE walk per micro-op: t[k] (:231-247, for an
+      // append too: `t[k].clone`, :405) goes from the root record in LDS down through one record per level — kind / range, key count, "loaded by"
+      // flags and the eight children in one round trip — and leaves behind what assoc (:158-197, :256-268) needs: the leaf's record, the path's
+      // pointers (depth 1 and 2 in registers, a chain's below that in aux[]) and its child indices; the copies of the branches above are then read
+      // at known addresses (independent loads) and written with the new pointers, which are known before anything is written: new pointers go
+      // leaf first, then upwards (new_ptr, :352-355) — with n branches above a leaf level of L new nodes (1, or 8 leaves + their branch) the leaf
+      // level takes base+1 .. base+L, the branch at depth i base+L+(n-i).
       auto apply = [&]() {
-        const u32 ref = cu[DC_REF], off0 = ref & 0xFFFFFFu, n = ref >> 24;
-        u32 j = cu[DC_J];
-        while (j < n) {
+        const u32 ref = cu[DC_REF], off0 = ref & 0xFFFFFFu, nm = ref >> 24;
+        const u32 rv = cu[DC_RV], pstart = cu[DC_PSTART];
+        const u32 jw = cu[DC_J];
+        u32 j = jw & 0xFFu, napp = (jw >> 8) & 0xFFu, ndead = jw >> 16;
+        u32 troot = cu[DC_T];
+        u32 *const nk = aux + D8_AUX_KEYS;
+        auto is_new = [&](u32 ptr) -> bool { return (ptr >> 20) == l && (ptr & 0xFFFFFu) >= pstart; };
+        while (j < nm) {
           const u32 w = g_pay[off0 + j], k = (w >> 1) & 0x7FFFu;
-          const u32 miss = descend(k);   // t[k] — for an append too (:405)
-          if (miss != DT_NONE) { cu[DC_J] = j; load(miss); return; }
-          if (w & 1u) assoc(k);
+          const u32 h = g_hash[k], first = g_first[k];
+          u32 d = 0, pt = troot, c0 = 0, c1 = 0, pa = 0, pb = 0;
+          u32 w0 = cu[DC_RC], w1 = 0;
+          bool miss = false, deep = false;
+          if ((w0 & 1u) == 0u) w1 = rec_of(pt)[1];   // the root is a leaf (the first few transactions of a run): its key count
+          else {
+            c0 = br_index(w0, h);
+            pt = cu[DC_RC + 1u + c0]; d = 1u;
+            for (;;) {
+              const u32 *const r = rec_of(pt);
+              const u32 w3 = __hip_atomic_load(r + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (word 3 is the one word of a record that changes after its creation, by L2 atomics: read past the L1)
+              w0 = r[0]; w1 = r[1];
+              u32 ch[8];
+#pragma unroll
+              for (u32 c = 0; c < 8u; c++) ch[c] = r[4u + c];
+              if (!is_new(pt) && !((w3 >> (2u + l)) & 1u)) { miss = true; break; }   // neither created by this transaction nor loaded by this node
+              if (d >= DT_MAXDEPTH) { deep = true; break; }   // engine capacity
+              if ((w0 & 1u) == 0u) break;   // the key's leaf
+              const u32 ci = br_index(w0, h);
+              if (d == 1u) { c1 = ci; pa = pt; } else if (d == 2u) pb = pt; else aux[D8_AUX_PATH + d] = pt;
+              pt = ch[0];
+#pragma unroll
+              for (u32 c = 1; c < 8u; c++) pt = c == ci ? ch[c] : pt;
+              d++;
+            }
+          }
+          if (miss) { cu[DC_J] = j | (napp << 8) | (ndead << 16); cu[DC_T] = troot; load(pt); return; }
+          if (deep) my_flags |= MSIM_FLAG_ARENA_OVERRUN;
+          else if (w & 1u) {   // assoc
+            const u32 n = d, lw0 = w0, lcount = w1;
+            bool has = first <= rv;   // (DT_NONE is above every version)
+            { const u32 no = cu[DC_NOWN]; for (u32 i = 0; i < no; i++) has = has || cu[DC_OWN + i] == k; }
+            const u32 L = (has || lcount < 8u) ? 1u : 9u, base = next_p, ver = rv + 1u;
+            if (base + L + n >= TC || base + L + n - pstart >= D8_MAXNEW) my_flags |= MSIM_FLAG_ARENA_OVERRUN;   // engine capacity
+            else {
+              auto put = [&](u32 idx, u32 pw0, u32 cnt, u32 key) -> u32 * {   // (word 3: lww-kv replica in bits 0-1, 3 = not written; bit 2 + i: node i has loaded it)
+                u32 *const r = g_rec + ((size_t)l * TC + idx) * DT_RW; r[0] = pw0; r[1] = cnt; r[2] = ver; __hip_atomic_store(r + 3, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                nk[idx - pstart] = key; return r; };
+              auto dies = [&](u32 ptr) { if (is_new(ptr)) { nk[(ptr & 0xFFFFFu) - pstart] = D8_DEAD; ndead++; } };   // its position is taken by a node created now
+              // the copies' sources at depth 1 and 2, at known addresses: in flight together
+              u32 wa = 0, wb = 0, cha[8], chb[8];
+              if (n >= 2u) { const u32 *const r = rec_of(pa); wa = r[0];
+#pragma unroll
+                for (u32 c = 0; c < 8u; c++) cha[c] = r[4u + c]; }
+              if (n >= 3u) { const u32 *const r = rec_of(pb); wb = r[0];
+#pragma unroll
+                for (u32 c = 0; c < 8u; c++) chb[c] = r[4u + c]; }
+              dies(pt);
+              const u32 lo = (lw0 >> 8) & 0xFFu, hi = (lw0 >> 16) & 0xFFu;
+              if (L == 1u) put(base + 1u, lw0, lcount + (has ? 0u : 1u), poskey(n, c0, c1));
+              else {   // eight leaves under a new branch: the lineage's keys of this range (and the new one) by sub-range
+                const u32 bs = (hi - lo) / 8u, nkeys = gen[32];
+                u64 c_lo = 0, c_hi = 0;   // 4 x 16-bit counters each
+                for (u32 q0 = 0; q0 < nkeys; q0 += 4u) {   // four keys per round trip
+                  u32 f4[4], h4[4];
+#pragma unroll
+                  for (u32 t = 0; t < 4u; t++) { const u32 q = min(q0 + t, nkeys - 1u); f4[t] = g_first[q]; h4[t] = g_hash[q]; }
+#pragma unroll
+                  for (u32 t = 0; t < 4u; t++) {
+                    const u32 q = q0 + t;
+                    if (q >= nkeys) continue;
+                    bool in = q == k || f4[t] <= rv;
+                    { const u32 no = cu[DC_NOWN]; for (u32 i = 0; i < no; i++) in = in || cu[DC_OWN + i] == q; }
+                    const u32 hq = h4[t];
+                    if (!in || hq < lo || hq >= hi) continue;
+                    const u32 ci = bs ? min((hq - lo) / bs, 7u) : 7u;
+                    if (ci < 4u) c_lo += 1ull << (16u * ci); else c_hi += 1ull << (16u * (ci - 4u));
+                  }
+                }
+                u32 *const br = put(base + 9u, 1u | (lo << 8) | (hi << 16), 0u, poskey(n, c0, c1));
+                for (u32 i = 0; i < 8u; i++) {
+                  const u32 b_lo = lo + i * bs, b_hi = i == 7u ? hi : b_lo + bs;
+                  const u32 cnt = (u32)((i < 4u ? c_lo >> (16u * i) : c_hi >> (16u * (i - 4u))) & 0xFFFFu);
+                  put(base + 1u + i, (b_lo << 8) | (b_hi << 16), cnt, childkey(n, i, c0, c1));
+                  br[4u + i] = (l << 20) | (base + 1u + i);
+                }
+                if (n == 0u) { cu[DC_RC] = 1u | (lo << 8) | (hi << 16); for (u32 i = 0; i < 8u; i++) cu[DC_RC + 1u + i] = (l << 20) | (base + 1u + i); }   // the new root is this branch
+              }
+              // a copy of every branch above, pointing at the new child (:256-268)
+              for (u32 i = n; i-- > 0u;) {
+                const u32 child_new = (l << 20) | (i + 1u == n ? base + L : base + L + (n - i - 1u));
+                const u32 idx = base + L + (n - i);
+                if (i == 0u) {   // the root: its record is in LDS, and stays there as the new root's
+                  dies(troot);
+                  const u32 rw0 = cu[DC_RC];
+                  u32 *const nr = put(idx, rw0, 0u, poskey(0u, c0, c1));
+                  cu[DC_RC + 1u + c0] = child_new;
+#pragma unroll
+                  for (u32 c = 0; c < 8u; c++) nr[4u + c] = cu[DC_RC + 1u + c];
+                } else if (i == 1u) {
+                  dies(pa);
+                  u32 *const nr = put(idx, wa, 0u, poskey(1u, c0, c1));
+#pragma unroll
+                  for (u32 c = 0; c < 8u; c++) nr[4u + c] = c == c1 ? child_new : cha[c];
+                } else if (i == 2u) {
+                  dies(pb);
+                  const u32 ci = br_index(wb, h);
+                  u32 *const nr = put(idx, wb, 0u, poskey(2u, c0, c1));
+#pragma unroll
+                  for (u32 c = 0; c < 8u; c++) nr[4u + c] = c == ci ? child_new : chb[c];
+                } else {   // a chain below depth 2: one link at a time
+                  const u32 pp = aux[D8_AUX_PATH + i];
+                  dies(pp);
+                  const u32 *const r = rec_of(pp);
+                  const u32 xw0 = r[0], ci = br_index(xw0, h);
+                  u32 ch[8];
+#pragma unroll
+                  for (u32 c = 0; c < 8u; c++) ch[c] = r[4u + c];
+                  u32 *const nr = put(idx, xw0, 0u, poskey(i, c0, c1));
+#pragma unroll
+                  for (u32 c = 0; c < 8u; c++) nr[4u + c] = c == ci ? child_new : ch[c];
+                }
+              }
+              if (n == 0u && L == 1u) { /* the root stays a leaf: its record in LDS (kind / range) is unchanged */ }
+              next_p = base + L + n;
+              troot = (l << 20) | next_p;
+              napp++;
+              if (!has) { const u32 no = cu[DC_NOWN]; if (no < 8u) { cu[DC_OWN + no] = k; cu[DC_NOWN] = no + 1u; } }
+            }
+          }
           j++;
         }
-        cu[DC_J] = j;
-        if (cu[DC_T] == cu[DC_P1]) { do_reply_ok = true; do_unlock = true; return; }   // nothing appended: no write, no cas
-        save();
+        cu[DC_J] = j | (napp << 8) | (ndead << 16); cu[DC_T] = troot;
+        if (troot == cu[DC_P1]) { do_reply_ok = true; do_unlock = true; return; }   // nothing appended: no write, no cas
+        save(napp, ndead);
       };
 
       const bool await_over = normal && is_node && wait_until <= T;   // a node's due timer comes before its due message
@@ -683,9 +728,9 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
               } break;
             case M_TXN:
               if (st == DS_IDLE) start_txn(qb, qa);
-              else { const u32 wqn = cu[DC_WQN];
-                if (wqn == DT_WAITQ) my_flags |= MSIM_FLAG_ARENA_OVERRUN;
-                else { cu[DC_WQ + 2u * wqn] = qb; cu[DC_WQ + 2u * wqn + 1u] = qa; cu[DC_WQN] = wqn + 1u; } }
+              else { const u32 wq = cu[DC_WQN], cnt = wq & 0xFFu;
+                if (cnt == DT_WAITQ) my_flags |= MSIM_FLAG_ARENA_OVERRUN;
+                else { const u32 slot = ((wq >> 8) + cnt) & (DT_WAITQ - 1u); aux[D8_AUX_WQ + 2u * slot] = qb; aux[D8_AUX_WQ + 2u * slot + 1u] = qa; cu[DC_WQN] = wq + 1u; } }
               break;
             case M_READ_OK: case M_WRITE_OK: case M_CAS_OK: case M_ERROR:
               switch (st) {
@@ -701,7 +746,15 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
                   if (qb != cu[DC_RPC]) break;
                   if (qtype != M_READ_OK) { rep = true; r_type = M_ERROR; r_a = 14; r_b = cu[DC_CMSG]; do_unlock = true; break; }   // "Unsure how to handle" (:364)
                   cu[DC_P1] = qa; cu[DC_T] = qa; cu[DC_PSTART] = next_p + 1u;
-                  { const u32 *const rr = rec_of(qa); const u32 rv2 = rr[2], rw3 = __hip_atomic_load(rr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); cu[DC_RV] = rv2; if ((rw3 >> (2u + l)) & 1u) do_apply = true; else load(qa); }
+                  { const u32 *const rr = rec_of(qa);   // the root's record stays in LDS for the walks of this transaction (its content never changes)
+                    const u32 rw0 = rr[0], rv2 = rr[2], rw3 = __hip_atomic_load(rr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    u32 rch[8];
+#pragma unroll
+                    for (u32 c = 0; c < 8u; c++) rch[c] = rr[4u + c];
+                    cu[DC_RV] = rv2; cu[DC_RC] = rw0;
+#pragma unroll
+                    for (u32 c = 0; c < 8u; c++) cu[DC_RC + 1u + c] = rch[c];
+                    if ((rw3 >> (2u + l)) & 1u) do_apply = true; else load(qa); }
                   break;
                 case DS_LOAD:
                   if (qb != cu[DC_RPC]) break;
@@ -930,9 +983,9 @@ bool msim_dt8_eligible(const msim_config &c) {
 }
 
 // Extra per-instance scratch words behind the queues' spill area: what of the LDS queues of dt_kernel<> does not fit this kernel's RQ slots,
-// the clients' spill, the nodes' save stacks.
+// the clients' spill, the nodes' auxiliary words (waiting ring, path, position keys).
 uint64_t msim_dt8_extra_scratch_words(const msim_config &c) {
-  return ((uint64_t)(c.n_nodes + 2) * c.inbox_capacity + (uint64_t)c.n_nodes * M8_CLIENT_CAP) * 4 + (((uint64_t)c.n_nodes * D8_STK + 3) & ~3ull);   // (an instance's scratch stays a multiple of 16 bytes: the queues are read as uint4)
+  return ((uint64_t)(c.n_nodes + 2) * c.inbox_capacity + (uint64_t)c.n_nodes * M8_CLIENT_CAP) * 4 + (((uint64_t)c.n_nodes * D8_AUX + 3) & ~3ull);   // (an instance's scratch stays a multiple of 16 bytes: the queues are read as uint4)
 }
 
 hipError_t msim_launch_dt8(const KParams &kp, uint32_t n, hipStream_t st) {

@@ -276,7 +276,7 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
     if (ctx->d_journal) MSIM_HIP_TRY(ctx, hipMemsetAsync(ctx->d_journal, poison, (size_t)ctx->cap_inst * c.journal_capacity * sizeof(msim_event), st));
     if (ctx->d_check_scratch) MSIM_HIP_TRY(ctx, hipMemsetAsync(ctx->d_check_scratch, poison, ctx->cap_check_scratch, st));
   }
-  if (blocking) MSIM_HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
+  MSIM_HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));   // (the launch's duration is read from these events on its own stream: msim_last_kernel_ms)
   hipError_t e;
   // the headline layout: two clusters per wavefront (duo.hip); MSIM_DEV_FLAGS bit 9 keeps the one-cluster kernels
   e = MSIM_LAYOUT_DOES_NOT_FIT;
@@ -321,10 +321,12 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   if (e != hipSuccess) { ctx->err = std::string("kernel launch: ") + hipGetErrorString(e); return MSIM_E_HIP; }
   ctx->n_inst = n; ctx->first_instance = first;
   ctx->fetched = false; ctx->fetch_pending = false; ctx->checked = false; ctx->check_fetched = false; ctx->ran = true;
+  MSIM_HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
+  ctx->sim_ms_stale = true;   // msim_run_async: the elapsed time is taken when somebody asks for it (the launch is over by then, or is waited for)
   if (blocking) {
-    MSIM_HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
     MSIM_HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
     MSIM_HIP_TRY(ctx, hipEventElapsedTime(&ctx->sim_ms, ctx->ev0, ctx->ev1));
+    ctx->sim_ms_stale = false;
   }
   return MSIM_OK;
 }
@@ -610,6 +612,12 @@ extern "C" int msim_device_buffers_get(msim_ctx *ctx, msim_device_buffers *out) 
 
 extern "C" int msim_last_kernel_ms(msim_ctx *ctx, float *sim_ms, float *check_ms) {
   if (!ctx) return MSIM_E_INVALID;
+  if (ctx->sim_ms_stale) {   // the last launch was asynchronous: its events are read now
+    MSIM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    MSIM_HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+    MSIM_HIP_TRY(ctx, hipEventElapsedTime(&ctx->sim_ms, ctx->ev0, ctx->ev1));
+    ctx->sim_ms_stale = false;
+  }
   if (sim_ms) *sim_ms = ctx->sim_ms;
   if (check_ms) *check_ms = ctx->check_ms;
   return MSIM_OK;

@@ -50,6 +50,7 @@ struct msim_ctx {
   uint64_t *d_sizes = nullptr;   // world x 4 u64 for the size all-gather
   bool fetched = false, checked = false, check_fetched = false, ran = false;
   float sim_ms = 0.f, check_ms = 0.f;
+  bool sim_ms_stale = false;        // the last launch was msim_run_async: sim_ms is read from ev0 / ev1 on demand
   uint32_t dev_flags = 0;           // msim_set_dev_flags: ORed with the MSIM_DEV_FLAGS of the environment (developer switches)
   uint32_t txn_big = 0;             // txn_check_dev.hip: histories of the last check whose tables did not fit LDS (HBM-table kernel)
   uint32_t lin_host_rechecks = 0;   // lin_check_dev.hip: histories of the last check the host search had to finish

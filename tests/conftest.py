@@ -36,8 +36,8 @@ def _guard_after_every_test(request):
     _abi._lib.msim_guard_check.restype = C.c_ulonglong
     damaged = int(_abi._lib.msim_guard_check(None))
     if damaged != _guard_seen[0]:
-        print(f"\n[msim guard] {damaged - _guard_seen[0]} newly damaged byte(s) after {request.node.nodeid}", flush=True)
-        _guard_seen[0] = damaged
+        new, _guard_seen[0] = damaged - _guard_seen[0], damaged
+        pytest.fail(f"[msim guard] {new} byte(s) outside a device slab were overwritten during {request.node.nodeid}", pytrace=False)
 
 
 def pytest_sessionfinish(session, exitstatus):
