@@ -58,7 +58,7 @@ constexpr u32 D8_DEAD = 0xFFFFFFFFu;
 struct M8Params {
   KParams k;
   u32 n_inst;
-  u32 off_cq, off_cur, off_gen, off_misc;               // LDS byte offsets (queues at 0)
+  u32 off_cq, off_cur, off_gen, off_misc, off_cs;       // LDS byte offsets (queues at 0)
   u32 node_spill, client_spill;                          // HBM spill entries per node-or-service queue / client inbox
   u64 client_spill_off, stack_off;                       // word offsets inside the per-instance scratch: the clients' spill area, the nodes' auxiliary words (D8_AUX each)
   u32 round_limit;
@@ -97,6 +97,255 @@ __device__ __forceinline__ u32 m8_oct_min(u32 v) {
   return v;
 }
 
+// ---- apply_txn as a function of its own ---------------------------------------------------------------------------------------------------
+// The walk down the tree, the path copies and the write list are the kernel's heaviest code and need registers of their own (three records' worth
+// of children in flight); inlined into the round loop their pressure met the loop's own state and the kernel sat at 224-256 registers — one or
+// two wavefronts per SIMD for a kernel that waits for dependent HBM loads.  As a separate function the body keeps only what it touches in
+// registers (the recipe of sim_kernel_colo.inc's quiet_run<>): the lane's state it reads and writes crosses the call by value, the run's constants
+// come as scalars-in-vector-registers and are made scalar again, LDS and the instance's scratch are addressed from the lane id and the instance.
+struct D8ApplyIO {
+  u32 np, mid, my_flags, wait_until;                       // per lane: the node (@ptr, msg_id of its last RPC, ..)
+  u32 n_out, o_dest, o1_type, o1_a, o1_b, o_wlo;           // what the node sends after this step
+  u32 done;                                                // bit 0: answer txn_ok, bit 1: unlock
+};
+struct D8ApplyK {   // constants of the launch
+  u32 *scratch; u32 *payload; u64 scratch_words; u32 max_pay, N, TC, mv, mw, off_aux, off_cur, off_gen;
+};
+#ifdef D8_APPLY_INLINE   // (developer A/B)
+#define D8_APPLY_ATTR __forceinline__
+#else
+#define D8_APPLY_ATTR __attribute__((noinline))
+#endif
+__device__ D8_APPLY_ATTR D8ApplyIO d8_apply(D8ApplyIO io, const D8ApplyK kc, u32 inst, u32 lane, u32 T_in, bool active) {   // (called by the whole wavefront: the constants are made scalar with every lane in)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#define UNI(x) ((u32)__builtin_amdgcn_readfirstlane((int)(x)))
+  const u32 N = UNI(kc.N), TC = UNI(kc.TC), mv = UNI(kc.mv), mw = UNI(kc.mw), max_pay = UNI(kc.max_pay);
+  u32 *const scratch0 = reinterpret_cast<u32 *>(((u64)UNI((u32)((u64)kc.scratch >> 32)) << 32) | UNI((u32)(u64)kc.scratch));
+  u32 *const payload0 = reinterpret_cast<u32 *>(((u64)UNI((u32)((u64)kc.payload >> 32)) << 32) | UNI((u32)(u64)kc.payload));
+  const u64 scratch_words = ((u64)UNI((u32)(kc.scratch_words >> 32)) << 32) | UNI((u32)kc.scratch_words);
+  const u32 OFF_AUX = UNI(kc.off_aux), off_cur = UNI(kc.off_cur), off_gen = UNI(kc.off_gen);
+#undef UNI
+  const u32 l = lane & 7u, grp = lane >> 3;
+  const u32 OFF_KVN = mv * mw, OFF_FIRST = OFF_KVN + mv, OFF_HASHW = OFF_FIRST + mv, OFF_REC = OFF_HASHW + (mv + 3u) / 4u;
+  const u32 OFF_WL = OFF_REC + N * TC * DT_RW;
+  (void)OFF_KVN;
+  u32 *const g_scr = scratch0 + (size_t)inst * scratch_words;
+  const u32 *const g_pay = payload0 + (size_t)inst * max_pay;
+  const u32 *const g_first = g_scr + OFF_FIRST;
+  const unsigned char *const g_hash = reinterpret_cast<const unsigned char *>(g_scr + OFF_HASHW);
+  u32 *const g_rec = g_scr + OFF_REC;
+  u32 *const aux = g_scr + OFF_AUX + l * D8_AUX;
+  u32 *const my_wl = g_scr + OFF_WL + l * DT_MAXW;
+  u32 *const cu = reinterpret_cast<u32 *>(smem + off_cur) + (grp * N + l) * D8_CW;
+  const u32 *const gen = reinterpret_cast<const u32 *>(smem + off_gen) + grp * 36;
+  const u32 T = T_in;
+  u32 next_p = io.np, node_msgid = io.mid, my_flags = io.my_flags, wait_until = io.wait_until;
+  u32 n_out = io.n_out, o_dest = io.o_dest, o1_type = io.o1_type, o1_a = io.o1_a, o1_b = io.o1_b, o_wlo = io.o_wlo;
+  bool do_reply_ok = false, do_unlock = false;
+  auto rec_of = [&](u32 ptr) -> u32 * { return g_rec + ((size_t)(ptr >> 20) * TC + (ptr & 0xFFFFFu)) * DT_RW; };
+  auto send1 = [&](u32 dest, u32 type, u32 a, u32 b) { o_dest = dest; n_out = 1; o1_type = type; o1_a = a; o1_b = b; };
+  auto br_index = [&](u32 w0, u32 h) -> u32 {   // branch_index (:231-247) with the split's bounds (:170-181)
+    const u32 lo = (w0 >> 8) & 0xFFu, hi = (w0 >> 16) & 0xFFu, bs = (hi - lo) / 8u;
+    u32 r = 7u;
+  #pragma unroll
+    for (u32 i = 7u; i-- > 0u;) r = h < lo + (i + 1u) * bs ? i : r;
+    return r;
+  };
+  auto load = [&](u32 ptr) {   // Tree.load with a cache miss (:83-101)
+    const u32 rid = ++node_msgid;
+    cu[DC_STAGE] = DS_LOAD; cu[DC_TARGET] = ptr; cu[DC_RPC] = rid;
+    send1(D_LWW, M_READ, ptr, rid);
+    wait_until = T + DT_AWAIT_US;
+  };
+  // Where a tree node sits decides when save! writes it: children before their parent, siblings by child index (:291-320) — ascending
+  // in this key.  Positions are (c0, c1, then the chain): a 128-wide root splits into 16-wide ranges, those into 2-wide ones, and a
+  // 2-wide range can only hand everything to its LAST child (branch_index, :231-247), so below depth 2 a path is all sevens: the spine
+  // node at depth 2 + m gets 1023 - m (deeper first), its seven empty siblings 8 m + i (before every spine node).  An absent digit
+  // (the node IS the c0 / c1 subtree's root) is 8 / 1023: after everything below it.
+  auto poskey = [&](u32 d, u32 c0, u32 c1) -> u32 { return d == 0u ? ((8u << 14) | (8u << 10) | 1023u) : d == 1u ? ((c0 << 14) | (8u << 10) | 1023u) : ((c0 << 14) | (c1 << 10) | (1023u - (d - 2u))); };
+  auto childkey = [&](u32 n, u32 i, u32 c0, u32 c1) -> u32 {   // child i of the node at depth n of that path
+    if (n == 0u) return (i << 14) | (8u << 10) | 1023u;
+    if (n == 1u) return (c0 << 14) | (i << 10) | 1023u;
+    return (c0 << 14) | (c1 << 10) | (i == 7u ? 1023u - (n - 1u) : (n - 1u) * 8u + i);
+  };
+  // save! (:212-224, :291-320): the new tree nodes the final tree reaches, children before their parent.  Nothing is walked: every node the
+  // transaction created left its position key in aux[], a node whose position a later copy took is marked dead there, and a live node's
+  // place in the write list is the number of live keys below its own.  One append alone: creation order IS that order (leaf level first, then upwards).
+  auto save = [&](u32 napp, u32 ndead) {
+    const u32 pstart = cu[DC_PSTART], M = next_p + 1u - pstart, wlo = node_msgid + 1u;
+    u32 wn = M - ndead;
+    if (wn > DT_MAXW) { my_flags |= MSIM_FLAG_ARENA_OVERRUN; wn = DT_MAXW; }
+    if (napp == 1u) {
+      for (u32 i = 0; i < wn; i++) my_wl[i] = (l << 20) | (pstart + i);
+    } else {
+      u32 *const nk = aux + D8_AUX_KEYS;
+      nk[M] = D8_DEAD; nk[M + 1u] = D8_DEAD; nk[M + 2u] = D8_DEAD;   // (the rank loop reads four keys at a time)
+      for (u32 i = 0; i < M; i++) {
+        const u32 ki = nk[i];
+        if (ki == D8_DEAD) continue;
+        u32 rank = 0;
+        for (u32 j4 = 0; j4 < M; j4 += 4u) {
+          const uint4 q = *reinterpret_cast<const uint4 *>(nk + j4);
+          rank += (q.x < ki ? 1u : 0u) + (q.y < ki ? 1u : 0u) + (q.z < ki ? 1u : 0u) + (q.w < ki ? 1u : 0u);
+        }
+        if (rank < DT_MAXW) my_wl[rank] = (l << 20) | (pstart + i);
+      }
+    }
+    node_msgid += wn;
+    cu[DC_STAGE] = DS_SAVE; cu[DC_WLO] = wlo; cu[DC_WN] = wn; cu[DC_WOUT] = wn;
+    o_dest = D_LWW; n_out = wn; o_wlo = wlo;
+    wait_until = T + DT_AWAIT_US;   // `tree2.save!.await` (:366)
+  };
+  // apply_txn (:391-415) from micro-op j on; stops at the first tree node that has to be fetched.  ONE walk per micro-op: t[k] (:231-247, for an
+  // append too: `t[k].clone`, :405) goes from the root record in LDS down through one record per level — kind / range, key count, "loaded by"
+  // flags and the eight children in one round trip — and leaves behind what assoc (:158-197, :256-268) needs: the leaf's record, the path's
+  // pointers (depth 1 and 2 in registers, a chain's below that in aux[]) and its child indices; the copies of the branches above are then read
+  // at known addresses (independent loads) and written with the new pointers, which are known before anything is written: new pointers go
+  // leaf first, then upwards (new_ptr, :352-355) — with n branches above a leaf level of L new nodes (1, or 8 leaves + their branch) the leaf
+  // level takes base+1 .. base+L, the branch at depth i base+L+(n-i).
+  auto apply = [&]() {
+    const u32 ref = cu[DC_REF], off0 = ref & 0xFFFFFFu, nm = ref >> 24;
+    const u32 rv = cu[DC_RV], pstart = cu[DC_PSTART];
+    const u32 jw = cu[DC_J];
+    u32 j = jw & 0xFFu, napp = (jw >> 8) & 0xFFu, ndead = jw >> 16;
+    u32 troot = cu[DC_T];
+    u32 *const nk = aux + D8_AUX_KEYS;
+    auto is_new = [&](u32 ptr) -> bool { return (ptr >> 20) == l && (ptr & 0xFFFFFu) >= pstart; };
+    while (j < nm) {
+      const u32 w = g_pay[off0 + j], k = (w >> 1) & 0x7FFFu;
+      const u32 h = g_hash[k], first = g_first[k];
+      u32 d = 0, pt = troot, c0 = 0, c1 = 0, pa = 0, pb = 0;
+      u32 w0 = cu[DC_RC], w1 = 0;
+      bool miss = false, deep = false;
+      if ((w0 & 1u) == 0u) w1 = rec_of(pt)[1];   // the root is a leaf (the first few transactions of a run): its key count
+      else {
+        c0 = br_index(w0, h);
+        pt = cu[DC_RC + 1u + c0]; d = 1u;
+        for (;;) {
+          const u32 *const r = rec_of(pt);
+          const u32 w3 = __hip_atomic_load(r + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (word 3 is the one word of a record that changes after its creation, by L2 atomics: read past the L1)
+          w0 = r[0]; w1 = r[1];
+          u32 ch[8];
+  #pragma unroll
+          for (u32 c = 0; c < 8u; c++) ch[c] = r[4u + c];
+          if (!is_new(pt) && !((w3 >> (2u + l)) & 1u)) { miss = true; break; }   // neither created by this transaction nor loaded by this node
+          if (d >= DT_MAXDEPTH) { deep = true; break; }   // engine capacity
+          if ((w0 & 1u) == 0u) break;   // the key's leaf
+          const u32 ci = br_index(w0, h);
+          if (d == 1u) { c1 = ci; pa = pt; } else if (d == 2u) pb = pt; else aux[D8_AUX_PATH + d] = pt;
+          pt = ch[0];
+  #pragma unroll
+          for (u32 c = 1; c < 8u; c++) pt = c == ci ? ch[c] : pt;
+          d++;
+        }
+      }
+      if (miss) { cu[DC_J] = j | (napp << 8) | (ndead << 16); cu[DC_T] = troot; load(pt); return; }
+      if (deep) my_flags |= MSIM_FLAG_ARENA_OVERRUN;
+      else if (w & 1u) {   // assoc
+        const u32 n = d, lw0 = w0, lcount = w1;
+        bool has = first <= rv;   // (DT_NONE is above every version)
+        { const u32 no = cu[DC_NOWN]; for (u32 i = 0; i < no; i++) has = has || cu[DC_OWN + i] == k; }
+        const u32 L = (has || lcount < 8u) ? 1u : 9u, base = next_p, ver = rv + 1u;
+        if (base + L + n >= TC || base + L + n - pstart >= D8_MAXNEW) my_flags |= MSIM_FLAG_ARENA_OVERRUN;   // engine capacity
+        else {
+          auto put = [&](u32 idx, u32 pw0, u32 cnt, u32 key) -> u32 * {   // (word 3: lww-kv replica in bits 0-1, 3 = not written; bit 2 + i: node i has loaded it)
+            u32 *const r = g_rec + ((size_t)l * TC + idx) * DT_RW; r[0] = pw0; r[1] = cnt; r[2] = ver; __hip_atomic_store(r + 3, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            nk[idx - pstart] = key; return r; };
+          auto dies = [&](u32 ptr) { if (is_new(ptr)) { nk[(ptr & 0xFFFFFu) - pstart] = D8_DEAD; ndead++; } };   // its position is taken by a node created now
+          // the copies' sources at depth 1 and 2, at known addresses: in flight together
+          u32 wa = 0, wb = 0, cha[8], chb[8];
+          if (n >= 2u) { const u32 *const r = rec_of(pa); wa = r[0];
+  #pragma unroll
+            for (u32 c = 0; c < 8u; c++) cha[c] = r[4u + c]; }
+          if (n >= 3u) { const u32 *const r = rec_of(pb); wb = r[0];
+  #pragma unroll
+            for (u32 c = 0; c < 8u; c++) chb[c] = r[4u + c]; }
+          dies(pt);
+          const u32 lo = (lw0 >> 8) & 0xFFu, hi = (lw0 >> 16) & 0xFFu;
+          if (L == 1u) put(base + 1u, lw0, lcount + (has ? 0u : 1u), poskey(n, c0, c1));
+          else {   // eight leaves under a new branch: the lineage's keys of this range (and the new one) by sub-range
+            const u32 bs = (hi - lo) / 8u, nkeys = gen[32];
+            u64 c_lo = 0, c_hi = 0;   // 4 x 16-bit counters each
+            for (u32 q0 = 0; q0 < nkeys; q0 += 4u) {   // four keys per round trip
+              u32 f4[4], h4[4];
+  #pragma unroll
+              for (u32 t = 0; t < 4u; t++) { const u32 q = min(q0 + t, nkeys - 1u); f4[t] = g_first[q]; h4[t] = g_hash[q]; }
+  #pragma unroll
+              for (u32 t = 0; t < 4u; t++) {
+                const u32 q = q0 + t;
+                if (q >= nkeys) continue;
+                bool in = q == k || f4[t] <= rv;
+                { const u32 no = cu[DC_NOWN]; for (u32 i = 0; i < no; i++) in = in || cu[DC_OWN + i] == q; }
+                const u32 hq = h4[t];
+                if (!in || hq < lo || hq >= hi) continue;
+                const u32 ci = bs ? min((hq - lo) / bs, 7u) : 7u;
+                if (ci < 4u) c_lo += 1ull << (16u * ci); else c_hi += 1ull << (16u * (ci - 4u));
+              }
+            }
+            u32 *const br = put(base + 9u, 1u | (lo << 8) | (hi << 16), 0u, poskey(n, c0, c1));
+            for (u32 i = 0; i < 8u; i++) {
+              const u32 b_lo = lo + i * bs, b_hi = i == 7u ? hi : b_lo + bs;
+              const u32 cnt = (u32)((i < 4u ? c_lo >> (16u * i) : c_hi >> (16u * (i - 4u))) & 0xFFFFu);
+              put(base + 1u + i, (b_lo << 8) | (b_hi << 16), cnt, childkey(n, i, c0, c1));
+              br[4u + i] = (l << 20) | (base + 1u + i);
+            }
+            if (n == 0u) { cu[DC_RC] = 1u | (lo << 8) | (hi << 16); for (u32 i = 0; i < 8u; i++) cu[DC_RC + 1u + i] = (l << 20) | (base + 1u + i); }   // the new root is this branch
+          }
+          // a copy of every branch above, pointing at the new child (:256-268)
+          for (u32 i = n; i-- > 0u;) {
+            const u32 child_new = (l << 20) | (i + 1u == n ? base + L : base + L + (n - i - 1u));
+            const u32 idx = base + L + (n - i);
+            if (i == 0u) {   // the root: its record is in LDS, and stays there as the new root's
+              dies(troot);
+              const u32 rw0 = cu[DC_RC];
+              u32 *const nr = put(idx, rw0, 0u, poskey(0u, c0, c1));
+              cu[DC_RC + 1u + c0] = child_new;
+  #pragma unroll
+              for (u32 c = 0; c < 8u; c++) nr[4u + c] = cu[DC_RC + 1u + c];
+            } else if (i == 1u) {
+              dies(pa);
+              u32 *const nr = put(idx, wa, 0u, poskey(1u, c0, c1));
+  #pragma unroll
+              for (u32 c = 0; c < 8u; c++) nr[4u + c] = c == c1 ? child_new : cha[c];
+            } else if (i == 2u) {
+              dies(pb);
+              const u32 ci = br_index(wb, h);
+              u32 *const nr = put(idx, wb, 0u, poskey(2u, c0, c1));
+  #pragma unroll
+              for (u32 c = 0; c < 8u; c++) nr[4u + c] = c == ci ? child_new : chb[c];
+            } else {   // a chain below depth 2: one link at a time
+              const u32 pp = aux[D8_AUX_PATH + i];
+              dies(pp);
+              const u32 *const r = rec_of(pp);
+              const u32 xw0 = r[0], ci = br_index(xw0, h);
+              u32 ch[8];
+  #pragma unroll
+              for (u32 c = 0; c < 8u; c++) ch[c] = r[4u + c];
+              u32 *const nr = put(idx, xw0, 0u, poskey(i, c0, c1));
+  #pragma unroll
+              for (u32 c = 0; c < 8u; c++) nr[4u + c] = c == ci ? child_new : ch[c];
+            }
+          }
+          if (n == 0u && L == 1u) { /* the root stays a leaf: its record in LDS (kind / range) is unchanged */ }
+          next_p = base + L + n;
+          troot = (l << 20) | next_p;
+          napp++;
+          if (!has) { const u32 no = cu[DC_NOWN]; if (no < 8u) { cu[DC_OWN + no] = k; cu[DC_NOWN] = no + 1u; } }
+        }
+      }
+      j++;
+    }
+    cu[DC_J] = j | (napp << 8) | (ndead << 16); cu[DC_T] = troot;
+    if (troot == cu[DC_P1]) { do_reply_ok = true; do_unlock = true; return; }   // nothing appended: no write, no cas
+    save(napp, ndead);
+  };
+  if (active) apply();
+  io.np = next_p; io.mid = node_msgid; io.my_flags = my_flags; io.wait_until = wait_until;
+  io.n_out = n_out; io.o_dest = o_dest; io.o1_type = o1_type; io.o1_a = o1_a; io.o1_b = o1_b; io.o_wlo = o_wlo;
+  io.done = (do_reply_ok ? 1u : 0u) | (do_unlock ? 2u : 0u);
+  return io;
+}
+
 #ifdef D8_WAVES_PER_EU   // (developer A/B: a register budget for that many wavefronts per SIMD)
 #define D8_OCC __attribute__((amdgpu_waves_per_eu(D8_WAVES_PER_EU)))
 #else
@@ -122,23 +371,31 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
   const u32 TC = p.mk_tcap;   // tree nodes a node may create
   const u32 round_limit = tp.round_limit;
 
-  msim_op *const g_rows = p.rows + (size_t)inst * max_rows;
-  u32 *const g_pay = p.payload + (size_t)inst * max_pay;
-  u32 *const g_scr = p.scratch + (size_t)inst * p.scratch_words;
-  // the per-instance scratch of dt_kernel<> (sim_kernel_dt.inc), same layout
-  u32 *const g_kv = g_scr;                                           // [max_values][mw]: element | version << 8
-  u32 *const g_kvn = g_kv + (size_t)mv * mw;                         // [max_values]
-  u32 *const g_first = g_kvn + mv;                                   // [max_values] version at which the key entered the tree (DT_NONE: never)
-  unsigned char *const g_hash = reinterpret_cast<unsigned char *>(g_first + mv);   // [max_values] Tree.hash of the key
-  u32 *const g_rec = g_first + mv + (mv + 3u) / 4u;                  // [N][TC][DT_RW] tree nodes by pointer
-  u32 *const g_wl = g_rec + (size_t)N * TC * DT_RW;                  // [N][DT_MAXW] the pointers a node writes this round
-  u32 *const g_cas = g_wl + (size_t)N * DT_MAXW;                     // [N][DT_CASQ] x {msg_id, from, transaction}: what a node's cas requests carry beside `to`
+  // A register diet for four wavefronts per SIMD (128 registers): nothing that can be recomputed is carried through the round loop.  Every
+  // address in an instance's slabs is the slab's base (a kernel argument: scalar registers) + the instance's offset, formed where it is used from
+  // `inst` behind an optimization barrier (loop-invariant code motion would otherwise hold a dozen 64-bit pointers per lane for the whole run);
+  // the offsets of the regions inside an instance's scratch (dt_kernel<>'s layout, sim_kernel_dt.inc) are the same for every cluster: scalars.
+  const u32 OFF_KVN = mv * mw, OFF_FIRST = OFF_KVN + mv, OFF_HASHW = OFF_FIRST + mv, OFF_REC = OFF_HASHW + (mv + 3u) / 4u;
+  const u32 OFF_WL = OFF_REC + N * TC * DT_RW, OFF_CAS = OFF_WL + N * DT_MAXW;
+  const u32 OFF_SPILL = (u32)p.spill_off, OFF_CSPILL = (u32)tp.client_spill_off, OFF_AUX = (u32)tp.stack_off;
   const u32 qlane = l <= N + 1u ? l : 0u;
-  uint4 *const my_spill = reinterpret_cast<uint4 *>(g_scr + p.spill_off) + (size_t)qlane * tp.node_spill;
-  uint4 *const my_cspill = reinterpret_cast<uint4 *>(g_scr + tp.client_spill_off) + (size_t)(is_node ? l : 0u) * tp.client_spill;
   const u32 my_spill_cap = l <= N + 1u ? tp.node_spill : 0u;
   const u32 my_node = is_node ? l : 0u;
-  u32 *const aux = g_scr + tp.stack_off + (size_t)my_node * D8_AUX;
+#define D8_INST ([&]() -> size_t { u32 i_ = inst; MSIM_OPAQUE(i_); return (size_t)i_; }())
+#define g_rows (p.rows + D8_INST * max_rows)
+#define g_pay (p.payload + D8_INST * max_pay)
+#define g_scr (p.scratch + D8_INST * p.scratch_words)
+#define g_kv g_scr                                                  /* [max_values][mw]: element | version << 8 */
+#define g_kvn (g_scr + OFF_KVN)                                     /* [max_values] */
+#define g_first (g_scr + OFF_FIRST)                                 /* [max_values] version at which the key entered the tree (DT_NONE: never) */
+#define g_hash (reinterpret_cast<unsigned char *>(g_scr + OFF_HASHW))   /* [max_values] Tree.hash of the key */
+#define g_rec (g_scr + OFF_REC)                                     /* [N][TC][DT_RW] tree nodes by pointer */
+#define g_wl (g_scr + OFF_WL)                                       /* [N][DT_MAXW] the pointers a node writes this round */
+#define g_cas (g_scr + OFF_CAS)                                     /* [N][DT_CASQ] x {msg_id, from, transaction}: what a node's cas requests carry beside `to` */
+#define my_spill (reinterpret_cast<uint4 *>(g_scr + OFF_SPILL) + qlane * tp.node_spill)
+#define my_cspill (reinterpret_cast<uint4 *>(g_scr + OFF_CSPILL) + my_node * tp.client_spill)
+#define aux (g_scr + OFF_AUX + my_node * D8_AUX)
+#define my_wl (g_scr + OFF_WL + my_node * DT_MAXW)
 
   uint4 *const my_q = reinterpret_cast<uint4 *>(smem) + lane;                                   // node / service queue: slot s at my_q[s * 64]
   uint4 *const my_cq = reinterpret_cast<uint4 *>(smem + tp.off_cq) + lane;                      // client inbox
@@ -146,7 +403,6 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
   u32 *const gen = reinterpret_cast<u32 *>(smem + tp.off_gen) + grp * 36;                       // active[16], next_val[16], next_key
   u32 *const misc = reinterpret_cast<u32 *>(smem + tp.off_misc) + grp * GS;
   u32 *const cu = curs_g + my_node * D8_CW;
-  u32 *const my_wl = g_wl + (size_t)my_node * DT_MAXW;
 
   for (u32 i = lane; i < 8 * N * D8_CW; i += 64) reinterpret_cast<u32 *>(smem + tp.off_cur)[i] = 0;
   for (u32 i = l; i < 16; i += GS) { gen[i] = i; gen[16 + i] = 1; }
@@ -162,25 +418,35 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
 
   // ---- node / service state ----
   u32 deliver_at = INF; uint4 cm = make_uint4(0, 0, 0, 0);
-  bool have_pm = false; uint4 pm = make_uint4(0, 0, 0, 0);
-  u32 in_n = 0, sp_n = 0, node_msgid = 0, part = 0;
-  u32 next_p = 0;                                      // node: @ptr (:332, :352-355)
+  u32 in_n = 0, sp_n = 0, part = 0;
   u32 wait_until = INF;                                // node: when the lock holder's Promise#await gives up (promise.rb:5,17-30), INF: not waiting
-  u32 casn = 0;                                        // node: cas requests so far
-  u32 root = 0, root_exists = 0, cur_v = 0;            // lin-kv lane: the root pointer; versions so far
-  u32 svc_ctr = 0;                                     // lww-kv lane: rand-int draws so far
+  // a lane is a node or a service, never both: what only one of them keeps shares a register with what only the other keeps
+  u32 ra = 0, rb = 0, rc = 0;
+#define next_p ra       /* node: @ptr (:332, :352-355) */
+#define root ra         /* lin-kv lane: the root pointer */
+#define casn rb         /* node: cas requests so far */
+#define cur_v rb        /* lin-kv lane: versions so far */
+#define node_msgid rc   /* node: msg_id of its last RPC */
+#define svc_ctr rc      /* lww-kv lane: rand-int draws so far */
+  u32 root_exists = 0;                                 // lin-kv lane
   // ---- client state ----
   bool busy = false, mark = false; u32 kind = K_NONE;
   u32 want = 0, timeout_at = 0, next_msg_id = 0, c_value = 0, process = l, m_value = 0, cin_n = 0, csp_n = 0;
   u32 s_send_cl = 0, s_send_sv = 0, s_recv_cl = 0, s_recv_sv = 0, my_flags = 0;
   // ---- per-cluster state (uniform within a group) ----
-  u32 T = 0, phase = PH_INIT, cutoff = 0, gen_next = 0, gen_k = 0, nem_next = 0, nem_j = 0;
-  u32 loss_on = 0, next_id = 0, n_rows = 0, n_payload = 0, flags = 0, rounds = 0;
+  u32 T = 0, phase = PH_INIT, next_id = 0, n_rows = 0, n_payload = 0;
+  // ... and what a round only looks at briefly lives in LDS, one copy per cluster (written by the cluster's lane 0, or or-ed in): rounds so far,
+  // the end of the main phase, the generator's and the nemesis' next times and counters, "losses are on", the instance's flags
+  enum { CS_ROUNDS = 0, CS_CUTOFF, CS_GEN_NEXT, CS_NEM_NEXT, CS_GEN_K, CS_NEM_J, CS_LOSS_ON, CS_FLAGS, CS_WORDS };
+  u32 *const cs = reinterpret_cast<u32 *>(smem + tp.off_cs) + grp * CS_WORDS;
+  if (l < CS_WORDS) cs[l] = 0;
+  wave_lds_fence();
+#define CFLAG(x_) atomicOr(&cs[CS_FLAGS], (x_))
   bool alive = real;
 
   auto q_push = [&](const uint4 m) __attribute__((always_inline)) {
     if (in_n < RQ) { my_q[in_n * 64u] = m; in_n++; return; }
-    if (sp_n < my_spill_cap) { my_spill[sp_n++] = m; return; }
+    if (sp_n < my_spill_cap) { my_spill[sp_n] = m; sp_n++; return; }
     my_flags |= MSIM_FLAG_INBOX_OVERFLOW;
   };
   // an envelope for THIS lane's node/service arrives (net.clj:189-221)
@@ -191,11 +457,8 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
       else if (lat_dist == MSIM_LAT_UNIFORM) lat = scale32(draw32(key, S_LATENCY, id), 2 * lat_mean);
       else lat = (u32)(((u64)lat_mean * m8_neg_ln_q16(draw32(key, S_LATENCY, id))) >> 16);
     }
-    if (NET_RANDOM && loss_on && p_loss && draw32(key, S_LOSS, id) < p_loss) return;
-    uint4 m = make_uint4(T + lat * 1000u, (id << 8) | type, a, b | (src << 24));
-    if (!have_pm) { pm = m; have_pm = true; return; }
-    if (m.x < pm.x || (m.x == pm.x && m.y < pm.y)) { const uint4 t = m; m = pm; pm = t; }
-    q_push(m);
+    if (NET_RANDOM && p_loss && cs[CS_LOSS_ON] && draw32(key, S_LOSS, id) < p_loss) return;
+    q_push(make_uint4(T + lat * 1000u, (id << 8) | type, a, b | (src << 24)));
   };
   auto try_commit = [&](const uint4 e) __attribute__((always_inline)) {
     const u32 src = e.w >> 24;
@@ -204,11 +467,6 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
     deliver_at = e.x <= T ? T : T + ((e.x - T) / 1000u) * 1000u;  // (Thread/sleep (long dt)) net.clj:236-238
   };
   auto poll = [&]() __attribute__((always_inline)) {
-    if (have_pm) {
-      have_pm = false;
-      if (alive && deliver_at == INF && (in_n | sp_n) == 0) try_commit(pm);
-      else q_push(pm);
-    }
     while (alive && l <= N + 1u && deliver_at == INF && (in_n | sp_n) != 0) {
       u32 best = 0; bool in_spill = false;
       uint2 bk = make_uint2(INF, INF);
@@ -216,10 +474,11 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
         const uint2 kk = *reinterpret_cast<const uint2 *>(&my_q[i * 64u]);
         if (kk.x < bk.x || (kk.x == bk.x && kk.y < bk.y)) { bk = kk; best = i; }
       }
+      uint4 *const spl = my_spill;
       for (u32 i0 = 0; i0 < sp_n; i0 += 8) {   // eight spilled keys per round trip
         uint2 k8[8];
 #pragma unroll
-        for (u32 t = 0; t < 8; t++) k8[t] = *reinterpret_cast<const uint2 *>(&my_spill[min(i0 + t, sp_n - 1u)]);
+        for (u32 t = 0; t < 8; t++) k8[t] = *reinterpret_cast<const uint2 *>(&spl[min(i0 + t, sp_n - 1u)]);
 #pragma unroll
         for (u32 t = 0; t < 8; t++) {
           const uint2 kk = k8[t];
@@ -227,7 +486,7 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
         }
       }
       uint4 e;
-      if (in_spill) { e = my_spill[best]; sp_n--; if (best != sp_n) my_spill[best] = my_spill[sp_n]; }
+      if (in_spill) { e = spl[best]; sp_n--; if (best != sp_n) spl[best] = spl[sp_n]; }
       else { e = my_q[best * 64u]; in_n--; if (best != in_n) my_q[best * 64u] = my_q[in_n * 64u]; }
       try_commit(e);
     }
@@ -236,17 +495,18 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
   // independent loads (one round trip) instead of one dependent load per element
   auto visible = [&](u32 k, u32 from) __attribute__((always_inline)) -> u32 {
     if (from == V_NIL) return 0u;
-    const u32 cnt = g_kvn[k];
+    const u32 *const kvr = g_kv + k * mw;
+    const u32 cnt = kvr[OFF_KVN + k - k * mw];   // (= g_kvn[k])
     u32 n = 0;
     if (mw <= 16u) {
       u32 row[16];
 #pragma unroll
-      for (u32 i = 0; i < 16u; i++) row[i] = i < cnt ? g_kv[k * mw + i] : 0xFFFFFFFFu;
+      for (u32 i = 0; i < 16u; i++) row[i] = i < cnt ? kvr[i] : 0xFFFFFFFFu;
 #pragma unroll
       for (u32 i = 0; i < 16u; i++) n += (i < cnt && (row[i] >> 8) <= from) ? 1u : 0u;
       return n;
     }
-    while (n < cnt && (g_kv[k * mw + n] >> 8) <= from) n++;
+    while (n < cnt && (kvr[n] >> 8) <= from) n++;
     return n;
   };
 
@@ -265,12 +525,17 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
     const u32 busy_mask = GB(busy);
 
     // ---- time-free phase transitions ----
+    // (every lane reads a shared word before a wave-wide operation, lane 0 of the cluster writes it after one: lanes of a wavefront run in step,
+    // but the rule also holds for the host emulator's lanes, which only meet at such operations)
+    u32 cutoff = cs[CS_CUTOFF], gen_next = cs[CS_GEN_NEXT], nem_next = NEM ? cs[CS_NEM_NEXT] : 0u;
+    const u32 rounds_before = cs[CS_ROUNDS];
     if (__ballot(alive && !(phase == PH_MAIN && ((rate > 0 && gen_next < cutoff) || (NEM && nem_next < cutoff))))) {
       for (;;) {
         bool ch = false;
         if (alive) {
           if (phase == PH_INIT_WAIT && !busy_mask) { phase = PH_MAIN_START; ch = true; }
-          if (phase == PH_MAIN_START) { cutoff = T + p.cfg.time_limit_ms * 1000u; gen_next = T; nem_next = T; next_msg_id = 0; loss_on = 1; phase = PH_MAIN; ch = true; }
+          if (phase == PH_MAIN_START) { cutoff = T + p.cfg.time_limit_ms * 1000u; gen_next = T; nem_next = T; next_msg_id = 0; phase = PH_MAIN; ch = true;
+            if (l == 0) { cs[CS_CUTOFF] = cutoff; cs[CS_GEN_NEXT] = T; cs[CS_NEM_NEXT] = T; cs[CS_LOSS_ON] = 1u; } }
           if (phase == PH_MAIN && !((rate > 0 && gen_next < cutoff) || (NEM && nem_next < cutoff)) && !(rate == 0 && T < cutoff)) { phase = PH_DRAIN; ch = true; }
           if (phase == PH_DRAIN && !busy_mask) { phase = PH_DONE; ch = true; }   // no final phase (txn_list_append.clj:142)
         }
@@ -279,7 +544,7 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
       if (phase == PH_DONE) alive = false;
       if (!__ballot(alive)) break;
     }
-    if (alive && ++rounds > round_limit) { flags |= MSIM_FLAG_ROUND_LIMIT; alive = false; }
+    if (alive) { const u32 r = rounds_before + 1u; if (l == 0) cs[CS_ROUNDS] = r; if (r > round_limit) { CFLAG(MSIM_FLAG_ROUND_LIMIT); alive = false; } }
     if (GB((my_flags & MSIM_FLAG_ARENA_OVERRUN) != 0)) alive = false;   // an engine capacity was exceeded: what follows would not be the program's behaviour
 
     // ---- R0: time ----
@@ -304,7 +569,7 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
         u32 km = m8_oct_min(k);
         if (due != INF) km = min(km, due * 2);
         if (jump) {
-          if (km == INF) { flags |= MSIM_FLAG_ROUND_LIMIT; alive = false; }
+          if (km == INF) { CFLAG(MSIM_FLAG_ROUND_LIMIT); alive = false; }
           else { timeout_round = (km & 1) != 0; T = max(T, km >> 1); }
         }
       }
@@ -347,10 +612,10 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
       if (NEM) {
         const bool nem_act = act && phase == PH_MAIN && nem_live && nem_next <= T;
         if (__ballot(nem_act)) {   // flip-flop start/stop (nemesis.clj:10-16 + [upstream] partition package)
-          const u32 j = nem_j;
+          const u32 j = cs[CS_NEM_J];
           const u32 spec = scale32(draw32(key, S_NEM_SPEC, j), 4);
           const bool start = nem_act && (j & 1) == 0;
-          if (nem_act) { nem_j++; nem_rows = 2; }
+          if (nem_act) nem_rows = 2;
           if (__ballot(start)) {
             misc[l] = l;
             wave_lds_fence();
@@ -385,7 +650,7 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
               part |= my_part;
               const u32 words = N * MSIM_MASK_WORDS;
               u32 off = 0;
-              if (n_payload + words > max_pay) flags |= MSIM_FLAG_PAYLOAD_OVERFLOW;
+              if (n_payload + words > max_pay) CFLAG(MSIM_FLAG_PAYLOAD_OVERFLOW);
               else {
                 off = n_payload; n_payload += words;
                 if (is_node) { g_pay[off + l * 4] = part; g_pay[off + l * 4 + 1] = 0; g_pay[off + l * 4 + 2] = 0; g_pay[off + l * 4 + 3] = 0; }
@@ -397,14 +662,14 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
             part = 0;
             nem_f = MSIM_F_STOP_PARTITION; nem_v1 = MSIM_NO_VALUE; nem_v2 = MSIM_NO_VALUE; nem_len2 = 0;
           }
-          if (nem_act) nem_next = T + __umulhi(draw32(key, S_NEM_STAGGER, j), p.nem_period2_us);
+          if (nem_act && l == 0) { cs[CS_NEM_J] = j + 1u; cs[CS_NEM_NEXT] = T + __umulhi(draw32(key, S_NEM_STAGGER, j), p.nem_period2_us); }
         }
       }
       {
         const bool gen_on = act && phase == PH_MAIN && gen_live && gen_next <= T && free_mask != 0;
         if (__ballot(gen_on)) {
           const u32 nfree = __popc(free_mask);
-          const u32 kk = gen_k;
+          const u32 kk = cs[CS_GEN_K];
           const u64 h = draw64(key, S_GEN, kk);
           const u32 r_hi = (u32)(h >> 32), r_lo = (u32)h;
           const u32 pick = scale32(r_lo, nfree);
@@ -433,12 +698,11 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
             }
           }
           bad = GGET(bad, 0);
-          if (gen_on && bad) { flags |= bad; phase = PH_DONE; alive = false; normal = false; }
+          if (gen_on && bad) { CFLAG(bad); phase = PH_DONE; alive = false; normal = false; }
           else if (gen_on) {
             if (sel) { mark = true; kind = K_OP; m_value = n_payload | (n_mops << 24); }
             n_payload += n_mops;
-            gen_k++;
-            gen_next = T + __umulhi(r_hi, p.gen_period2_us);
+            if (l == 0) { cs[CS_GEN_K] = kk + 1u; cs[CS_GEN_NEXT] = T + __umulhi(r_hi, p.gen_period2_us); }
           }
         }
       }
@@ -475,15 +739,12 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
       bool do_apply = false, do_reply_ok = false, do_unlock = false;
       u32 n_out = 0, o_dest = 0;           // node -> service: n_out messages, all to the same service; one in registers (o1_*) or the writes of my_wl[]
       u32 o1_type = 0, o1_a = 0, o1_b = 0, o_wlo = 0;
-      u32 o_type = 0, o_a = 0, o_b = 0, o_to = 0, need_words = 0, done_ref = 0, done_rv = 0;   // service -> node; the completed transaction's payload
+#define o_type o1_type   /* service -> node: a service lane's answer lies where a node lane keeps its request */
+#define o_a o1_a
+#define o_b o1_b
+#define o_to o_dest
+      u32 need_words = 0, done_ref = 0, done_rv = 0;   // the completed transaction's payload
       auto rec_of = [&](u32 ptr) -> u32 * { return g_rec + ((size_t)(ptr >> 20) * TC + (ptr & 0xFFFFFu)) * DT_RW; };
-      auto br_index = [&](u32 w0, u32 h) -> u32 {   // branch_index (:231-247) with the split's bounds (:170-181)
-        const u32 lo = (w0 >> 8) & 0xFFu, hi = (w0 >> 16) & 0xFFu, bs = (hi - lo) / 8u;
-        u32 r = 7u;
-#pragma unroll
-        for (u32 i = 7u; i-- > 0u;) r = h < lo + (i + 1u) * bs ? i : r;
-        return r;
-      };
       auto send1 = [&](u32 dest, u32 type, u32 a, u32 b) { o_dest = dest; n_out = 1; o1_type = type; o1_a = a; o1_b = b; };
       auto start_txn = [&](u32 cmsg, u32 ref) {   // the lock is ours: current_tree (:358-365)
         cu[DC_STAGE] = DS_ROOT; cu[DC_CMSG] = cmsg; cu[DC_REF] = ref; cu[DC_J] = 0; cu[DC_NOWN] = 0;
@@ -507,45 +768,6 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
         send1(D_LWW, M_READ, ptr, rid);
         wait_until = T + DT_AWAIT_US;
       };
-      // Where a tree node sits decides when save! writes it: children before their parent, siblings by child index (:291-320) — ascending
-      // in this key.  Positions are (c0, c1, then the chain): a 128-wide root splits into 16-wide ranges, those into 2-wide ones, and a
-      // 2-wide range can only hand everything to its LAST child (branch_index, :231-247), so below depth 2 a path is all sevens: the spine
-      // node at depth 2 + m gets 1023 - m (deeper first), its seven empty siblings 8 m + i (before every spine node).  An absent digit
-      // (the node IS the c0 / c1 subtree's root) is 8 / 1023: after everything below it.
-      auto poskey = [&](u32 d, u32 c0, u32 c1) -> u32 { return d == 0u ? ((8u << 14) | (8u << 10) | 1023u) : d == 1u ? ((c0 << 14) | (8u << 10) | 1023u) : ((c0 << 14) | (c1 << 10) | (1023u - (d - 2u))); };
-      auto childkey = [&](u32 n, u32 i, u32 c0, u32 c1) -> u32 {   // child i of the node at depth n of that path
-        if (n == 0u) return (i << 14) | (8u << 10) | 1023u;
-        if (n == 1u) return (c0 << 14) | (i << 10) | 1023u;
-        return (c0 << 14) | (c1 << 10) | (i == 7u ? 1023u - (n - 1u) : (n - 1u) * 8u + i);
-      };
-      // save! (:212-224, :291-320): the new tree nodes the final tree reaches, children before their parent.  Nothing is walked: every node the
-      // transaction created left its position key in aux[], a node whose position a later copy took is marked dead there, and a live node's
-      // place in the write list is the number of live keys below its own.  One append alone: creation order IS that order (leaf level first, then upwards).
-      auto save = [&](u32 napp, u32 ndead) {
-        const u32 pstart = cu[DC_PSTART], M = next_p + 1u - pstart, wlo = node_msgid + 1u;
-        u32 wn = M - ndead;
-        if (wn > DT_MAXW) { my_flags |= MSIM_FLAG_ARENA_OVERRUN; wn = DT_MAXW; }
-        if (napp == 1u) {
-          for (u32 i = 0; i < wn; i++) my_wl[i] = (l << 20) | (pstart + i);
-        } else {
-          u32 *const nk = aux + D8_AUX_KEYS;
-          nk[M] = D8_DEAD; nk[M + 1u] = D8_DEAD; nk[M + 2u] = D8_DEAD;   // (the rank loop reads four keys at a time)
-          for (u32 i = 0; i < M; i++) {
-            const u32 ki = nk[i];
-            if (ki == D8_DEAD) continue;
-            u32 rank = 0;
-            for (u32 j4 = 0; j4 < M; j4 += 4u) {
-              const uint4 q = *reinterpret_cast<const uint4 *>(nk + j4);
-              rank += (q.x < ki ? 1u : 0u) + (q.y < ki ? 1u : 0u) + (q.z < ki ? 1u : 0u) + (q.w < ki ? 1u : 0u);
-            }
-            if (rank < DT_MAXW) my_wl[rank] = (l << 20) | (pstart + i);
-          }
-        }
-        node_msgid += wn;
-        cu[DC_STAGE] = DS_SAVE; cu[DC_WLO] = wlo; cu[DC_WN] = wn; cu[DC_WOUT] = wn;
-        o_dest = D_LWW; n_out = wn; o_wlo = wlo;
-        wait_until = T + DT_AWAIT_US;   // `tree2.save!.await` (:366)
-      };
       auto reply_txn_ok = [&]() {   // the completed transaction: its reads see the version read + its own appends
         rep = true; r_type = M_TXN_OK; r_b = cu[DC_CMSG];
         done_ref = cu[DC_REF]; done_rv = cu[DC_RV];
@@ -559,149 +781,6 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
             need_words += (len + 3u) / 4u;
           }
         }
-      };
-      // apply_txn (:391-415) from micro-op j on; stops at the first tree node that has to be fetched.  ONE walk per micro-op: t[k] (:231-247, for an
-      // append too: `t[k].clone`, :405) goes from the root record in LDS down through one record per level — kind / range, key count, "loaded by"
-      // flags and the eight children in one round trip — and leaves behind what assoc (:158-197, :256-268) needs: the leaf's record, the path's
-      // pointers (depth 1 and 2 in registers, a chain's below that in aux[]) and its child indices; the copies of the branches above are then read
-      // at known addresses (independent loads) and written with the new pointers, which are known before anything is written: new pointers go
-      // leaf first, then upwards (new_ptr, :352-355) — with n branches above a leaf level of L new nodes (1, or 8 leaves + their branch) the leaf
-      // level takes base+1 .. base+L, the branch at depth i base+L+(n-i).
-      auto apply = [&]() {
-        const u32 ref = cu[DC_REF], off0 = ref & 0xFFFFFFu, nm = ref >> 24;
-        const u32 rv = cu[DC_RV], pstart = cu[DC_PSTART];
-        const u32 jw = cu[DC_J];
-        u32 j = jw & 0xFFu, napp = (jw >> 8) & 0xFFu, ndead = jw >> 16;
-        u32 troot = cu[DC_T];
-        u32 *const nk = aux + D8_AUX_KEYS;
-        auto is_new = [&](u32 ptr) -> bool { return (ptr >> 20) == l && (ptr & 0xFFFFFu) >= pstart; };
-        while (j < nm) {
-          const u32 w = g_pay[off0 + j], k = (w >> 1) & 0x7FFFu;
-          const u32 h = g_hash[k], first = g_first[k];
-          u32 d = 0, pt = troot, c0 = 0, c1 = 0, pa = 0, pb = 0;
-          u32 w0 = cu[DC_RC], w1 = 0;
-          bool miss = false, deep = false;
-          if ((w0 & 1u) == 0u) w1 = rec_of(pt)[1];   // the root is a leaf (the first few transactions of a run): its key count
-          else {
-            c0 = br_index(w0, h);
-            pt = cu[DC_RC + 1u + c0]; d = 1u;
-            for (;;) {
-              const u32 *const r = rec_of(pt);
-              const u32 w3 = __hip_atomic_load(r + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (word 3 is the one word of a record that changes after its creation, by L2 atomics: read past the L1)
-              w0 = r[0]; w1 = r[1];
-              u32 ch[8];
-#pragma unroll
-              for (u32 c = 0; c < 8u; c++) ch[c] = r[4u + c];
-              if (!is_new(pt) && !((w3 >> (2u + l)) & 1u)) { miss = true; break; }   // neither created by this transaction nor loaded by this node
-              if (d >= DT_MAXDEPTH) { deep = true; break; }   // engine capacity
-              if ((w0 & 1u) == 0u) break;   // the key's leaf
-              const u32 ci = br_index(w0, h);
-              if (d == 1u) { c1 = ci; pa = pt; } else if (d == 2u) pb = pt; else aux[D8_AUX_PATH + d] = pt;
-              pt = ch[0];
-#pragma unroll
-              for (u32 c = 1; c < 8u; c++) pt = c == ci ? ch[c] : pt;
-              d++;
-            }
-          }
-          if (miss) { cu[DC_J] = j | (napp << 8) | (ndead << 16); cu[DC_T] = troot; load(pt); return; }
-          if (deep) my_flags |= MSIM_FLAG_ARENA_OVERRUN;
-          else if (w & 1u) {   // assoc
-            const u32 n = d, lw0 = w0, lcount = w1;
-            bool has = first <= rv;   // (DT_NONE is above every version)
-            { const u32 no = cu[DC_NOWN]; for (u32 i = 0; i < no; i++) has = has || cu[DC_OWN + i] == k; }
-            const u32 L = (has || lcount < 8u) ? 1u : 9u, base = next_p, ver = rv + 1u;
-            if (base + L + n >= TC || base + L + n - pstart >= D8_MAXNEW) my_flags |= MSIM_FLAG_ARENA_OVERRUN;   // engine capacity
-            else {
-              auto put = [&](u32 idx, u32 pw0, u32 cnt, u32 key) -> u32 * {   // (word 3: lww-kv replica in bits 0-1, 3 = not written; bit 2 + i: node i has loaded it)
-                u32 *const r = g_rec + ((size_t)l * TC + idx) * DT_RW; r[0] = pw0; r[1] = cnt; r[2] = ver; __hip_atomic_store(r + 3, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                nk[idx - pstart] = key; return r; };
-              auto dies = [&](u32 ptr) { if (is_new(ptr)) { nk[(ptr & 0xFFFFFu) - pstart] = D8_DEAD; ndead++; } };   // its position is taken by a node created now
-              // the copies' sources at depth 1 and 2, at known addresses: in flight together
-              u32 wa = 0, wb = 0, cha[8], chb[8];
-              if (n >= 2u) { const u32 *const r = rec_of(pa); wa = r[0];
-#pragma unroll
-                for (u32 c = 0; c < 8u; c++) cha[c] = r[4u + c]; }
-              if (n >= 3u) { const u32 *const r = rec_of(pb); wb = r[0];
-#pragma unroll
-                for (u32 c = 0; c < 8u; c++) chb[c] = r[4u + c]; }
-              dies(pt);
-              const u32 lo = (lw0 >> 8) & 0xFFu, hi = (lw0 >> 16) & 0xFFu;
-              if (L == 1u) put(base + 1u, lw0, lcount + (has ? 0u : 1u), poskey(n, c0, c1));
-              else {   // eight leaves under a new branch: the lineage's keys of this range (and the new one) by sub-range
-                const u32 bs = (hi - lo) / 8u, nkeys = gen[32];
-                u64 c_lo = 0, c_hi = 0;   // 4 x 16-bit counters each
-                for (u32 q0 = 0; q0 < nkeys; q0 += 4u) {   // four keys per round trip
-                  u32 f4[4], h4[4];
-#pragma unroll
-                  for (u32 t = 0; t < 4u; t++) { const u32 q = min(q0 + t, nkeys - 1u); f4[t] = g_first[q]; h4[t] = g_hash[q]; }
-#pragma unroll
-                  for (u32 t = 0; t < 4u; t++) {
-                    const u32 q = q0 + t;
-                    if (q >= nkeys) continue;
-                    bool in = q == k || f4[t] <= rv;
-                    { const u32 no = cu[DC_NOWN]; for (u32 i = 0; i < no; i++) in = in || cu[DC_OWN + i] == q; }
-                    const u32 hq = h4[t];
-                    if (!in || hq < lo || hq >= hi) continue;
-                    const u32 ci = bs ? min((hq - lo) / bs, 7u) : 7u;
-                    if (ci < 4u) c_lo += 1ull << (16u * ci); else c_hi += 1ull << (16u * (ci - 4u));
-                  }
-                }
-                u32 *const br = put(base + 9u, 1u | (lo << 8) | (hi << 16), 0u, poskey(n, c0, c1));
-                for (u32 i = 0; i < 8u; i++) {
-                  const u32 b_lo = lo + i * bs, b_hi = i == 7u ? hi : b_lo + bs;
-                  const u32 cnt = (u32)((i < 4u ? c_lo >> (16u * i) : c_hi >> (16u * (i - 4u))) & 0xFFFFu);
-                  put(base + 1u + i, (b_lo << 8) | (b_hi << 16), cnt, childkey(n, i, c0, c1));
-                  br[4u + i] = (l << 20) | (base + 1u + i);
-                }
-                if (n == 0u) { cu[DC_RC] = 1u | (lo << 8) | (hi << 16); for (u32 i = 0; i < 8u; i++) cu[DC_RC + 1u + i] = (l << 20) | (base + 1u + i); }   // the new root is this branch
-              }
-              // a copy of every branch above, pointing at the new child (:256-268)
-              for (u32 i = n; i-- > 0u;) {
-                const u32 child_new = (l << 20) | (i + 1u == n ? base + L : base + L + (n - i - 1u));
-                const u32 idx = base + L + (n - i);
-                if (i == 0u) {   // the root: its record is in LDS, and stays there as the new root's
-                  dies(troot);
-                  const u32 rw0 = cu[DC_RC];
-                  u32 *const nr = put(idx, rw0, 0u, poskey(0u, c0, c1));
-                  cu[DC_RC + 1u + c0] = child_new;
-#pragma unroll
-                  for (u32 c = 0; c < 8u; c++) nr[4u + c] = cu[DC_RC + 1u + c];
-                } else if (i == 1u) {
-                  dies(pa);
-                  u32 *const nr = put(idx, wa, 0u, poskey(1u, c0, c1));
-#pragma unroll
-                  for (u32 c = 0; c < 8u; c++) nr[4u + c] = c == c1 ? child_new : cha[c];
-                } else if (i == 2u) {
-                  dies(pb);
-                  const u32 ci = br_index(wb, h);
-                  u32 *const nr = put(idx, wb, 0u, poskey(2u, c0, c1));
-#pragma unroll
-                  for (u32 c = 0; c < 8u; c++) nr[4u + c] = c == ci ? child_new : chb[c];
-                } else {   // a chain below depth 2: one link at a time
-                  const u32 pp = aux[D8_AUX_PATH + i];
-                  dies(pp);
-                  const u32 *const r = rec_of(pp);
-                  const u32 xw0 = r[0], ci = br_index(xw0, h);
-                  u32 ch[8];
-#pragma unroll
-                  for (u32 c = 0; c < 8u; c++) ch[c] = r[4u + c];
-                  u32 *const nr = put(idx, xw0, 0u, poskey(i, c0, c1));
-#pragma unroll
-                  for (u32 c = 0; c < 8u; c++) nr[4u + c] = c == ci ? child_new : ch[c];
-                }
-              }
-              if (n == 0u && L == 1u) { /* the root stays a leaf: its record in LDS (kind / range) is unchanged */ }
-              next_p = base + L + n;
-              troot = (l << 20) | next_p;
-              napp++;
-              if (!has) { const u32 no = cu[DC_NOWN]; if (no < 8u) { cu[DC_OWN + no] = k; cu[DC_NOWN] = no + 1u; } }
-            }
-          }
-          j++;
-        }
-        cu[DC_J] = j | (napp << 8) | (ndead << 16); cu[DC_T] = troot;
-        if (troot == cu[DC_P1]) { do_reply_ok = true; do_unlock = true; return; }   // nothing appended: no write, no cas
-        save(napp, ndead);
       };
 
       const bool await_over = normal && is_node && wait_until <= T;   // a node's due timer comes before its due message
@@ -813,7 +892,18 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
         }
       }
 
-      if (do_apply) apply();            // apply_txn from where it stopped: may ask for a load, start the save, or finish a read-only transaction
+      if (__ballot(do_apply)) {   // apply_txn from where it stopped: may ask for a load, start the save, or finish a read-only transaction
+        D8ApplyIO io;
+        io.np = next_p; io.mid = node_msgid; io.my_flags = my_flags; io.wait_until = wait_until;
+        io.n_out = n_out; io.o_dest = o_dest; io.o1_type = o1_type; io.o1_a = o1_a; io.o1_b = o1_b; io.o_wlo = o_wlo; io.done = 0;
+        D8ApplyK kc;
+        kc.scratch = p.scratch; kc.payload = p.payload; kc.scratch_words = p.scratch_words; kc.max_pay = max_pay; kc.N = N; kc.TC = TC; kc.mv = mv; kc.mw = mw;
+        kc.off_aux = OFF_AUX; kc.off_cur = tp.off_cur; kc.off_gen = tp.off_gen;
+        io = d8_apply(io, kc, inst, lane, T, do_apply);
+        next_p = io.np; node_msgid = io.mid; my_flags = io.my_flags; wait_until = io.wait_until;
+        n_out = io.n_out; o_dest = io.o_dest; o1_type = io.o1_type; o1_a = io.o1_a; o1_b = io.o1_b; o_wlo = io.o_wlo;
+        do_reply_ok = do_reply_ok || (io.done & 1u) != 0; do_unlock = do_unlock || (io.done & 2u) != 0;
+      }
       if (do_reply_ok) reply_txn_ok();
       if (do_unlock) unlock();          // (after the answer: the next lock holder's root read follows it)
       M8_MARK(3)
@@ -822,7 +912,7 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
         u32 excl = 0, total = 0;
         for (u32 s = 0; s < N; s++) { const u32 v = GGET(need_words, s); excl += s < l ? v : 0u; total += v; }
         if (total) {
-          if (n_payload + total > max_pay) { flags |= MSIM_FLAG_PAYLOAD_OVERFLOW; if (need_words) r_a = 0; }
+          if (n_payload + total > max_pay) { CFLAG(MSIM_FLAG_PAYLOAD_OVERFLOW); if (need_words) r_a = 0; }
           else {
             if (need_words) {
               const u32 off0 = done_ref & 0xFFFFFFu, n = done_ref >> 24;
@@ -884,7 +974,7 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
           // node -> its own client: no latency; lost like any other message (net.clj:214)
           if (rep) {
             const u32 id = next_id + my_off;
-            if (!(NET_RANDOM && loss_on && p_loss && draw32(key, S_LOSS, id) < p_loss)) { c_arr = true; ca_y = (id << 8) | r_type; ca_a = r_a; ca_b = r_b; }
+            if (!(NET_RANDOM && p_loss && cs[CS_LOSS_ON] && draw32(key, S_LOSS, id) < p_loss)) { c_arr = true; ca_y = (id << 8) | r_type; ca_a = r_a; ca_b = r_b; }
           }
           next_id += total;
         }
@@ -935,7 +1025,7 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
       const u32 nr = nem_rows + ni + __popc(cmask);
       if (__ballot(alive && nr != 0)) {
         const bool ovf = alive && nr != 0 && n_rows + nr > max_rows;
-        if (ovf) { flags |= MSIM_FLAG_ROWS_OVERFLOW; alive = false; }
+        if (ovf) { CFLAG(MSIM_FLAG_ROWS_OVERFLOW); alive = false; }
         const bool wr = alive && nr != 0;
         const u64 tns = (u64)T * 1000ull;
         const u32 tlo = (u32)tns, thi = (u32)(tns >> 32);
@@ -957,6 +1047,9 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
   // ---- epilogue ----
   u32 t_send_cl = 0, t_send_sv = 0, t_recv_cl = 0, t_recv_sv = 0;
   for (u32 s = 0; s < GS; s++) { t_send_cl += GGET(s_send_cl, s); t_send_sv += GGET(s_send_sv, s); t_recv_cl += GGET(s_recv_cl, s); t_recv_sv += GGET(s_recv_sv, s); }
+  wave_lds_fence();
+  u32 flags = cs[CS_FLAGS];
+  const u32 rounds = cs[CS_ROUNDS];
   for (u32 b = 1; b <= MSIM_FLAG_ARENA_OVERRUN; b <<= 1) if (GB((my_flags & b) != 0)) flags |= b;
   if (real && l == 0) {
     msim_net_stats st;
@@ -974,6 +1067,33 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
     p.meta[inst] = m;
   }
 }
+
+#undef o_type
+#undef o_a
+#undef o_b
+#undef o_to
+#undef next_p
+#undef root
+#undef casn
+#undef cur_v
+#undef node_msgid
+#undef svc_ctr
+#undef CFLAG
+#undef D8_INST
+#undef g_rows
+#undef g_pay
+#undef g_scr
+#undef g_kv
+#undef g_kvn
+#undef g_first
+#undef g_hash
+#undef g_rec
+#undef g_wl
+#undef g_cas
+#undef my_spill
+#undef my_cspill
+#undef aux
+#undef my_wl
 
 }  // namespace
 
@@ -1004,6 +1124,7 @@ hipError_t msim_launch_dt8(const KParams &kp, uint32_t n, hipStream_t st) {
   tp.off_gen = (u32)off; off += (size_t)8 * 36 * 4;
   off = (off + 15) & ~(size_t)15;
   tp.off_misc = (u32)off; off += 64 * 4;
+  tp.off_cs = (u32)off; off += 8 * 8 * 4;   // the clusters' shared words (CS_WORDS each)
   tp.round_limit = (kp.dev_flags & 0x100u) ? 4000000u : ROUND_LIMIT;
   const size_t lds = off;
   const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
