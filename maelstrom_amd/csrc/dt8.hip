@@ -54,6 +54,7 @@ enum { DC_STAGE = 0, DC_CMSG, DC_REF, DC_RPC, DC_P1, DC_RV, DC_T, DC_TARGET, DC_
 // depth 2, and one position key per tree node the transaction has created (what save! sorts by)
 constexpr u32 D8_AUX_WQ = 0u, D8_AUX_PATH = 16u, D8_AUX_KEYS = 64u, D8_MAXNEW = 512u, D8_AUX = D8_AUX_KEYS + D8_MAXNEW + 4u;
 constexpr u32 D8_DEAD = 0xFFFFFFFFu;
+constexpr u32 D8_NOFIRST = 0xFFFFFFu;   // a key that is in no committed tree yet (above every version)
 
 struct M8Params {
   KParams k;
@@ -111,10 +112,10 @@ struct D8ApplyIO {
 struct D8ApplyK {   // constants of the launch
   u32 *scratch; u32 *payload; u64 scratch_words; u32 max_pay, N, TC, mv, mw, off_aux, off_cur, off_gen;
 };
-#ifdef D8_APPLY_INLINE   // (developer A/B)
-#define D8_APPLY_ATTR __forceinline__
-#else
+#ifdef D8_APPLY_NOINLINE   // (developer A/B: as a function of its own the call costs more than it saves — 1039 ms against 675 per 32768 clusters, profiles/r06_dt8_variants.jsonl)
 #define D8_APPLY_ATTR __attribute__((noinline))
+#else
+#define D8_APPLY_ATTR __forceinline__
 #endif
 __device__ D8_APPLY_ATTR D8ApplyIO d8_apply(D8ApplyIO io, const D8ApplyK kc, u32 inst, u32 lane, u32 T_in, bool active) {   // (called by the whole wavefront: the constants are made scalar with every lane in)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -126,13 +127,13 @@ __device__ D8_APPLY_ATTR D8ApplyIO d8_apply(D8ApplyIO io, const D8ApplyK kc, u32
   const u32 OFF_AUX = UNI(kc.off_aux), off_cur = UNI(kc.off_cur), off_gen = UNI(kc.off_gen);
 #undef UNI
   const u32 l = lane & 7u, grp = lane >> 3;
-  const u32 OFF_KVN = mv * mw, OFF_FIRST = OFF_KVN + mv, OFF_HASHW = OFF_FIRST + mv, OFF_REC = OFF_HASHW + (mv + 3u) / 4u;
+  const u32 OFF_KVN = mv * mw, OFF_FIRST = OFF_KVN + mv, OFF_HASHW = OFF_FIRST + mv, OFF_REC = (OFF_HASHW + (mv + 3u) / 4u + 3u) & ~3u;   // (records are read and written 16 bytes at a time)
   const u32 OFF_WL = OFF_REC + N * TC * DT_RW;
   (void)OFF_KVN;
   u32 *const g_scr = scratch0 + (size_t)inst * scratch_words;
   const u32 *const g_pay = payload0 + (size_t)inst * max_pay;
-  const u32 *const g_first = g_scr + OFF_FIRST;
-  const unsigned char *const g_hash = reinterpret_cast<const unsigned char *>(g_scr + OFF_HASHW);
+  const u32 *const g_first = g_scr + OFF_FIRST;   // per key: the version at which it entered the tree << 8 | Tree.hash (one word, one request)
+  (void)OFF_HASHW;
   u32 *const g_rec = g_scr + OFF_REC;
   u32 *const aux = g_scr + OFF_AUX + l * D8_AUX;
   u32 *const my_wl = g_scr + OFF_WL + l * DT_MAXW;
@@ -147,7 +148,7 @@ __device__ D8_APPLY_ATTR D8ApplyIO d8_apply(D8ApplyIO io, const D8ApplyK kc, u32
   auto br_index = [&](u32 w0, u32 h) -> u32 {   // branch_index (:231-247) with the split's bounds (:170-181)
     const u32 lo = (w0 >> 8) & 0xFFu, hi = (w0 >> 16) & 0xFFu, bs = (hi - lo) / 8u;
     u32 r = 7u;
-  #pragma unroll
+#pragma unroll
     for (u32 i = 7u; i-- > 0u;) r = h < lo + (i + 1u) * bs ? i : r;
     return r;
   };
@@ -211,9 +212,19 @@ __device__ D8_APPLY_ATTR D8ApplyIO d8_apply(D8ApplyIO io, const D8ApplyK kc, u32
     u32 troot = cu[DC_T];
     u32 *const nk = aux + D8_AUX_KEYS;
     auto is_new = [&](u32 ptr) -> bool { return (ptr >> 20) == l && (ptr & 0xFFFFFu) >= pstart; };
+    u32 wq[4] = {0, 0, 0, 0}, hfq[4] = {0, 0, 0, 0}, qbase = 0xFFFFFFF0u;   // four micro-ops and their keys' words per pair of round trips
     while (j < nm) {
-      const u32 w = g_pay[off0 + j], k = (w >> 1) & 0x7FFFu;
-      const u32 h = g_hash[k], first = g_first[k];
+      if (j - qbase >= 4u) {
+        qbase = j;
+#pragma unroll
+        for (u32 t = 0; t < 4u; t++) wq[t] = g_pay[off0 + min(j + t, nm - 1u)];
+#pragma unroll
+        for (u32 t = 0; t < 4u; t++) hfq[t] = g_first[(wq[t] >> 1) & 0x7FFFu];
+      }
+      const u32 tq = j - qbase;
+      const u32 w = tq == 0u ? wq[0] : tq == 1u ? wq[1] : tq == 2u ? wq[2] : wq[3];
+      const u32 hf = tq == 0u ? hfq[0] : tq == 1u ? hfq[1] : tq == 2u ? hfq[2] : hfq[3];
+      const u32 k = (w >> 1) & 0x7FFFu, h = hf & 0xFFu, first = hf >> 8;
       u32 d = 0, pt = troot, c0 = 0, c1 = 0, pa = 0, pb = 0;
       u32 w0 = cu[DC_RC], w1 = 0;
       bool miss = false, deep = false;
@@ -224,17 +235,18 @@ __device__ D8_APPLY_ATTR D8ApplyIO d8_apply(D8ApplyIO io, const D8ApplyK kc, u32
         for (;;) {
           const u32 *const r = rec_of(pt);
           const u32 w3 = __hip_atomic_load(r + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (word 3 is the one word of a record that changes after its creation, by L2 atomics: read past the L1)
-          w0 = r[0]; w1 = r[1];
-          u32 ch[8];
-  #pragma unroll
-          for (u32 c = 0; c < 8u; c++) ch[c] = r[4u + c];
+          // a record is three 16-byte accesses (kind / range, key count, version, -; children 0-3; children 4-7): what a CU's L1 serves is
+          // requests, not bytes — at full occupancy the kernel sits on that, so a record is never read word by word
+          const uint4 rq0 = reinterpret_cast<const uint4 *>(r)[0], rq1 = reinterpret_cast<const uint4 *>(r)[1], rq2 = reinterpret_cast<const uint4 *>(r)[2];
+          w0 = rq0.x; w1 = rq0.y;
+          const u32 ch[8] = {rq1.x, rq1.y, rq1.z, rq1.w, rq2.x, rq2.y, rq2.z, rq2.w};
           if (!is_new(pt) && !((w3 >> (2u + l)) & 1u)) { miss = true; break; }   // neither created by this transaction nor loaded by this node
           if (d >= DT_MAXDEPTH) { deep = true; break; }   // engine capacity
           if ((w0 & 1u) == 0u) break;   // the key's leaf
           const u32 ci = br_index(w0, h);
           if (d == 1u) { c1 = ci; pa = pt; } else if (d == 2u) pb = pt; else aux[D8_AUX_PATH + d] = pt;
           pt = ch[0];
-  #pragma unroll
+#pragma unroll
           for (u32 c = 1; c < 8u; c++) pt = c == ci ? ch[c] : pt;
           d++;
         }
@@ -249,17 +261,18 @@ __device__ D8_APPLY_ATTR D8ApplyIO d8_apply(D8ApplyIO io, const D8ApplyK kc, u32
         if (base + L + n >= TC || base + L + n - pstart >= D8_MAXNEW) my_flags |= MSIM_FLAG_ARENA_OVERRUN;   // engine capacity
         else {
           auto put = [&](u32 idx, u32 pw0, u32 cnt, u32 key) -> u32 * {   // (word 3: lww-kv replica in bits 0-1, 3 = not written; bit 2 + i: node i has loaded it)
-            u32 *const r = g_rec + ((size_t)l * TC + idx) * DT_RW; r[0] = pw0; r[1] = cnt; r[2] = ver; __hip_atomic_store(r + 3, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            u32 *const r = g_rec + ((size_t)l * TC + idx) * DT_RW; *reinterpret_cast<uint4 *>(r) = make_uint4(pw0, cnt, ver, 3u);
             nk[idx - pstart] = key; return r; };
+          auto put_children = [&](u32 *nr, uint4 q1, uint4 q2, u32 ci, u32 child_new) {   // eight children, the one at ci replaced: two 16-byte stores
+            q1.x = ci == 0u ? child_new : q1.x; q1.y = ci == 1u ? child_new : q1.y; q1.z = ci == 2u ? child_new : q1.z; q1.w = ci == 3u ? child_new : q1.w;
+            q2.x = ci == 4u ? child_new : q2.x; q2.y = ci == 5u ? child_new : q2.y; q2.z = ci == 6u ? child_new : q2.z; q2.w = ci == 7u ? child_new : q2.w;
+            reinterpret_cast<uint4 *>(nr)[1] = q1; reinterpret_cast<uint4 *>(nr)[2] = q2; };
           auto dies = [&](u32 ptr) { if (is_new(ptr)) { nk[(ptr & 0xFFFFFu) - pstart] = D8_DEAD; ndead++; } };   // its position is taken by a node created now
           // the copies' sources at depth 1 and 2, at known addresses: in flight together
-          u32 wa = 0, wb = 0, cha[8], chb[8];
-          if (n >= 2u) { const u32 *const r = rec_of(pa); wa = r[0];
-  #pragma unroll
-            for (u32 c = 0; c < 8u; c++) cha[c] = r[4u + c]; }
-          if (n >= 3u) { const u32 *const r = rec_of(pb); wb = r[0];
-  #pragma unroll
-            for (u32 c = 0; c < 8u; c++) chb[c] = r[4u + c]; }
+          u32 wa = 0, wb = 0;
+          uint4 qa1 = make_uint4(0, 0, 0, 0), qa2 = qa1, qb1 = qa1, qb2 = qa1;
+          if (n >= 2u) { const uint4 *const r = reinterpret_cast<const uint4 *>(rec_of(pa)); wa = r[0].x; qa1 = r[1]; qa2 = r[2]; }
+          if (n >= 3u) { const uint4 *const r = reinterpret_cast<const uint4 *>(rec_of(pb)); wb = r[0].x; qb1 = r[1]; qb2 = r[2]; }
           dies(pt);
           const u32 lo = (lw0 >> 8) & 0xFFu, hi = (lw0 >> 16) & 0xFFu;
           if (L == 1u) put(base + 1u, lw0, lcount + (has ? 0u : 1u), poskey(n, c0, c1));
@@ -268,9 +281,9 @@ __device__ D8_APPLY_ATTR D8ApplyIO d8_apply(D8ApplyIO io, const D8ApplyK kc, u32
             u64 c_lo = 0, c_hi = 0;   // 4 x 16-bit counters each
             for (u32 q0 = 0; q0 < nkeys; q0 += 4u) {   // four keys per round trip
               u32 f4[4], h4[4];
-  #pragma unroll
-              for (u32 t = 0; t < 4u; t++) { const u32 q = min(q0 + t, nkeys - 1u); f4[t] = g_first[q]; h4[t] = g_hash[q]; }
-  #pragma unroll
+#pragma unroll
+              for (u32 t = 0; t < 4u; t++) { const u32 q = min(q0 + t, nkeys - 1u); const u32 hf = g_first[q]; f4[t] = hf >> 8; h4[t] = hf & 0xFFu; }
+#pragma unroll
               for (u32 t = 0; t < 4u; t++) {
                 const u32 q = q0 + t;
                 if (q >= nkeys) continue;
@@ -287,8 +300,9 @@ __device__ D8_APPLY_ATTR D8ApplyIO d8_apply(D8ApplyIO io, const D8ApplyK kc, u32
               const u32 b_lo = lo + i * bs, b_hi = i == 7u ? hi : b_lo + bs;
               const u32 cnt = (u32)((i < 4u ? c_lo >> (16u * i) : c_hi >> (16u * (i - 4u))) & 0xFFFFu);
               put(base + 1u + i, (b_lo << 8) | (b_hi << 16), cnt, childkey(n, i, c0, c1));
-              br[4u + i] = (l << 20) | (base + 1u + i);
             }
+            { const u32 k0 = (l << 20) | (base + 1u);
+              reinterpret_cast<uint4 *>(br)[1] = make_uint4(k0, k0 + 1u, k0 + 2u, k0 + 3u); reinterpret_cast<uint4 *>(br)[2] = make_uint4(k0 + 4u, k0 + 5u, k0 + 6u, k0 + 7u); }
             if (n == 0u) { cu[DC_RC] = 1u | (lo << 8) | (hi << 16); for (u32 i = 0; i < 8u; i++) cu[DC_RC + 1u + i] = (l << 20) | (base + 1u + i); }   // the new root is this branch
           }
           // a copy of every branch above, pointing at the new child (:256-268)
@@ -300,30 +314,25 @@ __device__ D8_APPLY_ATTR D8ApplyIO d8_apply(D8ApplyIO io, const D8ApplyK kc, u32
               const u32 rw0 = cu[DC_RC];
               u32 *const nr = put(idx, rw0, 0u, poskey(0u, c0, c1));
               cu[DC_RC + 1u + c0] = child_new;
-  #pragma unroll
-              for (u32 c = 0; c < 8u; c++) nr[4u + c] = cu[DC_RC + 1u + c];
+              reinterpret_cast<uint4 *>(nr)[1] = make_uint4(cu[DC_RC + 1u], cu[DC_RC + 2u], cu[DC_RC + 3u], cu[DC_RC + 4u]);
+              reinterpret_cast<uint4 *>(nr)[2] = make_uint4(cu[DC_RC + 5u], cu[DC_RC + 6u], cu[DC_RC + 7u], cu[DC_RC + 8u]);
             } else if (i == 1u) {
               dies(pa);
               u32 *const nr = put(idx, wa, 0u, poskey(1u, c0, c1));
-  #pragma unroll
-              for (u32 c = 0; c < 8u; c++) nr[4u + c] = c == c1 ? child_new : cha[c];
+              put_children(nr, qa1, qa2, c1, child_new);
             } else if (i == 2u) {
               dies(pb);
               const u32 ci = br_index(wb, h);
               u32 *const nr = put(idx, wb, 0u, poskey(2u, c0, c1));
-  #pragma unroll
-              for (u32 c = 0; c < 8u; c++) nr[4u + c] = c == ci ? child_new : chb[c];
+              put_children(nr, qb1, qb2, ci, child_new);
             } else {   // a chain below depth 2: one link at a time
               const u32 pp = aux[D8_AUX_PATH + i];
               dies(pp);
-              const u32 *const r = rec_of(pp);
-              const u32 xw0 = r[0], ci = br_index(xw0, h);
-              u32 ch[8];
-  #pragma unroll
-              for (u32 c = 0; c < 8u; c++) ch[c] = r[4u + c];
+              const uint4 *const r = reinterpret_cast<const uint4 *>(rec_of(pp));
+              const uint4 x0 = r[0], x1 = r[1], x2 = r[2];
+              const u32 xw0 = x0.x, ci = br_index(xw0, h);
               u32 *const nr = put(idx, xw0, 0u, poskey(i, c0, c1));
-  #pragma unroll
-              for (u32 c = 0; c < 8u; c++) nr[4u + c] = c == ci ? child_new : ch[c];
+              put_children(nr, x1, x2, ci, child_new);
             }
           }
           if (n == 0u && L == 1u) { /* the root stays a leaf: its record in LDS (kind / range) is unchanged */ }
@@ -375,7 +384,7 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
   // address in an instance's slabs is the slab's base (a kernel argument: scalar registers) + the instance's offset, formed where it is used from
   // `inst` behind an optimization barrier (loop-invariant code motion would otherwise hold a dozen 64-bit pointers per lane for the whole run);
   // the offsets of the regions inside an instance's scratch (dt_kernel<>'s layout, sim_kernel_dt.inc) are the same for every cluster: scalars.
-  const u32 OFF_KVN = mv * mw, OFF_FIRST = OFF_KVN + mv, OFF_HASHW = OFF_FIRST + mv, OFF_REC = OFF_HASHW + (mv + 3u) / 4u;
+  const u32 OFF_KVN = mv * mw, OFF_FIRST = OFF_KVN + mv, OFF_HASHW = OFF_FIRST + mv, OFF_REC = (OFF_HASHW + (mv + 3u) / 4u + 3u) & ~3u;   // (records are read and written 16 bytes at a time)
   const u32 OFF_WL = OFF_REC + N * TC * DT_RW, OFF_CAS = OFF_WL + N * DT_MAXW;
   const u32 OFF_SPILL = (u32)p.spill_off, OFF_CSPILL = (u32)tp.client_spill_off, OFF_AUX = (u32)tp.stack_off;
   const u32 qlane = l <= N + 1u ? l : 0u;
@@ -387,8 +396,7 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
 #define g_scr (p.scratch + D8_INST * p.scratch_words)
 #define g_kv g_scr                                                  /* [max_values][mw]: element | version << 8 */
 #define g_kvn (g_scr + OFF_KVN)                                     /* [max_values] */
-#define g_first (g_scr + OFF_FIRST)                                 /* [max_values] version at which the key entered the tree (DT_NONE: never) */
-#define g_hash (reinterpret_cast<unsigned char *>(g_scr + OFF_HASHW))   /* [max_values] Tree.hash of the key */
+#define g_first (g_scr + OFF_FIRST)                                 /* [max_values] version at which the key entered the tree (D8_NOFIRST: never) << 8 | Tree.hash of the key: what a walk needs of a key in ONE word (dt_kernel<> keeps the hashes in a byte array behind this one) */
 #define g_rec (g_scr + OFF_REC)                                     /* [N][TC][DT_RW] tree nodes by pointer */
 #define g_wl (g_scr + OFF_WL)                                       /* [N][DT_MAXW] the pointers a node writes this round */
 #define g_cas (g_scr + OFF_CAS)                                     /* [N][DT_CASQ] x {msg_id, from, transaction}: what a node's cas requests carry beside `to` */
@@ -408,7 +416,7 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
   for (u32 i = l; i < 16; i += GS) { gen[i] = i; gen[16 + i] = 1; }
   if (l == 0) gen[32] = p.cfg.key_count;
   if (real) {
-    for (u32 i = l; i < mv; i += GS) { g_kvn[i] = 0; g_first[i] = DT_NONE; g_hash[i] = (unsigned char)d8_hash(i); }
+    for (u32 i = l; i < mv; i += GS) { g_kvn[i] = 0; g_first[i] = (D8_NOFIRST << 8) | d8_hash(i); }
     for (u32 i = l; i < N * DT_CASQ * 3u; i += GS) g_cas[i] = 0;
   }
   __syncthreads();
@@ -498,7 +506,15 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
     const u32 *const kvr = g_kv + k * mw;
     const u32 cnt = kvr[OFF_KVN + k - k * mw];   // (= g_kvn[k])
     u32 n = 0;
-    if (mw <= 16u) {
+    if (mw == 16u) {   // (the default max-writes-per-key: a key's row is four aligned 16-byte words)
+      const uint4 *const q = reinterpret_cast<const uint4 *>(kvr);
+      const uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+      const u32 row[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+#pragma unroll
+      for (u32 i = 0; i < 16u; i++) n += (i < cnt && (row[i] >> 8) <= from) ? 1u : 0u;
+      return n;
+    }
+    if (mw < 16u) {
       u32 row[16];
 #pragma unroll
       for (u32 i = 0; i < 16u; i++) row[i] = i < cnt ? kvr[i] : 0xFFFFFFFFu;
@@ -514,8 +530,16 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
   u64 pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; u32 wave_rounds = 0;
   u64 tprev = __builtin_readcyclecounter();
 #define M8_MARK(i) { const u64 now_ = __builtin_readcyclecounter(); pacc[i] += now_ - tprev; tprev = now_; }
+#ifdef D8_PROF2   // the finer split of tools/dt8_prof_report.py --fine: 0 top .. R2, 1 handlers, 2 apply_txn, 3 answer + unlock, 4 payload, 5 arrivals, 6 poll, 7 R4 + rows
+#define M8_MARK2(i) { const u64 now_ = __builtin_readcyclecounter(); pacc[i] += now_ - tprev; tprev = now_; }
+#undef M8_MARK
+#define M8_MARK(i)
+#else
+#define M8_MARK2(i)
+#endif
 #else
 #define M8_MARK(i)
+#define M8_MARK2(i)
 #endif
   for (;;) {
     if (!__ballot(alive)) break;
@@ -731,6 +755,7 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
       }
 
       M8_MARK(2)
+      M8_MARK2(0)
       // ---- R3: one input per node, then one for each service (endpoint order: lin-kv, lww-kv) ----
       bool rep = false, svc_rep = false;   // node -> own client, service -> node
       u32 r_type = 0, r_a = 0, r_b = 0;    // the answer to the client
@@ -793,14 +818,25 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
         const uint4 q = cm; deliver_at = INF;
         const u32 qsrc = q.w >> 24, qb = q.w & 0xFFFFFFu, qtype = q.y & 0xFFu, qa = q.z;
         if (qsrc >= N && qsrc < LIN) s_recv_cl++; else s_recv_sv++;
+        // What a handler reads from HBM first is known from the envelope alone, and the three kinds of lanes would otherwise wait for it one after
+        // the other (divergent branches run in sequence): a node whose root read is answered wants the root's record, lin-kv its sender's table of
+        // cas requests, lww-kv the word of the record that holds the replica.  One batch for all of them: three 16-byte words + the flags word past the L1.
+        const u32 st = is_node ? cu[DC_STAGE] : 0u;
+        const bool pf_root = is_node && st == DS_ROOT && qtype == M_READ_OK && qb == cu[DC_RPC];
+        const bool pf_cas = is_lin && qtype == M_CAS, pf_lww = l == N + 1u;
+        uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = pf0, pf2 = pf0; u32 pf3 = 0;
+        if (pf_root || pf_cas || pf_lww) {
+          const u32 *const pp = pf_cas ? g_cas + (size_t)qsrc * DT_CASQ * 3u : rec_of(qa);
+          if (!pf_cas) pf3 = __hip_atomic_load(pp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (word 3 changes after a record's creation, by L2 atomics)
+          if (!pf_lww) { pf0 = reinterpret_cast<const uint4 *>(pp)[0]; pf1 = reinterpret_cast<const uint4 *>(pp)[1]; pf2 = reinterpret_cast<const uint4 *>(pp)[2]; }
+        }
         if (is_node) {
-          const u32 st = cu[DC_STAGE];
           switch (qtype) {
             case M_INIT:
               if (l != 0u) { rep = true; r_type = M_INIT_OK; r_b = qb; break; }
               {   // the first node writes the initial state (:337-345): Tree.empty, then the root pointer
                 u32 *const r = g_rec;
-                r[0] = (128u << 16); r[1] = 0; r[2] = 0; __hip_atomic_store(r + 3, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *reinterpret_cast<uint4 *>(r) = make_uint4(128u << 16, 0u, 0u, 3u);
                 const u32 rid = ++node_msgid;
                 cu[DC_STAGE] = DS_INIT_LEAF; cu[DC_CMSG] = qb; cu[DC_RPC] = rid;
                 send1(D_LWW, M_WRITE, 0, rid);
@@ -825,11 +861,11 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
                   if (qb != cu[DC_RPC]) break;
                   if (qtype != M_READ_OK) { rep = true; r_type = M_ERROR; r_a = 14; r_b = cu[DC_CMSG]; do_unlock = true; break; }   // "Unsure how to handle" (:364)
                   cu[DC_P1] = qa; cu[DC_T] = qa; cu[DC_PSTART] = next_p + 1u;
-                  { const u32 *const rr = rec_of(qa);   // the root's record stays in LDS for the walks of this transaction (its content never changes)
-                    const u32 rw0 = rr[0], rv2 = rr[2], rw3 = __hip_atomic_load(rr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    u32 rch[8];
-#pragma unroll
-                    for (u32 c = 0; c < 8u; c++) rch[c] = rr[4u + c];
+                  {   // the root's record (prefetched above) stays in LDS for the walks of this transaction (its content never changes)
+                    const u32 rw3 = pf3;
+                    const uint4 rq1 = pf1, rq2 = pf2;
+                    const u32 rw0 = pf0.x, rv2 = pf0.z;
+                    const u32 rch[8] = {rq1.x, rq1.y, rq1.z, rq1.w, rq2.x, rq2.y, rq2.z, rq2.w};
                     cu[DC_RV] = rv2; cu[DC_RC] = rw0;
 #pragma unroll
                     for (u32 c = 0; c < 8u; c++) cu[DC_RC + 1u + c] = rch[c];
@@ -866,7 +902,7 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
           else {   // cas, no create_if_not_exists.  The request is self-contained (:376-388): its `from` and its transaction come from the sender's
             // table of cas requests under the msg_id, not from what the sender holds NOW (it may have given up on this cas and moved on)
             u32 c_from = 0, c_ref = 0; bool c_hit = false;
-            { const u32 *const ce = g_cas + (size_t)qsrc * DT_CASQ * 3u;
+            { const u32 ce[12] = {pf0.x, pf0.y, pf0.z, pf0.w, pf1.x, pf1.y, pf1.z, pf1.w, pf2.x, pf2.y, pf2.z, pf2.w};   // (the sender's table, prefetched above)
 #pragma unroll
               for (u32 i = 0; i < DT_CASQ; i++) { const u32 e0 = ce[3u * i], e1 = ce[3u * i + 1u], e2 = ce[3u * i + 2u]; if (e0 == qb) { c_hit = true; c_from = e1; c_ref = e2; } } }
             if (!c_hit) { my_flags |= MSIM_FLAG_ARENA_OVERRUN; o_type = M_ERROR; o_a = 22; }   // engine capacity: DT_CASQ outstanding cas requests per node
@@ -875,9 +911,23 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
             else {
               const u32 ref = c_ref, off0 = ref & 0xFFFFFFu, n = ref >> 24, v = ++cur_v;
               root = qa;
-              for (u32 i = 0; i < n; i++) { const u32 w = g_pay[off0 + i];
-                if (w & 1u) { const u32 k = (w >> 1) & 0x7FFFu, c = g_kvn[k]; if (g_first[k] == DT_NONE) g_first[k] = v;
-                  g_kv[k * mw + c] = ((w >> 16) & 0xFFu) | (v << 8); g_kvn[k] = c + 1u; } }
+              for (u32 i0 = 0; i0 < n; i0 += 4u) {   // the transaction's appends enter the log: four micro-ops per pair of round trips
+                u32 w4[4], c4[4], hf4[4];
+#pragma unroll
+                for (u32 t = 0; t < 4u; t++) w4[t] = g_pay[off0 + min(i0 + t, n - 1u)];
+#pragma unroll
+                for (u32 t = 0; t < 4u; t++) { const u32 k = (w4[t] >> 1) & 0x7FFFu; c4[t] = g_kvn[k]; hf4[t] = g_first[k]; }
+#pragma unroll
+                for (u32 t = 0; t < 4u; t++) {
+                  const u32 w = w4[t], k = (w >> 1) & 0x7FFFu;
+                  if (i0 + t >= n || !(w & 1u)) continue;
+                  u32 c = c4[t];
+#pragma unroll
+                  for (u32 u = 0; u < t; u++) c += ((w4[u] & 1u) && ((w4[u] >> 1) & 0x7FFFu) == k) ? 1u : 0u;   // (an earlier append of this batch to the same key)
+                  if ((hf4[t] >> 8) == D8_NOFIRST) g_first[k] = (v << 8) | (hf4[t] & 0xFFu);
+                  g_kv[k * mw + c] = ((w >> 16) & 0xFFu) | (v << 8); g_kvn[k] = c + 1u;
+                }
+              }
               o_type = M_CAS_OK; o_a = 0;
             }
           }
@@ -887,11 +937,12 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
           const u32 r = scale32(draw32(key, 12u /* S_SVC */, svc_ctr++), 2);
           u32 *const rp = rec_of(qa) + 3;   // (the replica bits; the nodes set their "loaded" bits in the same word: atomics)
           if (qtype == M_WRITE) { atomicAnd(rp, ~3u); atomicOr(rp, r); o_type = M_WRITE_OK; o_a = qa; }
-          else if ((__hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 3u) == r) { o_type = M_READ_OK; o_a = qa; }
+          else if ((pf3 & 3u) == r) { o_type = M_READ_OK; o_a = qa; }   // (the word was prefetched above)
           else { o_type = M_ERROR; o_a = 20; }
         }
       }
 
+      M8_MARK2(1)
       if (__ballot(do_apply)) {   // apply_txn from where it stopped: may ask for a load, start the save, or finish a read-only transaction
         D8ApplyIO io;
         io.np = next_p; io.mid = node_msgid; io.my_flags = my_flags; io.wait_until = wait_until;
@@ -904,9 +955,11 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
         n_out = io.n_out; o_dest = io.o_dest; o1_type = io.o1_type; o1_a = io.o1_a; o1_b = io.o1_b; o_wlo = io.o_wlo;
         do_reply_ok = do_reply_ok || (io.done & 1u) != 0; do_unlock = do_unlock || (io.done & 2u) != 0;
       }
+      M8_MARK2(2)
       if (do_reply_ok) reply_txn_ok();
       if (do_unlock) unlock();          // (after the answer: the next lock holder's root read follows it)
       M8_MARK(3)
+      M8_MARK2(3)
       // completed transactions: payload words allocated in node order, each node writes its own
       if (__ballot(need_words != 0)) {
         u32 excl = 0, total = 0;
@@ -937,6 +990,7 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
       }
 
       M8_MARK(4)
+      M8_MARK2(4)
       // COMMIT: ids in lane order (nodes, lin-kv, lww-kv); a node's messages in the order it emitted them: the answer to its client, then
       // what the next step sends to a service
       bool c_arr = false; u32 ca_y = 0, ca_a = 0, ca_b = 0;
@@ -978,10 +1032,12 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
           }
           next_id += total;
         }
+        M8_MARK2(5)
         poll();
       }
 
       M8_MARK(5)
+      M8_MARK2(6)
       // ---- R4: the clients' recv! loops (client.clj:94-107) ----
       if (__ballot(c_arr || (busy && (cin_n | csp_n) != 0))) {
         for (;;) {
@@ -1042,6 +1098,7 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
       }
     }
     M8_MARK(7)
+    M8_MARK2(7)
   }
 
   // ---- epilogue ----
@@ -1086,7 +1143,6 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
 #undef g_kv
 #undef g_kvn
 #undef g_first
-#undef g_hash
 #undef g_rec
 #undef g_wl
 #undef g_cas

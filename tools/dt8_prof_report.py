@@ -22,6 +22,8 @@ with E.Engine(cfg) as eng:
     v = np.array([[eng.meta(i).n_events, *eng.meta(i).reserved, eng.meta(i + 1).n_events, *eng.meta(i + 1).reserved, eng.meta(i + 2).n_events] for i in range(0, n - 7, 8)], dtype=np.float64)
     rounds = np.array([eng.meta(i).n_rounds for i in range(n)], dtype=np.float64)
 names = ["top + R0 time", "R1 scheduler", "R2 invoke", "R3 nodes + services", "completed txns -> payload", "commit + poll", "R4 clients", "rows"]
+if os.environ.get("FINE"):   # the -DD8_PROF2 build
+    names = ["top .. R2 invoke", "R3 handlers (nodes, lin-kv, lww-kv)", "R3 apply_txn", "R3 answer + unlock", "completed txns -> payload", "commit: arrivals", "commit: poll", "R4 clients + rows"]
 cyc = v[:, :8] * 64
 wr = v[:, 8]
 tot = cyc.sum(axis=1)
