@@ -106,11 +106,13 @@ extern "C" int msim_create(const msim_config *cfg, int device, msim_ctx **out, c
   msim_config c = *cfg;
   int rc = msim_config_finalize(&c, err, errlen);
   if (rc != MSIM_OK) return rc;
-  if ((c.node_program == MSIM_NODE_TXN_MULTI_KEY || c.node_program == MSIM_NODE_TXN_DATOMIC) && (c.concurrency != c.n_nodes || c.n_nodes > 30)) {
-    set_err(err, errlen, "multi_key_txn / datomic: one worker per node and at most 30 nodes (two service lanes) in this build");
+  const bool dt_many = c.node_program == MSIM_NODE_TXN_DATOMIC && c.concurrency > c.n_nodes;   // several workers per node: dtg_kernel<> (endpoint per lane)
+  if ((c.node_program == MSIM_NODE_TXN_MULTI_KEY || c.node_program == MSIM_NODE_TXN_DATOMIC) && !dt_many && (c.concurrency != c.n_nodes || c.n_nodes > 30)) {
+    set_err(err, errlen, "multi_key_txn / datomic: one worker per node and at most 30 nodes (two service lanes) in this build; datomic also k x node-count workers");
     return MSIM_E_UNSUPPORTED;
   }
-  const uint32_t slots = c.concurrency > c.n_nodes ? c.concurrency : c.n_nodes;
+  if (dt_many && c.n_nodes + c.concurrency + 2 > 64) { set_err(err, errlen, "datomic with several workers per node: nodes + workers + 2 services <= 64"); return MSIM_E_UNSUPPORTED; }
+  const uint32_t slots = (c.concurrency > c.n_nodes ? c.concurrency : c.n_nodes) + (dt_many ? 2 : 0);
   // wide clusters (33..127 nodes): two node/client pairs per lane, one worker per node: the g-set CRDT and fire-and-forget broadcast
   const bool wide_prog = c.node_program == MSIM_NODE_G_SET || c.node_program == MSIM_NODE_BCAST_FF || c.node_program == MSIM_NODE_BCAST_FF_ECHOBACK ||
                          c.node_program == MSIM_NODE_BCAST_ACK_RETRY || c.node_program == MSIM_NODE_BCAST_RPC_ALL || c.node_program == MSIM_NODE_PN_COUNTER;
@@ -246,11 +248,12 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   const bool is_hat = c.node_program == MSIM_NODE_TXN_RW_HAT, is_mk = c.node_program == MSIM_NODE_TXN_MULTI_KEY, is_kf = c.node_program == MSIM_NODE_KAFKA, is_dt = c.node_program == MSIM_NODE_TXN_DATOMIC;
   kp.mk_tcap = is_mk ? mk_tcap(c) : is_dt ? dt_tcap(c) : 0; kp.mk_ccap = is_mk ? mk_ccap(c) : 0;
   kp.off_inbox = (u32)off;
-  off += (is_mk || is_dt) ? ((size_t)(kp.N + 2) * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16 : is_hat ? ((size_t)kp.N * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16 : is_px ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.CS * R_CLIENT_CAP) * 16 : (is_txn || is_kf) ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16
+  const bool dt_many = is_dt && c.concurrency > c.n_nodes;   // dtg_kernel<>: a lane per endpoint, a client inbox per worker slot
+  off += (is_mk || is_dt) ? ((size_t)(kp.N + 2) * kp.cap_node + (size_t)(dt_many ? kp.CS : kp.N) * T_CLIENT_CAP) * 16 : is_hat ? ((size_t)kp.N * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16 : is_px ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.CS * R_CLIENT_CAP) * 16 : (is_txn || is_kf) ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16
                 : ((size_t)kp.N * kp.cap_node + (size_t)kp.CS * (is_raft ? R_CLIENT_CAP : CLIENT_INBOX_CAP)) * 16 + wide_client_bytes(c);   // (wide: + the pairs' client state)
   kp.off_seen = (u32)off;
   off += is_mk ? ((size_t)kp.N * MK_SL * mk_slot_words(mk_keys_for(c)) + (size_t)kp.N * mk_keys_for(c) * 3 + 36) * 4   // transactions in flight (the first MK_SL per node), a round's messages per node, the generator's key pool
-       : is_dt ? ((size_t)kp.N * DC_WORDS + 36) * 4   // the nodes' transactions (lock holder, waiting queue, save stack), the generator's key pool
+       : is_dt ? ((size_t)kp.N * (dt_many ? DG_WORDS : DC_WORDS) + 36) * 4   // the nodes' transactions (lock holder, waiting queue, save stack), the generator's key pool
        : is_hat ? 36 * 4   // the generator's key pool
        : is_px ? (size_t)kp.N * PX_SLOTS * 8 + 34 * 256 + 64 * 4   // callbacks per node + service states + seq-kv indices
        : is_txn ? (size_t)kp.N * TXN_SLOTS * 16 + 36 * 4   // transactions in flight per node + the generator's key pool
@@ -313,7 +316,7 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
     case MSIM_NODE_LIN_KV_PROXY: case MSIM_NODE_TSO_IDS: e = msim_launch_svc1(kp, n, lds, st); break;   // (lin-tso ids: the proxy's layout with the timestamp oracle on the service lane)
     case MSIM_NODE_TXN_SINGLE_KEY: e = msim_launch_txn1(kp, n, lds, st); break;
     case MSIM_NODE_TXN_MULTI_KEY: e = msim_launch_mk1(kp, n, lds, st); break;
-    case MSIM_NODE_TXN_DATOMIC: e = msim_launch_dt1(kp, n, lds, st); break;
+    case MSIM_NODE_TXN_DATOMIC: e = dt_many ? msim_launch_dtg(kp, n, lds, st) : msim_launch_dt1(kp, n, lds, st); break;
     case MSIM_NODE_KAFKA: e = msim_launch_kafka1(kp, n, lds, st); break;
     case MSIM_NODE_TXN_RW_HAT: e = msim_launch_hat1(kp, n, lds, st); break;
     default: ctx->err = "node program not built into this engine"; return MSIM_E_UNSUPPORTED;

@@ -47,8 +47,9 @@ def replay(cfg, instance):
     rows, pay = ora.history(0)
     ev = ora.events(0)
     N = cfg.n_nodes
-    LIN, LWW = 2 * N, 2 * N + 1
-    names = [f"n{i}" for i in range(N)] + [f"c{i}" for i in range(N)] + ["lin-kv", "lww-kv"]
+    CS = max(cfg.concurrency, N)   # client worker slots (several per node with --concurrency k n: worker t talks to node t mod N)
+    LIN, LWW = N + CS, N + CS + 1
+    names = [f"n{i}" for i in range(N)] + [f"c{i}" for i in range(CS)] + ["lin-kv", "lww-kv"]
     idx = {n: i for i, n in enumerate(names)}
     outq = {i: [] for i in range(len(names))}
     ctr = [0]
@@ -61,7 +62,8 @@ def replay(cfg, instance):
     now = [0]
     nodes = [R.DatomicListAppendNode((lambda i: lambda dest, body: outq[i].append((dest, body)))(i), clock=lambda: now[0]) for i in range(N)]
     lin, lww = R.LinKV(), R.LwwKV(rand_int)
-    inflight, stats = {}, {"loads": 0, "load_retries": 0, "writes": 0, "cas_ok": 0, "cas_lost": 0, "max_depth": 0, "splits": 0, "txn_ok": 0, "await_timeouts": 0, "late_cas_ok": 0, "late_cas_lost": 0}
+    inflight, stats = {}, {"loads": 0, "load_retries": 0, "writes": 0, "cas_ok": 0, "cas_lost": 0, "max_depth": 0, "splits": 0, "txn_ok": 0, "await_timeouts": 0, "late_cas_ok": 0, "late_cas_lost": 0, "max_waiting": 0, "arrival_order": True}
+    arrived = {i: [] for i in range(N)}   # per node: the transactions in the order their requests arrived (client, msg_id)
 
     def check_a(src, dest, body, a, req_key):
         t = body["type"]
@@ -85,7 +87,7 @@ def replay(cfg, instance):
         src, dest, b = route & 0xFF, (route >> 8) & 0xFF, route >> 16
         now[0] = int(ev["time_us"][i])
         if not recv:
-            if N <= src < 2 * N:   # a client's request: the journal says what it is
+            if N <= src < LIN:   # a client's request: the journal says what it is
                 if typ == "init":
                     body = {"type": "init", "node_id": names[dest], "node_ids": names[:N], "msg_id": b}
                 else:
@@ -101,13 +103,19 @@ def replay(cfg, instance):
             assert (body.get("msg_id") or body.get("in_reply_to") or 0) & 0xFFFF == b, (i, body, b)
             assert check_a(src, dest, body, a, body.pop("_key", None)), (i, names[src], names[dest], body, hex(a))
             inflight[mid] = {"src": names[src], "dest": d, "body": body, "t": now[0]}
+            if src < N and N <= dest < LIN and typ != "init_ok":   # a transaction's answer: the lock was taken in arrival order (datomic_list_append.rb:348, node.rb:147-183)
+                if not arrived[src] or arrived[src].pop(0) != (d, body.get("in_reply_to")):
+                    stats["arrival_order"] = False
             if src < N and dest == LWW:
                 stats["writes" if typ == "write" else "loads"] += 1
             continue
         m = inflight.pop(mid)
         assert idx[m["dest"]] == dest
         if dest < N:
+            if m["body"]["type"] == "txn":
+                arrived[dest].append((m["src"], m["body"]["msg_id"]))
             nodes[dest].handle(m)
+            stats["max_waiting"] = max(stats["max_waiting"], len(nodes[dest].lock_waiters))
         elif dest == LIN or dest == LWW:
             rep = (lin if dest == LIN else lww).handle(m["body"])
             rep = {**rep, "in_reply_to": m["body"]["msg_id"], "_key": m["body"].get("key")}
@@ -199,6 +207,26 @@ def test_a_cas_served_after_its_sender_gave_up_is_still_its_own(kw, instance, ok
     rows, pay = st["history"]
     res = E.check_txn_history(rows, pay)
     assert res["valid?"] is not False and not res["anomalies"], res   # (with awaits giving up all over a run may acknowledge nothing: :unknown)
+
+
+@pytest.mark.parametrize("kw,instance,depth", [
+    (dict(node_count=1, concurrency=10, rate=100, time_limit=8, latency=2), 0, 3),     # the reference's own invocation for this workload: --node-count 1 --concurrency 10n --rate 100
+    (dict(node_count=2, concurrency=20, rate=300, time_limit=5, latency=3, latency_dist="uniform"), 1, 4),
+    (dict(node_count=5, concurrency=10, rate=200, time_limit=6, latency=5, nemesis=["partition"], nemesis_interval=2), 2, 1),
+    (dict(node_count=3, concurrency=9, rate=150, time_limit=20, latency=10, p_loss=0.03), 3, 2),   # lost messages: awaits give up while others wait for the lock
+])
+def test_several_workers_per_node_queue_behind_the_lock_in_arrival_order(kw, instance, depth):
+    """`--concurrency 10n` (doc/05-datomic/01-single-node.md:257,322): ten workers talk to one node, their transactions reach it within a
+    millisecond of each other and wait for its @txn_lock (datomic_list_append.rb:347-372; every message runs in its own thread, node.rb:147-183).
+    The reference classes — the lock as a FIFO of coroutines — replayed against the oracle's journal: every message is the oracle's, the queue
+    gets at least `depth` deep, and every answer names the oldest transaction the node has not answered yet (arrival order)."""
+    st = replay(_cfg(**kw), instance)
+    assert st["max_waiting"] >= depth, st["max_waiting"]
+    assert st["arrival_order"]
+    rows, pay = st["history"]
+    res = E.check_txn_history(rows, pay)
+    assert res["valid?"] is True, res
+    assert res["ok-count"] > (10 if kw.get("p_loss") else 50)
 
 
 def test_many_keys_grow_branches_and_chains():

@@ -127,6 +127,11 @@ def test_random_datomic_txn_options_engine_equals_oracle(lib, case):
     first = rng.randrange(1 << 20)
     _compare(cfg, first, N_INST, dev_flags=0x400)   # eight clusters per wavefront where csrc/dt8.hip applies (else the same kernel again)
     _compare(cfg, first, 3)                          # one cluster per wavefront
+    # ... and the same options with several workers per node (dtg_kernel<>: a lane per endpoint), where nodes + workers + 2 services fit a wavefront
+    k = rng.choice([2, 3, 10])
+    if kw["node_count"] * (k + 1) + 2 <= 64:
+        many = E.test_config(wl, concurrency=k * kw["node_count"], **kw)
+        _compare(many, first, 3)
 
 
 @pytest.mark.parametrize("case", range(int(os.environ.get("MSIM_FUZZ_CASES", "24"))))

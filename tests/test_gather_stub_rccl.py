@@ -70,7 +70,7 @@ def emu_env():
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("world,root", [(2, 0), (2, 1), (3, 1)])
+@pytest.mark.parametrize("world,root", [(2, 0), (2, 1), (3, 1), (8, 0), (8, 3), (8, 7)])   # 8 = the ranks of one MI355X node, ragged shards of 3 .. 17 instances
 def test_gather_branch_for_several_ranks_runs_and_equals_the_ranks_own_histories(emu_env, tmp_path, world, root):
     script = tmp_path / "rank.py"
     script.write_text(_RANK_SCRIPT)

@@ -30,6 +30,8 @@ CASES = [
     "{'workload':'txn-list-append','bin':'datomic','node_count':6,'rate':120,'time_limit':4,'latency':10,'latency_dist':'uniform','p_loss':0.02,'n':9,'flags':0x400}",
     "{'workload':'txn-list-append','bin':'datomic','node_count':2,'rate':15,'time_limit':60,'latency':1300,'latency_dist':'exponential','seed':91,'n':8,'flags':0x400}",   # instances 2 and 4: a cas served after its sender's await gave up (the request carries its own from / transaction)
     "{'workload':'txn-list-append','bin':'datomic','node_count':2,'rate':15,'time_limit':60,'latency':1300,'latency_dist':'exponential','seed':91,'n':5}",
+    "{'workload':'txn-list-append','bin':'datomic','node_count':1,'concurrency':10,'rate':100,'time_limit':6,'latency':2,'n':2}",   # several workers per node: dtg_kernel<> (a lane per endpoint); the lock's waiting queue under load
+    "{'workload':'txn-list-append','bin':'datomic','node_count':5,'concurrency':10,'rate':100,'time_limit':6,'latency':5,'nemesis':['partition'],'nemesis_interval':2,'n':2}",
     "{'workload':'txn-rw-register','node_count':2,'rate':100,'time_limit':8,'nemesis':['partition'],'nemesis_interval':2,'flags':0x400,'n':11}",
     "{'workload':'txn-rw-register','node_count':4,'rate':200,'time_limit':6,'latency':20,'latency_dist':'exponential','p_loss':0.05,'flags':0x8400,'n':19}",
     "{'workload':'txn-rw-register','node_count':5,'rate':200,'time_limit':8,'latency':5,'nemesis':['partition'],'nemesis_interval':3,'flags':0x400,'n':9}",

@@ -337,6 +337,21 @@ def test_datomic_late_cas_parity(lib, kw, first):
     _compare(cfg, first, 4)
 
 
+@pytest.mark.parametrize("kw", [
+    dict(node_count=1, concurrency=10, rate=100, time_limit=8, latency=0),                                     # doc/05-datomic/01-single-node.md:257: --node-count 1 --concurrency 10n --rate 100
+    dict(node_count=2, concurrency=20, rate=300, time_limit=5, latency=3, latency_dist="uniform"),
+    dict(node_count=5, concurrency=10, rate=200, time_limit=6, latency=5, nemesis=["partition"], nemesis_interval=2),
+    dict(node_count=3, concurrency=9, rate=150, time_limit=20, latency=10, p_loss=0.03, journal_capacity=400000),   # lost messages: awaits give up while others wait for the lock
+    dict(node_count=6, concurrency=48, rate=400, time_limit=4, latency=20, latency_dist="exponential"),       # 6 + 48 + 2 = 56 lanes
+    dict(node_count=1, concurrency=61, rate=1000, time_limit=3, latency=1),                                    # a full wavefront: 1 node, 61 workers, lin-kv, lww-kv
+])
+def test_datomic_many_workers_parity(lib, kw):
+    """Several workers per node (`--concurrency k n`): dtg_kernel<> (csrc/sim_kernel_dtg.inc: a lane per endpoint) against oracle/dt_nodes.inc,
+    which tests/test_datomic_tree.py::test_several_workers_per_node_queue_behind_the_lock_in_arrival_order holds to the reference classes."""
+    cfg = E.test_config("txn-list-append", bin="datomic", seed=23, **kw)
+    _compare(cfg, 0, 5)
+
+
 def test_deep_queues_spill_to_hbm(lib):
     """Exponential latency => long head-of-line sleeps => queues far deeper than the LDS part: the HBM spill area
     behind each node's queue keeps the result bit-identical (and unflagged)."""
