@@ -164,6 +164,27 @@ def test_reference_multi_key_txn_js_reproduces_the_oracle_history(kw):
     _against_oracle("txn-list-append", [_NODE, os.path.join(REF_JS, "multi_key_txn.js")], oracle_bin="multi-key-txn", **kw)
 
 
+DATOMIC_NODE = [sys.executable, os.path.join(ROOT, "tools", "datomic_node.py")]
+
+
+@pytest.mark.parametrize("kw", [
+    dict(node_count=1, rate=40, time_limit=4, latency=2, seed=5),
+    dict(node_count=3, rate=60, time_limit=4, latency=5, seed=6),
+    dict(node_count=5, rate=80, time_limit=3, latency=10, latency_dist="exponential", nemesis=["partition"], nemesis_interval=1, seed=7),
+    dict(node_count=3, rate=150, time_limit=3, latency=0, key_count=16, max_writes_per_key=2, seed=8),   # many keys: splits and chains
+    dict(node_count=1, concurrency=10, rate=100, time_limit=4, latency=1, seed=9),                        # --concurrency 10n (doc/05-datomic/01-single-node.md:257): the lock's queue
+    dict(node_count=2, concurrency=6, rate=120, time_limit=3, latency=3, latency_dist="uniform", seed=10),
+])
+def test_datomic_node_process_reproduces_the_oracle_history(kw):
+    """The Datomic-style node (row a18) as REAL PROCESSES — the Ruby classes written out in Python (tests/datomic_ref.py) behind the wire protocol
+    (tools/datomic_node.py): materialised trees, maps and lists, the node's lock as a FIFO, tree nodes as JSON values in the bridge's own lww-kv (two
+    replicas that never exchange state), the root pointer in its lin-kv — under the bridge's scheduler yield the history, the round count and the
+    net stats of the oracle's restatement (oracle/dt_nodes.inc: counts, versions and a lineage rule instead of values), whole runs, several
+    workers per node included.  Not the replay of tests/test_datomic_tree.py (which feeds the classes the oracle's own journal): here nothing of
+    the oracle steers the run.  The classes are the same author's reading of the Ruby — parity with the reference itself stays unpinned."""
+    _against_oracle("txn-list-append", DATOMIC_NODE, oracle_bin="datomic", **kw)
+
+
 @needs_js
 def test_reference_multi_key_txn_js_runs_strict_serializably_on_the_bridge():
     """demo/js/multi_key_txn.js (thunks in lww-kv, the root map in lin-kv, retry on a lost root cas) is not a built-in node of the
