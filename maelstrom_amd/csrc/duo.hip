@@ -41,6 +41,10 @@ __constant__ u32 duo_log2_q24[257];
 
 enum { DK_PLAIN = 0, DK_BCAST = 1, DK_READ = 2, DK_READ_FINAL = 3, DK_INIT = 4, DK_TOPO = 5 };  // kind of an envelope (bits 24-26)
 constexpr u32 DUO_STAGE_ROWS = 128u;
+#ifndef DUO_BAG_N
+#define DUO_BAG_N 16
+#endif
+constexpr u32 DUO_BAG = DUO_BAG_N;   // random latencies: envelopes of a node's queue that live in LDS (a power of two, 4 .. 16; the rest spills to HBM behind a cached minimum)
 // History rows go from their lanes to HBM unstaged (two 16-byte rows per operation; the L2 merges them into lines: WRITE_SIZE stays at the
 // algorithmic bytes): 9.00 -> 8.90 ms per 4096 clusters against staging 64 rows in LDS (-DDUO_STAGED_ROWS keeps that variant for A/B runs).
 #ifdef DUO_STAGED_ROWS
@@ -142,7 +146,7 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
   //  lane-major bags of 128 bytes put every lane on the same banks)
   const u32 BS = N + 1u;   // lanes per slot: the nodes and one dummy shared by the lanes that hold no node
   u32 *const bag_dl = reinterpret_cast<u32 *>(hmem + dp.off_ring) + (is_node ? i : N);             // deadlines: what recv! scans
-  u32 *const bag_e = bag_dl + 16u * BS;                                                           // envelope words
+  u32 *const bag_e = bag_dl + DUO_BAG * BS;                                                           // envelope words
   unsigned short *const bag_seq = reinterpret_cast<unsigned short *>(hmem + dp.off_seq) + (is_node ? i : N);
 #define BAGDL(j_) bag_dl[(j_) * BS]
 #define BAGE(j_) bag_e[(j_) * BS]
@@ -152,7 +156,7 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
 
   for (u32 k = i; k < N * Wp + 32u; k += 32) seen[k] = 0;
   if (RND) for (u32 k = lane; k < 257u; k += 64) log2_tab[k] = duo_log2_q24[k];
-  if (RND) for (u32 k = i; k < 16u * BS; k += 32) reinterpret_cast<u32 *>(hmem + dp.off_ring)[k] = INF;   // every bag slot is free
+  if (RND) for (u32 k = i; k < DUO_BAG * BS; k += 32) reinterpret_cast<u32 *>(hmem + dp.off_ring)[k] = INF;   // every bag slot is free
   __syncthreads();
 
   const u32 adj = is_node ? topo_adj(p.cfg.topology, N, i) : 0u;
@@ -257,21 +261,21 @@ __global__ void __launch_bounds__(64) sim_kernel_duo(const DuoParams dp) {
       const bool pl_go = pl_idle & ((in_n | sp_n) != 0);                                                                  \
       if (__ballot(pl_go)) {                                                                                              \
         const u32 pl_sb = 32768u - my_seq;                                                                                \
-        u32 pl_d[16];                                                                                                     \
-        _Pragma("unroll") for (int pl_j = 0; pl_j < 16; pl_j++) pl_d[pl_j] = BAGDL(pl_j);   /* (free slots hold INF) */          \
-        u32 pl_m[8];                                                                                                      \
-        _Pragma("unroll") for (int pl_j = 0; pl_j < 8; pl_j++) pl_m[pl_j] = min(pl_d[pl_j], pl_d[pl_j + 8]);              \
-        _Pragma("unroll") for (int pl_w = 4; pl_w >= 1; pl_w >>= 1)                                                       \
+        u32 pl_d[DUO_BAG];                                                                                                   \
+        _Pragma("unroll") for (int pl_j = 0; pl_j < (int)DUO_BAG; pl_j++) pl_d[pl_j] = BAGDL(pl_j);   /* (free slots hold INF) */          \
+        u32 pl_m[DUO_BAG / 2];                                                                                            \
+        _Pragma("unroll") for (int pl_j = 0; pl_j < (int)(DUO_BAG / 2); pl_j++) pl_m[pl_j] = min(pl_d[pl_j], pl_d[pl_j + DUO_BAG / 2]);  \
+        _Pragma("unroll") for (int pl_w = (int)(DUO_BAG / 4); pl_w >= 1; pl_w >>= 1)                                      \
           _Pragma("unroll") for (int pl_j = 0; pl_j < pl_w; pl_j++) pl_m[pl_j] = min(pl_m[pl_j], pl_m[pl_j + pl_w]);      \
         const u32 pl_dmin = pl_m[0];                                                                                      \
         u32 pl_bi = 0, pl_cnt = 0;                                                                                        \
-        _Pragma("unroll") for (int pl_j = 0; pl_j < 16; pl_j++) { const bool pl_eq = pl_d[pl_j] == pl_dmin; pl_bi = pl_eq ? (u32)pl_j : pl_bi; pl_cnt += pl_eq ? 1u : 0u; } \
+        _Pragma("unroll") for (int pl_j = 0; pl_j < (int)DUO_BAG; pl_j++) { const bool pl_eq = pl_d[pl_j] == pl_dmin; pl_bi = pl_eq ? (u32)pl_j : pl_bi; pl_cnt += pl_eq ? 1u : 0u; } \
         u32 pl_bq = 0;   /* the winner's sequence number, relative; only read when it matters */                           \
         const bool pl_tie = pl_go & (in_n != 0) & ((pl_cnt > 1u) | (sp_n != 0 && spm_dl == pl_dmin));                      \
         if (__ballot(pl_tie)) {                                                                                           \
           if (pl_tie) {                                                                                                   \
             pl_bq = 0xFFFFFFFFu;                                                                                          \
-            for (u32 pl_j = 0; pl_j < 16u; pl_j++) {                                                                      \
+            for (u32 pl_j = 0; pl_j < DUO_BAG; pl_j++) {                                                                      \
               if (BAGDL(pl_j) == pl_dmin) { const u32 pl_q = ((u32)BAGSEQ(pl_j) + pl_sb) & 0xFFFFu; if (pl_q < pl_bq) { pl_bq = pl_q; pl_bi = pl_j; } } \
             }                                                                                                             \
           }                                                                                                               \
@@ -792,8 +796,8 @@ hipError_t msim_launch_duo(const KParams &kp, uint32_t n, hipStream_t st) {
   const size_t stage_bytes = (rnd || DUO_DIRECT) ? 0 : DUO_STAGE_ROWS * 16;   // (rows are staged only in the -DDUO_STAGED_ROWS build)
   const size_t fixed = seen_bytes + stage_bytes;
   const size_t per_entry = rnd ? 0 : (size_t)32 * (lat0 ? 4 : 8);   // (RND: bags of a fixed 16 entries)
-  const size_t budget = (20 * 1024 - (rnd ? 257 * 4 + 16 : 0)) / 2;
-  uint32_t R = rnd ? 16 : 8;
+  const size_t budget = (20 * 1024 - (rnd ? 257 * 4 + 16 : 0)) / 2;   // (RND with DUO_BAG = 8: 13 KiB per wavefront, twelve per CU)
+  uint32_t R = rnd ? DUO_BAG : 8;
   while (!rnd && R < 64 && R < cap_tot && fixed + ((per_entry * (R * 2) + 15) & ~(size_t)15) + 32 <= budget && (rnd || R < c.inbox_capacity)) R <<= 1;
   if (!rnd && R > cap_tot) { R = 2; while (R * 2 <= cap_tot) R <<= 1; }
   if (rnd && R > cap_tot) R = cap_tot ? cap_tot : 1;
@@ -802,8 +806,8 @@ hipError_t msim_launch_duo(const KParams &kp, uint32_t n, hipStream_t st) {
   if ((size_t)dp.S * (rnd ? 12 : 8) > (size_t)c.spill_capacity * 16) return MSIM_LAYOUT_DOES_NOT_FIT;
   if (rnd) MSIM_UPLOAD_ONCE(duo_log2_q24, msim_log2_q24, sizeof(msim_log2_q24));   // (1 KiB, once per device)
   size_t off = stage_bytes;
-  dp.off_ring = (u32)off; off += rnd ? (size_t)(kp.N + 1) * 16 * 8 : (size_t)32 * R * (lat0 ? 4 : 8);
-  dp.off_seq = (u32)off; if (rnd) off += (((size_t)(kp.N + 1) * 16 * 2) + 15) & ~(size_t)15;
+  dp.off_ring = (u32)off; off += rnd ? (size_t)(kp.N + 1) * DUO_BAG * 8 : (size_t)32 * R * (lat0 ? 4 : 8);
+  dp.off_seq = (u32)off; if (rnd) off += (((size_t)(kp.N + 1) * DUO_BAG * 2) + 15) & ~(size_t)15;
   dp.R = R;
   off = (off + 15) & ~(size_t)15;
   dp.off_seen = (u32)off; off += seen_bytes;
