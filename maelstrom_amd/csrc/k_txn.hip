@@ -4,3 +4,8 @@
 hipError_t msim_launch_txn1(const KParams &kp, uint32_t n, size_t lds, hipStream_t st) {
   MSIM_LAUNCH_NR(txn_kernel);
 }
+
+// ... and txng_kernel<NEM, NET_RANDOM>: the same node with several workers per node (a lane per endpoint; sim_kernel_txng.inc)
+hipError_t msim_launch_txng(const KParams &kp, uint32_t n, size_t lds, hipStream_t st) {
+  MSIM_LAUNCH_NR(txng_kernel);
+}

@@ -854,6 +854,7 @@ static sim_t *sim_new(const msim_config *cfg, uint64_t instance, msim_op *rows, 
   } else if (s->S || cfg->node_program == MSIM_NODE_TXN_RW_HAT) { /* (the multi-key node too: generator state + the elements' versions) */
     txn_t *t = (txn_t *)calloc(1, sizeof(txn_t)); /* the rw-register workload only uses the generator state */
     t->slots = (tslot *)calloc((size_t)s->N * TXN_SLOTS, sizeof(tslot));
+    t->slots_cap = s->cfg.concurrency > s->N ? TXN_SLOTS : 8u;
     t->root = V_NIL;
     t->kv = (u32 *)calloc((size_t)cfg->max_values * cfg->max_writes_per_key, 4);
     t->kv_n = (u8 *)calloc(cfg->max_values, 1);

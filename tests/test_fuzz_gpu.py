@@ -194,7 +194,12 @@ def test_random_kv_options_engine_equals_oracle(lib, case):
         E.Engine(cfg).close()
     except E.EngineError as e:
         pytest.skip(str(e))
-    _compare(cfg, rng.randrange(1 << 20), N_INST)
+    first = rng.randrange(1 << 20)
+    _compare(cfg, first, N_INST)
+    if wl == "txn-list-append" and "bin" not in kw:   # the single-root node: the same options with several workers per node (txng_kernel<>)
+        k = rng.choice([2, 3, 10])
+        if kw["node_count"] * (k + 1) + 2 <= 64:
+            _compare(E.test_config(wl, concurrency=k * kw["node_count"], **kw), first, 3)
 
 
 def _random_wide_case(rng):

@@ -352,6 +352,20 @@ def test_datomic_many_workers_parity(lib, kw):
     _compare(cfg, 0, 5)
 
 
+@pytest.mark.parametrize("kw", [
+    dict(node_count=1, concurrency=10, rate=100, time_limit=8, latency=0),
+    dict(node_count=2, concurrency=20, rate=300, time_limit=5, latency=3, latency_dist="uniform"),
+    dict(node_count=5, concurrency=10, rate=200, time_limit=6, latency=5, nemesis=["partition"], nemesis_interval=2),
+    dict(node_count=3, concurrency=9, rate=150, time_limit=10, latency=10, p_loss=0.03, journal_capacity=400000),
+    dict(node_count=1, concurrency=61, rate=1000, time_limit=3, latency=1),                                    # 1 node, 61 workers, lin-kv
+])
+def test_single_key_txn_many_workers_parity(lib, kw):
+    """Several workers per node for the single-root node (demo/clojure/single_key_txn.clj): txng_kernel<> (csrc/sim_kernel_txng.inc: a lane per
+    endpoint, up to 64 transactions in flight per node) against oracle/txn_nodes.inc."""
+    cfg = E.test_config("txn-list-append", seed=29, **kw)
+    _compare(cfg, 0, 5)
+
+
 def test_deep_queues_spill_to_hbm(lib):
     """Exponential latency => long head-of-line sleeps => queues far deeper than the LDS part: the HBM spill area
     behind each node's queue keeps the result bit-identical (and unflagged)."""
