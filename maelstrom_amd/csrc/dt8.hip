@@ -180,16 +180,31 @@ __device__ D8_APPLY_ATTR D8ApplyIO d8_apply(D8ApplyIO io, const D8ApplyK kc, u32
       for (u32 i = 0; i < wn; i++) my_wl[i] = (l << 20) | (pstart + i);
     } else {
       u32 *const nk = aux + D8_AUX_KEYS;
-      nk[M] = D8_DEAD; nk[M + 1u] = D8_DEAD; nk[M + 2u] = D8_DEAD;   // (the rank loop reads four keys at a time)
-      for (u32 i = 0; i < M; i++) {
-        const u32 ki = nk[i];
-        if (ki == D8_DEAD) continue;
-        u32 rank = 0;
-        for (u32 j4 = 0; j4 < M; j4 += 4u) {
-          const uint4 q = *reinterpret_cast<const uint4 *>(nk + j4);
-          rank += (q.x < ki ? 1u : 0u) + (q.y < ki ? 1u : 0u) + (q.z < ki ? 1u : 0u) + (q.w < ki ? 1u : 0u);
+      if (M <= 16u) {   // the usual case (two to four appends of three or four tree nodes each): every key in registers after ONE round trip, ranks by comparison
+        const uint4 *const q = reinterpret_cast<const uint4 *>(nk);
+        const uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+        u32 kk[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+#pragma unroll
+        for (u32 i = 0; i < 16u; i++) kk[i] = i < M ? kk[i] : D8_DEAD;   // (what lies behind the transaction's keys is stale)
+#pragma unroll
+        for (u32 i = 0; i < 16u; i++) {
+          u32 rank = 0;
+#pragma unroll
+          for (u32 j = 0; j < 16u; j++) rank += kk[j] < kk[i] ? 1u : 0u;
+          if (kk[i] != D8_DEAD && rank < DT_MAXW) my_wl[rank] = (l << 20) | (pstart + i);
         }
-        if (rank < DT_MAXW) my_wl[rank] = (l << 20) | (pstart + i);
+      } else {   // (a load per key and four keys per load: a wait each — only for transactions that create more than sixteen tree nodes)
+        nk[M] = D8_DEAD; nk[M + 1u] = D8_DEAD; nk[M + 2u] = D8_DEAD;   // (the rank loop reads four keys at a time)
+        for (u32 i = 0; i < M; i++) {
+          const u32 ki = nk[i];
+          if (ki == D8_DEAD) continue;
+          u32 rank = 0;
+          for (u32 j4 = 0; j4 < M; j4 += 4u) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(nk + j4);
+            rank += (q.x < ki ? 1u : 0u) + (q.y < ki ? 1u : 0u) + (q.z < ki ? 1u : 0u) + (q.w < ki ? 1u : 0u);
+          }
+          if (rank < DT_MAXW) my_wl[rank] = (l << 20) | (pstart + i);
+        }
       }
     }
     node_msgid += wn;
@@ -355,11 +370,10 @@ __device__ D8_APPLY_ATTR D8ApplyIO d8_apply(D8ApplyIO io, const D8ApplyK kc, u32
   return io;
 }
 
-#ifdef D8_WAVES_PER_EU   // (developer A/B: a register budget for that many wavefronts per SIMD)
-#define D8_OCC __attribute__((amdgpu_waves_per_eu(D8_WAVES_PER_EU)))
-#else
-#define D8_OCC
+#ifndef D8_WAVES_PER_EU   // a register budget for that many wavefronts per SIMD.  Two: left alone the allocator takes 256 + a few accumulator registers for the
+#define D8_WAVES_PER_EU 2 // nemesis variants and ONE wavefront per SIMD is what remains (1180 ms per 32768 clusters instead of 616); three / four spill in the round loop and lose
 #endif
+#define D8_OCC __attribute__((amdgpu_waves_per_eu(D8_WAVES_PER_EU)))
 template <bool NEM, bool NET_RANDOM>
 __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -793,16 +807,39 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
         send1(D_LWW, M_READ, ptr, rid);
         wait_until = T + DT_AWAIT_US;
       };
-      auto reply_txn_ok = [&]() {   // the completed transaction: its reads see the version read + its own appends
+      // The completed transaction: its reads see the version read + its own appends.  Sized here, written behind the cross-lane allocation below.
+      // Waits, not bytes, are what this costs (a wavefront runs ~28 memory waits a round, one after the other): the micro-ops come in ONE batch, the
+      // keys' element counts in one, and a key's row is four 16-byte words (max-writes-per-key 16, the default; other widths take the loops).
+      u32 vis_pack_lo = 0, vis_pack_hi = 0;   // visible elements of the keys the micro-ops read, 8 bits each (kept for the writer below)
+      auto reply_txn_ok = [&]() {
         rep = true; r_type = M_TXN_OK; r_b = cu[DC_CMSG];
         done_ref = cu[DC_REF]; done_rv = cu[DC_RV];
         const u32 off0 = done_ref & 0xFFFFFFu, n = done_ref >> 24;
-        for (u32 j = 0; j < n; j++) {
-          const u32 w = g_pay[off0 + j], k = (w >> 1) & 0x7FFFu;
+        u32 wv[8], cn[8];
+#pragma unroll
+        for (u32 j = 0; j < 8u; j++) wv[j] = g_pay[off0 + min(j, n - 1u)];
+#pragma unroll
+        for (u32 j = 0; j < 8u; j++) { cn[j] = 0; if (j < n && !(wv[j] & 1u) && done_rv != V_NIL) cn[j] = g_kvn[(wv[j] >> 1) & 0x7FFFu]; }
+#pragma unroll
+        for (u32 j = 0; j < 8u; j++) {
+          if (j >= n) continue;
+          const u32 w = wv[j], k = (w >> 1) & 0x7FFFu;
           need_words++;
           if (!(w & 1u)) {
-            u32 len = visible(k, done_rv);
-            for (u32 e = 0; e < j; e++) { const u32 we = g_pay[off0 + e]; if ((we & 1u) && ((we >> 1) & 0x7FFFu) == k) len++; }
+            u32 len = 0;
+            if (cn[j]) {
+              const u32 *const kvr = g_kv + k * mw;
+              if (mw == 16u) {
+                const uint4 *const q = reinterpret_cast<const uint4 *>(kvr);
+                const uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                const u32 row[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+#pragma unroll
+                for (u32 i = 0; i < 16u; i++) len += (i < cn[j] && (row[i] >> 8) <= done_rv) ? 1u : 0u;
+              } else { while (len < cn[j] && (kvr[len] >> 8) <= done_rv) len++; }
+            }
+            if (j < 4u) vis_pack_lo |= len << (8u * j); else vis_pack_hi |= len << (8u * (j - 4u));
+#pragma unroll
+            for (u32 e = 0; e < 8u; e++) len += (e < j && (wv[e] & 1u) && ((wv[e] >> 1) & 0x7FFFu) == k) ? 1u : 0u;
             need_words += (len + 3u) / 4u;
           }
         }
@@ -971,15 +1008,30 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
               const u32 off0 = done_ref & 0xFFFFFFu, n = done_ref >> 24;
               u32 pp = n_payload + excl;
               r_a = pp | (need_words << 24);
-              for (u32 j = 0; j < n; j++) {
-                const u32 w = g_pay[off0 + j], k = (w >> 1) & 0x7FFFu;
+              u32 wv[8];
+#pragma unroll
+              for (u32 j = 0; j < 8u; j++) wv[j] = g_pay[off0 + min(j, n - 1u)];
+#pragma unroll
+              for (u32 j = 0; j < 8u; j++) {
+                if (j >= n) continue;
+                const u32 w = wv[j], k = (w >> 1) & 0x7FFFu;
                 if (w & 1u) { g_pay[pp++] = w; continue; }
-                const u32 vis = visible(k, done_rv);
+                const u32 vis = ((j < 4u ? vis_pack_lo >> (8u * j) : vis_pack_hi >> (8u * (j - 4u))) & 0xFFu);
                 u32 e = 0, acc = 0;
                 const u32 hdr = pp++;
-                for (u32 i = 0; i < vis; i++) { acc |= (g_kv[k * mw + i] & 0xFFu) << (8 * (e & 3)); if ((++e & 3) == 0) { g_pay[pp++] = acc; acc = 0; } }
-                for (u32 i = 0; i < j; i++) { const u32 wi = g_pay[off0 + i];
-                  if ((wi & 1u) && ((wi >> 1) & 0x7FFFu) == k) { acc |= ((wi >> 16) & 0xFFu) << (8 * (e & 3)); if ((++e & 3) == 0) { g_pay[pp++] = acc; acc = 0; } } }
+                if (vis) {
+                  const u32 *const kvr = g_kv + k * mw;
+                  if (mw == 16u) {   // the visible prefix of the row from four 16-byte words
+                    const uint4 *const q = reinterpret_cast<const uint4 *>(kvr);
+                    const uint4 q0 = q[0], q1 = vis > 4u ? q[1] : make_uint4(0, 0, 0, 0), q2 = vis > 8u ? q[2] : make_uint4(0, 0, 0, 0), q3 = vis > 12u ? q[3] : make_uint4(0, 0, 0, 0);
+                    const u32 row[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+#pragma unroll
+                    for (u32 i = 0; i < 16u; i++) if (i < vis) { acc |= (row[i] & 0xFFu) << (8 * (e & 3)); if ((++e & 3) == 0) { g_pay[pp++] = acc; acc = 0; } }
+                  } else for (u32 i = 0; i < vis; i++) { acc |= (kvr[i] & 0xFFu) << (8 * (e & 3)); if ((++e & 3) == 0) { g_pay[pp++] = acc; acc = 0; } }
+                }
+#pragma unroll
+                for (u32 i = 0; i < 8u; i++) { const u32 wi = wv[i];
+                  if (i < j && (wi & 1u) && ((wi >> 1) & 0x7FFFu) == k) { acc |= ((wi >> 16) & 0xFFu) << (8 * (e & 3)); if ((++e & 3) == 0) { g_pay[pp++] = acc; acc = 0; } } }
                 if (e & 3) g_pay[pp++] = acc;
                 g_pay[hdr] = (k << 1) | ((e ? e : 0xFFu) << 16);  // a key without elements reads nil
               }
@@ -1011,8 +1063,14 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
             const u32 t1 = GGET(o1_type, s), a1 = GGET(o1_a, s), b1 = GGET(o1_b, s), wlo = GGET(o_wlo, s);
             if (on && l == N + dst) {
               if (wlo == 0u) arrive(next_id + off, t1, a1, b1, s);
-              else { const u32 *const wl = g_wl + (size_t)s * DT_MAXW;
-                for (u32 k = 0; k < kn; k++) arrive(next_id + off + k, M_WRITE, wl[k], wlo + k, s); }
+              else { const u32 *const wl = g_wl + (size_t)s * DT_MAXW;   // the node's write list: eight pointers per round trip (a load per envelope made every write of a save a wait of its own)
+                for (u32 k0 = 0; k0 < kn; k0 += 8u) {
+                  u32 w8[8];
+#pragma unroll
+                  for (u32 t = 0; t < 8u; t++) w8[t] = wl[min(k0 + t, kn - 1u)];
+#pragma unroll
+                  for (u32 t = 0; t < 8u; t++) if (k0 + t < kn) arrive(next_id + off + k0 + t, M_WRITE, w8[t], wlo + k0 + t, s);
+                } }
             }
           }
           // service -> node (lin-kv, then lww-kv)
