@@ -470,7 +470,11 @@ static void client_deliver(sim_t *s, u32 slot, const qent *q) {
       if (txn_workload(s) && q->a == 0) client_complete(s, slot, MSIM_T_INFO, MSIM_ERR_TIMEOUT, c->value & 0xFFFFFFu, c->value >> 24); /* code 0 :timeout is not :definite? (errors.edn:2-4) */
       else if (txn_workload(s)) client_complete(s, slot, MSIM_T_FAIL, err, c->value & 0xFFFFFFu, c->value >> 24); /* :value stays the requested txn */
       else client_complete(s, slot, MSIM_T_FAIL, err, c->value, 0); } break;
-    default: client_complete(s, slot, MSIM_T_OK, 0, c->value, 0); break;
+    default: /* init_ok / topology_ok; for an operation of a transactional client (only after a failed init handshake — a flagged run — whose late init_ok meets the
+              * first transaction's msg_id): completed :ok with the requested transaction, as the kernels do */
+      if (c->kind == K_OP && c->f == MSIM_F_TXN) client_complete(s, slot, MSIM_T_OK, 0, c->value & 0xFFFFFFu, c->value >> 24);
+      else client_complete(s, slot, MSIM_T_OK, 0, c->value, 0);
+      break;
   }
 }
 
