@@ -414,10 +414,14 @@ def main():
                     kcycles = c.get("SQ_BUSY_CYCLES", 0.0) / n_se
                     live_lanes = 2 * cfg.n_nodes if args.config == "cfg2" else 4 * (cfg.n_nodes + cfg.concurrency)
                     out["roofline"]["secondary"] = {
-                        "bound": "VALU issue: the vector pipes are busy valu_issue_frac of the kernel's cycles with lane_utilisation of the lanes carrying a cluster's endpoints; "
-                                 "the batch (%d wavefronts on %d SIMDs) gives every SIMD %.1f wavefronts to hide LDS / ds_bpermute round trips with" % (int(kd.get("wavefronts") or 0), int(n_simd), (kd.get("wavefronts") or 0) / n_simd),
+                        "bound": "VALU issue: in an undisturbed launch (what the PMC passes see: counters serialise launches) the vector pipes are busy valu_issue_frac of the kernel's cycles "
+                                 "with lane_utilisation of the lanes carrying a cluster's endpoints, and one batch (%d wavefronts on %d SIMDs) gives every SIMD %.1f wavefronts to hide LDS / ds_bpermute "
+                                 "round trips with; the timed region keeps %d steps in flight, so that the next launches' wavefronts fill those stalls (valu_issue_frac_in_flight: the same instruction "
+                                 "count over the measured ms_per_step)" % (int(kd.get("wavefronts") or 0), int(n_simd), (kd.get("wavefronts") or 0) / n_simd, depth),
                         "source": f"profiles/{counters_file} (rocprofv3 --pmc SQ_* passes of the same kernel at the same batch)",
                         "valu_issue_frac": 4.0 * c.get("SQ_INSTS_VALU", 0.0) / (n_simd * kcycles) if kcycles else None,
+                        # the same instructions over the time a step takes with the pipeline full (clock from the profile: kernel cycles / profiled kernel time)
+                        "valu_issue_frac_in_flight": (4.0 * c.get("SQ_INSTS_VALU", 0.0) / (n_simd * (kcycles / kd["avg_ms"]) * (elapsed / k * 1e3))) if kcycles and kd.get("avg_ms") else None,
                         "lane_utilisation": live_lanes / 64.0,
                         "kernel_cycles": kcycles,
                         "wavefronts": kd.get("wavefronts"), "lds_bytes_per_wavefront": kd.get("lds_bytes"),
