@@ -43,7 +43,7 @@ enum { M_WRITE = 14, M_WRITE_OK, M_CAS, M_CAS_OK, M_ERROR, M_TXN = 23, M_TXN_OK 
 enum { S_GEN3 = 3 };
 enum { D_LIN = 0, D_LWW = 1 };
 // what dt_kernel<> defines (sim_kernel_dt.inc): capacities, stages, the words of a node's transaction — here without the save stack
-constexpr u32 DT_WAITQ = 8u, DT_MAXDEPTH = 40u, DT_MAXW = 256u, DT_NONE = 0xFFFFFFFFu, DT_RW = 12u, DT_AWAIT_US = 5000000u, DT_CASQ = 4u;
+constexpr u32 DT_WAITQ = 8u, DT_MAXDEPTH = 40u, DT_MAXW = 256u, DT_RW = 12u, DT_AWAIT_US = 5000000u, DT_CASQ = 4u;
 enum { DS_IDLE = 0, DS_ROOT, DS_LOAD, DS_SAVE, DS_CAS, DS_INIT_LEAF, DS_INIT_ROOT };
 // a node's transaction (the lock holder) in LDS.  DC_J packs the next micro-op, the appends applied so far and the new tree nodes they have
 // replaced again (j | appends << 8 | replaced << 16); DC_WQN the waiting transactions (count | ring head << 8; the ring itself is in HBM
@@ -270,7 +270,7 @@ __device__ D8_APPLY_ATTR D8ApplyIO d8_apply(D8ApplyIO io, const D8ApplyK kc, u32
       if (deep) my_flags |= MSIM_FLAG_ARENA_OVERRUN;
       else if (w & 1u) {   // assoc
         const u32 n = d, lw0 = w0, lcount = w1;
-        bool has = first <= rv;   // (DT_NONE is above every version)
+        bool has = first <= rv;   // (D8_NOFIRST is above every version)
         { const u32 no = cu[DC_NOWN]; for (u32 i = 0; i < no; i++) has = has || cu[DC_OWN + i] == k; }
         const u32 L = (has || lcount < 8u) ? 1u : 9u, base = next_p, ver = rv + 1u;
         if (base + L + n >= TC || base + L + n - pstart >= D8_MAXNEW) my_flags |= MSIM_FLAG_ARENA_OVERRUN;   // engine capacity
@@ -513,33 +513,6 @@ __global__ void __launch_bounds__(64) D8_OCC dt8_kernel(const M8Params tp) {
       try_commit(e);
     }
   };
-  // elements of `k` visible at version `from`: versions only grow along a key's row, so the answer is a count — the row is read with
-  // independent loads (one round trip) instead of one dependent load per element
-  auto visible = [&](u32 k, u32 from) __attribute__((always_inline)) -> u32 {
-    if (from == V_NIL) return 0u;
-    const u32 *const kvr = g_kv + k * mw;
-    const u32 cnt = kvr[OFF_KVN + k - k * mw];   // (= g_kvn[k])
-    u32 n = 0;
-    if (mw == 16u) {   // (the default max-writes-per-key: a key's row is four aligned 16-byte words)
-      const uint4 *const q = reinterpret_cast<const uint4 *>(kvr);
-      const uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-      const u32 row[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
-#pragma unroll
-      for (u32 i = 0; i < 16u; i++) n += (i < cnt && (row[i] >> 8) <= from) ? 1u : 0u;
-      return n;
-    }
-    if (mw < 16u) {
-      u32 row[16];
-#pragma unroll
-      for (u32 i = 0; i < 16u; i++) row[i] = i < cnt ? kvr[i] : 0xFFFFFFFFu;
-#pragma unroll
-      for (u32 i = 0; i < 16u; i++) n += (i < cnt && (row[i] >> 8) <= from) ? 1u : 0u;
-      return n;
-    }
-    while (n < cnt && (kvr[n] >> 8) <= from) n++;
-    return n;
-  };
-
 #ifdef D8_PROF   // developer build (tools/variant_lib.sh d8prof dt8.hip -DD8_PROF; tools/dt8_prof_report.py): cycle counters of the round's sections -> the meta of the wavefront's first three clusters
   u64 pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; u32 wave_rounds = 0;
   u64 tprev = __builtin_readcyclecounter();
