@@ -389,7 +389,12 @@ __device__ __forceinline__ void t_wave_fence() {   // orders the LDS / workspace
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__global__ void __launch_bounds__(1024) txn_check_lds_kernel(const TParams p) {
+// Two workgroups of sixteen wavefronts share a CU only at EIGHT wavefronts per SIMD: <= 64 vector and <= 96 scalar registers (the compiler's own choice,
+// 106 scalar registers, allowed seven — the second workgroup waited for the first to END: 252 histories in flight, not 512; tools/txn_check_prof_report.py).
+#ifndef TC_WAVES_PER_EU
+#define TC_WAVES_PER_EU 8
+#endif
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(TC_WAVES_PER_EU, TC_WAVES_PER_EU))) txn_check_lds_kernel(const TParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const u32 tid = threadIdx.x, NT = blockDim.x, lane = tid & 63u, wave = tid >> 6;
   const u32 hist = p.list ? p.list[p.first + blockIdx.x] : p.first + blockIdx.x;
@@ -418,6 +423,7 @@ __global__ void __launch_bounds__(1024) txn_check_lds_kernel(const TParams p) {
 #define LEAVE_IF_DECIDED() do { __syncthreads(); const u32 vd_ = hdr[0]; if (vd_) { if (tid == 0) { res.valid = vd_ == 1u ? NEEDS_HBM : NEEDS_HOST; p.out[hist] = res; } return; } } while (0)
 #ifdef TC_PROF   // developer build: cycles per phase (as wavefront 0 sees them: the barriers close a phase for the whole workgroup)
   u64 tl_prev = __builtin_readcyclecounter(); u32 tl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const u32 tl_real0 = (u32)__builtin_readsteadycounter();   // 100 MHz, the same for every CU: when this workgroup began (error_count) and ended (stable_count)
 #define TL_MARK(i_) { const u64 now_ = __builtin_readcyclecounter(); tl[i_] += (u32)((now_ - tl_prev) >> 6); tl_prev = now_; }
 #else
 #define TL_MARK(i_)
@@ -426,28 +432,37 @@ __global__ void __launch_bounds__(1024) txn_check_lds_kernel(const TParams p) {
   __syncthreads();
   if (n_words >= (1u << 24)) { if (tid == 0) p.out[hist] = res; return; }
 
-  // ---- A: transactions; completions paired process by process (wavefront 0; the next block of rows is in flight while one is paired) ---------
-  if (wave == 0) {
-    u32 n = 0, c_ok = 0, c_fail = 0, c_info = 0;
-    bool o_used = false; u32 o_proc = 0, o_txn = 0, o_len = 0; u32 bad = 0;   // lane = one open call (o_len: words of its request); bad: 1 host, 2 HBM kernel
-    uint4 row_next = make_uint4(0, 0, 0, 0);
-    if (lane < n_rows) row_next = r[lane];
-    for (u32 base = 0; base < n_rows && !bad; base += 64) {
-      const u32 idx = base + lane;
-      const uint4 row = row_next;
-      row_next = make_uint4(0, 0, 0, 0);
-      if (idx + 64u < n_rows) row_next = r[idx + 64u];
+  // ---- A: transactions; completions paired process by process — every wavefront takes blocks of 64 rows ------------------------------------
+  // The rows of one process alternate, so a completion's invocation is the previous row of its process.  Wavefront 0 used to walk the
+  // history block by block with the processes' open calls in its lanes (half of the kernel once Kahn's queue had gone, fifteen wavefronts
+  // waiting).  Now, with the tables' LDS still free:
+  //   A1  per block (all wavefronts): the number of invocations, every row's previous row of the same process INSIDE the block (a lane
+  //       index, one byte per row), and for every process present its LAST row in the block {process, invocation? | its rank among the
+  //       block's invocations | the words of its request} — at most TC_PROCS entries per block;
+  //   A2  blocks' invocation counts -> transaction numbers (prefix sums, wavefront 0);
+  //   A3  invocations write their transaction's defaults;  A4  completions look their invocation up — in the block (the byte), or in the
+  //       nearest earlier block that holds the process (its entry) — and write what became of the transaction.
+  // A history with more rows than the LDS holds bytes for, or a block with more than TC_PROCS processes, goes to txn_check_kernel.
+  constexpr u32 TC_PROCS = 16;
+  const u32 NB = (n_rows + 63u) / 64u, NW = NT / 64u;
+  u32 *const blk_base = reinterpret_cast<u32 *>(tab);            // [NB + 1] invocations in the block, then before it
+  u32 *const blk_np = blk_base + NB + 1;                         // [NB] entries of the block's list
+  u32 *const blk_list = blk_np + NB;                             // [NB][TC_PROCS] {process, info}: info = invocation << 31 | rank << 16 | words
+  unsigned char *const prevl = reinterpret_cast<unsigned char *>(blk_list + (size_t)NB * TC_PROCS * 2u);   // [n_rows] 64: none, 255: not a transaction's row
+  if (64u + ((size_t)NB * (2u + TC_PROCS * 2u) + 1u) * 4u + n_rows + 64u > p.lds_bytes) { if (tid == 0) { res.valid = NEEDS_HBM; p.out[hist] = res; } return; }
+  {
+    u32 bad = 0;   // 1 host, 2 txn_check_kernel
+    for (u32 b = wave; b < NB; b += NW) {   // A1
+      const u32 idx = b * 64u + lane;
+      uint4 row = make_uint4(0, 0, 0, 0);
+      if (idx < n_rows) row = r[idx];
       const u32 type = row.z & 3u, f = (row.z >> 2) & 31u, proc = row.z >> 12, len = row.y >> 16, woff = row.w;
       const bool is = idx < n_rows && proc != MSIM_PROCESS_NEMESIS && f == MSIM_F_TXN;
-      if (__ballot(is && (u64)woff + len > n_words)) { bad = 1; break; }
+      if (__ballot(is && (u64)woff + len > n_words)) bad = max(bad, 1u);
       const bool inv = is && type == MSIM_T_INVOKE;
       const u64 im = __ballot(inv);
-      const u32 my_t = n + (u32)__popcll(im & lt);
-      if (n + (u32)__popcll(im) > NM) { bad = 1; break; }
-      if (n + (u32)__popcll(im) > 8190u) { bad = 2; break; }   // 13-bit ids in the writer table, 0x1FFF | INFO | fin would read as "nobody"
-      if (inv) { t_cmp[my_t] = NONE; t_off[my_t] = woff; t_lt[my_t] = len | (MSIM_T_INFO << 16); t_first[my_t] = 0; }   // never completed = indeterminate
-      // one pass per process present in the block
-      u32 m_id = NONE, m_len = 0;   // a completion lane: the transaction it completes, the words of its request
+      const u32 rank = (u32)__popcll(im & lt);
+      u32 pl = is ? 64u : 255u, np = 0;
       u64 rem = __ballot(is);
       while (rem) {
         const u32 j = (u32)__builtin_ctzll(rem);
@@ -455,40 +470,85 @@ __global__ void __launch_bounds__(1024) txn_check_lds_kernel(const TParams p) {
         const u64 same = __ballot(is && proc == pj);
         rem &= ~same;
         const u64 below = same & lt;
-        const u32 prev = below ? 63u - (u32)__builtin_clzll(below) : 64u;   // the previous row of this process inside the block
-        const u32 p_t = (u32)__shfl((int)my_t, (int)(prev & 63u)), p_inv = (u32)__shfl((int)(inv ? 1u : 0u), (int)(prev & 63u)), p_len = (u32)__shfl((int)len, (int)(prev & 63u));
-        const u64 hit = __ballot(o_used && o_proc == pj);   // the process's open call from earlier blocks
-        const u32 hs = hit ? (u32)__builtin_ctzll(hit) : 0u;
-        const u32 h_t = t_rl(o_txn, hs), h_len = t_rl(o_len, hs);
-        if (is && proc == pj && !inv) {
-          if (prev < 64u) { if (p_inv) { m_id = p_t; m_len = p_len; } }          // (after a completion nothing is open: a stray one)
-          else if (hit) { m_id = h_t; m_len = h_len; }
-        }
-        // what stays open after the block: the process's last row, if it is an invocation
+        if (is && proc == pj && below) pl = 63u - (u32)__builtin_clzll(below);
         const u32 last = 63u - (u32)__builtin_clzll(same);
-        const u32 l_inv = t_rl(inv ? 1u : 0u, last), l_t = t_rl(my_t, last), l_len = t_rl(len, last);
-        if (l_inv) {
-          u32 s;
-          if (hit) s = hs;
-          else { const u64 used = __ballot(o_used); if (used == ~0ull) { bad = 1; break; } s = (u32)__builtin_ctzll(~used); }
-          if (lane == s) { o_used = true; o_proc = pj; o_txn = l_t; o_len = l_len; }
-        } else if (hit && lane == hs) o_used = false;
+        const u32 info = (t_rl(inv ? 1u : 0u, last) << 31) | (t_rl(rank, last) << 16) | t_rl(len, last);
+        if (np < TC_PROCS) { if (lane == 0) { blk_list[((size_t)b * TC_PROCS + np) * 2u] = pj; blk_list[((size_t)b * TC_PROCS + np) * 2u + 1u] = info; } }
+        else bad = max(bad, 2u);
+        np++;
       }
-      if (bad) break;
+      if (idx < n_rows) prevl[idx] = (unsigned char)pl;
+      if (lane == 0) { blk_base[b] = (u32)__popcll(im); blk_np[b] = min(np, TC_PROCS); }
+    }
+    if (bad && lane == 0) VERDICT(bad == 2u ? 1u : 2u);
+  }
+  LEAVE_IF_DECIDED();
+  if (wave == 0) {   // A2
+    u32 carry = 0;
+    for (u32 base = 0; base <= NB; base += 64) {
+      const u32 b = base + lane;
+      const u32 d = b < NB ? blk_base[b] : 0u;
+      const u32 ex = t_excl_scan(d, lane), tot = t_sum(d);
+      if (b <= NB) blk_base[b] = carry + ex;
+      carry += tot;
+    }
+    if (lane == 0) {
+      hdr[1] = carry;
+      if (carry > NM) VERDICT(2);
+      else if (carry > 8190u) VERDICT(1);   // 13-bit ids in the writer table, 0x1FFF | INFO | fin would read as "nobody"
+    }
+  }
+  LEAVE_IF_DECIDED();
+  for (u32 b = wave; b < NB; b += NW) {   // A3
+    const u32 idx = b * 64u + lane;
+    uint4 row = make_uint4(0, 0, 0, 0);
+    if (idx < n_rows) row = r[idx];
+    const bool inv = idx < n_rows && prevl[idx] != 255u && (row.z & 3u) == MSIM_T_INVOKE;
+    const u32 my_t = blk_base[b] + (u32)__popcll(__ballot(inv) & lt);
+    if (inv) { t_cmp[my_t] = NONE; t_off[my_t] = row.w; t_lt[my_t] = (row.y >> 16) | (MSIM_T_INFO << 16); t_first[my_t] = 0; }   // never completed = indeterminate
+  }
+  __threadfence_block();
+  __syncthreads();
+  {
+    u32 c_ok = 0, c_fail = 0, c_info = 0;
+    for (u32 b = wave; b < NB; b += NW) {   // A4
+      const u32 idx = b * 64u + lane;
+      uint4 row = make_uint4(0, 0, 0, 0);
+      if (idx < n_rows) row = r[idx];
+      const u32 type = row.z & 3u, proc = row.z >> 12, len = row.y >> 16, woff = row.w;
+      const u32 pl = idx < n_rows ? (u32)prevl[idx] : 255u;
+      const bool is = pl != 255u, inv = is && type == MSIM_T_INVOKE;
+      const u64 im = __ballot(inv);
+      const u32 rank = (u32)__popcll(im & lt), base = blk_base[b];
+      const u32 p_rank = (u32)__shfl((int)rank, (int)(pl & 63u)), p_inv = (u32)__shfl((int)(inv ? 1u : 0u), (int)(pl & 63u)), p_len = (u32)__shfl((int)len, (int)(pl & 63u));
+      u32 m_id = NONE, m_len = 0;   // a completion lane: the transaction it completes, the words of its request
+      if (is && !inv) {
+        if (pl < 64u) { if (p_inv) { m_id = base + p_rank; m_len = p_len; } }   // (after a completion nothing is open: a stray one)
+        else {
+          for (u32 bb = b; bb-- > 0 && m_id == NONE;) {
+            const u32 ne = blk_np[bb];
+            for (u32 e = 0; e < ne; e++)
+              if (blk_list[((size_t)bb * TC_PROCS + e) * 2u] == proc) {
+                const u32 info = blk_list[((size_t)bb * TC_PROCS + e) * 2u + 1u];
+                if (info >> 31) { m_id = blk_base[bb] + ((info >> 16) & 0x7Fu); m_len = info & 0xFFFFu; }
+                bb = 0; break;   // the process's last row before this block: an invocation (paired) or a completion (this one is stray)
+              }
+          }
+        }
+      }
       const bool matched = m_id != NONE;
       if (matched) {
-        t_cmp[m_id] = idx; t_first[m_id] = n + (u32)__popcll(im & lt);
+        t_cmp[m_id] = idx; t_first[m_id] = base + rank;
         if (type == MSIM_T_OK) { t_off[m_id] = woff; t_lt[m_id] = len | (MSIM_T_OK << 16); }   // the completed form replaces the requested one
         else t_lt[m_id] = m_len | (type << 16);
       }
       c_ok += (u32)__popcll(__ballot(matched && type == MSIM_T_OK));
       c_fail += (u32)__popcll(__ballot(matched && type == MSIM_T_FAIL));
       c_info += (u32)__popcll(__ballot(matched && type == MSIM_T_INFO));
-      n += (u32)__popcll(im);
-      t_wave_fence();   // (a later block's completion may rewrite t_off / t_lt of a transaction this block's invocation wrote)
     }
-    if (lane == 0) { hdr[0] = bad == 2 ? 1u : bad ? 2u : 0u; hdr[1] = n; hdr[2] = c_ok; hdr[3] = c_fail; hdr[4] = c_info; }
+    if (lane == 0) { atomicAdd(&hdr[2], c_ok); atomicAdd(&hdr[3], c_fail); atomicAdd(&hdr[4], c_info); }
   }
+  __threadfence_block();
   LEAVE_IF_DECIDED();
   TL_MARK(0)
   const u32 n = hdr[1], c_ok = hdr[2], c_fail = hdr[3], c_info = hdr[4];
@@ -510,9 +570,9 @@ __global__ void __launch_bounds__(1024) txn_check_lds_kernel(const TParams p) {
   const u32 max_key = hdr[5], max_val = hdr[6];
   const u32 stride = max_val + 1u, K = max_key + 1u;
   // LDS (bytes, behind the header): in-degrees [n] and CSR offsets [n + 1] as halves of words | R1 = writer [K x stride] u16 + longest [K] u32,
-  // later the ready queue [n] u16 + realtime ranges [n] 2 x u16 | adjacency of the dependency edges, u16, whatever is left
+  // later the ready queue [n] u16 + realtime ranges [n] 2 x u16 + positions [n] u32 | adjacency of the dependency edges, u16, whatever is left
   const u32 hw = (n + 2u) >> 1;                                   // words for n + 1 halves
-  const u32 r1_a = ((K * stride + 1u) >> 1) + K, r1_b = ((n + 1u) >> 1) + n;
+  const u32 r1_a = ((K * stride + 1u) >> 1) + K, r1_b = ((n + 1u) >> 1) + 2u * n;
   const u32 r1_words = max(r1_a, r1_b);
   if (max_key >= KMAX || (u64)K * stride > WMAX || (u64)(2u * hw + r1_words) * 4u + 128u > p.lds_bytes) {   // (the same for every thread)
     if (tid == 0) { res.valid = NEEDS_HBM; p.out[hist] = res; }
@@ -688,16 +748,63 @@ __global__ void __launch_bounds__(1024) txn_check_lds_kernel(const TParams p) {
 #undef W_FIN
 
   TL_MARK(5)
-  // ---- F: acyclic?  Kahn's algorithm, 64 ready transactions per step; queue and realtime ranges where the writer table was --------------------------
+  // ---- F: acyclic?  Realtime ranges, positions and (if needed) Kahn's queue where the writer table was ----------------------------------------------
   unsigned short *const l_queue = reinterpret_cast<unsigned short *>(l_r1);
   u32 *const l_rt = l_r1 + ((n + 1u) >> 1);   // first | last << 16
+  u32 *const l_pos = l_rt + n;
   for (u32 t = tid; t < n; t += NT) {
-    u32 first = 0, last = 0;
-    if ((t_lt[t] >> 16) == MSIM_T_OK) { first = t_first[t]; last = sm[first] == NONE ? n : smf[first]; }
+    u32 first = 0, last = 0, pos = 0;
+    if ((t_lt[t] >> 16) == MSIM_T_OK) { first = t_first[t]; last = sm[first] == NONE ? n : smf[first]; pos = t_cmp[t] + 1u; }
     l_rt[t] = first | (last << 16);
+    l_pos[t] = pos;
   }
+  if (tid == 0) { hdr[9] = 0; hdr[10] = 0; }
   __syncthreads();
-  if (wave != 0) return;   // the queue is one wavefront's work (a ready set is about as wide as the clients' concurrency)
+  // F1: a POTENTIAL instead of a queue.  The graph is acyclic iff positions exist that grow along every edge.  Start from where a clean
+  // history of a serializable store nearly is — an :ok transaction at its completion row (every realtime edge already grows: u's completion
+  // precedes v's invocation, hence v's completion), an indeterminate one at 0 — and raise the head of every edge that does not grow
+  // (pos[w] = max(pos[w], pos[t] + 1), all threads, all edges, until a sweep changes nothing).  What is out of order at the start are
+  // dependencies between transactions that were open together and completed the other way round; a raise travels on through the few
+  // transactions completed inside the lifetime of a slower one, so a handful of sweeps settle it, every one of them the whole workgroup's
+  // work (Kahn's steps are one wavefront's, a ready set about as wide as the clients' concurrency: 55 % of the kernel before).  A cycle
+  // never settles: after TC_SWEEPS sweeps Kahn's algorithm below decides, exactly as before.
+  bool proven = false; u32 sweeps = 0;
+#ifndef TC_SWEEPS
+#define TC_SWEEPS 48u
+#endif
+#ifndef TC_NO_POTENTIAL
+  for (u32 sweep = 0; sweep < TC_SWEEPS; sweep++) {
+    bool raised = false;
+    for (u32 t = tid; t < n; t += NT) {
+      const u32 a1 = h16_get(l_off, t), a0 = t ? h16_get(l_off, t - 1u) : 0u;   // (after pass 1 off[t] is the end of t's entries)
+      const u32 rt = l_rt[t], r0 = rt & 0xFFFFu, r1 = rt >> 16;
+      const u32 mine = l_pos[t] + 1u;
+      for (u32 k = a0; k < a1; k++) { const u32 w = l_adj[k]; if (l_pos[w] < mine) { atomicMax(&l_pos[w], mine); raised = true; } }
+      for (u32 w = r0; w < r1; w++) if (l_pos[w] < mine) { atomicMax(&l_pos[w], mine); raised = true; }
+    }
+    u32 *const flag = &hdr[9 + (sweep & 1u)];   // (two words in turn: a thread still reading this sweep's never meets the next sweep's write)
+    if (raised) *flag = sweep + 1u;
+    __syncthreads();
+    sweeps = sweep + 1u;
+    if (*flag != sweep + 1u) { proven = true; break; }
+  }
+#endif
+  if (wave != 0) return;
+  if (proven) {
+    if (lane == 0) {
+      res.lost_count = n_edges;   // edges of the dependency graph
+      res.valid = flags ? 0u : (c_ok == 0 ? 2u : 1u);
+#ifdef TC_PROF
+      TL_MARK(6)
+      for (int i = 0; i < 5; i++) res.stable_latency_ms[i] = tl[i];
+      res.never_read_count = tl[5]; res.duplicated_count = tl[6]; res.stale_count = sweeps; res.error_count = tl_real0; res.stable_count = (u32)__builtin_readsteadycounter();
+#endif
+      p.out[hist] = res;
+    }
+    return;
+  }
+  (void)sweeps;
+  // F2: Kahn's algorithm, 64 ready transactions per step — the queue is one wavefront's work
   u32 tail = 0;
   for (u32 base = 0; base < n; base += 64) {
     const u32 t = base + lane;
@@ -739,7 +846,8 @@ __global__ void __launch_bounds__(1024) txn_check_lds_kernel(const TParams p) {
 #ifdef TC_PROF
     TL_MARK(6)
     for (int i = 0; i < 5; i++) res.stable_latency_ms[i] = tl[i];
-    res.never_read_count = tl[5]; res.duplicated_count = tl[6];
+    res.never_read_count = tl[5]; res.duplicated_count = tl[6]; res.stale_count = 1000u + sweeps;   // (Kahn decided)
+    res.error_count = tl_real0; res.stable_count = (u32)__builtin_readsteadycounter();
 #endif
     p.out[hist] = res;
   }
@@ -754,7 +862,7 @@ uint64_t ws_words_lds(u32 nmax) { return (uint64_t)nmax * 6 + 8; }
 // LDS of a workgroup of txn_check_lds_kernel: what a history of `nmax` transactions over `keys` keys with elements below `stride`
 // needs with 4.5 dependency edges per transaction, at most 78 KiB (two workgroups per CU)
 u32 lds_bytes_for(u32 nmax, u32 keys, u32 stride) {
-  const uint64_t hw = (nmax + 2u) / 2, r1 = std::max<uint64_t>(((uint64_t)keys * stride + 1) / 2 + keys, (nmax + 1u) / 2 + nmax);
+  const uint64_t hw = (nmax + 2u) / 2, r1 = std::max<uint64_t>(((uint64_t)keys * stride + 1) / 2 + keys, (nmax + 1u) / 2 + 2ull * nmax);
   const uint64_t need = (2 * hw + r1) * 4 + (uint64_t)nmax * 9 + 256;
   return (u32)std::min<uint64_t>(78 * 1024, std::max<uint64_t>(8 * 1024, (need + 255) & ~255ull));
 }
