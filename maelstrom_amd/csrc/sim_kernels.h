@@ -68,12 +68,14 @@ __host__ __device__ static inline uint32_t wide_crdt_ticks(const msim_config &c)
   return (uint32_t)(((uint64_t)c.time_limit_ms + c.quiesce_ms + 2ull * c.client_timeout_ms) / 5000 + 3);
 }
 // ... and the LDS a wide CRDT cluster keeps per node for the replicates it has received and not merged yet (sim_kernel_wide.inc: WPEND words)
-#define WPEND 6u
+#define WPEND 8u   /* {mask x 4, tick, arrived, hold time, hold count}: the last two belong to the quiet windows */
+// ... and the table of its quiet windows (sim_kernel_wide.inc: per millisecond of the next 1024, how many deliveries some node has made ahead of the rounds at that time)
+#define WIDE_QW_WORDS 1024u
 // ... and for every wide cluster the client state that lives in LDS (sim_kernel_wide.inc CL(): WIDE_CLW words per pair + a dummy entry)
 #define WIDE_CLW 11u
 static inline size_t wide_client_bytes(const msim_config &c) { return c.n_nodes > 32 ? (((size_t)c.n_nodes + 1) * WIDE_CLW * 4 + 15) & ~(size_t)15 : 0; }
 static inline size_t wide_pending_bytes(const msim_config &c) {
-  return c.n_nodes > 32 && (c.node_program == MSIM_NODE_G_SET || c.node_program == MSIM_NODE_PN_COUNTER) ? (size_t)c.n_nodes * WPEND * 4 : 0;
+  return c.n_nodes > 32 && (c.node_program == MSIM_NODE_G_SET || c.node_program == MSIM_NODE_PN_COUNTER) ? (size_t)c.n_nodes * WPEND * 4 + WIDE_QW_WORDS * 4 : 0;
 }
 
 #include "sim_kernel_general.inc"

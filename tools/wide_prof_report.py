@@ -23,11 +23,12 @@ with E.Engine(cfg) as eng:
     a = []
     for i in range(0, n, max(1, n // 512)):
         st, m = eng.net_stats_raw(i), eng.meta(i)
-        a.append([st.all_send, st.all_recv, st.clients_send, st.clients_recv, st.servers_send, st.servers_recv, m.reserved[0] * 64, m.reserved[1] * 64, m.reserved[2] * 64, m.n_events * 64, m.n_rounds])
+        a.append([st.all_send, st.all_recv, st.clients_send, st.clients_recv, st.servers_send, st.servers_recv, m.reserved[0] * 64, m.reserved[1] * 64, m.reserved[2] * 64, m.n_events * 64, m.n_rounds, m.n_payload_words, m.flags & 0xFFFF, m.flags >> 16])
 a = np.array(a, dtype=np.float64)
 names = ["phase checks + R0 (time)", "quiet-round test", "quiet: deliveries noted", "quiet: polls", "general: scheduler .. arrivals", "general: sort passes", "general: polls", "rows", "lone-operation path + its test", "general: R4 (clients)"]
 NS = len(names)
 tot = a[:, :NS].sum(axis=1).mean()
 print(f"{kw['workload']} n={kw['node_count']} latency {kw['latency']} ms {kw['latency_dist']}, {n} instances: sim kernel {sim_ms:.2f} ms, cycles per wavefront {tot:.3e}, rounds {a[:, NS].mean():.0f} ({tot / a[:, NS].mean():.0f} cycles per round)")
+print(f"  turns of the round loop {a[:, NS + 1].mean():.0f}; quiet windows entered {a[:, NS + 2].mean():.0f}, turns of their loops {a[:, NS + 3].mean():.0f}")
 for i, nm in enumerate(names):
     print(f"  {nm:34s} {a[:, i].mean():12.3e} cycles  {100 * a[:, i].mean() / tot:5.1f} %")
