@@ -175,7 +175,7 @@ static uint64_t proto_scratch_words(const msim_config &c) {
     const uint64_t ticks = total_ms / 5000 + 3;
     w = ticks * c.n_nodes * (c.max_values / 32);
     // wide clusters: + the union of every tick's snapshots (wide_union_off: what a node that received all of a tick merges in one go) + the nodes' sets
-    if (c.n_nodes > 32) w = ((w + ticks * (c.max_values / 32) + 3) & ~3ull) + (((uint64_t)c.n_nodes * (c.max_values / 32) + 3) & ~3ull);
+    if (c.n_nodes > 32) w = ((w + ticks * (c.max_values / 32) + 3) & ~3ull) + (c.node_program == MSIM_NODE_G_SET ? wide_sparse_words(ticks, c.max_values / 32) : 0) + (((uint64_t)c.n_nodes * (c.max_values / 32) + 3) & ~3ull);   // (+ the ticks' frequent elements and rare holders: sim_kernel_wide.inc SPARSE)
   }
   const bool bcast_ff = c.node_program == MSIM_NODE_BCAST_FF || c.node_program == MSIM_NODE_BCAST_FF_ECHOBACK;
   const bool bcast_rpc = c.node_program == MSIM_NODE_BCAST_ACK_RETRY || c.node_program == MSIM_NODE_BCAST_RPC_ALL;

@@ -71,6 +71,9 @@ __host__ __device__ static inline uint32_t wide_crdt_ticks(const msim_config &c)
 #define WPEND 8u   /* {mask x 4, tick, arrived, hold time, hold count}: the last two belong to the quiet windows */
 // ... and the table of its quiet windows (sim_kernel_wide.inc: per millisecond of the next 1024, how many deliveries some node has made ahead of the rounds at that time)
 #define WIDE_QW_WORDS 1024u
+// ... and in HBM scratch, per replicate tick of a wide g-set cluster: the frequent elements (one word per word of the sets), the holders of rare ones (four) and a flag
+#define WIDE_RARE_MAX 16u
+__host__ __device__ static inline uint64_t wide_sparse_words(uint64_t ticks, uint64_t W) { return ((ticks * W + 3) & ~3ull) + ticks * W * 4 + ((ticks + 3) & ~3ull); }
 // ... and for every wide cluster the client state that lives in LDS (sim_kernel_wide.inc CL(): WIDE_CLW words per pair + a dummy entry)
 #define WIDE_CLW 11u
 static inline size_t wide_client_bytes(const msim_config &c) { return c.n_nodes > 32 ? (((size_t)c.n_nodes + 1) * WIDE_CLW * 4 + 15) & ~(size_t)15 : 0; }

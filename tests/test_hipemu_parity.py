@@ -20,6 +20,8 @@ CASES = [
     "{'workload':'g-set','node_count':40,'rate':40,'time_limit':11,'latency':50,'latency_dist':'exponential','n':2,'flags':0x4000}",   # whole ticks: the union merge; sets in LDS
     "{'workload':'g-set','node_count':45,'rate':50,'time_limit':12,'latency':3000,'latency_dist':'exponential','n':1}",             # ticks overlap: a slot is flushed for another tick
     "{'workload':'pn-counter','node_count':40,'rate':50,'time_limit':12,'latency':50,'p_loss':0.2,'n':1}",
+    "{'workload':'pn-counter','node_count':50,'rate':100,'time_limit':11,'latency':200,'latency_dist':'exponential','n':1}",   # quiet windows: a time jump past the whole per-millisecond table
+    "{'workload':'g-set','node_count':100,'rate':100,'time_limit':11,'latency':100,'latency_dist':'exponential','n':1}",       # quiet windows at cfg3's shape
     "{'workload':'broadcast','node_count':36,'rate':20,'time_limit':3,'latency':10,'topology':'tree3','n':1}",
     "{'workload':'txn-list-append','bin':'multi-key-txn','node_count':5,'rate':60,'time_limit':5,'latency':5,'nemesis':['partition'],'nemesis_interval':2,'n':9}",
     "{'workload':'txn-list-append','node_count':5,'rate':60,'time_limit':5,'latency':5,'nemesis':['partition'],'nemesis_interval':2,'n':9}",

@@ -173,6 +173,24 @@ def test_wide_g_set_parity(lib, n, kw):
     _compare(cfg, 0, 2, dev_flags=0x4002)
 
 
+@pytest.mark.parametrize("wl,n,kw", [
+    ("g-set", 100, dict(rate=100, time_limit=11, latency=100, latency_dist="exponential")),                 # cfg3's shape: bursts of ~1400 rounds
+    ("g-set", 45, dict(rate=50, time_limit=12, latency=3000, latency_dist="exponential")),                  # ticks overlap (stale slots stop a node in the middle of a time); in flight at the END of the run
+    ("g-set", 60, dict(rate=100, time_limit=11, latency=400, latency_dist="uniform", p_loss=0.2)),          # lost requests: client timeouts bound the windows
+    ("g-set", 70, dict(rate=100, time_limit=11, latency=7)),                                                # constant latency: every replicate of a tick due at one time
+    ("pn-counter", 50, dict(rate=100, time_limit=11, latency=200, latency_dist="exponential")),             # time jumps of more than the table's 1024 ms
+    ("g-counter", 70, dict(rate=100, time_limit=16, latency=1000, latency_dist="exponential")),
+    ("g-set", 127, dict(rate=200, time_limit=11, latency=30, latency_dist="uniform")),
+])
+def test_wide_quiet_windows_keep_the_rounds(lib, wl, n, kw):
+    """sim_kernel_wide<>'s quiet windows (replicate deliveries made ahead of the rounds, each node at its own times; sim_kernel_wide.inc R0)
+    leave every word of the result as it was — the round count included, which they reconstruct from per-millisecond maxima — with the windows
+    (default) and without (MSIM_DEV_FLAGS bit 2), against the oracle, which knows no windows."""
+    cfg = E.test_config(wl, node_count=n, seed=123, **kw)
+    _compare(cfg, 0, 4)
+    _compare(cfg, 0, 2, dev_flags=0x4)
+
+
 @pytest.mark.parametrize("n,kw", [
     (33, dict(latency=0)),
     (36, dict(latency=10, topology="line")),

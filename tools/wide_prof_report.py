@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer tool (GPU box): BASELINE cfg3 (or WL=broadcast) with the WIDE_PROF build (tools/variant_lib.sh wprof k_wide_gset.hip -DWIDE_PROF): cycles of a wavefront of
-sim_kernel_wide<> by section of the round.  Env: N (instances), WL, NODES, LAT, DIST, MSIM_LIB, MSIM_DEV_FLAGS."""
+sim_kernel_wide<> by section of the round.  Env: N (instances), WL, NODES, LAT, DIST, PLOSS, MSIM_LIB, MSIM_DEV_FLAGS."""
 import os
 import sys
 
@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 from maelstrom_amd import engine as E  # noqa: E402
 
 kw = dict(workload=os.environ.get("WL", "g-set"), node_count=int(os.environ.get("NODES", "100")), rate=100, time_limit=20,
-          latency=int(os.environ.get("LAT", "100")), latency_dist=os.environ.get("DIST", "exponential"), seed=99)
+          latency=int(os.environ.get("LAT", "100")), latency_dist=os.environ.get("DIST", "exponential"), p_loss=float(os.environ.get("PLOSS", "0")), seed=99)
 n = int(os.environ.get("N", "16384"))
 cfg = E.test_config(**kw)
 with E.Engine(cfg) as eng:
@@ -25,7 +25,7 @@ with E.Engine(cfg) as eng:
         st, m = eng.net_stats_raw(i), eng.meta(i)
         a.append([st.all_send, st.all_recv, st.clients_send, st.clients_recv, st.servers_send, st.servers_recv, m.reserved[0] * 64, m.reserved[1] * 64, m.reserved[2] * 64, m.n_events * 64, m.n_rounds, m.n_payload_words, m.flags & 0xFFFF, m.flags >> 16])
 a = np.array(a, dtype=np.float64)
-names = ["phase checks + R0 (time)", "quiet-round test", "quiet: deliveries noted", "quiet: polls", "general: scheduler .. arrivals", "general: sort passes", "general: polls", "rows", "lone-operation path + its test", "general: R4 (clients)"]
+names = ["phase checks + R0 (time) + the windows' bounds", "quiet-round test + windows: who is eligible", "quiet rounds + windows: deliveries noted", "quiet rounds + windows: polls", "general: scheduler .. arrivals", "general: sort passes", "general: polls", "rows", "lone-operation path + its test", "general: R4 (clients)"]
 NS = len(names)
 tot = a[:, :NS].sum(axis=1).mean()
 print(f"{kw['workload']} n={kw['node_count']} latency {kw['latency']} ms {kw['latency_dist']}, {n} instances: sim kernel {sim_ms:.2f} ms, cycles per wavefront {tot:.3e}, rounds {a[:, NS].mean():.0f} ({tot / a[:, NS].mean():.0f} cycles per round)")
