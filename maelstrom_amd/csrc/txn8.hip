@@ -180,8 +180,8 @@ __global__ void __launch_bounds__(64) txn8_kernel(const T8Params tp) {
     }
   };
   // What a node needs from HBM to complete a transaction (its micro-ops, the element counts and rows of the keys it reads) and
-  // what the service needs to apply a cas (the micro-ops, the counts of the keys appended to): three dependent batches of
-  // independent loads, shared by every lane of the wavefront that needs any this round, kept in registers for the completion.
+  // what the service needs to apply a cas (the micro-ops, the counts of the keys appended to): two dependent batches of
+  // independent loads (three until round 6: the rows waited for the counts), shared by every lane of the wavefront that needs any this round, kept in registers for the completion.
   // (Issuing them rounds ahead — the plan is known when the envelope is committed to — was tried and bought nothing: with two
   // wavefronts per SIMD the round trips of ~10^4 clusters' scattered pages stay longer than a round of other work.)
   bool pf_valid = false, pf_done = false, pf_cas = false; u32 pf_off0 = 0, pf_n = 0, pf_from = V_NIL;
@@ -195,30 +195,32 @@ __global__ void __launch_bounds__(64) txn8_kernel(const T8Params tp) {
     if (tf_g) { _Pragma("unroll") for (int j = 0; j < MM; j++) { pf_wv[j] = pf_cas ? 0u : 1u; if ((u32)j < pf_n) pf_wv[j] = g_pay[pf_off0 + (u32)j]; } } \
     pf_stage = tf_g ? 1u : pf_stage;                                                                                                \
   } while (0)
-  /* element counts: of the keys a completing node reads (none if it started from nil), of the keys the service appends to */
-#define T8_STAGE_C(go_) do {                                                                                                        \
+  /* element counts — of the keys a completing node reads (none if it started from nil), of the keys the service appends to — and, in the
+     same batch, the rows of the keys a completing node reads -> number of visible elements and their values (16 bytes).  A row is
+     requested whole before its count is known (what lies behind the count is masked by it): one round trip instead of two. */
+#define T8_STAGE_CR(go_) do {                                                                                                       \
     const bool tf_g = (go_);                                                                                                        \
-    if (tf_g) { _Pragma("unroll") for (int j = 0; j < MM; j++) {                                                                    \
-      const bool tf_want = (u32)j < pf_n && (pf_cas ? (pf_wv[j] & 1u) != 0 : (!(pf_wv[j] & 1u) && pf_from != V_NIL));               \
-      pf_cn[j] = 0u; if (tf_want) pf_cn[j] = g_kvn[(pf_wv[j] >> 1) & 0x7FFFu];                                                      \
-    } }                                                                                                                             \
-    pf_stage = tf_g ? 2u : pf_stage;                                                                                                \
-  } while (0)
-  /* completing nodes: the rows of the keys they read -> number of visible elements and their values (16 bytes) */
-#define T8_STAGE_R(go_) do {                                                                                                        \
-    const bool tf_g = (go_);                                                                                                        \
+    uint4 tf_r[MM][4];                                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < MM; j++) {                                                                                \
+      const bool tf_want = tf_g && (u32)j < pf_n && (pf_cas ? (pf_wv[j] & 1u) != 0 : (!(pf_wv[j] & 1u) && pf_from != V_NIL));       \
+      const u32 tf_k = (pf_wv[j] >> 1) & 0x7FFFu;                                                                                   \
+      if (tf_g) pf_cn[j] = 0u;                                                                                                      \
+      if (tf_want) pf_cn[j] = g_kvn[tf_k];                                                                                          \
+      _Pragma("unroll") for (int qq = 0; qq < 4; qq++) tf_r[j][qq] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu); \
+      if (tf_want && pf_done) {                                                                                                     \
+        const uint4 *tf_row = reinterpret_cast<const uint4 *>(g_kv + (size_t)tf_k * mw);                                            \
+        _Pragma("unroll") for (int qq = 0; qq < 4; qq++) if (4u * (u32)qq < mw) tf_r[j][qq] = tf_row[qq];                           \
+      }                                                                                                                             \
+    }                                                                                                                               \
     _Pragma("unroll") for (int j = 0; j < MM; j++) {                                                                                \
       if (tf_g) { pf_vis[j] = 0; pf_el[j] = make_uint4(0, 0, 0, 0); }                                                               \
       if (tf_g && pf_done && (u32)j < pf_n && !(pf_wv[j] & 1u) && pf_cn[j] != 0) {                                                  \
-        const uint4 *tf_row = reinterpret_cast<const uint4 *>(g_kv + (size_t)((pf_wv[j] >> 1) & 0x7FFFu) * mw);                     \
-        uint4 tf_r[4];                                                                                                              \
-        _Pragma("unroll") for (int qq = 0; qq < 4; qq++) tf_r[qq] = 4u * (u32)qq < pf_cn[j] ? tf_row[qq] : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu); \
         u32 tf_v = 0, tf_e[4];                                                                                                      \
         _Pragma("unroll") for (int qq = 0; qq < 4; qq++) {                                                                          \
           const u32 tf_b = 4u * (u32)qq;                                                                                            \
-          tf_v += (tf_b + 0 < pf_cn[j] && (tf_r[qq].x >> 8) <= pf_from) ? 1u : 0u; tf_v += (tf_b + 1 < pf_cn[j] && (tf_r[qq].y >> 8) <= pf_from) ? 1u : 0u; \
-          tf_v += (tf_b + 2 < pf_cn[j] && (tf_r[qq].z >> 8) <= pf_from) ? 1u : 0u; tf_v += (tf_b + 3 < pf_cn[j] && (tf_r[qq].w >> 8) <= pf_from) ? 1u : 0u; \
-          tf_e[qq] = (tf_r[qq].x & 0xFFu) | ((tf_r[qq].y & 0xFFu) << 8) | ((tf_r[qq].z & 0xFFu) << 16) | ((tf_r[qq].w & 0xFFu) << 24); \
+          tf_v += (tf_b + 0 < pf_cn[j] && (tf_r[j][qq].x >> 8) <= pf_from) ? 1u : 0u; tf_v += (tf_b + 1 < pf_cn[j] && (tf_r[j][qq].y >> 8) <= pf_from) ? 1u : 0u; \
+          tf_v += (tf_b + 2 < pf_cn[j] && (tf_r[j][qq].z >> 8) <= pf_from) ? 1u : 0u; tf_v += (tf_b + 3 < pf_cn[j] && (tf_r[j][qq].w >> 8) <= pf_from) ? 1u : 0u; \
+          tf_e[qq] = (tf_r[j][qq].x & 0xFFu) | ((tf_r[j][qq].y & 0xFFu) << 8) | ((tf_r[j][qq].z & 0xFFu) << 16) | ((tf_r[j][qq].w & 0xFFu) << 24); \
         }                                                                                                                           \
         pf_vis[j] = tf_v; pf_el[j] = make_uint4(tf_e[0], tf_e[1], tf_e[2], tf_e[3]);                                                \
       }                                                                                                                             \
@@ -506,8 +508,13 @@ __global__ void __launch_bounds__(64) txn8_kernel(const T8Params tp) {
         const bool mem = do_done || do_cas;
         if (mem && !have) { pf_valid = true; pf_done = do_done; pf_cas = do_cas; pf_off0 = m_off0; pf_n = m_n; pf_from = m_from; pf_stage = 0; }
         if (__ballot(mem && pf_stage < 1u)) T8_STAGE_W(mem && pf_stage < 1u);
-        if (__ballot(mem && pf_stage < 2u)) T8_STAGE_C(mem && pf_stage < 2u);
-        if (__ballot(mem && pf_stage < 3u)) T8_STAGE_R(mem && pf_stage < 3u);
+#ifdef T8_FINE
+        T8_MARK(5)
+#endif
+        if (__ballot(mem && pf_stage < 3u)) T8_STAGE_CR(mem && pf_stage < 3u);
+#ifdef T8_FINE
+        T8_MARK(6)
+#endif
         if (do_done) {   // size of the completed form
 #pragma unroll
           for (int j = 0; j < MM; j++) if ((u32)j < m_n) {
@@ -536,6 +543,9 @@ __global__ void __launch_bounds__(64) txn8_kernel(const T8Params tp) {
         }
       }
 
+#ifdef T8_FINE
+      T8_MARK(7)
+#endif
       if (take) pf_valid = false;   // (the registers stay as they are for the completion below)
 
       // completed transactions: payload words allocated in node order, each node writes its own (from the registers filled above)
