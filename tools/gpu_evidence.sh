@@ -6,6 +6,7 @@ cd "$GRAFT_REPO_ROOT"
 R=$GRAFT_REPO_ROOT; TAG=${1:-evidence}
 timeout 600 bash tools/profile_headline.sh ${TAG}_headline full > gpurun_out/${TAG}_headline.log 2>&1
 timeout 600 bash tools/profile_config.sh ${TAG}_cfg3 "cfg3 g-set n=100 lat100 exponential" > gpurun_out/${TAG}_cfg3.log 2>&1
+timeout 600 bash tools/profile_config.sh ${TAG}_cfg3loss "cfg3 g-set n=100 lat100 exponential p_loss 0.05" > gpurun_out/${TAG}_cfg3loss.log 2>&1
 timeout 600 bash tools/profile_config.sh ${TAG}_cfg4 "cfg4 lin-kv raft n=5 c=10 rate30 60s" > gpurun_out/${TAG}_cfg4.log 2>&1
 timeout 600 bash tools/profile_config.sh ${TAG}_cfg5 "cfg5 txn-list-append n=5 rate100 30s lat5 + partitions" > gpurun_out/${TAG}_cfg5.log 2>&1
 timeout 600 bash tools/profile_config.sh ${TAG}_cfg5dt "cfg5-datomic txn-list-append datomic n=5 rate100 30s lat5 + partitions" > gpurun_out/${TAG}_cfg5dt.log 2>&1
