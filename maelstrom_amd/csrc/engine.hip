@@ -106,12 +106,12 @@ extern "C" int msim_create(const msim_config *cfg, int device, msim_ctx **out, c
   msim_config c = *cfg;
   int rc = msim_config_finalize(&c, err, errlen);
   if (rc != MSIM_OK) return rc;
-  const bool dt_many = c.node_program == MSIM_NODE_TXN_DATOMIC && c.concurrency > c.n_nodes;   // several workers per node: dtg_kernel<> (endpoint per lane)
+  const bool dt_many = (c.node_program == MSIM_NODE_TXN_DATOMIC || c.node_program == MSIM_NODE_TXN_MULTI_KEY) && c.concurrency > c.n_nodes;   // several workers per node: dtg_kernel<> / mkg_kernel<> (endpoint per lane)
   if ((c.node_program == MSIM_NODE_TXN_MULTI_KEY || c.node_program == MSIM_NODE_TXN_DATOMIC) && !dt_many && (c.concurrency != c.n_nodes || c.n_nodes > 30)) {
-    set_err(err, errlen, "multi_key_txn / datomic: one worker per node and at most 30 nodes (two service lanes) in this build; datomic also k x node-count workers");
+    set_err(err, errlen, "multi_key_txn / datomic: one worker per node and at most 30 nodes (two service lanes), or k x node-count workers with nodes + workers + 2 <= 64");
     return MSIM_E_UNSUPPORTED;
   }
-  if (dt_many && c.n_nodes + c.concurrency + 2 > 64) { set_err(err, errlen, "datomic with several workers per node: nodes + workers + 2 services <= 64"); return MSIM_E_UNSUPPORTED; }
+  if (dt_many && c.n_nodes + c.concurrency + 2 > 64) { set_err(err, errlen, "multi_key_txn / datomic with several workers per node: nodes + workers + 2 services <= 64"); return MSIM_E_UNSUPPORTED; }
   const bool txn_many = c.node_program == MSIM_NODE_TXN_SINGLE_KEY && c.concurrency > c.n_nodes;   // txng_kernel<>
   const uint32_t slots = (c.concurrency > c.n_nodes ? c.concurrency : c.n_nodes) + (dt_many ? 2 : txn_many ? 1 : 0);
   // wide clusters (33..127 nodes): two node/client pairs per lane, one worker per node: the g-set CRDT and fire-and-forget broadcast
@@ -163,7 +163,7 @@ static uint64_t proto_scratch_words(const msim_config &c) {
   if (c.node_program == MSIM_NODE_TXN_SINGLE_KEY) w = (uint64_t)c.max_values * (c.max_writes_per_key + 1);  // elements + counts per key
   if (c.node_program == MSIM_NODE_TXN_MULTI_KEY)   // elements, counts, map position, entry version, thunk counts, thunk versions + ids, the nodes' caches, the replica bytes
     w = (uint64_t)c.max_values * (c.max_writes_per_key + 4 + 2 * (c.max_writes_per_key + 1)) + (uint64_t)c.n_nodes * mk_ccap(c) + (uint64_t)c.n_nodes * mk_tcap(c) / 4 + 4 +
-        (uint64_t)c.n_nodes * (MK_SLOTS - MK_SL) * mk_slot_words(8);   // + the transaction slots that are not in LDS
+        (uint64_t)c.n_nodes * ((c.concurrency > c.n_nodes ? MKG_SLOTS : MK_SLOTS) - MK_SL) * mk_slot_words(8);   // + the transaction slots that are not in LDS (several workers per node: mkg_kernel<> has MKG_SLOTS)
   if (c.node_program == MSIM_NODE_TXN_DATOMIC) w = dt_scratch_words(c);   // elements, counts, first versions, key hashes, the tree nodes, the nodes' caches, a round's write lists
   if (c.node_program == MSIM_NODE_KAFKA) w = (uint64_t)KF_KEYS * (2 * (c.max_writes_per_key + 1) + 1);   // the logs + the committed-offset lists of the keys
   if (c.node_program == MSIM_NODE_TXN_RW_HAT) {  // registers per node + txn table + pending masks (bytes) + replicate lists
@@ -249,7 +249,7 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   const bool is_hat = c.node_program == MSIM_NODE_TXN_RW_HAT, is_mk = c.node_program == MSIM_NODE_TXN_MULTI_KEY, is_kf = c.node_program == MSIM_NODE_KAFKA, is_dt = c.node_program == MSIM_NODE_TXN_DATOMIC;
   kp.mk_tcap = is_mk ? mk_tcap(c) : is_dt ? dt_tcap(c) : 0; kp.mk_ccap = is_mk ? mk_ccap(c) : 0;
   kp.off_inbox = (u32)off;
-  const bool dt_many = is_dt && c.concurrency > c.n_nodes;   // dtg_kernel<>: a lane per endpoint, a client inbox per worker slot
+  const bool dt_many = (is_dt || is_mk) && c.concurrency > c.n_nodes;   // dtg_kernel<> / mkg_kernel<>: a lane per endpoint, a client inbox per worker slot
   const bool txn_many = is_txn && c.concurrency > c.n_nodes; // txng_kernel<>: likewise
   off += (is_mk || is_dt) ? ((size_t)(kp.N + 2) * kp.cap_node + (size_t)(dt_many ? kp.CS : kp.N) * T_CLIENT_CAP) * 16 : is_hat ? ((size_t)kp.N * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16 : is_px ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.CS * R_CLIENT_CAP) * 16 : (is_txn || is_kf) ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)(txn_many ? kp.CS : kp.N) * T_CLIENT_CAP) * 16
                 : ((size_t)kp.N * kp.cap_node + (size_t)kp.CS * (is_raft ? R_CLIENT_CAP : CLIENT_INBOX_CAP)) * 16 + wide_client_bytes(c);   // (wide: + the pairs' client state)
@@ -317,7 +317,7 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
     case MSIM_NODE_RAFT: e = msim_launch_raft1(kp, n, lds, st); break;
     case MSIM_NODE_LIN_KV_PROXY: case MSIM_NODE_TSO_IDS: e = msim_launch_svc1(kp, n, lds, st); break;   // (lin-tso ids: the proxy's layout with the timestamp oracle on the service lane)
     case MSIM_NODE_TXN_SINGLE_KEY: e = txn_many ? msim_launch_txng(kp, n, lds, st) : msim_launch_txn1(kp, n, lds, st); break;
-    case MSIM_NODE_TXN_MULTI_KEY: e = msim_launch_mk1(kp, n, lds, st); break;
+    case MSIM_NODE_TXN_MULTI_KEY: e = dt_many ? msim_launch_mkg(kp, n, lds, st) : msim_launch_mk1(kp, n, lds, st); break;
     case MSIM_NODE_TXN_DATOMIC: e = dt_many ? msim_launch_dtg(kp, n, lds, st) : msim_launch_dt1(kp, n, lds, st); break;
     case MSIM_NODE_KAFKA: e = msim_launch_kafka1(kp, n, lds, st); break;
     case MSIM_NODE_TXN_RW_HAT: e = msim_launch_hat1(kp, n, lds, st); break;

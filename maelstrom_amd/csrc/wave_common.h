@@ -177,6 +177,7 @@ hipError_t msim_launch_mk1(const KParams &kp, uint32_t n, size_t lds, hipStream_
 hipError_t msim_launch_dt1(const KParams &kp, uint32_t n, size_t lds, hipStream_t st);
 hipError_t msim_launch_dtg(const KParams &kp, uint32_t n, size_t lds, hipStream_t st);
 hipError_t msim_launch_txng(const KParams &kp, uint32_t n, size_t lds, hipStream_t st);
+hipError_t msim_launch_mkg(const KParams &kp, uint32_t n, size_t lds, hipStream_t st);
 hipError_t msim_launch_kafka1(const KParams &kp, uint32_t n, size_t lds, hipStream_t st);
 hipError_t msim_launch_hat1(const KParams &kp, uint32_t n, size_t lds, hipStream_t st);
 // duo.hip: two clusters per wavefront (fire-and-forget broadcast, constant latency, colocated clients)

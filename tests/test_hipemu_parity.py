@@ -35,6 +35,7 @@ CASES = [
     "{'workload':'txn-list-append','bin':'datomic','node_count':1,'concurrency':10,'rate':100,'time_limit':6,'latency':2,'n':2}",   # several workers per node: dtg_kernel<> (a lane per endpoint); the lock's waiting queue under load
     "{'workload':'txn-list-append','bin':'datomic','node_count':5,'concurrency':10,'rate':100,'time_limit':6,'latency':5,'nemesis':['partition'],'nemesis_interval':2,'n':2}",
     "{'workload':'txn-list-append','node_count':2,'concurrency':20,'rate':300,'time_limit':5,'latency':3,'latency_dist':'uniform','n':2}",   # several workers per node, single-root node: txng_kernel<>
+    "{'workload':'txn-list-append','bin':'multi-key-txn','node_count':5,'concurrency':10,'rate':100,'time_limit':6,'latency':5,'nemesis':['partition'],'nemesis_interval':2,'n':2}",   # ... multi-key node: mkg_kernel<>
     "{'workload':'txn-rw-register','node_count':2,'rate':100,'time_limit':8,'nemesis':['partition'],'nemesis_interval':2,'flags':0x400,'n':11}",
     "{'workload':'txn-rw-register','node_count':4,'rate':200,'time_limit':6,'latency':20,'latency_dist':'exponential','p_loss':0.05,'flags':0x8400,'n':19}",
     "{'workload':'txn-rw-register','node_count':5,'rate':200,'time_limit':8,'latency':5,'nemesis':['partition'],'nemesis_interval':3,'flags':0x400,'n':9}",

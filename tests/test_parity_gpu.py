@@ -384,6 +384,22 @@ def test_single_key_txn_many_workers_parity(lib, kw):
     _compare(cfg, 0, 5)
 
 
+@pytest.mark.parametrize("kw", [
+    dict(node_count=1, concurrency=10, rate=100, time_limit=8, latency=0),
+    dict(node_count=2, concurrency=20, rate=300, time_limit=5, latency=3, latency_dist="uniform"),
+    dict(node_count=5, concurrency=10, rate=200, time_limit=6, latency=5, nemesis=["partition"], nemesis_interval=2),
+    dict(node_count=3, concurrency=9, rate=150, time_limit=8, latency=10, latency_dist="exponential", journal_capacity=600000),
+    dict(node_count=2, concurrency=8, rate=200, time_limit=4, latency=2, key_count=3, max_txn_length=8, max_writes_per_key=32),   # eight keys per transaction slot
+    dict(node_count=1, concurrency=61, rate=1000, time_limit=3, latency=1),                                    # a full wavefront: 1 node, 61 workers, lin-kv, lww-kv
+])
+def test_multi_key_txn_many_workers_parity(lib, kw):
+    """Several workers per node for the multi-key node (demo/js/multi_key_txn.js): mkg_kernel<> (csrc/sim_kernel_mkg.inc: a lane per endpoint, up
+    to 64 transactions in flight per node) against oracle/mk_nodes.inc, which tests/test_process_bridge.py holds to the real program with
+    several workers per node."""
+    cfg = E.test_config("txn-list-append", bin="multi-key-txn", seed=31, **kw)
+    _compare(cfg, 0, 5)
+
+
 def test_deep_queues_spill_to_hbm(lib):
     """Exponential latency => long head-of-line sleeps => queues far deeper than the LDS part: the HBM spill area
     behind each node's queue keeps the result bit-identical (and unflagged)."""

@@ -163,6 +163,8 @@ def test_reference_single_key_txn_js_reproduces_the_oracle_history(kw):
     dict(node_count=5, rate=60, time_limit=3, latency=10, latency_dist="exponential", nemesis=["partition"], nemesis_interval=1, seed=7),
     dict(node_count=3, rate=150, time_limit=2, latency=3, latency_dist="uniform", key_count=2, max_txn_length=8, max_writes_per_key=32, seed=8),
     dict(node_count=7, rate=100, time_limit=2, latency=0, seed=9),
+    dict(node_count=2, concurrency=8, rate=200, time_limit=3, latency=2, key_count=3, seed=11),   # several workers per node (--concurrency 4n): transactions of one node race for the root
+    dict(node_count=1, concurrency=10, rate=100, time_limit=3, latency=1, seed=12),               # --concurrency 10n (doc/05-datomic/01-single-node.md:257)
 ])
 def test_reference_multi_key_txn_js_reproduces_the_oracle_history(kw):
     """The canonical txn-list-append node (row a18): the REFERENCE's own demo/js/multi_key_txn.js as real node.js processes — thunks in
