@@ -117,12 +117,12 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
     if (c->key_count > 16 || c->max_txn_length > 8 || c->max_writes_per_key > 63) {
       set_err(err, errlen, "transactional workloads: key-count <= 16, max-txn-length <= 8, max-writes-per-key <= 63"); return MSIM_E_INVALID; }
     // Several workers per node (`--concurrency 10n`, doc/05-datomic/01-single-node.md:257,322: what puts transactions behind each other at a
-    // node's lock) for the nodes whose kernels have the general lane layout: the Datomic-style node (dtg_kernel<>), the single-root node (txng_kernel<>) and the multi-key node (mkg_kernel<>).  Worker t talks to node
+    // node's lock) for the nodes whose kernels have the general lane layout: the Datomic-style node (dtg_kernel<>), the single-root node (txng_kernel<>), the multi-key node (mkg_kernel<>) and txn-rw-register's node (hatg_kernel<>).  Worker t talks to node
     // t mod n ([upstream] interpreter), so the count must be a multiple of the node count here.
-    const bool many_workers_ok = (c->node_program == MSIM_NODE_TXN_DATOMIC || c->node_program == MSIM_NODE_TXN_SINGLE_KEY || c->node_program == MSIM_NODE_TXN_MULTI_KEY) && !hat &&
-                                 c->concurrency > c->n_nodes && c->concurrency % c->n_nodes == 0 && c->n_nodes + c->concurrency + 2 <= 64;
+    const bool many_workers_ok = (c->node_program == MSIM_NODE_TXN_DATOMIC || c->node_program == MSIM_NODE_TXN_SINGLE_KEY || c->node_program == MSIM_NODE_TXN_MULTI_KEY || hat) &&
+                                 c->concurrency > c->n_nodes && c->concurrency % c->n_nodes == 0 && c->n_nodes + c->concurrency + (hat ? 0u : 2u) <= 64;   // (a lane per endpoint: nodes, workers, up to two services)
     if ((c->concurrency != c->n_nodes && !many_workers_ok) || c->n_nodes > 31) {
-      set_err(err, errlen, "transactional workloads: one worker per node (concurrency == node-count <= 31) in this build; the three txn-list-append nodes also take k x node-count workers (nodes + workers + 2 <= 64)"); return MSIM_E_UNSUPPORTED; }
+      set_err(err, errlen, "transactional workloads: one worker per node (concurrency == node-count <= 31) in this build; the three txn-list-append nodes and the txn-rw-register node also take k x node-count workers (nodes + workers + 2 <= 64)"); return MSIM_E_UNSUPPORTED; }
     // txn_rw_register_hat.clj:85-90: with no other node the pending set of a txn is empty and replicate-step! sends to nil
     if (hat && (c->n_nodes < 2 || c->n_nodes > 8)) { set_err(err, errlen, "txn-rw-register: 2..8 nodes in this build"); return MSIM_E_UNSUPPORTED; }
   }
@@ -190,7 +190,7 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
     if (txn || kafka) depth = 16 + 4 * c->n_nodes + (c->concurrency > c->n_nodes ? 2 * c->concurrency : 0);   // the service sees <= 2 requests per transaction in flight (+ every worker's at once)
     if (c->node_program == MSIM_NODE_TXN_MULTI_KEY) depth = 16 + 16 * c->n_nodes + (c->concurrency > c->n_nodes ? 8 * c->concurrency : 0);   // lww-kv: up to max-txn-length thunk reads / writes per transaction (several workers per node: per worker)
     if (c->node_program == MSIM_NODE_TXN_DATOMIC) depth = 16 + (c->n_nodes < 4 ? 304 : 96 * c->n_nodes) + (c->concurrency > c->n_nodes ? c->concurrency : 0);   // (+ every worker's request at its node at once); lww-kv: every node may have the new tree nodes of a transaction in flight (a path per append; one transaction writes at most DT_MAXW = 256)
-    if (hat) depth = 16 + 4 * c->n_nodes + (uint32_t)(20.0 * c->n_nodes * lat_s);  // a replicate + n-1 acks per peer per 100 ms tick
+    if (hat) depth = 16 + 4 * c->n_nodes + (uint32_t)(20.0 * c->n_nodes * lat_s) + (c->concurrency > c->n_nodes ? c->concurrency : 0);  // a replicate + n-1 acks per peer per 100 ms tick
     if (c->node_program == MSIM_NODE_LIN_KV_PROXY || c->node_program == MSIM_NODE_TSO_IDS) depth = 16 + 2 * c->concurrency;   // the service sees every worker's request at once
     // wide clusters: 100+ queues would take a fifth of the LDS budget of a cluster; their queues live in the HBM spill area
     // only (kept sorted, the head cached in registers: sim_kernel_wide.inc), which buys a sixth wavefront per CU

@@ -251,7 +251,7 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   kp.off_inbox = (u32)off;
   const bool dt_many = (is_dt || is_mk) && c.concurrency > c.n_nodes;   // dtg_kernel<> / mkg_kernel<>: a lane per endpoint, a client inbox per worker slot
   const bool txn_many = is_txn && c.concurrency > c.n_nodes; // txng_kernel<>: likewise
-  off += (is_mk || is_dt) ? ((size_t)(kp.N + 2) * kp.cap_node + (size_t)(dt_many ? kp.CS : kp.N) * T_CLIENT_CAP) * 16 : is_hat ? ((size_t)kp.N * kp.cap_node + (size_t)kp.N * T_CLIENT_CAP) * 16 : is_px ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.CS * R_CLIENT_CAP) * 16 : (is_txn || is_kf) ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)(txn_many ? kp.CS : kp.N) * T_CLIENT_CAP) * 16
+  off += (is_mk || is_dt) ? ((size_t)(kp.N + 2) * kp.cap_node + (size_t)(dt_many ? kp.CS : kp.N) * T_CLIENT_CAP) * 16 : is_hat ? ((size_t)kp.N * kp.cap_node + (size_t)kp.CS * T_CLIENT_CAP) * 16   /* (hatg_kernel<>: an inbox per worker slot; CS == N otherwise) */ : is_px ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.CS * R_CLIENT_CAP) * 16 : (is_txn || is_kf) ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)(txn_many ? kp.CS : kp.N) * T_CLIENT_CAP) * 16
                 : ((size_t)kp.N * kp.cap_node + (size_t)kp.CS * (is_raft ? R_CLIENT_CAP : CLIENT_INBOX_CAP)) * 16 + wide_client_bytes(c);   // (wide: + the pairs' client state)
   kp.off_seen = (u32)off;
   off += is_mk ? ((size_t)kp.N * MK_SL * mk_slot_words(mk_keys_for(c)) + (size_t)kp.N * mk_keys_for(c) * 3 + 36) * 4   // transactions in flight (the first MK_SL per node), a round's messages per node, the generator's key pool
@@ -320,7 +320,7 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
     case MSIM_NODE_TXN_MULTI_KEY: e = dt_many ? msim_launch_mkg(kp, n, lds, st) : msim_launch_mk1(kp, n, lds, st); break;
     case MSIM_NODE_TXN_DATOMIC: e = dt_many ? msim_launch_dtg(kp, n, lds, st) : msim_launch_dt1(kp, n, lds, st); break;
     case MSIM_NODE_KAFKA: e = msim_launch_kafka1(kp, n, lds, st); break;
-    case MSIM_NODE_TXN_RW_HAT: e = msim_launch_hat1(kp, n, lds, st); break;
+    case MSIM_NODE_TXN_RW_HAT: e = c.concurrency > c.n_nodes ? msim_launch_hatg(kp, n, lds, st) : msim_launch_hat1(kp, n, lds, st); break;
     default: ctx->err = "node program not built into this engine"; return MSIM_E_UNSUPPORTED;
   }
   if (e != hipSuccess) { ctx->err = std::string("kernel launch: ") + hipGetErrorString(e); return MSIM_E_HIP; }

@@ -92,6 +92,7 @@ static inline size_t wide_pending_bytes(const msim_config &c) {
 #include "sim_kernel_txng.inc"
 #include "sim_kernel_mkg.inc"
 #include "sim_kernel_hat.inc"
+#include "sim_kernel_hatg.inc"
 #include "sim_kernel_kafka.inc"
 #include "sim_kernel_svc.inc"
 

@@ -153,6 +153,9 @@ def test_random_rw_register_options_engine_equals_oracle(lib, case):
     _compare(cfg, first, N_INST, dev_flags=0x400)       # eight clusters per wavefront where csrc/hat8.hip applies (else the same kernel again)
     if cfg.n_nodes <= 4:
         _compare(cfg, first, N_INST, dev_flags=0x8400)  # its 4-lane groups
+    k = rng.choice([2, 3, 7])                           # ... and the same options with several workers per node (hatg_kernel<>: a lane per endpoint)
+    if kw["node_count"] * (k + 1) + 2 <= 64:
+        _compare(E.test_config(wl, concurrency=k * kw["node_count"], **kw), first, 3)
 
 
 @pytest.mark.parametrize("case", range(int(os.environ.get("MSIM_FUZZ_CASES", "16"))))

@@ -37,6 +37,7 @@ CASES = [
     "{'workload':'txn-list-append','node_count':2,'concurrency':20,'rate':300,'time_limit':5,'latency':3,'latency_dist':'uniform','n':2}",   # several workers per node, single-root node: txng_kernel<>
     "{'workload':'txn-list-append','bin':'multi-key-txn','node_count':5,'concurrency':10,'rate':100,'time_limit':6,'latency':5,'nemesis':['partition'],'nemesis_interval':2,'n':2}",   # ... multi-key node: mkg_kernel<>
     "{'workload':'txn-rw-register','node_count':2,'rate':100,'time_limit':8,'nemesis':['partition'],'nemesis_interval':2,'flags':0x400,'n':11}",
+    "{'workload':'txn-rw-register','node_count':5,'concurrency':10,'rate':100,'time_limit':6,'latency':5,'nemesis':['partition'],'nemesis_interval':2,'n':2}",   # several workers per node: hatg_kernel<>
     "{'workload':'txn-rw-register','node_count':4,'rate':200,'time_limit':6,'latency':20,'latency_dist':'exponential','p_loss':0.05,'flags':0x8400,'n':19}",
     "{'workload':'txn-rw-register','node_count':5,'rate':200,'time_limit':8,'latency':5,'nemesis':['partition'],'nemesis_interval':3,'flags':0x400,'n':9}",
     "{'workload':'kafka','node_count':5,'rate':80,'time_limit':8,'latency':5,'nemesis':['partition'],'nemesis_interval':3,'flags':0x400,'n':9}",

@@ -400,6 +400,20 @@ def test_multi_key_txn_many_workers_parity(lib, kw):
     _compare(cfg, 0, 5)
 
 
+@pytest.mark.parametrize("kw", [
+    dict(node_count=2, concurrency=10, rate=100, time_limit=8, nemesis=["partition"], nemesis_interval=2),   # the reference's demo shape (core.clj:115-121) with --concurrency 5n
+    dict(node_count=2, concurrency=20, rate=300, time_limit=5, latency=3, latency_dist="uniform"),
+    dict(node_count=5, concurrency=10, rate=200, time_limit=6, latency=5, nemesis=["partition"], nemesis_interval=2),
+    dict(node_count=3, concurrency=9, rate=150, time_limit=8, latency=10, latency_dist="exponential", p_loss=0.03, journal_capacity=600000),
+    dict(node_count=8, concurrency=56, rate=500, time_limit=3, latency=2),                                    # a full wavefront: 8 nodes, 56 workers
+])
+def test_rw_register_many_workers_parity(lib, kw):
+    """Several workers per node for txn-rw-register's node (demo/clojure/txn_rw_register_hat.clj): hatg_kernel<> (csrc/sim_kernel_hatg.inc: a lane
+    per endpoint) against oracle/hat_nodes.inc."""
+    cfg = E.test_config("txn-rw-register", seed=37, **kw)
+    _compare(cfg, 0, 5)
+
+
 def test_deep_queues_spill_to_hbm(lib):
     """Exponential latency => long head-of-line sleeps => queues far deeper than the LDS part: the HBM spill area
     behind each node's queue keeps the result bit-identical (and unflagged)."""
