@@ -133,7 +133,8 @@ extern "C" int msim_config_finalize(msim_config *c, char *err, size_t errlen) {
     // the {key offset} maps of the protocol keep insertion order up to 8 entries (Clojure array-maps); message values and offsets
     // travel in 11 bits of a history row
     if (c->key_count > 8 || c->max_writes_per_key > 2046) { set_err(err, errlen, "kafka: key-count <= 8, max-writes-per-key <= 2046"); return MSIM_E_INVALID; }
-    if (c->concurrency != c->n_nodes || c->n_nodes > 30) { set_err(err, errlen, "kafka: one worker per node (concurrency == node-count <= 30) in this build"); return MSIM_E_UNSUPPORTED; }
+    const bool kf_many = c->concurrency > c->n_nodes && c->concurrency % c->n_nodes == 0 && c->n_nodes + c->concurrency + 1 <= 64;   // kafkag_kernel<>: a lane per endpoint
+    if ((c->concurrency != c->n_nodes && !kf_many) || c->n_nodes > 30) { set_err(err, errlen, "kafka: one worker per node (concurrency == node-count <= 30), or k x node-count workers with nodes + workers + 1 <= 64"); return MSIM_E_UNSUPPORTED; }
   }
   double expected = (double)c->rate_mhz * (double)c->time_limit_ms / 1e6;
   uint32_t ops_max = (uint32_t)(expected + expected / 8.0) + 64;

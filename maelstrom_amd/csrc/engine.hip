@@ -112,7 +112,7 @@ extern "C" int msim_create(const msim_config *cfg, int device, msim_ctx **out, c
     return MSIM_E_UNSUPPORTED;
   }
   if (dt_many && c.n_nodes + c.concurrency + 2 > 64) { set_err(err, errlen, "multi_key_txn / datomic with several workers per node: nodes + workers + 2 services <= 64"); return MSIM_E_UNSUPPORTED; }
-  const bool txn_many = c.node_program == MSIM_NODE_TXN_SINGLE_KEY && c.concurrency > c.n_nodes;   // txng_kernel<>
+  const bool txn_many = (c.node_program == MSIM_NODE_TXN_SINGLE_KEY || c.node_program == MSIM_NODE_KAFKA) && c.concurrency > c.n_nodes;   // txng_kernel<> / kafkag_kernel<>: + the lin-kv lane
   const uint32_t slots = (c.concurrency > c.n_nodes ? c.concurrency : c.n_nodes) + (dt_many ? 2 : txn_many ? 1 : 0);
   // wide clusters (33..127 nodes): two node/client pairs per lane, one worker per node: the g-set CRDT and fire-and-forget broadcast
   const bool wide_prog = c.node_program == MSIM_NODE_G_SET || c.node_program == MSIM_NODE_BCAST_FF || c.node_program == MSIM_NODE_BCAST_FF_ECHOBACK ||
@@ -250,7 +250,7 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   kp.mk_tcap = is_mk ? mk_tcap(c) : is_dt ? dt_tcap(c) : 0; kp.mk_ccap = is_mk ? mk_ccap(c) : 0;
   kp.off_inbox = (u32)off;
   const bool dt_many = (is_dt || is_mk) && c.concurrency > c.n_nodes;   // dtg_kernel<> / mkg_kernel<>: a lane per endpoint, a client inbox per worker slot
-  const bool txn_many = is_txn && c.concurrency > c.n_nodes; // txng_kernel<>: likewise
+  const bool txn_many = (is_txn || is_kf) && c.concurrency > c.n_nodes; // txng_kernel<> / kafkag_kernel<>: likewise
   off += (is_mk || is_dt) ? ((size_t)(kp.N + 2) * kp.cap_node + (size_t)(dt_many ? kp.CS : kp.N) * T_CLIENT_CAP) * 16 : is_hat ? ((size_t)kp.N * kp.cap_node + (size_t)kp.CS * T_CLIENT_CAP) * 16   /* (hatg_kernel<>: an inbox per worker slot; CS == N otherwise) */ : is_px ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.CS * R_CLIENT_CAP) * 16 : (is_txn || is_kf) ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)(txn_many ? kp.CS : kp.N) * T_CLIENT_CAP) * 16
                 : ((size_t)kp.N * kp.cap_node + (size_t)kp.CS * (is_raft ? R_CLIENT_CAP : CLIENT_INBOX_CAP)) * 16 + wide_client_bytes(c);   // (wide: + the pairs' client state)
   kp.off_seen = (u32)off;
@@ -259,7 +259,7 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
        : is_hat ? 36 * 4   // the generator's key pool
        : is_px ? (size_t)kp.N * PX_SLOTS * 8 + 34 * 256 + 64 * 4   // callbacks per node + service states + seq-kv indices
        : is_txn ? (size_t)kp.N * (txn_many ? TG_SLOTS : TXN_SLOTS) * 16 + 36 * 4   // transactions in flight per node + the generator's key pool
-       : is_kf ? ((size_t)kp.N * KF_SLOTS * KSW + 2 * (size_t)kp.N * KF_KEYS + 36 + 2 * KF_KEYS) * 4   // request handlers, offset caches, client offsets, key pool, lin-kv lengths
+       : is_kf ? ((size_t)kp.N * (txn_many ? KFG_SLOTS : KF_SLOTS) * KSW + (size_t)kp.N * KF_KEYS + (size_t)(txn_many ? kp.CS : kp.N) * KF_KEYS + 36 + 2 * KF_KEYS) * 4   // request handlers, offset caches, client offsets (per worker slot), key pool, lin-kv lengths
        : is_raft ? (size_t)kp.N * 256 + (size_t)kp.N * kp.N * 3 * 4   // KV state + next/match index + append_entries refs
        : wide ? (wide_setl ? (size_t)kp.N * kp.W * 4 : 0) + wide_pending_bytes(c)   // the sets of a wide cluster live in HBM scratch unless they fit LDS (wide_sets_in_lds); + the CRDTs' delivered-but-unmerged replicates
                  : (size_t)kp.N * kp.W * 4;
@@ -319,7 +319,7 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
     case MSIM_NODE_TXN_SINGLE_KEY: e = txn_many ? msim_launch_txng(kp, n, lds, st) : msim_launch_txn1(kp, n, lds, st); break;
     case MSIM_NODE_TXN_MULTI_KEY: e = dt_many ? msim_launch_mkg(kp, n, lds, st) : msim_launch_mk1(kp, n, lds, st); break;
     case MSIM_NODE_TXN_DATOMIC: e = dt_many ? msim_launch_dtg(kp, n, lds, st) : msim_launch_dt1(kp, n, lds, st); break;
-    case MSIM_NODE_KAFKA: e = msim_launch_kafka1(kp, n, lds, st); break;
+    case MSIM_NODE_KAFKA: e = txn_many ? msim_launch_kafkag(kp, n, lds, st) : msim_launch_kafka1(kp, n, lds, st); break;
     case MSIM_NODE_TXN_RW_HAT: e = c.concurrency > c.n_nodes ? msim_launch_hatg(kp, n, lds, st) : msim_launch_hat1(kp, n, lds, st); break;
     default: ctx->err = "node program not built into this engine"; return MSIM_E_UNSUPPORTED;
   }

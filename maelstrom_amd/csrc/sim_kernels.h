@@ -94,6 +94,7 @@ static inline size_t wide_pending_bytes(const msim_config &c) {
 #include "sim_kernel_hat.inc"
 #include "sim_kernel_hatg.inc"
 #include "sim_kernel_kafka.inc"
+#include "sim_kernel_kafkag.inc"
 #include "sim_kernel_svc.inc"
 
 // Which wide clusters keep their nodes' sets in LDS (SETL) instead of HBM scratch.  Round 3 took the layout for g-set when sets + client

@@ -181,6 +181,7 @@ hipError_t msim_launch_mkg(const KParams &kp, uint32_t n, size_t lds, hipStream_
 hipError_t msim_launch_kafka1(const KParams &kp, uint32_t n, size_t lds, hipStream_t st);
 hipError_t msim_launch_hat1(const KParams &kp, uint32_t n, size_t lds, hipStream_t st);
 hipError_t msim_launch_hatg(const KParams &kp, uint32_t n, size_t lds, hipStream_t st);
+hipError_t msim_launch_kafkag(const KParams &kp, uint32_t n, size_t lds, hipStream_t st);
 // duo.hip: two clusters per wavefront (fire-and-forget broadcast, constant latency, colocated clients)
 bool msim_duo_eligible(const msim_config &c);
 hipError_t msim_launch_duo(const KParams &kp, uint32_t n, hipStream_t st);

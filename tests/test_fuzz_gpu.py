@@ -185,6 +185,9 @@ def test_random_kafka_options_engine_equals_oracle(lib, case):
     _compare(cfg, first, N_INST)
     if n <= 7 and not kw.get("journal_capacity"):
         _compare(cfg, first, N_INST + 5, dev_flags=0x400)   # eight clusters per wavefront (csrc/kafka8.hip; large batches take it unasked)
+    k = rng.choice([2, 3, 8])                                  # ... and the same options with several workers per node (kafkag_kernel<>: a lane per endpoint)
+    if n * (k + 1) + 1 <= 64:
+        _compare(E.test_config("kafka", concurrency=k * n, **kw), first, 3)
 
 
 @pytest.mark.parametrize("case", range(int(os.environ.get("MSIM_FUZZ_CASES", "36"))))

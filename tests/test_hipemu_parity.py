@@ -42,6 +42,7 @@ CASES = [
     "{'workload':'txn-rw-register','node_count':5,'rate':200,'time_limit':8,'latency':5,'nemesis':['partition'],'nemesis_interval':3,'flags':0x400,'n':9}",
     "{'workload':'kafka','node_count':5,'rate':80,'time_limit':8,'latency':5,'nemesis':['partition'],'nemesis_interval':3,'flags':0x400,'n':9}",
     "{'workload':'kafka','node_count':2,'rate':200,'time_limit':4,'latency':2,'key_count':2,'max_writes_per_key':40,'flags':0x400,'n':9}",
+    "{'workload':'kafka','node_count':5,'concurrency':10,'rate':100,'time_limit':8,'latency':5,'nemesis':['partition'],'nemesis_interval':3,'n':2}",   # several workers per node: kafkag_kernel<>
     "{'workload':'unique-ids','node_count':3,'rate':500,'time_limit':4,'latency':5,'nemesis':['partition'],'nemesis_interval':2,'flags':0x400,'n':11}",
     "{'workload':'echo','node_count':5,'rate':300,'time_limit':3,'latency':2,'p_loss':0.1,'flags':0x400,'n':9}",
     "{'workload':'g-set','node_count':5,'rate':100,'time_limit':8,'latency':10,'nemesis':['partition'],'nemesis_interval':3,'flags':0x400,'n':11}",

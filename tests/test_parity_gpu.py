@@ -414,6 +414,21 @@ def test_rw_register_many_workers_parity(lib, kw):
     _compare(cfg, 0, 5)
 
 
+@pytest.mark.parametrize("kw", [
+    dict(node_count=1, concurrency=10, rate=100, time_limit=8, latency=0),
+    dict(node_count=2, concurrency=20, rate=300, time_limit=5, latency=3, latency_dist="uniform"),
+    dict(node_count=5, concurrency=10, rate=200, time_limit=8, latency=5, nemesis=["partition"], nemesis_interval=3),
+    dict(node_count=3, concurrency=9, rate=150, time_limit=8, latency=10, latency_dist="exponential", p_loss=0.03, journal_capacity=600000),
+    dict(node_count=1, concurrency=12, rate=150, time_limit=6, latency=2, key_count=2, max_writes_per_key=200),  # full chunks (32 messages): the send path recurs
+    dict(node_count=3, concurrency=60, rate=1000, time_limit=3, latency=1),                                    # a full wavefront: 3 nodes, 60 workers, lin-kv
+])
+def test_kafka_many_workers_parity(lib, kw):
+    """Several workers per node for the kafka workload (demo/clojure/kafka.clj): kafkag_kernel<> (csrc/sim_kernel_kafkag.inc: a lane per endpoint,
+    up to 64 request handlers in flight per node, a client's offsets and assign / poll / commit state in its own lane) against oracle/kafka_nodes.inc."""
+    cfg = E.test_config("kafka", seed=41, **kw)
+    _compare(cfg, 0, 5)
+
+
 def test_deep_queues_spill_to_hbm(lib):
     """Exponential latency => long head-of-line sleeps => queues far deeper than the LDS part: the HBM spill area
     behind each node's queue keeps the result bit-identical (and unflagged)."""
