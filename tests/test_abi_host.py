@@ -52,8 +52,10 @@ def test_finalize_derives_capacities_and_rejects_bad_options(lib):
     assert E.test_config("txn-list-append", node_count=5, concurrency=10).concurrency == 10   # several workers per node: the single-root and the Datomic-style node (round 6)
     with pytest.raises(E.EngineError, match="one worker per node"):
         E.test_config("txn-list-append", node_count=5, concurrency=7)                          # ... in multiples of the node count
+    assert E.test_config("txn-list-append", bin="multi-key-txn", node_count=5, concurrency=10).concurrency == 10
+    assert E.test_config("kafka", node_count=5, concurrency=10).concurrency == 10
     with pytest.raises(E.EngineError, match="one worker per node"):
-        E.test_config("txn-list-append", bin="multi-key-txn", node_count=5, concurrency=10)
+        E.test_config("kafka", node_count=5, concurrency=12)
     with pytest.raises(E.EngineError, match="max-txn-length"):
         E.test_config("txn-list-append", node_count=5, max_txn_length=9)
     with pytest.raises(E.EngineError, match="multiple of 2 x node-count"):

@@ -31,7 +31,8 @@ def test_defaults_and_limits():
     with pytest.raises(E.EngineError):
         _cfg(key_count=9)          # {key offset} maps keep insertion order only up to 8 entries
     with pytest.raises(E.EngineError):
-        _cfg(concurrency=6)        # one worker per node in this build
+        _cfg(concurrency=7)        # one worker per node, or a multiple of the node count (round 6: kafkag_kernel<>)
+    assert _cfg(concurrency=6).concurrency == 6
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(latency=0, rate=120.0), dict(node_count=5, latency=20, latency_dist="exponential"),
