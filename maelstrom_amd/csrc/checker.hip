@@ -82,6 +82,9 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
   __syncthreads();
 
   u32 v_cur = 0, n_ri = 0, errors = 0;
+#ifdef CK_PROF   // developer build (tools/check_prof_report.py): cycles of pass 1 / pass 2 / the rest in stable_latency_ms[0..2], pairing rounds in [3], reads in [4]
+  const u64 ck_t0 = __builtin_readcyclecounter(); u64 ck_t1 = 0, ck_t2 = 0; u32 ck_rounds = 0;
+#endif
   u32 cnt_lo = 0, cnt_hi = 0;    // per lane: rows of type :invoke | :ok << 16, :fail | :info << 16 (summed over the wavefront at the end)
   u32 round_key = 0x3FFFFFFu;    // decreases with every pairing round: a later round's ds_min beats whatever an earlier one left
 
@@ -158,6 +161,9 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
       round_key--;
       __syncthreads();
       pm = __ballot(pend);
+#ifdef CK_PROF
+      ck_rounds++;
+#endif
     }
   }
   if (!setfull) { for (u32 i = lane; i < C; i += 64) errors += slot[i] != NONE32 ? 1u : 0u; }   // invocations left without a completion
@@ -168,6 +174,9 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
   __threadfence_block();
   __syncthreads();
   if (n_ri > p.max_reads) n_ri = p.max_reads;
+#ifdef CK_PROF
+  ck_t1 = __builtin_readcyclecounter();
+#endif
 
   // ---- pass 2: ONE sweep over the :ok reads in invocation order, lane w = word w of the bitmaps (elements 32w .. 32w+31) -----------------
   // Every bitmap word is loaded once (round 2 read them twice: forwards in completion order for `known`, backwards in invocation
@@ -180,6 +189,10 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
   //     the sweep has passed the latest such completion).
   // The loads of 8 reads are issued together, and the next 8 before those are folded in (one dependent global load per read
   // would bound the sweep; so would one exposed round trip per batch).
+  // (Round 6 split it again — forwards for `known`, BACKWARDS for last-present / last-absent, where the first read seen with the bit decides and
+  //  every element is written once instead of at every transition — on the guess that the transition loops were what a read cost: 0.53 -> 0.70 ms
+  //  at the headline shape, pass 2 8.6e5 -> 1.17e6 cycles per history.  A read costs what walking it costs — taking its rank, three readlanes,
+  //  the load, the masks: ~570 cycles per read and sweep with four wavefronts per SIMD — not what it changes.  tools/check_prof_report.py.)
   {
     u32 unk = 0xFFFFFFFFu, fresh = 0, fresh_until = 0 /* wave-uniform */, prev_w = 0, prev_a = 0, prev_inv = 0;
     const u32 lo = lane * 32;
@@ -262,6 +275,9 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
   }
   __syncthreads();
 
+#ifdef CK_PROF
+  ck_t2 = __builtin_readcyclecounter();
+#endif
   // ---- per-element outcomes (each lane owns elements e = lane, lane+64, ...; at most 32 per lane) ----
   u32 c_stable = 0, c_lost = 0, c_never = 0, c_stale = 0;
   u32 my_lat[32];  // statically indexed (unrolled): stays in VGPRs
@@ -316,6 +332,9 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
     o.attempt_count = v_cur; o.stable_count = n_stable; o.lost_count = n_lost; o.never_read_count = n_never;
     o.stale_count = n_stale; o.duplicated_count = 0; o.error_count = errors;
     for (int i = 0; i < 5; i++) o.stable_latency_ms[i] = q[i];
+#ifdef CK_PROF
+    o.stable_latency_ms[0] = (u32)(ck_t1 - ck_t0); o.stable_latency_ms[1] = (u32)(ck_t2 - ck_t1); o.stable_latency_ms[2] = (u32)(__builtin_readcyclecounter() - ck_t2); o.stable_latency_ms[3] = ck_rounds; o.stable_latency_ms[4] = n_ri;
+#endif
     o.op_count = op_count; o.ok_count = n_ok; o.fail_count = n_fail; o.info_count = n_info;
     if (meta.flags) o.valid = 0;
     else if (!setfull) o.valid = errors == 0 ? 1 : 0;
