@@ -49,11 +49,30 @@ struct CParams {
   float rcp_C;
 };
 
+#ifdef MSIM_HIPEMU
+struct __attribute__((packed, aligned(4))) ck_u32x4 { u32 x, y, z, w; };
+#else
+typedef u32 ck_u32x4 __attribute__((ext_vector_type(4), aligned(4)));   // 16 bytes of a u32 array from any word on: global memory takes one dwordx4 at a 4-byte boundary
+#endif
 __device__ __forceinline__ u32 c_rdlane(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
 __device__ __forceinline__ u32 c_wave_sum(u32 v) {
   for (int o = 32; o; o >>= 1) v += (u32)__shfl_xor((int)v, o);
   return v;
 }
+
+// maximum over the 64 lanes (uniform) / inclusive prefix maximum, by DPP
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ u32 c_dpp(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, BOUND); }
+__device__ __forceinline__ u32 c_wave_incl_max(u32 v) {
+  v = max(v, c_dpp<0x111, 0xF, true>(v));   // row_shr:1 (lanes without a source read 0)
+  v = max(v, c_dpp<0x112, 0xF, true>(v));   // row_shr:2
+  v = max(v, c_dpp<0x114, 0xF, true>(v));   // row_shr:4
+  v = max(v, c_dpp<0x118, 0xF, true>(v));   // row_shr:8
+  v = max(v, c_dpp<0x142, 0xA, false>(v));  // row_bcast:15 -> rows 1, 3
+  v = max(v, c_dpp<0x143, 0xC, false>(v));  // row_bcast:31 -> rows 2, 3
+  return v;
+}
+__device__ __forceinline__ u32 c_wave_max(u32 v) { return c_rdlane(c_wave_incl_max(v), 63); }
 
 __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char csmem[];
@@ -178,68 +197,26 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
   ck_t1 = __builtin_readcyclecounter();
 #endif
 
-  // ---- pass 2: ONE sweep over the :ok reads in invocation order, lane w = word w of the bitmaps (elements 32w .. 32w+31) -----------------
-  // Every bitmap word is loaded once (round 2 read them twice: forwards in completion order for `known`, backwards in invocation
-  // order for last-present / last-absent).  In invocation order
-  //   last-present / last-absent = the invocation of the LAST read that has / lacks the element: written when the element LEAVES that
-  //     state (a word compared with the previous read's: one XOR-like mask per read, a bit loop per transition) and for the state the
-  //     last read leaves it in;
-  //   known = the smallest :ok index among the reads containing the element: the first containing read F, unless a read invoked while
-  //     F was still open completed before it — only reads invoked before F's completion can (`fresh` keeps those elements apart until
-  //     the sweep has passed the latest such completion).
-  // The loads of 8 reads are issued together, and the next 8 before those are folded in (one dependent global load per read
-  // would bound the sweep; so would one exposed round trip per batch).
-  // (Round 6 split it again — forwards for `known`, BACKWARDS for last-present / last-absent, where the first read seen with the bit decides and
-  //  every element is written once instead of at every transition — on the guess that the transition loops were what a read cost: 0.53 -> 0.70 ms
-  //  at the headline shape, pass 2 8.6e5 -> 1.17e6 cycles per history.  A read costs what walking it costs — taking its rank, three readlanes,
-  //  the load, the masks: ~570 cycles per read and sweep with four wavefronts per SIMD — not what it changes.  tools/check_prof_report.py.)
+  // ---- pass 2: ONE sweep over the :ok reads in invocation order, 64 reads at a time, LANE r = READ r of the chunk ----------------------------
+  // Per element three reductions over the reads (§ header): last-present = the LAST read that has it, last-absent = the LAST read that lacks
+  // it while it exists, known = the smallest :ok index among the reads that have it.  Rounds 3-6 swept with lane w = word w of ONE read's
+  // bitmap at a time: a read cost ~140 issued instructions whatever it changed (its rank, three readlanes, the load, the masks, three bit
+  // loops), half the lanes idle (17 words on average).  Now a lane holds its OWN read's bitmap (16-byte loads at the read's own address, three
+  // in flight) and the wavefront walks the words 0 .. max words of the chunk; for word w
+  //   last-present: the highest lane with a bit decides ALL its bits at once (one 32-lane store, lane b = element 32w + b); what is left
+  //     (bits some lower lane has and that one has not: only at the frontier of the elements still spreading) takes the next-highest lane with
+  //     one of them, and so on.  Later chunks overwrite: the last chunk's last read wins.  last-absent likewise over ~word & existing
+  //     (nothing to do for words whose elements every read of the chunk holds);
+  //   known: the FIRST lane that has a not-yet-seen element gives its :ok index (lowest lane first, all its new bits at once) — right unless a
+  //     read invoked later completed earlier; such a read has an :ok index below the maximum of the reads before it, so every lane of which
+  //     that is true (`nm`: rare) takes the minimum over ALL its bits — which is always allowed, `known` being a minimum over containing reads.
+  // Element 32w + b is always written by lane b: no cross-lane ordering in LDS.
   {
-    u32 unk = 0xFFFFFFFFu, fresh = 0, fresh_until = 0 /* wave-uniform */, prev_w = 0, prev_a = 0, prev_inv = 0;
-    const u32 lo = lane * 32;
-    u32 rx = 0, ry = 0, rz = 0;   // {payload ref | words << 24, invoke index | elements existing at completion << 16, :ok index}
-    u64 todo = 0;
-    // the next (up to) 8 valid ranks of this chunk, earliest first: their bitmap words are requested
-    auto issue = [&](u32 (&wv)[8], u32 &nb) {
-      nb = 0;
-#pragma unroll
-      for (u32 t = 0; t < 8; t++) {
-        const bool have = todo != 0;
-        const u32 j = have ? (u32)__builtin_ctzll(todo) : 0u;
-        if (have) { todo &= todo - 1; nb = t + 1; }
-        const u32 ref = c_rdlane(rx, j);
-        const bool mine = have && lane < (ref >> 24);                 // (the other lanes load word 0 of the slab: no branch around the load)
-        const u32 got = pay[mine ? (ref & 0xFFFFFFu) + lane : 0u];
-        wv[t] = mine ? got : 0u;
-      }
-    };
-    // `tf` = the ranks the batch was issued for (todo as it was then).  Everything a read usually changes is straight-line; ONE
-    // wave-wide test guards the bit loops (an element seen for the first time, or leaving present / absent).  `fresh_until` is kept
-    // wave-uniform (the latest completion behind ANY fresh element): elements stay in `fresh` a little longer than they have to,
-    // which only repeats a minimum.
-    auto fold = [&](u64 tf, const u32 (&wv)[8], const u32 nb) {
-#pragma unroll
-      for (u32 t = 0; t < 8; t++) {
-        if (t >= nb) break;
-        const u32 j = (u32)__builtin_ctzll(tf); tf &= tf - 1;
-        const u32 iv = c_rdlane(ry, j), ok = c_rdlane(rz, j), inv = iv & 0xFFFFu, v_here = iv >> 16;
-        const u32 w = wv[t];
-        const int d = (int)v_here - (int)lo;
-        const u32 ex = d >= 32 ? 0xFFFFFFFFu : (d <= 0 ? 0u : ((1u << d) - 1));  // elements that exist at this read
-        const u32 a = ~w & ex;
-        if (inv > fresh_until) fresh = 0;                    // every read behind a fresh element has completed before this one began
-        const u32 first = w & unk, again = w & fresh;
-        unk &= ~w;
-        fresh |= first;
-        if (__ballot(first != 0)) fresh_until = max(fresh_until, ok);
-        u32 upd = first | again, lv = prev_w & ~w, lva = prev_a & ~a;
-        if (__ballot((upd | lv | lva) != 0)) {
-          while (upd) { const u32 e = lo + (u32)__builtin_ctz(upd); upd &= upd - 1; if (e < p.max_values && known[e] > ok) known[e] = (u16)ok; }
-          while (lv) { const u32 e = lo + (u32)__builtin_ctz(lv); lv &= lv - 1; if (e < p.max_values) lp_idx[e] = (u16)prev_inv; }
-          while (lva) { const u32 e = lo + (u32)__builtin_ctz(lva); lva &= lva - 1; if (e < p.max_values) la_idx[e] = (u16)prev_inv; }
-        }
-        prev_w = w; prev_a = a; prev_inv = inv;
-      }
-    };
+    const u32 sub = lane & 31u;
+    uint4 tiny = make_uint4(0, 0, 0, 0);   // a payload slab of less than four words, whole
+    if (p.max_pay < 4) { if (p.max_pay > 0) tiny.x = pay[0]; if (p.max_pay > 1) tiny.y = pay[1]; if (p.max_pay > 2) tiny.z = pay[2]; }
+    u32 unkv = 0xFFFFFFFFu;          // lane j: the elements of word j no read has contained yet
+    u32 ok_carry = 0;                // the largest :ok index of the chunks before
     auto chunk_mask = [&](u32 cb) -> u64 {
       if (cb >= n_ri) return 0ull;
       const u32 cn = min(64u, n_ri - cb);
@@ -251,27 +228,118 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
     if ((nmask >> lane) & 1) { const u32 *q = rec + (size_t)lane * 3; nx = q[0]; ny = q[1]; nz = q[2]; }
     for (u32 cb = 0; cb < n_ri; cb += 64) {
       const u64 vmask = nmask;
-      rx = nx; ry = ny; rz = nz;
+      const u32 rx = nx, ry = ny, rz = nz;   // {payload ref | words << 24, invoke index | elements existing at completion << 16, :ok index}; 0 for a rank without an :ok
       nmask = chunk_mask(cb + 64);
       nx = ny = nz = 0;
       if ((nmask >> lane) & 1) { const u32 *q = rec + (size_t)(cb + 64 + lane) * 3; nx = q[0]; ny = q[1]; nz = q[2]; }
       if (!vmask) continue;
-      todo = vmask;
-      u32 wA[8], nA, wB[8], nB;
-      u64 tA = todo, tB;
-      issue(wA, nA);
-      while (nA) {
-        tB = todo;
-        issue(wB, nB);
-        fold(tA, wA, nA);
-        if (!nB) break;
-        tA = todo;
-        issue(wA, nA);
-        fold(tB, wB, nB);
+      const u32 ref = rx & 0xFFFFFFu, nw = rx >> 24, inv = ry & 0xFFFFu, v_here = ry >> 16, ok = rz;
+      // four words of this lane's bitmap from word 4g on: ONE unconditional 16-byte load (a lane with nothing there reads the slab's first
+      // words and ignores them: no branch around the load, so the loads in flight stay countable).  A bitmap that ends in the slab's last
+      // three words — one instance in thousands — reads the slab's last four words and shifts.  (A slab of less than four words holds no bitmap
+      // worth the name: it is read once, before the sweep.)
+      auto ld = [&](u32 g) -> uint4 {
+        const u32 at = ref + 4 * g;
+        const bool in = 4 * g < nw;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (p.max_pay >= 4) {
+          const u32 last4 = p.max_pay - 4;
+          const ck_u32x4 q = *reinterpret_cast<const ck_u32x4 *>(pay + (in ? min(at, last4) : 0u));   // (16 bytes at a 4-byte boundary)
+          v = make_uint4(q.x, q.y, q.z, q.w);
+          if (__ballot(in && at > last4)) {
+            const u32 sh = in && at > last4 ? at - last4 : 0u;
+            if (sh == 1) v = make_uint4(v.y, v.z, v.w, 0); else if (sh == 2) v = make_uint4(v.z, v.w, 0, 0); else if (sh >= 3) v = make_uint4(sh == 3 ? v.w : 0u, 0, 0, 0);
+          }
+        } else if (in) {   // (no load here: a load on this path would make the loads in flight uncountable for the path that matters)
+          auto tw = [&](u32 i) { return i == 0 ? tiny.x : (i == 1 ? tiny.y : (i == 2 ? tiny.z : 0u)); };
+          v = make_uint4(tw(at), tw(at + 1), tw(at + 2), 0);
+        }
+        return v;
+      };
+      uint4 b0 = ld(0), b1 = ld(1), b2 = ld(2), b3 = ld(3);
+      const u32 maxw = c_wave_max(nw);
+      // lanes whose :ok index is below the largest of the reads before them: inclusive prefix maximum, then the lane below's
+      const u32 pm = c_wave_incl_max(ok);
+      u32 before = (u32)__shfl_up((int)pm, 1);
+      before = max(lane ? before : 0u, ok_carry);
+      const u64 nm_mask = __ballot(((vmask >> lane) & 1) && ok < before);
+      ok_carry = max(ok_carry, c_rdlane(pm, 63));
+      // one word of the 64 bitmaps.  What the loops decide for element 32w + b collects in lane b's registers; LDS is touched once per word and kind
+      auto word = [&](const u32 w, const u32 raw) {
+        const u32 W = w < nw ? raw : 0u;
+        const int d = (int)v_here - (int)(32 * w);
+        const u32 ex = d >= 32 ? 0xFFFFFFFFu : (d <= 0 ? 0u : ((1u << d) - 1));  // elements that exist at this read
+        const u32 A = ~W & ex;
+        const u32 e = 32 * w + sub;
+        const bool e_ok = lane < 32 && e < p.max_values;
+        u64 m = __ballot(W != 0);
+        const u64 holders = m;
+        if (m) {   // last-present
+          u32 rem = 0xFFFFFFFFu, got = 0;
+          do {
+            const u32 L = 63u - (u32)__builtin_clzll(m);
+            const u32 bits = c_rdlane(W, L) & rem, iv = c_rdlane(inv, L);
+            got = ((bits >> sub) & 1) ? iv : got;
+            rem &= ~bits;
+            m = __ballot((W & rem) != 0);
+          } while (m);
+          if (e_ok && !((rem >> sub) & 1)) lp_idx[e] = (u16)got;
+        }
+        m = __ballot(A != 0);
+        if (m) {   // last-absent
+          u32 rem = 0xFFFFFFFFu, got = 0;
+          do {
+            const u32 L = 63u - (u32)__builtin_clzll(m);
+            const u32 bits = c_rdlane(A, L) & rem, iv = c_rdlane(inv, L);
+            got = ((bits >> sub) & 1) ? iv : got;
+            rem &= ~bits;
+            m = __ballot((A & rem) != 0);
+          } while (m);
+          if (e_ok && !((rem >> sub) & 1)) la_idx[e] = (u16)got;
+        }
+        u32 kmin = NONE;
+        bool any = false;   // wave-uniform
+        u32 unk_w = c_rdlane(unkv, w);
+        if (unk_w) {   // known: the first containing read
+          m = __ballot((W & unk_w) != 0);
+          if (m) {
+            any = true;
+            do {
+              const u32 L = (u32)__builtin_ctzll(m);
+              const u32 bits = c_rdlane(W, L) & unk_w, okl = c_rdlane(ok, L);
+              kmin = ((bits >> sub) & 1) ? okl : kmin;   // (a bit leaves unk_w with its first read: set once)
+              unk_w &= ~bits;
+              m = __ballot((W & unk_w) != 0);
+            } while (m);
+            if (lane == w) unkv = unk_w;
+          }
+        }
+        m = nm_mask & holders;
+        if (m) {   // ... and the reads that overtook an earlier one
+          any = true;
+          do {
+            const u32 L = (u32)__builtin_ctzll(m); m &= m - 1;
+            const u32 bits = c_rdlane(W, L), okl = c_rdlane(ok, L);
+            kmin = ((bits >> sub) & 1) ? min(kmin, okl) : kmin;
+          } while (m);
+        }
+        if (any && e_ok && known[e] > kmin) known[e] = (u16)kmin;
+      };
+      auto group = [&](const u32 g, const uint4 &c) {
+        word(4 * g, c.x);
+        if (4 * g + 1 < maxw) word(4 * g + 1, c.y);
+        if (4 * g + 2 < maxw) word(4 * g + 2, c.z);
+        if (4 * g + 3 < maxw) word(4 * g + 3, c.w);
+      };
+      // four 16-byte loads per lane in flight; the buffers keep their registers (a rotation by moves would wait for the load just issued)
+      const u32 ng = (maxw + 3) >> 2;
+      for (u32 g = 0; g < ng; g += 4) {
+        group(g, b0); if (g + 1 >= ng) break; b0 = ld(g + 4);
+        group(g + 1, b1); if (g + 2 >= ng) break; b1 = ld(g + 5);
+        group(g + 2, b2); if (g + 3 >= ng) break; b2 = ld(g + 6);
+        group(g + 3, b3); b3 = ld(g + 7);
       }
     }
-    while (prev_w) { const u32 e = lo + (u32)__builtin_ctz(prev_w); prev_w &= prev_w - 1; if (e < p.max_values) lp_idx[e] = (u16)prev_inv; }
-    while (prev_a) { const u32 e = lo + (u32)__builtin_ctz(prev_a); prev_a &= prev_a - 1; if (e < p.max_values) la_idx[e] = (u16)prev_inv; }
   }
   __syncthreads();
 
