@@ -72,6 +72,23 @@ __device__ __forceinline__ u32 c_wave_incl_max(u32 v) {
   v = max(v, c_dpp<0x143, 0xC, false>(v));  // row_bcast:31 -> rows 2, 3
   return v;
 }
+// OR over the lanes BELOW this one
+__device__ __forceinline__ u32 c_wave_excl_or(u32 v) {
+  v = c_dpp<0x138, 0xF, true>(v);           // wave_shr:1 (lane 0 reads 0)
+  v |= c_dpp<0x111, 0xF, true>(v);
+  v |= c_dpp<0x112, 0xF, true>(v);
+  v |= c_dpp<0x114, 0xF, true>(v);
+  v |= c_dpp<0x118, 0xF, true>(v);
+  v |= c_dpp<0x142, 0xA, false>(v);
+  v |= c_dpp<0x143, 0xC, false>(v);
+  return v;
+}
+// orders this wavefront's LDS traffic across its lanes (LDS operations of one wavefront execute in order: the compiler must not move them)
+__device__ __forceinline__ void c_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __device__ __forceinline__ u32 c_wave_max(u32 v) { return c_rdlane(c_wave_incl_max(v), 63); }
 
 __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
@@ -216,6 +233,7 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
     uint4 tiny = make_uint4(0, 0, 0, 0);   // a payload slab of less than four words, whole
     if (p.max_pay < 4) { if (p.max_pay > 0) tiny.x = pay[0]; if (p.max_pay > 1) tiny.y = pay[1]; if (p.max_pay > 2) tiny.z = pay[2]; }
     u32 unkv = 0xFFFFFFFFu;          // lane j: the elements of word j no read has contained yet
+    u32 pend = NONE;                 // lane j: word j was SETTLED in the last chunk that had it (below) — last-present of its 32 elements, not yet written
     u32 ok_carry = 0;                // the largest :ok index of the chunks before
     auto chunk_mask = [&](u32 cb) -> u64 {
       if (cb >= n_ri) return 0ull;
@@ -264,14 +282,22 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
       before = max(lane ? before : 0u, ok_carry);
       const u64 nm_mask = __ballot(((vmask >> lane) & 1) && ok < before);
       ok_carry = max(ok_carry, c_rdlane(pm, 63));
+      const u32 inv_top = c_rdlane(inv, 63u - (u32)__builtin_clzll(vmask));
       // one word of the 64 bitmaps.  What the loops decide for element 32w + b collects in lane b's registers; LDS is touched once per word and kind
       auto word = [&](const u32 w, const u32 raw) {
         const u32 W = w < nw ? raw : 0u;
+        u32 unk_w = c_rdlane(unkv, w);
+        const u32 e = 32 * w + sub;
+        const bool e_ok = lane < 32 && e < p.max_values;
+        // A SETTLED word — every read of the chunk holds all 32 elements, all of them seen before, no overtaker among the reads: most words,
+        // the elements behind the frontier — changes one thing: last-present = the chunk's last read, for all 32.  That is noted in `pend`
+        // and written when a chunk finds the word unsettled, or at the end.
+        if (__ballot(W == 0xFFFFFFFFu) == vmask && unk_w == 0 && nm_mask == 0) { if (lane == w) pend = inv_top; return; }
+        const u32 pw = c_rdlane(pend, w);
+        if (pw != NONE) { if (e_ok) lp_idx[e] = (u16)pw; if (lane == w) pend = NONE; }
         const int d = (int)v_here - (int)(32 * w);
         const u32 ex = d >= 32 ? 0xFFFFFFFFu : (d <= 0 ? 0u : ((1u << d) - 1));  // elements that exist at this read
         const u32 A = ~W & ex;
-        const u32 e = 32 * w + sub;
-        const bool e_ok = lane < 32 && e < p.max_values;
         u64 m = __ballot(W != 0);
         const u64 holders = m;
         if (m) {   // last-present
@@ -297,23 +323,23 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
           } while (m);
           if (e_ok && !((rem >> sub) & 1)) la_idx[e] = (u16)got;
         }
-        u32 kmin = NONE;
-        bool any = false;   // wave-uniform
-        u32 unk_w = c_rdlane(unkv, w);
-        if (unk_w) {   // known: the first containing read
-          m = __ballot((W & unk_w) != 0);
-          if (m) {
-            any = true;
-            do {
-              const u32 L = (u32)__builtin_ctzll(m);
-              const u32 bits = c_rdlane(W, L) & unk_w, okl = c_rdlane(ok, L);
-              kmin = ((bits >> sub) & 1) ? okl : kmin;   // (a bit leaves unk_w with its first read: set once)
-              unk_w &= ~bits;
-              m = __ballot((W & unk_w) != 0);
-            } while (m);
+        if (unk_w) {   // known: the first read that holds a not-yet-seen element gives its :ok index.  Every lane takes the bits NO LOWER lane
+          const u32 nw_bits = W & unk_w;   // holds (a prefix OR across the lanes) and writes them itself: as many turns as ONE read has new elements
+          if (__ballot(nw_bits != 0)) {
+            u32 mine = nw_bits & ~c_wave_excl_or(nw_bits);
+            while (mine) {
+              const u32 x = 32 * w + (u32)__builtin_ctz(mine); mine &= mine - 1;
+              if (x < p.max_values && known[x] > ok) known[x] = (u16)ok;
+            }
+            c_lds_fence();   // (the elements of word w are lane b's again below)
+            u32 all = nw_bits;
+            all |= c_dpp<0xB1, 0xF, false>(all); all |= c_dpp<0x4E, 0xF, false>(all); all |= c_dpp<0x141, 0xF, false>(all); all |= c_dpp<0x140, 0xF, false>(all);
+            unk_w &= ~(c_rdlane(all, 0) | c_rdlane(all, 16) | c_rdlane(all, 32) | c_rdlane(all, 48));
             if (lane == w) unkv = unk_w;
           }
         }
+        u32 kmin = NONE;
+        bool any = false;   // wave-uniform
         m = nm_mask & holders;
         if (m) {   // ... and the reads that overtook an earlier one
           any = true;
@@ -339,6 +365,10 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
         group(g + 2, b2); if (g + 3 >= ng) break; b2 = ld(g + 6);
         group(g + 3, b3); b3 = ld(g + 7);
       }
+    }
+    for (u64 m = __ballot(pend != NONE); m; m &= m - 1) {   // the words that were settled to the end
+      const u32 w = (u32)__builtin_ctzll(m), pw = c_rdlane(pend, w), e = 32 * w + sub;
+      if (lane < 32 && e < p.max_values) lp_idx[e] = (u16)pw;
     }
   }
   __syncthreads();
