@@ -125,13 +125,12 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
   u32 round_key = 0x3FFFFFFu;    // decreases with every pairing round: a later round's ds_min beats whatever an earlier one left
 
   // ---- pass 1 ----
-  uint4 r_next = make_uint4(0, 0, 0, 0);
-  if (lane < n_rows) r_next = rows[lane];
-  for (u32 base = 0; base < n_rows; base += 64) {
+  // Four chunks of rows (4 KiB) are in flight: with one, a chunk's 150 instructions waited out an HBM round trip each time (round 6: pass 1 took
+  // 1.7e5 cycles per history, 2700 per chunk).  The buffers keep their registers — a rotation by moves would wait for the load just issued —
+  // and the loads are unconditional (past the end: the last row again; every use of a row is behind `lane < cnt`).
+  auto ldrow = [&](u32 b) -> uint4 { return rows[min(b + lane, n_rows ? n_rows - 1 : 0u)]; };
+  auto rowchunk = [&](const u32 base, const uint4 r) {
     const u32 cnt = min(64u, n_rows - base);
-    const uint4 r = r_next;
-    r_next = make_uint4(0, 0, 0, 0);
-    if (base + 64 + lane < n_rows) r_next = rows[base + 64 + lane];
     const u32 my_type = r.z & 3, my_f = (r.z >> 2) & 31, my_proc = r.z >> 12, idx = base + lane;
     const bool live = lane < cnt && my_proc != MSIM_PROCESS_NEMESIS;  // (r/filter (comp number? :process))
     const bool add_like = my_f == MSIM_F_ADD || my_f == MSIM_F_BROADCAST;
@@ -145,15 +144,6 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
     const u64 ri = __ballot(is_r && my_type == MSIM_T_INVOKE);
     const u32 rank = n_ri + (u32)__popcll(ri & lt);                                // invocation order of the reads
     n_ri += (u32)__popcll(ri);
-    // worker thread = process mod C ([upstream] jepsen's interpreter): one float multiply and a correction instead of a division
-    u32 tt = 0;
-    if (is_r) {
-      const u32 qd = (u32)((float)my_proc * p.rcp_C);
-      int rem = (int)(my_proc - qd * C);
-      if (rem < 0) rem += (int)C;
-      if (rem >= (int)C) rem -= (int)C;
-      tt = (u32)rem;
-    }
     // what a read :ok leaves behind: its record at the rank of its invocation `sv` = row | rank << 16
     auto record = [&](u32 sv) {
       const u32 rk = sv >> 16;
@@ -165,23 +155,33 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
     };
     // A completion that directly follows its invocation (all but a few: the rows of one operation are only separated when another
     // worker thread's row falls between them) is settled from the lane below; the pair never touches the thread's table entry.
-    const u32 mine = (is_r && my_type == MSIM_T_INVOKE ? 0x80000000u : 0u) | (tt << 16) | (rank & 0xFFFFu);
-    const u32 below = (u32)__shfl_up((int)mine, 1);
-    const u32 below_v = setfull ? 0u : (u32)__shfl_up((int)r.w, 1);
-    const bool adj = is_r && my_type != MSIM_T_INVOKE && lane > 0 && (below >> 31) && ((below >> 16) & 0x7FFFu) == tt;
+    // (Same PROCESS, which is the same worker thread for the two rows of one operation; the invocation's rank is this lane's count of the
+    //  invocations below it, less one.  Rows reach the lane above by DPP: the packed word, and for echo the value.)
+    const u32 below_z = c_dpp<0x138, 0xF, true>(r.z);   // wave_shr:1
+    const u32 below_v = setfull ? 0u : c_dpp<0x138, 0xF, true>(r.w);
+    const bool adj = is_r && my_type != MSIM_T_INVOKE && lane > 0 && (below_z & 3) == MSIM_T_INVOKE && ((below_z ^ r.z) & 0xFFFFF07Cu) == 0;
     const u64 adj_m = __ballot(adj);
     if (adj) {
-      if (setfull) { if (my_type == MSIM_T_OK) record((idx - 1) | (below << 16)); }
+      if (setfull) { if (my_type == MSIM_T_OK) record((idx - 1) | ((rank - 1) << 16)); }
       // echo.clj:44-63: every :invoke whose completion is not an :ok carrying the same :echo is an error — a :fail, an
       // :info (its :value is the request string, (:echo "...") = nil) and an invocation that never completes included
       else if (my_type != MSIM_T_OK || below_v != r.w) errors++;
     }
     bool pend = is_r && !adj && !((adj_m >> 1 >> lane) & 1);
     u64 pm = __ballot(pend);
+    // worker thread = process mod C ([upstream] jepsen's interpreter): one float multiply and a correction instead of a division
+    u32 tt = 0;
+    if (pm && pend) {
+      const u32 qd = (u32)((float)my_proc * p.rcp_C);
+      int rem = (int)(my_proc - qd * C);
+      if (rem < 0) rem += (int)C;
+      if (rem >= (int)C) rem -= (int)C;
+      tt = (u32)rem;
+    }
     while (pm) {   // rounds: the earliest pending read row of every worker thread acts on the thread's table entry
       const u32 key = (round_key << 6) | lane;
       if (pend) atomicMin(&first[tt], key);
-      __syncthreads();
+      c_lds_fence();   // (one wavefront: LDS is in order; __syncthreads would also wait for the rows in flight)
       if (pend && first[tt] == key) {
         pend = false;
         const u32 s = slot[tt];
@@ -195,11 +195,23 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
         }
       }
       round_key--;
-      __syncthreads();
+      c_lds_fence();   // (one wavefront: LDS is in order; __syncthreads would also wait for the rows in flight)
       pm = __ballot(pend);
 #ifdef CK_PROF
       ck_rounds++;
 #endif
+    }
+  };
+  if (n_rows) {
+    uint4 q0 = ldrow(0), q1 = ldrow(64), q2 = ldrow(128), q3 = ldrow(192);
+    for (u32 base = 0; base < n_rows; base += 256) {
+      rowchunk(base, q0); q0 = ldrow(base + 256);
+      if (base + 64 >= n_rows) break;
+      rowchunk(base + 64, q1); q1 = ldrow(base + 320);
+      if (base + 128 >= n_rows) break;
+      rowchunk(base + 128, q2); q2 = ldrow(base + 384);
+      if (base + 192 >= n_rows) break;
+      rowchunk(base + 192, q3); q3 = ldrow(base + 448);
     }
   }
   if (!setfull) { for (u32 i = lane; i < C; i += 64) errors += slot[i] != NONE32 ? 1u : 0u; }   // invocations left without a completion
