@@ -21,11 +21,12 @@
 //           a chunk are taken in rounds, in each round the EARLIEST pending row of every worker thread (ds_min over the thread's
 //           slot) acts on the thread's table entry in LDS — an invocation leaves {row, rank}, a completion takes it — so a chunk costs
 //           as many rounds as its busiest thread has read rows in it (2-3), not one step per row.  A read :ok RECORDS itself at the
-//           rank of its invocation {payload ref, invoke index, elements existing at completion, :ok index} (12 B, HBM scratch).
-//   pass 2  ONE sweep over the recorded reads in invocation order, lane w = word w of the bitmaps: every word is loaded once
-//           (round 2: twice) and gives known (first containing read, corrected for reads that overtook it), last-present and
-//           last-absent (written when an element leaves the state) — see the comment at the sweep.  Two batches of 8 bitmap loads
-//           are kept in flight.
+//           rank of its invocation {payload ref, invoke index, elements existing at completion, :ok index} (12 B, HBM scratch).  Four chunks
+//           of rows are in flight.
+//   pass 2  ONE sweep over the recorded reads in invocation order, 64 reads at a time, lane r = read r of the chunk (round 6; before: lane w =
+//           word w of one read's bitmap at a time).  Every lane loads its own read's bitmap 16 bytes at a time; per word the highest / lowest
+//           lane with a bit decides all its bits at once, words every read of the chunk holds completely are only noted — see the comment
+//           at the sweep.
 // Per-element state: three u16 row indices in LDS (8.4 KB for 1408 elements keeps 4096 histories resident).
 #include <hip/hip_runtime.h>
 
