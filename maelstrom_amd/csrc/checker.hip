@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
         return v;
       };
       uint4 b0 = ld(0), b1 = ld(1), b2 = ld(2), b3 = ld(3);
-      const u32 maxw = c_wave_max(nw);
+      const u32 maxw = min(64u, c_wave_max(max(nw, (v_here + 31) >> 5)));   // (a bitmap may be shorter than the elements that exist: they are absent)
       // lanes whose :ok index is below the largest of the reads before them: inclusive prefix maximum, then the lane below's
       const u32 pm = c_wave_incl_max(ok);
       u32 before = (u32)__shfl_up((int)pm, 1);

@@ -101,6 +101,7 @@ def test_device_checkers_on_the_emulator_equal_the_host_checkers(emu_lib):
     env = dict(os.environ, MSIM_LIB=emu_lib, HIPEMU_DIVERGENT="1")
     for args in ([os.path.join(ROOT, "tests", "test_checker_gpu.py"), "-k", "unique"], [os.path.join(ROOT, "tests", "test_rw_check_gpu.py")],
                  [os.path.join(ROOT, "tests", "test_lin_check_gpu.py")],   # the linearizability search beyond 64 configurations: LDS pools, the host for the rest
-                 [os.path.join(ROOT, "tests", "test_checker_reference_vectors.py")]):   # set-full / linearizability against the runs the reference docs print
+                 [os.path.join(ROOT, "tests", "test_checker_reference_vectors.py")],   # set-full / linearizability against the runs the reference docs print
+                 [os.path.join(ROOT, "tests", "test_set_full_synthetic_gpu.py")]):   # check_kernel on synthetic histories: overtaking reads, failures, > 1024 elements, the slab's end
         r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
         assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
