@@ -314,6 +314,16 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     rows_tot, words_tot = int(acc[3]), int(acc[4])
+    # the workload checker alone on the chip (outside the timed region): five launches over the batch the first context still holds —
+    # check_kernel / lin_check_kernel is the one kernel of a step that IS bandwidth work (it reads every history once), so its own
+    # roofline fraction is reported beside the simulation kernel's (roofline.checker)
+    chk_solo = []
+    try:
+        for _ in range(5):
+            engs[0].check()
+            chk_solo.append(engs[0].kernel_ms()[1])
+    except Exception:
+        chk_solo = []
     agg = acc[:3].clone()
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist:
@@ -393,6 +403,12 @@ def main():
                          "launches_in_flight": in_flight, "achieved_per_launch": b_alg / (sim_avg * 1e-3) / 1e9,
                          "how": "achieved = launches_in_flight x algorithmic_bytes_per_launch / the kernel's average launch duration (kernel_ms.sim); launches_in_flight = summed launch durations / timed region"},
         }
+        if chk_solo:
+            cs = sorted(chk_solo)[len(chk_solo) // 2]
+            out["roofline"]["checker"] = {"kernel": "check_kernel (csrc/checker.hip: set-full)" if args.config == "cfg2" else "lin_check_kernel (csrc/lin_check_dev.hip)",
+                                          "bound": "hbm", "ms": cs, "achieved": b_alg / (cs * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                          "frac": b_alg / (cs * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                          "how": "the same algorithmic bytes (the checker reads every history row and payload word once) / the median of five launches alone on the chip, after the timed region"}
         # HBM bytes per launch and the instruction-issue picture from the PMC passes of the committed profile (counters cannot be
         # read inside this process): FETCH_SIZE x 2 + WRITE_SIZE, KiB -> bytes; SQ_* per launch (tools/profile_headline.sh ->
         # tools/rocpd_summary.py --counters).  null if the profile is absent or was taken with a different batch size.

@@ -32,6 +32,8 @@ def test_one_json_line_with_the_contract_fields():
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 1e8
     assert d["histories_valid"] == d["histories_checked"] == 3 * 1024 and d["instances_flagged"] == 0
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+    ck = d["roofline"]["checker"]   # the set-full checker alone on the chip: the step's one bandwidth kernel (a third of the HBM peak at the headline's 4096 histories; this run has 1024)
+    assert ck["bound"] == "hbm" and 0.02 < ck["frac"] < 1 and abs(ck["achieved"] / ck["peak"] - ck["frac"]) < 1e-9, ck
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
     assert d["value_incl_fetch"] and d["history_gather"]["bytes"] > 0
     assert "attempts" not in d
