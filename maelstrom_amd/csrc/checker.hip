@@ -246,6 +246,7 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
     uint4 tiny = make_uint4(0, 0, 0, 0);   // a payload slab of less than four words, whole
     if (p.max_pay < 4) { if (p.max_pay > 0) tiny.x = pay[0]; if (p.max_pay > 1) tiny.y = pay[1]; if (p.max_pay > 2) tiny.z = pay[2]; }
     u32 unkv = 0xFFFFFFFFu;          // lane j: the elements of word j no read has contained yet
+    u64 unk_any = ~0ull;             // wave-uniform: the lanes of unkv that are not zero
     u32 pend = NONE;                 // lane j: word j was SETTLED in the last chunk that had it (below) — last-present of its 32 elements, not yet written
     u32 ok_carry = 0;                // the largest :ok index of the chunks before
     auto chunk_mask = [&](u32 cb) -> u64 {
@@ -276,7 +277,7 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
         if (p.max_pay >= 4) {
           const u32 last4 = p.max_pay - 4;
           const ck_u32x4 q = *reinterpret_cast<const ck_u32x4 *>(pay + (in ? min(at, last4) : 0u));   // (16 bytes at a 4-byte boundary)
-          v = make_uint4(q.x, q.y, q.z, q.w);
+          v = in ? make_uint4(q.x, q.y, q.z, q.w) : make_uint4(0, 0, 0, 0);   // (a lane without a word in this group — a rank without a record among them — holds zeros)
           if (__ballot(in && at > last4)) {
             const u32 sh = in && at > last4 ? at - last4 : 0u;
             if (sh == 1) v = make_uint4(v.y, v.z, v.w, 0); else if (sh == 2) v = make_uint4(v.z, v.w, 0, 0); else if (sh >= 3) v = make_uint4(sh == 3 ? v.w : 0u, 0, 0, 0);
@@ -296,16 +297,18 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
       const u64 nm_mask = __ballot(((vmask >> lane) & 1) && ok < before);
       ok_carry = max(ok_carry, c_rdlane(pm, 63));
       const u32 inv_top = c_rdlane(inv, 63u - (u32)__builtin_clzll(vmask));
+      const u32 minw = ~c_wave_max(((vmask >> lane) & 1) ? ~nw : 0u);   // every read of the chunk has at least this many words
       // one word of the 64 bitmaps.  What the loops decide for element 32w + b collects in lane b's registers; LDS is touched once per word and kind
       auto word = [&](const u32 w, const u32 raw) {
-        const u32 W = w < nw ? raw : 0u;
-        u32 unk_w = c_rdlane(unkv, w);
-        const u32 e = 32 * w + sub;
-        const bool e_ok = lane < 32 && e < p.max_values;
+        u32 W = raw;
+        if (w >= minw) W = w < nw ? raw : 0u;   // (wave-uniform test: below minw every read of the chunk has the word, and a lane without a read holds zeros)
+        u32 unk_w = (unk_any >> w) & 1 ? c_rdlane(unkv, w) : 0u;
         // A SETTLED word — every read of the chunk holds all 32 elements, all of them seen before, no overtaker among the reads: most words,
         // the elements behind the frontier — changes one thing: last-present = the chunk's last read, for all 32.  That is noted in `pend`
         // and written when a chunk finds the word unsettled, or at the end.
         if (__ballot(W == 0xFFFFFFFFu) == vmask && unk_w == 0 && nm_mask == 0) { if (lane == w) pend = inv_top; return; }
+        const u32 e = 32 * w + sub;
+        const bool e_ok = lane < 32 && e < p.max_values;
         const u32 pw = c_rdlane(pend, w);
         if (pw != NONE) { if (e_ok) lp_idx[e] = (u16)pw; if (lane == w) pend = NONE; }
         const int d = (int)v_here - (int)(32 * w);
@@ -339,16 +342,16 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
         if (unk_w) {   // known: the first read that holds a not-yet-seen element gives its :ok index.  Every lane takes the bits NO LOWER lane
           const u32 nw_bits = W & unk_w;   // holds (a prefix OR across the lanes) and writes them itself: as many turns as ONE read has new elements
           if (__ballot(nw_bits != 0)) {
-            u32 mine = nw_bits & ~c_wave_excl_or(nw_bits);
+            const u32 below = c_wave_excl_or(nw_bits);
+            u32 mine = nw_bits & ~below;
             while (mine) {
               const u32 x = 32 * w + (u32)__builtin_ctz(mine); mine &= mine - 1;
               if (x < p.max_values && known[x] > ok) known[x] = (u16)ok;
             }
             c_lds_fence();   // (the elements of word w are lane b's again below)
-            u32 all = nw_bits;
-            all |= c_dpp<0xB1, 0xF, false>(all); all |= c_dpp<0x4E, 0xF, false>(all); all |= c_dpp<0x141, 0xF, false>(all); all |= c_dpp<0x140, 0xF, false>(all);
-            unk_w &= ~(c_rdlane(all, 0) | c_rdlane(all, 16) | c_rdlane(all, 32) | c_rdlane(all, 48));
+            unk_w &= ~(c_rdlane(below, 63) | c_rdlane(nw_bits, 63));   // everything some lane holds
             if (lane == w) unkv = unk_w;
+            unk_any = __ballot(unkv != 0);
           }
         }
         u32 kmin = NONE;
@@ -365,6 +368,11 @@ __global__ void __launch_bounds__(64) check_kernel(const CParams p) {
         if (any && e_ok && known[e] > kmin) known[e] = (u16)kmin;
       };
       auto group = [&](const u32 g, const uint4 &c) {
+        // four settled words at once (most groups: everything well behind the frontier)
+        if (4 * g + 3 < minw && nm_mask == 0 && ((unk_any >> (4 * g)) & 0xFu) == 0 && __ballot((c.x & c.y & c.z & c.w) == 0xFFFFFFFFu) == vmask) {
+          if ((lane >> 2) == g) pend = inv_top;
+          return;
+        }
         word(4 * g, c.x);
         if (4 * g + 1 < maxw) word(4 * g + 1, c.y);
         if (4 * g + 2 < maxw) word(4 * g + 2, c.z);
