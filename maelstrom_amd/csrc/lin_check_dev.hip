@@ -54,6 +54,20 @@ struct LParams {
 };
 
 __device__ __forceinline__ u32 rl(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ __forceinline__ u32 l_bperm(u32 v, u32 l) { return (u32)__builtin_amdgcn_ds_bpermute((int)(l << 2), (int)v); }
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ u32 l_dpp(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, BOUND); }
+// maximum over the lanes BELOW this one (0 for lane 0), by DPP
+__device__ __forceinline__ u32 l_excl_max(u32 v) {
+  v = l_dpp<0x138, 0xF, true>(v);            // wave_shr:1
+  v = max(v, l_dpp<0x111, 0xF, true>(v));    // row_shr:1 .. 8, then the rows before
+  v = max(v, l_dpp<0x112, 0xF, true>(v));
+  v = max(v, l_dpp<0x114, 0xF, true>(v));
+  v = max(v, l_dpp<0x118, 0xF, true>(v));
+  v = max(v, l_dpp<0x142, 0xA, false>(v));
+  v = max(v, l_dpp<0x143, 0xC, false>(v));
+  return v;
+}
 __device__ __forceinline__ u32 l_wave_sum(u32 v) {
   for (int o = 32; o; o >>= 1) v += (u32)__shfl_xor((int)v, o);
   return v;
@@ -88,6 +102,25 @@ __device__ bool pair_rows(const uint4 *r, u32 n, u32 *key_lo, u32 *key_hi, const
     const bool reg = live && (f == MSIM_F_READ || f == MSIM_F_WRITE || f == MSIM_F_CAS);
     if (reg) { atomicMin(&key_lo[row.w & 0xFFu], idx); atomicMax(&key_hi[row.w & 0xFFu], idx); }
     u64 m = __ballot(reg);
+    // While no call is open, the rows of a chunk that come as whole pairs — an invocation directly followed (among the register rows) by
+    // the completion of the same process on the same key: nearly all of them, the clients of a key seldom overlap — are paired by every
+    // lane at once (round 6; before, every row walked the loop below: a readlane, two ballots, a table lane).  From the first row that
+    // does not fit on, the loop below takes over.
+    if (m && !__ballot(o_used)) {
+      const u64 below = m & ((1ull << lane) - 1ull);
+      const u32 rank = (u32)__popcll(below);
+      const u32 pl = below ? 63u - (u32)__builtin_clzll(below) : 0u;
+      const u32 pz = l_bperm(row.z, pl), pw = l_bperm(row.w, pl);
+      const bool fit = (rank & 1u) ? (type != MSIM_T_INVOKE && (pz & 3u) == MSIM_T_INVOKE && (pz >> 12) == proc && (pw & 0xFFu) == (row.w & 0xFFu)) : type == MSIM_T_INVOKE;
+      const u64 viol = __ballot(reg && !fit);
+      const u32 nclean = (u32)__popcll(viol ? m & ((1ull << (u32)__builtin_ctzll(viol)) - 1ull) : m) & ~1u;   // whole pairs before the first row that does not fit
+      if (reg && (rank & 1u) && rank < nclean) {
+        const u32 irow = base + pl;
+        outcome.val[irow] = (unsigned short)(row.w >> 8);
+        atomicOr(&outcome.state[irow >> 4], type << ((irow & 15u) * 2u));
+      }
+      m &= ~__ballot(reg && rank < nclean);
+    }
     while (m) {
       const u32 j = (u32)__builtin_ctzll(m); m &= m - 1;
       const u32 z = rl(row.z, j), w = rl(row.w, j);
@@ -320,6 +353,7 @@ __device__ int pool_close_grow(Pool &P, u32 &n_out, const Grow &g) {
 template <class Acquire>
 __device__ int search_key(const uint4 *r, u32 n, u32 k, u32 lo, u32 hi, const Outcome outcome, u32 lane, Pool &P, Acquire acquire, const Grow &grow) {
   RegSet S; S.c_lin = 0; S.c_val = 0xFFu; S.alive = 1ull;
+  const bool prof = P.ctr[8] != 0;   // (developer trace: ctr[9..13] = register closures, their time, pool closures, their time, entries they admitted)
   bool in_pool = false;                               // the configurations are in the pool (more than 64 survived the last call)
   u64 pending = 0, info_bits = 0;
   u32 s_proc = 0, s_op = 0; bool s_ok = false; u64 s_tw = 0;
@@ -330,7 +364,43 @@ __device__ int search_key(const uint4 *r, u32 n, u32 k, u32 lo, u32 hi, const Ou
     const u32 f0 = (row.z >> 2) & 31u;
     const bool reg = idx < n && (row.z >> 12) != MSIM_PROCESS_NEMESIS && (f0 == MSIM_F_READ || f0 == MSIM_F_WRITE || f0 == MSIM_F_CAS) && (row.w & 0xFFu) == k;
     u64 m = __ballot(reg);
+    bool fast_ok = true;
     while (m) {
+      // ONE configuration, no call open (none that never returns either): the rows that come as whole pairs — an invocation directly followed
+      // by its own :ok / :fail — have exactly one linearization, their order.  Every lane checks its own pair against the value the nearest
+      // earlier write / cas of the run leaves (a prefix maximum over the lanes) and the run's last one is the register afterwards (round 6;
+      // before, every row of such a run went through the loop below: 4000 cycles a row, and such runs are most of a healthy history).  A
+      // pair that does not check leaves everything to the search below, which then finds the key not linearizable.
+      if (fast_ok && pending == 0 && !in_pool && S.alive && !(S.alive & (S.alive - 1ull))) {
+        fast_ok = false;
+        const u32 a = (u32)__builtin_ctzll(S.alive), cur = rl(S.c_val, a);
+        const u64 below = m & ((1ull << lane) - 1ull);
+        const u32 rank = (u32)__popcll(below);
+        const u32 pl = below ? 63u - (u32)__builtin_clzll(below) : 0u;
+        const u32 pz = l_bperm(row.z, pl);
+        const u32 type = row.z & 3u, proc = row.z >> 12;
+        const bool mine_row = ((m >> lane) & 1ull) != 0;
+        const bool fit = (rank & 1u) ? ((type == MSIM_T_OK || type == MSIM_T_FAIL) && (pz & 3u) == MSIM_T_INVOKE && (pz >> 12) == proc && ((pz >> 2) & 31u) == f0) : type == MSIM_T_INVOKE;
+        const u64 viol = __ballot(mine_row && !fit);
+        const u32 nclean = (u32)__popcll(viol ? m & ((1ull << (u32)__builtin_ctzll(viol)) - 1ull) : m) & ~1u;
+        if (nclean) {
+          const bool okc = mine_row && (rank & 1u) && rank < nclean && type == MSIM_T_OK;    // the completion of an :ok pair (a :fail never happened)
+          const u32 v1 = (row.w >> 8) & 0xFFu, v2 = (row.w >> 16) & 0xFFu;                    // (an :ok carries the values: search below, `vv`)
+          const bool setter = okc && (f0 == MSIM_F_WRITE || f0 == MSIM_F_CAS);
+          const u32 sval = f0 == MSIM_F_WRITE ? v1 : v2;
+          const u32 ps = l_excl_max(setter ? lane + 1u : 0u);
+          const u32 got = l_bperm(sval, ps ? ps - 1u : 0u);
+          const u32 before = ps ? got : cur;
+          const bool bad = okc && f0 != MSIM_F_WRITE && before != v1;                         // a read sees the value, a cas finds it
+          if (!__ballot(bad)) {
+            const u64 sm = __ballot(setter);
+            if (sm) { const u32 nv = rl(sval, 63u - (u32)__builtin_clzll(sm)); if (lane == a) S.c_val = nv; }
+            m &= ~__ballot(mine_row && rank < nclean);
+          }
+        }
+        continue;
+      }
+      fast_ok = true;
       const u32 j = (u32)__builtin_ctzll(m); m &= m - 1;
       const u32 z = rl(row.z, j), w = rl(row.w, j);
       const u32 jt = z & 3u, jf = (z >> 2) & 31u, jp = z >> 12;
@@ -363,7 +433,6 @@ __device__ int search_key(const uint4 *r, u32 n, u32 k, u32 lo, u32 hi, const Ou
       const u64 bit = 1ull << s;
       int st = KEY_TOO_WIDE;
       u64 ov_lin = 0; u32 ov_val = 0;
-      const bool prof = P.ctr[8] != 0;   // (developer trace: ctr[9..13] = register closures, their time, pool closures, their time, entries they admitted)
       const u64 tq0 = prof ? wall_clock64() : 0;
       if (!in_pool) st = close_regs(S, pending, info_bits, s_op, s_tw, bit, lane, ov_lin, ov_val);
       if (prof && lane == 0) { P.ctr[9]++; P.ctr[10] += (u32)(wall_clock64() - tq0); }

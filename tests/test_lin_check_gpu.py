@@ -76,3 +76,77 @@ def test_changed_reads_agree_with_the_independent_search(lib):
     for rows, (_, pay), d in zip(hs, good, dev):
         ref = L.check(E.decode_history(rows, pay, 5, A.WL_LIN_KV))
         assert int(d["attempt_count"]) == len(ref) and int(d["error_count"]) == sum(1 for ok in ref.values() if not ok)
+
+
+def _synthetic(seed, n_ops, keys, workers, p_overlap, p_wrong, p_fail, p_info, odd=0.0):
+    """A lin-kv history built by hand: mostly operations that complete before the next begins (the runs the device's pair paths of
+    round 6 take in one step: pair_rows / search_key in csrc/lin_check_dev.hip), with — at the given rates — operations that overlap,
+    results no register ever held, :fail and :info completions, and (`odd`) rows no client produces: a completion without an invocation,
+    a process that invokes twice."""
+    import random
+    rnd = random.Random(seed)
+    ops, open_ops = [], []     # open: (process, key, f, v1, v2)
+    reg = {}
+    t = 0
+    free = list(range(workers))
+    done = 0
+    while done < n_ops or open_ops:
+        t += rnd.randrange(1, 2_000_000)
+        start = done < n_ops and free and (not open_ops or rnd.random() < p_overlap)
+        if start:
+            p = free.pop(rnd.randrange(len(free)))
+            k = rnd.choice(keys)
+            f = rnd.choice([":read", ":write", ":cas"])
+            v1, v2 = rnd.randrange(5), rnd.randrange(5)
+            val = [k, None] if f == ":read" else ([k, v1] if f == ":write" else [k, [v1, v2]])
+            ops.append({"type": ":invoke", "f": f, "process": p, "value": val, "time": t})
+            open_ops.append((p, k, f, v1, v2)); done += 1
+            if rnd.random() < odd:   # the same process again, before its completion
+                ops.append({"type": ":invoke", "f": f, "process": p, "value": val, "time": t + 1})
+            continue
+        if not open_ops:
+            continue
+        p, k, f, v1, v2 = open_ops.pop(rnd.randrange(len(open_ops)))
+        x = rnd.random()
+        cur = reg.get(k)
+        if x < p_fail or (f == ":cas" and cur != v1 and rnd.random() >= p_wrong):
+            typ = ":fail"
+        elif x < p_fail + p_info:
+            typ = ":info"
+        else:
+            typ = ":ok"
+        if typ == ":info" and f != ":read" and rnd.random() < 0.5:   # an indeterminate write / cas may have happened
+            if f == ":write": reg[k] = v1
+            elif cur == v1: reg[k] = v2
+        if typ == ":ok":
+            if f == ":write": reg[k] = v1
+            elif f == ":cas": reg[k] = v2
+            else:
+                v1 = cur if rnd.random() >= p_wrong else rnd.randrange(5)
+        val = [k, v1] if f != ":cas" else [k, [v1, v2]]
+        ops.append({"type": typ, "f": f, "process": p, "value": val, "time": t})
+        if rnd.random() < odd:   # a completion nobody invoked
+            ops.append({"type": ":ok", "f": ":read", "process": 90 + rnd.randrange(5), "value": [k, rnd.randrange(5)], "time": t + 1})
+        free.append(p)
+    return ops
+
+
+def test_synthetic_histories_device_equals_host(lib):
+    """Sequential runs (the device's pair paths), overlaps, wrong results, :fail / :info, several keys interleaved, rows no client produces:
+    field by field what the host search reports."""
+    import random
+    rnd = random.Random(77)
+    hs = []
+    for i in range(60):
+        hs.append(_synthetic(1000 + i, n_ops=rnd.randrange(20, 400), keys=list(range(rnd.choice([1, 1, 2, 5]))), workers=rnd.choice([1, 2, 4, 10]),
+                             p_overlap=rnd.choice([0.0, 0.05, 0.3]), p_wrong=rnd.choice([0.0, 0.0, 0.01, 0.1]), p_fail=rnd.choice([0.0, 0.1]),
+                             p_info=rnd.choice([0.0, 0.0, 0.02]), odd=rnd.choice([0.0, 0.0, 0.02])))
+    rows = [E.encode_lin_kv_history(h) for h in hs]
+    dev = E.check_lin_kv_batch(rows)
+    verdicts = set()
+    for i, r in enumerate(rows):
+        h = _host(r)
+        for f in FIELDS:
+            assert int(dev[i][f]) == int(getattr(h, f)), (i, f, int(dev[i][f]), int(getattr(h, f)))
+        verdicts.add(int(dev[i]["valid"]))
+    assert {0, 1} <= verdicts
