@@ -4,7 +4,7 @@
 // rows are streamed once (1 KiB per load), every :ok id goes into an open-addressing table in HBM workspace (compare-and-swap on
 // the key word, an atomic count beside it), and the duplicated values are the table slots counted twice or more.  Complete: no
 // host pass behind it.  Histories whose ids fit a table in LDS (up to 19660 acknowledged ids: every bench shape) take
-// unique_check_lds_kernel instead — a workgroup of 256 threads per history, 32768 id slots and a "seen again" bitmap in 132 KiB of LDS:
+// unique_check_lds_kernel instead — a workgroup of 1024 threads (round 6; 256 before) per history, 32768 id slots and a "seen again" bitmap in 132 KiB of LDS:
 // the HBM tables cost 256 KiB of initialisation and scattered compare-and-swaps per history (25 ms per 16384 histories of the demo shape).
 #include <hip/hip_runtime.h>
 
@@ -77,10 +77,13 @@ __global__ void __launch_bounds__(64) unique_check_kernel(const UParams p) {
   }
 }
 
+#ifndef UNIQ_WG   // threads per history: the table's 132 KiB leave a CU one workgroup, so the workgroup is what hides the rows' way from HBM (round 6: 256 -> 1024, four wavefronts per SIMD)
+#define UNIQ_WG 1024
+#endif
 constexpr u32 LDS_SLOTS = 32768u;   // ids a workgroup's table holds (power of two); + LDS_SLOTS / 32 words of "seen again" bits
 
 // the same check with the table in LDS: one workgroup per history
-__global__ void __launch_bounds__(256) unique_check_lds_kernel(const UParams p) {
+__global__ void __launch_bounds__(UNIQ_WG) unique_check_lds_kernel(const UParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32 *const tab = reinterpret_cast<u32 *>(smem);            // [LDS_SLOTS] id (EMPTY: free)
   u32 *const again = tab + LDS_SLOTS;                        // [LDS_SLOTS / 32] the slot's id was acknowledged more than once
@@ -88,14 +91,14 @@ __global__ void __launch_bounds__(256) unique_check_lds_kernel(const UParams p) 
   const u32 tid = threadIdx.x, hist = p.first + blockIdx.x;
   const uint4 *const r = reinterpret_cast<const uint4 *>(p.rows) + (u64)hist * p.max_rows;
   const u32 n = p.meta[hist].n_rows, flags = p.meta[hist].flags;
-  for (u32 i = tid; i < LDS_SLOTS; i += 256) tab[i] = EMPTY;
-  for (u32 i = tid; i < LDS_SLOTS / 32 + 16; i += 256) again[i] = 0;
+  for (u32 i = tid; i < LDS_SLOTS; i += UNIQ_WG) tab[i] = EMPTY;
+  for (u32 i = tid; i < LDS_SLOTS / 32 + 16; i += UNIQ_WG) again[i] = 0;
   __syncthreads();
   if (tid == 0) hdr[8] = EMPTY;   // (the minimum; the loop above zeroed the counters)
   __syncthreads();
 
   u32 c_inv = 0, c_ok = 0, c_fail = 0, c_info = 0, c_att = 0, lo = EMPTY, hi = 0, n_empty_id = 0, n_ids = 0;
-  for (u32 idx = tid; idx < n; idx += 256) {
+  for (u32 idx = tid; idx < n; idx += UNIQ_WG) {
     const uint4 row = r[idx];
     const u32 type = row.z & 3u, f = (row.z >> 2) & 31u, proc = row.z >> 12;
     if (proc == MSIM_PROCESS_NEMESIS) continue;
@@ -123,7 +126,7 @@ __global__ void __launch_bounds__(256) unique_check_lds_kernel(const UParams p) 
   atomicAdd(&hdr[5], n_empty_id); atomicAdd(&hdr[6], n_ids); atomicMin(&hdr[8], lo); atomicMax(&hdr[9], hi);
   __syncthreads();
   u32 dups = 0;
-  for (u32 i = tid; i < LDS_SLOTS / 32; i += 256) dups += (u32)__popc(again[i]);
+  for (u32 i = tid; i < LDS_SLOTS / 32; i += UNIQ_WG) dups += (u32)__popc(again[i]);
   atomicAdd(&hdr[7], dups);
   __syncthreads();
   if (tid == 0) {
@@ -150,7 +153,7 @@ static int unique_dev_run(msim_ctx *ctx, UParams up, u32 n, void **ws, size_t *w
     const size_t lds = ((size_t)LDS_SLOTS + LDS_SLOTS / 32 + 16) * 4;
     MSIM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&unique_check_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     up.first = 0;
-    hipLaunchKernelGGL(unique_check_lds_kernel, dim3(n), dim3(256), lds, st, up);
+    hipLaunchKernelGGL(unique_check_lds_kernel, dim3(n), dim3(UNIQ_WG), lds, st, up);
     MSIM_HIP_TRY(ctx, hipGetLastError());
     return MSIM_OK;
   }
