@@ -40,7 +40,7 @@ constexpr u32 NEEDS_HOST = 3u;
 constexpr u32 EMPTY = 0xFFFFFFFFu;
 constexpr u32 KEYS = 8u;          // kafka_check.cpp's bound (a poll block names its key in 3 bits)
 constexpr u32 OFFS = 2048u;       // kafka_check.cpp's bound on offsets and messages
-constexpr u32 NT = 256u, NWV = NT / 64u;
+constexpr u32 NT = 512u, NWV = NT / 64u;   // (round 6: 256 -> 512 threads per history: 14.1 -> 10.0 ms per 16384 at the bench shape; 1024: 21.8)
 constexpr u32 STAGE = 128u;       // payload words of a poll staged per wavefront (longer polls read the rest from HBM)
 constexpr u32 CMAX = 64u;         // worker threads
 constexpr u32 WST = 17u;          // per worker: last polled offset x 8, last sent offset x 8, current process
@@ -63,7 +63,7 @@ __device__ __forceinline__ void k_wave_fence() {   // orders the LDS traffic of 
 
 size_t kafka_lds_bytes(u32 T) { return ((size_t)KEYS * T * 2 + 3 * (size_t)KEYS * T / 32 + KEYS + 16 + CMAX * WST + NWV * STAGE) * 4; }
 
-__global__ void __launch_bounds__(256) kafka_check_kernel(const KCParams p) {
+__global__ void __launch_bounds__(NT) kafka_check_kernel(const KCParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const u32 hist = blockIdx.x, T = p.T, KT = KEYS * T, C = p.C;
@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(256) kafka_check_kernel(const KCParams p) {
 
 // The highest offset / message value any :ok send or poll of the launch names: sizes the tables (most tests use a fraction of what
 // max-writes-per-key allows, and the LDS a history's tables take decides how many histories a CU works on at once).
-__global__ void __launch_bounds__(256) kafka_bound_kernel(const KCParams p, u32 *bound) {
+__global__ void __launch_bounds__(NT) kafka_bound_kernel(const KCParams p, u32 *bound) {
   const u32 tid = threadIdx.x, hist = blockIdx.x;
   const uint4 *const r = reinterpret_cast<const uint4 *>(p.rows) + (p.row_off ? p.row_off[hist] : (u64)hist * p.max_rows);
   const u32 *const pay = p.payload + (p.pay_off ? p.pay_off[hist] : (u64)hist * p.max_pay);
