@@ -257,7 +257,7 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   off += is_mk ? ((size_t)kp.N * MK_SL * mk_slot_words(mk_keys_for(c)) + (size_t)kp.N * mk_keys_for(c) * 3 + 36) * 4   // transactions in flight (the first MK_SL per node), a round's messages per node, the generator's key pool
        : is_dt ? ((size_t)kp.N * (dt_many ? DG_WORDS : DC_WORDS) + 36) * 4   // the nodes' transactions (lock holder, waiting queue, save stack), the generator's key pool
        : is_hat ? 36 * 4   // the generator's key pool
-       : is_px ? (size_t)kp.N * PX_SLOTS * 8 + 34 * 256 + 64 * 4   // callbacks per node + service states + seq-kv indices
+       : is_px ? (size_t)kp.N * PX_SLOTS * 8 + ((c.node_program == MSIM_NODE_LIN_KV_PROXY && c.proxy_service == MSIM_SVC_SEQ_KV) ? 34 : 2) * 256 + 64 * 4   // callbacks per node + service states (seq-kv: + its ring of 32) + seq-kv indices
        : is_txn ? (size_t)kp.N * (txn_many ? TG_SLOTS : TXN_SLOTS) * 16 + 36 * 4   // transactions in flight per node + the generator's key pool
        : is_kf ? ((size_t)kp.N * (txn_many ? KFG_SLOTS : KF_SLOTS) * KSW + (size_t)kp.N * KF_KEYS + (size_t)(txn_many ? kp.CS : kp.N) * KF_KEYS + 36 + 2 * KF_KEYS) * 4   // request handlers, offset caches, client offsets (per worker slot), key pool, lin-kv lengths
        : is_raft ? (size_t)kp.N * 256 + (size_t)kp.N * kp.N * 3 * 4   // KV state + next/match index + append_entries refs
