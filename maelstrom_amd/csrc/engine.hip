@@ -187,6 +187,7 @@ static uint64_t proto_scratch_words(const msim_config &c) {
 static uint64_t scratch_words(const msim_config &c) {
   const uint64_t queues = c.n_nodes + (c.node_program == MSIM_NODE_KAFKA || c.node_program == MSIM_NODE_TXN_SINGLE_KEY || c.node_program == MSIM_NODE_LIN_KV_PROXY || c.node_program == MSIM_NODE_TSO_IDS ? 1 : c.node_program == MSIM_NODE_TXN_MULTI_KEY || c.node_program == MSIM_NODE_TXN_DATOMIC ? 2 : 0);  // + the services
   uint64_t w = proto_scratch_words(c) + queues * c.spill_capacity * 4;
+  if (c.node_program == MSIM_NODE_LIN_KV_PROXY || c.node_program == MSIM_NODE_TSO_IDS) w += (uint64_t)(c.concurrency > c.n_nodes ? c.concurrency : c.n_nodes) * (R_CLIENT_CAP - PX_CL) * 4;   // svc_kernel<>: the clients' inboxes beyond PX_CL envelopes
   if (msim_raft4_eligible(c)) w += msim_raft4_extra_scratch_words(c);   // raft4.hip keeps fewer envelopes in LDS
   if (msim_txn8_eligible(c)) w += msim_txn8_extra_scratch_words(c);     // txn8.hip likewise
   if (msim_mk8_eligible(c)) w += msim_mk8_extra_scratch_words(c);       // mk8.hip likewise
@@ -251,7 +252,7 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   kp.off_inbox = (u32)off;
   const bool dt_many = (is_dt || is_mk) && c.concurrency > c.n_nodes;   // dtg_kernel<> / mkg_kernel<>: a lane per endpoint, a client inbox per worker slot
   const bool txn_many = (is_txn || is_kf) && c.concurrency > c.n_nodes; // txng_kernel<> / kafkag_kernel<>: likewise
-  off += (is_mk || is_dt) ? ((size_t)(kp.N + 2) * kp.cap_node + (size_t)(dt_many ? kp.CS : kp.N) * T_CLIENT_CAP) * 16 : is_hat ? ((size_t)kp.N * kp.cap_node + (size_t)kp.CS * T_CLIENT_CAP) * 16   /* (hatg_kernel<>: an inbox per worker slot; CS == N otherwise) */ : is_px ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.CS * R_CLIENT_CAP) * 16 : (is_txn || is_kf) ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)(txn_many ? kp.CS : kp.N) * T_CLIENT_CAP) * 16
+  off += (is_mk || is_dt) ? ((size_t)(kp.N + 2) * kp.cap_node + (size_t)(dt_many ? kp.CS : kp.N) * T_CLIENT_CAP) * 16 : is_hat ? ((size_t)kp.N * kp.cap_node + (size_t)kp.CS * T_CLIENT_CAP) * 16   /* (hatg_kernel<>: an inbox per worker slot; CS == N otherwise) */ : is_px ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)kp.CS * PX_CL) * 16 : (is_txn || is_kf) ? ((size_t)(kp.N + 1) * kp.cap_node + (size_t)(txn_many ? kp.CS : kp.N) * T_CLIENT_CAP) * 16
                 : ((size_t)kp.N * kp.cap_node + (size_t)kp.CS * (is_raft ? R_CLIENT_CAP : CLIENT_INBOX_CAP)) * 16 + wide_client_bytes(c);   // (wide: + the pairs' client state)
   kp.off_seen = (u32)off;
   off += is_mk ? ((size_t)kp.N * MK_SL * mk_slot_words(mk_keys_for(c)) + (size_t)kp.N * mk_keys_for(c) * 3 + 36) * 4   // transactions in flight (the first MK_SL per node), a round's messages per node, the generator's key pool
