@@ -19,4 +19,5 @@
 #define MSIM_HAT8_MIN_CLUSTERS_PER_NODE 3200u
 #define MSIM_KAFKA8_MIN_CLUSTERS 8192u
 #define MSIM_DT8_MIN_CLUSTERS 12288u
+#define MSIM_SVC4_MIN_CLUSTERS 4096u
 #endif

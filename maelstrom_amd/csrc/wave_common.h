@@ -189,6 +189,10 @@ hipError_t msim_launch_duo(const KParams &kp, uint32_t n, hipStream_t st);
 bool msim_raft4_eligible(const msim_config &c);
 uint64_t msim_raft4_extra_scratch_words(const msim_config &c);
 hipError_t msim_launch_raft4(const KParams &kp, uint32_t n, hipStream_t st);
+// svc4.hip: four lin-kv-proxy clusters per wavefront (lin_kv_proxy.rb over lin-kv / lww-kv, clusters of <= 16 endpoints incl. the service)
+bool msim_svc4_eligible(const msim_config &c);
+uint64_t msim_svc4_extra_scratch_words(const msim_config &c);
+hipError_t msim_launch_svc4(const KParams &kp, uint32_t n, hipStream_t st);
 // txn8.hip: eight txn-list-append clusters per wavefront (single-root node over lin-kv, clusters of <= 8 lanes)
 bool msim_txn8_eligible(const msim_config &c);
 uint64_t msim_txn8_extra_scratch_words(const msim_config &c);

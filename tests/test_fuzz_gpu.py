@@ -202,6 +202,8 @@ def test_random_kv_options_engine_equals_oracle(lib, case):
         pytest.skip(str(e))
     first = rng.randrange(1 << 20)
     _compare(cfg, first, N_INST)
+    if kw.get("bin") == "lin-kv-proxy":   # four clusters per wavefront (svc4_kernel<>) where it applies
+        _compare(cfg, first, N_INST, dev_flags=0x400)
     if wl == "txn-list-append" and kw.get("bin") in (None, "multi-key-txn"):   # the single-root and the multi-key node: the same options with several workers per node (txng_kernel<> / mkg_kernel<>)
         k = rng.choice([2, 3, 10])
         if kw["node_count"] * (k + 1) + 2 <= 64:

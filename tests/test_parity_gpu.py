@@ -590,13 +590,21 @@ def test_unique_ids_parity(lib, kw):
     ("seq-kv", dict(latency=30, latency_dist="uniform", node_count=3)),
     ("lww-kv", dict(rate=100)),
     ("lww-kv", dict(node_count=7, concurrency=28, latency=10)),
+    ("lin-kv", dict(concurrency=10, rate=30, time_limit=20)),    # the reference's demo invocation (core.clj:112): a full 16-lane group
+    ("lin-kv", dict(concurrency=10, rate=400, latency=40, latency_dist="exponential", p_loss=0.1, nemesis=["partition"], nemesis_interval=3)),   # queues beyond their LDS slots, timeouts, late replies
+    ("lww-kv", dict(concurrency=10, rate=200, latency=20, latency_dist="uniform", p_loss=0.02)),
+    ("lin-kv", dict(node_count=1, concurrency=4, rate=100)),
+    ("lww-kv", dict(node_count=3, concurrency=12, rate=100, inbox_capacity=2, spill_capacity=3)),   # 16 lanes; inbox overflow flagged alike
 ])
 def test_lin_kv_proxy_and_services_parity(lib, service, kw):
-    """demo/ruby/lin_kv_proxy.rb over lin-kv / seq-kv / lww-kv (service.clj), svc_kernel<>."""
+    """demo/ruby/lin_kv_proxy.rb over lin-kv / seq-kv / lww-kv (service.clj): one cluster per wavefront (svc_kernel<>) and four (svc4_kernel<>,
+    csrc/svc4.hip: lin-kv / lww-kv, clusters of <= 15 endpoints + the service, journal off; large launches take it unasked, here MSIM_DEV_FLAGS
+    bit 10 asks for it; 6 clusters = a full wavefront of four and a partial one)."""
     base = dict(node_count=5, rate=60, time_limit=12, latency=5, seed=91)
     base.update(kw)
     cfg = E.test_config("lin-kv", bin="lin-kv-proxy", proxy_service=service, **base)
     _compare(cfg, 0, 6)
+    _compare(cfg, 3, 6, dev_flags=0x400)
 
 
 def test_raft_runs_match_the_recorded_reference_replays(lib):
