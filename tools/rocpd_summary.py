@@ -38,7 +38,7 @@ def summarise(path):
         print(f"-- no PMC data ({e.__class__.__name__}: {e})")
 
 
-OURS = ("sim_kernel", "check_kernel", "raft_kernel", "raft4_kernel", "txn_kernel", "txn8_kernel", "mk_kernel", "mk8_kernel", "hat_kernel", "svc_kernel", "compact_", "availability_kernel",
+OURS = ("sim_kernel", "check_kernel", "raft_kernel", "raft4_kernel", "txn_kernel", "txn8_kernel", "mk_kernel", "mk8_kernel", "hat_kernel", "svc_kernel", "svc4_kernel", "compact_", "availability_kernel",
         "txn_check_kernel", "rw_check_kernel", "lin_check_kernel", "lin_check_wg_kernel", "unique_check_kernel", "pn_check_kernel", "kafka_kernel", "kafka8_kernel", "kafka_check_kernel",
         "hat8_kernel", "uid8_kernel", "crdt8_kernel", "bcast8_kernel", "dt_kernel", "dt8_kernel", "txn_check_lds_kernel")
 
