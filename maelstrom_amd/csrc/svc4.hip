@@ -10,7 +10,7 @@
 // wavefront (16 live lanes of 64) and is bound by instruction issue; here one instruction stream serves four clusters.
 //
 // Scope (engine.hip picks this kernel when all of it holds, else svc_kernel<> runs): the proxy over lin-kv or lww-kv (seq-kv's ring of 32
-// states is 8 KiB per cluster: svc_kernel<>), n_nodes + max(concurrency, n_nodes) + 1 <= 16, net journal off, at least
+// states is 8 KiB per cluster: svc_kernel<>) or unique-ids over the lin-tso node (TSO: the service lane is the timestamp oracle), n_nodes + max(concurrency, n_nodes) + 1 <= 16, net journal off, at least
 // MSIM_SVC4_MIN_CLUSTERS clusters in the launch.
 //
 // LDS of a wavefront: envelope queues slot-major (slot s of lane e at [s * 64 + e]; RQ envelopes, the rest spills to HBM: servers
@@ -42,6 +42,7 @@ constexpr u32 S4_CLIENT_CAP = 32u;   // Reusable lin-kv clients (lin_kv.clj:74-7
 constexpr u32 S4_SLOTS = 32u;     // callbacks per node (PX_SLOTS of sim_kernel_svc.inc / oracle/svc_nodes.inc)
 enum { M_WRITE = 14, M_WRITE_OK, M_CAS, M_CAS_OK, M_ERROR };
 enum { S_SVC = 12 };
+enum { M_TS = 28, M_TS_OK = 29 };   // include/maelsim.h MSIM_M_TS*
 
 struct S4Params {
   KParams k;
@@ -81,7 +82,7 @@ __device__ __forceinline__ u32 row_scan(u32 v) {
   return v;
 }
 
-template <bool NEM, bool NET_RANDOM>
+template <bool NEM, bool NET_RANDOM, bool TSO>   // TSO: unique-ids over the lin-tso timestamp oracle (the node asks the service for a ts per generate)
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S4_WAVES))) svc4_kernel(const S4Params rp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const KParams &p = rp.k;
@@ -106,6 +107,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S4_WAVE
   const u32 rate = p.cfg.rate_mhz;
   const bool lww = p.cfg.proxy_service == MSIM_SVC_LWW_KV;
   u32 rpc_timeout_ms = 10 * lat_mean; if (rpc_timeout_ms < 1000) rpc_timeout_ms = 1000;   // lin_kv.clj:54
+  if (TSO) rpc_timeout_ms = p.cfg.client_timeout_ms;                                       // client.clj:18-20
   const u32 round_limit = rp.round_limit;
 
   msim_op *const g_rows = p.rows + (size_t)inst * max_rows;
@@ -132,7 +134,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S4_WAVE
   bool has_c = false; u32 deliver_at = 0; uint4 cm = make_uint4(0, 0, 0, 0);
   bool have_pm = false; uint4 pm = make_uint4(0, 0, 0, 0);
   u32 in_n = 0, sp_n = 0, part = 0;
-  u32 node_msgid = 0, svc_ctr = 0;   // node: rpc ids; service lane: rand-int draws so far
+  u32 node_msgid = 0, svc_ctr = 0;   // node: rpc ids; service lane: rand-int draws so far (lin-tso: the next timestamp)
   // ---- client state ----
   bool busy = false, mark = false; u32 kind = K_NONE;
   u32 want = 0, timeout_at = 0, next_msg_id = 0, c_f = 0, c_value = 0, process = slot;
@@ -342,6 +344,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S4_WAVE
           const u32 r_hi = (u32)(h >> 32), r_lo = (u32)h;
           const u32 pick = scale32(r_lo, nfree);
           const bool sel = gen && is_worker && !busy && (u32)__popc(free_mask & lt) == pick;
+          if (TSO) {   // (gen/repeat {:f :generate}), unique_ids.clj:71
+            if (sel) { mark = true; kind = K_OP; m_f = MSIM_F_GENERATE; m_value = MSIM_NO_VALUE; }
+            if (gen) { gen_k++; gen_next = T + __umulhi(r_hi, p.gen_period2_us); }
+          } else {
           const u32 selm = GB(sel);
           const u32 sl = selm ? (u32)__builtin_ctz(selm) : 0u;                       // the chosen lane of my group
           const u32 s_proc = GGET(process, sl), s_reg = GGET(key_reg, sl);
@@ -365,6 +371,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S4_WAVE
             else { m_f = MSIM_F_CAS; m_value = kx | (v1 << 8) | (v2 << 16); }
           }
           if (gen && !key_ovf) { gen_k++; gen_next = T + __umulhi(r_hi, p.gen_period2_us); }
+          }
         }
       }
 
@@ -379,8 +386,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S4_WAVE
             c_f = m_f; c_value = m_value;
             rq_dest = dest_node;
             inv_row = true; inv_packed = MSIM_T_INVOKE | (c_f << 2) | (process << 12); inv_value = c_value;
-            rq_type = c_f == MSIM_F_WRITE ? M_WRITE : c_f == MSIM_F_CAS ? M_CAS : M_READ;
-            rq_a = c_value;
+            rq_type = TSO ? (u32)M_GENERATE : c_f == MSIM_F_WRITE ? (u32)M_WRITE : c_f == MSIM_F_CAS ? (u32)M_CAS : (u32)M_READ;
+            rq_a = TSO ? 0u : c_value;
           }
           want = ++next_msg_id;
           timeout_at = T + (kind == K_OP ? rpc_timeout_ms : 10000u) * 1000u;
@@ -409,26 +416,29 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S4_WAVE
         if (qsrc >= N && qsrc < SVC) s_recv_cl++; else s_recv_sv++;
         if (is_node) {
           if (qtype == M_INIT) { rep = true; rep_dest = qsrc; rep_type = M_INIT_OK; rep_b = qb; }
-          else if (qtype == M_READ || qtype == M_WRITE || qtype == M_CAS) {  // proxy!, lin_kv_proxy.rb:27-38
+          else if (TSO ? qtype == M_GENERATE : (qtype == M_READ || qtype == M_WRITE || qtype == M_CAS)) {  // proxy!, lin_kv_proxy.rb:27-38 / generate -> ts
             const u32 rid = ++node_msgid;
             // engine capacity: the 32 newest callbacks per node (an evicted one is flagged only if its reply still arrives)
             my_cbs[rid % S4_SLOTS] = make_uint2((rid & 0xFFFFFFu) | (qsrc << 24), (qb & 0xFFFFFFu) | 0x80000000u);
-            rep = true; rep_dest = SVC; rep_type = qtype; rep_a = qa; rep_b = rid;
-          } else if (qtype == M_READ_OK || qtype == M_WRITE_OK || qtype == M_CAS_OK || qtype == M_ERROR) {
+            rep = true; rep_dest = SVC; rep_type = TSO ? (u32)M_TS : qtype; rep_a = TSO ? 0u : qa; rep_b = rid;
+          } else if (TSO ? qtype == M_TS_OK : (qtype == M_READ_OK || qtype == M_WRITE_OK || qtype == M_CAS_OK || qtype == M_ERROR)) {
             const uint2 c = my_cbs[qb % S4_SLOTS];
             if ((c.y >> 31) && (c.x & 0xFFFFFFu) == qb) {
               my_cbs[qb % S4_SLOTS] = make_uint2(0, 0);
-              rep = true; rep_dest = c.x >> 24; rep_type = qtype; rep_a = qa; rep_b = c.y & 0x7FFFFFFFu;
+              rep = true; rep_dest = c.x >> 24; rep_type = TSO ? (u32)M_GENERATE_OK : qtype; rep_a = qa; rep_b = c.y & 0x7FFFFFFFu;
             } else if (qb + S4_SLOTS <= node_msgid) my_flags |= MSIM_FLAG_ARENA_OVERRUN;
           }
         } else {  // the service
           u32 rt = 0, ra = 0, ri = 0;
+          if (TSO) { if (qtype == M_TS) { rep = true; rep_dest = qsrc; rep_type = M_TS_OK; rep_a = svc_ctr++; rep_b = qb; } }   // PersistentTSO, service.clj:116-123
+          else {
           if (lww) {  // Eventual over LWWKV, 2 replicas; the merge is computed and discarded (service.clj:222-235)
             svc_ctr += 2;  // merge-source, merge-dest
             ri = scale32(draw32(key, S_SVC, svc_ctr++), 2);
           }
           kv_handle(kvs_g + ri * 256u, qtype, qa, rt, ra);
           rep = true; rep_dest = qsrc; rep_type = rt; rep_a = ra; rep_b = qb;
+          }
         }
       }
 
@@ -462,7 +472,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S4_WAVE
           s_recv_cl++;
           const u32 qb = q.w & 0xFFFFFFu, qtype = q.y & 0x7Fu, qa = q.z;
           if (busy && qb == want) {  // else stale (client.clj:105-107)
-            if (qtype == M_READ_OK) complete(MSIM_T_OK, 0, (c_value & 0xFFu) | ((qa & 0xFFu) << 8) | 0xFF0000u);   // [k v], lin_kv.clj:56-61
+            if (TSO && qtype == M_GENERATE_OK) complete(MSIM_T_OK, 0, qa);   // unique_ids.clj:53-57
+            else if (qtype == M_READ_OK) complete(MSIM_T_OK, 0, (c_value & 0xFFu) | ((qa & 0xFFu) << 8) | 0xFF0000u);   // [k v], lin_kv.clj:56-61
             else if (qtype == M_ERROR) complete(MSIM_T_FAIL, qa == 11 ? MSIM_ERR_TEMPORARILY_UNAVAILABLE : qa == 20 ? MSIM_ERR_KEY_DOES_NOT_EXIST : MSIM_ERR_PRECONDITION_FAILED, c_value);
             else complete(MSIM_T_OK, 0, c_value);
           }
@@ -515,7 +526,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S4_WAVE
 
 // Whether four clusters per wavefront simulate this configuration (see the header of this file).
 bool msim_svc4_eligible(const msim_config &c) {
-  if (c.node_program != MSIM_NODE_LIN_KV_PROXY || c.journal_capacity != 0 || c.proxy_service == MSIM_SVC_SEQ_KV) return false;
+  if (c.journal_capacity != 0) return false;
+  if (c.node_program != MSIM_NODE_TSO_IDS && (c.node_program != MSIM_NODE_LIN_KV_PROXY || c.proxy_service == MSIM_SVC_SEQ_KV)) return false;
   const uint32_t cs = c.concurrency > c.n_nodes ? c.concurrency : c.n_nodes;
   return c.n_nodes >= 1 && c.n_nodes + cs + 1 <= GS;
 }
@@ -525,6 +537,13 @@ bool msim_svc4_eligible(const msim_config &c) {
 uint64_t msim_svc4_extra_scratch_words(const msim_config &c) {
   const uint32_t cs = c.concurrency > c.n_nodes ? c.concurrency : c.n_nodes;
   return ((uint64_t)(c.n_nodes + 1) * c.inbox_capacity + (uint64_t)cs * S4_CLIENT_CAP) * 4;
+}
+
+template <bool TSO>
+static void svc4_launch(const S4Params &rp, bool nem, bool rnd, dim3 grid, size_t lds, hipStream_t st) {
+  const dim3 block(64);
+  if (nem) { if (rnd) hipLaunchKernelGGL((svc4_kernel<true, true, TSO>), grid, block, lds, st, rp); else hipLaunchKernelGGL((svc4_kernel<true, false, TSO>), grid, block, lds, st, rp); }
+  else { if (rnd) hipLaunchKernelGGL((svc4_kernel<false, true, TSO>), grid, block, lds, st, rp); else hipLaunchKernelGGL((svc4_kernel<false, false, TSO>), grid, block, lds, st, rp); }
 }
 
 hipError_t msim_launch_svc4(const KParams &kp, uint32_t n, hipStream_t st) {
@@ -544,8 +563,8 @@ hipError_t msim_launch_svc4(const KParams &kp, uint32_t n, hipStream_t st) {
   const size_t lds = off;
   const bool rnd = c.latency_dist != MSIM_LAT_CONSTANT || c.p_loss_q32 != 0;
   if (rnd) MSIM_UPLOAD_ONCE(s4_log2_q24, msim_log2_q24, sizeof(msim_log2_q24));   // (1 KiB, once per device)
-  const dim3 grid((n + 3) / 4), block(64);
-  if (c.nemesis_mask) { if (rnd) hipLaunchKernelGGL((svc4_kernel<true, true>), grid, block, lds, st, rp); else hipLaunchKernelGGL((svc4_kernel<true, false>), grid, block, lds, st, rp); }
-  else { if (rnd) hipLaunchKernelGGL((svc4_kernel<false, true>), grid, block, lds, st, rp); else hipLaunchKernelGGL((svc4_kernel<false, false>), grid, block, lds, st, rp); }
+  const dim3 grid((n + 3) / 4);
+  if (c.node_program == MSIM_NODE_TSO_IDS) svc4_launch<true>(rp, c.nemesis_mask != 0, rnd, grid, lds, st);
+  else svc4_launch<false>(rp, c.nemesis_mask != 0, rnd, grid, lds, st);
   return hipGetLastError();
 }

@@ -636,12 +636,15 @@ def test_raft_runs_match_the_recorded_reference_replays(lib):
     dict(node_count=3, rate=200, time_limit=6, latency=3, nemesis=["partition"], nemesis_interval=2, journal_capacity=200000),
     dict(node_count=4, concurrency=12, rate=500, time_limit=4, latency=20, latency_dist="uniform", p_loss=0.05),
     dict(node_count=1, rate=50, time_limit=2),
+    dict(node_count=5, concurrency=10, rate=1000, time_limit=3, latency=8, latency_dist="exponential", p_loss=0.05, nemesis=["partition"], nemesis_interval=1),   # a full 16-lane group
 ])
 def test_unique_ids_over_lin_tso_parity(lib, kw):
-    """unique-ids served through the lin-tso timestamp oracle (service.clj:116-132): svc_kernel<.., TSO> against oracle/svc_nodes.inc,
-    which the process bridge pins with a real node process (tests/test_process_bridge.py)."""
+    """unique-ids served through the lin-tso timestamp oracle (service.clj:116-132): svc_kernel<.., TSO> (one cluster per wavefront) and
+    svc4_kernel<.., TSO> (four: nodes + workers + the service <= 16, journal off; MSIM_DEV_FLAGS bit 10 asks for it here) against
+    oracle/svc_nodes.inc, which the process bridge pins with a real node process (tests/test_process_bridge.py)."""
     cfg = E.test_config("unique-ids", bin="tso-ids", seed=17, **kw)
     ora = _compare(cfg, 0, 6)
+    _compare(cfg, 0, 6, dev_flags=0x400)
     for i in range(6):
         ops = E.decode_history(*ora.history(i), cfg.n_nodes, cfg.workload, cfg.node_program)
         ids = sorted(o["value"] for o in ops if o["type"] == ":ok")

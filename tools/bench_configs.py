@@ -26,6 +26,7 @@ CONFIGS = {
     "cfg4 lin-kv raft + partitions lat10": (dict(workload="lin-kv", bin="raft", node_count=5, rate=30, time_limit=60, latency=10, nemesis=["partition"], nemesis_interval=10), 8192),
     # the reference's own demo invocation of the proxy node (core.clj:112: lin_kv_proxy.rb, concurrency 10) over the linearizable service
     "lin-kv proxy n=5 c=10 rate30 60s lat5": (dict(workload="lin-kv", bin="lin-kv-proxy", node_count=5, concurrency=10, rate=30, time_limit=60, latency=5, proxy_service="lin-kv"), 16384),
+    "unique-ids over lin-tso n=3 rate1000 10s lat5 + partitions": (dict(workload="unique-ids", bin="tso-ids", node_count=3, rate=1000, time_limit=10, latency=5, nemesis=["partition"], nemesis_interval=3), 16384),
     "pn-counter n=5 rate100 20s lat100 exponential": (dict(workload="pn-counter", node_count=5, rate=100, time_limit=20, latency=100, latency_dist="exponential"), 16384),
     "g-counter n=5 rate100 20s lat10": (dict(workload="g-counter", node_count=5, rate=100, time_limit=20, latency=10), 16384),
     "unique-ids n=3 rate1000 10s lat5 + partitions": (dict(workload="unique-ids", node_count=3, rate=1000, time_limit=10, latency=5, nemesis=["partition"], nemesis_interval=3), 16384),
