@@ -45,9 +45,9 @@ def cfg4_config(E, seed):
 CONFIGS = {
     # name: (config builder, instances over the whole job or None = --instances per GPU, description, dominant kernel)
     "cfg2": (headline_config, None, "broadcast n=25 x %d instances/GPU (grid, rate 100/s, time-limit 20 s + 10 s quiesce + final reads, latency 0, fire-and-forget gossip)",
-             "sim_kernel_duo<LAT0, DEG4> (duo.hip: two clusters per wavefront)", "sim_kernel_duo", "r06e_headline_counters.json"),
+             "sim_kernel_duo<LAT0, DEG4> (duo.hip: two clusters per wavefront)", "sim_kernel_duo", "r06f_headline_counters.json"),
     "cfg4": (cfg4_config, 65536, "lin-kv over 5-node Raft x %d instances/GPU (65536 over the job; concurrency 10, rate 30/s, time-limit 60 s, latency 0), histories gathered to rank 0 over RCCL",
-             "raft4_kernel<> (raft4.hip: four clusters per wavefront)", "raft4_kernel", "r06e_cfg4_counters.json"),
+             "raft4_kernel<> (raft4.hip: four clusters per wavefront)", "raft4_kernel", "r06f_cfg4_counters.json"),
 }
 
 
