@@ -96,6 +96,28 @@ def test_cfg5_datomic_shape(lib):
     _compare_digests(cfg, 0, 64, batch=12288)   # the batch size from which eight clusters per wavefront are taken (csrc/dt8.hip)
 
 
+@pytest.mark.parametrize("service", ["lin-kv", "lww-kv"])
+def test_the_reference_demo_invocation_of_the_lin_kv_proxy(lib, service):
+    """core.clj:112: `{:workload :lin-kv :bin "demo/ruby/lin_kv_proxy.rb" :concurrency 10}` at tools/bench_configs.py's shape — one cluster per
+    wavefront (a small launch) and, as part of a launch of 4096 (the size from which four clusters per wavefront are taken: csrc/svc4.hip), the
+    same instances again; every history of the full launch passes (lin-kv) or is judged by (lww-kv) the device's linearizability search."""
+    cfg = E.test_config("lin-kv", bin="lin-kv-proxy", node_count=5, concurrency=10, rate=30, time_limit=60, latency=5, proxy_service=service, seed=99)
+    _compare_digests(cfg, 0, 48)
+    _compare_digests(cfg, 0, 48, batch=4096)
+    _compare_digests(cfg, 4096 * 3 + 1, 31, batch=4097)   # a last wavefront with one cluster
+    if service == "lin-kv":
+        with E.Engine(cfg) as eng:
+            eng.run(0, 4096)
+            eng.check()
+            assert (eng.check_results()["valid"] == 1).all()
+
+
+def test_unique_ids_over_lin_tso_at_the_bench_shape(lib):
+    cfg = E.test_config("unique-ids", bin="tso-ids", node_count=3, rate=1000, time_limit=10, latency=5, nemesis=["partition"], nemesis_interval=3, seed=99)
+    _compare_digests(cfg, 0, 32)
+    _compare_digests(cfg, 7, 32, batch=4096)   # four clusters per wavefront (svc4_kernel<.., TSO>)
+
+
 def test_the_reference_demo_invocation_for_txn_list_append(lib):
     """core.clj:113-114: `{:workload :txn-list-append :bin "demo/ruby/datomic_list_append.rb"}` with the defaults of core.clj:136-229 — five nodes,
     one worker per node, rate 5, 60 s, latency 0."""
