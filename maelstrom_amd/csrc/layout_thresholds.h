@@ -12,6 +12,7 @@
 //   MSIM_KAFKA8_MIN_CLUSTERS      8192   kafka 1 / 3 / 5 / 7 nodes: packed 30 / 73 / 88 / 93 ms against 21 / 50 / 61 / 63 at 4096 (loses), 31 / 77 / 92 / 97 against 34 / 80 / 94 / 97 at 8192 (even), 34 / 83 / 99 / 105 against 65 / 151 / 177 / 184 at 16384   profiles/r05_kafka8_threshold_sweep.jsonl
 //   MSIM_DT8_MIN_CLUSTERS        12288   txn-list-append over the Datomic-style node, 2 / 5 nodes: packed 125 / 294 ms against 56 / 142 at 4096 (loses), 136 / 326 against 108 / 277 at 8192, 158 / 383 against 207 / 536 at 16384, 316 / 760 against 401 / 1042 at 32768   profiles/r05_dt8_threshold_sweep.jsonl
 //   MSIM_SVC4_MIN_CLUSTERS        4096   lin-kv proxy 5 nodes c=10: four per wavefront 16.0 against 17.2 ms at 4096, 18.0 / 31.9 at 8192, 24.9 / 59.6 at 16384 (loses below: 15.6 / 12.3 at 2048)   profiles/r06f_svc4_threshold_sweep.jsonl
+//   MSIM_TXNG4_MIN_CLUSTERS       8192   txn-list-append, single-root node, 1 node x 10 workers: four per wavefront 107.6 against 116.6 ms at 8192, 134.5 / 222.6 at 16384 (loses below: 98 / 61 at 4096); 5 nodes x 2: 105 / 176 at 8192, 130 / 323 at 16384   profiles/r06f_txng4_threshold_sweep.jsonl
 #ifndef MSIM_LAYOUT_THRESHOLDS_H
 #define MSIM_LAYOUT_THRESHOLDS_H
 #define MSIM_UID8_MIN_CLUSTERS 4096u
@@ -21,4 +22,5 @@
 #define MSIM_KAFKA8_MIN_CLUSTERS 8192u
 #define MSIM_DT8_MIN_CLUSTERS 12288u
 #define MSIM_SVC4_MIN_CLUSTERS 4096u
+#define MSIM_TXNG4_MIN_CLUSTERS 8192u
 #endif

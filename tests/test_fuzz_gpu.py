@@ -208,6 +208,8 @@ def test_random_kv_options_engine_equals_oracle(lib, case):
         k = rng.choice([2, 3, 10])
         if kw["node_count"] * (k + 1) + 2 <= 64:
             _compare(E.test_config(wl, concurrency=k * kw["node_count"], **kw), first, 3)
+            if kw.get("bin") is None:   # single-root node: four clusters per wavefront (txng4_kernel<>) where it applies
+                _compare(E.test_config(wl, concurrency=k * kw["node_count"], **kw), first, 5, dev_flags=0x400)
 
 
 def _random_wide_case(rng):

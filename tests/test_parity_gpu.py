@@ -376,12 +376,20 @@ def test_datomic_many_workers_parity(lib, kw):
     dict(node_count=5, concurrency=10, rate=200, time_limit=6, latency=5, nemesis=["partition"], nemesis_interval=2),
     dict(node_count=3, concurrency=9, rate=150, time_limit=10, latency=10, p_loss=0.03, journal_capacity=400000),
     dict(node_count=1, concurrency=61, rate=1000, time_limit=3, latency=1),                                    # 1 node, 61 workers, lin-kv
+    dict(node_count=1, concurrency=10, rate=100, time_limit=30, latency=5),                                    # the shape of the reference's own runs (doc/05-datomic/01-single-node.md:257)
+    dict(node_count=5, concurrency=10, rate=400, time_limit=6, latency=20, latency_dist="exponential", p_loss=0.1, nemesis=["partition"], nemesis_interval=2),   # a full 16-lane group; loss: clients time out, queues beyond their LDS slots
+    dict(node_count=2, concurrency=8, rate=300, time_limit=5, latency=3, latency_dist="uniform", key_count=3, max_txn_length=8, max_writes_per_key=40),
+    dict(node_count=3, concurrency=12, rate=200, time_limit=5, latency=5, inbox_capacity=2, spill_capacity=40),  # 16 lanes; the servers' queues live in the spill
+    dict(node_count=1, concurrency=14, rate=500, time_limit=4, latency=8),                                      # 16 lanes: 1 node, 14 workers, lin-kv
 ])
 def test_single_key_txn_many_workers_parity(lib, kw):
     """Several workers per node for the single-root node (demo/clojure/single_key_txn.clj): txng_kernel<> (csrc/sim_kernel_txng.inc: a lane per
-    endpoint, up to 64 transactions in flight per node) against oracle/txn_nodes.inc."""
+    endpoint, up to 64 transactions in flight per node) and txng4_kernel<> (csrc/txng4.hip: four clusters per wavefront where nodes + workers +
+    lin-kv <= 16 and the journal is off; large launches take it unasked, here MSIM_DEV_FLAGS bit 10 asks for it; 6 clusters = a full wavefront
+    and a partial one) against oracle/txn_nodes.inc."""
     cfg = E.test_config("txn-list-append", seed=29, **kw)
     _compare(cfg, 0, 5)
+    _compare(cfg, 2, 6, dev_flags=0x400)
 
 
 @pytest.mark.parametrize("kw", [

@@ -32,6 +32,9 @@ CONFIGS = {
     "unique-ids n=3 rate1000 10s lat5 + partitions": (dict(workload="unique-ids", node_count=3, rate=1000, time_limit=10, latency=5, nemesis=["partition"], nemesis_interval=3), 16384),
     "cfg5 txn-list-append n=5 rate100 30s lat5 + partitions": (dict(workload="txn-list-append", node_count=5, rate=100, time_limit=30, latency=5,
                                                                      nemesis=["partition"], nemesis_interval=10), 32768),
+    # the single-root node as the reference's own runs of this workload are invoked (doc/05-datomic/01-single-node.md:257,322: one node, --concurrency 10n)
+    "txn-list-append n=1 c=10 rate100 30s lat5 (single-root node)": (dict(workload="txn-list-append", node_count=1, concurrency=10, rate=100, time_limit=30, latency=5), 16384),
+    "txn-list-append n=5 c=10 rate100 30s lat5 + partitions (single-root node)": (dict(workload="txn-list-append", node_count=5, concurrency=10, rate=100, time_limit=30, latency=5, nemesis=["partition"], nemesis_interval=10), 16384),
     # the multi-key node (multi_key_txn.js; same architecture as core.clj:113-114's datomic_list_append.rb, a different program): thunks in lww-kv, root map in lin-kv
     "cfg5-mk txn-list-append multi-key n=5 rate100 30s lat5 + partitions": (dict(workload="txn-list-append", bin="multi-key-txn", node_count=5, rate=100, time_limit=30, latency=5,
                                                                                   nemesis=["partition"], nemesis_interval=10), 32768),
