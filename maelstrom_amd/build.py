@@ -20,7 +20,7 @@ SOURCES = ["config.cpp", "engine.hip",
            # the one-cluster-per-wavefront kernels (csrc/sim_kernels.h), one unit per family or part of one
            "k_general_a.hip", "k_general_b.hip", "k_general_c.hip", "k_wide_gset.hip", "k_wide_bcast.hip", "k_wide_ack.hip", "k_wide_pn.hip",
            "k_raft.hip", "k_svc.hip", "k_txn.hip", "k_mk.hip", "k_dt.hip", "k_kafka.hip", "k_hat.hip",
-           "duo.hip", "raft4.hip", "svc4.hip", "txng4.hip", "txn8.hip", "mk8.hip", "dt8.hip", "hat8.hip", "kafka8.hip", "uid8.hip", "crdt8.hip", "bcast8.hip", "checker.hip", "lin_check.cpp", "lin_check_dev.hip", "txn_check.cpp", "txn_check_dev.hip", "rw_check_dev.hip", "pn_check.cpp", "kafka_check.cpp", "kafka_check_dev.hip", "pn_check_dev.hip", "unique_check_dev.hip", "edn.cpp",
+           "duo.hip", "raft4.hip", "svc4.hip", "txng4.hip", "dtg4.hip", "txn8.hip", "mk8.hip", "dt8.hip", "hat8.hip", "kafka8.hip", "uid8.hip", "crdt8.hip", "bcast8.hip", "checker.hip", "lin_check.cpp", "lin_check_dev.hip", "txn_check.cpp", "txn_check_dev.hip", "rw_check_dev.hip", "pn_check.cpp", "kafka_check.cpp", "kafka_check_dev.hip", "pn_check_dev.hip", "unique_check_dev.hip", "edn.cpp",
            "fressian.cpp", "gather.cpp", "guard.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 LINK_LIBS = ["-ldl"]

@@ -191,6 +191,7 @@ static uint64_t scratch_words(const msim_config &c) {
   if (msim_raft4_eligible(c)) w += msim_raft4_extra_scratch_words(c);   // raft4.hip keeps fewer envelopes in LDS
   if (msim_svc4_eligible(c)) w += msim_svc4_extra_scratch_words(c);     // svc4.hip likewise
   if (msim_txng4_eligible(c)) w += msim_txng4_extra_scratch_words(c);   // txng4.hip likewise
+  if (msim_dtg4_eligible(c)) w += msim_dtg4_extra_scratch_words(c);     // dtg4.hip likewise
   if (msim_txn8_eligible(c)) w += msim_txn8_extra_scratch_words(c);     // txn8.hip likewise
   if (msim_mk8_eligible(c)) w += msim_mk8_extra_scratch_words(c);       // mk8.hip likewise
   if (msim_dt8_eligible(c)) w += msim_dt8_extra_scratch_words(c);       // dt8.hip likewise (+ the nodes' save stacks)
@@ -300,6 +301,8 @@ static int run_impl(msim_ctx *ctx, uint64_t first, uint32_t n, hipStream_t st, b
   if (msim_svc4_eligible(c) && !(kp.dev_flags & 0x200u)) e = msim_launch_svc4(kp, n, st);
   // txn-list-append, single-root node with several workers per node: four clusters per wavefront (txng4.hip) for large batches when nodes + workers + lin-kv fit a 16-lane group
   if (msim_txng4_eligible(c) && !(kp.dev_flags & 0x200u)) e = msim_launch_txng4(kp, n, st);
+  // the Datomic-style node with several workers per node: four clusters per wavefront (dtg4.hip) for large batches when nodes + workers + the two services fit a 16-lane group
+  if (msim_dtg4_eligible(c) && !(kp.dev_flags & 0x200u)) e = msim_launch_dtg4(kp, n, st);
   // txn-list-append: eight clusters per wavefront (txn8.hip) when a cluster fits an 8-lane group
   if (msim_txn8_eligible(c) && !(kp.dev_flags & 0x200u)) e = msim_launch_txn8(kp, n, st);
   // the canonical txn-list-append node: eight clusters per wavefront (mk8.hip) when a cluster fits an 8-lane group

@@ -13,6 +13,7 @@
 //   MSIM_DT8_MIN_CLUSTERS        12288   txn-list-append over the Datomic-style node, 2 / 5 nodes: packed 125 / 294 ms against 56 / 142 at 4096 (loses), 136 / 326 against 108 / 277 at 8192, 158 / 383 against 207 / 536 at 16384, 316 / 760 against 401 / 1042 at 32768   profiles/r05_dt8_threshold_sweep.jsonl
 //   MSIM_SVC4_MIN_CLUSTERS        4096   lin-kv proxy 5 nodes c=10: four per wavefront 16.0 against 17.2 ms at 4096, 18.0 / 31.9 at 8192, 24.9 / 59.6 at 16384 (loses below: 15.6 / 12.3 at 2048)   profiles/r06f_svc4_threshold_sweep.jsonl
 //   MSIM_TXNG4_MIN_CLUSTERS       8192   txn-list-append, single-root node, 1 node x 10 workers: four per wavefront 107.6 against 116.6 ms at 8192, 134.5 / 222.6 at 16384 (loses below: 98 / 61 at 4096); 5 nodes x 2: 105 / 176 at 8192, 130 / 323 at 16384   profiles/r06f_txng4_threshold_sweep.jsonl
+//   MSIM_DTG4_MIN_CLUSTERS       16384   txn-list-append, Datomic-style node, 1 node x 10 workers at latency 0 (the reference's invocation): four per wavefront 708.5 against 952.9 ms at 16384 (loses below: 549 / 493 at 8192); latency 5: 97.7 / 131.1; 2 nodes x 6 + partitions: 315 / 357   profiles/r06f_dtg4_threshold_sweep.jsonl
 #ifndef MSIM_LAYOUT_THRESHOLDS_H
 #define MSIM_LAYOUT_THRESHOLDS_H
 #define MSIM_UID8_MIN_CLUSTERS 4096u
@@ -23,4 +24,5 @@
 #define MSIM_DT8_MIN_CLUSTERS 12288u
 #define MSIM_SVC4_MIN_CLUSTERS 4096u
 #define MSIM_TXNG4_MIN_CLUSTERS 8192u
+#define MSIM_DTG4_MIN_CLUSTERS 16384u
 #endif

@@ -197,6 +197,10 @@ hipError_t msim_launch_svc4(const KParams &kp, uint32_t n, hipStream_t st);
 bool msim_txng4_eligible(const msim_config &c);
 uint64_t msim_txng4_extra_scratch_words(const msim_config &c);
 hipError_t msim_launch_txng4(const KParams &kp, uint32_t n, hipStream_t st);
+// dtg4.hip: four clusters of the Datomic-style txn-list-append node with several workers per node per wavefront (nodes + workers + lin-kv + lww-kv <= 16)
+bool msim_dtg4_eligible(const msim_config &c);
+uint64_t msim_dtg4_extra_scratch_words(const msim_config &c);
+hipError_t msim_launch_dtg4(const KParams &kp, uint32_t n, hipStream_t st);
 // txn8.hip: eight txn-list-append clusters per wavefront (single-root node over lin-kv, clusters of <= 8 lanes)
 bool msim_txn8_eligible(const msim_config &c);
 uint64_t msim_txn8_extra_scratch_words(const msim_config &c);

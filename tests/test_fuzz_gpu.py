@@ -210,6 +210,11 @@ def test_random_kv_options_engine_equals_oracle(lib, case):
             _compare(E.test_config(wl, concurrency=k * kw["node_count"], **kw), first, 3)
             if kw.get("bin") is None:   # single-root node: four clusters per wavefront (txng4_kernel<>) where it applies
                 _compare(E.test_config(wl, concurrency=k * kw["node_count"], **kw), first, 5, dev_flags=0x400)
+    if wl == "txn-list-append" and kw.get("bin") == "datomic":   # the Datomic-style node with several workers per node: one cluster per wavefront (dtg_kernel<>) and four (dtg4_kernel<>)
+        k = rng.choice([2, 3, 10])
+        if kw["node_count"] * (k + 1) + 2 <= 16:
+            _compare(E.test_config(wl, concurrency=k * kw["node_count"], **kw), first, 3)
+            _compare(E.test_config(wl, concurrency=k * kw["node_count"], **kw), first, 5, dev_flags=0x400)
 
 
 def _random_wide_case(rng):

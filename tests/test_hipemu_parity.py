@@ -55,6 +55,8 @@ CASES = [
     "{'workload':'unique-ids','bin':'tso-ids','node_count':3,'concurrency':6,'rate':300,'time_limit':4,'latency':5,'nemesis':['partition'],'nemesis_interval':1,'flags':0x400,'n':5}",   # unique-ids over lin-tso, four clusters per wavefront (svc4_kernel<.., TSO>)
     "{'workload':'txn-list-append','node_count':1,'concurrency':10,'rate':100,'time_limit':6,'latency':5,'flags':0x400,'n':6}",   # the single-root txn node with several workers per node, four clusters per wavefront (txng4.hip)
     "{'workload':'txn-list-append','node_count':5,'concurrency':10,'rate':200,'time_limit':4,'latency':5,'nemesis':['partition'],'nemesis_interval':1,'p_loss':0.05,'flags':0x400,'n':5}",   # a full 16-lane group; lost replies leave slots taken
+    "{'workload':'txn-list-append','bin':'datomic','node_count':1,'concurrency':10,'rate':100,'time_limit':6,'latency':2,'flags':0x400,'n':6}",   # the Datomic-style node with several workers per node, four clusters per wavefront (dtg4.hip): the lock's waiting queue under load
+    "{'workload':'txn-list-append','bin':'datomic','node_count':2,'concurrency':12,'rate':200,'time_limit':5,'latency':5,'nemesis':['partition'],'nemesis_interval':2,'p_loss':0.03,'flags':0x400,'n':5}",   # a full 16-lane group
     "{'workload':'lin-kv','bin':'lin-kv-proxy','proxy_service':'seq-kv','node_count':3,'rate':100,'time_limit':4,'latency':10,'n':2}",   # seq-kv: one cluster per wavefront (svc_kernel<>)
 ]
 

@@ -362,12 +362,19 @@ def test_datomic_late_cas_parity(lib, kw, first):
     dict(node_count=3, concurrency=9, rate=150, time_limit=20, latency=10, p_loss=0.03, journal_capacity=400000),   # lost messages: awaits give up while others wait for the lock
     dict(node_count=6, concurrency=48, rate=400, time_limit=4, latency=20, latency_dist="exponential"),       # 6 + 48 + 2 = 56 lanes
     dict(node_count=1, concurrency=61, rate=1000, time_limit=3, latency=1),                                    # a full wavefront: 1 node, 61 workers, lin-kv, lww-kv
+    dict(node_count=1, concurrency=10, rate=100, time_limit=30, latency=5),                                    # the reference's invocation at bench length
+    dict(node_count=2, concurrency=12, rate=300, time_limit=6, latency=10, latency_dist="exponential", p_loss=0.05, nemesis=["partition"], nemesis_interval=2),   # a full 16-lane group; lost messages: awaits give up
+    dict(node_count=1, concurrency=13, rate=400, time_limit=5, latency=3, latency_dist="uniform", key_count=16, max_writes_per_key=2),   # 16 lanes; many keys: splits, chains
+    dict(node_count=2, concurrency=4, rate=15, time_limit=60, latency=1300, latency_dist="exponential"),       # latencies of seconds: a cas served after its sender's await gave up
 ])
 def test_datomic_many_workers_parity(lib, kw):
-    """Several workers per node (`--concurrency k n`): dtg_kernel<> (csrc/sim_kernel_dtg.inc: a lane per endpoint) against oracle/dt_nodes.inc,
-    which tests/test_datomic_tree.py::test_several_workers_per_node_queue_behind_the_lock_in_arrival_order holds to the reference classes."""
+    """Several workers per node (`--concurrency k n`): dtg_kernel<> (csrc/sim_kernel_dtg.inc: a lane per endpoint) and dtg4_kernel<> (csrc/dtg4.hip:
+    four clusters per wavefront where nodes + workers + lin-kv + lww-kv <= 16 and the journal is off; large launches take it unasked, here
+    MSIM_DEV_FLAGS bit 10 asks for it) against oracle/dt_nodes.inc, which
+    tests/test_datomic_tree.py::test_several_workers_per_node_queue_behind_the_lock_in_arrival_order holds to the reference classes."""
     cfg = E.test_config("txn-list-append", bin="datomic", seed=23, **kw)
     _compare(cfg, 0, 5)
+    _compare(cfg, 2, 6, dev_flags=0x400)
 
 
 @pytest.mark.parametrize("kw", [

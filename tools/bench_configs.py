@@ -41,6 +41,8 @@ CONFIGS = {
     # the node core.clj:113-114 runs (demo/ruby/datomic_list_append.rb): a persistent hash tree in lww-kv, the root pointer in lin-kv, a lock per node
     "cfg5-datomic txn-list-append datomic n=5 rate100 30s lat5 + partitions": (dict(workload="txn-list-append", bin="datomic", node_count=5, rate=100, time_limit=30, latency=5,
                                                                                     nemesis=["partition"], nemesis_interval=10), 32768),
+    # ... and the same node as the reference's own runs invoke it (doc/05-datomic/01-single-node.md:257,322: one node, --concurrency 10n)
+    "txn-list-append datomic n=1 c=10 rate100 30s lat0": (dict(workload="txn-list-append", bin="datomic", node_count=1, concurrency=10, rate=100, time_limit=30), 16384),
     "broadcast n=100 grid lat0": (dict(workload="broadcast", node_count=100, rate=100, time_limit=20), 2048),
     "broadcast n=100 grid lat100 exponential": (dict(workload="broadcast", node_count=100, rate=100, time_limit=20, latency=100, latency_dist="exponential"), 2048),
     # the reference's own demo invocation for this workload (core.clj:115-121): 2 nodes, rate 100, partitions, read-committed
