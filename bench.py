@@ -195,8 +195,8 @@ def cpu_baseline(cfg, seconds):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--instances", type=int, default=0, help="test instances per GPU per step (default: 4096 for cfg2; 65536 / --gpus for cfg4)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2", help="BASELINE.json config: cfg2 = the headline (broadcast n=25), cfg4 = lin-kv over Raft, 65536 instances over the job + RCCL history gather")
     ap.add_argument("--cpu-sample", type=float, default=10.0, help="seconds of CPU-oracle work for cpu_baseline (0 = skip)")
