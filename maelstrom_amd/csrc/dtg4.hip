@@ -8,7 +8,7 @@
 // group — 1 node with 10 workers is 13 — and a wavefront carries four clusters.
 //
 // Scope (engine.hip picks this kernel when all of it holds, else dtg_kernel<> runs): concurrency a multiple of n above n, n + concurrency + 2 <= 16,
-// net journal off, at least MSIM_DTG4_MIN_CLUSTERS clusters in the launch.
+// net journal off, at least MSIM_DTG4_MIN_CLUSTERS clusters in the launch (half of that with two nodes or more).
 //
 // LDS of a wavefront: envelope queues slot-major (RQ envelopes per endpoint, the rest spills to HBM), per node the lock holder's cursor, the waiting
 // ring of 64 transactions and the save stack (DG_WORDS words), per cluster the generator's key pool and the nemesis shuffle.  Tree records, write
@@ -844,7 +844,7 @@ uint64_t msim_dtg4_extra_scratch_words(const msim_config &c) {
 
 hipError_t msim_launch_dtg4(const KParams &kp, uint32_t n, hipStream_t st) {
   const msim_config &c = kp.cfg;
-  if (n < MSIM_DTG4_MIN_CLUSTERS && !(kp.dev_flags & 0x400u)) return MSIM_LAYOUT_DOES_NOT_FIT;
+  if (n < (kp.N == 1 ? MSIM_DTG4_MIN_CLUSTERS : MSIM_DTG4_MIN_CLUSTERS / 2u) && !(kp.dev_flags & 0x400u)) return MSIM_LAYOUT_DOES_NOT_FIT;   // (two nodes and more: even from 8192 on, profiles/r06f_dtg4_threshold_sweep.jsonl)
   D4Params rp;
   rp.k = kp; rp.n_inst = n;
   const uint32_t cap_tot = c.inbox_capacity + c.spill_capacity;
